@@ -1,0 +1,128 @@
+"""ctypes binding of libcopo_hip.so (include/copo_hip.h).
+
+This is the thin host layer the north star asks for: Python hosts the loop, the simulator and the
+custom learn-side ops are HIP kernels behind a C ABI.  There is NO fallback: if the shared library
+is missing or a symbol is absent, importing this module raises, and every op raises on a non-zero
+return code with the library's own error string.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcopo_hip.so")
+
+MAX_AGENTS = 64
+MAX_SEGS = 8
+SEG_STRIDE = 8
+MAX_LASERS = 256
+MAX_SPAWNS = 256
+MAX_ROUTES = 128
+EGO_DIM = 9
+NAVI_DIM = 10
+INFO_DIM = 8
+STATE_FIELDS = 16
+LCF_STATS_DOUBLES = 8 + 6 * 256
+ABI_VERSION = 1
+
+F_ACTED, F_DONE, F_ARRIVE, F_CRASH, F_OUT, F_MAXSTEP, F_SPAWNED, F_ENV_RESET = (1 << i for i in range(8))
+I_VELOCITY, I_STEERING, I_ACCELERATION, I_STEP_REWARD, I_COST, I_EPISODE_LENGTH, I_EPISODE_REWARD, \
+    I_ROUTE_COMPLETION = range(8)
+
+ERR_NAMES = {0: "COPO_OK", -1: "COPO_ERR_NULL", -2: "COPO_ERR_DIM", -3: "COPO_ERR_DEVICE", -4: "COPO_ERR_STATE",
+             -5: "COPO_ERR_CONFIG"}
+
+
+class CopoError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (ERR_NAMES.get(code, "?"), code, msg))
+        self.code = code
+
+
+class SimCfg(C.Structure):
+    """Mirror of `copo_sim_cfg`."""
+    _fields_ = [
+        ("num_envs", C.c_int32), ("num_agents", C.c_int32), ("num_lasers", C.c_int32), ("obs_dim", C.c_int32),
+        ("nbr_k", C.c_int32), ("enable_lcf", C.c_int32), ("horizon", C.c_int32), ("delay_done", C.c_int32),
+        ("respawn_cooldown", C.c_int32), ("substeps", C.c_int32),
+        ("lidar_range", C.c_float), ("neighbours_distance", C.c_float), ("mf_distance", C.c_float),
+        ("dt", C.c_float), ("veh_half_len", C.c_float), ("veh_half_wid", C.c_float), ("wheelbase", C.c_float),
+        ("max_steer", C.c_float), ("max_speed", C.c_float), ("acc_max", C.c_float), ("brake_max", C.c_float),
+        ("drag", C.c_float), ("spawn_clearance", C.c_float),
+        ("driving_reward", C.c_float), ("speed_reward", C.c_float), ("success_reward", C.c_float),
+        ("crash_penalty", C.c_float), ("out_penalty", C.c_float), ("arrive_margin", C.c_float),
+        ("lane_width", C.c_float),
+        ("lcf_mean", C.c_double), ("lcf_std", C.c_double),
+        ("n_routes", C.c_int32), ("n_spawns", C.c_int32),
+        ("route_segs", C.c_void_p), ("route_meta", C.c_void_p), ("spawn_tab", C.c_void_p), ("spawn_s", C.c_void_p),
+        ("ray_cs", C.c_void_p),
+    ]
+
+
+class StepOut(C.Structure):
+    """Mirror of `copo_step_out` (device pointers, 0 = skip)."""
+    _fields_ = [(n, C.c_void_p) for n in ("obs", "rew", "nei_rew", "glob_rew", "flags", "nbr_idx", "nbr_cnt", "mf_cnt",
+                                          "nbr_dist", "lcf", "info", "agent_id")]
+
+
+_SIGS = {
+    "copo_version": (C.c_int, []),
+    "copo_last_error": (C.c_char_p, []),
+    "copo_sim_create": (C.c_int, [C.POINTER(SimCfg), C.c_int, C.POINTER(C.c_void_p)]),
+    "copo_sim_destroy": (C.c_int, [C.c_void_p]),
+    "copo_sim_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(StepOut), C.c_void_p]),
+    "copo_sim_set_lcf_dist": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
+    "copo_sim_set_force_lcf": (C.c_int, [C.c_void_p, C.c_double]),
+    "copo_sim_set_block": (C.c_int, [C.c_void_p, C.c_int32]),
+    "copo_sim_step": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(StepOut), C.c_void_p]),
+    "copo_sim_get_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "copo_sim_set_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "copo_neighbours_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                                      C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]),
+    "copo_gae3_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                C.POINTER(C.c_double), C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "copo_cc_fuse_mf_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p]),
+    "copo_cc_fuse_concat_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 7 + [C.c_void_p, C.c_void_p]),
+    "copo_lcf_mix_partial_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "copo_lcf_mix_apply_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libcopo_hip.so not found at %s -- build it with `python __graft_entry__.py` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.copo_version()
+    if v != ABI_VERSION:
+        raise ImportError("libcopo_hip.so ABI %d != binding ABI %d" % (v, ABI_VERSION))
+    return lib
+
+
+lib = _load()
+
+
+def check(rc):
+    if rc != 0:
+        raise CopoError(rc, lib.copo_last_error().decode("utf-8", "replace"))
+
+
+def ptr(t):
+    """Device/host address of a torch tensor or numpy array (None -> NULL)."""
+    if t is None:
+        return None
+    if hasattr(t, "data_ptr"):
+        return t.data_ptr()
+    return t.ctypes.data
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,298 @@
+// C ABI of libcopo_hip.so (include/copo_hip.h): argument validation, handle lifetime, error strings.
+// No torch types; all launches are asynchronous on the caller's stream.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "sim_common.h"
+
+using namespace copo;
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) return fail(COPO_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+struct copo_sim {
+    SimParams p;
+    int device;
+    int block;
+    bool started;
+    double lcf_mean, lcf_std, force_lcf;
+    std::vector<void*> allocs;
+};
+
+extern "C" int copo_version(void) { return COPO_ABI_VERSION; }
+extern "C" const char* copo_last_error(void) { return g_err; }
+
+template <typename T>
+static int upload(copo_sim* s, const T* host, size_t count, const T** dev) {
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, count * sizeof(T) ? count * sizeof(T) : sizeof(T)));
+    s->allocs.push_back(d);
+    if (count) HIP_TRY(hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice));
+    *dev = static_cast<const T*>(d);
+    return COPO_OK;
+}
+
+static int pick_block(int E) { return E <= 1024 ? 1024 : (E <= 4096 ? 512 : 256); }
+
+extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** out) {
+    if (!cfg || !out) return fail(COPO_ERR_NULL, "copo_sim_create: cfg/out is NULL");
+    *out = nullptr;
+    if (cfg->num_envs < 1 || cfg->num_agents < 1 || cfg->num_agents > COPO_MAX_AGENTS)
+        return fail(COPO_ERR_DIM, "num_envs=%d num_agents=%d (agents must be 1..%d)", cfg->num_envs, cfg->num_agents,
+                    COPO_MAX_AGENTS);
+    if (cfg->num_lasers < 1 || cfg->num_lasers > COPO_MAX_LASERS)
+        return fail(COPO_ERR_DIM, "num_lasers=%d out of 1..%d", cfg->num_lasers, COPO_MAX_LASERS);
+    const int O = COPO_EGO_DIM + COPO_NAVI_DIM + cfg->num_lasers + (cfg->enable_lcf ? 1 : 0);
+    if (cfg->obs_dim != O) return fail(COPO_ERR_DIM, "obs_dim=%d but 9+10+lasers(+1 lcf)=%d", cfg->obs_dim, O);
+    if (cfg->nbr_k < 1 || cfg->nbr_k > COPO_MAX_AGENTS) return fail(COPO_ERR_DIM, "nbr_k=%d out of 1..64", cfg->nbr_k);
+    if (cfg->n_routes < 1 || cfg->n_routes > COPO_MAX_ROUTES || cfg->n_spawns < cfg->num_agents ||
+        cfg->n_spawns > COPO_MAX_SPAWNS)
+        return fail(COPO_ERR_CONFIG, "n_routes=%d n_spawns=%d (need num_agents <= n_spawns <= %d)", cfg->n_routes,
+                    cfg->n_spawns, COPO_MAX_SPAWNS);
+    if (!cfg->route_segs || !cfg->route_meta || !cfg->spawn_tab || !cfg->spawn_s || !cfg->ray_cs)
+        return fail(COPO_ERR_NULL, "copo_sim_create: a map table pointer is NULL");
+    if (cfg->substeps < 1 || cfg->horizon < 1 || cfg->respawn_cooldown < 1 || cfg->delay_done < 0 ||
+        cfg->delay_done > (1 << 20))
+        return fail(COPO_ERR_CONFIG, "substeps/horizon/respawn_cooldown must be >= 1, delay_done >= 0");
+    if (!(cfg->lcf_std > 0.0) || cfg->lcf_mean < -1.0 || cfg->lcf_mean > 1.0)
+        return fail(COPO_ERR_CONFIG, "lcf_mean must be in [-1,1] and lcf_std > 0 (env_wrappers.py:195,425-426)");
+    for (int r = 0; r < cfg->n_routes; ++r) {
+        const int nseg = (int)cfg->route_meta[r * 4 + 3];
+        if (nseg < 1 || nseg > COPO_MAX_SEGS) return fail(COPO_ERR_CONFIG, "route %d has %d segments", r, nseg);
+    }
+    for (int s = 0; s < cfg->n_spawns; ++s) {
+        const int r0 = cfg->spawn_tab[s * 4], nc = cfg->spawn_tab[s * 4 + 1];
+        if (r0 < 0 || nc < 1 || r0 + nc > cfg->n_routes) return fail(COPO_ERR_CONFIG, "spawn %d: bad route range", s);
+        for (int r = r0; r < r0 + nc; ++r) {
+            const float* g = cfg->route_segs + (size_t)r * (COPO_MAX_SEGS + 1) * COPO_SEG_STRIDE;
+            if (g[5] != 0.0f || !(cfg->spawn_s[s] < g[4]))
+                return fail(COPO_ERR_CONFIG, "spawn %d must lie on the straight first segment of route %d", s, r);
+        }
+    }
+    copo_sim* s = new (std::nothrow) copo_sim();
+    if (!s) return fail(COPO_ERR_DEVICE, "out of host memory");
+    s->device = device;
+    s->started = false;
+    s->lcf_mean = cfg->lcf_mean;
+    s->lcf_std = cfg->lcf_std;
+    s->force_lcf = -100.0;
+    s->block = pick_block(cfg->num_envs);
+    if (hipSetDevice(device) != hipSuccess) {
+        delete s;
+        return fail(COPO_ERR_DEVICE, "hipSetDevice(%d) failed", device);
+    }
+    SimParams& p = s->p;
+    memset(&p, 0, sizeof(p));
+    p.E = cfg->num_envs; p.N = cfg->num_agents; p.O = cfg->obs_dim; p.K = cfg->nbr_k; p.num_lasers = cfg->num_lasers;
+    p.enable_lcf = cfg->enable_lcf; p.horizon = cfg->horizon; p.delay_done = cfg->delay_done;
+    p.respawn_cooldown = cfg->respawn_cooldown; p.substeps = cfg->substeps;
+    p.n_routes = cfg->n_routes; p.n_spawns = cfg->n_spawns;
+    p.lidar_range = cfg->lidar_range; p.neighbours_distance = cfg->neighbours_distance; p.mf_distance = cfg->mf_distance;
+    p.dt = cfg->dt; p.hl = cfg->veh_half_len; p.hw = cfg->veh_half_wid; p.wheelbase = cfg->wheelbase;
+    p.max_steer = cfg->max_steer; p.max_speed = cfg->max_speed; p.acc_max = cfg->acc_max; p.brake_max = cfg->brake_max;
+    p.drag = cfg->drag; p.spawn_clearance = cfg->spawn_clearance;
+    p.driving_reward = cfg->driving_reward; p.speed_reward = cfg->speed_reward; p.success_reward = cfg->success_reward;
+    p.crash_penalty = cfg->crash_penalty; p.out_penalty = cfg->out_penalty; p.arrive_margin = cfg->arrive_margin;
+    p.lane_width = cfg->lane_width;
+    int rc = COPO_OK;
+    const size_t EN = (size_t)p.E * p.N;
+    void* d = nullptr;
+    auto dev_alloc = [&](size_t bytes, void** ptr) -> int {
+        hipError_t e = hipMalloc(ptr, bytes);
+        if (e != hipSuccess) return fail(COPO_ERR_DEVICE, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+        s->allocs.push_back(*ptr);
+        e = hipMemset(*ptr, 0, bytes);
+        if (e != hipSuccess) return fail(COPO_ERR_DEVICE, "hipMemset: %s", hipGetErrorString(e));
+        return COPO_OK;
+    };
+    if (rc == COPO_OK && (rc = dev_alloc(COPO_STATE_FIELDS * EN * 4, &d)) == COPO_OK) p.state = (float*)d;
+    if (rc == COPO_OK && (rc = dev_alloc((size_t)p.E * 16, &d)) == COPO_OK) p.env = (int32_t*)d;
+    if (rc == COPO_OK && (rc = dev_alloc((size_t)p.E * 8, &d)) == COPO_OK) p.seeds = (const uint64_t*)d;
+    if (rc == COPO_OK)
+        rc = upload(s, cfg->route_segs, (size_t)cfg->n_routes * (COPO_MAX_SEGS + 1) * COPO_SEG_STRIDE, &p.route_segs);
+    if (rc == COPO_OK) rc = upload(s, cfg->route_meta, (size_t)cfg->n_routes * 4, &p.route_meta);
+    if (rc == COPO_OK) rc = upload(s, cfg->spawn_tab, (size_t)cfg->n_spawns * 4, &p.spawn_tab);
+    if (rc == COPO_OK) rc = upload(s, cfg->spawn_s, (size_t)cfg->n_spawns, &p.spawn_s);
+    if (rc == COPO_OK) rc = upload(s, cfg->ray_cs, (size_t)cfg->num_lasers * 2, &p.ray_cs);
+    if (rc != COPO_OK) {
+        for (void* a : s->allocs) (void)hipFree(a);
+        delete s;
+        return rc;
+    }
+    *out = s;
+    return COPO_OK;
+}
+
+extern "C" int copo_sim_destroy(copo_sim* s) {
+    if (!s) return fail(COPO_ERR_NULL, "copo_sim_destroy: NULL handle");
+    (void)hipSetDevice(s->device);
+    for (void* a : s->allocs) (void)hipFree(a);
+    delete s;
+    return COPO_OK;
+}
+
+static void refresh_lcf(copo_sim* s) {
+    s->p.lcf_mean = (float)((s->force_lcf != -100.0) ? s->force_lcf : s->lcf_mean);
+    s->p.lcf_std = (float)s->lcf_std;
+}
+
+extern "C" int copo_sim_set_lcf_dist(copo_sim* s, double mean, double std) {
+    if (!s) return fail(COPO_ERR_NULL, "copo_sim_set_lcf_dist: NULL handle");
+    if (!(std > 0.0) || mean < -1.0 || mean > 1.0)
+        return fail(COPO_ERR_CONFIG, "set_lcf_dist(mean=%g, std=%g): need -1 <= mean <= 1, std > 0", mean, std);
+    s->lcf_mean = mean;
+    s->lcf_std = std;
+    return COPO_OK;
+}
+
+extern "C" int copo_sim_set_force_lcf(copo_sim* s, double v) {
+    if (!s) return fail(COPO_ERR_NULL, "copo_sim_set_force_lcf: NULL handle");
+    if (v != -100.0 && (v < -1.0 || v > 1.0)) return fail(COPO_ERR_CONFIG, "force_lcf=%g not in [-1,1] (or -100)", v);
+    s->force_lcf = v;
+    return COPO_OK;
+}
+
+extern "C" int copo_sim_set_block(copo_sim* s, int32_t threads) {
+    if (!s) return fail(COPO_ERR_NULL, "copo_sim_set_block: NULL handle");
+    if (threads == 0) threads = pick_block(s->p.E);
+    if (threads != 64 && threads != 128 && threads != 256 && threads != 512 && threads != 1024)
+        return fail(COPO_ERR_DIM, "block=%d must be 64/128/256/512/1024", threads);
+    s->block = threads;
+    return COPO_OK;
+}
+
+extern "C" int copo_sim_reset(copo_sim* s, const uint64_t* seeds, const copo_step_out* out, void* stream) {
+    if (!s || !seeds || !out) return fail(COPO_ERR_NULL, "copo_sim_reset: NULL argument");
+    HIP_TRY(hipSetDevice(s->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemcpyAsync(const_cast<uint64_t*>(s->p.seeds), seeds, (size_t)s->p.E * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(s->p.state, 0, COPO_STATE_FIELDS * (size_t)s->p.E * s->p.N * 4, st));
+    refresh_lcf(s);
+    HIP_TRY(launch_sim_reset(s->p, *out, s->block, st));
+    s->started = true;
+    return COPO_OK;
+}
+
+extern "C" int copo_sim_step(copo_sim* s, const float* act, const copo_step_out* out, void* stream) {
+    if (!s || !act || !out) return fail(COPO_ERR_NULL, "copo_sim_step: NULL argument");
+    if (!s->started) return fail(COPO_ERR_STATE, "copo_sim_step before copo_sim_reset");
+    refresh_lcf(s);
+    HIP_TRY(launch_sim_step(s->p, act, *out, s->block, static_cast<hipStream_t>(stream)));
+    return COPO_OK;
+}
+
+extern "C" int copo_sim_get_state(copo_sim* s, float* slot_state, int32_t* env_state, void* stream) {
+    if (!s || !slot_state || !env_state) return fail(COPO_ERR_NULL, "copo_sim_get_state: NULL argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemcpyAsync(slot_state, s->p.state, COPO_STATE_FIELDS * (size_t)s->p.E * s->p.N * 4,
+                           hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(env_state, s->p.env, (size_t)s->p.E * 16, hipMemcpyDeviceToDevice, st));
+    return COPO_OK;
+}
+
+extern "C" int copo_sim_set_state(copo_sim* s, const float* slot_state, const int32_t* env_state, void* stream) {
+    if (!s || !slot_state || !env_state) return fail(COPO_ERR_NULL, "copo_sim_set_state: NULL argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemcpyAsync(s->p.state, slot_state, COPO_STATE_FIELDS * (size_t)s->p.E * s->p.N * 4,
+                           hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->p.env, env_state, (size_t)s->p.E * 16, hipMemcpyDeviceToDevice, st));
+    s->started = true;
+    return COPO_OK;
+}
+
+// ---- stateless ops --------------------------------------------------------------------------------
+
+extern "C" int copo_neighbours_f32(const float* pos, const uint8_t* present, const float* rew, int32_t E, int32_t N,
+                                   int32_t K, float radius, float mf_distance, int32_t* nbr_idx, int32_t* nbr_cnt,
+                                   int32_t* mf_cnt, float* nbr_dist, float* nei_rew, float* glob_rew, void* stream) {
+    if (!pos || !present) return fail(COPO_ERR_NULL, "copo_neighbours_f32: pos/present is NULL");
+    if (E < 0 || N < 1 || N > COPO_MAX_AGENTS || K < 1 || K > COPO_MAX_AGENTS)
+        return fail(COPO_ERR_DIM, "copo_neighbours_f32: E=%d N=%d K=%d (N,K in 1..64)", E, N, K);
+    if (E == 0) return COPO_OK;
+    SimParams p;
+    memset(&p, 0, sizeof(p));
+    p.E = E; p.N = N; p.K = K;
+    p.neighbours_distance = radius;
+    p.mf_distance = mf_distance;
+    StepOut out;
+    memset(&out, 0, sizeof(out));
+    out.nbr_idx = nbr_idx; out.nbr_cnt = nbr_cnt; out.mf_cnt = mf_cnt; out.nbr_dist = nbr_dist;
+    out.nei_rew = rew ? nei_rew : nullptr;
+    out.glob_rew = rew ? glob_rew : nullptr;
+    HIP_TRY(launch_neighbours(pos, present, rew, p, out, static_cast<hipStream_t>(stream)));
+    return COPO_OK;
+}
+
+extern "C" int copo_gae3_f32(const float* rew, const float* val, const uint8_t* flags, int32_t T, int32_t M,
+                             int32_t heads, const double* gamma, double lam, float* adv, float* tgt, void* stream) {
+    if (!rew || !val || !flags || !gamma || !adv || !tgt) return fail(COPO_ERR_NULL, "copo_gae3_f32: NULL argument");
+    if (T < 0 || M < 0 || heads < 1 || heads > 4) return fail(COPO_ERR_DIM, "copo_gae3_f32: T=%d M=%d heads=%d", T, M, heads);
+    if (T == 0 || M == 0) return COPO_OK;
+    HIP_TRY(launch_gae3(rew, val, flags, T, M, heads, gamma, lam, adv, tgt, static_cast<hipStream_t>(stream)));
+    return COPO_OK;
+}
+
+static int check_fuse(const char* name, const void* obs, const void* act, const void* flags, const void* idx,
+                      const void* cnt, const void* cc, int R, int N, int O, int A, int K) {
+    if (!obs || !act || !flags || !idx || !cnt || !cc) return fail(COPO_ERR_NULL, "%s: NULL argument", name);
+    if (R < 0 || N < 1 || N > COPO_MAX_AGENTS || O < 1 || A < 0 || K < 1 || K > COPO_MAX_AGENTS)
+        return fail(COPO_ERR_DIM, "%s: R=%d N=%d O=%d A=%d K=%d", name, R, N, O, A, K);
+    return COPO_OK;
+}
+
+extern "C" int copo_cc_fuse_mf_f32(const float* obs, const float* act, const uint8_t* flags, const int32_t* nbr_idx,
+                                   const int32_t* cnt, int32_t R, int32_t N, int32_t O, int32_t A, int32_t K,
+                                   int32_t counterfactual, float* cc_obs, void* stream) {
+    int rc = check_fuse("copo_cc_fuse_mf_f32", obs, act, flags, nbr_idx, cnt, cc_obs, R, N, O, A, K);
+    if (rc != COPO_OK || R == 0) return rc;
+    HIP_TRY(launch_cc_fuse_mf(obs, act, flags, nbr_idx, cnt, R, N, O, A, K, counterfactual, cc_obs,
+                              static_cast<hipStream_t>(stream)));
+    return COPO_OK;
+}
+
+extern "C" int copo_cc_fuse_concat_f32(const float* obs, const float* act, const uint8_t* flags, const int32_t* nbr_idx,
+                                       const int32_t* cnt, int32_t R, int32_t N, int32_t O, int32_t A, int32_t K,
+                                       int32_t num_neighbours, int32_t counterfactual, float* cc_obs, void* stream) {
+    int rc = check_fuse("copo_cc_fuse_concat_f32", obs, act, flags, nbr_idx, cnt, cc_obs, R, N, O, A, K);
+    if (rc != COPO_OK || R == 0) return rc;
+    if (num_neighbours < 0 || num_neighbours > COPO_MAX_AGENTS)
+        return fail(COPO_ERR_DIM, "copo_cc_fuse_concat_f32: num_neighbours=%d", num_neighbours);
+    HIP_TRY(launch_cc_fuse_concat(obs, act, flags, nbr_idx, cnt, R, N, O, A, K, num_neighbours, counterfactual, cc_obs,
+                                  static_cast<hipStream_t>(stream)));
+    return COPO_OK;
+}
+
+extern "C" int copo_lcf_mix_partial_f32(const float* adv, const float* nei_adv, const float* glob_adv, const float* lcf,
+                                        const uint8_t* valid, int64_t B, float* mixed, double* stats, void* stream) {
+    if (!adv || !nei_adv || !glob_adv || !lcf || !mixed || !stats)
+        return fail(COPO_ERR_NULL, "copo_lcf_mix_partial_f32: NULL argument");
+    if (B < 0) return fail(COPO_ERR_DIM, "copo_lcf_mix_partial_f32: B=%lld", (long long)B);
+    HIP_TRY(launch_lcf_mix_partial(adv, nei_adv, glob_adv, lcf, valid, B, mixed, stats, static_cast<hipStream_t>(stream)));
+    return COPO_OK;
+}
+
+extern "C" int copo_lcf_mix_apply_f32(const float* mixed, const float* glob_adv, const uint8_t* valid, int64_t B,
+                                      const double* stats, float* norm_adv, float* glob_adv_std, void* stream) {
+    if (!mixed || !glob_adv || !stats || !norm_adv || !glob_adv_std)
+        return fail(COPO_ERR_NULL, "copo_lcf_mix_apply_f32: NULL argument");
+    if (B < 0) return fail(COPO_ERR_DIM, "copo_lcf_mix_apply_f32: B=%lld", (long long)B);
+    if (B == 0) return COPO_OK;
+    HIP_TRY(launch_lcf_mix_apply(mixed, glob_adv, valid, B, stats, norm_adv, glob_adv_std, static_cast<hipStream_t>(stream)));
+    return COPO_OK;
+}

@@ -1,0 +1,271 @@
+// Learn-side custom ops for gfx950 (HBM-bound scans / gathers / reductions):
+//   gae3            three GAE heads in one segmented reverse scan        (algo_ccppo.py:362-373, algo_copo.py:189-204,492-500)
+//   cc_fuse_mf      mean-field centralised-critic observation            (algo_ccppo.py:266-311)
+//   cc_fuse_concat  concat centralised-critic observation                (algo_ccppo.py:225-263)
+//   lcf_mix         coordinated advantage + batch standardisation        (algo_copo.py:539-551)
+#include "sim_common.h"
+
+namespace copo {
+
+// ------------------------------------------------------------------------------------------------
+// GAE: one thread per (head, column); columns are contiguous so every time-step is a coalesced row read.
+// The dtype path of the reference is kept: delta in fp32 for truncated trajectories (numpy fp32
+// expression), in fp64 for trajectories that ended with done; the discounted cumsum always in fp64.
+// ------------------------------------------------------------------------------------------------
+struct Gae3Args {
+    double gamma[4];
+    double lam;
+};
+
+__global__ void __launch_bounds__(256) gae3_kernel(const float* __restrict__ rew, const float* __restrict__ val,
+                                                   const uint8_t* __restrict__ flags, int T, int M, int heads,
+                                                   Gae3Args a, float* __restrict__ adv, float* __restrict__ tgt) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)heads * M) return;
+    const int hd = (int)(gid / M), m = (int)(gid - (long long)hd * M);
+    const size_t hoff = (size_t)hd * T * M;
+    const double g64 = a.gamma[hd];
+    const float g32 = (float)g64;
+    const double c = g64 * a.lam;
+    double acc = 0.0, vnext64 = 0.0;
+    float vnext32 = 0.0f;
+    bool seg_done = false, in_seg = false;
+    for (int t = T - 1; t >= 0; --t) {
+        const size_t ix = (size_t)t * M + m;
+        const uint8_t f = flags[ix];
+        if (!(f & COPO_F_ACTED)) {
+            adv[hoff + ix] = 0.0f;
+            tgt[hoff + ix] = 0.0f;
+            in_seg = false;
+            continue;
+        }
+        const float r = rew[hoff + ix], v = val[hoff + ix];
+        if (!in_seg || (f & COPO_F_DONE)) {
+            seg_done = (f & COPO_F_DONE) != 0;
+            acc = 0.0;
+            vnext32 = v;
+            vnext64 = 0.0;
+            in_seg = true;
+        }
+        double delta;
+        if (seg_done) {
+            delta = ((double)r + g64 * vnext64) - (double)v;
+        } else {
+            const float d32 = (r + g32 * vnext32) - v;
+            delta = (double)d32;
+        }
+        acc = delta + c * acc;
+        adv[hoff + ix] = (float)acc;
+        tgt[hoff + ix] = (float)(acc + (double)v);
+        vnext32 = v;
+        vnext64 = (double)v;
+    }
+}
+
+hipError_t launch_gae3(const float* rew, const float* val, const uint8_t* flags, int T, int M, int heads,
+                       const double* gamma_host, double lam, float* adv, float* tgt, hipStream_t stream) {
+    Gae3Args a{};
+    for (int h = 0; h < heads && h < 4; ++h) a.gamma[h] = gamma_host[h];
+    a.lam = lam;
+    const long long total = (long long)heads * M;
+    const int block = 256;
+    const int grid = (int)((total + block - 1) / block);
+    hipLaunchKernelGGL(gae3_kernel, dim3(grid), dim3(block), 0, stream, rew, val, flags, T, M, heads, a, adv, tgt);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Centralised-critic fusion: one wave per row (r, n); lanes stride the feature columns, so every
+// neighbour row is one coalesced read and the per-column accumulation order is the list order.
+// A neighbour contributes only if it has a row at the same env time-step (ACTED flag), which is the
+// `np.where(nei_batch["t"] == environmental_time_step)` match of the reference.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) cc_fuse_mf_kernel(const float* __restrict__ obs, const float* __restrict__ act,
+                                                         const uint8_t* __restrict__ flags,
+                                                         const int32_t* __restrict__ nbr_idx,
+                                                         const int32_t* __restrict__ cnt, long long rows, int N, int O,
+                                                         int A, int K, int cf, float* __restrict__ cc) {
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int C = 2 * O + (cf ? A : 0);
+    float* o = cc + (size_t)row * C;
+    if (!(flags[row] & COPO_F_ACTED)) {
+        for (int k = lane; k < C; k += 64) o[k] = 0.0f;
+        return;
+    }
+    const long long r0 = (row / N) * N;  // first row of this (t, env)
+    int m = cnt[row];
+    if (m > K) m = K;
+    const int W = O + (cf ? A : 0);  // fused columns: O obs then A act
+    for (int k0 = 0; k0 < W; k0 += 64) {
+        const int k = k0 + lane;
+        float sum = 0.0f;
+        int got = 0;
+        for (int q = 0; q < m; ++q) {
+            const int j = nbr_idx[(size_t)row * K + q];
+            if (j < 0) continue;
+            const long long jr = r0 + j;
+            if (!(flags[jr] & COPO_F_ACTED)) continue;
+            if (k < O) sum += obs[(size_t)jr * O + k];
+            else if (k < W) sum += act[(size_t)jr * A + (k - O)];
+            got++;
+        }
+        if (k < W) o[O + k] = got > 0 ? sum / (float)got : 0.0f;
+    }
+    for (int k = lane; k < O; k += 64) o[k] = obs[(size_t)row * O + k];
+}
+
+__global__ void __launch_bounds__(256) cc_fuse_concat_kernel(const float* __restrict__ obs, const float* __restrict__ act,
+                                                             const uint8_t* __restrict__ flags,
+                                                             const int32_t* __restrict__ nbr_idx,
+                                                             const int32_t* __restrict__ cnt, long long rows, int N,
+                                                             int O, int A, int K, int nn, int cf,
+                                                             float* __restrict__ cc) {
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int W = O + (cf ? A : 0);
+    const int C = O + nn * W;
+    float* o = cc + (size_t)row * C;
+    const bool acted = (flags[row] & COPO_F_ACTED) != 0;
+    for (int k = lane; k < O; k += 64) o[k] = acted ? obs[(size_t)row * O + k] : 0.0f;
+    const long long r0 = (row / N) * N;
+    int m = acted ? cnt[row] : 0;
+    if (m > K) m = K;
+    for (int q = 0; q < nn; ++q) {  // slot = rank in the neighbour list, not compacted
+        long long jr = -1;
+        if (q < m) {
+            const int j = nbr_idx[(size_t)row * K + q];
+            if (j >= 0 && (flags[r0 + j] & COPO_F_ACTED)) jr = r0 + j;
+        }
+        float* d = o + O + q * W;
+        for (int k = lane; k < W; k += 64) {
+            float v = 0.0f;
+            if (jr >= 0) v = k < O ? obs[(size_t)jr * O + k] : act[(size_t)jr * A + (k - O)];
+            d[k] = v;
+        }
+    }
+}
+
+hipError_t launch_cc_fuse_mf(const float* obs, const float* act, const uint8_t* flags, const int32_t* nbr_idx,
+                             const int32_t* cnt, int R, int N, int O, int A, int K, int counterfactual, float* cc,
+                             hipStream_t stream) {
+    const long long rows = (long long)R * N;
+    const int wpb = 4;
+    const int grid = (int)((rows + wpb - 1) / wpb);
+    hipLaunchKernelGGL(cc_fuse_mf_kernel, dim3(grid), dim3(wpb * 64), 0, stream, obs, act, flags, nbr_idx, cnt, rows, N,
+                       O, A, K, counterfactual, cc);
+    return hipGetLastError();
+}
+
+hipError_t launch_cc_fuse_concat(const float* obs, const float* act, const uint8_t* flags, const int32_t* nbr_idx,
+                                 const int32_t* cnt, int R, int N, int O, int A, int K, int num_neighbours,
+                                 int counterfactual, float* cc, hipStream_t stream) {
+    const long long rows = (long long)R * N;
+    const int wpb = 4;
+    const int grid = (int)((rows + wpb - 1) / wpb);
+    hipLaunchKernelGGL(cc_fuse_concat_kernel, dim3(grid), dim3(wpb * 64), 0, stream, obs, act, flags, nbr_idx, cnt, rows,
+                       N, O, A, K, num_neighbours, counterfactual, cc);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Coordinated advantage + standardisation.  Deterministic two-launch reduction: COPO_LCF_BLOCKS
+// per-block partials (fixed tree order) then one block folds them in index order.
+// stats layout (doubles): [0..5] = {n, sum, sumsq}(A_c), {n, sum, sumsq}(glob); [8 + 6*b ..] partials.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;
+}
+
+__global__ void __launch_bounds__(256) lcf_mix_partial_kernel(const float* __restrict__ adv,
+                                                              const float* __restrict__ nei,
+                                                              const float* __restrict__ glob,
+                                                              const float* __restrict__ lcf,
+                                                              const uint8_t* __restrict__ valid, long long B,
+                                                              float* __restrict__ mixed, double* __restrict__ stats) {
+    __shared__ double red[4][6];
+    double a[6] = {0, 0, 0, 0, 0, 0};
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += stride) {
+        if (valid && !valid[i]) {
+            mixed[i] = 0.0f;
+            continue;
+        }
+        const float ang = lcf[i] * kHalfPi;
+        float sn, cs;
+        sincos_det(ang, sn, cs);
+        const float m = cs * adv[i] + sn * nei[i];
+        mixed[i] = m;
+        const double g = (double)glob[i];
+        a[0] += 1.0; a[1] += (double)m; a[2] += (double)m * (double)m;
+        a[3] += 1.0; a[4] += g; a[5] += g * g;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double s = wave_sum(a[k]);
+        if (lane == 0) red[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = threadIdx.x;
+        stats[8 + 6 * blockIdx.x + k] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+    }
+}
+
+__global__ void lcf_mix_fold_kernel(double* __restrict__ stats, int nblocks) {
+    const int k = threadIdx.x;
+    if (k < 6) {
+        double s = 0.0;
+        for (int b = 0; b < nblocks; ++b) s += stats[8 + 6 * b + k];
+        stats[k] = s;
+    }
+}
+
+__global__ void __launch_bounds__(256) lcf_mix_apply_kernel(const float* __restrict__ mixed,
+                                                            const float* __restrict__ glob,
+                                                            const uint8_t* __restrict__ valid, long long B,
+                                                            const double* __restrict__ stats,
+                                                            float* __restrict__ norm_adv, float* __restrict__ glob_std) {
+    const double m0 = stats[1] / stats[0], v0 = stats[2] / stats[0] - m0 * m0;
+    const double m1 = stats[4] / stats[3], v1 = stats[5] / stats[3] - m1 * m1;
+    double s0 = sqrt(v0 > 0 ? v0 : 0), s1 = sqrt(v1 > 0 ? v1 : 0);
+    if (s0 < 1e-4) s0 = 1e-4;
+    if (s1 < 1e-4) s1 = 1e-4;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += stride) {
+        if (valid && !valid[i]) {
+            norm_adv[i] = 0.0f;
+            glob_std[i] = 0.0f;
+            continue;
+        }
+        norm_adv[i] = (float)(((double)mixed[i] - m0) / s0);
+        glob_std[i] = (float)(((double)glob[i] - m1) / s1);
+    }
+}
+
+constexpr int kLcfBlocks = 256;
+
+hipError_t launch_lcf_mix_partial(const float* adv, const float* nei_adv, const float* glob_adv, const float* lcf,
+                                  const uint8_t* valid, int64_t B, float* mixed, double* stats, hipStream_t stream) {
+    hipLaunchKernelGGL(lcf_mix_partial_kernel, dim3(kLcfBlocks), dim3(256), 0, stream, adv, nei_adv, glob_adv, lcf,
+                       valid, (long long)B, mixed, stats);
+    hipLaunchKernelGGL(lcf_mix_fold_kernel, dim3(1), dim3(64), 0, stream, stats, kLcfBlocks);
+    return hipGetLastError();
+}
+
+hipError_t launch_lcf_mix_apply(const float* mixed, const float* glob_adv, const uint8_t* valid, int64_t B,
+                                const double* stats, float* norm_adv, float* glob_std, hipStream_t stream) {
+    int grid = (int)((B + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(lcf_mix_apply_kernel, dim3(grid), dim3(256), 0, stream, mixed, glob_adv, valid, (long long)B,
+                       stats, norm_adv, glob_std);
+    return hipGetLastError();
+}
+
+}  // namespace copo

@@ -1,0 +1,55 @@
+// Shared declarations of the simulator kernels and their host launchers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/copo_hip.h"
+#include "sim_math.h"
+
+#define COPO_SIM_MAX_BLOCK 1024
+
+namespace copo {
+
+enum : int { ST_EMPTY = 0, ST_ALIVE = 1, ST_WRECK = 2 };
+enum : uint32_t { RNG_ROUTE = 1, RNG_LCF1 = 2, RNG_LCF2 = 3, RNG_SPAWN = 4, RNG_PERM = 16 };
+
+// Kernel parameter block (passed by value).  All pointers are device pointers owned by the handle.
+struct SimParams {
+    int32_t E, N, O, K, num_lasers, enable_lcf, horizon, delay_done, respawn_cooldown, substeps;
+    int32_t n_routes, n_spawns;
+    float lidar_range, neighbours_distance, mf_distance, dt, hl, hw, wheelbase, max_steer, max_speed;
+    float acc_max, brake_max, drag, spawn_clearance;
+    float driving_reward, speed_reward, success_reward, crash_penalty, out_penalty, arrive_margin, lane_width;
+    float lcf_mean, lcf_std;       // distribution for agents spawned in THIS launch (force_lcf folded into mean)
+    float* state;                  // [COPO_STATE_FIELDS][E][N] 32-bit words
+    int32_t* env;                  // [E][4] = {t_env, episode, next_aid, started}
+    const uint64_t* seeds;         // [E]
+    const float* route_segs;       // [R][COPO_MAX_SEGS+1][COPO_SEG_STRIDE]
+    const float* route_meta;       // [R][4]
+    const int32_t* spawn_tab;      // [P][4]
+    const float* spawn_s;          // [P]
+    const float* ray_cs;           // [num_lasers][2]
+};
+
+using StepOut = copo_step_out;
+
+hipError_t launch_sim_reset(const SimParams& p, const StepOut& out, int block, hipStream_t stream);
+hipError_t launch_sim_step(const SimParams& p, const float* act, const StepOut& out, int block, hipStream_t stream);
+hipError_t launch_neighbours(const float* pos, const uint8_t* present, const float* rew, const SimParams& p,
+                             const StepOut& out, hipStream_t stream);
+
+// learn-side ops (learn_kernels.hip)
+hipError_t launch_gae3(const float* rew, const float* val, const uint8_t* flags, int T, int M, int heads,
+                       const double* gamma_host, double lam, float* adv, float* tgt, hipStream_t stream);
+hipError_t launch_cc_fuse_mf(const float* obs, const float* act, const uint8_t* flags, const int32_t* nbr_idx,
+                             const int32_t* cnt, int R, int N, int O, int A, int K, int counterfactual, float* cc,
+                             hipStream_t stream);
+hipError_t launch_cc_fuse_concat(const float* obs, const float* act, const uint8_t* flags, const int32_t* nbr_idx,
+                                 const int32_t* cnt, int R, int N, int O, int A, int K, int num_neighbours,
+                                 int counterfactual, float* cc, hipStream_t stream);
+hipError_t launch_lcf_mix_partial(const float* adv, const float* nei_adv, const float* glob_adv, const float* lcf,
+                                  const uint8_t* valid, int64_t B, float* mixed, double* stats, hipStream_t stream);
+hipError_t launch_lcf_mix_apply(const float* mixed, const float* glob_adv, const uint8_t* valid, int64_t B,
+                                const double* stats, float* norm_adv, float* glob_std, hipStream_t stream);
+
+}  // namespace copo

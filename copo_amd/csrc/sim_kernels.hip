@@ -1,0 +1,691 @@
+// Vectorised multi-agent driving step for gfx950: one workgroup per env, the env's N <= 64 agent slots
+// live in the lanes of wave 0 (state in registers), pair work (collision, neighbour ranking, LiDAR
+// candidates) is wave64-ballot based with the other agent along the lanes, and the LiDAR ray casts
+// are spread over every thread of the workgroup.  Per-scene poses / masks are staged in LDS.
+//
+// Replaces, behind the C ABI of include/copo_hip.h:
+//   MultiAgent*Env.step / reset          (MetaDrive; call site utils/env_wrappers.py:95)  -- build-defined spec
+//   CCEnv._update_distance_map/_find_in_range/step   (utils/env_wrappers.py:89-158)
+//   LCFEnv.step reward block + _add_lcf  (utils/env_wrappers.py:307-418)
+//
+// HBM traffic per agent-step: state 64 B in + 64 B out, action 8 B, obs 4*O B,
+// row outputs ~50 B; everything else stays in LDS / registers.
+#include "sim_common.h"
+
+namespace copo {
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ const float* seg_ptr(const SimParams& p, int route, int k) {
+    return p.route_segs + ((size_t)route * (COPO_MAX_SEGS + 1) + k) * COPO_SEG_STRIDE;
+}
+
+__device__ __forceinline__ void project_seg(const float* __restrict__ g, float x, float y, float& sl, float& lat,
+                                            float& thr) {
+    const float gx = g[0], gy = g[1], gc = g[2], gs = g[3], kap = g[5], th0 = g[7];
+    const float dx = x - gx, dy = y - gy;
+    if (kap == 0.0f) {
+        sl = dx * gc + dy * gs;
+        lat = dy * gc - dx * gs;
+        thr = th0;
+    } else {
+        const float sg = kap > 0.0f ? 1.0f : -1.0f;
+        const float R = 1.0f / fabsf(kap);
+        const float cx = gx - sg * R * gs, cy = gy + sg * R * gc;
+        const float ex = x - cx, ey = y - cy;
+        const float ux = sg * gs, uy = -sg * gc;
+        const float rho = sqrtf(ex * ex + ey * ey);
+        const float dotp = ux * ex + uy * ey;
+        const float crs = ux * ey - uy * ex;
+        const float ang = atan2_det(sg * crs, dotp);
+        sl = ang * R;
+        lat = sg * (R - rho);
+        thr = wrap_pi(th0 + kap * sl);
+    }
+}
+
+__device__ __forceinline__ bool obb_overlap(float xi, float yi, float ci, float si, float xj, float yj, float cj,
+                                            float sj, float hl, float hw) {
+    const float dx = xj - xi, dy = yj - yi;
+    const float cc = fabsf(ci * cj + si * sj), ss = fabsf(ci * sj - si * cj);
+    if (fabsf(dx * ci + dy * si) > hl + hl * cc + hw * ss) return false;
+    if (fabsf(dy * ci - dx * si) > hw + hl * ss + hw * cc) return false;
+    if (fabsf(dx * cj + dy * sj) > hl + hl * cc + hw * ss) return false;
+    if (fabsf(dy * cj - dx * sj) > hw + hl * ss + hw * cc) return false;
+    return true;
+}
+
+// Slot state held in the registers of lane n of wave 0.
+struct Slot {
+    float x, y, th, v, steer, throttle, yawrate, prog, lat, lcf, eprew;
+    int32_t route, status, age, aid, spawncnt;
+};
+
+__device__ __forceinline__ void load_slot(const SimParams& p, int e, int n, Slot& s) {
+    const size_t EN = (size_t)p.E * p.N, o = (size_t)e * p.N + n;
+    const float* st = p.state;
+    s.x = st[0 * EN + o]; s.y = st[1 * EN + o]; s.th = st[2 * EN + o]; s.v = st[3 * EN + o];
+    s.steer = st[4 * EN + o]; s.throttle = st[5 * EN + o]; s.yawrate = st[6 * EN + o]; s.prog = st[7 * EN + o];
+    s.lat = st[8 * EN + o]; s.lcf = st[9 * EN + o]; s.eprew = st[10 * EN + o];
+    const int32_t* si = reinterpret_cast<const int32_t*>(st);
+    s.route = si[11 * EN + o]; s.status = si[12 * EN + o]; s.age = si[13 * EN + o]; s.aid = si[14 * EN + o];
+    s.spawncnt = si[15 * EN + o];
+}
+
+__device__ __forceinline__ void store_slot(const SimParams& p, int e, int n, const Slot& s) {
+    const size_t EN = (size_t)p.E * p.N, o = (size_t)e * p.N + n;
+    float* st = p.state;
+    st[0 * EN + o] = s.x; st[1 * EN + o] = s.y; st[2 * EN + o] = s.th; st[3 * EN + o] = s.v;
+    st[4 * EN + o] = s.steer; st[5 * EN + o] = s.throttle; st[6 * EN + o] = s.yawrate; st[7 * EN + o] = s.prog;
+    st[8 * EN + o] = s.lat; st[9 * EN + o] = s.lcf; st[10 * EN + o] = s.eprew;
+    int32_t* si = reinterpret_cast<int32_t*>(st);
+    si[11 * EN + o] = s.route; si[12 * EN + o] = s.status; si[13 * EN + o] = s.age; si[14 * EN + o] = s.aid;
+    si[15 * EN + o] = s.spawncnt;
+}
+
+// Spawn a fresh agent into this lane's slot at spawn point sp (spec 3.6).  `aid` is the env-wide id.
+__device__ __forceinline__ void spawn_slot(const SimParams& p, uint64_t seed, uint32_t episode, int n, int sp,
+                                           int32_t aid, Slot& s) {
+    const uint32_t cnt = (uint32_t)s.spawncnt;
+    const uint32_t h = hash_rng(seed, (uint32_t)n, cnt, episode, RNG_ROUTE);
+    const int route = p.spawn_tab[sp * 4 + 0] + (int)(h % (uint32_t)p.spawn_tab[sp * 4 + 1]);
+    const float* g = seg_ptr(p, route, 0);
+    const float s0 = p.spawn_s[sp];
+    s.x = g[0] + g[2] * s0;
+    s.y = g[1] + g[3] * s0;
+    s.th = g[7];
+    s.v = 0.0f; s.steer = 0.0f; s.throttle = 0.0f; s.yawrate = 0.0f;
+    s.prog = s0; s.lat = 0.0f; s.eprew = 0.0f;
+    s.route = route;
+    s.status = ST_ALIVE;
+    s.age = 0;
+    s.aid = aid;
+    float lcf = 0.0f;
+    if (p.enable_lcf) {
+        const float u1 = uniform01(hash_rng(seed, (uint32_t)n, cnt, episode, RNG_LCF1));
+        const float u2 = uniform01(hash_rng(seed, (uint32_t)n, cnt, episode, RNG_LCF2));
+        float sn, cs;
+        sincos_det(kTwoPi * u2 - kPi, sn, cs);
+        const float z = sqrtf(-2.0f * log_det(u1)) * cs;
+        lcf = clipf(p.lcf_mean + p.lcf_std * z, -1.0f, 1.0f);
+    }
+    s.lcf = lcf;
+    s.spawncnt = (int32_t)(cnt + 1);
+}
+
+struct __align__(16) EnvLds {
+    float x[64], y[64], cs[64], sn[64], rew[64];
+    float ego[64][20];
+    float ray[COPO_MAX_LASERS][2];
+    unsigned long long cand[64];
+    unsigned long long m_acted, m_present, m_solid;
+    uint8_t crash[64];
+    int16_t perm[COPO_MAX_SPAWNS];
+    int32_t ending;
+};
+
+// Full reset of one env by wave 0 (all lanes call; lane n < N owns slot n).
+__device__ __forceinline__ void reset_env_wave0(const SimParams& p, EnvLds& L, uint64_t seed, uint32_t episode, int lane,
+                                                Slot& s) {
+    if (lane == 0) {
+        const int P = p.n_spawns;
+        for (int i = 0; i < P; ++i) L.perm[i] = (int16_t)i;
+        for (int i = 0; i < p.N; ++i) {
+            const uint32_t h = hash_rng(seed, (uint32_t)i, episode, 0u, RNG_PERM);
+            const int j = i + (int)(h % (uint32_t)(P - i));
+            const int16_t t = L.perm[i];
+            L.perm[i] = L.perm[j];
+            L.perm[j] = t;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (lane < p.N) spawn_slot(p, seed, episode, lane, (int)L.perm[lane], lane, s);
+}
+
+// neighbour lists + reward reductions (CCEnv / LCFEnv) for agents i = wave, wave+nw, ...; lane = other agent j
+__device__ __forceinline__ void neighbours_phase(const SimParams& p, const EnvLds& L, int e, int wave, int nwaves,
+                                                 int lane, const StepOut& out) {
+    const int N = p.N, K = p.K;
+    const unsigned long long present = L.m_present;
+    const bool pj = (lane < N) && ((present >> lane) & 1ull);
+    const double xj = (double)L.x[lane & 63], yj = (double)L.y[lane & 63];
+    const size_t base = (size_t)e * N;
+    if (wave == 0 && out.glob_rew) {  // LCFEnv.step: sum(r.values()) / len(r.values()) in slot order, fp64
+        double gs = 0.0;
+        int gc = 0;
+        unsigned long long m = present;
+        while (m) {
+            const int j = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            gs += (double)L.rew[j];
+            gc++;
+        }
+        if (lane == 0) out.glob_rew[e] = gc ? (float)(gs / (double)gc) : 0.0f;
+    }
+    for (int i = wave; i < N; i += nwaves) {
+        const bool pi = (present >> i) & 1ull;
+        const double dx = (double)L.x[i] - xj, dy = (double)L.y[i] - yj;
+        const double d = sqrt(dx * dx + dy * dy);
+        const bool inr = pi && pj && (lane != i) && (d < (double)p.neighbours_distance);
+        const unsigned long long mask = __ballot(inr);
+        const int cnt = __popcll(mask);
+        const int mfc = __popcll(__ballot(inr && (d <= (double)p.mf_distance)));
+        // rank of j in i's list: stable order by (d, slot) == python sorted() on an insertion-ordered dict
+        int rank = 0;
+        double nsum = 0.0;
+        unsigned long long m = mask;
+        while (m) {
+            const int k = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const double dk = __shfl(d, k);
+            rank += (dk < d || (dk == d && k < lane)) ? 1 : 0;
+        }
+        if (out.nei_rew) {  // mean of neighbour rewards, summed in list order in fp64 (env_wrappers.py:321-325)
+            for (int r = 0; r < cnt; ++r) {
+                const unsigned long long who = __ballot(inr && rank == r);
+                const int j = __ffsll((long long)who) - 1;
+                nsum += (double)L.rew[j];
+            }
+            if (lane == 0) out.nei_rew[base + i] = cnt ? (float)(nsum / (double)cnt) : 0.0f;
+        }
+        if (lane == 0) {
+            if (out.nbr_cnt) out.nbr_cnt[base + i] = cnt;
+            if (out.mf_cnt) out.mf_cnt[base + i] = mfc;
+        }
+        if (inr && rank < K) {
+            if (out.nbr_idx) out.nbr_idx[(base + i) * K + rank] = lane;
+            if (out.nbr_dist) out.nbr_dist[(base + i) * K + rank] = (float)d;
+        }
+        if (lane >= cnt && lane < K) {
+            if (out.nbr_idx) out.nbr_idx[(base + i) * K + lane] = -1;
+            if (out.nbr_dist) out.nbr_dist[(base + i) * K + lane] = 0.0f;
+        }
+    }
+}
+
+// ego + navigation block of the observation for this lane's slot -> LDS tile
+__device__ __forceinline__ void ego_navi_obs(const SimParams& p, EnvLds& L, int lane, const Slot& s, bool present) {
+    float* o = L.ego[lane];
+    if (!present) {
+#pragma unroll
+        for (int k = 0; k < 20; ++k) o[k] = 0.0f;
+        return;
+    }
+    const int route = s.route & 0xffff, seg = s.route >> 16;
+    const float* meta = p.route_meta + route * 4;
+    const float total = meta[0], latl = meta[1], latr = meta[2];
+    const int nseg = (int)meta[3];
+    const float* g = seg_ptr(p, route, seg);
+    float sl, lat, thr;
+    project_seg(g, s.x, s.y, sl, lat, thr);
+    const float psi = wrap_pi(s.th - thr);
+    const float W = latl + latr;
+    const float cs = L.cs[lane], sn = L.sn[lane];
+    o[0] = clipf((latl - lat) / W, 0.0f, 1.0f);
+    o[1] = clipf((lat + latr) / W, 0.0f, 1.0f);
+    o[2] = clipf(0.5f + psi / kPi, 0.0f, 1.0f);
+    o[3] = clipf(s.v / p.max_speed, 0.0f, 1.0f);
+    o[4] = clipf(0.5f + 0.5f * s.steer, 0.0f, 1.0f);
+    o[5] = clipf(0.5f + 0.5f * s.steer, 0.0f, 1.0f);
+    o[6] = clipf(0.5f + 0.5f * s.throttle, 0.0f, 1.0f);
+    o[7] = clipf(0.5f + 0.5f * s.yawrate, 0.0f, 1.0f);
+    o[8] = clipf(0.5f + 0.5f * lat / p.lane_width, 0.0f, 1.0f);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int kk = seg + j;
+        if (kk > nseg - 1) kk = nseg - 1;
+        const float* gk = seg_ptr(p, route, kk);
+        const float* gn = seg_ptr(p, route, kk + 1);
+        const float rx = gn[0] - s.x, ry = gn[1] - s.y;
+        const float fx = rx * cs + ry * sn, fy = ry * cs - rx * sn;
+        float* q = o + COPO_EGO_DIM + 5 * j;
+        q[0] = clipf(0.5f + fx * 0.01f, 0.0f, 1.0f);
+        q[1] = clipf(0.5f + fy * 0.01f, 0.0f, 1.0f);
+        q[2] = clipf(0.5f + gk[5] * 5.0f, 0.0f, 1.0f);
+        q[3] = clipf(gk[4] * 0.01f, 0.0f, 1.0f);
+        q[4] = (j == 0) ? clipf(s.prog / total, 0.0f, 1.0f) : ((kk == nseg - 1) ? 1.0f : 0.0f);
+    }
+    o[19] = (s.lcf + 1.0f) * 0.5f;
+}
+
+// LiDAR + observation write-out, all threads of the workgroup.  Precondition: L.x/y/cs/sn, m_present,
+// m_solid, ego tile are final and visible (caller synchronised).
+__device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, int tid, int nthreads,
+                                          float* __restrict__ obs) {
+    const int N = p.N, O = p.O, NL = p.num_lasers;
+    const int wave = tid >> 6, lane = tid & 63, nwaves = nthreads >> 6;
+    const float hl = p.hl, hw = p.hw;
+    const float circ = sqrtf(hl * hl + hw * hw);
+    const float range = p.lidar_range;
+    const float lim = range + circ;
+    const unsigned long long solid = L.m_solid, present = L.m_present;
+    // candidate masks: solid vehicles within range + circumradius of agent i
+    for (int i = wave; i < N; i += nwaves) {
+        const float rx = L.x[lane] - L.x[i], ry = L.y[lane] - L.y[i];
+        const bool c = (lane < N) && (lane != i) && ((solid >> lane) & 1ull) && !(rx * rx + ry * ry > lim * lim);
+        const unsigned long long m = __ballot(c);
+        if (lane == 0) L.cand[i] = m;
+    }
+    __syncthreads();
+    float* eobs = obs + (size_t)e * N * O;
+    // ego / navigation / lcf columns
+    for (int q = tid; q < N * 20; q += nthreads) {
+        const int i = q / 20, c = q - i * 20;
+        if (c < 19) eobs[(size_t)i * O + c] = L.ego[i][c];
+        else if (p.enable_lcf) eobs[(size_t)i * O + O - 1] = L.ego[i][19];
+    }
+    // rays
+    const int total = N * NL;
+    for (int q = tid; q < total; q += nthreads) {
+        const int i = q / NL, k = q - i * NL;
+        float val = 0.0f;
+        if ((present >> i) & 1ull) {
+            const float x = L.x[i], y = L.y[i], ci = L.cs[i], si = L.sn[i];
+            const float rc = L.ray[k][0], rs = L.ray[k][1];
+            const float dxr = ci * rc - si * rs;
+            const float dyr = si * rc + ci * rs;
+            float best = range;
+            unsigned long long m = L.cand[i];
+            while (m) {
+                const int j = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const float rx = L.x[j] - x, ry = L.y[j] - y;
+                const float along = dxr * rx + dyr * ry;
+                const float perp = dxr * ry - dyr * rx;
+                if (along < -circ || fabsf(perp) > circ) continue;
+                const float cj = L.cs[j], sj = L.sn[j];
+                const float ox = -(rx * cj + ry * sj), oy = -(ry * cj - rx * sj);
+                const float ddx = dxr * cj + dyr * sj, ddy = dyr * cj - dxr * sj;
+                float tlo = -1e30f, thi = 1e30f;
+                bool miss = false;
+                if (fabsf(ddx) < 1e-9f) {
+                    if (fabsf(ox) > hl) miss = true;
+                } else {
+                    const float t1 = (-hl - ox) / ddx, t2 = (hl - ox) / ddx;
+                    const float a = t1 < t2 ? t1 : t2, b = t1 < t2 ? t2 : t1;
+                    if (a > tlo) tlo = a;
+                    if (b < thi) thi = b;
+                }
+                if (fabsf(ddy) < 1e-9f) {
+                    if (fabsf(oy) > hw) miss = true;
+                } else {
+                    const float t1 = (-hw - oy) / ddy, t2 = (hw - oy) / ddy;
+                    const float a = t1 < t2 ? t1 : t2, b = t1 < t2 ? t2 : t1;
+                    if (a > tlo) tlo = a;
+                    if (b < thi) thi = b;
+                }
+                if (miss || tlo > thi || thi < 0.0f) continue;
+                const float t = tlo > 0.0f ? tlo : 0.0f;
+                if (t < best) best = t;
+            }
+            val = best / range;
+        }
+        eobs[(size_t)i * O + COPO_EGO_DIM + COPO_NAVI_DIM + k] = val;
+    }
+}
+
+__device__ __forceinline__ void stage_pose(EnvLds& L, int lane, const Slot& s) {
+    float sn, cs;
+    sincos_det(s.th, sn, cs);
+    L.x[lane] = s.x;
+    L.y[lane] = s.y;
+    L.cs[lane] = cs;
+    L.sn[lane] = sn;
+}
+
+__device__ __forceinline__ void load_rays(const SimParams& p, EnvLds& L, int tid, int nthreads) {
+    for (int q = tid; q < p.num_lasers * 2; q += nthreads) (&L.ray[0][0])[q] = p.ray_cs[q];
+}
+
+// ------------------------------------------------------------------------------------------------
+// reset kernel
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_reset_kernel(SimParams p, StepOut out) {
+    __shared__ EnvLds L;
+    const int e = blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
+    const int wave = tid >> 6, lane = tid & 63, nwaves = nthreads >> 6;
+    const int N = p.N;
+    load_rays(p, L, tid, nthreads);
+    Slot s;
+    if (wave == 0) {
+        const uint64_t seed = p.seeds[e];
+        s = Slot{};
+        reset_env_wave0(p, L, seed, 0u, lane, s);
+        if (lane < N) {
+            stage_pose(L, lane, s);
+            store_slot(p, e, lane, s);
+            L.rew[lane] = 0.0f;
+            const size_t o = (size_t)e * N + lane;
+            if (out.rew) out.rew[o] = 0.0f;
+            if (out.flags) out.flags[o] = COPO_F_SPAWNED;
+            if (out.lcf) out.lcf[o] = s.lcf;
+            if (out.agent_id) out.agent_id[o] = s.aid;
+            if (out.info)
+                for (int k = 0; k < COPO_INFO_DIM; ++k) out.info[o * COPO_INFO_DIM + k] = 0.0f;
+        } else {
+            L.x[lane] = 0.0f; L.y[lane] = 0.0f; L.cs[lane] = 1.0f; L.sn[lane] = 0.0f; L.rew[lane] = 0.0f;
+        }
+        const unsigned long long all = __ballot(lane < N);
+        if (lane == 0) {
+            L.m_present = all;
+            L.m_solid = all;
+            L.m_acted = 0ull;
+            int32_t* env = p.env + (size_t)e * 4;
+            env[0] = 0; env[1] = 0; env[2] = N; env[3] = 1;
+        }
+        ego_navi_obs(p, L, lane, s, lane < N);
+    }
+    __syncthreads();
+    neighbours_phase(p, L, e, wave, nwaves, lane, out);
+    if (out.obs) obs_phase(p, L, e, tid, nthreads, out.obs);
+}
+
+// ------------------------------------------------------------------------------------------------
+// step kernel
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams p, const float* __restrict__ act,
+                                                                      StepOut out) {
+    __shared__ EnvLds L;
+    const int e = blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
+    const int wave = tid >> 6, lane = tid & 63, nwaves = nthreads >> 6;
+    const int N = p.N;
+    const float hl = p.hl, hw = p.hw;
+    load_rays(p, L, tid, nthreads);
+
+    // ---- P0 (wave 0): timers + bicycle dynamics, poses -> LDS ------------------------------------
+    Slot s = Slot{};
+    bool acted = false;
+    float acc = 0.0f;
+    int32_t t_env = 0, episode = 0, next_aid = 0;
+    uint64_t seed = 0;
+    if (wave == 0) {
+        const int32_t* env = p.env + (size_t)e * 4;
+        t_env = env[0]; episode = env[1]; next_aid = env[2];
+        seed = p.seeds[e];
+        if (lane < N) {
+            load_slot(p, e, lane, s);
+            const int st = s.status & 0xff;
+            int tm = s.status >> 8;
+            acted = (st == ST_ALIVE);
+            if (st == ST_WRECK) {
+                tm -= 1;
+                s.status = (tm <= 0) ? (ST_EMPTY | (p.respawn_cooldown << 8)) : (ST_WRECK | (tm << 8));
+            } else if (st == ST_EMPTY && tm > 0) {
+                s.status = ST_EMPTY | ((tm - 1) << 8);
+            }
+            if (acted) {
+                const float2 a = reinterpret_cast<const float2*>(act)[(size_t)e * N + lane];
+                float a0 = a.x, a1 = a.y;
+                if (!(a0 == a0)) a0 = 0.0f;
+                if (!(a1 == a1)) a1 = 0.0f;
+                a0 = clipf(a0, -1.0f, 1.0f);
+                a1 = clipf(a1, -1.0f, 1.0f);
+                const float delta = a0 * p.max_steer;
+                float sd, cd;
+                sincos_det(delta, sd, cd);
+                const float tan_over_L = (sd / cd) / p.wheelbase;
+                const float h = p.dt / (float)p.substeps;
+                float x = s.x, y = s.y, th = s.th, v = s.v;
+                const float v0 = v, th0 = th;
+                for (int k = 0; k < p.substeps; ++k) {
+                    float a = a1 >= 0.0f ? a1 * p.acc_max * (1.0f - v / p.max_speed) : a1 * p.brake_max;
+                    a = a - p.drag * v;
+                    v = v + a * h;
+                    if (v < 0.0f) v = 0.0f;
+                    float sn, cs;
+                    sincos_det(th, sn, cs);
+                    x = x + v * cs * h;
+                    y = y + v * sn * h;
+                    th = wrap_pi(th + v * tan_over_L * h);
+                }
+                s.x = x; s.y = y; s.th = th; s.v = v;
+                s.steer = a0; s.throttle = a1;
+                s.yawrate = wrap_pi(th - th0) / p.dt;
+                acc = (v - v0) / p.dt;
+                s.age += 1;
+            }
+            stage_pose(L, lane, s);
+        } else {
+            L.x[lane] = 0.0f; L.y[lane] = 0.0f; L.cs[lane] = 1.0f; L.sn[lane] = 0.0f;
+        }
+        const unsigned long long ma = __ballot(acted);
+        const unsigned long long ms = __ballot(lane < N && (s.status & 0xff) != ST_EMPTY);
+        if (lane == 0) {
+            L.m_acted = ma;
+            L.m_solid = ms;
+            L.ending = (t_env + 1 >= p.horizon) ? 1 : 0;
+        }
+    }
+    __syncthreads();
+
+    // ---- P1 (all waves): collision of acting agent i against every solid slot j (lane) ------------
+    {
+        const unsigned long long ma = L.m_acted, ms = L.m_solid;
+        const float xj = L.x[lane], yj = L.y[lane], cj = L.cs[lane], sj = L.sn[lane];
+        const bool sol = (ms >> lane) & 1ull;
+        for (int i = wave; i < N; i += nwaves) {
+            bool hit = false;
+            if ((ma >> i) & 1ull)
+                hit = sol && (lane != i) && obb_overlap(L.x[i], L.y[i], L.cs[i], L.sn[i], xj, yj, cj, sj, hl, hw);
+            const unsigned long long m = __ballot(hit);
+            if (lane == 0) L.crash[i] = m ? 1 : 0;
+        }
+    }
+    __syncthreads();
+
+    const bool ending = L.ending != 0;
+    uint8_t fl = 0;
+    float rew = 0.0f, lcf_row = 0.0f;
+    int32_t aid_row = -1;
+    bool present = false;
+    // ---- P2 (wave 0): route projection, termination, reward, respawn ------------------------------
+    if (wave == 0) {
+        bool term = false;
+        lcf_row = s.lcf;
+        aid_row = acted ? s.aid : -1;
+        if (acted) {
+            const int route = s.route & 0xffff;
+            int seg = s.route >> 16;
+            const float* meta = p.route_meta + route * 4;
+            const float total = meta[0], latl = meta[1], latr = meta[2];
+            const int nseg = (int)meta[3];
+            const float* g = seg_ptr(p, route, seg);
+            float sl, lat, thr;
+            project_seg(g, s.x, s.y, sl, lat, thr);
+            for (int it = 0; it < 2; ++it) {
+                if (sl > g[4] && seg < nseg - 1) {
+                    seg += 1;
+                    g = seg_ptr(p, route, seg);
+                    project_seg(g, s.x, s.y, sl, lat, thr);
+                }
+            }
+            if (sl < 0.0f && seg > 0) {
+                seg -= 1;
+                g = seg_ptr(p, route, seg);
+                project_seg(g, s.x, s.y, sl, lat, thr);
+            }
+            const float prog = g[6] + sl;
+            const float prev = s.prog;
+            s.route = route | (seg << 16);
+            s.prog = prog;
+            s.lat = lat;
+            const bool arrive = (prog >= total - p.arrive_margin) && (lat <= latl) && (lat >= -latr);
+            const bool oor = (lat > latl) || (lat < -latr) || (prog < -5.0f);
+            const bool crash = L.crash[lane] != 0;
+            const float lf = clipf(1.0f - 2.0f * fabsf(lat) / p.lane_width, 0.0f, 1.0f);
+            float r = p.driving_reward * (prog - prev) * lf + p.speed_reward * (s.v / p.max_speed);
+            fl = COPO_F_ACTED;
+            if (arrive) { r = p.success_reward; fl |= COPO_F_ARRIVE; }
+            else if (oor) { r = -p.out_penalty; }
+            else if (crash) { r = -p.crash_penalty; }
+            if (oor) fl |= COPO_F_OUT;
+            if (crash) fl |= COPO_F_CRASH;
+            bool done = arrive || oor || crash;
+            if (!done && ending) { fl |= COPO_F_MAXSTEP; done = true; }
+            if (done) fl |= COPO_F_DONE;
+            if (ending) fl |= COPO_F_ENV_RESET;
+            term = done;
+            rew = r;
+            s.eprew += r;
+            if (out.info) {
+                float* q = out.info + ((size_t)e * N + lane) * COPO_INFO_DIM;
+                q[COPO_I_VELOCITY] = s.v * 3.6f;
+                q[COPO_I_STEERING] = s.steer;
+                q[COPO_I_ACCELERATION] = acc;
+                q[COPO_I_STEP_REWARD] = r;
+                q[COPO_I_COST] = (crash || oor) ? 1.0f : 0.0f;
+                q[COPO_I_EPISODE_LENGTH] = (float)s.age;
+                q[COPO_I_EPISODE_REWARD] = s.eprew;
+                q[COPO_I_ROUTE_COMPLETION] = clipf(prog / total, 0.0f, 1.0f);
+            }
+            if (term) {
+                if ((fl & COPO_F_CRASH) && !(fl & (COPO_F_ARRIVE | COPO_F_OUT)) && p.delay_done > 0)
+                    s.status = ST_WRECK | (p.delay_done << 8);
+                else
+                    s.status = ST_EMPTY | (p.respawn_cooldown << 8);
+            }
+        } else if (lane < N && out.info) {
+            float* q = out.info + ((size_t)e * N + lane) * COPO_INFO_DIM;
+            for (int k = 0; k < COPO_INFO_DIM; ++k) q[k] = 0.0f;
+        }
+        present = acted;
+        // respawn, serial over eligible slots in slot order; every lane tests its own vehicle
+        if (!ending) {
+            unsigned long long elig = __ballot(lane < N && !acted && s.status == ST_EMPTY);
+            while (elig) {
+                const int n = __ffsll((long long)elig) - 1;
+                elig &= elig - 1;
+                const uint32_t cnt = (uint32_t)__shfl(s.spawncnt, n);
+                for (uint32_t a = 0; a < 3; ++a) {
+                    const uint32_t hh = hash_rng(seed, (uint32_t)n, cnt, (uint32_t)t_env, RNG_SPAWN + a);
+                    const int sp = (int)(hh % (uint32_t)p.n_spawns);
+                    const float* g = seg_ptr(p, p.spawn_tab[sp * 4], 0);
+                    const float s0 = p.spawn_s[sp];
+                    const float sx = g[0] + g[2] * s0, sy = g[1] + g[3] * s0;
+                    const float dx = s.x - sx, dy = s.y - sy;
+                    const bool blk = (lane < N) && ((s.status & 0xff) != ST_EMPTY) &&
+                                     (dx * dx + dy * dy < p.spawn_clearance * p.spawn_clearance);
+                    if (__ballot(blk) == 0ull) {
+                        if (lane == n) {
+                            spawn_slot(p, seed, (uint32_t)episode, n, sp, next_aid, s);
+                            present = true;
+                            fl = COPO_F_SPAWNED;
+                            lcf_row = s.lcf;
+                        }
+                        next_aid += 1;
+                        break;
+                    }
+                }
+            }
+        }
+        if (lane < N) {
+            stage_pose(L, lane, s);
+            L.rew[lane] = rew;
+        } else {
+            L.rew[lane] = 0.0f;
+        }
+        const unsigned long long mp = __ballot(present);
+        const unsigned long long ms = __ballot(lane < N && (s.status & 0xff) != ST_EMPTY);
+        if (lane == 0) {
+            L.m_present = mp;
+            L.m_solid = ms;
+        }
+    }
+    __syncthreads();
+
+    // ---- P3 (all waves): neighbour lists + reward reductions on the post-step (pre-reset) scene ---
+    neighbours_phase(p, L, e, wave, nwaves, lane, out);
+    if (ending) __syncthreads();  // neighbours read the poses that the reset below overwrites
+
+    // ---- P4 (wave 0): horizon reset, row outputs, state write-back, ego/navi obs ------------------
+    if (wave == 0) {
+        uint8_t fl_out = fl;
+        float lcf_out = lcf_row;
+        if (ending) {
+            episode += 1;
+            next_aid = 0;
+            reset_env_wave0(p, L, seed, (uint32_t)episode, lane, s);
+            next_aid = N;
+            present = lane < N;
+            fl_out |= COPO_F_SPAWNED | COPO_F_ENV_RESET;
+            if (!acted) lcf_out = s.lcf;
+            if (lane < N) stage_pose(L, lane, s);
+            const unsigned long long all = __ballot(lane < N);
+            if (lane == 0) {
+                L.m_present = all;
+                L.m_solid = all;
+            }
+        }
+        if (lane < N) {
+            const size_t o = (size_t)e * N + lane;
+            if (out.rew) out.rew[o] = rew;
+            if (out.flags) out.flags[o] = fl_out;
+            if (out.lcf) out.lcf[o] = lcf_out;
+            if (out.agent_id) out.agent_id[o] = aid_row;
+            store_slot(p, e, lane, s);
+        }
+        if (lane == 0) {
+            int32_t* env = p.env + (size_t)e * 4;
+            env[0] = ending ? 0 : t_env + 1;
+            env[1] = episode;
+            env[2] = next_aid;
+        }
+        ego_navi_obs(p, L, lane, s, present);
+    }
+    __syncthreads();
+
+    // ---- P5 (all threads): LiDAR + observation write-out -------------------------------------------
+    if (out.obs) obs_phase(p, L, e, tid, nthreads, out.obs);
+}
+
+// ------------------------------------------------------------------------------------------------
+// stateless neighbour op (CCEnv + LCFEnv reward block) on caller-provided positions
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) neighbours_kernel(const float* __restrict__ pos,
+                                                         const uint8_t* __restrict__ present_in,
+                                                         const float* __restrict__ rew, SimParams p, StepOut out) {
+    __shared__ EnvLds L;
+    const int e = blockIdx.x, tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, nwaves = blockDim.x >> 6;
+    const int N = p.N;
+    if (wave == 0) {
+        bool pr = false;
+        if (lane < N) {
+            const size_t o = (size_t)e * N + lane;
+            L.x[lane] = pos[o * 2];
+            L.y[lane] = pos[o * 2 + 1];
+            L.rew[lane] = rew ? rew[o] : 0.0f;
+            pr = present_in[o] != 0;
+        } else {
+            L.x[lane] = 0.0f; L.y[lane] = 0.0f; L.rew[lane] = 0.0f;
+        }
+        const unsigned long long m = __ballot(pr);
+        if (lane == 0) L.m_present = m;
+    }
+    __syncthreads();
+    neighbours_phase(p, L, e, wave, nwaves, lane, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------------
+hipError_t launch_sim_reset(const SimParams& p, const StepOut& out, int block, hipStream_t stream) {
+    hipLaunchKernelGGL(sim_reset_kernel, dim3(p.E), dim3(block), 0, stream, p, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_sim_step(const SimParams& p, const float* act, const StepOut& out, int block, hipStream_t stream) {
+    hipLaunchKernelGGL(sim_step_kernel, dim3(p.E), dim3(block), 0, stream, p, act, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_neighbours(const float* pos, const uint8_t* present, const float* rew, const SimParams& p,
+                             const StepOut& out, hipStream_t stream) {
+    hipLaunchKernelGGL(neighbours_kernel, dim3(p.E), dim3(256), 0, stream, pos, present, rew, p, out);
+    return hipGetLastError();
+}
+
+}  // namespace copo

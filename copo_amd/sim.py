@@ -1,0 +1,180 @@
+"""Vectorised multi-agent driving simulator handle (host side of `copo_sim_*`).
+
+`VecSim` owns one `copo_sim` handle on one GPU and the output tensors of a step.  It is the
+array-level interface; `copo_amd.torch_copo.utils.env_wrappers` layers the reference's dict-style
+`MultiAgentEnv` surface on top of it.
+"""
+import ctypes as C
+import math
+from dataclasses import asdict, dataclass, field
+
+import numpy as np
+
+from . import maps as _maps
+
+EGO_DIM, NAVI_DIM = 9, 10
+
+
+@dataclass
+class SimConfig:
+    """Python mirror of `copo_sim_cfg` with the build's defaults."""
+    map: str = "intersection"
+    map_kwargs: dict = field(default_factory=dict)
+    num_envs: int = 1
+    num_agents: int = None            # default: the map's population (Inter 30, Round 40, ...)
+    num_lasers: int = 72
+    nbr_k: int = 8
+    enable_lcf: bool = True
+    horizon: int = 1000
+    delay_done: int = 25
+    respawn_cooldown: int = 1
+    substeps: int = 5
+    lidar_range: float = 40.0
+    neighbours_distance: float = 40.0  # env_wrappers.py:168
+    mf_distance: float = 10.0          # algo_ccppo.py:43
+    dt: float = 0.1
+    veh_half_len: float = 2.25
+    veh_half_wid: float = 0.925
+    wheelbase: float = 2.7
+    max_steer: float = math.radians(40.0)
+    max_speed: float = 80.0 / 3.6
+    acc_max: float = 6.0
+    brake_max: float = 9.0
+    drag: float = 0.05
+    spawn_clearance: float = 7.5
+    driving_reward: float = 1.0
+    speed_reward: float = 0.1
+    success_reward: float = 10.0
+    crash_penalty: float = 10.0
+    out_penalty: float = 10.0
+    arrive_margin: float = 5.0
+    lane_width: float = 3.5
+    lcf_mean: float = 0.0
+    lcf_std: float = 0.1               # env_wrappers.py:176
+    start_seed: int = 5000
+
+    def tables(self):
+        return _maps.MAP_BUILDERS[self.map](**self.map_kwargs)
+
+    def resolved(self):
+        t = self.tables()
+        n = self.num_agents if self.num_agents is not None else t.default_num_agents
+        return t, int(n)
+
+    @property
+    def obs_dim(self):
+        return EGO_DIM + NAVI_DIM + self.num_lasers + (1 if self.enable_lcf else 0)
+
+
+def fill_cfg_struct(cfg: SimConfig, struct_cls):
+    """Build the C struct (works for both the HIP library and the test oracle, which share the layout).
+    Returns (struct, keepalive) -- keepalive holds the numpy tables the struct points into."""
+    t, n = cfg.resolved()
+    c = struct_cls()
+    c.num_envs, c.num_agents, c.num_lasers, c.obs_dim = cfg.num_envs, n, cfg.num_lasers, cfg.obs_dim
+    c.nbr_k = min(cfg.nbr_k, 64)
+    c.enable_lcf = 1 if cfg.enable_lcf else 0
+    c.horizon, c.delay_done, c.respawn_cooldown, c.substeps = cfg.horizon, cfg.delay_done, cfg.respawn_cooldown, cfg.substeps
+    for k in ("lidar_range", "neighbours_distance", "mf_distance", "dt", "veh_half_len", "veh_half_wid", "wheelbase",
+              "max_steer", "max_speed", "acc_max", "brake_max", "drag", "spawn_clearance", "driving_reward",
+              "speed_reward", "success_reward", "crash_penalty", "out_penalty", "arrive_margin", "lane_width"):
+        setattr(c, k, float(getattr(cfg, k)))
+    c.lcf_mean, c.lcf_std = float(cfg.lcf_mean), float(cfg.lcf_std)
+    keep = dict(
+        route_segs=np.ascontiguousarray(t.route_segs, np.float32), route_meta=np.ascontiguousarray(t.route_meta, np.float32),
+        spawn_tab=np.ascontiguousarray(t.spawn_tab, np.int32), spawn_s=np.ascontiguousarray(t.spawn_s, np.float32),
+        ray_cs=_maps.ray_table(cfg.num_lasers))
+    c.n_routes, c.n_spawns = t.n_routes, t.n_spawns
+    for k, v in keep.items():
+        setattr(c, k, v.ctypes.data)
+    return c, keep
+
+
+class VecSim:
+    """E independent scenes x N agent slots on one GPU; every call is asynchronous on torch's current stream."""
+
+    OUT_FIELDS = ("obs", "rew", "nei_rew", "glob_rew", "flags", "nbr_idx", "nbr_cnt", "mf_cnt", "nbr_dist", "lcf",
+                  "info", "agent_id")
+
+    def __init__(self, cfg: SimConfig, device=0, with_info=True):
+        import torch
+        from . import _capi
+        self._capi, self._torch = _capi, torch
+        self.cfg = cfg
+        self.tables, self.N = cfg.resolved()
+        self.E, self.O, self.K = cfg.num_envs, cfg.obs_dim, min(cfg.nbr_k, 64)
+        self.device = torch.device("cuda", device)
+        struct, self._keep = fill_cfg_struct(cfg, _capi.SimCfg)
+        h = C.c_void_p()
+        _capi.check(_capi.lib.copo_sim_create(C.byref(struct), device, C.byref(h)))
+        self._h = h
+        E, N, O, K, dev = self.E, self.N, self.O, self.K, self.device
+        f32, i32, u8 = torch.float32, torch.int32, torch.uint8
+        self.out = dict(
+            obs=torch.zeros(E, N, O, dtype=f32, device=dev), rew=torch.zeros(E, N, dtype=f32, device=dev),
+            nei_rew=torch.zeros(E, N, dtype=f32, device=dev), glob_rew=torch.zeros(E, dtype=f32, device=dev),
+            flags=torch.zeros(E, N, dtype=u8, device=dev), nbr_idx=torch.zeros(E, N, K, dtype=i32, device=dev),
+            nbr_cnt=torch.zeros(E, N, dtype=i32, device=dev), mf_cnt=torch.zeros(E, N, dtype=i32, device=dev),
+            nbr_dist=torch.zeros(E, N, K, dtype=f32, device=dev), lcf=torch.zeros(E, N, dtype=f32, device=dev),
+            info=torch.zeros(E, N, _capi.INFO_DIM, dtype=f32, device=dev) if with_info else None,
+            agent_id=torch.zeros(E, N, dtype=i32, device=dev),
+        )
+        self._step_out = self.make_step_out(self.out)
+
+    def make_step_out(self, tensors):
+        so = self._capi.StepOut()
+        for k in self.OUT_FIELDS:
+            t = tensors.get(k)
+            setattr(so, k, t.data_ptr() if t is not None else None)
+        return so
+
+    def _stream(self):
+        return self._torch.cuda.current_stream(self.device).cuda_stream
+
+    def reset(self, seeds=None, out=None):
+        if seeds is None:
+            seeds = np.arange(self.E, dtype=np.uint64) + np.uint64(self.cfg.start_seed)
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        assert seeds.shape == (self.E,)
+        so = self._step_out if out is None else self.make_step_out(out)
+        self._capi.check(self._capi.lib.copo_sim_reset(self._h, seeds.ctypes.data, C.byref(so), self._stream()))
+        self._torch.cuda.current_stream(self.device).synchronize()   # seeds is a host buffer
+        return self.out if out is None else out
+
+    def step(self, act, out=None):
+        """act: [E, N, 2] fp32 cuda tensor.  Returns the dict of output tensors (overwritten every step)."""
+        assert act.is_cuda and act.dtype == self._torch.float32 and act.is_contiguous() and act.numel() == self.E * self.N * 2
+        so = self._step_out if out is None else self.make_step_out(out)
+        self._capi.check(self._capi.lib.copo_sim_step(self._h, act.data_ptr(), C.byref(so), self._stream()))
+        return self.out if out is None else out
+
+    def set_lcf_dist(self, mean, std):
+        self._capi.check(self._capi.lib.copo_sim_set_lcf_dist(self._h, float(mean), float(std)))
+
+    def set_force_lcf(self, v):
+        self._capi.check(self._capi.lib.copo_sim_set_force_lcf(self._h, float(v)))
+
+    def set_block(self, threads):
+        self._capi.check(self._capi.lib.copo_sim_set_block(self._h, int(threads)))
+
+    def get_state(self):
+        torch = self._torch
+        st = torch.empty(self._capi.STATE_FIELDS, self.E, self.N, dtype=torch.float32, device=self.device)
+        env = torch.empty(self.E, 4, dtype=torch.int32, device=self.device)
+        self._capi.check(self._capi.lib.copo_sim_get_state(self._h, st.data_ptr(), env.data_ptr(), self._stream()))
+        return st, env
+
+    def set_state(self, st, env):
+        assert st.is_cuda and env.is_cuda and st.is_contiguous() and env.is_contiguous()
+        self._capi.check(self._capi.lib.copo_sim_set_state(self._h, st.data_ptr(), env.data_ptr(), self._stream()))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._capi.lib.copo_sim_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

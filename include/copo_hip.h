@@ -1,0 +1,192 @@
+/*
+ * copo_hip.h -- C ABI of libcopo_hip.so, the MI355X (gfx950) hot path of the CoPO rollout-and-update engine.
+ *
+ * Every entry point replaces one Python interface of the reference (decisionforce/CoPO,
+ * paths relative to copo_code/copo/torch_copo/); see INTEGRATION.md for the ctypes binding a
+ * maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch types.  All data pointers are DEVICE pointers owned by the
+ *     caller (kept alive by the caller until the stream has consumed them) unless marked HOST.
+ *   - every call returns COPO_OK (0) or a negative error code; nothing throws.  copo_last_error()
+ *     returns a thread-local, library-owned message for the last failing call on this thread.
+ *   - asynchronous on the hipStream_t passed as `void* stream` (NULL = default stream); no implicit
+ *     device synchronisation inside any op.
+ *   - one opaque handle per GPU process; a handle is not thread-safe (the reference runs one env per
+ *     process, README.md:179-180).
+ *   - deterministic: counter-based RNG keyed by (seed, env, slot, spawn counter).
+ */
+#ifndef COPO_HIP_H
+#define COPO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COPO_ABI_VERSION 1
+
+#define COPO_OK 0
+#define COPO_ERR_NULL (-1)      /* required pointer is NULL */
+#define COPO_ERR_DIM (-2)       /* size/shape out of the supported range */
+#define COPO_ERR_DEVICE (-3)    /* HIP runtime error (message in copo_last_error) */
+#define COPO_ERR_STATE (-4)     /* call order violated (e.g. step before reset) */
+#define COPO_ERR_CONFIG (-5)    /* inconsistent configuration / map tables */
+
+#define COPO_MAX_AGENTS 64      /* slots per env (one wave64 owns an env's agents) */
+#define COPO_MAX_SEGS 8         /* segments per route */
+#define COPO_SEG_STRIDE 8       /* floats per segment record  */
+#define COPO_MAX_LASERS 256
+#define COPO_MAX_SPAWNS 256     /* spawn points per map */
+#define COPO_MAX_ROUTES 128
+#define COPO_EGO_DIM 9
+#define COPO_NAVI_DIM 10
+#define COPO_INFO_DIM 8
+#define COPO_STATE_FIELDS 16
+#define COPO_LCF_STATS_DOUBLES (8 + 6 * 256) /* size of the `stats` workspace of copo_lcf_mix_* */
+
+/* per-slot step flags (uint8 bitfield), the device-side equivalent of the info dict keys consumed by
+ * utils/callbacks.py:63-91 (arrive_dest / crash / out_of_road / max_step) plus row bookkeeping. */
+#define COPO_F_ACTED 0x01u      /* slot held an agent that acted this step -> a (obs, act, rew, done) row exists */
+#define COPO_F_DONE 0x02u       /* that agent terminated this step */
+#define COPO_F_ARRIVE 0x04u
+#define COPO_F_CRASH 0x08u
+#define COPO_F_OUT 0x10u
+#define COPO_F_MAXSTEP 0x20u
+#define COPO_F_SPAWNED 0x40u    /* a new agent occupies the slot after this step (obs valid, reward 0, no row) */
+#define COPO_F_ENV_RESET 0x80u  /* the env hit its horizon this step and was reset (done["__all__"]) */
+
+/* columns of the optional per-slot info output [E][N][COPO_INFO_DIM] (utils/callbacks.py:35-46) */
+#define COPO_I_VELOCITY 0       /* km/h */
+#define COPO_I_STEERING 1
+#define COPO_I_ACCELERATION 2
+#define COPO_I_STEP_REWARD 3
+#define COPO_I_COST 4
+#define COPO_I_EPISODE_LENGTH 5
+#define COPO_I_EPISODE_REWARD 6
+#define COPO_I_ROUTE_COMPLETION 7
+
+/* Segment record, COPO_SEG_STRIDE floats: {x0, y0, cos0, sin0, length, kappa, s_start, theta0}.
+ * A route has nseg real segments followed by one terminal record (length 0) holding the end pose.  */
+
+typedef struct copo_sim_cfg {
+    /* population */
+    int32_t num_envs;          /* E */
+    int32_t num_agents;        /* N slots per env, <= COPO_MAX_AGENTS */
+    int32_t num_lasers;        /* LiDAR beams (72; 240 for config C5) */
+    int32_t obs_dim;           /* O = 9 + 10 + num_lasers (+1 when enable_lcf) */
+    int32_t nbr_k;             /* neighbour ids stored per slot (<= N-1) */
+    int32_t enable_lcf;        /* 1: LCFEnv (append (lcf+1)/2 to obs, sample LCF at spawn); 0: CCEnv only */
+    int32_t horizon;           /* env steps per episode (MetaDrive `horizon`, 1000) */
+    int32_t delay_done;        /* steps a crashed vehicle lingers as an obstacle (MetaDrive `delay_done`) */
+    int32_t respawn_cooldown;  /* min steps a slot stays empty before re-use (>= 1) */
+    int32_t substeps;          /* physics sub-steps per env step (5) */
+    /* radii */
+    float lidar_range;         /* m */
+    float neighbours_distance; /* env_wrappers.py:40,168 (strict <) */
+    float mf_distance;         /* algo_ccppo.py:43,283 (prefix of the sorted list with d <= mf) */
+    /* vehicle + bicycle model */
+    float dt;                  /* env step seconds (0.1) */
+    float veh_half_len, veh_half_wid, wheelbase;
+    float max_steer;           /* rad */
+    float max_speed;           /* m/s */
+    float acc_max, brake_max, drag;
+    float spawn_clearance;     /* m: spawn point must be this far from every solid vehicle */
+    /* reward (MetaDrive-style, build-defined) */
+    float driving_reward, speed_reward, success_reward, crash_penalty, out_penalty;
+    float arrive_margin;       /* m before route end that counts as arrival */
+    float lane_width;
+    /* LCF distribution at creation (LCFEnv.current_lcf_mean/std, env_wrappers.py:200-201) */
+    double lcf_mean, lcf_std;
+    /* map tables (HOST pointers, copied at create) */
+    int32_t n_routes;
+    int32_t n_spawns;
+    const float* route_segs;   /* [n_routes][COPO_MAX_SEGS + 1][COPO_SEG_STRIDE] */
+    const float* route_meta;   /* [n_routes][4] = {total_len, lat_left, lat_right, nseg} */
+    const int32_t* spawn_tab;  /* [n_spawns][4] = {first_route, n_route_choices, 0, 0} */
+    const float* spawn_s;      /* [n_spawns] longitudinal offset of the spawn pose on its routes */
+    const float* ray_cs;       /* [num_lasers][2] = {cos, sin}(2*pi*k/num_lasers) */
+} copo_sim_cfg;
+
+typedef struct copo_sim copo_sim;
+
+/* outputs of one vectorised env step; any pointer except obs may be NULL to skip that output */
+typedef struct copo_step_out {
+    float* obs;          /* [E][N][O]   obs AFTER the step (the next policy input)                        */
+    float* rew;          /* [E][N]      native reward of the acting agent (return_native_reward=True)     */
+    float* nei_rew;      /* [E][N]      env_wrappers.py:321-325                                           */
+    float* glob_rew;     /* [E]         env_wrappers.py:313                                               */
+    uint8_t* flags;      /* [E][N]      COPO_F_* bitfield                                                 */
+    int32_t* nbr_idx;    /* [E][N][K]   slot ids sorted by (distance, slot), -1 padded  (:125-139)        */
+    int32_t* nbr_cnt;    /* [E][N]      neighbours within neighbours_distance (may exceed K)              */
+    int32_t* mf_cnt;     /* [E][N]      length of the list prefix with distance <= mf_distance            */
+    float* nbr_dist;     /* [E][N][K]   distances (float64 compare, stored fp32)                          */
+    float* lcf;          /* [E][N]      LCF in [-1,1] of the acting agent (info["lcf"]) / new occupant    */
+    float* info;         /* [E][N][COPO_INFO_DIM]                                                          */
+    int32_t* agent_id;   /* [E][N]      per-env running id of the acting agent ("agent%d"), -1 if none    */
+} copo_step_out;
+
+/* ---- library ---- */
+int copo_version(void);
+const char* copo_last_error(void);
+
+/* ---- vectorised multi-agent env: replaces MultiAgent*Env.step/reset (MetaDrive, call site
+ *      utils/env_wrappers.py:95), CCEnv.step (:89-123) and LCFEnv.step/_get_reset_return (:274-391) ---- */
+int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** out);
+int copo_sim_destroy(copo_sim* sim);
+/* seeds: HOST [E]; writes the reset observation + flags(SPAWNED) + lcf.  env_wrappers.py:274-305 */
+int copo_sim_reset(copo_sim* sim, const uint64_t* seeds, const copo_step_out* out, void* stream);
+/* LCFEnv.set_lcf_dist (env_wrappers.py:420-426): affects agents spawned from now on */
+int copo_sim_set_lcf_dist(copo_sim* sim, double mean, double std);
+/* LCFEnv.set_force_lcf (env_wrappers.py:428-430): v == -100 disables */
+int copo_sim_set_force_lcf(copo_sim* sim, double v);
+/* act: [E][N][2] device fp32 (clipped to [-1,1] inside, as RLlib's clip_actions does) */
+int copo_sim_step(copo_sim* sim, const float* act, const copo_step_out* out, void* stream);
+/* raw state access for tests / checkpointing: [COPO_STATE_FIELDS][E][N] fp32 words + [E][4] int32 env words */
+int copo_sim_get_state(copo_sim* sim, float* slot_state, int32_t* env_state, void* stream);
+int copo_sim_set_state(copo_sim* sim, const float* slot_state, const int32_t* env_state, void* stream);
+/* workgroup size of the step kernel: 256, 512 or 1024 (0 = pick from E); tuning knob, results do not depend on it */
+int copo_sim_set_block(copo_sim* sim, int32_t threads);
+
+/* ---- stateless ops ---- */
+
+/* CCEnv._update_distance_map + _find_in_range (env_wrappers.py:125-158) + LCFEnv reward block (:313-326).
+ * pos [E][N][2] fp32, present [E][N] u8, rew [E][N] (may be NULL -> no reward outputs). */
+int copo_neighbours_f32(const float* pos, const uint8_t* present, const float* rew, int32_t E, int32_t N, int32_t K,
+                        float radius, float mf_distance, int32_t* nbr_idx, int32_t* nbr_cnt, int32_t* mf_cnt,
+                        float* nbr_dist, float* nei_rew, float* glob_rew, void* stream);
+
+/* Three GAE heads in one segmented reverse scan over [T][M] (M = E*N columns):
+ * compute_advantages (algo_ccppo.py:362-373), compute_nei_advantage / compute_global_advantage
+ * (algo_copo.py:189-204, 492-500).  rew/val/adv/tgt: [3][T][M]; flags [T][M] (ACTED/DONE bits);
+ * gamma[heads] (HOST doubles); bootstrap = value of the segment's LAST row unless DONE.  Rows without ACTED get 0. */
+int copo_gae3_f32(const float* rew, const float* val, const uint8_t* flags, int32_t T, int32_t M, int32_t heads,
+                  const double* gamma, double lam, float* adv, float* tgt, void* stream);
+
+/* mean_field_ccppo_process / concat_ccppo_process (algo_ccppo.py:225-311) over [T][E][N] rows.
+ * obs [R][N][O], act [R][N][A], flags [R][N], nbr_idx [R][N][K], cnt [R][N] (mf: mf_cnt, concat: nbr_cnt),
+ * with R = T*E.  cc_obs [R][N][C]: C = 2O+A (mf, counterfactual), 2O (mf), O+k(O+A) / O+kO (concat). */
+int copo_cc_fuse_mf_f32(const float* obs, const float* act, const uint8_t* flags, const int32_t* nbr_idx,
+                        const int32_t* cnt, int32_t R, int32_t N, int32_t O, int32_t A, int32_t K,
+                        int32_t counterfactual, float* cc_obs, void* stream);
+int copo_cc_fuse_concat_f32(const float* obs, const float* act, const uint8_t* flags, const int32_t* nbr_idx,
+                            const int32_t* cnt, int32_t R, int32_t N, int32_t O, int32_t A, int32_t K,
+                            int32_t num_neighbours, int32_t counterfactual, float* cc_obs, void* stream);
+
+/* CoPOTrainer.training_step coordinated-advantage block (algo_copo.py:539-551):
+ *   A_c = cos(lcf*pi/2)*adv + sin(lcf*pi/2)*nei_adv ; stats of A_c and glob_adv over valid rows;
+ *   norm_adv = (A_c-mean)/max(1e-4,std) ; glob_adv_std likewise (population std).
+ * Two-phase for data-parallel runs: `_partial` writes {count, sum, sumsq} x2 as doubles stats[0..5]
+ * (caller all-reduces those six), `_apply` consumes the (reduced) stats.  `stats` is a device workspace of
+ * COPO_LCF_STATS_DOUBLES doubles (per-block partials live behind the six results; the reduction order is
+ * fixed, so results are run-to-run deterministic).  valid [B] u8 may be NULL. */
+int copo_lcf_mix_partial_f32(const float* adv, const float* nei_adv, const float* glob_adv, const float* lcf,
+                             const uint8_t* valid, int64_t B, float* mixed, double* stats, void* stream);
+int copo_lcf_mix_apply_f32(const float* mixed, const float* glob_adv, const uint8_t* valid, int64_t B,
+                           const double* stats, float* norm_adv, float* glob_adv_std, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COPO_HIP_H */

@@ -1,0 +1,834 @@
+/*
+ * copo_oracle.c -- CPU restatement (scalar C) of the CoPO hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the
+ * product path (copo_amd/, libcopo_hip.so) never does.
+ *
+ * Two halves:
+ *  (1) wrapper / learn-side arithmetic that restates the reference line by line and is pinned by the
+ *      golden vectors under tests/golden/ (generated from the reference's own functions):
+ *        oracle_neighbours      <- utils/env_wrappers.py:125-158 (CCEnv) + :313-326 (LCFEnv rewards)
+ *        oracle_gae3            <- algo_ccppo.py:362-373, algo_copo.py:189-204,492-500
+ *        oracle_cc_fuse_mf      <- algo_ccppo.py:266-311
+ *        oracle_cc_fuse_concat  <- algo_ccppo.py:225-263
+ *        oracle_lcf_mix         <- algo_copo.py:539-551
+ *  (2) the simulator step.  MetaDrive 0.2.5 (the reference's simulator, README.md:42) is a pip
+ *      dependency whose source is NOT in the reference tree, so this half restates the BUILD-DEFINED
+ *      spec of DESIGN.md section 3 ("parity unpinned" against MetaDrive; pinned only on obs dims, info keys and
+ *      the wrapper semantics above).  It is the canonical definition the HIP kernel is checked
+ *      against, bit for bit: all float math is +,-,*,/,sqrt on IEEE fp32/fp64 with contraction off
+ *      and hand-written polynomials for sin/cos/atan2/log, so CPU and GPU agree exactly.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math -shared -fPIC (see oracle/Makefile).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/copo_hip.h"
+
+/* ------------------------------------------------------------------------------------------------
+ * deterministic math (spec: DESIGN.md section 3.2)
+ * ---------------------------------------------------------------------------------------------- */
+#define PI_F 3.14159265f
+#define TWO_PI_F 6.28318531f
+#define HALF_PI_F 1.57079633f
+
+static void o_sincosf(float x, float* s, float* c) {
+    float kf = floorf(x * 0.636619772f + 0.5f);
+    int k = (int)kf;
+    float r = x - kf * 1.5703125f;
+    r = r - kf * 4.83751297e-4f;
+    r = r - kf * 7.54978996e-8f;
+    float z = r * r;
+    float sp = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+    float cp = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z -
+               0.5f * z + 1.0f;
+    switch (k & 3) {
+        case 0: *s = sp; *c = cp; break;
+        case 1: *s = cp; *c = -sp; break;
+        case 2: *s = -sp; *c = -cp; break;
+        default: *s = -cp; *c = sp; break;
+    }
+}
+
+static float o_atan2f(float y, float x) {
+    float ax = fabsf(x), ay = fabsf(y);
+    float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+    if (mx == 0.0f) return 0.0f;
+    float a = mn / mx;
+    float off = 0.0f, t = a;
+    if (a > 0.414213562f) {
+        t = (a - 1.0f) / (a + 1.0f);
+        off = 0.785398163f;
+    }
+    float z = t * t;
+    float p = (((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * t + t;
+    float r = off + p;
+    if (ay > ax) r = HALF_PI_F - r;
+    if (x < 0.0f) r = PI_F - r;
+    return y < 0.0f ? -r : r;
+}
+
+static float o_logf(float u) { /* u in (0, 1] normal */
+    uint32_t b;
+    memcpy(&b, &u, 4);
+    int e = (int)(b >> 23) - 127;
+    b = (b & 0x007fffffu) | 0x3f800000u;
+    float m;
+    memcpy(&m, &b, 4);
+    if (m > 1.41421356f) {
+        m = m * 0.5f;
+        e += 1;
+    }
+    float f = m - 1.0f;
+    float s = f / (2.0f + f);
+    float z = s * s;
+    float p = (((0.111111111f * z + 0.142857143f) * z + 0.2f) * z + 0.333333333f) * z + 1.0f;
+    return (float)e * 0.693147181f + 2.0f * s * p;
+}
+
+static float o_wrap_pi(float a) {
+    if (a > PI_F) a -= TWO_PI_F;
+    if (a < -PI_F) a += TWO_PI_F;
+    return a;
+}
+
+static float o_clip(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+static uint32_t o_mix32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h;
+}
+
+static uint32_t o_hash(uint64_t seed, uint32_t a, uint32_t b, uint32_t c, uint32_t stream) {
+    uint32_t h = o_mix32((uint32_t)seed + 0x9E3779B9u);
+    h = o_mix32(h ^ (uint32_t)(seed >> 32));
+    h = o_mix32(h ^ a);
+    h = o_mix32(h ^ b);
+    h = o_mix32(h ^ c);
+    h = o_mix32(h ^ stream);
+    return h;
+}
+
+static float o_uniform(uint32_t h) { return ((float)(h >> 9) + 0.5f) * 1.1920929e-7f; /* 2^-23 */ }
+
+enum { ST_EMPTY = 0, ST_ALIVE = 1, ST_WRECK = 2 };
+enum { RNG_ROUTE = 1, RNG_LCF1 = 2, RNG_LCF2 = 3, RNG_SPAWN = 4, RNG_PERM = 16 };
+
+/* state field indices: [COPO_STATE_FIELDS][E][N] 32-bit words */
+enum {
+    S_X = 0, S_Y, S_TH, S_V, S_STEER, S_THROTTLE, S_YAWRATE, S_PROG, S_LAT, S_LCF, S_EPREW, S_ROUTE /* route | seg<<16 */,
+    S_STATUS /* status | timer<<8 */, S_AGE, S_AID, S_SPAWNCNT
+};
+/* env words: [E][4] int32 = {t_env, episode, next_aid, started} */
+
+typedef struct oracle_sim {
+    copo_sim_cfg cfg;
+    float* route_segs;
+    float* route_meta;
+    int32_t* spawn_tab;
+    float* spawn_s;
+    float* ray_cs;
+    float* st;      /* [16][E][N] */
+    int32_t* env;   /* [E][4] */
+    uint64_t* seeds;
+    double lcf_mean, lcf_std, force_lcf;
+} oracle_sim;
+
+static float* FP(oracle_sim* s, int f, int e) { return s->st + ((size_t)f * s->cfg.num_envs + e) * s->cfg.num_agents; }
+static int32_t* IP(oracle_sim* s, int f, int e) { return (int32_t*)FP(s, f, e); }
+
+static void* dup_mem(const void* p, size_t n) {
+    void* q = malloc(n ? n : 1);
+    if (n) memcpy(q, p, n);
+    return q;
+}
+
+int oracle_sim_create(const copo_sim_cfg* cfg, oracle_sim** out) {
+    if (!cfg || !out) return COPO_ERR_NULL;
+    if (cfg->num_agents < 1 || cfg->num_agents > COPO_MAX_AGENTS || cfg->num_envs < 1) return COPO_ERR_DIM;
+    if (cfg->num_lasers < 1 || cfg->num_lasers > COPO_MAX_LASERS) return COPO_ERR_DIM;
+    if (cfg->obs_dim != COPO_EGO_DIM + COPO_NAVI_DIM + cfg->num_lasers + (cfg->enable_lcf ? 1 : 0)) return COPO_ERR_DIM;
+    if (cfg->n_spawns < cfg->num_agents || cfg->n_spawns > COPO_MAX_SPAWNS || cfg->nbr_k < 1 || cfg->nbr_k > COPO_MAX_AGENTS) return COPO_ERR_CONFIG;
+    oracle_sim* s = (oracle_sim*)calloc(1, sizeof(oracle_sim));
+    s->cfg = *cfg;
+    size_t E = cfg->num_envs, N = cfg->num_agents;
+    s->route_segs = dup_mem(cfg->route_segs, sizeof(float) * cfg->n_routes * (COPO_MAX_SEGS + 1) * COPO_SEG_STRIDE);
+    s->route_meta = dup_mem(cfg->route_meta, sizeof(float) * cfg->n_routes * 4);
+    s->spawn_tab = dup_mem(cfg->spawn_tab, sizeof(int32_t) * cfg->n_spawns * 4);
+    s->spawn_s = dup_mem(cfg->spawn_s, sizeof(float) * cfg->n_spawns);
+    s->ray_cs = dup_mem(cfg->ray_cs, sizeof(float) * cfg->num_lasers * 2);
+    s->st = (float*)calloc(COPO_STATE_FIELDS * E * N, 4);
+    s->env = (int32_t*)calloc(E * 4, 4);
+    s->seeds = (uint64_t*)calloc(E, 8);
+    s->lcf_mean = cfg->lcf_mean;
+    s->lcf_std = cfg->lcf_std;
+    s->force_lcf = -100.0;
+    *out = s;
+    return COPO_OK;
+}
+
+int oracle_sim_destroy(oracle_sim* s) {
+    if (!s) return COPO_ERR_NULL;
+    free(s->route_segs); free(s->route_meta); free(s->spawn_tab); free(s->spawn_s); free(s->ray_cs);
+    free(s->st); free(s->env); free(s->seeds); free(s);
+    return COPO_OK;
+}
+
+int oracle_sim_set_lcf_dist(oracle_sim* s, double mean, double std) { s->lcf_mean = mean; s->lcf_std = std; return COPO_OK; }
+int oracle_sim_set_force_lcf(oracle_sim* s, double v) { s->force_lcf = v; return COPO_OK; }
+
+int oracle_sim_get_state(oracle_sim* s, float* slot_state, int32_t* env_state) {
+    size_t E = s->cfg.num_envs, N = s->cfg.num_agents;
+    memcpy(slot_state, s->st, COPO_STATE_FIELDS * E * N * 4);
+    memcpy(env_state, s->env, E * 16);
+    return COPO_OK;
+}
+int oracle_sim_set_state(oracle_sim* s, const float* slot_state, const int32_t* env_state) {
+    size_t E = s->cfg.num_envs, N = s->cfg.num_agents;
+    memcpy(s->st, slot_state, COPO_STATE_FIELDS * E * N * 4);
+    memcpy(s->env, env_state, E * 16);
+    return COPO_OK;
+}
+int oracle_sim_set_seeds(oracle_sim* s, const uint64_t* seeds) { memcpy(s->seeds, seeds, 8 * (size_t)s->cfg.num_envs); return COPO_OK; }
+
+static const float* SEG(oracle_sim* s, int route, int k) {
+    return s->route_segs + ((size_t)route * (COPO_MAX_SEGS + 1) + k) * COPO_SEG_STRIDE;
+}
+
+/* spawn a fresh agent into slot n of env e at spawn point sp */
+static void spawn_agent(oracle_sim* s, int e, int n, int sp) {
+    const copo_sim_cfg* c = &s->cfg;
+    int32_t* env = s->env + e * 4;
+    uint64_t seed = s->seeds[e];
+    uint32_t cnt = (uint32_t)IP(s, S_SPAWNCNT, e)[n];
+    uint32_t epi = (uint32_t)env[1];
+    uint32_t h = o_hash(seed, (uint32_t)n, cnt, epi, RNG_ROUTE);
+    int route = s->spawn_tab[sp * 4 + 0] + (int)(h % (uint32_t)s->spawn_tab[sp * 4 + 1]);
+    const float* g = SEG(s, route, 0);
+    float s0 = s->spawn_s[sp];
+    FP(s, S_X, e)[n] = g[0] + g[2] * s0;
+    FP(s, S_Y, e)[n] = g[1] + g[3] * s0;
+    FP(s, S_TH, e)[n] = g[7];
+    FP(s, S_V, e)[n] = 0.0f;
+    FP(s, S_STEER, e)[n] = 0.0f;
+    FP(s, S_THROTTLE, e)[n] = 0.0f;
+    FP(s, S_YAWRATE, e)[n] = 0.0f;
+    FP(s, S_PROG, e)[n] = s0;
+    FP(s, S_LAT, e)[n] = 0.0f;
+    FP(s, S_EPREW, e)[n] = 0.0f;
+    IP(s, S_ROUTE, e)[n] = route;
+    IP(s, S_STATUS, e)[n] = ST_ALIVE;
+    IP(s, S_AGE, e)[n] = 0;
+    IP(s, S_AID, e)[n] = env[2];
+    env[2] += 1;
+    float lcf = 0.0f;
+    if (c->enable_lcf) {
+        float u1 = o_uniform(o_hash(seed, (uint32_t)n, cnt, epi, RNG_LCF1));
+        float u2 = o_uniform(o_hash(seed, (uint32_t)n, cnt, epi, RNG_LCF2));
+        float sn, cs;
+        o_sincosf(TWO_PI_F * u2 - PI_F, &sn, &cs);
+        float z = sqrtf(-2.0f * o_logf(u1)) * cs;
+        float mean = (s->force_lcf != -100.0) ? (float)s->force_lcf : (float)s->lcf_mean;
+        lcf = o_clip(mean + (float)s->lcf_std * z, -1.0f, 1.0f);
+    }
+    FP(s, S_LCF, e)[n] = lcf;
+    IP(s, S_SPAWNCNT, e)[n] = (int32_t)(cnt + 1);
+}
+
+static void reset_env(oracle_sim* s, int e) {
+    const copo_sim_cfg* c = &s->cfg;
+    int N = c->num_agents, P = c->n_spawns;
+    int32_t* env = s->env + e * 4;
+    env[0] = 0;
+    env[2] = 0;
+    int perm[COPO_MAX_SPAWNS];
+    for (int i = 0; i < P; ++i) perm[i] = i;
+    for (int i = 0; i < N; ++i) { /* partial Fisher-Yates: first N entries */
+        uint32_t h = o_hash(s->seeds[e], (uint32_t)i, (uint32_t)env[1], 0u, RNG_PERM);
+        int j = i + (int)(h % (uint32_t)(P - i));
+        int t = perm[i]; perm[i] = perm[j]; perm[j] = t;
+    }
+    for (int n = 0; n < N; ++n) spawn_agent(s, e, n, perm[n]);
+}
+
+/* projection of (x,y) on route segment k: returns local arclength, lateral offset (left +), route heading */
+static void project_seg(const float* g, float x, float y, float* sl, float* lat, float* thr) {
+    float dx = x - g[0], dy = y - g[1];
+    float kap = g[5];
+    if (kap == 0.0f) {
+        *sl = dx * g[2] + dy * g[3];
+        *lat = dy * g[2] - dx * g[3];
+        *thr = g[7];
+    } else {
+        float sg = kap > 0.0f ? 1.0f : -1.0f;
+        float R = 1.0f / fabsf(kap);
+        /* centre = p0 + sg*R*n0, n0 = (-sin0, cos0); u0 = -sg*n0 */
+        float cx = g[0] - sg * R * g[3], cy = g[1] + sg * R * g[2];
+        float ex = x - cx, ey = y - cy;
+        float ux = sg * g[3], uy = -sg * g[2];
+        float rho = sqrtf(ex * ex + ey * ey);
+        float dotp = ux * ex + uy * ey;
+        float crs = ux * ey - uy * ex;
+        float ang = o_atan2f(sg * crs, dotp);
+        *sl = ang * R;
+        *lat = sg * (R - rho);
+        *thr = o_wrap_pi(g[7] + kap * (*sl));
+    }
+}
+
+typedef struct step_tmp {
+    uint8_t acted[COPO_MAX_AGENTS], newly[COPO_MAX_AGENTS], fl[COPO_MAX_AGENTS];
+    float rew[COPO_MAX_AGENTS], acc[COPO_MAX_AGENTS], lcf_row[COPO_MAX_AGENTS];
+    int32_t aid_row[COPO_MAX_AGENTS];
+    float cs[COPO_MAX_AGENTS], sn[COPO_MAX_AGENTS];
+} step_tmp;
+
+/* SAT overlap of two identical-size OBBs */
+static int obb_overlap(float xi, float yi, float ci, float si, float xj, float yj, float cj, float sj, float hl, float hw) {
+    float dx = xj - xi, dy = yj - yi;
+    float cc = fabsf(ci * cj + si * sj), ss = fabsf(ci * sj - si * cj);
+    /* axes of i */
+    if (fabsf(dx * ci + dy * si) > hl + hl * cc + hw * ss) return 0;
+    if (fabsf(dy * ci - dx * si) > hw + hl * ss + hw * cc) return 0;
+    /* axes of j */
+    if (fabsf(dx * cj + dy * sj) > hl + hl * cc + hw * ss) return 0;
+    if (fabsf(dy * cj - dx * sj) > hw + hl * ss + hw * cc) return 0;
+    return 1;
+}
+
+static void write_obs(oracle_sim* s, int e, const copo_step_out* out, const uint8_t* present) {
+    const copo_sim_cfg* c = &s->cfg;
+    int N = c->num_agents, O = c->obs_dim, L = c->num_lasers;
+    float hl = c->veh_half_len, hw = c->veh_half_wid;
+    float circ = sqrtf(hl * hl + hw * hw);
+    float cs[COPO_MAX_AGENTS], sn[COPO_MAX_AGENTS];
+    uint8_t solid[COPO_MAX_AGENTS];
+    for (int j = 0; j < N; ++j) {
+        int st = IP(s, S_STATUS, e)[j] & 0xff;
+        solid[j] = (st == ST_ALIVE || st == ST_WRECK);
+        o_sincosf(FP(s, S_TH, e)[j], &sn[j], &cs[j]);
+    }
+    for (int i = 0; i < N; ++i) {
+        float* o = out->obs + ((size_t)e * N + i) * O;
+        if (!present[i]) {
+            for (int k = 0; k < O; ++k) o[k] = 0.0f;
+            continue;
+        }
+        float x = FP(s, S_X, e)[i], y = FP(s, S_Y, e)[i], th = FP(s, S_TH, e)[i];
+        int rw = IP(s, S_ROUTE, e)[i];
+        int route = rw & 0xffff, seg = rw >> 16;
+        const float* meta = s->route_meta + route * 4;
+        int nseg = (int)meta[3];
+        const float* g = SEG(s, route, seg);
+        float sl, lat, thr;
+        project_seg(g, x, y, &sl, &lat, &thr);
+        float psi = o_wrap_pi(th - thr);
+        float W = meta[1] + meta[2];
+        /* ego block */
+        o[0] = o_clip((meta[1] - lat) / W, 0.0f, 1.0f);
+        o[1] = o_clip((lat + meta[2]) / W, 0.0f, 1.0f);
+        o[2] = o_clip(0.5f + psi / PI_F, 0.0f, 1.0f);
+        o[3] = o_clip(FP(s, S_V, e)[i] / c->max_speed, 0.0f, 1.0f);
+        o[4] = o_clip(0.5f + 0.5f * FP(s, S_STEER, e)[i], 0.0f, 1.0f);
+        o[5] = o_clip(0.5f + 0.5f * FP(s, S_STEER, e)[i], 0.0f, 1.0f);   /* last action[0] == applied steering */
+        o[6] = o_clip(0.5f + 0.5f * FP(s, S_THROTTLE, e)[i], 0.0f, 1.0f);
+        o[7] = o_clip(0.5f + 0.5f * FP(s, S_YAWRATE, e)[i], 0.0f, 1.0f);
+        o[8] = o_clip(0.5f + 0.5f * lat / c->lane_width, 0.0f, 1.0f);
+        /* navigation block: checkpoints at the end of the current and of the next segment */
+        for (int j = 0; j < 2; ++j) {
+            int kk = seg + j;
+            if (kk > nseg - 1) kk = nseg - 1;
+            const float* gk = SEG(s, route, kk);
+            const float* gn = SEG(s, route, kk + 1);
+            float rx = gn[0] - x, ry = gn[1] - y;
+            float fx = rx * cs[i] + ry * sn[i], fy = ry * cs[i] - rx * sn[i];
+            float* q = o + COPO_EGO_DIM + 5 * j;
+            q[0] = o_clip(0.5f + fx * 0.01f, 0.0f, 1.0f);
+            q[1] = o_clip(0.5f + fy * 0.01f, 0.0f, 1.0f);
+            q[2] = o_clip(0.5f + gk[5] * 5.0f, 0.0f, 1.0f);
+            q[3] = o_clip(gk[4] * 0.01f, 0.0f, 1.0f);
+            q[4] = (j == 0) ? o_clip(FP(s, S_PROG, e)[i] / meta[0], 0.0f, 1.0f) : ((kk == nseg - 1) ? 1.0f : 0.0f);
+        }
+        /* LiDAR */
+        float* lid = o + COPO_EGO_DIM + COPO_NAVI_DIM;
+        float range = c->lidar_range;
+        for (int k = 0; k < L; ++k) {
+            float dxr = cs[i] * s->ray_cs[2 * k] - sn[i] * s->ray_cs[2 * k + 1];
+            float dyr = sn[i] * s->ray_cs[2 * k] + cs[i] * s->ray_cs[2 * k + 1];
+            float best = range;
+            for (int j = 0; j < N; ++j) {
+                if (j == i || !solid[j]) continue;
+                float rx = FP(s, S_X, e)[j] - x, ry = FP(s, S_Y, e)[j] - y;
+                float lim = range + circ;
+                if (rx * rx + ry * ry > lim * lim) continue;
+                float along = dxr * rx + dyr * ry;
+                float perp = dxr * ry - dyr * rx;
+                if (along < -circ || fabsf(perp) > circ) continue;
+                /* slab test in j's frame */
+                float ox = -(rx * cs[j] + ry * sn[j]), oy = -(ry * cs[j] - rx * sn[j]);
+                float ddx = dxr * cs[j] + dyr * sn[j], ddy = dyr * cs[j] - dxr * sn[j];
+                float tlo = -1e30f, thi = 1e30f;
+                int miss = 0;
+                if (fabsf(ddx) < 1e-9f) {
+                    if (fabsf(ox) > hl) miss = 1;
+                } else {
+                    float t1 = (-hl - ox) / ddx, t2 = (hl - ox) / ddx;
+                    float a = t1 < t2 ? t1 : t2, b = t1 < t2 ? t2 : t1;
+                    if (a > tlo) tlo = a;
+                    if (b < thi) thi = b;
+                }
+                if (fabsf(ddy) < 1e-9f) {
+                    if (fabsf(oy) > hw) miss = 1;
+                } else {
+                    float t1 = (-hw - oy) / ddy, t2 = (hw - oy) / ddy;
+                    float a = t1 < t2 ? t1 : t2, b = t1 < t2 ? t2 : t1;
+                    if (a > tlo) tlo = a;
+                    if (b < thi) thi = b;
+                }
+                if (miss || tlo > thi || thi < 0.0f) continue;
+                float t = tlo > 0.0f ? tlo : 0.0f;
+                if (t < best) best = t;
+            }
+            lid[k] = best / range;
+        }
+        if (c->enable_lcf) o[O - 1] = (FP(s, S_LCF, e)[i] + 1.0f) * 0.5f;
+    }
+}
+
+/* neighbour lists + reward reductions for one env on an explicit present set (fp64 distances) */
+static void neighbours_env(const float* px, const float* py, const uint8_t* present, const float* rew, int N, int K,
+                           float radius, float mf, int32_t* nbr_idx, int32_t* nbr_cnt, int32_t* mf_cnt, float* nbr_dist,
+                           float* nei_rew, float* glob_rew) {
+    double gsum = 0.0;
+    int gcnt = 0;
+    for (int i = 0; i < N; ++i)
+        if (present[i] && rew) { gsum += (double)rew[i]; gcnt++; }
+    if (glob_rew) *glob_rew = gcnt ? (float)(gsum / (double)gcnt) : 0.0f;
+    for (int i = 0; i < N; ++i) {
+        int ids[COPO_MAX_AGENTS];
+        double ds[COPO_MAX_AGENTS];
+        int cnt = 0;
+        if (present[i]) {
+            for (int j = 0; j < N; ++j) {
+                if (j == i || !present[j]) continue;
+                double dx = (double)px[i] - (double)px[j], dy = (double)py[i] - (double)py[j];
+                double d = sqrt(dx * dx + dy * dy);
+                if (d < (double)radius) {
+                    /* stable insertion sort by distance: ties keep ascending slot order (python sorted) */
+                    int p = cnt;
+                    while (p > 0 && ds[p - 1] > d) { ds[p] = ds[p - 1]; ids[p] = ids[p - 1]; --p; }
+                    ds[p] = d; ids[p] = j; cnt++;
+                }
+            }
+        }
+        if (nbr_cnt) nbr_cnt[i] = cnt;
+        int m = 0;
+        for (int k = 0; k < cnt; ++k)
+            if (ds[k] <= (double)mf) m++; else break;
+        if (mf_cnt) mf_cnt[i] = m;
+        for (int k = 0; k < K; ++k) {
+            if (nbr_idx) nbr_idx[i * K + k] = k < cnt ? ids[k] : -1;
+            if (nbr_dist) nbr_dist[i * K + k] = k < cnt ? (float)ds[k] : 0.0f;
+        }
+        if (nei_rew) {
+            double sum = 0.0;
+            for (int k = 0; k < cnt; ++k) sum += (double)rew[ids[k]];
+            nei_rew[i] = cnt ? (float)(sum / (double)cnt) : 0.0f;
+        }
+    }
+}
+
+int oracle_neighbours(const float* pos, const uint8_t* present, const float* rew, int32_t E, int32_t N, int32_t K,
+                      float radius, float mf_distance, int32_t* nbr_idx, int32_t* nbr_cnt, int32_t* mf_cnt,
+                      float* nbr_dist, float* nei_rew, float* glob_rew) {
+    if (N > COPO_MAX_AGENTS || K > COPO_MAX_AGENTS) return COPO_ERR_DIM;
+    for (int e = 0; e < E; ++e) {
+        float px[COPO_MAX_AGENTS], py[COPO_MAX_AGENTS];
+        for (int i = 0; i < N; ++i) { px[i] = pos[((size_t)e * N + i) * 2]; py[i] = pos[((size_t)e * N + i) * 2 + 1]; }
+        neighbours_env(px, py, present + (size_t)e * N, rew ? rew + (size_t)e * N : NULL, N, K, radius, mf_distance,
+                       nbr_idx ? nbr_idx + (size_t)e * N * K : NULL, nbr_cnt ? nbr_cnt + (size_t)e * N : NULL,
+                       mf_cnt ? mf_cnt + (size_t)e * N : NULL, nbr_dist ? nbr_dist + (size_t)e * N * K : NULL,
+                       (rew && nei_rew) ? nei_rew + (size_t)e * N : NULL, (rew && glob_rew) ? glob_rew + e : NULL);
+    }
+    return COPO_OK;
+}
+
+static void emit_outputs(oracle_sim* s, int e, const copo_step_out* out, step_tmp* t, const uint8_t* present) {
+    const copo_sim_cfg* c = &s->cfg;
+    int N = c->num_agents, K = c->nbr_k;
+    size_t b = (size_t)e * N;
+    /* neighbour lists on post-step positions of the present set; rewards of new spawns are 0 */
+    neighbours_env(FP(s, S_X, e), FP(s, S_Y, e), present, t->rew, N, K, c->neighbours_distance, c->mf_distance,
+                   out->nbr_idx ? out->nbr_idx + b * K : NULL, out->nbr_cnt ? out->nbr_cnt + b : NULL,
+                   out->mf_cnt ? out->mf_cnt + b : NULL, out->nbr_dist ? out->nbr_dist + b * K : NULL,
+                   out->nei_rew ? out->nei_rew + b : NULL, out->glob_rew ? out->glob_rew + e : NULL);
+    for (int n = 0; n < N; ++n) {
+        if (out->rew) out->rew[b + n] = t->rew[n];
+        if (out->flags) out->flags[b + n] = t->fl[n];
+        if (out->lcf) out->lcf[b + n] = t->lcf_row[n];
+        if (out->agent_id) out->agent_id[b + n] = t->aid_row[n];
+    }
+}
+
+int oracle_sim_reset(oracle_sim* s, const uint64_t* seeds, const copo_step_out* out) {
+    const copo_sim_cfg* c = &s->cfg;
+    int E = c->num_envs, N = c->num_agents;
+    memcpy(s->seeds, seeds, 8 * (size_t)E);
+    memset(s->st, 0, COPO_STATE_FIELDS * (size_t)E * N * 4);
+    for (int e = 0; e < E; ++e) {
+        int32_t* env = s->env + e * 4;
+        env[0] = env[1] = env[2] = 0;
+        env[3] = 1;
+        reset_env(s, e);
+        step_tmp t;
+        memset(&t, 0, sizeof(t));
+        uint8_t present[COPO_MAX_AGENTS];
+        for (int n = 0; n < N; ++n) {
+            present[n] = 1;
+            t.fl[n] = COPO_F_SPAWNED;
+            t.lcf_row[n] = FP(s, S_LCF, e)[n];
+            t.aid_row[n] = IP(s, S_AID, e)[n];
+        }
+        emit_outputs(s, e, out, &t, present);
+        if (out->info) memset(out->info + (size_t)e * N * COPO_INFO_DIM, 0, sizeof(float) * N * COPO_INFO_DIM);
+        if (out->obs) write_obs(s, e, out, present);
+    }
+    return COPO_OK;
+}
+
+int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
+    const copo_sim_cfg* c = &s->cfg;
+    int E = c->num_envs, N = c->num_agents;
+    float hl = c->veh_half_len, hw = c->veh_half_wid;
+    float h = c->dt / (float)c->substeps;
+    for (int e = 0; e < E; ++e) {
+        int32_t* env = s->env + e * 4;
+        if (!env[3]) return COPO_ERR_STATE;
+        step_tmp t;
+        memset(&t, 0, sizeof(t));
+        float *X = FP(s, S_X, e), *Y = FP(s, S_Y, e), *TH = FP(s, S_TH, e), *V = FP(s, S_V, e);
+        int32_t* STA = IP(s, S_STATUS, e);
+        /* 0. timers of non-alive slots */
+        for (int n = 0; n < N; ++n) {
+            int st = STA[n] & 0xff, tm = STA[n] >> 8;
+            t.acted[n] = (st == ST_ALIVE);
+            if (st == ST_WRECK) {
+                tm -= 1;
+                if (tm <= 0) STA[n] = ST_EMPTY | (c->respawn_cooldown << 8); else STA[n] = ST_WRECK | (tm << 8);
+            } else if (st == ST_EMPTY && tm > 0) {
+                STA[n] = ST_EMPTY | ((tm - 1) << 8);
+            }
+        }
+        /* 1. bicycle dynamics for acting slots */
+        for (int n = 0; n < N; ++n) {
+            t.lcf_row[n] = FP(s, S_LCF, e)[n];
+            t.aid_row[n] = t.acted[n] ? IP(s, S_AID, e)[n] : -1;
+            if (!t.acted[n]) continue;
+            float a0 = act[((size_t)e * N + n) * 2], a1 = act[((size_t)e * N + n) * 2 + 1];
+            if (!(a0 == a0)) a0 = 0.0f;
+            if (!(a1 == a1)) a1 = 0.0f;
+            a0 = o_clip(a0, -1.0f, 1.0f);
+            a1 = o_clip(a1, -1.0f, 1.0f);
+            float delta = a0 * c->max_steer;
+            float sd, cd;
+            o_sincosf(delta, &sd, &cd);
+            float tan_over_L = (sd / cd) / c->wheelbase;
+            float x = X[n], y = Y[n], th = TH[n], v = V[n];
+            float v0 = v, th0 = th;
+            for (int k = 0; k < c->substeps; ++k) {
+                float a = a1 >= 0.0f ? a1 * c->acc_max * (1.0f - v / c->max_speed) : a1 * c->brake_max;
+                a = a - c->drag * v;
+                v = v + a * h;
+                if (v < 0.0f) v = 0.0f;
+                float sn, cs;
+                o_sincosf(th, &sn, &cs);
+                x = x + v * cs * h;
+                y = y + v * sn * h;
+                th = o_wrap_pi(th + v * tan_over_L * h);
+            }
+            X[n] = x; Y[n] = y; TH[n] = th; V[n] = v;
+            FP(s, S_STEER, e)[n] = a0;
+            FP(s, S_THROTTLE, e)[n] = a1;
+            FP(s, S_YAWRATE, e)[n] = o_wrap_pi(th - th0) / c->dt;
+            t.acc[n] = (v - v0) / c->dt;
+            IP(s, S_AGE, e)[n] += 1;
+        }
+        /* 2. heading unit vectors of all slots */
+        for (int n = 0; n < N; ++n) o_sincosf(TH[n], &t.sn[n], &t.cs[n]);
+        int ending = (env[0] + 1 >= c->horizon);
+        /* 3-5. collision, route projection, termination, reward */
+        uint8_t term[COPO_MAX_AGENTS];
+        uint8_t crash_any[COPO_MAX_AGENTS];
+        for (int n = 0; n < N; ++n) {
+            crash_any[n] = 0;
+            if (!t.acted[n]) continue;
+            for (int j = 0; j < N; ++j) {
+                int stj = STA[j] & 0xff;
+                if (j == n || stj == ST_EMPTY) continue;
+                if (obb_overlap(X[n], Y[n], t.cs[n], t.sn[n], X[j], Y[j], t.cs[j], t.sn[j], hl, hw)) crash_any[n] = 1;
+            }
+        }
+        for (int n = 0; n < N; ++n) {
+            term[n] = 0;
+            t.rew[n] = 0.0f;
+            t.fl[n] = 0;
+            if (!t.acted[n]) continue;
+            int rw = IP(s, S_ROUTE, e)[n];
+            int route = rw & 0xffff, seg = rw >> 16;
+            const float* meta = s->route_meta + route * 4;
+            int nseg = (int)meta[3];
+            float sl, lat, thr;
+            const float* g = SEG(s, route, seg);
+            project_seg(g, X[n], Y[n], &sl, &lat, &thr);
+            for (int it = 0; it < 2; ++it) {
+                if (sl > g[4] && seg < nseg - 1) {
+                    seg += 1;
+                    g = SEG(s, route, seg);
+                    project_seg(g, X[n], Y[n], &sl, &lat, &thr);
+                }
+            }
+            if (sl < 0.0f && seg > 0) {
+                seg -= 1;
+                g = SEG(s, route, seg);
+                project_seg(g, X[n], Y[n], &sl, &lat, &thr);
+            }
+            float prog = g[6] + sl;
+            float prev = FP(s, S_PROG, e)[n];
+            IP(s, S_ROUTE, e)[n] = route | (seg << 16);
+            FP(s, S_PROG, e)[n] = prog;
+            FP(s, S_LAT, e)[n] = lat;
+            int arrive = (prog >= meta[0] - c->arrive_margin) && (lat <= meta[1]) && (lat >= -meta[2]);
+            int out_of_road = (lat > meta[1]) || (lat < -meta[2]) || (prog < -5.0f);
+            int crash = crash_any[n];
+            float lf = o_clip(1.0f - 2.0f * fabsf(lat) / c->lane_width, 0.0f, 1.0f);
+            float r = c->driving_reward * (prog - prev) * lf + c->speed_reward * (V[n] / c->max_speed);
+            uint8_t fl = COPO_F_ACTED;
+            if (arrive) { r = c->success_reward; fl |= COPO_F_ARRIVE; }
+            else if (out_of_road) { r = -c->out_penalty; }
+            else if (crash) { r = -c->crash_penalty; }
+            if (out_of_road) fl |= COPO_F_OUT;
+            if (crash) fl |= COPO_F_CRASH;
+            int done = arrive || out_of_road || crash;
+            if (!done && ending) { fl |= COPO_F_MAXSTEP; done = 1; }
+            if (done) fl |= COPO_F_DONE;
+            if (ending) fl |= COPO_F_ENV_RESET;
+            term[n] = (uint8_t)done;
+            t.rew[n] = r;
+            t.fl[n] = fl;
+            FP(s, S_EPREW, e)[n] += r;
+            if (out->info) {
+                float* q = out->info + ((size_t)e * N + n) * COPO_INFO_DIM;
+                q[COPO_I_VELOCITY] = V[n] * 3.6f;
+                q[COPO_I_STEERING] = FP(s, S_STEER, e)[n];
+                q[COPO_I_ACCELERATION] = t.acc[n];
+                q[COPO_I_STEP_REWARD] = r;
+                q[COPO_I_COST] = (crash || out_of_road) ? 1.0f : 0.0f;
+                q[COPO_I_EPISODE_LENGTH] = (float)IP(s, S_AGE, e)[n];
+                q[COPO_I_EPISODE_REWARD] = FP(s, S_EPREW, e)[n];
+                q[COPO_I_ROUTE_COMPLETION] = o_clip(prog / meta[0], 0.0f, 1.0f);
+            }
+        }
+        if (out->info)
+            for (int n = 0; n < N; ++n)
+                if (!t.acted[n]) memset(out->info + ((size_t)e * N + n) * COPO_INFO_DIM, 0, sizeof(float) * COPO_INFO_DIM);
+        /* 6. status update of terminated slots */
+        for (int n = 0; n < N; ++n) {
+            if (!term[n]) continue;
+            if ((t.fl[n] & COPO_F_CRASH) && !(t.fl[n] & (COPO_F_ARRIVE | COPO_F_OUT)) && c->delay_done > 0)
+                STA[n] = ST_WRECK | (c->delay_done << 8);
+            else
+                STA[n] = ST_EMPTY | (c->respawn_cooldown << 8);
+        }
+        uint8_t present[COPO_MAX_AGENTS];
+        for (int n = 0; n < N; ++n) present[n] = t.acted[n];
+        /* 7. respawn (serial in slot order) */
+        if (!ending) {
+            for (int n = 0; n < N; ++n) {
+                if (t.acted[n] || STA[n] != ST_EMPTY) continue; /* EMPTY with timer 0 only */
+                uint32_t cnt = (uint32_t)IP(s, S_SPAWNCNT, e)[n];
+                for (uint32_t a = 0; a < 3; ++a) {
+                    uint32_t hh = o_hash(s->seeds[e], (uint32_t)n, cnt, (uint32_t)env[0], RNG_SPAWN + a);
+                    int sp = (int)(hh % (uint32_t)c->n_spawns);
+                    int route0 = s->spawn_tab[sp * 4];
+                    const float* g = SEG(s, route0, 0);
+                    float sx = g[0] + g[2] * s->spawn_s[sp], sy = g[1] + g[3] * s->spawn_s[sp];
+                    int blocked = 0;
+                    for (int j = 0; j < N; ++j) {
+                        if ((STA[j] & 0xff) == ST_EMPTY) continue;
+                        float dx = X[j] - sx, dy = Y[j] - sy;
+                        if (dx * dx + dy * dy < c->spawn_clearance * c->spawn_clearance) blocked = 1;
+                    }
+                    if (!blocked) {
+                        spawn_agent(s, e, n, sp);
+                        present[n] = 1;
+                        t.newly[n] = 1;
+                        t.fl[n] = COPO_F_SPAWNED;
+                        t.lcf_row[n] = FP(s, S_LCF, e)[n];
+                        break;
+                    }
+                }
+            }
+        }
+        /* 8. neighbour lists, reward reductions, row outputs (on the pre-reset scene) */
+        emit_outputs(s, e, out, &t, present);
+        env[0] += 1;
+        /* 9-10. horizon: reset the env, then observations of whoever occupies the slots now */
+        if (ending) {
+            env[1] += 1;
+            reset_env(s, e);
+            for (int n = 0; n < N; ++n) {
+                present[n] = 1;
+                if (out->flags) out->flags[(size_t)e * N + n] |= COPO_F_SPAWNED | COPO_F_ENV_RESET;
+                if (out->lcf && !t.acted[n]) out->lcf[(size_t)e * N + n] = FP(s, S_LCF, e)[n];
+            }
+        }
+        if (out->obs) write_obs(s, e, out, present);
+    }
+    return COPO_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * learn-side ops
+ * ---------------------------------------------------------------------------------------------- */
+
+/* GAE, restating the dtype path of the reference: delta in fp32 when the trajectory is truncated
+ * (last_r is a np.float32 value -> all-fp32 numpy expression), in fp64 when it ended with done
+ * (last_r = python 0.0 -> np.array([0.0]) is fp64); the discounted cumsum (scipy lfilter) always fp64. */
+int oracle_gae3(const float* rew, const float* val, const uint8_t* flags, int32_t T, int32_t M, int32_t heads,
+                const double* gamma, double lam, float* adv, float* tgt) {
+    for (int hd = 0; hd < heads; ++hd) {
+        const float* R = rew + (size_t)hd * T * M;
+        const float* Vv = val + (size_t)hd * T * M;
+        float* A = adv + (size_t)hd * T * M;
+        float* G = tgt + (size_t)hd * T * M;
+        double g64 = gamma[hd];     /* python float gamma */
+        float g32 = (float)g64;
+        double c = g64 * lam;
+        for (int m = 0; m < M; ++m) {
+            double acc = 0.0;
+            int seg_done = 0, in_seg = 0;
+            float vnext32 = 0.0f;
+            double vnext64 = 0.0;
+            for (int t = T - 1; t >= 0; --t) {
+                size_t ix = (size_t)t * M + m;
+                uint8_t f = flags[ix];
+                if (!(f & COPO_F_ACTED)) { A[ix] = 0.0f; G[ix] = 0.0f; in_seg = 0; continue; }
+                if (!in_seg || (f & COPO_F_DONE)) { /* last row of a trajectory */
+                    seg_done = (f & COPO_F_DONE) != 0;
+                    acc = 0.0;
+                    vnext32 = Vv[ix];
+                    vnext64 = 0.0;
+                    in_seg = 1;
+                }
+                double delta;
+                if (seg_done) delta = ((double)R[ix] + g64 * vnext64) - (double)Vv[ix];
+                else { float d32 = (R[ix] + g32 * vnext32) - Vv[ix]; delta = (double)d32; }
+                acc = delta + c * acc;
+                A[ix] = (float)acc;
+                G[ix] = (float)(acc + (double)Vv[ix]);
+                vnext32 = Vv[ix];
+                vnext64 = (double)Vv[ix];
+            }
+        }
+    }
+    return COPO_OK;
+}
+
+int oracle_cc_fuse_mf(const float* obs, const float* act, const uint8_t* flags, const int32_t* nbr_idx,
+                      const int32_t* cnt, int32_t R, int32_t N, int32_t O, int32_t A, int32_t K,
+                      int32_t counterfactual, float* cc) {
+    int C = 2 * O + (counterfactual ? A : 0);
+    for (int r = 0; r < R; ++r)
+        for (int n = 0; n < N; ++n) {
+            size_t row = (size_t)r * N + n;
+            float* o = cc + row * C;
+            for (int k = 0; k < C; ++k) o[k] = 0.0f;
+            if (!(flags[row] & COPO_F_ACTED)) continue;
+            for (int k = 0; k < O; ++k) o[k] = obs[row * O + k];
+            int m = cnt[row] < K ? cnt[row] : K, got = 0;
+            /* np.mean over a list of fp32 rows: pairwise-free for short lists -> sequential fp32 add, then / count */
+            for (int q = 0; q < m; ++q) {
+                int j = nbr_idx[row * K + q];
+                size_t jr = (size_t)r * N + j;
+                if (j < 0 || !(flags[jr] & COPO_F_ACTED)) continue;
+                for (int k = 0; k < O; ++k) o[O + k] += obs[jr * O + k];
+                if (counterfactual)
+                    for (int k = 0; k < A; ++k) o[2 * O + k] += act[jr * A + k];
+                got++;
+            }
+            if (got > 0) {
+                for (int k = 0; k < O; ++k) o[O + k] = o[O + k] / (float)got;
+                if (counterfactual)
+                    for (int k = 0; k < A; ++k) o[2 * O + k] = o[2 * O + k] / (float)got;
+            }
+        }
+    return COPO_OK;
+}
+
+int oracle_cc_fuse_concat(const float* obs, const float* act, const uint8_t* flags, const int32_t* nbr_idx,
+                          const int32_t* cnt, int32_t R, int32_t N, int32_t O, int32_t A, int32_t K,
+                          int32_t num_neighbours, int32_t counterfactual, float* cc) {
+    int other = O + (counterfactual ? A : 0);
+    int C = O + num_neighbours * other;
+    for (int r = 0; r < R; ++r)
+        for (int n = 0; n < N; ++n) {
+            size_t row = (size_t)r * N + n;
+            float* o = cc + row * C;
+            for (int k = 0; k < C; ++k) o[k] = 0.0f;
+            if (!(flags[row] & COPO_F_ACTED)) continue;
+            for (int k = 0; k < O; ++k) o[k] = obs[row * O + k];
+            int m = cnt[row] < K ? cnt[row] : K;
+            if (m > num_neighbours) m = num_neighbours;
+            for (int q = 0; q < m; ++q) { /* slot = rank in the neighbour list, not compacted */
+                int j = nbr_idx[row * K + q];
+                size_t jr = (size_t)r * N + j;
+                if (j < 0 || !(flags[jr] & COPO_F_ACTED)) continue;
+                float* d = o + O + q * other;
+                for (int k = 0; k < O; ++k) d[k] = obs[jr * O + k];
+                if (counterfactual)
+                    for (int k = 0; k < A; ++k) d[O + k] = act[jr * A + k];
+            }
+        }
+    return COPO_OK;
+}
+
+/* coordinated advantage + standardisation; stats = {n, sum, sumsq} of A_c then of glob_adv (doubles) */
+int oracle_lcf_mix_partial(const float* adv, const float* nei_adv, const float* glob_adv, const float* lcf,
+                           const uint8_t* valid, int64_t B, float* mixed, double* stats) {
+    for (int k = 0; k < 6; ++k) stats[k] = 0.0;
+    for (int64_t i = 0; i < B; ++i) {
+        if (valid && !valid[i]) { mixed[i] = 0.0f; continue; }
+        float ang = lcf[i] * HALF_PI_F; /* fp32 step_lcf * np.pi / 2 stays fp32 (python scalars are weak) */
+        float sn, cs;
+        o_sincosf(ang, &sn, &cs);
+        float m = cs * adv[i] + sn * nei_adv[i];
+        mixed[i] = m;
+        stats[0] += 1.0; stats[1] += (double)m; stats[2] += (double)m * (double)m;
+        stats[3] += 1.0; stats[4] += (double)glob_adv[i]; stats[5] += (double)glob_adv[i] * (double)glob_adv[i];
+    }
+    return COPO_OK;
+}
+
+int oracle_lcf_mix_apply(const float* mixed, const float* glob_adv, const uint8_t* valid, int64_t B,
+                         const double* stats, float* norm_adv, float* glob_std) {
+    double m0 = stats[1] / stats[0], v0 = stats[2] / stats[0] - m0 * m0;
+    double m1 = stats[4] / stats[3], v1 = stats[5] / stats[3] - m1 * m1;
+    double s0 = sqrt(v0 > 0 ? v0 : 0), s1 = sqrt(v1 > 0 ? v1 : 0);
+    if (s0 < 1e-4) s0 = 1e-4;
+    if (s1 < 1e-4) s1 = 1e-4;
+    for (int64_t i = 0; i < B; ++i) {
+        if (valid && !valid[i]) { norm_adv[i] = 0.0f; glob_std[i] = 0.0f; continue; }
+        norm_adv[i] = (float)(((double)mixed[i] - m0) / s0);
+        glob_std[i] = (float)(((double)glob_adv[i] - m1) / s1);
+    }
+    return COPO_OK;
+}
+
+int oracle_version(void) { return COPO_ABI_VERSION; }

@@ -1,0 +1,185 @@
+"""ctypes loader of the CPU oracle (oracle/copo_oracle.c).  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "_build", "libcopo_oracle.so")
+
+STATE_FIELDS, INFO_DIM = 16, 8
+LCF_STATS = 6
+
+
+def build(force=False):
+    src = os.path.join(ORACLE_DIR, "copo_oracle.c")
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-B", "_build/libcopo_oracle.so"], stdout=subprocess.DEVNULL)
+    return LIB
+
+
+class SimCfg(C.Structure):
+    _fields_ = [
+        ("num_envs", C.c_int32), ("num_agents", C.c_int32), ("num_lasers", C.c_int32), ("obs_dim", C.c_int32),
+        ("nbr_k", C.c_int32), ("enable_lcf", C.c_int32), ("horizon", C.c_int32), ("delay_done", C.c_int32),
+        ("respawn_cooldown", C.c_int32), ("substeps", C.c_int32),
+        ("lidar_range", C.c_float), ("neighbours_distance", C.c_float), ("mf_distance", C.c_float),
+        ("dt", C.c_float), ("veh_half_len", C.c_float), ("veh_half_wid", C.c_float), ("wheelbase", C.c_float),
+        ("max_steer", C.c_float), ("max_speed", C.c_float), ("acc_max", C.c_float), ("brake_max", C.c_float),
+        ("drag", C.c_float), ("spawn_clearance", C.c_float),
+        ("driving_reward", C.c_float), ("speed_reward", C.c_float), ("success_reward", C.c_float),
+        ("crash_penalty", C.c_float), ("out_penalty", C.c_float), ("arrive_margin", C.c_float),
+        ("lane_width", C.c_float),
+        ("lcf_mean", C.c_double), ("lcf_std", C.c_double),
+        ("n_routes", C.c_int32), ("n_spawns", C.c_int32),
+        ("route_segs", C.c_void_p), ("route_meta", C.c_void_p), ("spawn_tab", C.c_void_p), ("spawn_s", C.c_void_p),
+        ("ray_cs", C.c_void_p),
+    ]
+
+
+OUT_FIELDS = ("obs", "rew", "nei_rew", "glob_rew", "flags", "nbr_idx", "nbr_cnt", "mf_cnt", "nbr_dist", "lcf", "info",
+              "agent_id")
+
+
+class StepOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in OUT_FIELDS]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.oracle_version.restype = C.c_int
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class OracleSim:
+    """Scalar CPU simulator with the same interface shape as copo_amd.sim.VecSim (numpy arrays)."""
+
+    def __init__(self, cfg):
+        from copo_amd.sim import fill_cfg_struct
+        self.cfg = cfg
+        struct, self._keep = fill_cfg_struct(cfg, SimCfg)
+        self.E, self.N, self.O, self.K = struct.num_envs, struct.num_agents, struct.obs_dim, struct.nbr_k
+        h = C.c_void_p()
+        rc = lib().oracle_sim_create(C.byref(struct), C.byref(h))
+        assert rc == 0, rc
+        self._h = h
+        E, N, O, K = self.E, self.N, self.O, self.K
+        self.out = dict(
+            obs=np.zeros((E, N, O), np.float32), rew=np.zeros((E, N), np.float32), nei_rew=np.zeros((E, N), np.float32),
+            glob_rew=np.zeros(E, np.float32), flags=np.zeros((E, N), np.uint8), nbr_idx=np.zeros((E, N, K), np.int32),
+            nbr_cnt=np.zeros((E, N), np.int32), mf_cnt=np.zeros((E, N), np.int32),
+            nbr_dist=np.zeros((E, N, K), np.float32), lcf=np.zeros((E, N), np.float32),
+            info=np.zeros((E, N, INFO_DIM), np.float32), agent_id=np.zeros((E, N), np.int32))
+        self._so = StepOut()
+        for k in OUT_FIELDS:
+            setattr(self._so, k, self.out[k].ctypes.data)
+
+    def reset(self, seeds=None):
+        if seeds is None:
+            seeds = np.arange(self.E, dtype=np.uint64) + np.uint64(self.cfg.start_seed)
+        seeds = np.ascontiguousarray(seeds, np.uint64)
+        rc = lib().oracle_sim_reset(self._h, _p(seeds), C.byref(self._so))
+        assert rc == 0, rc
+        return self.out
+
+    def step(self, act):
+        act = np.ascontiguousarray(act, np.float32)
+        assert act.size == self.E * self.N * 2
+        rc = lib().oracle_sim_step(self._h, _p(act), C.byref(self._so))
+        assert rc == 0, rc
+        return self.out
+
+    def set_lcf_dist(self, mean, std):
+        lib().oracle_sim_set_lcf_dist(self._h, C.c_double(mean), C.c_double(std))
+
+    def set_force_lcf(self, v):
+        lib().oracle_sim_set_force_lcf(self._h, C.c_double(v))
+
+    def get_state(self):
+        st = np.zeros((STATE_FIELDS, self.E, self.N), np.float32)
+        env = np.zeros((self.E, 4), np.int32)
+        lib().oracle_sim_get_state(self._h, _p(st), _p(env))
+        return st, env
+
+    def set_state(self, st, env, seeds=None):
+        st = np.ascontiguousarray(st, np.float32)
+        env = np.ascontiguousarray(env, np.int32)
+        lib().oracle_sim_set_state(self._h, _p(st), _p(env))
+        if seeds is not None:
+            lib().oracle_sim_set_seeds(self._h, _p(np.ascontiguousarray(seeds, np.uint64)))
+
+    def close(self):
+        if self._h:
+            lib().oracle_sim_destroy(self._h)
+            self._h = None
+
+
+def neighbours(pos, present, rew, K, radius, mf):
+    pos = np.ascontiguousarray(pos, np.float32)
+    E, N = pos.shape[:2]
+    present = np.ascontiguousarray(present, np.uint8)
+    rew_c = None if rew is None else np.ascontiguousarray(rew, np.float32)
+    o = dict(nbr_idx=np.zeros((E, N, K), np.int32), nbr_cnt=np.zeros((E, N), np.int32), mf_cnt=np.zeros((E, N), np.int32),
+             nbr_dist=np.zeros((E, N, K), np.float32), nei_rew=np.zeros((E, N), np.float32), glob_rew=np.zeros(E, np.float32))
+    rc = lib().oracle_neighbours(_p(pos), _p(present), _p(rew_c), E, N, K, C.c_float(radius), C.c_float(mf),
+                                 _p(o["nbr_idx"]), _p(o["nbr_cnt"]), _p(o["mf_cnt"]), _p(o["nbr_dist"]),
+                                 _p(o["nei_rew"]), _p(o["glob_rew"]))
+    assert rc == 0, rc
+    return o
+
+
+def gae3(rew, val, flags, gamma, lam):
+    rew = np.ascontiguousarray(rew, np.float32)
+    val = np.ascontiguousarray(val, np.float32)
+    flags = np.ascontiguousarray(flags, np.uint8)
+    H, T, M = rew.shape
+    adv, tgt = np.zeros_like(rew), np.zeros_like(rew)
+    g = (C.c_double * H)(*[float(x) for x in gamma])
+    rc = lib().oracle_gae3(_p(rew), _p(val), _p(flags), T, M, H, g, C.c_double(lam), _p(adv), _p(tgt))
+    assert rc == 0, rc
+    return adv, tgt
+
+
+def cc_fuse(mode, obs, act, flags, nbr_idx, cnt, counterfactual=True, num_neighbours=4):
+    obs = np.ascontiguousarray(obs, np.float32)
+    act = np.ascontiguousarray(act, np.float32)
+    flags = np.ascontiguousarray(flags, np.uint8)
+    nbr_idx = np.ascontiguousarray(nbr_idx, np.int32)
+    cnt = np.ascontiguousarray(cnt, np.int32)
+    R, N, O = obs.shape
+    A, K = act.shape[-1], nbr_idx.shape[-1]
+    cf = 1 if counterfactual else 0
+    if mode == "mf":
+        Cd = 2 * O + (A if cf else 0)
+        cc = np.zeros((R, N, Cd), np.float32)
+        rc = lib().oracle_cc_fuse_mf(_p(obs), _p(act), _p(flags), _p(nbr_idx), _p(cnt), R, N, O, A, K, cf, _p(cc))
+    else:
+        Cd = O + num_neighbours * (O + (A if cf else 0))
+        cc = np.zeros((R, N, Cd), np.float32)
+        rc = lib().oracle_cc_fuse_concat(_p(obs), _p(act), _p(flags), _p(nbr_idx), _p(cnt), R, N, O, A, K,
+                                         num_neighbours, cf, _p(cc))
+    assert rc == 0, rc
+    return cc
+
+
+def lcf_mix(adv, nei, glob, lcf, valid=None):
+    adv, nei, glob, lcf = (np.ascontiguousarray(a, np.float32) for a in (adv, nei, glob, lcf))
+    B = adv.size
+    v = None if valid is None else np.ascontiguousarray(valid, np.uint8)
+    mixed = np.zeros(B, np.float32)
+    stats = np.zeros(6, np.float64)
+    lib().oracle_lcf_mix_partial(_p(adv), _p(nei), _p(glob), _p(lcf), _p(v), C.c_int64(B), _p(mixed), _p(stats))
+    norm, gstd = np.zeros(B, np.float32), np.zeros(B, np.float32)
+    lib().oracle_lcf_mix_apply(_p(mixed), _p(glob), _p(v), C.c_int64(B), _p(stats), _p(norm), _p(gstd))
+    return mixed, stats, norm, gstd

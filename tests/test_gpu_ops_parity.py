@@ -1,0 +1,215 @@
+"""HIP learn-side ops and the stateless neighbour op vs the CPU oracle and the golden vectors (C ABI calls)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def hip_neighbours(pos, present, rew, K, radius, mf):
+    import torch
+    from copo_amd import _capi
+    E, N = pos.shape[:2]
+    d = dict(pos=_t(pos.astype(np.float32)), present=_t(present.astype(np.uint8)),
+             rew=None if rew is None else _t(rew.astype(np.float32)))
+    o = dict(nbr_idx=torch.zeros(E, N, K, dtype=torch.int32).cuda(), nbr_cnt=torch.zeros(E, N, dtype=torch.int32).cuda(),
+             mf_cnt=torch.zeros(E, N, dtype=torch.int32).cuda(), nbr_dist=torch.zeros(E, N, K).cuda(),
+             nei_rew=torch.zeros(E, N).cuda(), glob_rew=torch.zeros(E).cuda())
+    _capi.check(_capi.lib.copo_neighbours_f32(
+        _capi.ptr(d["pos"]), _capi.ptr(d["present"]), _capi.ptr(d["rew"]), E, N, K, radius, mf, _capi.ptr(o["nbr_idx"]),
+        _capi.ptr(o["nbr_cnt"]), _capi.ptr(o["mf_cnt"]), _capi.ptr(o["nbr_dist"]), _capi.ptr(o["nei_rew"]),
+        _capi.ptr(o["glob_rew"]), _capi.current_stream()))
+    return {k: v.cpu().numpy() for k, v in o.items()}
+
+
+def test_neighbours_golden(golden_dir):
+    """Bit-exact neighbour indexing against the reference's CCEnv/LCFEnv (env_wrappers.py:125-158,313-326)."""
+    g = np.load(os.path.join(golden_dir, "lcfenv_step.npz"))
+    for c in range(int(g["n_cases"])):
+        pos, present, rew = g["c%d_in_pos" % c], g["c%d_in_present" % c], g["c%d_in_rew" % c]
+        N = len(pos)
+        if N < 2:
+            continue
+        K = N - 1
+        o = hip_neighbours(pos[None], present[None], rew[None], K, float(g["c%d_in_radius" % c]), 10.0)
+        assert np.array_equal(o["nbr_cnt"][0], g["c%d_out_nbr_cnt" % c]), c
+        assert np.array_equal(o["nbr_idx"][0], g["c%d_out_nbr_idx" % c]), c
+        np.testing.assert_allclose(o["nbr_dist"][0], g["c%d_out_nbr_dist" % c], rtol=1e-6, atol=0)
+        pres = present.astype(bool)
+        np.testing.assert_allclose(o["nei_rew"][0][pres], g["c%d_out_nei_r" % c][pres], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(o["glob_rew"][0], g["c%d_out_glob_r" % c][pres][0], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("E,N,K", [(64, 40, 8), (3, 64, 63), (17, 10, 9), (5, 2, 1)])
+def test_neighbours_vs_oracle(E, N, K):
+    import oracle_lib as ol
+    rng = np.random.RandomState(E * 100 + N)
+    pos = np.round(rng.uniform(-60, 60, (E, N, 2)) * 4) / 4          # quarter-metre grid -> many exact ties
+    present = rng.uniform(size=(E, N)) > 0.2
+    rew = rng.normal(0, 1, (E, N)).astype(np.float32)
+    a = hip_neighbours(pos, present, rew, K, 40.0, 10.0)
+    b = ol.neighbours(pos, present, rew, K, 40.0, 10.0)
+    for k in a:
+        assert np.array_equal(a[k].view(np.uint32) if a[k].dtype == np.float32 else a[k],
+                              b[k].view(np.uint32) if b[k].dtype == np.float32 else b[k]), k
+
+
+def hip_gae3(rew, val, flags, gamma, lam):
+    import torch
+    from copo_amd import _capi
+    H, T, M = rew.shape
+    r, v, f = _t(rew.astype(np.float32)), _t(val.astype(np.float32)), _t(flags.astype(np.uint8))
+    adv, tgt = torch.zeros_like(r), torch.zeros_like(r)
+    g = (C.c_double * H)(*[float(x) for x in gamma])
+    _capi.check(_capi.lib.copo_gae3_f32(r.data_ptr(), v.data_ptr(), f.data_ptr(), T, M, H, g, float(lam),
+                                        adv.data_ptr(), tgt.data_ptr(), _capi.current_stream()))
+    return adv.cpu().numpy(), tgt.cpu().numpy()
+
+
+def test_gae3_golden(golden_dir):
+    """compute_advantages / compute_nei_advantage / compute_global_advantage (algo_copo.py:189-204)."""
+    g = np.load(os.path.join(golden_dir, "gae.npz"))
+    lens, done_last = g["lens"], g["done_last"]
+    Kt, TM = len(lens), int(lens.max())
+    rew = np.zeros((3, TM, Kt), np.float32)
+    val = np.zeros_like(rew)
+    flags = np.zeros((TM, Kt), np.uint8)
+    for k, T in enumerate(lens):   # right-align each trajectory so that it ends at the window edge or with done
+        flags[:T, k] = 1
+        if done_last[k]:
+            flags[T - 1, k] |= 2
+        for h, (rk, vk) in enumerate([("r", "v"), ("nr", "nv"), ("gr", "gv")]):
+            rew[h, :T, k], val[h, :T, k] = g[rk][k, :T], g[vk][k, :T]
+    adv, tgt = hip_gae3(rew, val, flags, [0.99, 0.99, 1.0], 0.95)
+    for h, (ak, tk) in enumerate([("adv", "tgt"), ("nadv", "ntgt"), ("gadv", "gtgt")]):
+        for k, T in enumerate(lens):
+            np.testing.assert_allclose(adv[h, :T, k], g[ak][k, :T], rtol=1e-6, atol=1e-6)
+            np.testing.assert_allclose(tgt[h, :T, k], g[tk][k, :T], rtol=1e-6, atol=1e-6)
+            assert np.array_equal(adv[h, :T, k], g[ak][k, :T]), (h, k)   # in fact bit-exact
+
+
+@pytest.mark.parametrize("T,M", [(8, 10240), (200, 517), (1, 64), (33, 1)])
+def test_gae3_vs_oracle(T, M):
+    import oracle_lib as ol
+    rng = np.random.RandomState(T + M)
+    rew = rng.normal(0, 1, (3, T, M)).astype(np.float32)
+    val = rng.normal(0, 4, (3, T, M)).astype(np.float32)
+    acted = rng.uniform(size=(T, M)) > 0.1
+    done = acted & (rng.uniform(size=(T, M)) < 0.05)
+    flags = (acted * 1 + done * 2).astype(np.uint8)
+    a = hip_gae3(rew, val, flags, [0.99, 0.99, 1.0], 0.95)
+    b = ol.gae3(rew, val, flags, [0.99, 0.99, 1.0], 0.95)
+    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+    assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+
+
+def hip_cc_fuse(mode, obs, act, flags, nbr_idx, cnt, cf=True, nn=4):
+    import torch
+    from copo_amd import _capi
+    R, N, O = obs.shape
+    A, K = act.shape[-1], nbr_idx.shape[-1]
+    o, a, f, ni, c = _t(obs.astype(np.float32)), _t(act.astype(np.float32)), _t(flags.astype(np.uint8)), \
+        _t(nbr_idx.astype(np.int32)), _t(cnt.astype(np.int32))
+    if mode == "mf":
+        cc = torch.full((R, N, 2 * O + (A if cf else 0)), 7.0).cuda()
+        _capi.check(_capi.lib.copo_cc_fuse_mf_f32(o.data_ptr(), a.data_ptr(), f.data_ptr(), ni.data_ptr(), c.data_ptr(),
+                                                  R, N, O, A, K, int(cf), cc.data_ptr(), _capi.current_stream()))
+    else:
+        cc = torch.full((R, N, O + nn * (O + (A if cf else 0))), 7.0).cuda()
+        _capi.check(_capi.lib.copo_cc_fuse_concat_f32(o.data_ptr(), a.data_ptr(), f.data_ptr(), ni.data_ptr(),
+                                                      c.data_ptr(), R, N, O, A, K, nn, int(cf), cc.data_ptr(),
+                                                      _capi.current_stream()))
+    return cc.cpu().numpy()
+
+
+@pytest.mark.parametrize("policy,fuse", [("copo", "mf"), ("copo", "concat"), ("ccppo", "mf"), ("ccppo", "concat")])
+def test_cc_fuse_golden(golden_dir, policy, fuse):
+    """mean_field_ccppo_process / concat_ccppo_process (algo_ccppo.py:225-311) incl. absent-neighbour slots."""
+    g = np.load(os.path.join(golden_dir, "postprocess_%s_%s.npz" % (policy, fuse)))
+    obs, act, acted = g["in_obs"], g["in_act"], g["in_acted"]
+    flags = acted.astype(np.uint8)
+    nbr_idx, nbr_cnt, nbr_dist = g["in_nbr_idx"], g["in_nbr_cnt"], g["in_nbr_dist"]
+    if fuse == "mf":
+        K = nbr_idx.shape[-1]
+        cnt = ((nbr_dist <= 10.0) & (np.arange(K)[None, None] < nbr_cnt[..., None])).sum(-1)
+    else:
+        cnt = nbr_cnt
+    cc = hip_cc_fuse(fuse, obs, act, flags, nbr_idx, cnt)
+    ref = g["out_cc_obs"]
+    assert cc.shape == ref.shape
+    np.testing.assert_allclose(cc[acted], ref[acted], rtol=1e-6, atol=1e-7)
+    assert np.all(cc[~acted] == 0)
+
+
+@pytest.mark.parametrize("mode,cf", [("mf", True), ("mf", False), ("concat", True), ("concat", False)])
+def test_cc_fuse_vs_oracle(mode, cf):
+    import oracle_lib as ol
+    rng = np.random.RandomState(11)
+    R, N, O, A, K = 37, 40, 92, 2, 8
+    obs = rng.uniform(-1, 1, (R, N, O)).astype(np.float32)
+    act = rng.normal(0, 1, (R, N, A)).astype(np.float32)
+    flags = (rng.uniform(size=(R, N)) > 0.15).astype(np.uint8)
+    cnt = rng.randint(0, 12, (R, N))
+    nbr_idx = np.full((R, N, K), -1, np.int32)
+    for r in range(R):
+        for n in range(N):
+            m = min(cnt[r, n], K)
+            nbr_idx[r, n, :m] = rng.choice([j for j in range(N) if j != n], m, replace=False)
+    a = hip_cc_fuse(mode, obs, act, flags, nbr_idx, cnt, cf)
+    b = ol.cc_fuse(mode, obs, act, flags, nbr_idx, cnt, cf)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def hip_lcf_mix(adv, nei, glob, lcf, valid=None):
+    import torch
+    from copo_amd import _capi
+    B = adv.size
+    a, n, g, l = (_t(x.astype(np.float32)) for x in (adv, nei, glob, lcf))
+    v = None if valid is None else _t(valid.astype(np.uint8))
+    mixed, norm, gstd = torch.zeros(B).cuda(), torch.zeros(B).cuda(), torch.zeros(B).cuda()
+    stats = torch.zeros(_capi.LCF_STATS_DOUBLES, dtype=torch.float64).cuda()
+    s = _capi.current_stream()
+    _capi.check(_capi.lib.copo_lcf_mix_partial_f32(a.data_ptr(), n.data_ptr(), g.data_ptr(), l.data_ptr(), _capi.ptr(v),
+                                                   B, mixed.data_ptr(), stats.data_ptr(), s))
+    _capi.check(_capi.lib.copo_lcf_mix_apply_f32(mixed.data_ptr(), g.data_ptr(), _capi.ptr(v), B, stats.data_ptr(),
+                                                 norm.data_ptr(), gstd.data_ptr(), s))
+    return mixed.cpu().numpy(), stats[:6].cpu().numpy(), norm.cpu().numpy(), gstd.cpu().numpy()
+
+
+def test_lcf_mix_golden(golden_dir):
+    """CoPOTrainer.training_step coordinated-advantage block (algo_copo.py:539-551)."""
+    g = np.load(os.path.join(golden_dir, "training_step.npz"))
+    mixed, stats, norm, gstd = hip_lcf_mix(g["in_advantages"], g["in_nei_advantage"], g["in_global_advantages"],
+                                           g["in_step_lcf"])
+    np.testing.assert_allclose(mixed, g["out_raw_normalized_advantages"], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(norm, g["out_normalized_advantages"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(gstd, g["out_global_advantages"], rtol=1e-5, atol=1e-5)
+    mean = stats[1] / stats[0]
+    std = np.sqrt(stats[2] / stats[0] - mean * mean)
+    np.testing.assert_allclose([mean, std], g["out_raw_mean_std"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,masked", [(81920, True), (1200, False), (1, False), (2_000_003, True)])
+def test_lcf_mix_vs_oracle(B, masked):
+    import oracle_lib as ol
+    rng = np.random.RandomState(B % 1000)
+    adv, nei, glob = (rng.normal(0, 2, B).astype(np.float32) for _ in range(3))
+    lcf = np.clip(rng.normal(0.2, 0.4, B), -1, 1).astype(np.float32)
+    valid = (rng.uniform(size=B) > 0.1) if masked else None
+    if masked:
+        valid[0] = True
+    a = hip_lcf_mix(adv, nei, glob, lcf, valid)
+    b = ol.lcf_mix(adv, nei, glob, lcf, valid)
+    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))      # mixed advantage: bit-exact
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-12)                       # fp64 sums, different order
+    np.testing.assert_allclose(a[2], b[2], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(a[3], b[3], rtol=1e-6, atol=1e-6)
+    a2 = hip_lcf_mix(adv, nei, glob, lcf, valid)
+    assert all(np.array_equal(x, y) for x, y in zip(a, a2))                  # run-to-run deterministic

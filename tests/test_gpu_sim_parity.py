@@ -1,0 +1,133 @@
+"""HIP simulator vs the CPU oracle, through the C ABI: raw-bit equality of every output over rollouts."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+OUT_KEYS = ("obs", "rew", "nei_rew", "glob_rew", "flags", "nbr_idx", "nbr_cnt", "mf_cnt", "nbr_dist", "lcf", "info",
+            "agent_id")
+
+
+def _bits(a):
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.float32:
+        return a.view(np.uint32)
+    return a
+
+
+def _compare(tag, g, o):
+    for k in OUT_KEYS:
+        gv = g[k].cpu().numpy()
+        ov = o[k]
+        if not np.array_equal(_bits(gv), _bits(ov)):
+            bad = np.argwhere(_bits(gv) != _bits(ov))
+            i = tuple(bad[0])
+            raise AssertionError("%s: output %r differs at %s (%d mismatches): hip=%r oracle=%r" %
+                                 (tag, k, i, len(bad), gv[i], ov[i]))
+
+
+def _actions(rng, E, N, t):
+    steer = rng.normal(0, 0.12, (E, N))
+    thr = rng.uniform(-0.2, 1.0, (E, N))
+    a = np.stack([steer, thr], -1).astype(np.float32)
+    if t % 7 == 0:
+        a[0, 0] = [np.nan, 5.0]     # NaN guard + clipping
+    return a
+
+
+@pytest.mark.parametrize("map_name,N,E,lasers,steps,block", [
+    ("intersection", 40, 6, 72, 260, 1024),
+    ("roundabout", 40, 3, 72, 200, 256),
+    ("parkinglot", 10, 5, 240, 150, 512),
+    ("tollgate", 40, 2, 72, 120, 64),
+    ("intersection", 4, 3, 72, 150, 128),
+])
+def test_rollout_bit_exact(map_name, N, E, lasers, steps, block):
+    import torch
+    import oracle_lib as ol
+    from copo_amd.sim import SimConfig, VecSim
+    cfg = SimConfig(map=map_name, num_envs=E, num_agents=N, num_lasers=lasers, horizon=90, nbr_k=min(8, max(1, N - 1)),
+                    delay_done=5)
+    g, o = VecSim(cfg), ol.OracleSim(cfg)
+    g.set_block(block)
+    seeds = np.arange(E, dtype=np.uint64) * np.uint64(7919) + np.uint64(5000)
+    _compare("reset", g.reset(seeds), o.reset(seeds))
+    rng = np.random.RandomState(3)
+    for t in range(steps):
+        if t == 40:
+            g.set_lcf_dist(0.4, 0.3)
+            o.set_lcf_dist(0.4, 0.3)
+        a = _actions(rng, E, N, t)
+        go = g.step(torch.from_numpy(a).cuda())
+        oo = o.step(a)
+        _compare("%s step %d" % (map_name, t), go, oo)
+    gs, ge = g.get_state()
+    os_, oe = o.get_state()
+    assert np.array_equal(gs.cpu().numpy().view(np.uint32), os_.view(np.uint32))
+    assert np.array_equal(ge.cpu().numpy()[:, :3], oe[:, :3])
+    f = oo["flags"]
+    g.close()
+    o.close()
+
+
+def test_full_k_and_ccenv_mode():
+    """K = N-1 (complete lists) and enable_lcf=False (CCEnv-only obs of 91)."""
+    import torch
+    import oracle_lib as ol
+    from copo_amd.sim import SimConfig, VecSim
+    cfg = SimConfig(map="intersection", num_envs=2, num_agents=30, nbr_k=29, enable_lcf=False, horizon=60,
+                    neighbours_distance=10.0)
+    assert cfg.obs_dim == 91
+    g, o = VecSim(cfg), ol.OracleSim(cfg)
+    _compare("reset", g.reset(), o.reset())
+    rng = np.random.RandomState(5)
+    for t in range(100):
+        a = _actions(rng, 2, 30, t + 1)
+        _compare("step %d" % t, g.step(torch.from_numpy(a).cuda()), o.step(a))
+
+
+def test_state_roundtrip_and_determinism():
+    import torch
+    from copo_amd.sim import SimConfig, VecSim
+    cfg = SimConfig(map="roundabout", num_envs=8, num_agents=40, horizon=50)
+    g = VecSim(cfg)
+    g.reset()
+    rng = np.random.RandomState(1)
+    acts = [torch.from_numpy(_actions(rng, 8, 40, t + 1)).cuda() for t in range(80)]
+    for a in acts[:30]:
+        g.step(a)
+    st, env = g.get_state()
+    ref = []
+    for a in acts[30:]:
+        out = g.step(a)
+        ref.append({k: out[k].clone() for k in ("obs", "rew", "flags", "nbr_idx")})
+    g.set_state(st, env)
+    for a, r in zip(acts[30:], ref):
+        out = g.step(a)
+        for k, v in r.items():
+            assert torch.equal(out[k], v), k
+
+
+def test_error_codes():
+    import ctypes as C
+    import torch
+    from copo_amd import _capi
+    from copo_amd.sim import SimConfig, VecSim, fill_cfg_struct
+    cfg = SimConfig(num_envs=2, num_agents=8)
+    struct, keep = fill_cfg_struct(cfg, _capi.SimCfg)
+    h = C.c_void_p()
+    assert _capi.lib.copo_sim_create(None, 0, C.byref(h)) == -1
+    struct.num_agents = 65
+    assert _capi.lib.copo_sim_create(C.byref(struct), 0, C.byref(h)) == -2
+    assert b"num_agents" in _capi.lib.copo_last_error()
+    struct.num_agents = 8
+    struct.obs_dim = 50
+    assert _capi.lib.copo_sim_create(C.byref(struct), 0, C.byref(h)) == -2
+    g = VecSim(cfg)
+    with pytest.raises(_capi.CopoError) as ei:
+        g.step(torch.zeros(2, 8, 2, device="cuda"))
+    assert ei.value.code == -4          # step before reset
+    with pytest.raises(_capi.CopoError):
+        g.set_lcf_dist(2.0, 0.1)
+    with pytest.raises(_capi.CopoError):
+        g.set_lcf_dist(0.0, 0.0)
