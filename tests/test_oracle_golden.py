@@ -1,0 +1,142 @@
+"""CPU: pin the oracle (oracle/copo_oracle.c) against golden vectors produced by the reference's own code."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+
+def test_oracle_builds_and_versions():
+    assert ol.lib().oracle_version() == 1
+
+
+def test_neighbours_and_rewards_vs_reference(golden_dir):
+    """CCEnv._update_distance_map/_find_in_range + LCFEnv.step reward block (env_wrappers.py:125-158,313-326)."""
+    g = np.load(os.path.join(golden_dir, "lcfenv_step.npz"))
+    for c in range(int(g["n_cases"])):
+        pos, present, rew = g["c%d_in_pos" % c], g["c%d_in_present" % c].astype(bool), g["c%d_in_rew" % c]
+        N = len(pos)
+        K = max(1, N - 1)
+        o = ol.neighbours(pos[None], present[None], rew[None], K, float(g["c%d_in_radius" % c]), 10.0)
+        Kg = g["c%d_out_nbr_idx" % c].shape[1]
+        assert np.array_equal(o["nbr_cnt"][0], g["c%d_out_nbr_cnt" % c]), c
+        assert np.array_equal(o["nbr_idx"][0][:, :Kg], g["c%d_out_nbr_idx" % c]), c
+        np.testing.assert_allclose(o["nbr_dist"][0][:, :Kg], g["c%d_out_nbr_dist" % c], rtol=1e-6)
+        np.testing.assert_allclose(o["nei_rew"][0][present], g["c%d_out_nei_r" % c][present], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(o["glob_rew"][0], g["c%d_out_glob_r" % c][present][0], rtol=1e-6, atol=1e-7)
+        # mf prefix == number of listed neighbours with d <= 10 (algo_ccppo.py:283)
+        d, cnt = g["c%d_out_nbr_dist" % c], g["c%d_out_nbr_cnt" % c]
+        mf = ((d <= 10.0) & (np.arange(Kg)[None] < cnt[:, None])).sum(1)
+        assert np.array_equal(o["mf_cnt"][0], mf), c
+
+
+def test_known_answers_from_survey(golden_dir):
+    pos = np.array([[[0, 0], [3, 4], [30, 0], [100, 0]]], np.float32)
+    o = ol.neighbours(pos, np.ones((1, 4), bool), np.array([[1, 2, 3, 4]], np.float32), 3, 40.0, 10.0)
+    assert o["nbr_idx"][0].tolist() == [[1, 2, -1], [0, 2, -1], [1, 0, -1], [-1, -1, -1]]
+    np.testing.assert_allclose(o["nbr_dist"][0, 1, :2], [5.0, 27.294688], rtol=1e-6)
+    assert o["nei_rew"][0].tolist() == [2.5, 2.0, 1.5, 0.0] and o["glob_rew"][0] == 2.5
+    assert o["mf_cnt"][0].tolist() == [1, 1, 0, 0]
+
+
+def test_coordinated_reward_and_obs_tail(golden_dir):
+    """LCFEnv.step :350-353 and _add_lcf :417-418 -- formulas the build applies on the learner side."""
+    g = np.load(os.path.join(golden_dir, "lcfenv_step.npz"))
+    for c in range(int(g["n_cases"])):
+        pres = g["c%d_in_present" % c].astype(bool)
+        lcf, r, nr = g["c%d_out_lcf" % c][pres], g["c%d_in_rew" % c][pres], g["c%d_out_nei_r" % c][pres]
+        assert np.all(np.abs(lcf) <= 1)
+        np.testing.assert_allclose(np.cos(lcf * np.pi / 2) * r + np.sin(lcf * np.pi / 2) * nr,
+                                   g["c%d_out_coord_r" % c][pres], rtol=1e-12, atol=1e-12)
+        assert np.array_equal(g["c%d_out_obs_last" % c][pres], ((lcf + 1) / 2).astype(np.float32))
+        assert np.all(g["c%d_out_obs_len" % c][pres] == 92) and np.all(g["c%d_out_obs_dtype_is_f32" % c][pres])
+
+
+def _gae_inputs(g):
+    lens, done_last = g["lens"], g["done_last"]
+    Kt, TM = len(lens), int(lens.max())
+    rew = np.zeros((3, TM, Kt), np.float32)
+    val = np.zeros_like(rew)
+    flags = np.zeros((TM, Kt), np.uint8)
+    for k, T in enumerate(lens):
+        flags[:T, k] = 1
+        if done_last[k]:
+            flags[T - 1, k] |= 2
+        for h, (rk, vk) in enumerate([("r", "v"), ("nr", "nv"), ("gr", "gv")]):
+            rew[h, :T, k], val[h, :T, k] = g[rk][k, :T], g[vk][k, :T]
+    return rew, val, flags, lens
+
+
+def test_gae3_vs_reference(golden_dir):
+    """compute_nei_advantage / compute_global_advantage (algo_copo.py:189-204) + compute_advantages shim."""
+    g = np.load(os.path.join(golden_dir, "gae.npz"))
+    rew, val, flags, lens = _gae_inputs(g)
+    adv, tgt = ol.gae3(rew, val, flags, [0.99, 0.99, 1.0], 0.95)
+    for h, (ak, tk) in enumerate([("adv", "tgt"), ("nadv", "ntgt"), ("gadv", "gtgt")]):
+        for k, T in enumerate(lens):
+            assert np.array_equal(adv[h, :T, k], g[ak][k, :T]), (h, k)     # bit-exact incl. the fp32/fp64 dtype path
+            assert np.array_equal(tgt[h, :T, k], g[tk][k, :T]), (h, k)
+            assert np.all(adv[h, T:, k] == 0)
+    a, t = ol.gae3(np.array([[[1.], [0.], [2.]]], np.float32), np.array([[[.1], [.2], [.3]]], np.float32),
+                   np.array([[1], [1], [3]], np.uint8), [0.99], 0.95)
+    np.testing.assert_array_equal(a[0, :, 0], g["ka_nei_adv"])
+    np.testing.assert_array_equal(t[0, :, 0], g["ka_nei_tgt"])
+    a, t = ol.gae3(np.ones((1, 3, 1), np.float32), np.array([[[.5], [.4], [.3]]], np.float32),
+                   np.array([[1], [1], [1]], np.uint8), [1.0], 0.95)
+    np.testing.assert_array_equal(a[0, :, 0], g["ka_glob_adv"])
+    np.testing.assert_array_equal(t[0, :, 0], g["ka_glob_tgt"])
+
+
+def test_gae3_segments_inside_a_column():
+    """Several agents sharing a slot within one fragment: each trajectory bootstraps on its own last value."""
+    rng = np.random.RandomState(0)
+    T = 30
+    r, v = rng.normal(0, 1, T).astype(np.float32), rng.normal(0, 3, T).astype(np.float32)
+    flags = np.ones(T, np.uint8)
+    flags[9] |= 2        # agent A: rows 0..9, done
+    flags[10:13] = 0     # slot empty
+    flags[20] |= 2       # agent B: rows 13..20 done ; agent C rows 21..29 truncated
+    adv, tgt = ol.gae3(r[None, :, None], v[None, :, None], flags[:, None], [0.99], 0.95)
+    for lo, hi, done in [(0, 10, True), (13, 21, True), (21, 30, False)]:
+        vv = np.concatenate([v[lo:hi].astype(np.float64), [0.0 if done else float(v[hi - 1])]])
+        delta = r[lo:hi] + 0.99 * vv[1:] - vv[:-1]
+        acc, ref = 0.0, np.zeros(hi - lo)
+        for t in range(hi - lo - 1, -1, -1):
+            acc = delta[t] + 0.99 * 0.95 * acc
+            ref[t] = acc
+        np.testing.assert_allclose(adv[0, lo:hi, 0], ref, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(tgt[0, lo:hi, 0], ref + v[lo:hi], rtol=1e-5, atol=1e-5)
+    assert np.all(adv[0, 10:13, 0] == 0)
+
+
+@pytest.mark.parametrize("policy,fuse", [("copo", "none"), ("copo", "mf"), ("copo", "concat"), ("ccppo", "mf"),
+                                         ("ccppo", "concat")])
+def test_cc_fuse_vs_reference(golden_dir, policy, fuse):
+    """mean_field_ccppo_process / concat_ccppo_process (algo_ccppo.py:225-311)."""
+    g = np.load(os.path.join(golden_dir, "postprocess_%s_%s.npz" % (policy, fuse)))
+    obs, act, acted = g["in_obs"], g["in_act"], g["in_acted"]
+    ref = g["out_cc_obs"]
+    if fuse == "none":
+        assert np.array_equal(ref[acted], obs[acted])
+        return
+    nbr_idx, nbr_cnt, nbr_dist = g["in_nbr_idx"], g["in_nbr_cnt"], g["in_nbr_dist"]
+    K = nbr_idx.shape[-1]
+    cnt = ((nbr_dist <= 10.0) & (np.arange(K)[None, None] < nbr_cnt[..., None])).sum(-1) if fuse == "mf" else nbr_cnt
+    cc = ol.cc_fuse(fuse, obs, act, acted.astype(np.uint8), nbr_idx, cnt)
+    assert cc.shape == ref.shape
+    np.testing.assert_allclose(cc[acted], ref[acted], rtol=1e-6, atol=1e-7)
+    assert np.array_equal(cc[acted], ref[acted])          # same fp32 accumulation order as np.mean over the list
+
+
+def test_lcf_mix_vs_reference(golden_dir):
+    """CoPOTrainer.training_step coordinated advantage + standardized() (algo_copo.py:539-551)."""
+    g = np.load(os.path.join(golden_dir, "training_step.npz"))
+    mixed, stats, norm, gstd = ol.lcf_mix(g["in_advantages"], g["in_nei_advantage"], g["in_global_advantages"],
+                                          g["in_step_lcf"])
+    np.testing.assert_allclose(mixed, g["out_raw_normalized_advantages"], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(norm, g["out_normalized_advantages"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(gstd, g["out_global_advantages"], rtol=1e-5, atol=1e-5)
+    mean = stats[1] / stats[0]
+    np.testing.assert_allclose([mean, np.sqrt(stats[2] / stats[0] - mean ** 2)], g["out_raw_mean_std"], rtol=1e-5)
+    assert abs(norm.mean()) < 1e-6 and abs(norm.std() - 1) < 1e-5
