@@ -32,6 +32,8 @@ struct copo_sim {
     int block;
     bool started;
     double lcf_mean, lcf_std, force_lcf;
+    float lcf_host[2];
+    bool lcf_dirty;
     std::vector<void*> allocs;
 };
 
@@ -92,6 +94,7 @@ extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** o
     s->lcf_mean = cfg->lcf_mean;
     s->lcf_std = cfg->lcf_std;
     s->force_lcf = -100.0;
+    s->lcf_dirty = true;
     s->block = pick_block(cfg->num_envs);
     if (hipSetDevice(device) != hipSuccess) {
         delete s;
@@ -124,6 +127,7 @@ extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** o
     if (rc == COPO_OK && (rc = dev_alloc(COPO_STATE_FIELDS * EN * 4, &d)) == COPO_OK) p.state = (float*)d;
     if (rc == COPO_OK && (rc = dev_alloc((size_t)p.E * 16, &d)) == COPO_OK) p.env = (int32_t*)d;
     if (rc == COPO_OK && (rc = dev_alloc((size_t)p.E * 8, &d)) == COPO_OK) p.seeds = (const uint64_t*)d;
+    if (rc == COPO_OK && (rc = dev_alloc(8, &d)) == COPO_OK) p.lcf_dist = (const float*)d;
     if (rc == COPO_OK)
         rc = upload(s, cfg->route_segs, (size_t)cfg->n_routes * (COPO_MAX_SEGS + 1) * COPO_SEG_STRIDE, &p.route_segs);
     if (rc == COPO_OK) rc = upload(s, cfg->route_meta, (size_t)cfg->n_routes * 4, &p.route_meta);
@@ -147,9 +151,22 @@ extern "C" int copo_sim_destroy(copo_sim* s) {
     return COPO_OK;
 }
 
-static void refresh_lcf(copo_sim* s) {
-    s->p.lcf_mean = (float)((s->force_lcf != -100.0) ? s->force_lcf : s->lcf_mean);
-    s->p.lcf_std = (float)s->lcf_std;
+// Push the LCF distribution to device memory on `st` (kernels read it from there, so launches captured
+// in a hipGraph keep seeing later updates).  Skipped while the stream is capturing.
+static int flush_lcf(copo_sim* s, hipStream_t st) {
+    if (!s->lcf_dirty) return COPO_OK;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return COPO_OK;
+    s->lcf_host[0] = (float)((s->force_lcf != -100.0) ? s->force_lcf : s->lcf_mean);
+    s->lcf_host[1] = (float)s->lcf_std;
+    HIP_TRY(hipMemcpyAsync(const_cast<float*>(s->p.lcf_dist), s->lcf_host, 8, hipMemcpyHostToDevice, st));
+    s->lcf_dirty = false;
+    return COPO_OK;
+}
+
+extern "C" int copo_sim_flush(copo_sim* s, void* stream) {
+    if (!s) return fail(COPO_ERR_NULL, "copo_sim_flush: NULL handle");
+    return flush_lcf(s, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int copo_sim_set_lcf_dist(copo_sim* s, double mean, double std) {
@@ -158,6 +175,7 @@ extern "C" int copo_sim_set_lcf_dist(copo_sim* s, double mean, double std) {
         return fail(COPO_ERR_CONFIG, "set_lcf_dist(mean=%g, std=%g): need -1 <= mean <= 1, std > 0", mean, std);
     s->lcf_mean = mean;
     s->lcf_std = std;
+    s->lcf_dirty = true;
     return COPO_OK;
 }
 
@@ -165,6 +183,7 @@ extern "C" int copo_sim_set_force_lcf(copo_sim* s, double v) {
     if (!s) return fail(COPO_ERR_NULL, "copo_sim_set_force_lcf: NULL handle");
     if (v != -100.0 && (v < -1.0 || v > 1.0)) return fail(COPO_ERR_CONFIG, "force_lcf=%g not in [-1,1] (or -100)", v);
     s->force_lcf = v;
+    s->lcf_dirty = true;
     return COPO_OK;
 }
 
@@ -183,7 +202,8 @@ extern "C" int copo_sim_reset(copo_sim* s, const uint64_t* seeds, const copo_ste
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIP_TRY(hipMemcpyAsync(const_cast<uint64_t*>(s->p.seeds), seeds, (size_t)s->p.E * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(s->p.state, 0, COPO_STATE_FIELDS * (size_t)s->p.E * s->p.N * 4, st));
-    refresh_lcf(s);
+    int rc = flush_lcf(s, st);
+    if (rc != COPO_OK) return rc;
     HIP_TRY(launch_sim_reset(s->p, *out, s->block, st));
     s->started = true;
     return COPO_OK;
@@ -192,7 +212,8 @@ extern "C" int copo_sim_reset(copo_sim* s, const uint64_t* seeds, const copo_ste
 extern "C" int copo_sim_step(copo_sim* s, const float* act, const copo_step_out* out, void* stream) {
     if (!s || !act || !out) return fail(COPO_ERR_NULL, "copo_sim_step: NULL argument");
     if (!s->started) return fail(COPO_ERR_STATE, "copo_sim_step before copo_sim_reset");
-    refresh_lcf(s);
+    int rc = flush_lcf(s, static_cast<hipStream_t>(stream));
+    if (rc != COPO_OK) return rc;
     HIP_TRY(launch_sim_step(s->p, act, *out, s->block, static_cast<hipStream_t>(stream)));
     return COPO_OK;
 }

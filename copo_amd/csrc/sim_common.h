@@ -20,7 +20,6 @@ struct SimParams {
     float lidar_range, neighbours_distance, mf_distance, dt, hl, hw, wheelbase, max_steer, max_speed;
     float acc_max, brake_max, drag, spawn_clearance;
     float driving_reward, speed_reward, success_reward, crash_penalty, out_penalty, arrive_margin, lane_width;
-    float lcf_mean, lcf_std;       // distribution for agents spawned in THIS launch (force_lcf folded into mean)
     float* state;                  // [COPO_STATE_FIELDS][E][N] 32-bit words
     int32_t* env;                  // [E][4] = {t_env, episode, next_aid, started}
     const uint64_t* seeds;         // [E]
@@ -29,6 +28,7 @@ struct SimParams {
     const int32_t* spawn_tab;      // [P][4]
     const float* spawn_s;          // [P]
     const float* ray_cs;           // [num_lasers][2]
+    const float* lcf_dist;         // [2] = {mean (force_lcf folded in), std}: device memory so that captured graphs see updates
 };
 
 using StepOut = copo_step_out;

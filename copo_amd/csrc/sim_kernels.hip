@@ -108,7 +108,7 @@ __device__ __forceinline__ void spawn_slot(const SimParams& p, uint64_t seed, ui
         float sn, cs;
         sincos_det(kTwoPi * u2 - kPi, sn, cs);
         const float z = sqrtf(-2.0f * log_det(u1)) * cs;
-        lcf = clipf(p.lcf_mean + p.lcf_std * z, -1.0f, 1.0f);
+        lcf = clipf(p.lcf_dist[0] + p.lcf_dist[1] * z, -1.0f, 1.0f);
     }
     s.lcf = lcf;
     s.spawncnt = (int32_t)(cnt + 1);

@@ -154,6 +154,10 @@ class VecSim:
     def set_force_lcf(self, v):
         self._capi.check(self._capi.lib.copo_sim_set_force_lcf(self._h, float(v)))
 
+    def flush(self):
+        """Push pending set_lcf_dist/set_force_lcf values to the device (needed before replaying a captured graph)."""
+        self._capi.check(self._capi.lib.copo_sim_flush(self._h, self._stream()))
+
     def set_block(self, threads):
         self._capi.check(self._capi.lib.copo_sim_set_block(self._h, int(threads)))
 

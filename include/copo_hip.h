@@ -139,6 +139,10 @@ int copo_sim_destroy(copo_sim* sim);
 int copo_sim_reset(copo_sim* sim, const uint64_t* seeds, const copo_step_out* out, void* stream);
 /* LCFEnv.set_lcf_dist (env_wrappers.py:420-426): affects agents spawned from now on */
 int copo_sim_set_lcf_dist(copo_sim* sim, double mean, double std);
+/* The LCF distribution lives in device memory (launches captured in a hipGraph keep seeing updates).
+ * set_lcf_dist/set_force_lcf mark it dirty; the next reset/step pushes it on its stream, except while that
+ * stream is capturing -- replay-only callers push explicitly with copo_sim_flush before the replay. */
+int copo_sim_flush(copo_sim* sim, void* stream);
 /* LCFEnv.set_force_lcf (env_wrappers.py:428-430): v == -100 disables */
 int copo_sim_set_force_lcf(copo_sim* sim, double v);
 /* act: [E][N][2] device fp32 (clipped to [-1,1] inside, as RLlib's clip_actions does) */
