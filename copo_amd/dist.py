@@ -1,0 +1,76 @@
+"""Data-parallel plumbing: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on
+ROCm, "gloo" on CPU for tests).  The reference has no collective at all (Ray object store + in-process
+towers, algo_copo.py:519-577); the exchange steps below are the build's own:
+
+  * per SGD minibatch  : one flat-bucket all-reduce of the gradient sums
+  * per iteration      : one all-reduce of the advantage statistics (6 doubles) + row counts
+  * per meta minibatch : one flat bucket [g_new | g_old | dS/dlcf | S | n]  (both gradients BEFORE the dot)
+
+Env shards never talk to each other, so nothing else crosses ranks.
+"""
+import os
+
+import torch
+import torch.distributed as td
+
+
+def env_world():
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def init_from_env(device=None):
+    """Initialise the default process group from torchrun's env vars (no-op for a single process)."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not td.is_initialized():
+        use_cuda = torch.cuda.is_available() and (device is None or str(device).startswith("cuda"))
+        if use_cuda:
+            torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        td.init_process_group(backend="nccl" if use_cuda else "gloo", rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def is_dist():
+    return td.is_available() and td.is_initialized() and td.get_world_size() > 1
+
+
+def world_size():
+    return td.get_world_size() if is_dist() else 1
+
+
+def rank():
+    return td.get_rank() if is_dist() else 0
+
+
+def all_reduce_sum_(t):
+    if is_dist():
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+    return t
+
+
+def all_reduce_max_(t):
+    if is_dist():
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+    return t
+
+
+def all_gather_int(v, device):
+    """Every rank's python int, as a list (one tiny collective per iteration)."""
+    if not is_dist():
+        return [int(v)]
+    t = torch.zeros(world_size(), dtype=torch.int64, device=device)
+    t[rank()] = int(v)
+    td.all_reduce(t, op=td.ReduceOp.SUM)
+    return [int(x) for x in t.tolist()]
+
+
+def broadcast_module_(module, src=0):
+    """Same initial weights on every rank (the reference broadcasts weights from the learner, algo_copo.py:572-577)."""
+    if is_dist():
+        for p in list(module.parameters()) + list(module.buffers()):
+            td.broadcast(p.data, src=src)
+
+
+def barrier():
+    if is_dist():
+        td.barrier()

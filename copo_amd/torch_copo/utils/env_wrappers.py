@@ -1,0 +1,302 @@
+"""Multi-agent driving envs over the HIP simulator, with the wrapper surface of the reference.
+
+Reference: `copo/torch_copo/utils/env_wrappers.py` -- CCEnv (:30-158: pairwise distance map, distance-sorted
+in-radius neighbour lists in `info`), LCFEnv (:161-430: neighbourhood / global rewards, per-agent LCF sampled
+once at spawn and appended to the observation), get_ccenv / get_lcf_env / get_rllib_compatible_env (:433-597).
+The base classes `MultiAgent{Intersection,Roundabout,Tollgate,ParkingLot}Env` are MetaDrive symbols in the
+reference (train_copo.py:1-2); here they are thin front-ends of `copo_sim_*` (one HIP workgroup per scene).
+
+Everything the wrappers compute per step in Python there (O(N^2) distance map, N sorts, reward means, LCF
+sampling, obs concat) happens inside `copo_sim_step`; these classes only choose the configuration and expose
+  * the vector API used by the trainers: `.sim` (VecSim), `vec_reset()`, `vec_step(actions)`;
+  * the dict API of the reference for `num_envs == 1`: `reset() -> {agent_id: obs}`,
+    `step({agent_id: action}) -> (obs, rewards, dones, infos)` with `dones["__all__"]`, the same info keys.
+The communication / traffic-light / latent branches of the reference (off by default, :44-46) are not built.
+"""
+import copy
+import math
+
+import numpy as np
+
+from copo_amd import _capi
+from copo_amd.engine import Box, DictSpace
+from copo_amd.sim import SimConfig, VecSim
+
+_ENV_REGISTRY = {}
+
+SIM_KEYS = {f for f in SimConfig.__dataclass_fields__}  # env_config keys forwarded verbatim to the simulator
+
+
+def register_env(name, creator):
+    _ENV_REGISTRY[name] = creator
+
+
+def lookup_env(name_or_cls):
+    if isinstance(name_or_cls, str):
+        if name_or_cls not in _ENV_REGISTRY:
+            raise KeyError("env %r is not registered (call get_rllib_compatible_env first)" % name_or_cls)
+        return _ENV_REGISTRY[name_or_cls]
+    return name_or_cls
+
+
+class MultiAgentMetaDrive:
+    """Vectorised multi-agent driving env.  `config` keys: every `SimConfig` field plus the reference's
+    `num_agents`, `start_seed`, `horizon`, `neighbours_distance`, ... (unknown keys are kept in `.config`)."""
+    MAP = "intersection"
+    ENABLE_LCF = False
+    WRAPS_CC = False
+
+    @classmethod
+    def default_config(cls):
+        return dict(map=cls.MAP, num_envs=1, num_agents=None, start_seed=5000, horizon=1000, num_lasers=72,
+                    device=0, crash_done=True, out_of_road_done=True, allow_respawn=True, delay_done=25)
+
+    def __init__(self, config=None):
+        cfg = type(self).default_config()
+        cfg.update(config or {})
+        self.config = cfg
+        sim_kwargs = {k: v for k, v in cfg.items() if k in SIM_KEYS and k not in ("enable_lcf",)}
+        sim_kwargs["enable_lcf"] = bool(self.ENABLE_LCF and cfg.get("enable_copo", True))
+        if "lcf_normal_std" in cfg:
+            sim_kwargs["lcf_std"] = float(cfg["lcf_normal_std"])
+        self.sim_config = SimConfig(**sim_kwargs)
+        self.sim = VecSim(self.sim_config, device=int(cfg.get("device", 0) or 0))
+        self.num_envs, self.num_agents = self.sim.E, self.sim.N
+        self._slot_ids = None      # dict API state (num_envs == 1)
+        self._next_obs = None
+        self.current_lcf_mean, self.current_lcf_std = self.sim_config.lcf_mean, self.sim_config.lcf_std
+        if cfg.get("force_lcf", -100) != -100 and self.ENABLE_LCF:
+            self.sim.set_force_lcf(cfg["force_lcf"])
+
+    # ---- spaces --------------------------------------------------------------------------------------------
+    @classmethod
+    def spaces_for(cls, env_config):
+        cfg = cls.default_config()
+        cfg.update(env_config or {})
+        lcf = bool(cls.ENABLE_LCF and cfg.get("enable_copo", True))
+        odim = 9 + 10 + int(cfg.get("num_lasers", 72)) + (1 if lcf else 0)
+        # LCFEnv widens the space to [-1, 1] (env_wrappers.py:241-244); MetaDrive's own obs are in [0, 1]
+        return Box(-1.0 if lcf else 0.0, 1.0, (odim,)), Box(-1.0, 1.0, (2,))
+
+    @property
+    def observation_space(self):
+        o, _ = type(self).spaces_for(self.config)
+        return DictSpace({"agent%d" % i: o for i in range(self.num_agents)})
+
+    @property
+    def action_space(self):
+        _, a = type(self).spaces_for(self.config)
+        return DictSpace({"agent%d" % i: a for i in range(self.num_agents)})
+
+    def action_space_sample(self, agent_ids=None):
+        return self.action_space.sample()
+
+    # ---- vector API ----------------------------------------------------------------------------------------
+    def vec_reset(self, seeds=None):
+        return self.sim.reset(seeds)
+
+    def vec_step(self, actions):
+        return self.sim.step(actions)
+
+    def set_lcf_dist(self, mean, std):
+        assert self.ENABLE_LCF, "set_lcf_dist needs an LCF env (get_lcf_env)"
+        assert std > 0.0 and -1.0 <= mean <= 1.0
+        self.current_lcf_mean, self.current_lcf_std = mean, std
+        self.sim.set_lcf_dist(mean, std)
+
+    def set_force_lcf(self, v):
+        assert self.ENABLE_LCF
+        self.force_lcf = v
+        self.sim.set_force_lcf(v)
+
+    # ---- dict API of the reference (single scene) ---------------------------------------------------------------
+    def _ids(self, out):
+        return out["agent_id"][0].cpu().numpy()
+
+    @property
+    def vehicles(self):
+        """Active agents: {agent_id: slot}."""
+        return {} if self._slot_ids is None else {a: s for s, a in enumerate(self._slot_ids) if a is not None}
+
+    @property
+    def vehicles_including_just_terminated(self):
+        return dict(getattr(self, "_just_terminated", {}), **self.vehicles)
+
+    def reset(self, force_seed=None):
+        assert self.num_envs == 1, "the dict API serves one scene; use vec_reset/vec_step for num_envs > 1"
+        seed = self.config.get("start_seed", 5000) if force_seed is None else force_seed
+        out = self.sim.reset(np.array([seed], np.uint64))
+        ids = self._ids(out)
+        self._slot_ids = ["agent%d" % a for a in ids]
+        self._just_terminated = {}
+        obs = out["obs"][0].cpu().numpy()
+        return {a: obs[s] for s, a in enumerate(self._slot_ids)}
+
+    def step(self, actions):
+        import torch
+        assert self.num_envs == 1 and self._slot_ids is not None, "call reset() first"
+        N, F = self.num_agents, _capi
+        act = np.zeros((1, N, 2), np.float32)
+        for s, a in enumerate(self._slot_ids):
+            if a is not None:
+                act[0, s] = np.asarray(actions[a], np.float32)[:2]
+        out = self.sim.step(torch.from_numpy(act).to(self.sim.device))
+        h = {k: v[0].cpu().numpy() for k, v in out.items() if v is not None}
+        flags = h["flags"]
+        env_reset = bool((flags & F.F_ENV_RESET).any())
+        st, _ = self.sim.get_state()
+        aid_now = st[14, 0].cpu().numpy().view(np.int32)
+        before = list(self._slot_ids)
+        acting = {before[s]: s for s in range(N) if flags[s] & F.F_ACTED}
+        spawned = {"agent%d" % aid_now[s]: s for s in range(N) if flags[s] & F.F_SPAWNED}
+        # names of the slots as the neighbour lists of THIS step see them (post-step scene, before a horizon reset)
+        name_of_slot = {s: a for a, s in acting.items()}
+        if not env_reset:
+            name_of_slot.update({s: a for a, s in spawned.items()})
+        o, r, d, i = {}, {}, {}, {}
+        self._just_terminated = {}
+        for a, s in acting.items():
+            f = int(flags[s])
+            r[a], d[a] = float(h["rew"][s]), bool(f & F.F_DONE)
+            o[a] = h["obs"][s]
+            cnt = int(min(h["nbr_cnt"][s], self.sim.K))
+            inf = h["info"][s]
+            info = dict(
+                all_agents=list(name_of_slot.values()),
+                neighbours=[name_of_slot.get(int(j), "slot%d" % j) for j in h["nbr_idx"][s][:cnt]],
+                neighbours_distance=[float(x) for x in h["nbr_dist"][s][:cnt]],
+                arrive_dest=bool(f & F.F_ARRIVE), crash=bool(f & F.F_CRASH), crash_vehicle=bool(f & F.F_CRASH),
+                out_of_road=bool(f & F.F_OUT), max_step=bool(f & F.F_MAXSTEP), velocity=float(inf[0]),
+                steering=float(inf[1]), acceleration=float(inf[2]), step_reward=float(inf[3]), cost=float(inf[4]),
+                episode_length=int(inf[5]), episode_reward=float(inf[6]), route_completion=float(inf[7]))
+            if self.ENABLE_LCF:
+                lcf, nei_r = float(h["lcf"][s]), float(h["nei_rew"][s])
+                coord = math.cos(lcf * math.pi / 2) * r[a] + math.sin(lcf * math.pi / 2) * nei_r
+                info.update(nei_rewards=nei_r, global_rewards=float(h["glob_rew"]), lcf=lcf, lcf_deg=lcf * 90,
+                            coordinated_rewards=coord, native_rewards=r[a])
+                if not self.config.get("return_native_reward", True):
+                    r[a] = coord
+            i[a] = info
+            if d[a]:
+                self._just_terminated[a] = s
+        if not env_reset:
+            for a, s in spawned.items():     # respawned agents: first obs, zero reward, empty info (MetaDrive)
+                o[a], r[a], d[a], i[a] = h["obs"][s], 0.0, False, {}
+        d["__all__"] = env_reset
+        after = [None] * N
+        for s in range(N):
+            if flags[s] & F.F_SPAWNED:
+                after[s] = "agent%d" % aid_now[s]
+            elif (flags[s] & F.F_ACTED) and not (flags[s] & F.F_DONE):
+                after[s] = before[s]
+        self._slot_ids = after
+        if env_reset:                        # the sim auto-reset: first obs of the next episode, if the caller goes on
+            self._auto_reset_obs = {after[s]: h["obs"][s] for s in range(N)}
+        return o, r, d, i
+
+    def close(self):
+        self.sim.close()
+
+
+class MultiAgentIntersectionEnv(MultiAgentMetaDrive):
+    MAP = "intersection"
+
+
+class MultiAgentRoundaboutEnv(MultiAgentMetaDrive):
+    MAP = "roundabout"
+
+
+class MultiAgentTollgateEnv(MultiAgentMetaDrive):
+    MAP = "tollgate"
+
+
+class MultiAgentParkingLotEnv(MultiAgentMetaDrive):
+    MAP = "parkinglot"
+
+
+class CCEnv:
+    """Mixin: neighbour lists in `info` (`neighbours`, `neighbours_distance`, `all_agents`), radius
+    `neighbours_distance` (strict <), sorted by distance with ties in slot order (env_wrappers.py:89-158)."""
+    WRAPS_CC = True
+
+    @classmethod
+    def default_config(cls):
+        config = super(CCEnv, cls).default_config()
+        config["neighbours_distance"] = 40
+        config.update(dict(communication=dict(comm_method="none", comm_size=4, comm_neighbours=4, add_pos_in_comm=False),
+                           add_traffic_light=False, traffic_light_interval=30))
+        return config
+
+    def __init__(self, *args, **kwargs):
+        super(CCEnv, self).__init__(*args, **kwargs)
+        assert self.config["communication"]["comm_method"] == "none", "communication channel is not built"
+        assert not self.config["add_traffic_light"], "traffic-light message is not built"
+
+
+class LCFEnv(CCEnv):
+    """Mixin: LCF per agent (sampled once at spawn from clip(N(mean, std), -1, 1)), `(lcf+1)/2` appended to the
+    observation, neighbourhood / global rewards in `info` (env_wrappers.py:161-430)."""
+    ENABLE_LCF = True
+
+    @classmethod
+    def default_config(cls):
+        config = super(LCFEnv, cls).default_config()
+        config.update(dict(neighbours_distance=40, lcf_mode="angle", lcf_dist="normal", lcf_normal_std=0.1,
+                           return_native_reward=True, force_lcf=-100, enable_copo=True))
+        return config
+
+    def __init__(self, config=None):
+        super(LCFEnv, self).__init__(config)
+        assert self.config["lcf_mode"] in ["linear", "angle"] and self.config["lcf_mode"] == "angle", \
+            "only the 'angle' LCF mode is built (the reference default)"
+        assert self.config["lcf_dist"] == "normal", "only the normal LCF distribution is built"
+        assert self.config["lcf_normal_std"] > 0.0
+        self.force_lcf = self.config["force_lcf"]
+
+    @property
+    def enable_copo(self):
+        return self.config["enable_copo"]
+
+
+def _named_subclass(mixin, env_class, prefix=""):
+    name = prefix + env_class.__name__
+    return type(name, (mixin, env_class), {"__qualname__": name})
+
+
+def get_ccenv(env_class):
+    return _named_subclass(CCEnv, env_class)
+
+
+def get_lcf_env(env_class):
+    return _named_subclass(LCFEnv, env_class)
+
+
+def get_change_n_env(env_class):
+    """Curriculum wrapper of the reference (:444-460): re-create the env with another population."""
+    class ChangeNEnv(env_class):
+        def __init__(self, config):
+            self._raw_input_config = copy.deepcopy(config)
+            super(ChangeNEnv, self).__init__(config)
+
+        def close_and_reset_num_agents(self, num_agents):
+            config = copy.deepcopy(self._raw_input_config)
+            self.close()
+            config["num_agents"] = num_agents
+            super(ChangeNEnv, self).__init__(config)
+
+    ChangeNEnv.__name__ = ChangeNEnv.__qualname__ = "CL{}".format(env_class.__name__)
+    return ChangeNEnv
+
+
+def get_rllib_compatible_env(env_class, return_class=False):
+    """Register `env_class` under its class name and return the name (env_wrappers.py:559-597)."""
+    env_name = env_class.__name__
+
+    class MA(env_class):
+        _agent_ids = ["agent{}".format(i) for i in range(100)] + ["{}".format(i) for i in range(10000)] + ["sdc"]
+
+    MA.__name__ = MA.__qualname__ = env_name
+    register_env(env_name, MA)
+    if return_class:
+        return env_name, MA
+    return env_name

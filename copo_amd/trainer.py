@@ -1,0 +1,632 @@
+"""The host loop that replaces RLlib's rollout workers, sampler and SGD driver (SURVEY.md layer L1/L3).
+
+  VecSampler     T-step rollouts of E x N agent slots: policy inference (torch-ROCm) + `copo_sim_step`
+                 writing straight into the time-major rollout buffers; the whole T-step loop is one hipGraph.
+  PPOPolicyBase  model + Adam + KL coefficient + the static-shape minibatch SGD step (optionally a hipGraph),
+                 with the data-parallel gradient exchange of `copo_amd.dist`.
+  VecTrainer     `training_step()` = sample -> postprocess -> advantage statistics -> SGD epochs -> KL update,
+                 the control flow of RLlib PPO / the reference's `training_step` (algo_copo.py:516-661).
+
+Reference call sites being replaced: `synchronous_parallel_sample` (algo_copo.py:519-525), `train_one_step` /
+`multi_gpu_train_one_step` (:555-558), `minibatches` (:585), `update_kl` (:631-632).
+"""
+import math
+import os
+import time
+from collections import defaultdict
+
+import numpy as np
+import torch
+
+from . import dist as D
+from .engine import (LEARNER_STATS_KEY, NUM_AGENT_STEPS_SAMPLED, NUM_ENV_STEPS_SAMPLED, Postprocessing, SampleBatch,
+                     TorchDiagGaussian)
+
+F_ACTED, F_DONE, F_ARRIVE, F_CRASH, F_OUT, F_MAXSTEP, F_SPAWNED, F_ENV_RESET = (1 << i for i in range(8))
+
+
+def resolve_device(cfg_device=None):
+    if cfg_device is not None:
+        return torch.device(cfg_device)
+    if torch.cuda.is_available():
+        return torch.device("cuda", D.env_world()[1])
+    return torch.device("cpu")
+
+
+class GraphedCallable:
+    """Run `fn()` eagerly, or (CUDA + enabled) capture it once into a hipGraph after `warmup` eager calls and
+    replay it afterwards.  `fn` must only touch static tensors and must not synchronise."""
+
+    def __init__(self, fn, enabled, warmup=2):
+        self.fn, self.enabled, self.warmup = fn, bool(enabled), warmup
+        self.calls, self.graph = 0, None
+
+    def __call__(self):
+        if not self.enabled:
+            return self.fn()
+        if self.graph is not None:
+            self.graph.replay()
+            return
+        self.calls += 1
+        if self.calls <= self.warmup:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self.fn()
+            torch.cuda.current_stream().wait_stream(s)
+            return
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.fn()
+        self.graph = g
+        g.replay()
+
+    def reset(self):
+        self.calls, self.graph = 0, None
+
+
+# ----------------------------------------------------------------------------------------------------
+# sampler
+# ----------------------------------------------------------------------------------------------------
+class VecSampler:
+    """Time-major rollout buffers + the rollout loop.  Row (t, e, n) holds obs_t, the action sampled for it, and
+    the reward / flags / neighbour lists / LCF produced by the step that executed that action."""
+
+    def __init__(self, vec_env, policy, T, use_graph=True):
+        self.env, self.sim, self.policy, self.T = vec_env, vec_env.sim, policy, int(T)
+        sim = self.sim
+        E, N, O, K, dev = sim.E, sim.N, sim.O, sim.K, sim.device
+        self.E, self.N, self.O, self.K, self.device = E, N, O, K, dev
+        f32, i32, u8 = torch.float32, torch.int32, torch.uint8
+        T = self.T
+        z = lambda *s, dtype=f32: torch.zeros(*s, dtype=dtype, device=dev)  # noqa: E731
+        self.obs = z(T + 1, E, N, O)
+        self.actions, self.eps, self.clipped = z(T, E, N, 2), z(T, E, N, 2), z(T, E, N, 2)
+        self.logp, self.dist_inputs = z(T, E, N), z(T, E, N, 4)
+        self.rew3 = z(3, T, E, N)            # native / neighbourhood / global reward heads
+        self.glob = z(T, E)
+        self.flags = z(T, E, N, dtype=u8)
+        self.nbr_idx, self.nbr_dist = z(T, E, N, K, dtype=i32), z(T, E, N, K)
+        self.nbr_cnt, self.mf_cnt = z(T, E, N, dtype=i32), z(T, E, N, dtype=i32)
+        self.lcf, self.agent_id = z(T, E, N), z(T, E, N, dtype=i32)
+        self.info = z(T, E, N, 8)
+        self._outs = []
+        for t in range(T):
+            self._outs.append(sim.make_step_out(dict(
+                obs=self.obs[t + 1], rew=self.rew3[0, t], nei_rew=self.rew3[1, t], glob_rew=self.glob[t],
+                flags=self.flags[t], nbr_idx=self.nbr_idx[t], nbr_cnt=self.nbr_cnt[t], mf_cnt=self.mf_cnt[t],
+                nbr_dist=self.nbr_dist[t], lcf=self.lcf[t], info=self.info[t], agent_id=self.agent_id[t])))
+        self._reset_out = sim.make_step_out(dict(obs=self.obs[0]))
+        self._started = False
+        self._loop = GraphedCallable(self._rollout, use_graph and dev.type == "cuda")
+        self.env_steps_total = 0
+
+    def reset(self, seeds=None):
+        import ctypes as C
+        sim = self.sim
+        if seeds is None:
+            seeds = np.arange(sim.E, dtype=np.uint64) + np.uint64(sim.cfg.start_seed + 1000003 * D.rank())
+        seeds = np.ascontiguousarray(seeds, np.uint64)
+        sim._capi.check(sim._capi.lib.copo_sim_reset(sim._h, seeds.ctypes.data, C.byref(self._reset_out), sim._stream()))
+        torch.cuda.current_stream(self.device).synchronize()
+        self._started = True
+
+    def _rollout(self):
+        import ctypes as C
+        sim, pol = self.sim, self.policy
+        EN = self.E * self.N
+        lib, h, stream = sim._capi.lib, sim._h, sim._stream()
+        for t in range(self.T):
+            a, lp, di = pol.compute_actions(self.obs[t].view(EN, self.O), self.eps[t].view(EN, 2))
+            self.actions[t].view(EN, 2).copy_(a)
+            self.logp[t].view(EN).copy_(lp)
+            self.dist_inputs[t].view(EN, 4).copy_(di)
+            torch.clamp(a.view(self.E, self.N, 2), -1.0, 1.0, out=self.clipped[t])
+            sim._capi.check(lib.copo_sim_step(h, self.clipped[t].data_ptr(), C.byref(self._outs[t]), stream))
+
+    def sample(self):
+        """One fragment of T env steps on every scene; returns the dense SampleBatch (views, no copies)."""
+        if not self._started:
+            self.reset()
+        else:
+            self.obs[0].copy_(self.obs[self.T])
+        self.eps.normal_()
+        self.sim.flush()
+        self._loop()
+        self.env_steps_total += self.T * self.E
+        self.rew3[2].copy_(self.glob.unsqueeze(-1).expand(self.T, self.E, self.N))
+        return SampleBatch({
+            SampleBatch.OBS: self.obs[:self.T], SampleBatch.ACTIONS: self.actions, SampleBatch.ACTION_LOGP: self.logp,
+            SampleBatch.ACTION_DIST_INPUTS: self.dist_inputs, SampleBatch.REWARDS: self.rew3[0],
+            "nei_rewards": self.rew3[1], "global_rewards": self.rew3[2], "rew3": self.rew3,
+            SampleBatch.FLAGS: self.flags, "nbr_idx": self.nbr_idx, "nbr_cnt": self.nbr_cnt, "mf_cnt": self.mf_cnt,
+            "nbr_dist": self.nbr_dist, "step_lcf": self.lcf, "infos": self.info, "agent_id": self.agent_id,
+        })
+
+
+# ----------------------------------------------------------------------------------------------------
+# policy base
+# ----------------------------------------------------------------------------------------------------
+class PPOPolicyBase:
+    """Shared-policy PPO learner.  Subclasses provide `model_class`, `loss`, `postprocess_trajectory`."""
+    model_class = None
+    STAT_KEYS = ("total_loss", "mean_policy_loss", "mean_vf_loss", "mean_kl_loss", "mean_entropy")
+
+    def __init__(self, observation_space, action_space, config):
+        self.observation_space, self.action_space, self.config = observation_space, action_space, config
+        self.device = resolve_device(config.get("device"))
+        self.dist_class = TorchDiagGaussian
+        seed = config.get("seed")
+        if seed is not None:
+            torch.manual_seed(int(seed))
+        self.model = self.make_model("default_model").to(self.device)
+        D.broadcast_module_(self.model)
+        self.entropy_coeff = float(config.get("entropy_coeff", 0.0))
+        self._kl_value = float(config["kl_coeff"])
+        self.kl_coeff = torch.tensor(self._kl_value, dtype=torch.float32, device=self.device)
+        self.kl_target = float(config.get("kl_target", 0.01))
+        cuda = self.device.type == "cuda"
+        self._params = [p for p in self.model.parameters() if p.dtype == torch.float32]
+        self.optimizer = torch.optim.Adam(self._params, lr=float(config["lr"]), capturable=cuda, foreach=True if cuda else None)
+        self.num_grad_updates = 0
+        self.use_graphs = bool(config.get("use_hip_graphs", True)) and cuda
+        self.autocast_dtype = torch.bfloat16 if str(config.get("policy_dtype", "float32")) in ("bfloat16", "bf16") else None
+        self._flat_grad = None
+        self._sgd = None
+        self._row_sources = None
+
+    # ---- construction / inference --------------------------------------------------------------------
+    def make_model(self, name):
+        n_out = 2 * int(self.action_space.shape[0])
+        return self.model_class(self.observation_space, self.action_space, n_out, self.config["model"], name)
+
+    def _autocast(self):
+        if self.autocast_dtype is not None and self.device.type == "cuda":
+            return torch.autocast("cuda", dtype=self.autocast_dtype)
+        import contextlib
+        return contextlib.nullcontext()
+
+    @torch.no_grad()
+    def compute_actions(self, obs, eps=None, explore=True):
+        """obs [B, O] -> (action [B, A] unclipped, logp [B], dist_inputs [B, 2A])."""
+        with self._autocast():
+            logits, _ = self.model({"obs": obs})
+        logits = logits.float()
+        dist = self.dist_class(logits, self.model)
+        act = dist.sample(eps) if explore else dist.deterministic_sample()
+        return act, dist.logp(act), logits
+
+    def update_kl(self, sampled_kl):
+        """RLlib's adaptive KL rule (progress.csv 0.2 -> 0.675 = 0.2 * 1.5^3)."""
+        if sampled_kl > 2.0 * self.kl_target:
+            self._kl_value *= 1.5
+        elif sampled_kl < 0.5 * self.kl_target:
+            self._kl_value *= 0.5
+        self.kl_coeff.fill_(self._kl_value)
+        return self._kl_value
+
+    # ---- weights / checkpoint ----------------------------------------------------------------------------
+    def get_weights(self):
+        return {k: v.detach().cpu().numpy() for k, v in self.model.state_dict().items()}
+
+    def set_weights(self, weights):
+        sd = {k: torch.as_tensor(v) for k, v in weights.items()}
+        self.model.load_state_dict(sd)
+
+    def get_state(self):
+        return dict(model=self.model.state_dict(), optimizer=self.optimizer.state_dict(), kl_coeff=self._kl_value,
+                    num_grad_updates=self.num_grad_updates)
+
+    def set_state(self, state):
+        self.model.load_state_dict(state["model"])
+        self.optimizer.load_state_dict(state["optimizer"])
+        self._kl_value = float(state["kl_coeff"])
+        self.kl_coeff.fill_(self._kl_value)
+        self.num_grad_updates = int(state.get("num_grad_updates", 0))
+        if self._sgd is not None:
+            self._sgd.reset()
+
+    # ---- minibatch SGD --------------------------------------------------------------------------------
+    def loss(self, model, dist_class, train_batch):
+        raise NotImplementedError
+
+    def train_columns(self):
+        """Per-row scalar/vector columns packed for the minibatch gather (name -> width)."""
+        return [(SampleBatch.ACTIONS, 2), (SampleBatch.ACTION_LOGP, 1), (SampleBatch.ACTION_DIST_INPUTS, 4),
+                (Postprocessing.ADVANTAGES, 1), (SampleBatch.VF_PREDS, 1), (Postprocessing.VALUE_TARGETS, 1)]
+
+    def _ensure_flat_grads(self):
+        if self._flat_grad is not None:
+            return
+        n = sum(p.numel() for p in self._params)
+        self._flat_grad = torch.zeros(n, dtype=torch.float32, device=self.device)
+        off = 0
+        for p in self._params:
+            p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def prepare_sgd(self, dense, max_rows, mb):
+        """Bind the dense (flattened [T*E*N, ...]) sources of one iteration and (re)build the static minibatch
+        machinery.  `dense` maps column name -> tensor whose first dim is the flattened row index."""
+        cols = self.train_columns()
+        width = sum(w for _, w in cols)
+        dev = self.device
+        if self._row_sources is None or self._row_sources["max_rows"] != max_rows or self._row_sources["mb"] != mb:
+            max_mb = max(1, math.ceil(max_rows / mb))
+            self._row_sources = dict(
+                max_rows=max_rows, mb=mb, max_mb=max_mb,
+                pack=torch.zeros(max_rows, width, dtype=torch.float32, device=dev),
+                rows_all=torch.zeros(max_mb, mb, dtype=torch.int64, device=dev),
+                w_all=torch.zeros(max_mb, mb, dtype=torch.float32, device=dev),
+                denom_all=torch.ones(max_mb, dtype=torch.float32, device=dev),
+                k=torch.zeros(1, dtype=torch.int64, device=dev),
+                stats=torch.zeros(len(self.STAT_KEYS), dtype=torch.float32, device=dev),
+            )
+            self._sgd = None
+        rs = self._row_sources
+        off = 0
+        for name, w in cols:
+            src = dense[name].reshape(max_rows, w) if w > 1 else dense[name].reshape(max_rows, 1)
+            rs["pack"][:, off:off + w].copy_(src)
+            off += w
+        rs["obs"] = dense[SampleBatch.OBS].reshape(max_rows, -1)
+        cc = dense.get("centralized_critic_obs")
+        rs["cc_obs"] = None if cc is None else cc.reshape(max_rows, -1)
+        return rs
+
+    def _gather_minibatch(self):
+        rs = self._row_sources
+        k = rs["k"]
+        rows = rs["rows_all"].index_select(0, k).view(-1)
+        pk = rs["pack"].index_select(0, rows)
+        tb = SampleBatch()
+        off = 0
+        for name, w in self.train_columns():
+            tb[name] = pk[:, off:off + w] if w > 1 else pk[:, off]
+            off += w
+        tb[SampleBatch.OBS] = rs["obs"].index_select(0, rows)
+        tb["centralized_critic_obs"] = tb[SampleBatch.OBS] if rs["cc_obs"] is None else rs["cc_obs"].index_select(0, rows)
+        tb[SampleBatch.VALID] = rs["w_all"].index_select(0, k).view(-1)
+        tb["valid_denominator"] = rs["denom_all"].index_select(0, k).view(())
+        return tb
+
+    def _forward_backward(self):
+        self._flat_grad.zero_()
+        tb = self._gather_minibatch()
+        with self._autocast():
+            loss = self.loss(self.model, self.dist_class, tb)
+        loss.backward()
+        st = self.model.tower_stats
+        self._row_sources["stats"].add_(torch.stack([st[k].detach().float().reshape(()) for k in self.STAT_KEYS]))
+
+    def _apply(self):
+        clip = self.config.get("grad_clip")
+        if clip:
+            torch.nn.utils.clip_grad_norm_(self._params, float(clip))
+        self.optimizer.step()
+        self._row_sources["k"].add_(1)
+
+    def _sgd_step_local(self):
+        self._forward_backward()
+        self._apply()
+
+    def plan_epoch(self, valid_idx, B_local, B_all, mb, bufs=None):
+        """Shuffle this rank's valid rows and cut them into `n_mb` near-equal static-shape minibatches
+        (n_mb from the LARGEST rank so that every rank issues the same number of collectives).
+        `bufs` = dict(rows_all, w_all, denom_all, k); default: the SGD buffers."""
+        rs = self._row_sources if bufs is None else bufs
+        n_mb = max(1, math.ceil(max(B_all) / mb))
+        dev = self.device
+        perm = valid_idx[torch.randperm(B_local, device=dev)] if B_local > 0 else valid_idx
+        q, r = divmod(B_local, n_mb)
+        k = torch.arange(n_mb, device=dev)
+        start = k * q + torch.clamp(k, max=r)
+        size = q + (k < r).to(torch.int64)
+        j = torch.arange(mb, device=dev)
+        pos = start[:, None] + j[None, :]
+        w = (j[None, :] < size[:, None])
+        if B_local > 0:
+            rows = perm[torch.clamp(pos, max=B_local - 1)]
+        else:
+            rows = torch.zeros(n_mb, mb, dtype=torch.int64, device=dev)
+        rs["rows_all"][:n_mb].copy_(torch.where(w, rows, torch.zeros_like(rows)))
+        rs["w_all"][:n_mb].copy_(w.to(torch.float32))
+        denom = np.zeros(n_mb, np.float64)
+        for Br in B_all:
+            qq, rr = divmod(Br, n_mb)
+            denom += qq + (np.arange(n_mb) < rr)
+        rs["denom_all"][:n_mb].copy_(torch.as_tensor(np.maximum(denom, 1.0), dtype=torch.float32))
+        rs["k"].zero_()
+        return n_mb
+
+    def run_sgd(self, valid_idx, B_local, B_all, mb, num_epochs):
+        """`num_sgd_iter` epochs of minibatch SGD; returns the mean learner stats over every step taken."""
+        self._ensure_flat_grads()
+        rs = self._row_sources
+        if self._sgd is None:
+            if D.is_dist():
+                self._sgd = (GraphedCallable(self._forward_backward, self.use_graphs),
+                             GraphedCallable(self._apply, self.use_graphs))
+            else:
+                self._sgd = GraphedCallable(self._sgd_step_local, self.use_graphs)
+        rs["stats"].zero_()
+        steps = 0
+        for _ in range(num_epochs):
+            n_mb = self.plan_epoch(valid_idx, B_local, B_all, mb)
+            for _k in range(n_mb):
+                if D.is_dist():
+                    self._sgd[0]()
+                    D.all_reduce_sum_(self._flat_grad)
+                    self._sgd[1]()
+                else:
+                    self._sgd()
+                steps += 1
+        self.num_grad_updates += steps
+        vals = (rs["stats"] / max(1, steps)).tolist()
+        out = dict(zip(self.STAT_KEYS, vals))
+        return dict(total_loss=out["total_loss"], policy_loss=out["mean_policy_loss"], vf_loss=out["mean_vf_loss"],
+                    kl=out["mean_kl_loss"], entropy=out["mean_entropy"], cur_kl_coeff=self._kl_value,
+                    cur_lr=float(self.config["lr"]), num_sgd_steps=steps,
+                    **{k: v for k, v in out.items() if k not in ("total_loss", "mean_policy_loss", "mean_vf_loss",
+                                                                 "mean_kl_loss", "mean_entropy")})
+
+    # ---- postprocess (dense) -----------------------------------------------------------------------------
+    def critic_obs_dense(self, batch):
+        """[T, E, N, C] centralised-critic observation for every row (IPPO / fuse 'none': the obs itself)."""
+        return batch[SampleBatch.OBS]
+
+    def gae_heads(self):
+        return 1
+
+    def gae_gammas(self):
+        return [float(self.config["gamma"])]
+
+    @torch.no_grad()
+    def value_heads_dense(self, cc_flat):
+        """[heads, rows] values of every critic head for flattened critic observations."""
+        with self._autocast():
+            v = self.model._value_branch(self.model._value_branch_separate(cc_flat)).reshape(-1)
+        return v.float().unsqueeze(0)
+
+    @torch.no_grad()
+    def postprocess_trajectory(self, sample_batch, other_agent_batches=None, episode=None):
+        """Dense counterpart of `postprocess_trajectory` (algo_ccppo.py:322-374, algo_copo.py:473-502): critic
+        observation fusion, value heads, and every GAE head in one segmented scan, for all [T, E, N] rows at once.
+        Trajectories are cut at fragment boundaries of `rollout_fragment_length` steps like RLlib's
+        truncate_episodes mode."""
+        from . import ops
+        b = sample_batch
+        obs = b[SampleBatch.OBS]
+        T, E, N = obs.shape[0], obs.shape[1], obs.shape[2]
+        M = E * N
+        cc = self.critic_obs_dense(b)
+        b["centralized_critic_obs"] = cc
+        H = self.gae_heads()
+        vals = self.value_heads_dense(cc.reshape(T * M, -1)).reshape(H, T, M).contiguous()
+        rew = b["rew3"][:H].reshape(H, T, M)
+        flags = b[SampleBatch.FLAGS].reshape(T, M)
+        adv, tgt = torch.empty_like(vals), torch.empty_like(vals)
+        frag = int(self.config.get("rollout_fragment_length", T) or T)
+        lam = float(self.config["lambda"])
+        for lo in range(0, T, frag):
+            hi = min(T, lo + frag)
+            if lo == 0 and hi == T:
+                ops.gae3(rew.contiguous(), vals, flags, self.gae_gammas(), lam, adv, tgt)
+            else:
+                a, g = ops.gae3(rew[:, lo:hi].contiguous(), vals[:, lo:hi].contiguous(), flags[lo:hi].contiguous(),
+                                self.gae_gammas(), lam)
+                adv[:, lo:hi], tgt[:, lo:hi] = a, g
+        b[SampleBatch.VF_PREDS], b[Postprocessing.ADVANTAGES], b[Postprocessing.VALUE_TARGETS] = \
+            vals[0].view(T, E, N), adv[0].view(T, E, N), tgt[0].view(T, E, N)
+        b["_vals"], b["_adv"], b["_tgt"] = vals, adv, tgt
+        return b
+
+
+# ----------------------------------------------------------------------------------------------------
+# trainer
+# ----------------------------------------------------------------------------------------------------
+class VecTrainer:
+    """`Algorithm`-shaped driver: `train()` runs one iteration and returns an RLlib-style result dict."""
+    _name = "PPO"
+    _allow_unknown_configs = True
+
+    @classmethod
+    def get_default_config(cls):
+        raise NotImplementedError
+
+    def get_default_policy_class(self, config):
+        raise NotImplementedError
+
+    def __init__(self, config=None, env=None, logger_creator=None):
+        cfg = type(self).get_default_config()
+        user = dict(config or {})
+        if env is not None:
+            user["env"] = env
+        cfg.update_from_dict(user)
+        D.init_from_env(cfg.get("device"))
+        cfg.validate()
+        self.config = cfg
+        self._counters = defaultdict(int)
+        self._timers = defaultdict(float)
+        self.iteration = 0
+        self._t_start = time.time()
+        self.callbacks = cfg.callbacks() if isinstance(cfg.callbacks, type) else cfg.callbacks
+        self.setup(cfg)
+
+    def setup(self, cfg):
+        from copo_amd.torch_copo.utils.env_wrappers import lookup_env
+        env_cls = lookup_env(cfg["env"])
+        env_config = dict(cfg["env_config"])
+        env_config.setdefault("num_envs", int(cfg["num_envs"]))
+        device = resolve_device(cfg.get("device"))
+        env_config.setdefault("device", device.index or 0)
+        self.env = env_cls(env_config)
+        pol_cls = self.get_default_policy_class(cfg)
+        self.policy = pol_cls(cfg.observation_space, cfg.action_space, cfg)
+        E = self.env.sim.E
+        T = max(1, math.ceil(int(cfg["train_batch_size"]) / E))
+        self.sampler = VecSampler(self.env, self.policy, T, use_graph=cfg.get("use_hip_graphs", True))
+        self.workers = _LocalWorkerSet(self)
+        self._episode_stats = defaultdict(float)
+
+    # ---- RLlib-shaped accessors -----------------------------------------------------------------------------
+    def get_policy(self, policy_id="default"):
+        return self.policy
+
+    # ---- the iteration ------------------------------------------------------------------------------------
+    def collect(self):
+        t0 = time.perf_counter()
+        batch = self.sampler.sample()
+        self.policy.postprocess_trajectory(batch)
+        self._timers["sample_time_ms"] = (time.perf_counter() - t0) * 1e3
+        return batch
+
+    def valid_rows(self, batch):
+        flags = batch[SampleBatch.FLAGS].reshape(-1)
+        valid = (flags & F_ACTED).bool()
+        idx = valid.nonzero(as_tuple=False).view(-1)       # the one host sync of an iteration
+        return valid, idx, int(idx.numel())
+
+    def standardize_advantages(self, batch, valid):
+        """PPO's `standardize_fields(["advantages"])` over the valid rows of ALL ranks."""
+        adv = batch[Postprocessing.ADVANTAGES].reshape(-1)
+        w = valid.to(torch.float64)
+        a = adv.to(torch.float64)
+        stats = torch.stack([w.sum(), (a * w).sum(), (a * a * w).sum()])
+        D.all_reduce_sum_(stats)
+        n, s, ss = stats.tolist()
+        mean = s / max(n, 1.0)
+        std = max(1e-4, math.sqrt(max(ss / max(n, 1.0) - mean * mean, 0.0)))
+        batch[Postprocessing.ADVANTAGES] = ((adv - mean) / std * valid).view_as(batch[Postprocessing.ADVANTAGES])
+
+    def training_step(self):
+        cfg, pol = self.config, self.policy
+        batch = self.collect()
+        valid, idx, B = self.valid_rows(batch)
+        B_all = D.all_gather_int(B, pol.device)
+        self._counters[NUM_AGENT_STEPS_SAMPLED] += sum(B_all)
+        self._counters[NUM_ENV_STEPS_SAMPLED] += self.sampler.T * self.sampler.E * D.world_size()
+        self.standardize_advantages(batch, valid)
+        t0 = time.perf_counter()
+        max_rows = batch[SampleBatch.FLAGS].numel()
+        pol.prepare_sgd(batch, max_rows, int(cfg["sgd_minibatch_size"]))
+        stats = pol.run_sgd(idx, B, B_all, int(cfg["sgd_minibatch_size"]), int(cfg["num_sgd_iter"]))
+        self._timers["learn_time_ms"] = (time.perf_counter() - t0) * 1e3
+        pol.update_kl(stats["kl"])
+        self._last_batch = batch
+        return {"default": {LEARNER_STATS_KEY: stats, "custom_metrics": {}}}
+
+    # ---- metrics --------------------------------------------------------------------------------------------
+    def episode_metrics(self, batch):
+        """Device-side reduction of the terminal flags / info of this iteration's rows: the quantities
+        `MultiAgentDrivingCallbacks` derives from info dicts (utils/callbacks.py:48-110), aggregated over the
+        agents that terminated in this iteration."""
+        flags = batch[SampleBatch.FLAGS].reshape(-1).to(torch.int32)
+        info = batch["infos"].reshape(-1, 8)
+        acted = (flags & F_ACTED) > 0
+        done = ((flags & F_DONE) > 0) & acted
+        f64 = torch.float64
+        sums = torch.stack([
+            done.sum().to(f64), ((flags & F_ARRIVE) > 0)[done].sum().to(f64), ((flags & F_CRASH) > 0)[done].sum().to(f64),
+            ((flags & F_OUT) > 0)[done].sum().to(f64), ((flags & F_MAXSTEP) > 0)[done].sum().to(f64),
+            info[done, 5].sum().to(f64), info[done, 6].sum().to(f64), info[done, 7].sum().to(f64),
+            acted.sum().to(f64), info[acted, 0].sum().to(f64), info[acted, 1].sum().to(f64), info[acted, 2].sum().to(f64),
+            info[acted, 3].sum().to(f64), info[acted, 4].sum().to(f64),
+            batch["nbr_cnt"].reshape(-1)[acted].sum().to(f64),
+        ])
+        D.all_reduce_sum_(sums)
+        (nd, arr, crash, out, maxs, ep_len, ep_rew, rc, na, vel, steer, acc, srew, cost, nnb) = sums.tolist()
+        cm = {}
+        if nd > 0:
+            cm.update(success_rate_mean=arr / nd, crash_rate_mean=crash / nd, out_of_road_rate_mean=out / nd,
+                      max_step_rate_mean=maxs / nd, episode_length_mean=ep_len / nd, episode_reward_mean=ep_rew / nd,
+                      route_completion_mean=rc / nd, episode_cost_mean=(crash + out) / nd)
+        if na > 0:
+            cm.update(velocity_mean=vel / na, steering_mean=steer / na, acceleration_mean=acc / na,
+                      step_reward_mean=srew / na, cost_mean=cost / na, num_neighbours_mean=nnb / na)
+        cm["num_terminated_agents"] = nd
+        return cm
+
+    def train(self):
+        t0 = time.perf_counter()
+        train_results = self.training_step()
+        dt = time.perf_counter() - t0
+        self.iteration += 1
+        cm = self.episode_metrics(self._last_batch)
+        agent_steps = self._counters[NUM_AGENT_STEPS_SAMPLED]
+        result = dict(
+            training_iteration=self.iteration, timesteps_total=self._counters[NUM_ENV_STEPS_SAMPLED],
+            agent_timesteps_total=agent_steps, time_this_iter_s=dt, time_total_s=time.time() - self._t_start,
+            episode_reward_mean=cm.get("episode_reward_mean", float("nan")),
+            episode_len_mean=cm.get("episode_length_mean", float("nan")), policy_reward_mean={},
+            custom_metrics=cm, info=dict(learner=train_results, num_agent_steps_sampled=agent_steps,
+                                         num_env_steps_sampled=self._counters[NUM_ENV_STEPS_SAMPLED]),
+            timers=dict(self._timers), num_healthy_workers=D.world_size(),
+        )
+        if self.callbacks is not None and hasattr(self.callbacks, "on_train_result"):
+            self.callbacks.on_train_result(algorithm=self, result=result)
+        return result
+
+    # ---- checkpoints ---------------------------------------------------------------------------------------
+    def save_checkpoint(self, checkpoint_dir):
+        os.makedirs(checkpoint_dir, exist_ok=True)
+        path = os.path.join(checkpoint_dir, "checkpoint-%d.pt" % self.iteration)
+        if D.rank() == 0:
+            torch.save(dict(policy=self.policy.get_state(), counters=dict(self._counters), iteration=self.iteration,
+                            trainer=self._name), path)
+        return path
+
+    save = save_checkpoint
+
+    def load_checkpoint(self, path):
+        st = torch.load(path, map_location=self.policy.device, weights_only=False)
+        self.policy.set_state(st["policy"])
+        self._counters.update(st["counters"])
+        self.iteration = st["iteration"]
+
+    restore = load_checkpoint
+
+    def export_npz(self, path):
+        """Flat numpy export with the reference's key names (best_checkpoints/*.npz layout)."""
+        np.savez(path, **{k: v for k, v in self.policy.get_weights().items()})
+        return path
+
+    def stop(self):
+        try:
+            self.env.close()
+        except Exception:
+            pass
+
+
+class _LocalWorker:
+    def __init__(self, trainer):
+        self._t = trainer
+        self.policy_map = {"default": trainer.policy}
+
+    def foreach_policy(self, fn):
+        return [fn(self._t.policy, "default")]
+
+    def foreach_env(self, fn):
+        return [fn(self._t.env)]
+
+    def set_global_vars(self, gv):
+        self.global_vars = gv
+
+
+class _LocalWorkerSet:
+    """`self.workers` facade: there are no remote rollout workers, every rank is learner and sampler."""
+
+    def __init__(self, trainer):
+        self._w = _LocalWorker(trainer)
+
+    def num_remote_workers(self):
+        return 0
+
+    def local_worker(self):
+        return self._w
+
+    def foreach_worker_with_id(self, fn):
+        return [fn(0, self._w)]
+
+    def sync_weights(self, **kw):
+        return None
