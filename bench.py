@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Headline benchmark: agent-env-steps/sec (sim + learn) of CoPO on Intersection, 40 agent slots x 256 scenes per GPU.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" is one full training iteration of BASELINE.json configs[1] on every rank: an 8-step rollout of
+256 scenes (HIP simulator + policy inference, one hipGraph), the dense postprocess (HIP GAE x3 scan), the
+coordinated-advantage HIP reduction, 5 PPO epochs of 512-row minibatches and 5 LCF meta-update passes (the
+reference's hyper-parameters, algo_ippo.py:22-42 / algo_copo.py:66-72).  `value` = agent rows that acted,
+summed over all ranks, divided by the wall time of the K timed steps (barrier + synchronize on both sides,
+max over ranks).  Weak scaling: every rank owns 256 scenes and a 512-row minibatch; gradients / advantage
+statistics / meta gradients are all-reduced over RCCL.
+
+Extra objects on the JSON line:
+  roofline      the simulator step kernel (the path's dominant custom kernel): algorithmic bytes
+                (202 + 4*O per present agent slot) / mean launch time measured with HIP events
+                on the launch stream, against the 8 TB/s HBM peak.
+  cpu_baseline  the same iteration on the host: scalar C oracle simulator + oracle ops + the same torch code
+                on CPU threads ("port"), on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+CPU_BASELINE_THREADS = 8
+
+
+def make_trainer(num_envs, num_agents, device=None, graphs=True, seed=0):
+    from copo_amd.torch_copo.algo_copo import CoPOTrainer
+    from copo_amd.torch_copo.utils.env_wrappers import MultiAgentIntersectionEnv, get_lcf_env, get_rllib_compatible_env
+    env = get_rllib_compatible_env(get_lcf_env(MultiAgentIntersectionEnv))
+    T = max(1, -(-2000 // num_envs))      # reference train_batch_size = 2000 env steps (algo_ippo.py:25)
+    cfg = dict(env=env, env_config=dict(num_agents=num_agents, neighbours_distance=40), num_envs=num_envs,
+               train_batch_size=T * num_envs, seed=seed, use_hip_graphs=graphs)
+    if device is not None:
+        cfg["device"] = device
+    return CoPOTrainer(config=cfg)
+
+
+def measure_sim_kernel(trainer, launches=200):
+    """Mean duration of `copo_sim_step` launches (HIP events on the launch stream) and the mean number of present
+    agent slots per launch, on the live scenes of the trainer."""
+    sim = trainer.env.sim
+    act = torch.zeros(sim.E, sim.N, 2, device=sim.device)
+    gen = torch.Generator(device=sim.device).manual_seed(1)
+    acts = [torch.stack([torch.randn(sim.E, sim.N, device=sim.device, generator=gen) * 0.1,
+                         torch.rand(sim.E, sim.N, device=sim.device, generator=gen)], -1).contiguous() for _ in range(8)]
+    for i in range(20):
+        sim.step(acts[i % 8])
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    present = 0.0
+    e0.record()
+    for i in range(launches):
+        sim.step(acts[i % 8])
+    e1.record()
+    torch.cuda.synchronize()
+    for i in range(16):
+        out = sim.step(acts[i % 8])
+        present += float(((out["flags"] & 0x41) != 0).sum())
+    del act
+    return e0.elapsed_time(e1) * 1e-3 / launches, present / 16.0
+
+
+def cpu_baseline(num_envs, num_agents, iters=1):
+    """The same iteration on the host: C oracle simulator (scalar, 1 thread) + oracle GAE / LCF-mix + the build's
+    own torch learner on CPU threads.  Test infrastructure used as the measured CPU port, never as product."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(min(CPU_BASELINE_THREADS, os.cpu_count() or 1))   # tiny GEMMs: more threads only hurt
+    from copo_amd.engine import Postprocessing, SampleBatch
+    from copo_amd.sim import SimConfig
+    from copo_amd.torch_copo import algo_copo as A
+    from copo_amd.torch_copo.utils.env_wrappers import MultiAgentIntersectionEnv, get_lcf_env, get_rllib_compatible_env
+    env = get_rllib_compatible_env(get_lcf_env(MultiAgentIntersectionEnv))
+    cfg = A.CoPOConfig()
+    cfg.update_from_dict(dict(env=env, device="cpu", use_hip_graphs=False, env_config=dict(num_agents=num_agents)))
+    cfg.validate()
+    pol = A.CoPOPolicy(cfg.observation_space, cfg.action_space, cfg)
+    E, N = num_envs, num_agents
+    T = max(1, -(-2000 // E))
+    sim = ol.OracleSim(SimConfig(map="intersection", num_envs=E, num_agents=N))
+    O = sim.O
+    obs = torch.from_numpy(sim.reset()["obs"].copy())
+    agent_steps, t0 = 0, time.perf_counter()
+    for _ in range(iters):
+        buf = dict(obs=torch.zeros(T, E, N, O), act=torch.zeros(T, E, N, 2), logp=torch.zeros(T, E, N),
+                   di=torch.zeros(T, E, N, 4), rew3=np.zeros((3, T, E, N), np.float32), flags=np.zeros((T, E, N), np.uint8),
+                   lcf=np.zeros((T, E, N), np.float32))
+        for t in range(T):
+            a, lp, di = pol.compute_actions(obs.view(E * N, O))
+            buf["obs"][t], buf["act"][t], buf["logp"][t], buf["di"][t] = obs, a.view(E, N, 2), lp.view(E, N), di.view(E, N, 4)
+            out = sim.step(a.view(E, N, 2).clamp(-1, 1).numpy())
+            buf["rew3"][0, t], buf["rew3"][1, t] = out["rew"], out["nei_rew"]
+            buf["rew3"][2, t] = out["glob_rew"][:, None]
+            buf["flags"][t], buf["lcf"][t] = out["flags"], out["lcf"]
+            obs = torch.from_numpy(out["obs"].copy())
+        M = E * N
+        vals = pol.value_heads_dense(buf["obs"].view(T * M, O)).view(3, T, M).numpy()
+        adv, tgt = ol.gae3(buf["rew3"].reshape(3, T, M), vals, buf["flags"].reshape(T, M), pol.gae_gammas(), 0.95)
+        valid = (buf["flags"].reshape(-1) & 1) > 0
+        mixed, stats, norm, gstd = ol.lcf_mix(adv[0].ravel(), adv[1].ravel(), adv[2].ravel(), buf["lcf"].ravel(), valid)
+        mean = stats[1] / stats[0]
+        pol._raw_lcf_adv_mean.fill_(mean)
+        pol._raw_lcf_adv_std.fill_(max(1e-4, float(np.sqrt(max(stats[2] / stats[0] - mean * mean, 0)))))
+        f = lambda x: torch.from_numpy(np.ascontiguousarray(x)).view(T, E, N)  # noqa: E731
+        batch = SampleBatch({
+            SampleBatch.OBS: buf["obs"], SampleBatch.ACTIONS: buf["act"], SampleBatch.ACTION_LOGP: buf["logp"],
+            SampleBatch.ACTION_DIST_INPUTS: buf["di"], SampleBatch.FLAGS: torch.from_numpy(buf["flags"]),
+            Postprocessing.ADVANTAGES: f(adv[0]), SampleBatch.VF_PREDS: f(vals[0]), Postprocessing.VALUE_TARGETS: f(tgt[0]),
+            A.NEI_VALUES: f(vals[1]), A.NEI_ADVANTAGE: f(adv[1]), A.NEI_TARGET: f(tgt[1]), A.GLOBAL_VALUES: f(vals[2]),
+            A.GLOBAL_TARGET: f(tgt[2]), A.GLOBAL_ADVANTAGES: f(gstd), "normalized_advantages": f(norm)})
+        idx = torch.from_numpy(np.nonzero(valid)[0])
+        B = int(idx.numel())
+        pol.prepare_sgd(batch, T * M, 512)
+        pol.run_sgd(idx, B, [B], 512, 5)
+        pol.run_meta(idx, B, [B], 512, 5)
+        pol.update_old_policy()
+        agent_steps += B
+    dt = time.perf_counter() - t0
+    sim.close()
+    used = torch.get_num_threads()
+    torch.set_num_threads(prev_threads)
+    return agent_steps / dt, dt, agent_steps, used
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--num-envs", type=int, default=256, help="scenes per GPU (BASELINE configs[1]: 256)")
+    ap.add_argument("--num-agents", type=int, default=40)
+    ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from copo_amd import dist as D
+    rank, local_rank, world = D.init_from_env()
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local_rank)
+    trainer = make_trainer(args.num_envs, args.num_agents, graphs=not args.no_graphs)
+    warm = max(args.warmup, 4 if not args.no_graphs else 0)   # eager warm-ups + graph capture happen untimed
+    for _ in range(warm):
+        trainer.train()
+    D.barrier()
+    torch.cuda.synchronize()
+    a0 = trainer._counters["num_agent_steps_sampled"]
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = trainer.train()
+    torch.cuda.synchronize()
+    D.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    D.all_reduce_max_(tmax)
+    dt = float(tmax.item())
+    agent_steps = trainer._counters["num_agent_steps_sampled"] - a0      # already summed over ranks
+    value = agent_steps / dt
+
+    line = None
+    if rank == 0:
+        sim = trainer.env.sim
+        k_s, present = measure_sim_kernel(trainer)
+        bytes_per_unit = 202 + 4 * sim.O
+        achieved = present * bytes_per_unit / k_s * 1e-9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic_c2.json")
+        if os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get("bytes_per_launch")
+        timers = res["timers"]
+        line = {
+            "metric": "agent-env-steps/sec (sim+learn), Intersection 40-agent", "value": round(value, 1),
+            "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "CoPO Intersection, %d agent slots x %d scenes per GPU, fp32 (BASELINE configs[1])"
+                                   % (sim.N, sim.E), "rollout_steps": trainer.sampler.T,
+                       "sgd_minibatch_size_per_rank": 512, "num_sgd_iter": 5, "lcf_num_iters": 5,
+                       "parallelism": "dp%d" % world, "hip_graphs": not args.no_graphs,
+                       "agent_steps_per_iter": round(agent_steps / args.steps / world, 1),
+                       "sample_ms": round(timers.get("sample_time_ms", 0), 2),
+                       "learn_ms": round(timers.get("learn_time_ms", 0), 2),
+                       "meta_ms": round(timers.get("meta_time_ms", 0), 2)},
+            "roofline": {"bound": "hbm", "kernel": "copo::sim_step_kernel", "achieved": round(achieved, 2),
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
+                         "traffic": traffic, "us_per_launch": round(k_s * 1e6, 2),
+                         "units_per_launch": round(present, 1), "bytes_per_unit": bytes_per_unit},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            v, cdt, n, used = cpu_baseline(args.num_envs, args.num_agents)
+            line["cpu_baseline"] = {"value": round(v, 1), "unit": "agent-steps/s", "cores": used, "kind": "port",
+                                    "sample": "1 iteration of the same workload (%d agent-steps, %.1f s): scalar C oracle "
+                                              "simulator on 1 thread + the build's torch learner on %d CPU threads "
+                                              "(host has %d)" % (n, cdt, used, os.cpu_count() or 0)}
+    trainer.stop()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -96,6 +96,9 @@ def _load():
         raise ImportError(
             "libcopo_hip.so not found at %s -- build it with `python __graft_entry__.py` "
             "(hipcc --offload-arch=gfx950); there is no CPU fallback." % LIB_PATH)
+    # PyTorch-ROCm bundles its own libamdhip64.so.7; load it first so that this library binds to the SAME HIP
+    # runtime (one runtime per process -- two would not share devices, streams or allocations).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)   # AttributeError if the symbol is missing: fail loudly

@@ -298,6 +298,9 @@ class PPOPolicyBase:
         loss.backward()
         st = self.model.tower_stats
         self._row_sources["stats"].add_(torch.stack([st[k].detach().float().reshape(()) for k in self.STAT_KEYS]))
+        for k, v in list(st.items()):      # do not keep the autograd graph (and its AccumulateGrad nodes) alive
+            if torch.is_tensor(v):
+                st[k] = v.detach()
 
     def _apply(self):
         clip = self.config.get("grad_clip")
