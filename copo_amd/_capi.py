@@ -64,7 +64,33 @@ class StepOut(C.Structure):
                                           "nbr_dist", "lcf", "info", "agent_id")]
 
 
+class NetLayout(C.Structure):
+    """Mirror of `copo_net_layout`."""
+    _fields_ = [("w1", C.c_int64), ("b1", C.c_int64), ("w2", C.c_int64), ("b2", C.c_int64), ("w3", C.c_int64),
+                ("b3", C.c_int64), ("in_dim", C.c_int32), ("out_dim", C.c_int32)]
+
+
+class PpoCfg(C.Structure):
+    """Mirror of `copo_ppo_cfg`."""
+    _fields_ = [
+        ("mb", C.c_int32), ("hidden", C.c_int32), ("act_dim", C.c_int32), ("n_value_heads", C.c_int32),
+        ("pack_width", C.c_int32), ("col_actions", C.c_int32), ("col_logp", C.c_int32), ("col_dist", C.c_int32),
+        ("col_adv", C.c_int32), ("col_meta_adv", C.c_int32), ("col_vpred", C.c_int32 * 3), ("col_vtarget", C.c_int32 * 3),
+        ("use_kl", C.c_int32), ("old_value_loss", C.c_int32),
+        ("clip_param", C.c_float), ("vf_clip_param", C.c_float), ("vf_loss_coeff", C.c_float), ("entropy_coeff", C.c_float),
+        ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+        ("pol", NetLayout), ("val", NetLayout * 3),
+    ]
+
+
+HEAD_PPO, HEAD_META_NEW, HEAD_META_OLD = 0, 1, 2
+PPO_STATS = 8
+
 _SIGS = {
+    "copo_ppo_workspace_floats": (C.c_int64, [C.POINTER(PpoCfg)]),
+    "copo_ppo_fused_step_f32": (C.c_int, [C.POINTER(PpoCfg)] + [C.c_void_p] * 14 + [C.c_int32, C.c_int32, C.c_void_p,
+                                                                                   C.c_int32, C.c_void_p]),
+    "copo_adam_step_f32": (C.c_int, [C.POINTER(PpoCfg)] + [C.c_void_p] * 4 + [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "copo_version": (C.c_int, []),
     "copo_last_error": (C.c_char_p, []),
     "copo_sim_create": (C.c_int, [C.POINTER(SimCfg), C.c_int, C.POINTER(C.c_void_p)]),

@@ -1,0 +1,133 @@
+"""Host side of the fused minibatch learner (`copo_ppo_fused_step_f32`, include/copo_hip.h).
+
+`FusedLearner` re-homes every fp32 parameter of a policy's model into ONE flat device buffer (the
+nn.Parameters become views, so inference / checkpoints / state_dict keep working), owns the flat Adam
+moments and step counter, and issues the 7-kernel SGD step.  Used by `PPOPolicyBase.run_sgd` and by
+`CoPOPolicy.run_meta` (head modes META_NEW / META_OLD give the two policy gradients of the LCF meta update).
+"""
+import ctypes as C
+
+import torch
+
+from . import _capi
+
+
+def _mlp_layers(seq_or_list):
+    """[SlimFC, ...] -> list of nn.Linear."""
+    return [m._model[0] for m in seq_or_list]
+
+
+class FlatParams:
+    """All fp32 parameters of a module in one flat buffer (parameters become views into it)."""
+
+    def __init__(self, module, device):
+        self.params = [p for p in module.parameters() if p.dtype == torch.float32]
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(n, dtype=torch.float32, device=device)
+        self.offset = {}
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                k = p.numel()
+                self.flat[off:off + k].copy_(p.data.reshape(-1))
+                p.data = self.flat[off:off + k].view_as(p)
+                self.offset[id(p)] = off
+                off += k
+        self.numel = n
+
+    def layout(self, linears, in_dim, out_dim):
+        l1, l2, l3 = linears
+        o = self.offset
+        return _capi.NetLayout(o[id(l1.weight)], o[id(l1.bias)], o[id(l2.weight)], o[id(l2.bias)], o[id(l3.weight)],
+                               o[id(l3.bias)], int(in_dim), int(out_dim))
+
+
+def model_layouts(model, flat):
+    """(policy layout, [value layouts]) for FullyConnectedModel / CCModel / CoPOModel."""
+    hid = _mlp_layers(model._hidden_layers)
+    assert len(hid) == 2 and hid[0].out_features == hid[1].out_features, "fused learner: two equal hidden layers"
+    pol = flat.layout(hid + [model._logits._model[0]], hid[0].in_features, model._logits._model[0].out_features)
+    vh = _mlp_layers(model._value_branch_separate)
+    vals = [flat.layout(vh + [model._value_branch._model[0]], vh[0].in_features, 1)]
+    for name in ("nei_value_network", "global_value_network"):
+        net = getattr(model, name, None)
+        if net is not None:
+            ls = _mlp_layers(net)
+            vals.append(flat.layout(ls, ls[0].in_features, 1))
+    return pol, vals, hid[0].out_features
+
+
+class FusedLearner:
+    def __init__(self, policy, columns, mb, adv_key, meta_adv_key=None):
+        """columns: [(name, width)] of the row pack; adv_key: pack column used as the PPO advantage."""
+        self.policy = policy
+        dev = policy.device
+        cfg = policy.config
+        model = policy.model
+        self.flat = FlatParams(model, dev)
+        pol, vals, H = model_layouts(model, self.flat)
+        self.n_policy = sum(p.numel() for p in model.policy_parameters())
+        assert max(pol.w1, pol.b1, pol.w2, pol.b2, pol.w3, pol.b3) < self.n_policy, \
+            "the policy net must occupy the first block of the flat parameter buffer"
+        col, off = {}, 0
+        for name, w in columns:
+            col[name] = off
+            off += w
+        c = _capi.PpoCfg()
+        c.mb, c.hidden, c.act_dim, c.n_value_heads, c.pack_width = int(mb), int(H), 2, len(vals), off
+        c.col_actions, c.col_logp, c.col_dist = col["actions"], col["action_logp"], col["action_dist_inputs"]
+        c.col_adv = col[adv_key]
+        c.col_meta_adv = col[meta_adv_key] if meta_adv_key else col[adv_key]
+        vp = ["vf_preds", "nei_values", "global_values"]
+        vt = ["value_targets", "nei_target", "global_target"]
+        for g in range(len(vals)):
+            c.col_vpred[g], c.col_vtarget[g] = col[vp[g]], col[vt[g]]
+            c.val[g] = vals[g]
+        c.pol = pol
+        c.use_kl = 1 if cfg["kl_coeff"] > 0.0 else 0
+        c.old_value_loss = 1 if cfg["old_value_loss"] else 0
+        c.clip_param, c.vf_clip_param = float(cfg["clip_param"]), float(cfg["vf_clip_param"])
+        c.vf_loss_coeff, c.entropy_coeff = float(cfg["vf_loss_coeff"]), float(policy.entropy_coeff)
+        c.lr, c.beta1, c.beta2, c.eps = float(cfg["lr"]), 0.9, 0.999, 1e-8
+        self.cfg = c
+        n = self.flat.numel
+        self.adam_m = torch.zeros(n, device=dev)
+        self.adam_v = torch.zeros(n, device=dev)
+        self.grad = torch.zeros(n, device=dev)
+        self.step_count = torch.zeros(1, dtype=torch.int64, device=dev)
+        ws = _capi.lib.copo_ppo_workspace_floats(C.byref(c))
+        self.workspace = torch.zeros(int(ws), device=dev)
+        self.stats = torch.zeros(_capi.PPO_STATS, device=dev)
+        self.target_flat = None
+
+    def attach_target(self, target_model):
+        """Flat view of the target network (same layout as the model) for the META_OLD pass."""
+        self.target_flat = FlatParams(target_model, self.policy.device)
+        assert self.target_flat.numel == self.flat.numel
+
+    def step(self, rs, head_mode=_capi.HEAD_PPO, apply_adam=True, theta=None, grad=None, stats=None, bump_index=True):
+        """One fused minibatch pass over the sources bound in `rs` (PPOPolicyBase._row_sources layout)."""
+        cc = rs["cc_obs"]
+        kl = self.policy.kl_coeff
+        _capi.check(_capi.lib.copo_ppo_fused_step_f32(
+            C.byref(self.cfg), (self.flat.flat if theta is None else theta).data_ptr(), self.adam_m.data_ptr(),
+            self.adam_v.data_ptr(), (self.grad if grad is None else grad).data_ptr(), rs["obs"].data_ptr(),
+            None if cc is None else cc.data_ptr(), rs["pack"].data_ptr(), rs["rows_all"].data_ptr(),
+            rs["w_all"].data_ptr(), rs["denom_all"].data_ptr(), kl.data_ptr(), self.step_count.data_ptr(),
+            self.workspace.data_ptr(), None if stats is None else stats.data_ptr(), 1 if apply_adam else 0,
+            int(head_mode), rs["k"].data_ptr(), 1 if bump_index else 0, _capi.current_stream()))
+
+    def adam(self, rs, grad=None):
+        """Adam on the flat buffers after a gradient all-reduce; advances the minibatch index."""
+        _capi.check(_capi.lib.copo_adam_step_f32(
+            C.byref(self.cfg), self.flat.flat.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr(),
+            (self.grad if grad is None else grad).data_ptr(), self.flat.numel, self.step_count.data_ptr(),
+            rs["k"].data_ptr(), _capi.current_stream()))
+
+    def state(self):
+        return dict(adam_m=self.adam_m.clone(), adam_v=self.adam_v.clone(), step=self.step_count.clone())
+
+    def load_state(self, st):
+        self.adam_m.copy_(st["adam_m"])
+        self.adam_v.copy_(st["adam_v"])
+        self.step_count.copy_(st["step"])

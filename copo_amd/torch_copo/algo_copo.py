@@ -133,6 +133,8 @@ class CoPOPolicy(CCPPOPolicy):
     def __init__(self, observation_space, action_space, config):
         super().__init__(observation_space, action_space, config)
         self.target_model = self.make_model("copo_target_model").to(self.device)
+        if self.fused is not None:
+            self.fused.attach_target(self.target_model)
         self.update_old_policy()
         self._lcf_optimizer = torch.optim.Adam([self.model.lcf_parameters], lr=self.config[LCF_LR],
                                                capturable=self.device.type == "cuda")
@@ -164,6 +166,9 @@ class CoPOPolicy(CCPPOPolicy):
         b[NEI_VALUES], b[NEI_ADVANTAGE], b[NEI_TARGET] = (x[1].view(T, E, N) for x in (vals, adv, tgt))
         b[GLOBAL_VALUES], b[GLOBAL_ADVANTAGES], b[GLOBAL_TARGET] = (x[2].view(T, E, N) for x in (vals, adv, tgt))
         return b
+
+    def fused_adv_keys(self):
+        return "normalized_advantages", GLOBAL_ADVANTAGES
 
     def train_columns(self):
         return super().train_columns() + [(NEI_VALUES, 1), (NEI_TARGET, 1), (GLOBAL_VALUES, 1), (GLOBAL_TARGET, 1),
@@ -267,7 +272,36 @@ class CoPOPolicy(CCPPOPolicy):
         return out
 
     # static-shape (graph-capturable) meta loop over the rows bound by prepare_sgd --------------------------------
+    def _meta_step_a_fused(self):
+        """Both policy gradients from the fused HIP learner (head modes META_NEW / META_OLD, no Adam), the
+        two-scalar LCF part in torch fp64."""
+        from copo_amd import _capi
+        mb_, fz = self._meta_bufs, self.fused
+        rs = dict(self._row_sources, **{k: mb_[k] for k in ("rows_all", "w_all", "denom_all", "k")})
+        n = mb_["n_pol"]
+        mb_["stats_new"].zero_()
+        mb_["stats_old"].zero_()
+        fz.step(rs, head_mode=_capi.HEAD_META_NEW, apply_adam=False, grad=mb_["g_new"], stats=mb_["stats_new"],
+                bump_index=False)
+        fz.step(rs, head_mode=_capi.HEAD_META_OLD, apply_adam=False, theta=fz.target_flat.flat, grad=mb_["g_old"],
+                stats=mb_["stats_old"], bump_index=False)
+        k = mb_["k"]
+        rows = mb_["rows_all"].index_select(0, k).view(-1)
+        w = mb_["w_all"].index_select(0, k).view(-1).double()
+        denom = mb_["denom_all"].index_select(0, k).view(()).double()
+        pk = rs["pack"].index_select(0, rows)
+        eps = mb_["eps_all"].index_select(0, k).view(-1)
+        coordinated = self.model.compute_coordinated(ego=pk[:, mb_["col_adv"]], neighbor=pk[:, mb_["col_nei_adv"]], eps=eps)
+        lcf_loss = (((coordinated - self._raw_lcf_adv_mean) / self._raw_lcf_adv_std) * w).sum() / denom
+        d_lcf = torch.autograd.grad(lcf_loss, self.model.lcf_parameters)[0]
+        mb_["flat"].copy_(torch.cat([mb_["g_new"][:n].double(), mb_["g_old"][:n].double(), d_lcf.double(),
+                                     lcf_loss.detach().double().reshape(1)]))
+        mb_["stats_a"].copy_(torch.stack([mb_["stats_new"][1].double(), mb_["stats_old"][1].double(),
+                                          ((coordinated.detach() * w).sum() / denom), mb_["stats_new"][7].double()]))
+
     def _meta_step_a(self):
+        if self.fused is not None:
+            return self._meta_step_a_fused()
         mb_ = self._meta_bufs
         rs = dict(self._row_sources, **{k: mb_[k] for k in ("rows_all", "w_all", "denom_all", "k")})
         saved, self._row_sources = self._row_sources, rs
@@ -308,7 +342,18 @@ class CoPOPolicy(CCPPOPolicy):
                 eps_all=torch.zeros(max_mb, mb, dtype=torch.float64, device=dev),
                 flat=torch.zeros(2 * n_pol + 3, dtype=torch.float64, device=dev),
                 stats_a=torch.zeros(4, dtype=torch.float64, device=dev),
-                stats=torch.zeros(len(self.META_KEYS), dtype=torch.float64, device=dev))
+                stats=torch.zeros(len(self.META_KEYS), dtype=torch.float64, device=dev), n_pol=n_pol)
+            if self.fused is not None:
+                assert mb == self.fused.cfg.mb, "the fused learner is built for one minibatch size"
+                cols, off = {}, 0
+                for name, wdt in self.train_columns():
+                    cols[name] = off
+                    off += wdt
+                nflat = self.fused.flat.numel
+                self._meta_bufs.update(
+                    g_new=torch.zeros(nflat, device=dev), g_old=torch.zeros(nflat, device=dev),
+                    stats_new=torch.zeros(8, device=dev), stats_old=torch.zeros(8, device=dev),
+                    col_adv=cols[Postprocessing.ADVANTAGES], col_nei_adv=cols[NEI_ADVANTAGE])
             self._meta = None
         if self._meta is None:
             if D.is_dist():
@@ -339,7 +384,13 @@ class CoPOPolicy(CCPPOPolicy):
         return out
 
     def update_old_policy(self):
-        self.target_model.load_state_dict(self.model.state_dict())
+        fz = self.fused
+        if fz is not None and fz.target_flat is not None:     # one flat copy instead of 24 tensor copies
+            with torch.no_grad():
+                fz.target_flat.flat.copy_(fz.flat.flat)
+                self.target_model.lcf_parameters.data.copy_(self.model.lcf_parameters.data)
+        else:
+            self.target_model.load_state_dict(self.model.state_dict())
 
     def assign_lcf(self, lcf_parameters, lcf_mean, lcf_std=None, my_name=None):
         """Copy LCF parameters into this policy and check the derived mean/std (algo_copo.py:446-471)."""

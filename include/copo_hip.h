@@ -190,6 +190,53 @@ int copo_lcf_mix_partial_f32(const float* adv, const float* nei_adv, const float
 int copo_lcf_mix_apply_f32(const float* mixed, const float* glob_adv, const uint8_t* valid, int64_t B,
                            const double* stats, float* norm_adv, float* glob_adv_std, void* stream);
 
+/* ---- fused minibatch learner --------------------------------------------------------------------------------
+ * Replaces, for one static-shape minibatch, `Policy.loss` + autograd + Adam of the reference
+ * (algo_ippo.py:78-172, algo_ccppo.py:376-472, algo_copo.py:311-424; RLlib train_one_step, algo_copo.py:555-558)
+ * and the two policy-gradient evaluations of `CoPOPolicy.meta_update` (algo_copo.py:250-278).
+ * All fp32 parameters of the model live in ONE flat buffer `theta`; a net is obs -> H -> H -> out (tanh). */
+typedef struct copo_net_layout {
+    int64_t w1, b1, w2, b2, w3, b3;   /* offsets (floats) into theta; weights are [out][in] row-major */
+    int32_t in_dim, out_dim;
+} copo_net_layout;
+
+#define COPO_HEAD_PPO 0        /* full PPO loss: policy net + value heads */
+#define COPO_HEAD_META_NEW 1   /* policy net only, loss = mean(-clipped surrogate) with the global advantage */
+#define COPO_HEAD_META_OLD 2   /* policy net only, loss = mean(logp(action))  (target network)           */
+#define COPO_PPO_STATS 8       /* sums of: total, policy, vf_ego, kl, entropy, vf_nei, vf_glob, advantage  */
+
+typedef struct copo_ppo_cfg {
+    int32_t mb;                /* rows per minibatch (static shape; padded rows carry weight 0) */
+    int32_t hidden;            /* H: width of both hidden layers */
+    int32_t act_dim;           /* 2 */
+    int32_t n_value_heads;     /* 1 (IPPO / CCPPO) or 3 (CoPO: ego, neighbourhood, global) */
+    int32_t pack_width;        /* floats per row of pack_src */
+    int32_t col_actions, col_logp, col_dist, col_adv, col_meta_adv;  /* pack columns */
+    int32_t col_vpred[3], col_vtarget[3];
+    int32_t use_kl, old_value_loss;
+    float clip_param, vf_clip_param, vf_loss_coeff, entropy_coeff;
+    float lr, beta1, beta2, eps;   /* Adam (torch.optim.Adam semantics, no weight decay) */
+    copo_net_layout pol, val[3];
+} copo_ppo_cfg;
+
+/* floats of `workspace` needed for this configuration */
+int64_t copo_ppo_workspace_floats(const copo_ppo_cfg* cfg);
+/* One minibatch step.  rows [mb] index the dense sources (obs_src [R][pol.in_dim], cc_src [R][val.in_dim] or NULL
+ * = obs_src, pack_src [R][pack_width]); w [mb] row weights; denom [1] = global number of valid rows (device);
+ * apply_adam = 1: parameters and Adam moments are updated in the epilogues and *step is incremented;
+ * apply_adam = 0: only `grad` (flat, same layout as theta) is written.  stats (may be NULL) accumulates.
+ * mb_index (device int64, may be NULL = 0) selects the minibatch k: rows / w are then [n_mb][mb] tables and denom
+ * is [n_mb]; bump_index = 1 increments *mb_index at the end, so that a captured hipGraph of this call walks the
+ * epoch plan by itself. */
+int copo_ppo_fused_step_f32(const copo_ppo_cfg* cfg, float* theta, float* adam_m, float* adam_v, float* grad,
+                            const float* obs_src, const float* cc_src, const float* pack_src, const int64_t* rows,
+                            const float* w, const float* denom, const float* kl_coeff, int64_t* step,
+                            float* workspace, float* stats, int32_t apply_adam, int32_t head_mode,
+                            int64_t* mb_index, int32_t bump_index, void* stream);
+/* Adam on the flat buffers (the data-parallel path: after the gradient all-reduce) */
+int copo_adam_step_f32(const copo_ppo_cfg* cfg, float* theta, float* adam_m, float* adam_v, const float* grad,
+                       int64_t n, int64_t* step, int64_t* mb_index, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,173 @@
+"""Fused HIP minibatch learner (copo_ppo_fused_step_f32) vs the torch implementation of the same step --
+which itself is pinned to the reference's `loss` / `meta_update` golden vectors by tests/test_host_golden.py.
+Compared: loss statistics, every parameter gradient, parameters and Adam moments after real steps."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from copo_amd.engine import Box, Postprocessing, SampleBatch, TorchDiagGaussian  # noqa: E402
+
+
+def _make(pcls_name, fuse, odim, fused, hiddens=(256, 256), mb=512, **over):
+    from copo_amd.torch_copo import algo_ccppo as C, algo_copo as A, algo_ippo as I
+    from copo_amd.torch_copo.utils.env_wrappers import (MultiAgentIntersectionEnv, get_ccenv, get_lcf_env,
+                                                        get_rllib_compatible_env)
+    pcls, ccls = dict(copo=(A.CoPOPolicy, A.CoPOConfig), ccppo=(C.CCPPOPolicy, C.CCPPOConfig),
+                      ippo=(I.IPPOPolicy, I.IPPOConfig))[pcls_name]
+    cfg = ccls()
+    env = get_rllib_compatible_env(get_lcf_env(MultiAgentIntersectionEnv) if pcls_name == "copo"
+                                   else get_ccenv(MultiAgentIntersectionEnv))
+    cfg.update_from_dict(dict(env=env, device="cuda", use_hip_graphs=False, use_fused_learner=fused, seed=3,
+                              sgd_minibatch_size=mb, model={"fcnet_hiddens": list(hiddens)}, **over))
+    if "fuse_mode" in cfg:
+        cfg.fuse_mode = fuse
+    cfg.validate()
+    return pcls(Box(-1, 1, (odim,)), Box(-1, 1, (2,)), cfg)
+
+
+def _dense_batch(pol, R, odim, seed=0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, device="cuda", generator=g)  # noqa: E731
+    b = SampleBatch()
+    b[SampleBatch.OBS] = torch.rand(R, odim, device="cuda", generator=g) * 2 - 1
+    cdim = pol.model.value_input_dim()
+    if cdim != odim:
+        b["centralized_critic_obs"] = torch.cat([b[SampleBatch.OBS], rn(R, cdim - odim) * 0.5], 1)
+    b[SampleBatch.ACTIONS] = rn(R, 2) * 0.8
+    di = torch.cat([rn(R, 2) * 0.3, rn(R, 2) * 0.2 - 0.2], 1)
+    b[SampleBatch.ACTION_DIST_INPUTS] = di
+    b[SampleBatch.ACTION_LOGP] = TorchDiagGaussian(di).logp(b[SampleBatch.ACTIONS])
+    for k, s in [(Postprocessing.ADVANTAGES, 2), (SampleBatch.VF_PREDS, 3), ("nei_advantage", 2), ("global_advantages", 1),
+                 ("nei_values", 3), ("global_values", 30), ("normalized_advantages", 1)]:
+        b[k] = rn(R) * s
+    b[Postprocessing.VALUE_TARGETS] = b[SampleBatch.VF_PREDS] + rn(R) * 2 + rn(R) * 150 * (torch.rand(R, device="cuda", generator=g) < 0.3)
+    b["nei_target"] = b["nei_values"] + rn(R) * 2
+    b["global_target"] = b["global_values"] + rn(R) * 120
+    b[SampleBatch.FLAGS] = torch.ones(R, dtype=torch.uint8, device="cuda")
+    return b
+
+
+def _copy_weights(dst, src):
+    dst.model.load_state_dict(src.model.state_dict())
+    if hasattr(dst, "target_model"):
+        dst.target_model.load_state_dict(src.target_model.state_dict())
+
+
+@pytest.mark.parametrize("name,fuse,odim,over", [
+    ("copo", "none", 92, {}),
+    ("copo", "none", 92, dict(kl_coeff=0.0, old_value_loss=False, vf_clip_param=10.0, entropy_coeff=0.01)),
+    ("ippo", "none", 91, {}),
+    ("ccppo", "mf", 91, {}),
+    ("ccppo", "concat", 91, {}),
+    ("copo", "none", 260, {}),
+])
+def test_fused_sgd_matches_torch(name, fuse, odim, over):
+    R, mb = 1500, 512
+    ref = _make(name, fuse, odim, fused=False, **over)
+    fz = _make(name, fuse, odim, fused=True, **over)
+    assert fz.fused is not None and ref.fused is None
+    _copy_weights(fz, ref)
+    with torch.no_grad():                       # move off the near-zero head init
+        for p in ref.model.parameters():
+            if p.dtype == torch.float32:
+                p.add_(torch.randn_like(p) * 0.05)
+    _copy_weights(fz, ref)
+    batch = _dense_batch(ref, R, odim)
+    idx = torch.arange(R, device="cuda")[torch.randperm(R, device="cuda")][:1337].contiguous()
+    B = int(idx.numel())
+    for pol in (ref, fz):
+        pol.prepare_sgd(batch, R, mb)
+        torch.manual_seed(11)
+        pol.plan_epoch(idx, B, [B], mb)
+    # identical plans (same seed) -> compare gradients of minibatch 0
+    assert torch.equal(ref._row_sources["rows_all"], fz._row_sources["rows_all"])
+    ref._ensure_flat_grads()
+    ref._forward_backward()
+    fz.fused.stats.zero_()
+    fz.fused.step(fz._row_sources, apply_adam=False, stats=fz.fused.stats, bump_index=False)
+    g_ref, g_fz = ref._flat_grad, fz.fused.grad
+    scale = float(g_ref.abs().max())
+    err = float((g_ref - g_fz).abs().max())
+    assert err <= 2e-4 * scale + 1e-7, (err, scale)
+    st = ref._row_sources["stats"].tolist()          # total, policy, vf, kl, entropy, (nei, glob, adv)
+    fs = fz.fused.stats.tolist()                     # total, policy, vf_ego, kl, entropy, vf_nei, vf_glob, adv
+    np.testing.assert_allclose(fs[:5], st[:5], rtol=2e-4, atol=1e-5)
+    if name == "copo":
+        np.testing.assert_allclose(fs[5:8], st[5:8], rtol=2e-4, atol=1e-5)
+    # three real optimisation steps: parameters must track torch.optim.Adam
+    ref._row_sources["k"].zero_()
+    for _ in range(3):
+        ref._forward_backward()
+        ref._apply()
+        fz.fused.step(fz._row_sources, stats=fz.fused.stats)
+    assert int(fz._row_sources["k"]) == 3 and int(fz.fused.step_count) == 3
+    for (n1, p1), (n2, p2) in zip(ref.model.named_parameters(), fz.model.named_parameters()):
+        if p1.dtype != torch.float32:
+            continue
+        diff = (p1 - p2).abs()
+        # Adam's first steps move every weight by ~lr * sign(g): elements whose gradient is at the fp32 noise
+        # floor may legitimately take a different sign; everything else must agree to a fraction of one step
+        assert float((diff > 3e-5).float().mean()) < 2e-3, (n1, float(diff.max()))
+        assert float(diff.max()) <= 3 * 2 * 3e-4 + 1e-6, (n1, float(diff.max()))
+
+
+def test_fused_meta_gradients_match_autograd():
+    """META_NEW / META_OLD head modes == the two autograd.grad calls of CoPOPolicy.meta_update (algo_copo.py:250-272)."""
+    from copo_amd import _capi
+    R, mb, odim = 1200, 512, 92
+    ref = _make("copo", "none", odim, fused=False)
+    fz = _make("copo", "none", odim, fused=True)
+    with torch.no_grad():
+        for p in list(ref.model.parameters()) + list(ref.target_model.parameters()):
+            if p.dtype == torch.float32:
+                p.add_(torch.randn_like(p) * 0.05)
+    _copy_weights(fz, ref)
+    batch = _dense_batch(ref, R, odim, seed=5)
+    idx = torch.arange(R, device="cuda")
+    for pol in (ref, fz):
+        pol.prepare_sgd(batch, R, mb)
+        torch.manual_seed(1)
+        pol.plan_epoch(idx, R, [R], mb)
+    ref._raw_lcf_adv_mean.fill_(0.3)
+    ref._raw_lcf_adv_std.fill_(2.0)
+    tb = ref._gather_minibatch()
+    eps = torch.randn(mb, dtype=torch.float64, device="cuda")
+    flat, stats = ref._meta_pieces(tb, eps)
+    n = sum(p.numel() for p in ref.model.policy_parameters())
+    rs = fz._row_sources
+    g_new, g_old = torch.zeros_like(fz.fused.grad), torch.zeros_like(fz.fused.grad)
+    s_new, s_old = torch.zeros(8, device="cuda"), torch.zeros(8, device="cuda")
+    fz.fused.step(rs, head_mode=_capi.HEAD_META_NEW, apply_adam=False, grad=g_new, stats=s_new, bump_index=False)
+    fz.fused.step(rs, head_mode=_capi.HEAD_META_OLD, apply_adam=False, theta=fz.fused.target_flat.flat, grad=g_old,
+                  stats=s_old, bump_index=False)
+    # autograd order: model.policy_parameters() = hidden layers then logits == first block of the flat buffer
+    a_new, a_old = flat[:n].float(), flat[n:2 * n].float()
+    for a, g in ((a_new, g_new[:n]), (a_old, g_old[:n])):
+        scale = float(a.abs().max())
+        assert float((a - g).abs().max()) <= 2e-4 * scale + 1e-8
+    np.testing.assert_allclose(float(s_new[1]), float(stats["new_policy_ego_loss"]), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(float(s_old[1]), float(stats["old_policy_logp_loss"]), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(float(s_new[7]), float(stats["global_adv"]), rtol=1e-4, atol=1e-6)
+
+
+def test_fused_trainer_iteration_and_graph_replay():
+    """End to end: CoPO iterations with the fused learner inside hipGraphs keep learning signals finite and move
+    the LCF; the eager-torch trainer on the same seeds sees the same batch sizes."""
+    from copo_amd.torch_copo.algo_copo import CoPOTrainer
+    from copo_amd.torch_copo.utils.env_wrappers import MultiAgentIntersectionEnv, get_lcf_env, get_rllib_compatible_env
+    env = get_rllib_compatible_env(get_lcf_env(MultiAgentIntersectionEnv))
+    algo = CoPOTrainer(config=dict(env=env, env_config=dict(num_agents=12), num_envs=16, train_batch_size=16 * 8,
+                                   sgd_minibatch_size=128, num_sgd_iter=2, lcf_num_iters=2, seed=1,
+                                   model={"fcnet_hiddens": [64, 64]}))
+    assert algo.policy.fused is not None
+    lcf0 = algo.policy.model.lcf_parameters.detach().clone()
+    for _ in range(5):
+        res = algo.train()
+        st = res["info"]["learner"]["default"]["learner_stats"]
+        assert all(np.isfinite(v) for v in st.values()), st
+    assert not torch.equal(lcf0, algo.policy.model.lcf_parameters.detach())
+    w = algo.policy.model._hidden_layers[0]._model[0].weight
+    assert w.data_ptr() >= algo.policy.fused.flat.flat.data_ptr()      # parameters are views of the flat buffer
+    algo.stop()
