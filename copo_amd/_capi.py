@@ -79,7 +79,7 @@ class PpoCfg(C.Structure):
         ("use_kl", C.c_int32), ("old_value_loss", C.c_int32),
         ("clip_param", C.c_float), ("vf_clip_param", C.c_float), ("vf_loss_coeff", C.c_float), ("entropy_coeff", C.c_float),
         ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-        ("pol", NetLayout), ("val", NetLayout * 3),
+        ("pol", NetLayout), ("val", NetLayout * 3), ("n_params", C.c_int64),
     ]
 
 
@@ -91,6 +91,11 @@ _SIGS = {
     "copo_ppo_fused_step_f32": (C.c_int, [C.POINTER(PpoCfg)] + [C.c_void_p] * 14 + [C.c_int32, C.c_int32, C.c_void_p,
                                                                                    C.c_int32, C.c_void_p]),
     "copo_adam_step_f32": (C.c_int, [C.POINTER(PpoCfg)] + [C.c_void_p] * 4 + [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "copo_meta_grads_f32": (C.c_int, [C.POINTER(PpoCfg)] + [C.c_void_p] * 14),
+    "copo_meta_lcf_f64": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 4 + [C.c_int32] +
+                          [C.c_void_p] * 5),
+    "copo_meta_finish_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "copo_version": (C.c_int, []),
     "copo_last_error": (C.c_char_p, []),
     "copo_sim_create": (C.c_int, [C.POINTER(SimCfg), C.c_int, C.POINTER(C.c_void_p)]),

@@ -9,15 +9,17 @@
 //   H    heads (256 -> 4 / 1), the PPO loss terms and their ANALYTIC gradient w.r.t. the head outputs,
 //        dz2 = (dout W3) * (1 - h2^2), per-tile partials of dW3 / db3, loss statistics
 //   B2x  dz1 = (dz2 W2) * (1 - h1^2)
-//   B2w  dW2 = dz2^T [h1 | 1]  (+ Adam update in the epilogue)
-//   B1w  dW1 = dz1^T [X  | 1]  (+ Adam)
-//   A3   fold the dW3 partials (+ Adam), bump the step counter
+//   B2w  partial dW2 = dz2^T [h1 | 1]    rows split KSPLIT ways across workgroups (fixed split -> deterministic)
+//   B1w  partial dW1 = dz1^T [X  | 1]
+//   R    fold the split / tile partials in a fixed order, then Adam (or store the flat gradient)
 //
 // GEMMs are 64x64 output tiles per 256-thread workgroup, 4 waves x one 32x32 fp32 MFMA accumulator
-// (v_mfma_f32_32x32x2_f32: exact fp32 products at the fp32 vector rate), K staged through LDS in slabs of 16.
-// With apply_adam = 0 the kernels only write the flat gradient (data-parallel runs all-reduce it and call
-// copo_adam_step_f32); the same F/B kernels with head mode META_NEW / META_OLD produce the two policy
-// gradients of the LCF meta update (algo_copo.py:250-278).
+// (v_mfma_f32_32x32x2_f32: exact fp32 products at the fp32 vector rate), K staged through LDS in slabs of 32
+// with register prefetch of the next slab.
+//
+// The LCF meta update (algo_copo.py:228-309) reuses the same kernels in a 2-group mode: group 0 = current policy
+// with loss mean(-clipped surrogate(global advantage)), group 1 = target policy with loss mean(logp); two tiny
+// kernels then evaluate the fp64 LCF terms and apply <g_new, g_old> * dS/dlcf with Adam on the two LCF scalars.
 #include <cstring>
 
 #include "sim_common.h"
@@ -28,86 +30,122 @@ namespace copo {
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-constexpr int TM = 64, TN = 64, TK = 16, LDP = 68;   // LDP: padded LDS row (floats)
+constexpr int TM = 64, TN = 64, TK = 32, LDP = 68;   // LDP: padded LDS row (floats)
 constexpr int HT = 32;                                // rows per workgroup of the head kernel
+constexpr int MODE_META_BOTH = 3;                     // internal: group 0 = META_NEW on theta, group 1 = META_OLD on theta2
 
 struct FusedArgs {
     copo_ppo_cfg c;
     float* theta;
+    float* theta2;             // META_BOTH: target-network parameters (group 1)
     float* adam_m;
     float* adam_v;
     float* grad;
+    float* grad2;              // META_BOTH: gradient of group 1
     const float* obs_src;
     const float* cc_src;
     const float* pack_src;
-    const int64_t* rows;       // [mb]
-    const float* w;            // [mb] row weights (1 valid / 0 padding)
-    const float* denom;        // [1] global number of valid rows
+    const int64_t* rows;       // [n_mb][mb]
+    const float* w;            // [n_mb][mb] row weights (1 valid / 0 padding)
+    const float* denom;        // [n_mb] global number of valid rows
     const float* kl_coeff;     // [1]
     const int64_t* step;       // [1] Adam step counter BEFORE this step
     float* ws;                 // workspace, layout below
     float* stats;              // [COPO_PPO_STATS] accumulated sums
+    float* stats2;             // META_BOTH: statistics of group 1
     int32_t apply_adam;
     int32_t head_mode;
-    int32_t groups;            // nets processed: 1 (policy only) or 1 + n_value_heads
-    const int64_t* kptr;       // [1] device minibatch index k: rows/w are [*][mb] tables, denom is [*]; NULL -> 0
+    int32_t groups;            // nets processed
+    int32_t ksplit;            // row splits of the weight-gradient GEMMs
+    const int64_t* kptr;       // [1] device minibatch index k; NULL -> 0
     int32_t bump_k;            // increment *kptr at the end of this call
 };
 
 __device__ __forceinline__ int64_t kbase(const FusedArgs& a) { return a.kptr ? a.kptr[0] : 0; }
-__device__ __forceinline__ int64_t row_of(const FusedArgs& a, int m) { return a.rows[kbase(a) * a.c.mb + m]; }
-__device__ __forceinline__ float w_of(const FusedArgs& a, int m) { return a.w[kbase(a) * a.c.mb + m]; }
-__device__ __forceinline__ float denom_of(const FusedArgs& a) { return a.denom[kbase(a)]; }
+__device__ __forceinline__ bool both(const FusedArgs& a) { return a.head_mode == MODE_META_BOTH; }
+__device__ __forceinline__ const copo_net_layout& net_of(const FusedArgs& a, int g) {
+    return (g == 0 || both(a)) ? a.c.pol : a.c.val[g - 1];
+}
+__device__ __forceinline__ float* theta_of(const FusedArgs& a, int g) { return (both(a) && g == 1) ? a.theta2 : a.theta; }
+__device__ __forceinline__ float* grad_of(const FusedArgs& a, int g) { return (both(a) && g == 1) ? a.grad2 : a.grad; }
+__device__ __forceinline__ float* stats_of(const FusedArgs& a, int g) { return (both(a) && g == 1) ? a.stats2 : a.stats; }
+__device__ __forceinline__ int mode_of(const FusedArgs& a, int g) {
+    return both(a) ? (g == 0 ? COPO_HEAD_META_NEW : COPO_HEAD_META_OLD) : a.head_mode;
+}
+__device__ __forceinline__ bool is_policy(const FusedArgs& a, int g) { return g == 0 || both(a); }
+__device__ __forceinline__ const float* src_of(const FusedArgs& a, int g) { return is_policy(a, g) ? a.obs_src : a.cc_src; }
 
-// workspace layout (floats), G = 4 nets max, mb rows, H hidden
+// workspace layout (floats): 4 activation slabs x 4 groups, head partials, split partials (2 regions)
 __device__ __host__ inline size_t ws_h1(const copo_ppo_cfg& c, int g) { return (size_t)g * c.mb * c.hidden; }
 __device__ __host__ inline size_t ws_h2(const copo_ppo_cfg& c, int g) { return (size_t)(4 + g) * c.mb * c.hidden; }
 __device__ __host__ inline size_t ws_dz2(const copo_ppo_cfg& c, int g) { return (size_t)(8 + g) * c.mb * c.hidden; }
 __device__ __host__ inline size_t ws_dz1(const copo_ppo_cfg& c, int g) { return (size_t)(12 + g) * c.mb * c.hidden; }
-__device__ __host__ inline size_t ws_p3(const copo_ppo_cfg& c) { return (size_t)16 * c.mb * c.hidden; }
-// dW3 partials: [g][tile][out<=4][H+1]
-__device__ __host__ inline size_t ws_p3_at(const copo_ppo_cfg& c, int g, int tile) {
-    const int tiles = (c.mb + HT - 1) / HT;
-    return ws_p3(c) + ((size_t)g * tiles + tile) * 4 * (c.hidden + 1);
+__device__ __host__ inline int head_tiles(const copo_ppo_cfg& c) { return (c.mb + HT - 1) / HT; }
+__device__ __host__ inline size_t ws_p3_at(const copo_ppo_cfg& c, int g, int tile) {   // [g][tile][out<=4][H+1]
+    return (size_t)16 * c.mb * c.hidden + ((size_t)g * head_tiles(c) + tile) * 4 * (c.hidden + 1);
 }
-
-__device__ __forceinline__ const copo_net_layout& net_of(const copo_ppo_cfg& c, int g) { return g == 0 ? c.pol : c.val[g - 1]; }
-
-__device__ __forceinline__ void adam_update(const FusedArgs& a, size_t idx, float g) {
-    const float b1 = a.c.beta1, b2 = a.c.beta2;
-    const float t = (float)(a.step[0] + 1);
-    float m = a.adam_m[idx], v = a.adam_v[idx];
-    m = m + (g - m) * (1.0f - b1);
-    v = v * b2 + g * g * (1.0f - b2);
-    a.adam_m[idx] = m;
-    a.adam_v[idx] = v;
-    const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
-    const float den = sqrtf(v) / sqrtf(bc2) + a.c.eps;
-    a.theta[idx] = a.theta[idx] - (a.c.lr / bc1) * (m / den);
+__device__ __host__ inline size_t ws_split(const copo_ppo_cfg& c, int region, int split) {   // [region][split][n_params]
+    return (size_t)16 * c.mb * c.hidden + (size_t)4 * head_tiles(c) * 4 * (c.hidden + 1) +
+           ((size_t)region * COPO_PPO_MAX_KSPLIT + split) * (size_t)c.n_params;
 }
+__device__ __forceinline__ int region_of(const FusedArgs& a, int g) { return (both(a) && g == 1) ? 1 : 0; }
 
 // ------------------------------------------------------------------------------------------------------------
-// generic 64x64 tile GEMM:  C[m][n] = sum_k A(m,k) * B(k,n)   (operand functors return 0 outside their range)
+// generic 64x64 tile GEMM:  C[m][n] = sum_k A(m,k) * B(k,n), K staged through LDS in slabs of 32.
+// Operand functors return 4 consecutive elements along their memory-contiguous axis (float4 when aligned and
+// in range, masked scalars at the edges); the next slab is prefetched into registers while the MFMAs of the
+// current slab run.
 // ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 load4(const float* p, int valid) {
+    if (valid >= 4 && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) return *reinterpret_cast<const float4*>(p);
+    float4 v;
+    v.x = valid > 0 ? p[0] : 0.0f;
+    v.y = valid > 1 ? p[1] : 0.0f;
+    v.z = valid > 2 ? p[2] : 0.0f;
+    v.w = valid > 3 ? p[3] : 0.0f;
+    return v;
+}
+
 template <class Op>
-__device__ __forceinline__ void tile_gemm(const Op& op, int g, int m0, int n0, int K, v16f& acc) {
-    __shared__ float As[TK][LDP];
-    __shared__ float Bs[TK][LDP];
+__device__ __forceinline__ void tile_gemm(const Op& op, int g, int m0, int n0, int kbeg, int kend, v16f& acc) {
+    __shared__ __align__(16) float As[TK][LDP];
+    __shared__ __align__(16) float Bs[TK][LDP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    for (int k0 = 0; k0 < K; k0 += TK) {
+    // per-thread slab coordinates: k-contiguous operands -> (row = tid/4, k = 8*(tid%4) + {0,4});
+    //                              row-contiguous operands -> (k = tid/8, row = 8*(tid%8) + {0,4})
+    const int a_r = Op::A_KCONTIG ? (tid >> 2) : ((tid & 7) * 8), a_k = Op::A_KCONTIG ? ((tid & 3) * 8) : (tid >> 3);
+    const int b_r = Op::B_KCONTIG ? (tid >> 2) : ((tid & 7) * 8), b_k = Op::B_KCONTIG ? ((tid & 3) * 8) : (tid >> 3);
+    float4 ra[2], rb[2];
+    auto fetch = [&](int k0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int mm, kk;
-            if (Op::A_KCONTIG) { mm = tid >> 2; kk = (tid & 3) * 4 + r; }
-            else { kk = tid >> 4; mm = (tid & 15) * 4 + r; }
-            As[kk][mm] = op.lda(g, m0 + mm, k0 + kk);
-            int nn, kb;
-            if (Op::B_KCONTIG) { nn = tid >> 2; kb = (tid & 3) * 4 + r; }
-            else { kb = tid >> 4; nn = (tid & 15) * 4 + r; }
-            Bs[kb][nn] = op.ldb(g, k0 + kb, n0 + nn);
+        for (int h = 0; h < 2; ++h) {
+            ra[h] = Op::A_KCONTIG ? op.lda4(g, m0 + a_r, k0 + a_k + 4 * h, kend) : op.lda4(g, m0 + a_r + 4 * h, k0 + a_k, kend);
+            rb[h] = Op::B_KCONTIG ? op.ldb4(g, k0 + b_k + 4 * h, n0 + b_r, kend) : op.ldb4(g, k0 + b_k, n0 + b_r + 4 * h, kend);
         }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (Op::A_KCONTIG) {
+                As[a_k + 4 * h + 0][a_r] = ra[h].x; As[a_k + 4 * h + 1][a_r] = ra[h].y;
+                As[a_k + 4 * h + 2][a_r] = ra[h].z; As[a_k + 4 * h + 3][a_r] = ra[h].w;
+            } else {
+                *reinterpret_cast<float4*>(&As[a_k][a_r + 4 * h]) = ra[h];
+            }
+            if (Op::B_KCONTIG) {
+                Bs[b_k + 4 * h + 0][b_r] = rb[h].x; Bs[b_k + 4 * h + 1][b_r] = rb[h].y;
+                Bs[b_k + 4 * h + 2][b_r] = rb[h].z; Bs[b_k + 4 * h + 3][b_r] = rb[h].w;
+            } else {
+                *reinterpret_cast<float4*>(&Bs[b_k][b_r + 4 * h]) = rb[h];
+            }
+        }
+    };
+    fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += TK) {
+        stash();
         __syncthreads();
+        if (k0 + TK < kend) fetch(k0 + TK);
 #pragma unroll
         for (int kk = 0; kk < TK; kk += 2) {
             const float av = As[kk + (lane >> 5)][wm * 32 + (lane & 31)];
@@ -120,93 +158,120 @@ __device__ __forceinline__ void tile_gemm(const Op& op, int g, int m0, int n0, i
 
 template <class Op>
 __global__ void __launch_bounds__(256) gemm_kernel(Op op, int K) {
-    const int g = blockIdx.z, m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    const int G = op.a.groups;
+    const int g = blockIdx.z % G, split = blockIdx.z / G, m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    __shared__ int32_t srow[COPO_PPO_MAX_MB];
+    if (op.needs_rows()) {     // row indices of this minibatch once per workgroup (removes a dependent-load chain)
+        const int64_t base = kbase(op.a) * op.a.c.mb;
+        for (int i = threadIdx.x; i < op.a.c.mb; i += 256) srow[i] = (int32_t)op.a.rows[base + i];
+        __syncthreads();
+    }
+    op.srow = srow;
+    int kbeg = 0, kend = K;
+    if (Op::SPLITS_K) {
+        const int chunk = ((K + op.a.ksplit - 1) / op.a.ksplit + TK - 1) / TK * TK;
+        kbeg = split * chunk;
+        kend = kbeg + chunk < K ? kbeg + chunk : K;
+    }
     v16f acc;
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
-    tile_gemm(op, g, m0, n0, K, acc);
+    if (kbeg < kend) tile_gemm(op, g, m0, n0, kbeg, kend, acc);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int row = m0 + wm * 32 + (j >> 2) * 8 + (lane >> 5) * 4 + (j & 3);
         const int col = n0 + wn * 32 + (lane & 31);
-        op.store(g, row, col, acc[j]);
+        op.store(g, split, row, col, acc[j]);
     }
 }
 
 // ---- layer forward: Y[m][n] = tanh(sum_k X[m][k] W[n][k] + b[n]) --------------------------------------------
 struct FwdOp {
-    static constexpr bool A_KCONTIG = true, B_KCONTIG = true;
+    static constexpr bool A_KCONTIG = true, B_KCONTIG = true, SPLITS_K = false;
     FusedArgs a;
     int layer;   // 1 or 2
-    __device__ __forceinline__ int in_dim(int g) const { return layer == 1 ? net_of(a.c, g).in_dim : a.c.hidden; }
-    __device__ __forceinline__ float lda(int g, int m, int k) const {
-        if (m >= a.c.mb || k >= in_dim(g)) return 0.0f;
-        if (layer == 1) {
-            const float* src = (g == 0) ? a.obs_src : a.cc_src;
-            return src[(size_t)row_of(a, m) * in_dim(g) + k];
-        }
-        return a.ws[ws_h1(a.c, g) + (size_t)m * a.c.hidden + k];
+    const int32_t* srow;
+    __device__ __forceinline__ bool needs_rows() const { return layer == 1; }
+    __device__ __forceinline__ int in_dim(int g) const { return layer == 1 ? net_of(a, g).in_dim : a.c.hidden; }
+    __device__ __forceinline__ float4 lda4(int g, int m, int k, int) const {     // 4 consecutive k of row m
+        const int K = in_dim(g);
+        if (m >= a.c.mb || k >= K) return make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* p = (layer == 1) ? (src_of(a, g) + (size_t)srow[m] * K + k)
+                                      : (a.ws + ws_h1(a.c, g) + (size_t)m * a.c.hidden + k);
+        return load4(p, K - k);
     }
-    __device__ __forceinline__ float ldb(int g, int k, int n) const {
-        if (n >= a.c.hidden || k >= in_dim(g)) return 0.0f;
-        const copo_net_layout& L = net_of(a.c, g);
-        return a.theta[(layer == 1 ? L.w1 : L.w2) + (size_t)n * in_dim(g) + k];
+    __device__ __forceinline__ float4 ldb4(int g, int k, int n, int) const {     // 4 consecutive k of weight row n
+        const int K = in_dim(g);
+        if (n >= a.c.hidden || k >= K) return make_float4(0.f, 0.f, 0.f, 0.f);
+        const copo_net_layout& L = net_of(a, g);
+        return load4(theta_of(a, g) + (layer == 1 ? L.w1 : L.w2) + (size_t)n * K + k, K - k);
     }
-    __device__ __forceinline__ void store(int g, int m, int n, float v) const {
+    __device__ __forceinline__ void store(int g, int, int m, int n, float v) const {
         if (m >= a.c.mb || n >= a.c.hidden) return;
-        const copo_net_layout& L = net_of(a.c, g);
-        const float y = tanhf(v + a.theta[(layer == 1 ? L.b1 : L.b2) + n]);
+        const copo_net_layout& L = net_of(a, g);
+        const float y = tanhf(v + theta_of(a, g)[(layer == 1 ? L.b1 : L.b2) + n]);
         a.ws[(layer == 1 ? ws_h1(a.c, g) : ws_h2(a.c, g)) + (size_t)m * a.c.hidden + n] = y;
     }
 };
 
 // ---- B2x: dz1[m][i] = (sum_o dz2[m][o] W2[o][i]) * (1 - h1[m][i]^2) -------------------------------------------
 struct BxOp {
-    static constexpr bool A_KCONTIG = true, B_KCONTIG = false;
+    static constexpr bool A_KCONTIG = true, B_KCONTIG = false, SPLITS_K = false;
     FusedArgs a;
-    __device__ __forceinline__ float lda(int g, int m, int k) const {
-        if (m >= a.c.mb || k >= a.c.hidden) return 0.0f;
-        return a.ws[ws_dz2(a.c, g) + (size_t)m * a.c.hidden + k];
+    const int32_t* srow;
+    __device__ __forceinline__ bool needs_rows() const { return false; }
+    __device__ __forceinline__ float4 lda4(int g, int m, int k, int) const {     // dz2[m][k..k+3]
+        const int H = a.c.hidden;
+        if (m >= a.c.mb || k >= H) return make_float4(0.f, 0.f, 0.f, 0.f);
+        return load4(a.ws + ws_dz2(a.c, g) + (size_t)m * H + k, H - k);
     }
-    __device__ __forceinline__ float ldb(int g, int k, int n) const {
-        if (n >= a.c.hidden || k >= a.c.hidden) return 0.0f;
-        return a.theta[net_of(a.c, g).w2 + (size_t)k * a.c.hidden + n];
+    __device__ __forceinline__ float4 ldb4(int g, int k, int n, int) const {     // W2[k][n..n+3]
+        const int H = a.c.hidden;
+        if (k >= H || n >= H) return make_float4(0.f, 0.f, 0.f, 0.f);
+        return load4(theta_of(a, g) + net_of(a, g).w2 + (size_t)k * H + n, H - n);
     }
-    __device__ __forceinline__ void store(int g, int m, int n, float v) const {
+    __device__ __forceinline__ void store(int g, int, int m, int n, float v) const {
         if (m >= a.c.mb || n >= a.c.hidden) return;
         const float h = a.ws[ws_h1(a.c, g) + (size_t)m * a.c.hidden + n];
         a.ws[ws_dz1(a.c, g) + (size_t)m * a.c.hidden + n] = v * (1.0f - h * h);
     }
 };
 
-// ---- Bw: dW[o][i] = sum_m dz[m][o] * [In | 1][m][i]  (+ Adam); column i == in_dim is the bias gradient ---------
+// ---- Bw: partial dW[o][i] = sum_{m in split} dz[m][o] * [In | 1][m][i]; column i == in_dim is the bias --------
 struct BwOp {
-    static constexpr bool A_KCONTIG = false, B_KCONTIG = false;
+    static constexpr bool A_KCONTIG = false, B_KCONTIG = false, SPLITS_K = true;
     FusedArgs a;
     int layer;   // 2: dz2 x h1 ; 1: dz1 x X
-    __device__ __forceinline__ int in_dim(int g) const { return layer == 1 ? net_of(a.c, g).in_dim : a.c.hidden; }
-    __device__ __forceinline__ float lda(int g, int o, int m) const {   // A(mm = o, k = m)
-        if (o >= a.c.hidden || m >= a.c.mb) return 0.0f;
-        return a.ws[(layer == 2 ? ws_dz2(a.c, g) : ws_dz1(a.c, g)) + (size_t)m * a.c.hidden + o];
+    const int32_t* srow;
+    __device__ __forceinline__ bool needs_rows() const { return layer == 1; }
+    __device__ __forceinline__ int in_dim(int g) const { return layer == 1 ? net_of(a, g).in_dim : a.c.hidden; }
+    __device__ __forceinline__ float4 lda4(int g, int o, int m, int mend) const {   // A(mm = o.., k = m) = dz[m][o..o+3]
+        const int H = a.c.hidden;
+        if (o >= H || m >= mend) return make_float4(0.f, 0.f, 0.f, 0.f);
+        return load4(a.ws + (layer == 2 ? ws_dz2(a.c, g) : ws_dz1(a.c, g)) + (size_t)m * H + o, H - o);
     }
-    __device__ __forceinline__ float ldb(int g, int m, int i) const {   // B(k = m, n = i)
+    __device__ __forceinline__ float4 ldb4(int g, int m, int i, int mend) const {   // B(k = m, n = i..) = [In | 1][m][i..]
         const int K = in_dim(g);
-        if (m >= a.c.mb || i > K) return 0.0f;
-        if (i == K) return 1.0f;
-        if (layer == 2) return a.ws[ws_h1(a.c, g) + (size_t)m * a.c.hidden + i];
-        const float* src = (g == 0) ? a.obs_src : a.cc_src;
-        return src[(size_t)row_of(a, m) * K + i];
+        if (m >= mend || i > K) return make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* p = (layer == 2) ? (a.ws + ws_h1(a.c, g) + (size_t)m * a.c.hidden + i)
+                                      : (src_of(a, g) + (size_t)srow[m] * K + i);
+        float4 v = load4(p, K - i);
+        const int one = K - i;          // position of the bias column inside this quad (0..3) if in range
+        if (one == 0) v.x = 1.0f;
+        else if (one == 1) v.y = 1.0f;
+        else if (one == 2) v.z = 1.0f;
+        else if (one == 3) v.w = 1.0f;
+        return v;
     }
-    __device__ __forceinline__ void store(int g, int o, int i, float v) const {
+    __device__ __forceinline__ void store(int g, int split, int o, int i, float v) const {
         const int K = in_dim(g);
         if (o >= a.c.hidden || i > K) return;
-        const copo_net_layout& L = net_of(a.c, g);
+        const copo_net_layout& L = net_of(a, g);
         const size_t idx = (i == K) ? (size_t)(layer == 1 ? L.b1 : L.b2) + o
                                     : (size_t)(layer == 1 ? L.w1 : L.w2) + (size_t)o * K + i;
-        if (a.apply_adam) adam_update(a, idx, v);
-        else a.grad[idx] = v;
+        a.ws[ws_split(a.c, region_of(a, g), split) + idx] = v;
     }
 };
 
@@ -219,7 +284,10 @@ __global__ void __launch_bounds__(256) head_kernel(FusedArgs a) {
     extern __shared__ float lds[];
     const copo_ppo_cfg& c = a.c;
     const int H = c.hidden, g = blockIdx.y, tile = blockIdx.x, m0 = tile * HT;
-    const copo_net_layout& L = net_of(c, g);
+    const copo_net_layout& L = net_of(a, g);
+    const float* theta = theta_of(a, g);
+    const int mode = mode_of(a, g);
+    const bool policy = is_policy(a, g);
     const int OD = L.out_dim;            // 2*act_dim for the policy net, 1 for value nets
     float* h2s = lds;                    // [HT][H+1]
     float* w3s = h2s + HT * (H + 1);     // [4][H]
@@ -227,11 +295,9 @@ __global__ void __launch_bounds__(256) head_kernel(FusedArgs a) {
     float* red = douts + HT * 4;         // [8 stats][4 waves]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* h2g = a.ws + ws_h2(c, g);
-    for (int q = tid; q < HT * H; q += 256) {
-        const int r = q / H, i = q - r * H;
-        h2s[r * (H + 1) + i] = (m0 + r < c.mb) ? h2g[(size_t)(m0 + r) * H + i] : 0.0f;
-    }
-    for (int q = tid; q < OD * H; q += 256) w3s[q] = a.theta[L.w3 + q];
+    for (int r = tid >> 6; r < HT; r += 4)
+        for (int i = lane; i < H; i += 64) h2s[r * (H + 1) + i] = (m0 + r < c.mb) ? h2g[(size_t)(m0 + r) * H + i] : 0.0f;
+    for (int q = tid; q < OD * H; q += 256) w3s[q] = theta[L.w3 + q];
     __syncthreads();
     // outputs: 8 threads per row, each an eighth of the hidden units
     const int r = tid >> 3, part = tid & 7;
@@ -247,16 +313,17 @@ __global__ void __launch_bounds__(256) head_kernel(FusedArgs a) {
         out[j] += __shfl_xor(out[j], 1);
         out[j] += __shfl_xor(out[j], 2);
         out[j] += __shfl_xor(out[j], 4);
-        if (j < OD) out[j] += a.theta[L.b3 + j];
+        if (j < OD) out[j] += theta[L.b3 + j];
     }
     // per-row loss terms and d(loss)/d(out)
     float st[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // total, policy, vf_ego, kl, entropy, vf_nei, vf_glob, adv
     float dout[4] = {0.f, 0.f, 0.f, 0.f};
     const int m = m0 + r;
     if (part == 0 && m < c.mb) {
-        const float wgt = w_of(a, m) / denom_of(a);
-        const float* pk = a.pack_src + (size_t)row_of(a, m) * c.pack_width;
-        if (g == 0) {
+        const int64_t kb = kbase(a);
+        const float wgt = a.w[kb * c.mb + m] / a.denom[kb];
+        const float* pk = a.pack_src + (size_t)a.rows[kb * c.mb + m] * c.pack_width;
+        if (policy) {
             const int A = c.act_dim;     // A == 2
             float logp = 0.f, ent = 0.f, kl = 0.f, z[2], sig[2];
 #pragma unroll
@@ -267,7 +334,7 @@ __global__ void __launch_bounds__(256) head_kernel(FusedArgs a) {
                 logp += -0.5f * z[j] * z[j] - ls - 0.5f * kLog2Pi;
                 ent += ls + 0.5f + 0.5f * kLog2Pi;
             }
-            if (a.head_mode == COPO_HEAD_META_OLD) {       // loss = mean(logp) on the target net
+            if (mode == COPO_HEAD_META_OLD) {       // loss = mean(logp) on the target net
                 st[0] = st[1] = wgt * logp;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -275,7 +342,7 @@ __global__ void __launch_bounds__(256) head_kernel(FusedArgs a) {
                     dout[A + j] = wgt * (z[j] * z[j] - 1.0f);
                 }
             } else {
-                const float adv = pk[a.head_mode == COPO_HEAD_META_NEW ? c.col_meta_adv : c.col_adv];
+                const float adv = pk[mode == COPO_HEAD_META_NEW ? c.col_meta_adv : c.col_adv];
                 const float ratio = expf(logp - pk[c.col_logp]);
                 const float s1 = adv * ratio;
                 const float rc = fminf(fmaxf(ratio, 1.0f - c.clip_param), 1.0f + c.clip_param);
@@ -283,9 +350,9 @@ __global__ void __launch_bounds__(256) head_kernel(FusedArgs a) {
                 const float surr = fminf(s1, s2);
                 const bool inside = (ratio >= 1.0f - c.clip_param) && (ratio <= 1.0f + c.clip_param);
                 const float dsurr_dratio = (inside || s1 < s2) ? adv : 0.0f;
-                float dlogp = -dsurr_dratio * ratio;      // d(-surr)/d logp
+                const float dlogp = -dsurr_dratio * ratio;      // d(-surr)/d logp
                 float dmu[2] = {0.f, 0.f}, dls[2] = {0.f, 0.f};
-                const bool ppo = a.head_mode == COPO_HEAD_PPO;
+                const bool ppo = mode == COPO_HEAD_PPO;
                 if (ppo && c.use_kl) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
@@ -308,7 +375,7 @@ __global__ void __launch_bounds__(256) head_kernel(FusedArgs a) {
                 st[1] = wgt * (-surr);
                 st[3] = wgt * kl;
                 st[4] = wgt * ent;
-                st[0] = st[1] + (ppo ? (a.kl_coeff[0] * st[3] - c.entropy_coeff * st[4]) : 0.0f);
+                st[0] = st[1] + (ppo ? ((c.use_kl ? a.kl_coeff[0] * st[3] : 0.0f) - c.entropy_coeff * st[4]) : 0.0f);
                 st[7] = wgt * adv;
             }
         } else {
@@ -347,45 +414,66 @@ __global__ void __launch_bounds__(256) head_kernel(FusedArgs a) {
         if (lane == 0) red[k * 4 + wave] = s;
     }
     __syncthreads();
-    if (tid < 8 && a.stats) {
+    float* stats = stats_of(a, g);
+    if (tid < 8 && stats) {
         const float s = (red[tid * 4] + red[tid * 4 + 1]) + (red[tid * 4 + 2] + red[tid * 4 + 3]);
-        if (s != 0.0f) atomicAdd(a.stats + tid, s);
+        if (s != 0.0f) atomicAdd(stats + tid, s);
     }
     // dz2 = (dout W3) * (1 - h2^2);  per-tile partial of dW3 / db3
     float* dz2 = a.ws + ws_dz2(c, g);
-    for (int q = tid; q < HT * H; q += 256) {
-        const int rr = q / H, i = q - rr * H;
+    for (int rr = tid >> 6; rr < HT; rr += 4) {
         if (m0 + rr >= c.mb) continue;
-        float s = 0.0f;
+        for (int i = lane; i < H; i += 64) {
+            float s = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (j < OD) s += douts[rr * 4 + j] * w3s[j * H + i];
-        const float h = h2s[rr * (H + 1) + i];
-        dz2[(size_t)(m0 + rr) * H + i] = s * (1.0f - h * h);
+            for (int j = 0; j < 4; ++j)
+                if (j < OD) s += douts[rr * 4 + j] * w3s[j * H + i];
+            const float h = h2s[rr * (H + 1) + i];
+            dz2[(size_t)(m0 + rr) * H + i] = s * (1.0f - h * h);
+        }
     }
     float* p3 = a.ws + ws_p3_at(c, g, tile);
-    for (int q = tid; q < OD * (H + 1); q += 256) {
-        const int j = q / (H + 1), i = q - j * (H + 1);
-        float s = 0.0f;
-        for (int rr = 0; rr < HT; ++rr) s += douts[rr * 4 + j] * (i == H ? 1.0f : h2s[rr * (H + 1) + i]);
-        p3[j * (H + 1) + i] = s;
-    }
+    for (int j = 0; j < OD; ++j)
+        for (int i = tid; i <= H; i += 256) {
+            float s = 0.0f;
+            for (int rr = 0; rr < HT; ++rr) s += douts[rr * 4 + j] * (i == H ? 1.0f : h2s[rr * (H + 1) + i]);
+            p3[j * (H + 1) + i] = s;
+        }
 }
 
-// fold dW3 partials in tile order (deterministic), Adam or gradient store
-__global__ void __launch_bounds__(256) head_fold_kernel(FusedArgs a) {
+// fold the split partials (W1, b1, W2, b2) and the head tile partials (W3, b3) in a fixed order, then Adam or
+// gradient store.  grid = (ceil(max tensor / 256), 6 tensors, groups)
+__global__ void __launch_bounds__(256) reduce_adam_kernel(FusedArgs a) {
     const copo_ppo_cfg& c = a.c;
-    const int g = blockIdx.y, H = c.hidden;
-    const copo_net_layout& L = net_of(c, g);
-    const int tiles = (c.mb + HT - 1) / HT;
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= L.out_dim * (H + 1)) return;
-    const int j = q / (H + 1), i = q - j * (H + 1);
+    const int g = blockIdx.z, t = blockIdx.y, H = c.hidden;
+    const copo_net_layout& L = net_of(a, g);
+    const int K1 = L.in_dim, OD = L.out_dim;
+    const int64_t off[6] = {L.w1, L.b1, L.w2, L.b2, L.w3, L.b3};
+    const int sz[6] = {H * K1, H, H * H, H, OD * H, OD};
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= sz[t]) return;
+    const size_t idx = (size_t)off[t] + e;
     float s = 0.0f;
-    for (int t = 0; t < tiles; ++t) s += a.ws[ws_p3_at(c, g, t) + j * (H + 1) + i];
-    const size_t idx = (i == H) ? (size_t)L.b3 + j : (size_t)L.w3 + (size_t)j * H + i;
-    if (a.apply_adam) adam_update(a, idx, s);
-    else a.grad[idx] = s;
+    if (t < 4) {
+        const int reg = region_of(a, g);
+        for (int sp = 0; sp < a.ksplit; ++sp) s += a.ws[ws_split(c, reg, sp) + idx];
+    } else {
+        const int tiles = head_tiles(c);
+        const int j = (t == 4) ? e / H : e, i = (t == 4) ? e - j * H : H;
+        for (int tl = 0; tl < tiles; ++tl) s += a.ws[ws_p3_at(c, g, tl) + j * (H + 1) + i];
+    }
+    if (a.apply_adam) {
+        const float tt = (float)(a.step[0] + 1);
+        const float bc1 = 1.0f - powf(c.beta1, tt), bc2s = sqrtf(1.0f - powf(c.beta2, tt));
+        float m = a.adam_m[idx], v = a.adam_v[idx];
+        m = m + (s - m) * (1.0f - c.beta1);
+        v = v * c.beta2 + s * s * (1.0f - c.beta2);
+        a.adam_m[idx] = m;
+        a.adam_v[idx] = v;
+        a.theta[idx] = a.theta[idx] - (c.lr / bc1) * (m / (sqrtf(v) / bc2s + c.eps));
+    } else {
+        grad_of(a, g)[idx] = s;
+    }
 }
 
 __global__ void bump_kernel(int64_t* step, int64_t* k) {
@@ -395,33 +483,167 @@ __global__ void bump_kernel(int64_t* step, int64_t* k) {
 
 __global__ void __launch_bounds__(256) adam_flat_kernel(FusedArgs a, long long n) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) adam_update(a, (size_t)i, a.grad[i]);
+    if (i >= n) return;
+    const copo_ppo_cfg& c = a.c;
+    const float tt = (float)(a.step[0] + 1);
+    const float bc1 = 1.0f - powf(c.beta1, tt), bc2s = sqrtf(1.0f - powf(c.beta2, tt));
+    const float s = a.grad[i];
+    float m = a.adam_m[i], v = a.adam_v[i];
+    m = m + (s - m) * (1.0f - c.beta1);
+    v = v * c.beta2 + s * s * (1.0f - c.beta2);
+    a.adam_m[i] = m;
+    a.adam_v[i] = v;
+    a.theta[i] = a.theta[i] - (c.lr / bc1) * (m / (sqrtf(v) / bc2s + c.eps));
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// host launcher
+// LCF meta update tail (fp64, like the reference's float64 lcf_parameters)
+// ------------------------------------------------------------------------------------------------------------
+struct MetaArgs {
+    const float* pack_src;
+    const int64_t* rows;
+    const float* w;
+    const float* denom;
+    const double* eps;          // [n_mb][mb] standard normal draws of the reparameterised LCF sample
+    const int64_t* kptr;
+    int32_t mb, pack_width, col_adv, col_nei_adv;
+    const double* lcf_param;    // [2] = {p0, p1}
+    const double* raw_mean_std; // [2]
+    double* tail;               // [4] = {dS/dp0, dS/dp1, S, mean(A')}
+};
+
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int i = 0; i < nw; ++i) s += red[i];
+    return s;
+}
+
+// S = sum_i w_i ((A'_i - mu)/sigma) / D with A' = cos(phi) A_ego + sin(phi) A_nei, phi = (m + s eps) pi/2,
+// m = clamp(tanh p0, +-(1-1e-6)), s = exp(clamp(p1, -20, 2))   (algo_copo.py:155-179, 283-287)
+__global__ void __launch_bounds__(1024) meta_lcf_kernel(MetaArgs a) {
+    __shared__ double red[16];
+    const int64_t kb = a.kptr ? a.kptr[0] : 0;
+    const double p0 = a.lcf_param[0], p1 = a.lcf_param[1];
+    const double th = tanh(p0), lim = 1.0 - 1e-6;
+    const double mean = th > lim ? lim : (th < -lim ? -lim : th);
+    const double dmean = (th >= -lim && th <= lim) ? (1.0 - th * th) : 0.0;
+    const double p1c = p1 > 2.0 ? 2.0 : (p1 < -20.0 ? -20.0 : p1);
+    const double sd = exp(p1c), dsd = (p1 >= -20.0 && p1 <= 2.0) ? sd : 0.0;
+    const double half_pi = 3.14159265358979323846 / 2.0;
+    const double mu = a.raw_mean_std[0], sigma = a.raw_mean_std[1];
+    const double D = (double)a.denom[kb];
+    double s0 = 0.0, s1 = 0.0, sS = 0.0, sA = 0.0;
+    for (int m = threadIdx.x; m < a.mb; m += blockDim.x) {
+        const double w = (double)a.w[kb * a.mb + m];
+        if (w == 0.0) continue;
+        const float* pk = a.pack_src + (size_t)a.rows[kb * a.mb + m] * a.pack_width;
+        const double ego = (double)pk[a.col_adv], nei = (double)pk[a.col_nei_adv];
+        const double e = a.eps[kb * a.mb + m];
+        const double phi = (mean + sd * e) * half_pi;
+        const double cs = cos(phi), sn = sin(phi);
+        const double A = cs * ego + sn * nei;
+        const double dA = (-sn * ego + cs * nei) * half_pi;
+        sS += w * (A - mu) / sigma;
+        sA += w * A;
+        s0 += w * dA * dmean / sigma;
+        s1 += w * dA * e * dsd / sigma;
+    }
+    const double r0 = block_sum_d(s0, red), r1 = block_sum_d(s1, red), rS = block_sum_d(sS, red), rA = block_sum_d(sA, red);
+    if (threadIdx.x == 0) {
+        a.tail[0] = r0 / D;
+        a.tail[1] = r1 / D;
+        a.tail[2] = rS / D;
+        a.tail[3] = rA / D;
+    }
+}
+
+struct MetaFinishArgs {
+    const float* g_new;
+    const float* g_old;
+    int64_t n;
+    const double* tail;        // [4]
+    double* lcf_param;         // [2] updated in place
+    double* adam;              // [5] = {m0, m1, v0, v1, step}
+    double lr;
+    const float* stats_new;    // fused-step statistics of the two passes (may be NULL)
+    const float* stats_old;
+    double* stats;             // [7] accumulated: new_loss, old_loss, S, gv*S, gv, mean A', mean global adv
+    int64_t* kptr;
+    int32_t bump_k;
+};
+
+__global__ void __launch_bounds__(1024) meta_finish_kernel(MetaFinishArgs a) {
+    __shared__ double red[16];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < a.n; i += blockDim.x) s += (double)a.g_new[i] * (double)a.g_old[i];
+    const double gv = block_sum_d(s, red);
+    if (threadIdx.x == 0) {
+        const double b1 = 0.9, b2 = 0.999, eps = 1e-8;
+        const double t = a.adam[4] + 1.0;
+        const double bc1 = 1.0 - pow(b1, t), bc2 = 1.0 - pow(b2, t);
+        for (int j = 0; j < 2; ++j) {
+            const double g = gv * a.tail[j];
+            double m = a.adam[j], v = a.adam[2 + j];
+            m = m + (g - m) * (1.0 - b1);
+            v = v * b2 + g * g * (1.0 - b2);
+            a.adam[j] = m;
+            a.adam[2 + j] = v;
+            a.lcf_param[j] -= (a.lr / bc1) * (m / (sqrt(v) / sqrt(bc2) + eps));
+        }
+        a.adam[4] = t;
+        if (a.stats) {
+            a.stats[0] += a.stats_new ? (double)a.stats_new[1] : 0.0;
+            a.stats[1] += a.stats_old ? (double)a.stats_old[1] : 0.0;
+            a.stats[2] += a.tail[2];
+            a.stats[3] += gv * a.tail[2];
+            a.stats[4] += gv;
+            a.stats[5] += a.tail[3];
+            a.stats[6] += a.stats_new ? (double)a.stats_new[7] : 0.0;
+        }
+        if (a.bump_k && a.kptr) a.kptr[0] += 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host launchers
 // ------------------------------------------------------------------------------------------------------------
 size_t fused_ws_floats(const copo_ppo_cfg& c) {
-    const int tiles = (c.mb + HT - 1) / HT;
-    return (size_t)16 * c.mb * c.hidden + (size_t)4 * tiles * 4 * (c.hidden + 1);
+    return (size_t)16 * c.mb * c.hidden + (size_t)4 * head_tiles(c) * 4 * (c.hidden + 1) +
+           (size_t)2 * COPO_PPO_MAX_KSPLIT * (size_t)c.n_params;
 }
 
-hipError_t launch_fused_step(const FusedArgs& a, hipStream_t s) {
+static int pick_ksplit(int mb) {
+    int s = mb / 128;
+    if (s < 1) s = 1;
+    if (s > COPO_PPO_MAX_KSPLIT) s = COPO_PPO_MAX_KSPLIT;
+    return s;
+}
+
+hipError_t launch_fused_step(FusedArgs a, hipStream_t s) {
     const copo_ppo_cfg& c = a.c;
+    a.ksplit = pick_ksplit(c.mb);
     const int G = a.groups, mt = (c.mb + TM - 1) / TM, ht = (c.hidden + TN - 1) / TN;
-    FwdOp f1{a, 1}, f2{a, 2};
+    FwdOp f1{a, 1, nullptr}, f2{a, 2, nullptr};
     int kmax1 = c.pol.in_dim;
-    for (int g = 1; g < G; ++g) kmax1 = c.val[g - 1].in_dim > kmax1 ? c.val[g - 1].in_dim : kmax1;
+    if (a.head_mode == COPO_HEAD_PPO)
+        for (int g = 1; g < G; ++g) kmax1 = c.val[g - 1].in_dim > kmax1 ? c.val[g - 1].in_dim : kmax1;
     hipLaunchKernelGGL(gemm_kernel<FwdOp>, dim3(ht, mt, G), dim3(256), 0, s, f1, kmax1);
     hipLaunchKernelGGL(gemm_kernel<FwdOp>, dim3(ht, mt, G), dim3(256), 0, s, f2, c.hidden);
     const size_t lds = (size_t)(HT * (c.hidden + 1) + 4 * c.hidden + HT * 4 + 32) * sizeof(float);
-    hipLaunchKernelGGL(head_kernel, dim3((c.mb + HT - 1) / HT, G), dim3(256), lds, s, a);
-    BxOp bx{a};
+    hipLaunchKernelGGL(head_kernel, dim3(head_tiles(c), G), dim3(256), lds, s, a);
+    BxOp bx{a, nullptr};
     hipLaunchKernelGGL(gemm_kernel<BxOp>, dim3(ht, mt, G), dim3(256), 0, s, bx, c.hidden);
-    BwOp bw2{a, 2}, bw1{a, 1};
-    hipLaunchKernelGGL(gemm_kernel<BwOp>, dim3((c.hidden + 1 + TN - 1) / TN, ht, G), dim3(256), 0, s, bw2, c.mb);
-    hipLaunchKernelGGL(gemm_kernel<BwOp>, dim3((kmax1 + 1 + TN - 1) / TN, ht, G), dim3(256), 0, s, bw1, c.mb);
-    hipLaunchKernelGGL(head_fold_kernel, dim3((4 * (c.hidden + 1) + 255) / 256, G), dim3(256), 0, s, a);
+    BwOp bw2{a, 2, nullptr}, bw1{a, 1, nullptr};
+    hipLaunchKernelGGL(gemm_kernel<BwOp>, dim3((c.hidden + 1 + TN - 1) / TN, ht, G * a.ksplit), dim3(256), 0, s, bw2, c.mb);
+    hipLaunchKernelGGL(gemm_kernel<BwOp>, dim3((kmax1 + 1 + TN - 1) / TN, ht, G * a.ksplit), dim3(256), 0, s, bw1, c.mb);
+    int maxsz = c.hidden * (kmax1 > c.hidden ? kmax1 : c.hidden);
+    hipLaunchKernelGGL(reduce_adam_kernel, dim3((maxsz + 255) / 256, 6, G), dim3(256), 0, s, a);
     int64_t* st = a.apply_adam ? const_cast<int64_t*>(a.step) : nullptr;
     int64_t* kp = a.bump_k ? const_cast<int64_t*>(a.kptr) : nullptr;
     if (st || kp) hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, s, st, kp);
@@ -444,12 +666,22 @@ extern "C" int64_t copo_ppo_workspace_floats(const copo_ppo_cfg* cfg) { return c
 
 static int check_cfg(const copo_ppo_cfg* c) {
     if (!c) return COPO_ERR_NULL;
-    if (c->mb < 1 || c->hidden < 1 || c->hidden > 1024 || c->act_dim != 2 || c->n_value_heads < 0 || c->n_value_heads > 3)
+    if (c->mb < 1 || c->mb > COPO_PPO_MAX_MB || c->hidden < 1 || c->hidden > 1024 || c->act_dim != 2 ||
+        c->n_value_heads < 0 || c->n_value_heads > 3 || c->n_params < 1)
         return COPO_ERR_DIM;
     if (c->pol.out_dim != 4) return COPO_ERR_DIM;
     for (int g = 0; g < c->n_value_heads; ++g)
         if (c->val[g].out_dim != 1) return COPO_ERR_DIM;
     return COPO_OK;
+}
+
+static void fill_common(FusedArgs& a, const copo_ppo_cfg* cfg, const float* obs_src, const float* cc_src,
+                        const float* pack_src, const int64_t* rows, const float* w, const float* denom, float* workspace,
+                        int64_t* mb_index) {
+    memset(&a, 0, sizeof(a));
+    a.c = *cfg;
+    a.obs_src = obs_src; a.cc_src = cc_src ? cc_src : obs_src; a.pack_src = pack_src;
+    a.rows = rows; a.w = w; a.denom = denom; a.ws = workspace; a.kptr = mb_index;
 }
 
 extern "C" int copo_ppo_fused_step_f32(const copo_ppo_cfg* cfg, float* theta, float* adam_m, float* adam_v, float* grad,
@@ -462,17 +694,55 @@ extern "C" int copo_ppo_fused_step_f32(const copo_ppo_cfg* cfg, float* theta, fl
     if (!theta || !obs_src || !pack_src || !rows || !w || !denom || !workspace) return COPO_ERR_NULL;
     if (apply_adam && (!adam_m || !adam_v || !step)) return COPO_ERR_NULL;
     if (!apply_adam && !grad) return COPO_ERR_NULL;
+    if (head_mode < COPO_HEAD_PPO || head_mode > COPO_HEAD_META_OLD) return COPO_ERR_DIM;
     if (head_mode == COPO_HEAD_PPO && cfg->use_kl && !kl_coeff) return COPO_ERR_NULL;
     FusedArgs a;
-    a.c = *cfg;
+    fill_common(a, cfg, obs_src, cc_src, pack_src, rows, w, denom, workspace, mb_index);
     a.theta = theta; a.adam_m = adam_m; a.adam_v = adam_v; a.grad = grad;
-    a.obs_src = obs_src; a.cc_src = cc_src ? cc_src : obs_src; a.pack_src = pack_src;
-    a.rows = rows; a.w = w; a.denom = denom; a.kl_coeff = kl_coeff; a.step = step;
-    a.ws = workspace; a.stats = stats; a.apply_adam = apply_adam; a.head_mode = head_mode;
+    a.kl_coeff = kl_coeff; a.step = step; a.stats = stats; a.apply_adam = apply_adam; a.head_mode = head_mode;
     a.groups = (head_mode == COPO_HEAD_PPO) ? 1 + cfg->n_value_heads : 1;
-    a.kptr = mb_index; a.bump_k = (mb_index && bump_index) ? 1 : 0;
+    a.bump_k = (mb_index && bump_index) ? 1 : 0;
     hipError_t e = launch_fused_step(a, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
+}
+
+extern "C" int copo_meta_grads_f32(const copo_ppo_cfg* cfg, float* theta, float* theta_target, float* g_new, float* g_old,
+                                   const float* obs_src, const float* pack_src, const int64_t* rows, const float* w,
+                                   const float* denom, float* workspace, float* stats_new, float* stats_old,
+                                   int64_t* mb_index, void* stream) {
+    int rc = check_cfg(cfg);
+    if (rc != COPO_OK) return rc;
+    if (!theta || !theta_target || !g_new || !g_old || !obs_src || !pack_src || !rows || !w || !denom || !workspace)
+        return COPO_ERR_NULL;
+    FusedArgs a;
+    fill_common(a, cfg, obs_src, nullptr, pack_src, rows, w, denom, workspace, mb_index);
+    a.theta = theta; a.theta2 = theta_target; a.grad = g_new; a.grad2 = g_old;
+    a.stats = stats_new; a.stats2 = stats_old; a.apply_adam = 0; a.head_mode = MODE_META_BOTH; a.groups = 2;
+    hipError_t e = launch_fused_step(a, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
+}
+
+extern "C" int copo_meta_lcf_f64(const float* pack_src, int32_t pack_width, int32_t col_adv, int32_t col_nei_adv,
+                                 const int64_t* rows, const float* w, const float* denom, const double* eps, int32_t mb,
+                                 const int64_t* mb_index, const double* lcf_param, const double* raw_mean_std, double* tail,
+                                 void* stream) {
+    if (!pack_src || !rows || !w || !denom || !eps || !lcf_param || !raw_mean_std || !tail) return COPO_ERR_NULL;
+    if (mb < 1) return COPO_ERR_DIM;
+    MetaArgs a{pack_src, rows, w, denom, eps, mb_index, mb, pack_width, col_adv, col_nei_adv, lcf_param, raw_mean_std, tail};
+    hipLaunchKernelGGL(meta_lcf_kernel, dim3(1), dim3(512), 0, static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
+}
+
+extern "C" int copo_meta_finish_f64(const float* g_new, const float* g_old, int64_t n, const double* tail,
+                                    double* lcf_param, double* adam_state, double lr, const float* stats_new,
+                                    const float* stats_old, double* stats, int64_t* mb_index, int32_t bump_index,
+                                    void* stream) {
+    if (!g_new || !g_old || !tail || !lcf_param || !adam_state) return COPO_ERR_NULL;
+    if (n < 0) return COPO_ERR_DIM;
+    MetaFinishArgs a{g_new, g_old, n, tail, lcf_param, adam_state, lr, stats_new, stats_old, stats, mb_index,
+                     (mb_index && bump_index) ? 1 : 0};
+    hipLaunchKernelGGL(meta_finish_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
 }
 
 extern "C" int copo_adam_step_f32(const copo_ppo_cfg* cfg, float* theta, float* adam_m, float* adam_v, const float* grad,

@@ -89,7 +89,9 @@ class FusedLearner:
         c.clip_param, c.vf_clip_param = float(cfg["clip_param"]), float(cfg["vf_clip_param"])
         c.vf_loss_coeff, c.entropy_coeff = float(cfg["vf_loss_coeff"]), float(policy.entropy_coeff)
         c.lr, c.beta1, c.beta2, c.eps = float(cfg["lr"]), 0.9, 0.999, 1e-8
+        c.n_params = self.flat.numel
         self.cfg = c
+        self.columns = col
         n = self.flat.numel
         self.adam_m = torch.zeros(n, device=dev)
         self.adam_v = torch.zeros(n, device=dev)
@@ -123,6 +125,27 @@ class FusedLearner:
             C.byref(self.cfg), self.flat.flat.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr(),
             (self.grad if grad is None else grad).data_ptr(), self.flat.numel, self.step_count.data_ptr(),
             rs["k"].data_ptr(), _capi.current_stream()))
+
+    # ---- LCF meta update (CoPO) -------------------------------------------------------------------------------
+    def meta_grads(self, rs, g_new, g_old, stats_new, stats_old):
+        """Both policy gradients of `meta_update` in one grouped pass (current policy / target policy)."""
+        _capi.check(_capi.lib.copo_meta_grads_f32(
+            C.byref(self.cfg), self.flat.flat.data_ptr(), self.target_flat.flat.data_ptr(), g_new.data_ptr(),
+            g_old.data_ptr(), rs["obs"].data_ptr(), rs["pack"].data_ptr(), rs["rows_all"].data_ptr(),
+            rs["w_all"].data_ptr(), rs["denom_all"].data_ptr(), self.workspace.data_ptr(), stats_new.data_ptr(),
+            stats_old.data_ptr(), rs["k"].data_ptr(), _capi.current_stream()))
+
+    def meta_lcf(self, rs, eps_all, lcf_param, raw_mean_std, tail, col_adv, col_nei_adv):
+        _capi.check(_capi.lib.copo_meta_lcf_f64(
+            rs["pack"].data_ptr(), self.cfg.pack_width, int(col_adv), int(col_nei_adv), rs["rows_all"].data_ptr(),
+            rs["w_all"].data_ptr(), rs["denom_all"].data_ptr(), eps_all.data_ptr(), self.cfg.mb, rs["k"].data_ptr(),
+            lcf_param.data_ptr(), raw_mean_std.data_ptr(), tail.data_ptr(), _capi.current_stream()))
+
+    def meta_finish(self, rs, g_new, g_old, tail, lcf_param, adam_state, lr, stats_new, stats_old, stats, bump_index=True):
+        _capi.check(_capi.lib.copo_meta_finish_f64(
+            g_new.data_ptr(), g_old.data_ptr(), self.n_policy, tail.data_ptr(), lcf_param.data_ptr(),
+            adam_state.data_ptr(), float(lr), stats_new.data_ptr(), stats_old.data_ptr(), stats.data_ptr(),
+            rs["k"].data_ptr(), 1 if bump_index else 0, _capi.current_stream()))
 
     def state(self):
         return dict(adam_m=self.adam_m.clone(), adam_v=self.adam_v.clone(), step=self.step_count.clone())

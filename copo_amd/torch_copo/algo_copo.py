@@ -138,8 +138,9 @@ class CoPOPolicy(CCPPOPolicy):
         self.update_old_policy()
         self._lcf_optimizer = torch.optim.Adam([self.model.lcf_parameters], lr=self.config[LCF_LR],
                                                capturable=self.device.type == "cuda")
-        self._raw_lcf_adv_mean = torch.zeros((), dtype=torch.float64, device=self.device)
-        self._raw_lcf_adv_std = torch.ones((), dtype=torch.float64, device=self.device)
+        self._raw_ms = torch.tensor([0.0, 1.0], dtype=torch.float64, device=self.device)   # {mean, std} of A_c
+        self._raw_lcf_adv_mean, self._raw_lcf_adv_std = self._raw_ms[0], self._raw_ms[1]
+        self._lcf_adam = torch.zeros(5, dtype=torch.float64, device=self.device)         # fused path: m0 m1 v0 v1 step
         self._meta = None
         self._meta_bufs = None
 
@@ -278,26 +279,17 @@ class CoPOPolicy(CCPPOPolicy):
         from copo_amd import _capi
         mb_, fz = self._meta_bufs, self.fused
         rs = dict(self._row_sources, **{k: mb_[k] for k in ("rows_all", "w_all", "denom_all", "k")})
-        n = mb_["n_pol"]
         mb_["stats_new"].zero_()
         mb_["stats_old"].zero_()
-        fz.step(rs, head_mode=_capi.HEAD_META_NEW, apply_adam=False, grad=mb_["g_new"], stats=mb_["stats_new"],
-                bump_index=False)
-        fz.step(rs, head_mode=_capi.HEAD_META_OLD, apply_adam=False, theta=fz.target_flat.flat, grad=mb_["g_old"],
-                stats=mb_["stats_old"], bump_index=False)
-        k = mb_["k"]
-        rows = mb_["rows_all"].index_select(0, k).view(-1)
-        w = mb_["w_all"].index_select(0, k).view(-1).double()
-        denom = mb_["denom_all"].index_select(0, k).view(()).double()
-        pk = rs["pack"].index_select(0, rows)
-        eps = mb_["eps_all"].index_select(0, k).view(-1)
-        coordinated = self.model.compute_coordinated(ego=pk[:, mb_["col_adv"]], neighbor=pk[:, mb_["col_nei_adv"]], eps=eps)
-        lcf_loss = (((coordinated - self._raw_lcf_adv_mean) / self._raw_lcf_adv_std) * w).sum() / denom
-        d_lcf = torch.autograd.grad(lcf_loss, self.model.lcf_parameters)[0]
-        mb_["flat"].copy_(torch.cat([mb_["g_new"][:n].double(), mb_["g_old"][:n].double(), d_lcf.double(),
-                                     lcf_loss.detach().double().reshape(1)]))
-        mb_["stats_a"].copy_(torch.stack([mb_["stats_new"][1].double(), mb_["stats_old"][1].double(),
-                                          ((coordinated.detach() * w).sum() / denom), mb_["stats_new"][7].double()]))
+        fz.meta_grads(rs, mb_["g_new"], mb_["g_old"], mb_["stats_new"], mb_["stats_old"])
+        fz.meta_lcf(rs, mb_["eps_all"], self.model.lcf_parameters.data, self._raw_ms, mb_["tail"], mb_["col_adv"],
+                    mb_["col_nei_adv"])
+
+    def _meta_step_b_fused(self):
+        mb_, fz = self._meta_bufs, self.fused
+        rs = dict(self._row_sources, **{k: mb_[k] for k in ("rows_all", "w_all", "denom_all", "k")})
+        fz.meta_finish(rs, mb_["g_new"], mb_["g_old"], mb_["tail"], self.model.lcf_parameters.data, self._lcf_adam,
+                       self.config[LCF_LR], mb_["stats_new"], mb_["stats_old"], mb_["stats"])
 
     def _meta_step_a(self):
         if self.fused is not None:
@@ -316,6 +308,8 @@ class CoPOPolicy(CCPPOPolicy):
                                           ("new_policy_ego_loss", "old_policy_logp_loss", "coordinated_adv", "global_adv")]))
 
     def _meta_step_b(self):
+        if self.fused is not None:
+            return self._meta_step_b_fused()
         mb_ = self._meta_bufs
         st = self._meta_finish(mb_["flat"], {})
         a = mb_["stats_a"]
@@ -350,8 +344,10 @@ class CoPOPolicy(CCPPOPolicy):
                     cols[name] = off
                     off += wdt
                 nflat = self.fused.flat.numel
+                # one buffer: the policy blocks of g_new / g_old are adjacent -> a single [2 * n_pol] all-reduce
+                g_both = torch.zeros(n_pol + nflat, device=dev)
                 self._meta_bufs.update(
-                    g_new=torch.zeros(nflat, device=dev), g_old=torch.zeros(nflat, device=dev),
+                    g_both=g_both, g_new=g_both[:nflat], g_old=g_both[n_pol:], tail=torch.zeros(4, dtype=torch.float64, device=dev),
                     stats_new=torch.zeros(8, device=dev), stats_old=torch.zeros(8, device=dev),
                     col_adv=cols[Postprocessing.ADVANTAGES], col_nei_adv=cols[NEI_ADVANTAGE])
             self._meta = None
@@ -370,7 +366,11 @@ class CoPOPolicy(CCPPOPolicy):
             for _k in range(n_mb):
                 if D.is_dist():
                     self._meta[0]()
-                    D.all_reduce_sum_(mbuf["flat"])
+                    if self.fused is not None:
+                        D.all_reduce_sum_(mbuf["g_both"][:2 * mbuf["n_pol"]])
+                        D.all_reduce_sum_(mbuf["tail"])
+                    else:
+                        D.all_reduce_sum_(mbuf["flat"])
                     self._meta[1]()
                 else:
                     self._meta()
@@ -406,13 +406,16 @@ class CoPOPolicy(CCPPOPolicy):
 
     def get_state(self):
         st = super().get_state()
-        st.update(target_model=self.target_model.state_dict(), lcf_optimizer=self._lcf_optimizer.state_dict())
+        st.update(target_model=self.target_model.state_dict(), lcf_optimizer=self._lcf_optimizer.state_dict(),
+                  lcf_adam=self._lcf_adam.clone())
         return st
 
     def set_state(self, state):
         super().set_state(state)
         self.target_model.load_state_dict(state["target_model"])
         self._lcf_optimizer.load_state_dict(state["lcf_optimizer"])
+        if "lcf_adam" in state:
+            self._lcf_adam.copy_(state["lcf_adam"])
         if self._meta is not None:
             self._meta = None
 

@@ -113,9 +113,9 @@ def test_fused_sgd_matches_torch(name, fuse, odim, over):
         assert float(diff.max()) <= 3 * 2 * 3e-4 + 1e-6, (n1, float(diff.max()))
 
 
-def test_fused_meta_gradients_match_autograd():
-    """META_NEW / META_OLD head modes == the two autograd.grad calls of CoPOPolicy.meta_update (algo_copo.py:250-272)."""
-    from copo_amd import _capi
+def test_fused_meta_update_matches_autograd():
+    """Grouped META pass + fp64 LCF kernels == CoPOPolicy.meta_update's autograd path (algo_copo.py:228-309):
+    both policy gradients, the LCF loss terms, grad_value, and the LCF parameters after real Adam steps."""
     R, mb, odim = 1200, 512, 92
     ref = _make("copo", "none", odim, fused=False)
     fz = _make("copo", "none", odim, fused=True)
@@ -128,28 +128,36 @@ def test_fused_meta_gradients_match_autograd():
     idx = torch.arange(R, device="cuda")
     for pol in (ref, fz):
         pol.prepare_sgd(batch, R, mb)
+        pol._raw_lcf_adv_mean.fill_(0.3)
+        pol._raw_lcf_adv_std.fill_(2.0)
+    # drive both through run_meta's machinery with identical plans and eps
+    for pol in (ref, fz):
         torch.manual_seed(1)
-        pol.plan_epoch(idx, R, [R], mb)
-    ref._raw_lcf_adv_mean.fill_(0.3)
-    ref._raw_lcf_adv_std.fill_(2.0)
-    tb = ref._gather_minibatch()
-    eps = torch.randn(mb, dtype=torch.float64, device="cuda")
-    flat, stats = ref._meta_pieces(tb, eps)
-    n = sum(p.numel() for p in ref.model.policy_parameters())
-    rs = fz._row_sources
-    g_new, g_old = torch.zeros_like(fz.fused.grad), torch.zeros_like(fz.fused.grad)
-    s_new, s_old = torch.zeros(8, device="cuda"), torch.zeros(8, device="cuda")
-    fz.fused.step(rs, head_mode=_capi.HEAD_META_NEW, apply_adam=False, grad=g_new, stats=s_new, bump_index=False)
-    fz.fused.step(rs, head_mode=_capi.HEAD_META_OLD, apply_adam=False, theta=fz.fused.target_flat.flat, grad=g_old,
-                  stats=s_old, bump_index=False)
-    # autograd order: model.policy_parameters() = hidden layers then logits == first block of the flat buffer
-    a_new, a_old = flat[:n].float(), flat[n:2 * n].float()
-    for a, g in ((a_new, g_new[:n]), (a_old, g_old[:n])):
+        pol.use_graphs = False
+        pol.run_meta(idx, R, [R], mb, 0)            # allocates the meta buffers, no steps
+        torch.manual_seed(2)
+        pol.plan_epoch(idx, R, [R], mb, bufs=pol._meta_bufs)
+        pol._meta_bufs["eps_all"].normal_()
+    fz._meta_bufs["eps_all"].copy_(ref._meta_bufs["eps_all"])
+    assert torch.equal(ref._meta_bufs["rows_all"], fz._meta_bufs["rows_all"])
+    ref._meta_step_a()
+    fz._meta_step_a()
+    n = ref._meta_bufs["n_pol"]
+    flat = ref._meta_bufs["flat"]
+    for a, g in ((flat[:n].float(), fz._meta_bufs["g_new"][:n]), (flat[n:2 * n].float(), fz._meta_bufs["g_old"][:n])):
         scale = float(a.abs().max())
         assert float((a - g).abs().max()) <= 2e-4 * scale + 1e-8
-    np.testing.assert_allclose(float(s_new[1]), float(stats["new_policy_ego_loss"]), rtol=1e-4, atol=1e-6)
-    np.testing.assert_allclose(float(s_old[1]), float(stats["old_policy_logp_loss"]), rtol=1e-4, atol=1e-6)
-    np.testing.assert_allclose(float(s_new[7]), float(stats["global_adv"]), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(fz._meta_bufs["tail"][:3].cpu().numpy(), flat[2 * n:2 * n + 3].cpu().numpy(), rtol=1e-9, atol=1e-12)
+    # three full meta steps: LCF parameters must track the torch Adam path
+    ref._meta_step_b()
+    fz._meta_step_b()
+    for _ in range(2):
+        ref._meta_step_a(); ref._meta_step_b()
+        fz._meta_step_a(); fz._meta_step_b()
+    assert int(fz._meta_bufs["k"]) == 3 and int(ref._meta_bufs["k"]) == 3
+    np.testing.assert_allclose(fz.model.lcf_parameters.detach().cpu().numpy(), ref.model.lcf_parameters.detach().cpu().numpy(),
+                               rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(fz._meta_bufs["stats"].cpu().numpy(), ref._meta_bufs["stats"].cpu().numpy(), rtol=2e-4, atol=1e-7)
 
 
 def test_fused_trainer_iteration_and_graph_replay():
