@@ -96,56 +96,121 @@ __device__ __forceinline__ int region_of(const FusedArgs& a, int g) { return (bo
 // in range, masked scalars at the edges); the next slab is prefetched into registers while the MFMAs of the
 // current slab run.
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float4 load4(const float* p, int valid) {
-    if (valid >= 4 && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) return *reinterpret_cast<const float4*>(p);
+// 4 consecutive elements [off, off+4) of a row of `limit` floats, zeros beyond the limit or when !ok.
+// Branch-free on purpose: a divergent branch around a load makes the compiler drain vmcnt at the join, which
+// serialises the prefetch loads of a slab.  VEC requires 16-byte aligned rows and limit % 4 == 0.
+template <bool VEC>
+__device__ __forceinline__ float4 ld4(const float* row, int off, int limit, bool ok, int& mask) {
+    // returns RAW data from a clamped (always valid) address plus a 4-bit validity mask; the caller applies the
+    // mask when it stashes the registers to LDS, so that nothing consumes the load result before the MFMAs.
     float4 v;
-    v.x = valid > 0 ? p[0] : 0.0f;
-    v.y = valid > 1 ? p[1] : 0.0f;
-    v.z = valid > 2 ? p[2] : 0.0f;
-    v.w = valid > 3 ? p[3] : 0.0f;
+    if (VEC) {
+        const bool in = ok && (off + 4 <= limit);
+        v = *reinterpret_cast<const float4*>(row + (in ? off : 0));
+        mask = in ? 15 : 0;
+    } else {
+        const bool b0 = ok && off + 0 < limit, b1 = ok && off + 1 < limit, b2 = ok && off + 2 < limit, b3 = ok && off + 3 < limit;
+        v.x = row[b0 ? off + 0 : 0];
+        v.y = row[b1 ? off + 1 : 0];
+        v.z = row[b2 ? off + 2 : 0];
+        v.w = row[b3 ? off + 3 : 0];
+        mask = (b0 ? 1 : 0) | (b1 ? 2 : 0) | (b2 ? 4 : 0) | (b3 ? 8 : 0);
+    }
     return v;
 }
 
-template <class Op>
-__device__ __forceinline__ void tile_gemm(const Op& op, int g, int m0, int n0, int kbeg, int kend, v16f& acc) {
+__device__ __forceinline__ float4 apply_mask(float4 v, int mask, int one) {
+    // zero the invalid lanes of a quad; `one` (0..3, or -1) marks the position of the constant-1 bias column
+    v.x = (mask & 1) ? v.x : (one == 0 ? 1.0f : 0.0f);
+    v.y = (mask & 2) ? v.y : (one == 1 ? 1.0f : 0.0f);
+    v.z = (mask & 4) ? v.z : (one == 2 ? 1.0f : 0.0f);
+    v.w = (mask & 8) ? v.w : (one == 3 ? 1.0f : 0.0f);
+    return v;
+}
+
+// Per-workgroup operand context: plain scalars / global pointers in registers.  (Indexing the by-value argument
+// struct with a runtime group id, or mutating it, would push it to scratch and put dependent loads in front of
+// every operand fetch.)
+struct GemmCtx {
+    const float* __restrict__ abase;   // A operand rows
+    const float* __restrict__ bbase;   // B operand rows
+    const float* __restrict__ aux;     // bias (forward) / h1 (B2x)
+    float* __restrict__ out;
+    const int32_t* srow;               // LDS table of gathered row indices (layer 1)
+    int K;          // length of the k-contiguous rows / input width
+    int mb, H;
+    int64_t woff, boff;
+};
+
+template <class Op, bool VEC>
+__global__ void __launch_bounds__(256) gemm_kernel(FusedArgs a, int K) {
+    const int G = a.groups;
+    const int g = blockIdx.z % G, split = blockIdx.z / G, m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    __shared__ int32_t srow[COPO_PPO_MAX_MB];
     __shared__ __align__(16) float As[TK][LDP];
     __shared__ __align__(16) float Bs[TK][LDP];
+    if (Op::GATHER) {     // row indices of this minibatch once per workgroup (removes a dependent-load chain)
+        const int64_t base = kbase(a) * a.c.mb;
+        for (int i = threadIdx.x; i < a.c.mb; i += 256) srow[i] = (int32_t)a.rows[base + i];
+        __syncthreads();
+    }
+    const GemmCtx c = Op::prep(a, g, split, srow);
+    int kbeg = 0, kend = K;
+    if (Op::SPLITS_K) {
+        const int chunk = ((K + a.ksplit - 1) / a.ksplit + TK - 1) / TK * TK;
+        kbeg = split * chunk;
+        kend = kbeg + chunk < K ? kbeg + chunk : K;
+    }
+    v16f acc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     // per-thread slab coordinates: k-contiguous operands -> (row = tid/4, k = 8*(tid%4) + {0,4});
     //                              row-contiguous operands -> (k = tid/8, row = 8*(tid%8) + {0,4})
     const int a_r = Op::A_KCONTIG ? (tid >> 2) : ((tid & 7) * 8), a_k = Op::A_KCONTIG ? ((tid & 3) * 8) : (tid >> 3);
     const int b_r = Op::B_KCONTIG ? (tid >> 2) : ((tid & 7) * 8), b_k = Op::B_KCONTIG ? ((tid & 3) * 8) : (tid >> 3);
-    float4 ra[2], rb[2];
-    auto fetch = [&](int k0) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            ra[h] = Op::A_KCONTIG ? op.lda4(g, m0 + a_r, k0 + a_k + 4 * h, kend) : op.lda4(g, m0 + a_r + 4 * h, k0 + a_k, kend);
-            rb[h] = Op::B_KCONTIG ? op.ldb4(g, k0 + b_k + 4 * h, n0 + b_r, kend) : op.ldb4(g, k0 + b_k, n0 + b_r + 4 * h, kend);
-        }
-    };
-    auto stash = [&]() {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
+    float4 ra0, ra1, rb0, rb1;
+    int ma0, ma1, mb0, mb1, ob0 = -1, ob1 = -1;
+#define COPO_FETCH(k0)                                                                                              \
+    do {                                                                                                            \
+        if (Op::A_KCONTIG) {                                                                                        \
+            ra0 = Op::template lda4<VEC>(c, m0 + a_r, (k0) + a_k, kend, ma0);                                       \
+            ra1 = Op::template lda4<VEC>(c, m0 + a_r, (k0) + a_k + 4, kend, ma1);                                   \
+        } else {                                                                                                    \
+            ra0 = Op::template lda4<VEC>(c, m0 + a_r, (k0) + a_k, kend, ma0);                                       \
+            ra1 = Op::template lda4<VEC>(c, m0 + a_r + 4, (k0) + a_k, kend, ma1);                                   \
+        }                                                                                                           \
+        if (Op::B_KCONTIG) {                                                                                        \
+            rb0 = Op::template ldb4<VEC>(c, (k0) + b_k, n0 + b_r, kend, mb0, ob0);                                  \
+            rb1 = Op::template ldb4<VEC>(c, (k0) + b_k + 4, n0 + b_r, kend, mb1, ob1);                              \
+        } else {                                                                                                    \
+            rb0 = Op::template ldb4<VEC>(c, (k0) + b_k, n0 + b_r, kend, mb0, ob0);                                  \
+            rb1 = Op::template ldb4<VEC>(c, (k0) + b_k, n0 + b_r + 4, kend, mb1, ob1);                              \
+        }                                                                                                           \
+    } while (0)
+    if (kbeg < kend) COPO_FETCH(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += TK) {
+        {   // stash the prefetched registers (masking happens here, after the loads had a whole slab to land)
+            const float4 va0 = apply_mask(ra0, ma0, -1), va1 = apply_mask(ra1, ma1, -1);
+            const float4 vb0 = apply_mask(rb0, mb0, ob0), vb1 = apply_mask(rb1, mb1, ob1);
             if (Op::A_KCONTIG) {
-                As[a_k + 4 * h + 0][a_r] = ra[h].x; As[a_k + 4 * h + 1][a_r] = ra[h].y;
-                As[a_k + 4 * h + 2][a_r] = ra[h].z; As[a_k + 4 * h + 3][a_r] = ra[h].w;
+                As[a_k + 0][a_r] = va0.x; As[a_k + 1][a_r] = va0.y; As[a_k + 2][a_r] = va0.z; As[a_k + 3][a_r] = va0.w;
+                As[a_k + 4][a_r] = va1.x; As[a_k + 5][a_r] = va1.y; As[a_k + 6][a_r] = va1.z; As[a_k + 7][a_r] = va1.w;
             } else {
-                *reinterpret_cast<float4*>(&As[a_k][a_r + 4 * h]) = ra[h];
+                *reinterpret_cast<float4*>(&As[a_k][a_r]) = va0;
+                *reinterpret_cast<float4*>(&As[a_k][a_r + 4]) = va1;
             }
             if (Op::B_KCONTIG) {
-                Bs[b_k + 4 * h + 0][b_r] = rb[h].x; Bs[b_k + 4 * h + 1][b_r] = rb[h].y;
-                Bs[b_k + 4 * h + 2][b_r] = rb[h].z; Bs[b_k + 4 * h + 3][b_r] = rb[h].w;
+                Bs[b_k + 0][b_r] = vb0.x; Bs[b_k + 1][b_r] = vb0.y; Bs[b_k + 2][b_r] = vb0.z; Bs[b_k + 3][b_r] = vb0.w;
+                Bs[b_k + 4][b_r] = vb1.x; Bs[b_k + 5][b_r] = vb1.y; Bs[b_k + 6][b_r] = vb1.z; Bs[b_k + 7][b_r] = vb1.w;
             } else {
-                *reinterpret_cast<float4*>(&Bs[b_k][b_r + 4 * h]) = rb[h];
+                *reinterpret_cast<float4*>(&Bs[b_k][b_r]) = vb0;
+                *reinterpret_cast<float4*>(&Bs[b_k][b_r + 4]) = vb1;
             }
         }
-    };
-    fetch(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += TK) {
-        stash();
         __syncthreads();
-        if (k0 + TK < kend) fetch(k0 + TK);
+        if (k0 + TK < kend) COPO_FETCH(k0 + TK);
 #pragma unroll
         for (int kk = 0; kk < TK; kk += 2) {
             const float av = As[kk + (lane >> 5)][wm * 32 + (lane & 31)];
@@ -154,124 +219,131 @@ __device__ __forceinline__ void tile_gemm(const Op& op, int g, int m0, int n0, i
         }
         __syncthreads();
     }
+#undef COPO_FETCH
+    // accumulator element j of this lane: row = rbase + 8*(j/4) + (j%4), column = col
+    Op::store_tile(c, m0 + wm * 32 + (lane >> 5) * 4, n0 + wn * 32 + (lane & 31), acc);
 }
 
-template <class Op>
-__global__ void __launch_bounds__(256) gemm_kernel(Op op, int K) {
-    const int G = op.a.groups;
-    const int g = blockIdx.z % G, split = blockIdx.z / G, m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
-    __shared__ int32_t srow[COPO_PPO_MAX_MB];
-    if (op.needs_rows()) {     // row indices of this minibatch once per workgroup (removes a dependent-load chain)
-        const int64_t base = kbase(op.a) * op.a.c.mb;
-        for (int i = threadIdx.x; i < op.a.c.mb; i += 256) srow[i] = (int32_t)op.a.rows[base + i];
-        __syncthreads();
-    }
-    op.srow = srow;
-    int kbeg = 0, kend = K;
-    if (Op::SPLITS_K) {
-        const int chunk = ((K + op.a.ksplit - 1) / op.a.ksplit + TK - 1) / TK * TK;
-        kbeg = split * chunk;
-        kend = kbeg + chunk < K ? kbeg + chunk : K;
-    }
-    v16f acc;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
-    if (kbeg < kend) tile_gemm(op, g, m0, n0, kbeg, kend, acc);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int row = m0 + wm * 32 + (j >> 2) * 8 + (lane >> 5) * 4 + (j & 3);
-        const int col = n0 + wn * 32 + (lane & 31);
-        op.store(g, split, row, col, acc[j]);
-    }
-}
+#define COPO_ACC_ROW(rbase, j) ((rbase) + ((j) >> 2) * 8 + ((j) & 3))
 
 // ---- layer forward: Y[m][n] = tanh(sum_k X[m][k] W[n][k] + b[n]) --------------------------------------------
-struct FwdOp {
-    static constexpr bool A_KCONTIG = true, B_KCONTIG = true, SPLITS_K = false;
-    FusedArgs a;
-    int layer;   // 1 or 2
-    const int32_t* srow;
-    __device__ __forceinline__ bool needs_rows() const { return layer == 1; }
-    __device__ __forceinline__ int in_dim(int g) const { return layer == 1 ? net_of(a, g).in_dim : a.c.hidden; }
-    __device__ __forceinline__ float4 lda4(int g, int m, int k, int) const {     // 4 consecutive k of row m
-        const int K = in_dim(g);
-        if (m >= a.c.mb || k >= K) return make_float4(0.f, 0.f, 0.f, 0.f);
-        const float* p = (layer == 1) ? (src_of(a, g) + (size_t)srow[m] * K + k)
-                                      : (a.ws + ws_h1(a.c, g) + (size_t)m * a.c.hidden + k);
-        return load4(p, K - k);
+template <int LAYER>
+struct FwdOpT {
+    static constexpr bool A_KCONTIG = true, B_KCONTIG = true, SPLITS_K = false, GATHER = LAYER == 1;
+    __device__ static __forceinline__ GemmCtx prep(const FusedArgs& a, int g, int, const int32_t* srow) {
+        const copo_net_layout L = net_of(a, g);
+        GemmCtx c;
+        c.mb = a.c.mb; c.H = a.c.hidden; c.srow = srow;
+        c.K = GATHER ? L.in_dim : c.H;
+        c.abase = GATHER ? src_of(a, g) : a.ws + ws_h1(a.c, g);
+        const float* th = theta_of(a, g);
+        c.bbase = th + (GATHER ? L.w1 : L.w2);
+        c.aux = th + (GATHER ? L.b1 : L.b2);
+        c.out = a.ws + (GATHER ? ws_h1(a.c, g) : ws_h2(a.c, g));
+        c.woff = c.boff = 0;
+        return c;
     }
-    __device__ __forceinline__ float4 ldb4(int g, int k, int n, int) const {     // 4 consecutive k of weight row n
-        const int K = in_dim(g);
-        if (n >= a.c.hidden || k >= K) return make_float4(0.f, 0.f, 0.f, 0.f);
-        const copo_net_layout& L = net_of(a, g);
-        return load4(theta_of(a, g) + (layer == 1 ? L.w1 : L.w2) + (size_t)n * K + k, K - k);
+    template <bool VEC>
+    __device__ static __forceinline__ float4 lda4(const GemmCtx& c, int m, int k, int, int& mask) {   // row m, 4 k's
+        const bool ok = m < c.mb;
+        const int mc = ok ? m : 0;
+        const int r = GATHER ? c.srow[mc] : mc;
+        return ld4<VEC>(c.abase + (size_t)r * c.K, k, c.K, ok, mask);
     }
-    __device__ __forceinline__ void store(int g, int, int m, int n, float v) const {
-        if (m >= a.c.mb || n >= a.c.hidden) return;
-        const copo_net_layout& L = net_of(a, g);
-        const float y = tanhf(v + theta_of(a, g)[(layer == 1 ? L.b1 : L.b2) + n]);
-        a.ws[(layer == 1 ? ws_h1(a.c, g) : ws_h2(a.c, g)) + (size_t)m * a.c.hidden + n] = y;
+    template <bool VEC>
+    __device__ static __forceinline__ float4 ldb4(const GemmCtx& c, int k, int n, int, int& mask, int&) {   // weight row n
+        const bool ok = n < c.H;
+        return ld4<VEC>(c.bbase + (size_t)(ok ? n : 0) * c.K, k, c.K, ok, mask);
+    }
+    __device__ static __forceinline__ void store_tile(const GemmCtx& c, int rbase, int col, const v16f& acc) {
+        const bool cok = col < c.H;
+        const float bv = c.aux[cok ? col : 0];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int m = COPO_ACC_ROW(rbase, j);
+            const float y = tanhf(acc[j] + bv);
+            if (cok && m < c.mb) c.out[(size_t)m * c.H + col] = y;
+        }
     }
 };
 
 // ---- B2x: dz1[m][i] = (sum_o dz2[m][o] W2[o][i]) * (1 - h1[m][i]^2) -------------------------------------------
 struct BxOp {
-    static constexpr bool A_KCONTIG = true, B_KCONTIG = false, SPLITS_K = false;
-    FusedArgs a;
-    const int32_t* srow;
-    __device__ __forceinline__ bool needs_rows() const { return false; }
-    __device__ __forceinline__ float4 lda4(int g, int m, int k, int) const {     // dz2[m][k..k+3]
-        const int H = a.c.hidden;
-        if (m >= a.c.mb || k >= H) return make_float4(0.f, 0.f, 0.f, 0.f);
-        return load4(a.ws + ws_dz2(a.c, g) + (size_t)m * H + k, H - k);
+    static constexpr bool A_KCONTIG = true, B_KCONTIG = false, SPLITS_K = false, GATHER = false;
+    __device__ static __forceinline__ GemmCtx prep(const FusedArgs& a, int g, int, const int32_t* srow) {
+        GemmCtx c;
+        c.mb = a.c.mb; c.H = a.c.hidden; c.K = c.H; c.srow = srow;
+        c.abase = a.ws + ws_dz2(a.c, g);
+        c.bbase = theta_of(a, g) + net_of(a, g).w2;
+        c.aux = a.ws + ws_h1(a.c, g);
+        c.out = a.ws + ws_dz1(a.c, g);
+        c.woff = c.boff = 0;
+        return c;
     }
-    __device__ __forceinline__ float4 ldb4(int g, int k, int n, int) const {     // W2[k][n..n+3]
-        const int H = a.c.hidden;
-        if (k >= H || n >= H) return make_float4(0.f, 0.f, 0.f, 0.f);
-        return load4(theta_of(a, g) + net_of(a, g).w2 + (size_t)k * H + n, H - n);
+    template <bool VEC>
+    __device__ static __forceinline__ float4 lda4(const GemmCtx& c, int m, int k, int, int& mask) {     // dz2[m][k..k+3]
+        const bool ok = m < c.mb;
+        return ld4<VEC>(c.abase + (size_t)(ok ? m : 0) * c.H, k, c.H, ok, mask);
     }
-    __device__ __forceinline__ void store(int g, int, int m, int n, float v) const {
-        if (m >= a.c.mb || n >= a.c.hidden) return;
-        const float h = a.ws[ws_h1(a.c, g) + (size_t)m * a.c.hidden + n];
-        a.ws[ws_dz1(a.c, g) + (size_t)m * a.c.hidden + n] = v * (1.0f - h * h);
+    template <bool VEC>
+    __device__ static __forceinline__ float4 ldb4(const GemmCtx& c, int k, int n, int, int& mask, int&) {   // W2[k][n..n+3]
+        const bool ok = k < c.H;
+        return ld4<VEC>(c.bbase + (size_t)(ok ? k : 0) * c.H, n, c.H, ok, mask);
+    }
+    __device__ static __forceinline__ void store_tile(const GemmCtx& c, int rbase, int col, const v16f& acc) {
+        const bool cok = col < c.H;
+        float hv[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int m = COPO_ACC_ROW(rbase, j);
+            hv[j] = c.aux[(size_t)((cok && m < c.mb) ? m : 0) * c.H + (cok ? col : 0)];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int m = COPO_ACC_ROW(rbase, j);
+            if (cok && m < c.mb) c.out[(size_t)m * c.H + col] = acc[j] * (1.0f - hv[j] * hv[j]);
+        }
     }
 };
 
 // ---- Bw: partial dW[o][i] = sum_{m in split} dz[m][o] * [In | 1][m][i]; column i == in_dim is the bias --------
-struct BwOp {
-    static constexpr bool A_KCONTIG = false, B_KCONTIG = false, SPLITS_K = true;
-    FusedArgs a;
-    int layer;   // 2: dz2 x h1 ; 1: dz1 x X
-    const int32_t* srow;
-    __device__ __forceinline__ bool needs_rows() const { return layer == 1; }
-    __device__ __forceinline__ int in_dim(int g) const { return layer == 1 ? net_of(a, g).in_dim : a.c.hidden; }
-    __device__ __forceinline__ float4 lda4(int g, int o, int m, int mend) const {   // A(mm = o.., k = m) = dz[m][o..o+3]
-        const int H = a.c.hidden;
-        if (o >= H || m >= mend) return make_float4(0.f, 0.f, 0.f, 0.f);
-        return load4(a.ws + (layer == 2 ? ws_dz2(a.c, g) : ws_dz1(a.c, g)) + (size_t)m * H + o, H - o);
+template <int LAYER>   // 2: dz2 x h1 ; 1: dz1 x X (rows gathered)
+struct BwOpT {
+    static constexpr bool A_KCONTIG = false, B_KCONTIG = false, SPLITS_K = true, GATHER = LAYER == 1;
+    __device__ static __forceinline__ GemmCtx prep(const FusedArgs& a, int g, int split, const int32_t* srow) {
+        const copo_net_layout L = net_of(a, g);
+        GemmCtx c;
+        c.mb = a.c.mb; c.H = a.c.hidden; c.srow = srow;
+        c.K = GATHER ? L.in_dim : c.H;
+        c.abase = a.ws + (GATHER ? ws_dz1(a.c, g) : ws_dz2(a.c, g));
+        c.bbase = GATHER ? src_of(a, g) : a.ws + ws_h1(a.c, g);
+        c.aux = nullptr;
+        c.woff = GATHER ? L.w1 : L.w2;
+        c.boff = GATHER ? L.b1 : L.b2;
+        c.out = a.ws + ws_split(a.c, region_of(a, g), split);
+        return c;
     }
-    __device__ __forceinline__ float4 ldb4(int g, int m, int i, int mend) const {   // B(k = m, n = i..) = [In | 1][m][i..]
-        const int K = in_dim(g);
-        if (m >= mend || i > K) return make_float4(0.f, 0.f, 0.f, 0.f);
-        const float* p = (layer == 2) ? (a.ws + ws_h1(a.c, g) + (size_t)m * a.c.hidden + i)
-                                      : (src_of(a, g) + (size_t)srow[m] * K + i);
-        float4 v = load4(p, K - i);
-        const int one = K - i;          // position of the bias column inside this quad (0..3) if in range
-        if (one == 0) v.x = 1.0f;
-        else if (one == 1) v.y = 1.0f;
-        else if (one == 2) v.z = 1.0f;
-        else if (one == 3) v.w = 1.0f;
-        return v;
+    template <bool VEC>
+    __device__ static __forceinline__ float4 lda4(const GemmCtx& c, int o, int m, int mend, int& mask) {   // dz[m][o..o+3]
+        const bool ok = m < mend;
+        return ld4<VEC>(c.abase + (size_t)(ok ? m : 0) * c.H, o, c.H, ok, mask);
     }
-    __device__ __forceinline__ void store(int g, int split, int o, int i, float v) const {
-        const int K = in_dim(g);
-        if (o >= a.c.hidden || i > K) return;
-        const copo_net_layout& L = net_of(a, g);
-        const size_t idx = (i == K) ? (size_t)(layer == 1 ? L.b1 : L.b2) + o
-                                    : (size_t)(layer == 1 ? L.w1 : L.w2) + (size_t)o * K + i;
-        a.ws[ws_split(a.c, region_of(a, g), split) + idx] = v;
+    template <bool VEC>
+    __device__ static __forceinline__ float4 ldb4(const GemmCtx& c, int m, int i, int mend, int& mask, int& one) {   // [In|1][m][i..]
+        const bool ok = m < mend;
+        const int mc = ok ? m : 0;
+        const int r = GATHER ? c.srow[mc] : mc;
+        const int d = c.K - i;             // position of the constant-1 bias column inside this quad, if any
+        one = (ok && d >= 0 && d < 4) ? d : -1;
+        return ld4<VEC>(c.bbase + (size_t)r * c.K, i, c.K, ok, mask);
+    }
+    __device__ static __forceinline__ void store_tile(const GemmCtx& c, int rbase, int col, const v16f& acc) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int o = COPO_ACC_ROW(rbase, j);
+            if (o < c.H && col <= c.K)
+                c.out[(col == c.K) ? (size_t)c.boff + o : (size_t)c.woff + (size_t)o * c.K + col] = acc[j];
+        }
     }
 };
 
@@ -629,19 +701,29 @@ hipError_t launch_fused_step(FusedArgs a, hipStream_t s) {
     const copo_ppo_cfg& c = a.c;
     a.ksplit = pick_ksplit(c.mb);
     const int G = a.groups, mt = (c.mb + TM - 1) / TM, ht = (c.hidden + TN - 1) / TN;
-    FwdOp f1{a, 1, nullptr}, f2{a, 2, nullptr};
     int kmax1 = c.pol.in_dim;
     if (a.head_mode == COPO_HEAD_PPO)
         for (int g = 1; g < G; ++g) kmax1 = c.val[g - 1].in_dim > kmax1 ? c.val[g - 1].in_dim : kmax1;
-    hipLaunchKernelGGL(gemm_kernel<FwdOp>, dim3(ht, mt, G), dim3(256), 0, s, f1, kmax1);
-    hipLaunchKernelGGL(gemm_kernel<FwdOp>, dim3(ht, mt, G), dim3(256), 0, s, f2, c.hidden);
+    // vector path: every row the kernels touch is 16-byte aligned and a multiple of 4 floats long
+    bool vec = (c.hidden % 4 == 0) && (c.pol.in_dim % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.obs_src) & 15) == 0) &&
+               ((reinterpret_cast<uintptr_t>(a.cc_src) & 15) == 0) && ((reinterpret_cast<uintptr_t>(a.theta) & 15) == 0) &&
+               ((reinterpret_cast<uintptr_t>(a.ws) & 15) == 0) && (!a.theta2 || (reinterpret_cast<uintptr_t>(a.theta2) & 15) == 0);
+    const copo_net_layout* nets[4] = {&c.pol, &c.val[0], &c.val[1], &c.val[2]};
+    for (int g = 0; g < (a.head_mode == COPO_HEAD_PPO ? G : 1); ++g)
+        vec = vec && (nets[g]->in_dim % 4 == 0) && (nets[g]->w1 % 4 == 0) && (nets[g]->w2 % 4 == 0);
+#define COPO_GEMM(OP, grid, op, K)                                                                     \
+    do {                                                                                               \
+        if (vec) hipLaunchKernelGGL((gemm_kernel<OP, true>), grid, dim3(256), 0, s, a, K);             \
+        else hipLaunchKernelGGL((gemm_kernel<OP, false>), grid, dim3(256), 0, s, a, K);                \
+    } while (0)
+    COPO_GEMM(FwdOpT<1>, dim3(ht, mt, G), f1, kmax1);
+    COPO_GEMM(FwdOpT<2>, dim3(ht, mt, G), f2, c.hidden);
     const size_t lds = (size_t)(HT * (c.hidden + 1) + 4 * c.hidden + HT * 4 + 32) * sizeof(float);
     hipLaunchKernelGGL(head_kernel, dim3(head_tiles(c), G), dim3(256), lds, s, a);
-    BxOp bx{a, nullptr};
-    hipLaunchKernelGGL(gemm_kernel<BxOp>, dim3(ht, mt, G), dim3(256), 0, s, bx, c.hidden);
-    BwOp bw2{a, 2, nullptr}, bw1{a, 1, nullptr};
-    hipLaunchKernelGGL(gemm_kernel<BwOp>, dim3((c.hidden + 1 + TN - 1) / TN, ht, G * a.ksplit), dim3(256), 0, s, bw2, c.mb);
-    hipLaunchKernelGGL(gemm_kernel<BwOp>, dim3((kmax1 + 1 + TN - 1) / TN, ht, G * a.ksplit), dim3(256), 0, s, bw1, c.mb);
+    COPO_GEMM(BxOp, dim3(ht, mt, G), bx, c.hidden);
+    COPO_GEMM(BwOpT<2>, dim3((c.hidden + 1 + TN - 1) / TN, ht, G * a.ksplit), bw2, c.mb);
+    COPO_GEMM(BwOpT<1>, dim3((kmax1 + 1 + TN - 1) / TN, ht, G * a.ksplit), bw1, c.mb);
+#undef COPO_GEMM
     int maxsz = c.hidden * (kmax1 > c.hidden ? kmax1 : c.hidden);
     hipLaunchKernelGGL(reduce_adam_kernel, dim3((maxsz + 255) / 256, 6, G), dim3(256), 0, s, a);
     int64_t* st = a.apply_adam ? const_cast<int64_t*>(a.step) : nullptr;

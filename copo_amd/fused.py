@@ -22,17 +22,20 @@ class FlatParams:
 
     def __init__(self, module, device):
         self.params = [p for p in module.parameters() if p.dtype == torch.float32]
-        n = sum(p.numel() for p in self.params)
+        # every tensor starts on a 16-byte boundary so that the GEMM kernels can use float4 loads
+        offs, off = [], 0
+        for p in self.params:
+            offs.append(off)
+            off += (p.numel() + 3) // 4 * 4
+        n = off
         self.flat = torch.zeros(n, dtype=torch.float32, device=device)
         self.offset = {}
-        off = 0
         with torch.no_grad():
-            for p in self.params:
+            for p, off in zip(self.params, offs):
                 k = p.numel()
                 self.flat[off:off + k].copy_(p.data.reshape(-1))
                 p.data = self.flat[off:off + k].view_as(p)
                 self.offset[id(p)] = off
-                off += k
         self.numel = n
 
     def layout(self, linears, in_dim, out_dim):

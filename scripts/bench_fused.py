@@ -1,0 +1,29 @@
+"""Micro-benchmark of the fused learner step (eager launches, HIP events)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from test_gpu_fused_learner import _make, _dense_batch
+
+R, mb, odim = 82000, 512, 92
+pol = _make("copo", "none", odim, fused=True)
+batch = _dense_batch(pol, R, odim)
+idx = torch.arange(R, device="cuda")
+pol.prepare_sgd(batch, R, mb)
+pol.plan_epoch(idx, R, [R], mb)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+for _ in range(10):
+    pol.fused.step(pol._row_sources, stats=pol.fused.stats)
+torch.cuda.synchronize()
+pol._row_sources["k"].zero_()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+t0 = time.perf_counter()
+e0.record()
+for i in range(n):
+    if i % 128 == 0:
+        pol._row_sources["k"].zero_()          # stay inside the epoch plan (161 minibatches)
+    pol.fused.step(pol._row_sources, stats=pol.fused.stats)
+e1.record()
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+print("fused sgd step: %.1f us gpu, %.1f us host enqueue" % (e0.elapsed_time(e1) * 1e3 / n, (t1 - t0) * 1e6 / n))
