@@ -85,16 +85,17 @@ class PpoCfg(C.Structure):
 
 HEAD_PPO, HEAD_META_NEW, HEAD_META_OLD = 0, 1, 2
 PPO_STATS = 8
+META_DOT_PARTIALS = 8192
 
 _SIGS = {
     "copo_ppo_workspace_floats": (C.c_int64, [C.POINTER(PpoCfg)]),
     "copo_ppo_fused_step_f32": (C.c_int, [C.POINTER(PpoCfg)] + [C.c_void_p] * 14 + [C.c_int32, C.c_int32, C.c_void_p,
                                                                                    C.c_int32, C.c_void_p]),
     "copo_adam_step_f32": (C.c_int, [C.POINTER(PpoCfg)] + [C.c_void_p] * 4 + [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "copo_meta_grads_f32": (C.c_int, [C.POINTER(PpoCfg)] + [C.c_void_p] * 14),
+    "copo_meta_grads_f32": (C.c_int, [C.POINTER(PpoCfg)] + [C.c_void_p] * 15),
     "copo_meta_lcf_f64": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 4 + [C.c_int32] +
                           [C.c_void_p] * 5),
-    "copo_meta_finish_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
+    "copo_meta_finish_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "copo_version": (C.c_int, []),
     "copo_last_error": (C.c_char_p, []),

@@ -31,7 +31,7 @@ namespace copo {
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int TM = 64, TN = 64, TK = 32, LDP = 68;   // LDP: padded LDS row (floats)
-constexpr int HT = 32;                                // rows per workgroup of the head kernel
+constexpr int HT = 16;                                // rows per workgroup of the head kernel (16 threads per row)
 constexpr int MODE_META_BOTH = 3;                     // internal: group 0 = META_NEW on theta, group 1 = META_OLD on theta2
 
 struct FusedArgs {
@@ -59,6 +59,7 @@ struct FusedArgs {
     int32_t ksplit;            // row splits of the weight-gradient GEMMs
     const int64_t* kptr;       // [1] device minibatch index k; NULL -> 0
     int32_t bump_k;            // increment *kptr at the end of this call
+    double* dot_partials;      // META_BOTH: per-workgroup partials of <g_new, g_old> (COPO_META_DOT_PARTIALS doubles)
 };
 
 __device__ __forceinline__ int64_t kbase(const FusedArgs& a) { return a.kptr ? a.kptr[0] : 0; }
@@ -348,7 +349,7 @@ struct BwOpT {
 };
 
 // ------------------------------------------------------------------------------------------------------------
-// head + loss kernel: one workgroup per (32-row tile, net); 8 threads per row
+// head + loss kernel: one workgroup per (16-row tile, net); 16 threads per row
 // ------------------------------------------------------------------------------------------------------------
 constexpr float kLog2Pi = 1.8378770664093453f;
 
@@ -356,7 +357,7 @@ __global__ void __launch_bounds__(256) head_kernel(FusedArgs a) {
     extern __shared__ float lds[];
     const copo_ppo_cfg& c = a.c;
     const int H = c.hidden, g = blockIdx.y, tile = blockIdx.x, m0 = tile * HT;
-    const copo_net_layout& L = net_of(a, g);
+    const copo_net_layout L = net_of(a, g);
     const float* theta = theta_of(a, g);
     const int mode = mode_of(a, g);
     const bool policy = is_policy(a, g);
@@ -366,15 +367,21 @@ __global__ void __launch_bounds__(256) head_kernel(FusedArgs a) {
     float* douts = w3s + 4 * H;          // [HT][4]
     float* red = douts + HT * 4;         // [8 stats][4 waves]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // row bookkeeping first: these dependent loads (k -> row index -> pack row) overlap the tile load below
+    const int r = tid >> 4, part = tid & 15;
+    const int m = m0 + r;
+    const int64_t kb = kbase(a);
+    const bool rok = m < c.mb;
+    const float wgt = rok ? a.w[kb * c.mb + m] / a.denom[kb] : 0.0f;
+    const float* pk = a.pack_src + (size_t)(rok ? a.rows[kb * c.mb + m] : 0) * c.pack_width;
     const float* h2g = a.ws + ws_h2(c, g);
     for (int r = tid >> 6; r < HT; r += 4)
         for (int i = lane; i < H; i += 64) h2s[r * (H + 1) + i] = (m0 + r < c.mb) ? h2g[(size_t)(m0 + r) * H + i] : 0.0f;
     for (int q = tid; q < OD * H; q += 256) w3s[q] = theta[L.w3 + q];
     __syncthreads();
-    // outputs: 8 threads per row, each an eighth of the hidden units
-    const int r = tid >> 3, part = tid & 7;
+    // outputs: 16 threads per row, each a sixteenth of the hidden units
     float out[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int i = part; i < H; i += 8) {
+    for (int i = part; i < H; i += 16) {
         const float h = h2s[r * (H + 1) + i];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -385,16 +392,13 @@ __global__ void __launch_bounds__(256) head_kernel(FusedArgs a) {
         out[j] += __shfl_xor(out[j], 1);
         out[j] += __shfl_xor(out[j], 2);
         out[j] += __shfl_xor(out[j], 4);
+        out[j] += __shfl_xor(out[j], 8);
         if (j < OD) out[j] += theta[L.b3 + j];
     }
     // per-row loss terms and d(loss)/d(out)
     float st[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // total, policy, vf_ego, kl, entropy, vf_nei, vf_glob, adv
     float dout[4] = {0.f, 0.f, 0.f, 0.f};
-    const int m = m0 + r;
-    if (part == 0 && m < c.mb) {
-        const int64_t kb = kbase(a);
-        const float wgt = a.w[kb * c.mb + m] / a.denom[kb];
-        const float* pk = a.pack_src + (size_t)a.rows[kb * c.mb + m] * c.pack_width;
+    if (part == 0 && rok) {
         if (policy) {
             const int A = c.act_dim;     // A == 2
             float logp = 0.f, ent = 0.f, kl = 0.f, z[2], sig[2];
@@ -515,16 +519,9 @@ __global__ void __launch_bounds__(256) head_kernel(FusedArgs a) {
 
 // fold the split partials (W1, b1, W2, b2) and the head tile partials (W3, b3) in a fixed order, then Adam or
 // gradient store.  grid = (ceil(max tensor / 256), 6 tensors, groups)
-__global__ void __launch_bounds__(256) reduce_adam_kernel(FusedArgs a) {
+__device__ __forceinline__ float fold_partials(const FusedArgs& a, int g, int t, int e, size_t idx) {
     const copo_ppo_cfg& c = a.c;
-    const int g = blockIdx.z, t = blockIdx.y, H = c.hidden;
-    const copo_net_layout& L = net_of(a, g);
-    const int K1 = L.in_dim, OD = L.out_dim;
-    const int64_t off[6] = {L.w1, L.b1, L.w2, L.b2, L.w3, L.b3};
-    const int sz[6] = {H * K1, H, H * H, H, OD * H, OD};
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= sz[t]) return;
-    const size_t idx = (size_t)off[t] + e;
+    const int H = c.hidden;
     float s = 0.0f;
     if (t < 4) {
         const int reg = region_of(a, g);
@@ -534,6 +531,40 @@ __global__ void __launch_bounds__(256) reduce_adam_kernel(FusedArgs a) {
         const int j = (t == 4) ? e / H : e, i = (t == 4) ? e - j * H : H;
         for (int tl = 0; tl < tiles; ++tl) s += a.ws[ws_p3_at(c, g, tl) + j * (H + 1) + i];
     }
+    return s;
+}
+
+__global__ void __launch_bounds__(256) reduce_adam_kernel(FusedArgs a) {
+    const copo_ppo_cfg& c = a.c;
+    const int g = blockIdx.z, t = blockIdx.y, H = c.hidden;
+    const copo_net_layout L = net_of(a, g);
+    const int K1 = L.in_dim, OD = L.out_dim;
+    const int64_t off[6] = {L.w1, L.b1, L.w2, L.b2, L.w3, L.b3};
+    const int sz[6] = {H * K1, H, H * H, H, OD * H, OD};
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (both(a)) {
+        // meta pass: one thread folds BOTH gradients of its element and contributes g_new * g_old to a
+        // per-workgroup partial of the dot product (fixed order -> deterministic), consumed by meta_finish
+        __shared__ double red[4];
+        double prod = 0.0;
+        if (e < sz[t]) {
+            const size_t idx = (size_t)off[t] + e;
+            const float s0 = fold_partials(a, 0, t, e, idx), s1 = fold_partials(a, 1, t, e, idx);
+            a.grad[idx] = s0;
+            a.grad2[idx] = s1;
+            prod = (double)s0 * (double)s1;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) prod += __shfl_down(prod, o);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = prod;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            a.dot_partials[blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        return;
+    }
+    if (e >= sz[t]) return;
+    const size_t idx = (size_t)off[t] + e;
+    const float s = fold_partials(a, g, t, e, idx);
     if (a.apply_adam) {
         const float tt = (float)(a.step[0] + 1);
         const float bc1 = 1.0f - powf(c.beta1, tt), bc2s = sqrtf(1.0f - powf(c.beta2, tt));
@@ -636,15 +667,17 @@ __global__ void __launch_bounds__(1024) meta_lcf_kernel(MetaArgs a) {
 }
 
 struct MetaFinishArgs {
-    const float* g_new;
+    const float* g_new;        // used when dot_partials is NULL (data-parallel path: gradients were all-reduced)
     const float* g_old;
     int64_t n;
+    const double* dot_partials;
+    int32_t n_partials;
     const double* tail;        // [4]
     double* lcf_param;         // [2] updated in place
     double* adam;              // [5] = {m0, m1, v0, v1, step}
     double lr;
-    const float* stats_new;    // fused-step statistics of the two passes (may be NULL)
-    const float* stats_old;
+    float* stats_new;          // fused-step statistics of the two passes (may be NULL); cleared after use
+    float* stats_old;
     double* stats;             // [7] accumulated: new_loss, old_loss, S, gv*S, gv, mean A', mean global adv
     int64_t* kptr;
     int32_t bump_k;
@@ -653,7 +686,11 @@ struct MetaFinishArgs {
 __global__ void __launch_bounds__(1024) meta_finish_kernel(MetaFinishArgs a) {
     __shared__ double red[16];
     double s = 0.0;
-    for (int64_t i = threadIdx.x; i < a.n; i += blockDim.x) s += (double)a.g_new[i] * (double)a.g_old[i];
+    if (a.dot_partials) {
+        for (int i = threadIdx.x; i < a.n_partials; i += blockDim.x) s += a.dot_partials[i];
+    } else {
+        for (int64_t i = threadIdx.x; i < a.n; i += blockDim.x) s += (double)a.g_new[i] * (double)a.g_old[i];
+    }
     const double gv = block_sum_d(s, red);
     if (threadIdx.x == 0) {
         const double b1 = 0.9, b2 = 0.999, eps = 1e-8;
@@ -678,6 +715,9 @@ __global__ void __launch_bounds__(1024) meta_finish_kernel(MetaFinishArgs a) {
             a.stats[5] += a.tail[3];
             a.stats[6] += a.stats_new ? (double)a.stats_new[7] : 0.0;
         }
+        // the per-step statistics are consumed: clear them for the next meta step
+        if (a.stats_new) for (int j = 0; j < COPO_PPO_STATS; ++j) a.stats_new[j] = 0.0f;
+        if (a.stats_old) for (int j = 0; j < COPO_PPO_STATS; ++j) a.stats_old[j] = 0.0f;
         if (a.bump_k && a.kptr) a.kptr[0] += 1;
     }
 }
@@ -725,7 +765,7 @@ hipError_t launch_fused_step(FusedArgs a, hipStream_t s) {
     COPO_GEMM(BwOpT<1>, dim3((kmax1 + 1 + TN - 1) / TN, ht, G * a.ksplit), bw1, c.mb);
 #undef COPO_GEMM
     int maxsz = c.hidden * (kmax1 > c.hidden ? kmax1 : c.hidden);
-    hipLaunchKernelGGL(reduce_adam_kernel, dim3((maxsz + 255) / 256, 6, G), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(reduce_adam_kernel, dim3((maxsz + 255) / 256, 6, a.head_mode == MODE_META_BOTH ? 1 : G), dim3(256), 0, s, a);
     int64_t* st = a.apply_adam ? const_cast<int64_t*>(a.step) : nullptr;
     int64_t* kp = a.bump_k ? const_cast<int64_t*>(a.kptr) : nullptr;
     if (st || kp) hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, s, st, kp);
@@ -791,15 +831,17 @@ extern "C" int copo_ppo_fused_step_f32(const copo_ppo_cfg* cfg, float* theta, fl
 extern "C" int copo_meta_grads_f32(const copo_ppo_cfg* cfg, float* theta, float* theta_target, float* g_new, float* g_old,
                                    const float* obs_src, const float* pack_src, const int64_t* rows, const float* w,
                                    const float* denom, float* workspace, float* stats_new, float* stats_old,
-                                   int64_t* mb_index, void* stream) {
+                                   double* dot_partials, int64_t* mb_index, void* stream) {
     int rc = check_cfg(cfg);
     if (rc != COPO_OK) return rc;
-    if (!theta || !theta_target || !g_new || !g_old || !obs_src || !pack_src || !rows || !w || !denom || !workspace)
+    if (!theta || !theta_target || !g_new || !g_old || !obs_src || !pack_src || !rows || !w || !denom || !workspace ||
+        !dot_partials)
         return COPO_ERR_NULL;
     FusedArgs a;
     fill_common(a, cfg, obs_src, nullptr, pack_src, rows, w, denom, workspace, mb_index);
     a.theta = theta; a.theta2 = theta_target; a.grad = g_new; a.grad2 = g_old;
     a.stats = stats_new; a.stats2 = stats_old; a.apply_adam = 0; a.head_mode = MODE_META_BOTH; a.groups = 2;
+    a.dot_partials = dot_partials;
     hipError_t e = launch_fused_step(a, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
 }
@@ -815,14 +857,15 @@ extern "C" int copo_meta_lcf_f64(const float* pack_src, int32_t pack_width, int3
     return hipGetLastError() == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
 }
 
-extern "C" int copo_meta_finish_f64(const float* g_new, const float* g_old, int64_t n, const double* tail,
-                                    double* lcf_param, double* adam_state, double lr, const float* stats_new,
-                                    const float* stats_old, double* stats, int64_t* mb_index, int32_t bump_index,
-                                    void* stream) {
-    if (!g_new || !g_old || !tail || !lcf_param || !adam_state) return COPO_ERR_NULL;
+extern "C" int copo_meta_finish_f64(const float* g_new, const float* g_old, int64_t n, const double* dot_partials,
+                                    const double* tail, double* lcf_param, double* adam_state, double lr,
+                                    float* stats_new, float* stats_old, double* stats, int64_t* mb_index,
+                                    int32_t bump_index, void* stream) {
+    if (!tail || !lcf_param || !adam_state) return COPO_ERR_NULL;
+    if (!dot_partials && (!g_new || !g_old)) return COPO_ERR_NULL;
     if (n < 0) return COPO_ERR_DIM;
-    MetaFinishArgs a{g_new, g_old, n, tail, lcf_param, adam_state, lr, stats_new, stats_old, stats, mb_index,
-                     (mb_index && bump_index) ? 1 : 0};
+    MetaFinishArgs a{g_new, g_old, n, dot_partials, COPO_META_DOT_PARTIALS, tail, lcf_param, adam_state, lr, stats_new,
+                     stats_old, stats, mb_index, (mb_index && bump_index) ? 1 : 0};
     hipLaunchKernelGGL(meta_finish_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
 }

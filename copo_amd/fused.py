@@ -130,13 +130,14 @@ class FusedLearner:
             rs["k"].data_ptr(), _capi.current_stream()))
 
     # ---- LCF meta update (CoPO) -------------------------------------------------------------------------------
-    def meta_grads(self, rs, g_new, g_old, stats_new, stats_old):
-        """Both policy gradients of `meta_update` in one grouped pass (current policy / target policy)."""
+    def meta_grads(self, rs, g_new, g_old, stats_new, stats_old, dot_partials):
+        """Both policy gradients of `meta_update` in one grouped pass (current policy / target policy), plus the
+        per-workgroup partials of their dot product."""
         _capi.check(_capi.lib.copo_meta_grads_f32(
             C.byref(self.cfg), self.flat.flat.data_ptr(), self.target_flat.flat.data_ptr(), g_new.data_ptr(),
             g_old.data_ptr(), rs["obs"].data_ptr(), rs["pack"].data_ptr(), rs["rows_all"].data_ptr(),
             rs["w_all"].data_ptr(), rs["denom_all"].data_ptr(), self.workspace.data_ptr(), stats_new.data_ptr(),
-            stats_old.data_ptr(), rs["k"].data_ptr(), _capi.current_stream()))
+            stats_old.data_ptr(), dot_partials.data_ptr(), rs["k"].data_ptr(), _capi.current_stream()))
 
     def meta_lcf(self, rs, eps_all, lcf_param, raw_mean_std, tail, col_adv, col_nei_adv):
         _capi.check(_capi.lib.copo_meta_lcf_f64(
@@ -144,9 +145,12 @@ class FusedLearner:
             rs["w_all"].data_ptr(), rs["denom_all"].data_ptr(), eps_all.data_ptr(), self.cfg.mb, rs["k"].data_ptr(),
             lcf_param.data_ptr(), raw_mean_std.data_ptr(), tail.data_ptr(), _capi.current_stream()))
 
-    def meta_finish(self, rs, g_new, g_old, tail, lcf_param, adam_state, lr, stats_new, stats_old, stats, bump_index=True):
+    def meta_finish(self, rs, g_new, g_old, dot_partials, tail, lcf_param, adam_state, lr, stats_new, stats_old, stats,
+                    bump_index=True):
+        """dot_partials=None: recompute <g_new, g_old> from the (all-reduced) gradients."""
         _capi.check(_capi.lib.copo_meta_finish_f64(
-            g_new.data_ptr(), g_old.data_ptr(), self.n_policy, tail.data_ptr(), lcf_param.data_ptr(),
+            g_new.data_ptr(), g_old.data_ptr(), self.n_policy, None if dot_partials is None else dot_partials.data_ptr(),
+            tail.data_ptr(), lcf_param.data_ptr(),
             adam_state.data_ptr(), float(lr), stats_new.data_ptr(), stats_old.data_ptr(), stats.data_ptr(),
             rs["k"].data_ptr(), 1 if bump_index else 0, _capi.current_stream()))
 

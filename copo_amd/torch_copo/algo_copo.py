@@ -279,16 +279,15 @@ class CoPOPolicy(CCPPOPolicy):
         from copo_amd import _capi
         mb_, fz = self._meta_bufs, self.fused
         rs = dict(self._row_sources, **{k: mb_[k] for k in ("rows_all", "w_all", "denom_all", "k")})
-        mb_["stats_new"].zero_()
-        mb_["stats_old"].zero_()
-        fz.meta_grads(rs, mb_["g_new"], mb_["g_old"], mb_["stats_new"], mb_["stats_old"])
+        fz.meta_grads(rs, mb_["g_new"], mb_["g_old"], mb_["stats_new"], mb_["stats_old"], mb_["dot_partials"])
         fz.meta_lcf(rs, mb_["eps_all"], self.model.lcf_parameters.data, self._raw_ms, mb_["tail"], mb_["col_adv"],
                     mb_["col_nei_adv"])
 
     def _meta_step_b_fused(self):
         mb_, fz = self._meta_bufs, self.fused
         rs = dict(self._row_sources, **{k: mb_[k] for k in ("rows_all", "w_all", "denom_all", "k")})
-        fz.meta_finish(rs, mb_["g_new"], mb_["g_old"], mb_["tail"], self.model.lcf_parameters.data, self._lcf_adam,
+        fz.meta_finish(rs, mb_["g_new"], mb_["g_old"], None if D.is_dist() else mb_["dot_partials"], mb_["tail"],
+                       self.model.lcf_parameters.data, self._lcf_adam,
                        self.config[LCF_LR], mb_["stats_new"], mb_["stats_old"], mb_["stats"])
 
     def _meta_step_a(self):
@@ -348,6 +347,7 @@ class CoPOPolicy(CCPPOPolicy):
                 g_both = torch.zeros(n_pol + nflat, device=dev)
                 self._meta_bufs.update(
                     g_both=g_both, g_new=g_both[:nflat], g_old=g_both[n_pol:], tail=torch.zeros(4, dtype=torch.float64, device=dev),
+                    dot_partials=torch.zeros(8192, dtype=torch.float64, device=dev),
                     stats_new=torch.zeros(8, device=dev), stats_old=torch.zeros(8, device=dev),
                     col_adv=cols[Postprocessing.ADVANTAGES], col_nei_adv=cols[NEI_ADVANTAGE])
             self._meta = None

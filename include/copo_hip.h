@@ -204,6 +204,7 @@ typedef struct copo_net_layout {
 #define COPO_HEAD_META_NEW 1   /* policy net only, loss = mean(-clipped surrogate) with the global advantage */
 #define COPO_HEAD_META_OLD 2   /* policy net only, loss = mean(logp(action))  (target network)           */
 #define COPO_PPO_MAX_MB 1024   /* rows per minibatch supported by the fused learner */
+#define COPO_META_DOT_PARTIALS 8192 /* doubles in the `dot_partials` workspace of the meta update */
 #define COPO_PPO_MAX_KSPLIT 4  /* row splits of the weight-gradient GEMMs (fixed order -> deterministic sums) */
 #define COPO_PPO_STATS 8       /* sums of: total, policy, vf_ego, kl, entropy, vf_nei, vf_glob, advantage  */
 
@@ -246,8 +247,9 @@ int copo_adam_step_f32(const copo_ppo_cfg* cfg, float* theta, float* adam_m, flo
  *     block is written).  stats_new[1] / stats_old[1] accumulate the two losses, stats_new[7] the mean advantage. */
 int copo_meta_grads_f32(const copo_ppo_cfg* cfg, float* theta, float* theta_target, float* g_new, float* g_old,
                         const float* obs_src, const float* pack_src, const int64_t* rows, const float* w,
-                        const float* denom, float* workspace, float* stats_new, float* stats_old, int64_t* mb_index,
-                        void* stream);
+                        const float* denom, float* workspace, float* stats_new, float* stats_old,
+                        double* dot_partials /* [COPO_META_DOT_PARTIALS], zero-initialised once by the caller */,
+                        int64_t* mb_index, void* stream);
 /* (2) fp64 LCF terms of the minibatch: tail = {dS/dp0, dS/dp1, S, mean(A')} with S = mean((A' - mu)/sigma),
  *     A' = cos(phi) A_ego + sin(phi) A_nei, phi = (lcf_mean + lcf_std * eps) * pi/2 (reparameterised sample).
  *     eps [n_mb][mb] doubles; lcf_param [2] doubles (the model's lcf_parameters); raw_mean_std [2] doubles. */
@@ -255,13 +257,15 @@ int copo_meta_lcf_f64(const float* pack_src, int32_t pack_width, int32_t col_adv
                       const int64_t* rows, const float* w, const float* denom, const double* eps, int32_t mb,
                       const int64_t* mb_index, const double* lcf_param, const double* raw_mean_std, double* tail,
                       void* stream);
-/* (3) grad_value = <g_new[0:n], g_old[0:n]> (fp64 accumulate), LCF gradient grad_value * tail[0:2], Adam (fp64,
+/* (3) grad_value = <g_new[0:n], g_old[0:n]> -- from the per-workgroup partials that (1) left in dot_partials, or,
+ *     when dot_partials is NULL (data-parallel: the gradients were all-reduced in between), recomputed from
+ *     g_new / g_old -- (fp64 accumulate), LCF gradient grad_value * tail[0:2], Adam (fp64,
  *     betas 0.9/0.999, eps 1e-8) on lcf_param in place; adam_state [5] doubles = {m0, m1, v0, v1, step};
  *     stats [7] doubles accumulate {new loss, old loss, S, grad_value*S, grad_value, mean A', mean global adv}.
  *     Data-parallel runs all-reduce g_new/g_old (and tail) between (2) and (3). */
-int copo_meta_finish_f64(const float* g_new, const float* g_old, int64_t n, const double* tail, double* lcf_param,
-                         double* adam_state, double lr, const float* stats_new, const float* stats_old, double* stats,
-                         int64_t* mb_index, int32_t bump_index, void* stream);
+int copo_meta_finish_f64(const float* g_new, const float* g_old, int64_t n, const double* dot_partials,
+                         const double* tail, double* lcf_param, double* adam_state, double lr, float* stats_new,
+                         float* stats_old, double* stats, int64_t* mb_index, int32_t bump_index, void* stream);
 
 #ifdef __cplusplus
 }
