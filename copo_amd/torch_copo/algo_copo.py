@@ -324,7 +324,7 @@ class CoPOPolicy(CCPPOPolicy):
         """`lcf_num_iters` passes of shuffled minibatches through `meta_update` (algo_copo.py:581-589)."""
         rs = self._row_sources
         dev = self.device
-        max_mb = max(1, math.ceil(rs["max_rows"] / mb))
+        max_mb = max(rs["max_mb"], 1) if mb == rs["mb"] else max(1, math.ceil(rs["max_mb"] * rs["mb"] / mb))
         n_pol = sum(p.numel() for p in self.model.policy_parameters())
         if self._meta_bufs is None or self._meta_bufs["mb"] != mb or self._meta_bufs["max_mb"] != max_mb:
             self._meta_bufs = dict(

@@ -258,7 +258,10 @@ class PPOPolicyBase:
         width = sum(w for _, w in cols)
         dev = self.device
         if self._row_sources is None or self._row_sources["max_rows"] != max_rows or self._row_sources["mb"] != mb:
-            max_mb = max(1, math.ceil(max_rows / mb))
+            # minibatch tables are sized for the LARGEST rank (every rank runs the same number of steps)
+            gmax = torch.tensor([max_rows], dtype=torch.int64, device=dev)
+            D.all_reduce_max_(gmax)
+            max_mb = max(1, math.ceil(int(gmax.item()) / mb))
             self._row_sources = dict(
                 max_rows=max_rows, mb=mb, max_mb=max_mb,
                 pack=torch.zeros(max_rows, width, dtype=torch.float32, device=dev),

@@ -1,0 +1,150 @@
+"""CPU: the C-ABI library loads and exports every symbol include/copo_hip.h declares (no compute calls without a
+GPU); map tables are well-formed; invariants of the build-defined simulator spec on the CPU oracle."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from copo_amd import maps
+from copo_amd.sim import SimConfig
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from copo_amd import _capi
+    header = open(os.path.join(ROOT, "include", "copo_hip.h")).read()
+    declared = set(re.findall(r"\b(copo_[a-z0-9_]+)\s*\(", header))
+    declared -= {"copo_sim", "copo_sim_cfg", "copo_step_out", "copo_net_layout", "copo_ppo_cfg"}
+    assert len(declared) >= 20
+    lib = C.CDLL(_capi.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libcopo_hip.so does not export %s" % name
+    assert set(_capi.EXPORTED_SYMBOLS) == declared, set(_capi.EXPORTED_SYMBOLS) ^ declared
+    assert _capi.lib.copo_version() == _capi.ABI_VERSION == 1
+    assert C.sizeof(_capi.SimCfg) == C.sizeof(ol.SimCfg)
+
+
+def test_create_rejects_bad_arguments_without_a_gpu():
+    """Argument validation happens before any HIP call, so the error codes are observable on a CPU-only host."""
+    from copo_amd import _capi
+    from copo_amd.sim import fill_cfg_struct
+    h = C.c_void_p()
+    assert _capi.lib.copo_sim_create(None, 0, C.byref(h)) == -1
+    struct, keep = fill_cfg_struct(SimConfig(num_envs=2, num_agents=8), _capi.SimCfg)
+    struct.num_agents = 65
+    assert _capi.lib.copo_sim_create(C.byref(struct), 0, C.byref(h)) == -2
+    assert b"num_agents" in _capi.lib.copo_last_error()
+    struct.num_agents = 8
+    struct.n_spawns = 4                       # fewer spawn points than agents
+    assert _capi.lib.copo_sim_create(C.byref(struct), 0, C.byref(h)) == -5
+    assert _capi.lib.copo_gae3_f32(None, None, None, 1, 1, 1, None, 0.9, None, None, None) == -1
+    assert _capi.lib.copo_neighbours_f32(1, 1, None, 1, 65, 4, 40.0, 10.0, None, None, None, None, None, None, None) == -2
+
+
+@pytest.mark.parametrize("name", sorted(maps.MAP_BUILDERS))
+def test_map_tables(name):
+    t = maps.MAP_BUILDERS[name]()
+    assert t.route_segs.shape[1:] == (maps.MAX_SEGS + 1, maps.SEG_STRIDE) and t.n_spawns >= t.default_num_agents
+    for r in range(t.n_routes):
+        nseg = int(t.route_meta[r, 3])
+        seg = t.route_segs[r].astype(np.float64)
+        assert 1 <= nseg <= maps.MAX_SEGS and seg[0, 5] == 0.0            # first piece straight (spawn piece)
+        assert abs(seg[:nseg, 4].sum() - t.route_meta[r, 0]) < 1e-3       # lengths add up
+        assert np.all(np.abs(seg[:nseg, 5] * seg[:nseg, 4]) <= np.radians(100) + 1e-6)   # arcs never wrap atan2
+        pts = maps.route_points(t, r, 0.5)
+        assert np.linalg.norm(np.diff(pts, axis=0), axis=1).max() < 0.6   # G0 continuity across pieces
+    # spawn poses of one map keep the clearance the simulator asks for
+    sp = []
+    for s in range(t.n_spawns):
+        g = t.route_segs[t.spawn_tab[s, 0], 0]
+        sp.append((g[0] + g[2] * t.spawn_s[s], g[1] + g[3] * t.spawn_s[s]))
+    sp = np.array(sp)
+    d = np.linalg.norm(sp[:, None] - sp[None], axis=-1) + np.eye(len(sp)) * 1e9
+    assert d.min() > 3.0
+
+
+def _rollout(cfg, steps, seed=0, policy="cruise"):
+    s = ol.OracleSim(cfg)
+    o = s.reset()
+    rng = np.random.RandomState(seed)
+    hist = []
+    for t in range(steps):
+        if policy == "cruise":      # lane-keeping controller on the ego block of the observation
+            psi = (o["obs"][..., 2] - 0.5) * np.pi
+            lat = (o["obs"][..., 8] - 0.5) * 2 * cfg.lane_width
+            steer = np.clip(-1.5 * psi - 0.25 * lat + rng.normal(0, 0.02, psi.shape), -1, 1)
+            act = np.stack([steer, np.full((s.E, s.N), 0.5)], -1)
+        else:
+            act = rng.uniform(-1, 1, (s.E, s.N, 2))
+        o = s.step(act.astype(np.float32))
+        hist.append({k: v.copy() for k, v in o.items()})
+    return s, hist
+
+
+def test_sim_invariants_on_the_oracle():
+    cfg = SimConfig(map="intersection", num_envs=3, num_agents=30, horizon=200, delay_done=5)
+    s, hist = _rollout(cfg, 420)
+    spawned_total = 0
+    for t, o in enumerate(hist):
+        f = o["flags"]
+        acted, done, spawned = (f & 1) > 0, (f & 2) > 0, (f & 64) > 0
+        assert np.all(o["obs"] >= 0) and np.all(o["obs"] <= 1) and np.isfinite(o["rew"]).all()
+        assert not np.any(done & ~acted)                                    # only acting agents terminate
+        assert np.all(((f & (4 | 8 | 16 | 32)) > 0)[done])                  # every done has a reason
+        assert np.all(o["nbr_cnt"][~(acted | spawned)] == 0)                # absent slots have no neighbours
+        assert np.all(o["rew"][~acted] == 0)                                # respawned agents enter with reward 0
+        lcf = o["lcf"][acted | spawned]
+        assert np.all(np.abs(lcf) <= 1)
+        tails = o["obs"][..., -1][acted | spawned]
+        if not (f & 128).any():
+            np.testing.assert_array_equal(tails, ((lcf + 1) * 0.5).astype(np.float32))
+        # neighbour lists: sorted by distance, inside the radius, symmetric membership
+        for e in range(s.E):
+            for n in np.nonzero(acted[e])[0]:
+                c = min(o["nbr_cnt"][e, n], s.K)
+                d = o["nbr_dist"][e, n, :c]
+                assert np.all(np.diff(d) >= 0) and np.all(d < cfg.neighbours_distance)
+                assert o["mf_cnt"][e, n] == np.sum(o["nbr_dist"][e, n, :c] <= cfg.mf_distance) or o["nbr_cnt"][e, n] > s.K
+        spawned_total += int(spawned.sum())
+        if (f & 128).any():                                                 # horizon: the whole scene resets
+            assert (t + 1) % cfg.horizon == 0 and np.all((f[(f & 128) > 0] & 64) > 0)
+    assert spawned_total > 0
+    flags = np.stack([h["flags"] for h in hist])
+    assert ((flags & 4) > 0).sum() > 0, "cruising straight must reach some destinations"
+    s.close()
+
+
+def test_sim_is_deterministic_and_seed_sensitive():
+    cfg = SimConfig(map="roundabout", num_envs=2, num_agents=20, horizon=80)
+    _, a = _rollout(cfg, 100, seed=1, policy="random")
+    _, b = _rollout(cfg, 100, seed=1, policy="random")
+    for x, y in zip(a, b):
+        for k in x:
+            assert np.array_equal(x[k], y[k]), k
+    s = ol.OracleSim(cfg)
+    o1 = {k: v.copy() for k, v in s.reset(np.array([1, 2], np.uint64)).items()}
+    o2 = s.reset(np.array([3, 4], np.uint64))
+    assert not np.array_equal(o1["lcf"], o2["lcf"])
+    s.close()
+
+
+def test_lcf_sampling_matches_reference_distribution(golden_dir):
+    """LCF at spawn ~ clip(N(mean, std), -1, 1) (env_wrappers.py:410-413): the oracle's counter-based sampler must
+    reproduce the moments and clip mass of the reference's draws (different RNG streams -> statistical test)."""
+    g = np.load(os.path.join(golden_dir, "lcf_sampling.npz"))
+    for j in range(3):
+        mean, std = g["d%d_mean_std" % j]
+        cfg = SimConfig(map="intersection", num_envs=64, num_agents=40, lcf_mean=float(mean), lcf_std=float(std))
+        s = ol.OracleSim(cfg)
+        lcf = s.reset(np.arange(64, dtype=np.uint64) + 17 * j)["lcf"].ravel()
+        ref = g["d%d_lcf" % j]
+        n = len(lcf)
+        assert abs(lcf.mean() - ref.mean()) < 4 * ref.std() / np.sqrt(min(n, len(ref))) + 1e-3
+        assert abs(lcf.std() - ref.std()) < 0.06 * ref.std() + 1e-3
+        for edge in (-1.0, 1.0):
+            assert abs((lcf == edge).mean() - (ref == edge).mean()) < 0.03
+        s.close()

@@ -1,0 +1,151 @@
+"""CPU, world_size 2 over gloo: the data-parallel exchange steps of the learner (copo_amd/dist.py).
+
+Two ranks hold different rows.  After PPO minibatch steps and LCF meta steps both ranks must hold identical
+parameters, and those must equal a single-process replay on the UNION of the two ranks' minibatches:
+  * gradients are summed over ranks with the global row count as denominator (== mean over the union),
+  * both meta gradients are all-reduced BEFORE their dot product (the product of sums, not the sum of products),
+  * advantage statistics are global.
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R_PER_RANK = (300, 212)       # unequal shards: the smaller rank pads with zero-weight rows
+MB = 128
+
+
+def _policy():
+    from copo_amd.engine import Box
+    from copo_amd.torch_copo import algo_copo as A
+    from copo_amd.torch_copo.utils.env_wrappers import MultiAgentIntersectionEnv, get_lcf_env, get_rllib_compatible_env
+    cfg = A.CoPOConfig()
+    env = get_rllib_compatible_env(get_lcf_env(MultiAgentIntersectionEnv))
+    cfg.update_from_dict(dict(env=env, device="cpu", use_hip_graphs=False, seed=5, sgd_minibatch_size=MB,
+                              model={"fcnet_hiddens": [32, 32]}))
+    cfg.validate()
+    pol = A.CoPOPolicy(Box(-1, 1, (12,)), Box(-1, 1, (2,)), cfg)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(9)
+        for p in list(pol.model.parameters()) + list(pol.target_model.parameters()):
+            if p.dtype == torch.float32:
+                p.add_(torch.randn(p.shape, generator=g) * 0.05)
+    return pol
+
+
+def _batch(rank, R):
+    from copo_amd.engine import Postprocessing, SampleBatch, TorchDiagGaussian
+    g = torch.Generator().manual_seed(100 + rank)
+    rn = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
+    b = SampleBatch()
+    b[SampleBatch.OBS] = torch.rand(R, 12, generator=g) * 2 - 1
+    b[SampleBatch.ACTIONS] = rn(R, 2) * 0.8
+    di = torch.cat([rn(R, 2) * 0.3, rn(R, 2) * 0.2 - 0.2], 1)
+    b[SampleBatch.ACTION_DIST_INPUTS] = di
+    b[SampleBatch.ACTION_LOGP] = TorchDiagGaussian(di).logp(b[SampleBatch.ACTIONS])
+    for k, s in [(Postprocessing.ADVANTAGES, 2), (SampleBatch.VF_PREDS, 3), ("nei_advantage", 2), ("global_advantages", 1),
+                 ("nei_values", 3), ("global_values", 30), ("normalized_advantages", 1)]:
+        b[k] = rn(R) * s
+    b[Postprocessing.VALUE_TARGETS] = b[SampleBatch.VF_PREDS] + rn(R) * 2
+    b["nei_target"] = b["nei_values"] + rn(R) * 2
+    b["global_target"] = b["global_values"] + rn(R) * 20
+    b[SampleBatch.FLAGS] = torch.ones(R, dtype=torch.uint8)
+    return b
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    from copo_amd import dist as D
+    D.init_from_env("cpu")
+    assert D.world_size() == world
+    pol = _policy()
+    R = R_PER_RANK[rank]
+    batch = _batch(rank, R)
+    pol.prepare_sgd(batch, R, MB)
+    idx = torch.arange(R)
+    B_all = D.all_gather_int(R, "cpu")
+    assert B_all == list(R_PER_RANK)
+    # global advantage statistics (VecTrainer.standardize_advantages uses the same collective)
+    stats = torch.tensor([float(R), float(batch["advantages"].sum()), float((batch["advantages"] ** 2).sum())],
+                         dtype=torch.float64)
+    D.all_reduce_sum_(stats)
+    pol._raw_lcf_adv_mean.fill_(0.25)
+    pol._raw_lcf_adv_std.fill_(1.5)
+    torch.manual_seed(1234 + rank)           # different shuffles per rank, like real shards
+    sgd = pol.run_sgd(idx, R, B_all, MB, 1)
+    rows_sgd = pol._row_sources["rows_all"].clone()
+    w_sgd = pol._row_sources["w_all"].clone()
+    den_sgd = pol._row_sources["denom_all"].clone()
+    meta = pol.run_meta(idx, R, B_all, MB, 1)
+    mbuf = pol._meta_bufs
+    torch.save(dict(
+        params={k: v.clone() for k, v in pol.model.state_dict().items()}, sgd=sgd, meta=meta, stats=stats,
+        rows_sgd=rows_sgd, w_sgd=w_sgd, den_sgd=den_sgd, rows_meta=mbuf["rows_all"].clone(), w_meta=mbuf["w_all"].clone(),
+        den_meta=mbuf["denom_all"].clone(), eps_meta=mbuf["eps_all"].clone()), os.path.join(out_dir, "rank%d.pt" % rank))
+    D.barrier()
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_learner_equals_union_replay():
+    from copo_amd.engine import SampleBatch
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(2, _free_port(), d), nprocs=2, join=True)
+        r = [torch.load(os.path.join(d, "rank%d.pt" % k), weights_only=False) for k in range(2)]
+    # 1. ranks agree bit for bit
+    for k in r[0]["params"]:
+        assert torch.equal(r[0]["params"][k], r[1]["params"][k]), k
+    assert torch.equal(r[0]["stats"], r[1]["stats"]) and r[0]["stats"][0] == sum(R_PER_RANK)
+    assert r[0]["sgd"]["num_sgd_steps"] == r[1]["sgd"]["num_sgd_steps"] == 3        # ceil(300 / 128)
+    # 2. single-process replay on the union of the two ranks' minibatches
+    pol = _policy()
+    pol._raw_lcf_adv_mean.fill_(0.25)
+    pol._raw_lcf_adv_std.fill_(1.5)
+    batches = [_batch(k, R_PER_RANK[k]) for k in range(2)]
+    cols = [n for n, _ in pol.train_columns()] + [SampleBatch.OBS]
+
+    def union(rows_key, w_key, step):
+        tb = SampleBatch()
+        parts = {c: [] for c in cols}
+        ws = []
+        for k in range(2):
+            rows = r[k][rows_key][step]
+            for c in cols:
+                parts[c].append(batches[k][c][rows])
+            ws.append(r[k][w_key][step])
+        for c in cols:
+            tb[c] = torch.cat(parts[c])
+        tb["centralized_critic_obs"] = tb[SampleBatch.OBS]
+        tb[SampleBatch.VALID] = torch.cat(ws)
+        return tb
+
+    opt = torch.optim.Adam([p for p in pol.model.parameters() if p.dtype == torch.float32], lr=float(pol.config["lr"]))
+    for step in range(3):
+        tb = union("rows_sgd", "w_sgd", step)
+        assert float(tb[SampleBatch.VALID].sum()) == float(r[0]["den_sgd"][step])     # global denominator
+        opt.zero_grad()
+        pol.loss(pol.model, pol.dist_class, tb).backward()
+        opt.step()
+    for step in range(3):
+        tb = union("rows_meta", "w_meta", step)
+        eps = torch.cat([r[k]["eps_meta"][step] for k in range(2)])
+        pol.meta_update(tb, eps=eps)
+    for k, v in pol.model.state_dict().items():
+        torch.testing.assert_close(v, r[0]["params"][k], rtol=2e-5, atol=2e-7, msg=k)
+    assert abs(pol.model.lcf_parameters[0].item()) > 0           # the meta step moved the LCF
