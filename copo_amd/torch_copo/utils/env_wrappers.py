@@ -60,6 +60,9 @@ class MultiAgentMetaDrive:
         if "lcf_normal_std" in cfg:
             sim_kwargs["lcf_std"] = float(cfg["lcf_normal_std"])
         self.sim_config = SimConfig(**sim_kwargs)
+        if self.sim_config.num_envs == 1 and "nbr_k" not in cfg:
+            # the dict API reports complete neighbour lists like the reference (trainers keep the top-8 by default)
+            self.sim_config.nbr_k = max(1, self.sim_config.resolved()[1] - 1)
         self.sim = VecSim(self.sim_config, device=int(cfg.get("device", 0) or 0))
         self.num_envs, self.num_agents = self.sim.E, self.sim.N
         self._slot_ids = None      # dict API state (num_envs == 1)

@@ -1,0 +1,134 @@
+"""GPU: the dense postprocess against the reference's per-trajectory `postprocess_trajectory` golden vectors, the
+three trainers end to end, and the dict-style env API."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from copo_amd.engine import Box, Postprocessing, SampleBatch  # noqa: E402
+
+
+def _policy(kind, fuse, odim):
+    from copo_amd.torch_copo import algo_ccppo as C, algo_copo as A
+    from copo_amd.torch_copo.utils.env_wrappers import (MultiAgentIntersectionEnv, get_ccenv, get_lcf_env,
+                                                        get_rllib_compatible_env)
+    pcls, ccls = (A.CoPOPolicy, A.CoPOConfig) if kind == "copo" else (C.CCPPOPolicy, C.CCPPOConfig)
+    cfg = ccls()
+    env = get_rllib_compatible_env(get_lcf_env(MultiAgentIntersectionEnv) if kind == "copo"
+                                   else get_ccenv(MultiAgentIntersectionEnv))
+    cfg.update_from_dict(dict(env=env, device="cuda", use_hip_graphs=False, use_fused_learner=False,
+                              model={"fcnet_hiddens": [16, 16]}))
+    cfg.fuse_mode = fuse
+    cfg.validate()
+    return pcls(Box(-1, 1, (odim,)), Box(-1, 1, (2,)), cfg)
+
+
+@pytest.mark.parametrize("kind,fuse", [("copo", "none"), ("copo", "mf"), ("copo", "concat"), ("ccppo", "mf"),
+                                       ("ccppo", "concat")])
+def test_dense_postprocess_vs_reference(golden_dir, kind, fuse):
+    """CCPPOPolicy / CoPOPolicy.postprocess_trajectory (algo_ccppo.py:322-374, algo_copo.py:473-502): centralised
+    critic obs, value heads, GAE per agent trajectory incl. slot reuse and truncated-fragment bootstrap."""
+    g = np.load(os.path.join(golden_dir, "postprocess_%s_%s.npz" % (kind, fuse)))
+    obs = g["in_obs"]
+    T, N, O = obs.shape
+    pol = _policy(kind, fuse, O)
+    pol.model.load_state_dict({k[2:]: torch.as_tensor(g[k]) for k in g.files if k.startswith("w_")})
+    acted, done = g["in_acted"], g["in_done"]
+    flags = (acted * 1 + (done & acted) * 2).astype(np.uint8)
+    K = g["in_nbr_idx"].shape[-1]
+    mf_cnt = ((g["in_nbr_dist"] <= 10.0) & (np.arange(K)[None, None] < g["in_nbr_cnt"][..., None])).sum(-1)
+    cu = lambda a, dt=None: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).cuda().unsqueeze(1).contiguous()  # noqa: E731
+    rew3 = np.stack([g["in_rew"], g["in_nei_r"], g["in_glob_r"]]).astype(np.float32)
+    b = SampleBatch({SampleBatch.OBS: cu(obs), SampleBatch.ACTIONS: cu(g["in_act"]), SampleBatch.FLAGS: cu(flags),
+                     "nbr_idx": cu(g["in_nbr_idx"]), "nbr_cnt": cu(g["in_nbr_cnt"]), "mf_cnt": cu(mf_cnt.astype(np.int32)),
+                     "rew3": torch.as_tensor(rew3).cuda().unsqueeze(2).contiguous(), "step_lcf": cu(g["in_lcf"])})
+    out = pol.postprocess_trajectory(b)
+    m = acted
+    chk = [(SampleBatch.VF_PREDS, "vf_preds"), (Postprocessing.ADVANTAGES, "advantages"),
+           (Postprocessing.VALUE_TARGETS, "value_targets")]
+    if kind == "copo":
+        chk += [(k, k) for k in ("nei_values", "nei_advantage", "nei_target", "global_values", "global_advantages",
+                                 "global_target")]
+    np.testing.assert_allclose(out["centralized_critic_obs"][:, 0].cpu().numpy()[m], g["out_cc_obs"][m], rtol=1e-6, atol=1e-7)
+    for mine, ref in chk:
+        np.testing.assert_allclose(out[mine][:, 0].cpu().numpy()[m], g["out_" + ref][m], rtol=2e-5, atol=2e-5, err_msg=ref)
+
+
+@pytest.mark.parametrize("algo,extra", [("ippo", {}), ("ccppo", dict(fuse_mode="mf")), ("ccppo", dict(fuse_mode="concat")),
+                                        ("copo", {}), ("copo", dict(use_fused_learner=False, use_hip_graphs=False))])
+def test_trainers_run_and_report(algo, extra):
+    from copo_amd.torch_copo.algo_ccppo import CCPPOTrainer, get_ccppo_env
+    from copo_amd.torch_copo.algo_copo import CoPOTrainer
+    from copo_amd.torch_copo.algo_ippo import IPPOTrainer
+    from copo_amd.torch_copo.utils.callbacks import MultiAgentDrivingCallbacks
+    from copo_amd.torch_copo.utils.env_wrappers import (MultiAgentIntersectionEnv, MultiAgentRoundaboutEnv, get_lcf_env,
+                                                        get_rllib_compatible_env)
+    if algo == "ippo":
+        cls, env = IPPOTrainer, get_rllib_compatible_env(MultiAgentIntersectionEnv)
+    elif algo == "ccppo":
+        cls, env = CCPPOTrainer, get_ccppo_env(MultiAgentRoundaboutEnv)
+    else:
+        cls, env = CoPOTrainer, get_rllib_compatible_env(get_lcf_env(MultiAgentIntersectionEnv))
+    cfg = dict(env=env, env_config=dict(num_agents=12, horizon=60), num_envs=8, train_batch_size=8 * 10,
+               sgd_minibatch_size=128, num_sgd_iter=2, seed=0, callbacks=MultiAgentDrivingCallbacks,
+               model={"fcnet_hiddens": [64, 64]}, **extra)
+    if algo == "copo":
+        cfg["lcf_num_iters"] = 2
+    a = cls(config=cfg)
+    for _ in range(5):
+        res = a.train()
+    st = res["info"]["learner"]["default"]["learner_stats"]
+    assert all(np.isfinite(v) for v in st.values()), st
+    assert res["timesteps_total"] == 5 * 80 and res["agent_timesteps_total"] > 0
+    for k in ("success", "crash", "out", "max_step", "length", "cost", "rc", "episode_reward_mean"):
+        assert k in res
+    if algo == "copo":
+        mu = res["info"]["learner"]["default"]["custom_metrics"]["meta_update"]
+        assert {"lcf", "lcf_std", "grad_value", "raw_lcf_adv_mean_value", "lcf_final_loss"} <= set(mu)
+        assert abs(a.env.current_lcf_mean - mu["lcf"]) < 1e-9        # pushed to the envs (algo_copo.py:608-611)
+        tgt, cur = a.policy.target_model.state_dict(), a.policy.model.state_dict()
+        assert all(torch.equal(tgt[k], cur[k]) for k in cur)          # update_old_policy
+    path = a.save_checkpoint("/tmp/copo_ckpt_test")
+    w0 = {k: v.clone() for k, v in a.policy.model.state_dict().items()}
+    a.train()
+    a.load_checkpoint(path)
+    assert all(torch.equal(v, a.policy.model.state_dict()[k]) for k, v in w0.items())
+    a.stop()
+
+
+def test_dict_env_api_matches_reference_surface():
+    """reset()/step(dict) of `get_lcf_env(MultiAgentIntersectionEnv)` as the reference's scripts use it
+    (env_wrappers.py:600-617): agent-id keyed dicts, `__all__`, the info keys of CCEnv / LCFEnv."""
+    from copo_amd.torch_copo.utils.env_wrappers import MultiAgentIntersectionEnv, get_lcf_env
+    env = get_lcf_env(MultiAgentIntersectionEnv)(dict(num_agents=10, horizon=50))
+    o = env.reset(force_seed=0)
+    assert len(o) == 10 and all(v.shape == (92,) and v.dtype == np.float32 for v in o.values())
+    assert set(o) == set(env.vehicles) and env.observation_space["agent0"].contains(o["agent0"])
+    seen_done, seen_spawn = False, False
+    for t in range(50):
+        before = set(env.vehicles)
+        o, r, d, i = env.step({k: [0.0, 1.0] for k in env.vehicles})
+        assert set(r) == set(d) - {"__all__"} == set(i) and before <= set(i)
+        for k in before:
+            inf = i[k]
+            for key in ("neighbours", "neighbours_distance", "all_agents", "nei_rewards", "global_rewards", "lcf", "lcf_deg",
+                        "coordinated_rewards", "native_rewards", "arrive_dest", "crash", "out_of_road", "velocity",
+                        "steering", "acceleration", "step_reward", "cost", "episode_length", "episode_reward",
+                        "route_completion"):
+                assert key in inf, key
+            assert inf["native_rewards"] == r[k] and -1 <= inf["lcf"] <= 1 and 0 <= o[k][-1] <= 1
+            assert inf["neighbours_distance"] == sorted(inf["neighbours_distance"])
+            if inf["neighbours"]:
+                assert abs(inf["nei_rewards"] - np.mean([r[n] for n in inf["neighbours"] if n in r])) < 1e-5 or \
+                    any(n not in r for n in inf["neighbours"])
+            seen_done |= d[k]
+        seen_spawn |= len(set(o) - before) > 0
+        if d["__all__"]:
+            assert t == 49
+            break
+    assert seen_done and seen_spawn and d["__all__"]
+    env.set_lcf_dist(0.5, 0.2)
+    env.close()
