@@ -50,7 +50,7 @@ static int upload(copo_sim* s, const T* host, size_t count, const T** dev) {
     return COPO_OK;
 }
 
-static int pick_block(int E) { return E <= 1024 ? 1024 : (E <= 4096 ? 512 : 256); }
+static int pick_block(int E) { return E <= 512 ? 1024 : (E <= 2048 ? 512 : 256); }
 
 extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** out) {
     if (!cfg || !out) return fail(COPO_ERR_NULL, "copo_sim_create: cfg/out is NULL");
@@ -106,6 +106,7 @@ extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** o
     p.enable_lcf = cfg->enable_lcf; p.horizon = cfg->horizon; p.delay_done = cfg->delay_done;
     p.respawn_cooldown = cfg->respawn_cooldown; p.substeps = cfg->substeps;
     p.n_routes = cfg->n_routes; p.n_spawns = cfg->n_spawns;
+    p.lidar_task_cap = cfg->num_agents * cfg->num_lasers < 8192 ? cfg->num_agents * cfg->num_lasers : 8192;
     p.lidar_range = cfg->lidar_range; p.neighbours_distance = cfg->neighbours_distance; p.mf_distance = cfg->mf_distance;
     p.dt = cfg->dt; p.hl = cfg->veh_half_len; p.hw = cfg->veh_half_wid; p.wheelbase = cfg->wheelbase;
     p.max_steer = cfg->max_steer; p.max_speed = cfg->max_speed; p.acc_max = cfg->acc_max; p.brake_max = cfg->brake_max;
@@ -184,6 +185,12 @@ extern "C" int copo_sim_set_force_lcf(copo_sim* s, double v) {
     if (v != -100.0 && (v < -1.0 || v > 1.0)) return fail(COPO_ERR_CONFIG, "force_lcf=%g not in [-1,1] (or -100)", v);
     s->force_lcf = v;
     s->lcf_dirty = true;
+    return COPO_OK;
+}
+
+extern "C" int copo_sim_set_debug(copo_sim* s, int64_t* stamps) {
+    if (!s) return fail(COPO_ERR_NULL, "copo_sim_set_debug: NULL handle");
+    s->p.dbg = reinterpret_cast<long long*>(stamps);
     return COPO_OK;
 }
 

@@ -17,6 +17,7 @@ enum : uint32_t { RNG_ROUTE = 1, RNG_LCF1 = 2, RNG_LCF2 = 3, RNG_SPAWN = 4, RNG_
 struct SimParams {
     int32_t E, N, O, K, num_lasers, enable_lcf, horizon, delay_done, respawn_cooldown, substeps;
     int32_t n_routes, n_spawns;
+    int32_t lidar_task_cap;        // entries of the LDS (ray, candidate) task list of the LiDAR pass
     float lidar_range, neighbours_distance, mf_distance, dt, hl, hw, wheelbase, max_steer, max_speed;
     float acc_max, brake_max, drag, spawn_clearance;
     float driving_reward, speed_reward, success_reward, crash_penalty, out_penalty, arrive_margin, lane_width;
@@ -28,6 +29,7 @@ struct SimParams {
     const int32_t* spawn_tab;      // [P][4]
     const float* spawn_s;          // [P]
     const float* ray_cs;           // [num_lasers][2]
+    long long* dbg;                // optional [E][8] phase timestamps (clock64) of the step kernel; NULL = off
     const float* lcf_dist;         // [2] = {mean (force_lcf folded in), std}: device memory so that captured graphs see updates
 };
 

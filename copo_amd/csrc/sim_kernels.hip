@@ -119,10 +119,12 @@ struct __align__(16) EnvLds {
     float ego[64][20];
     float ray[COPO_MAX_LASERS][2];
     unsigned long long cand[64];
+    float sorted[16][64];      // per-wave scratch of the neighbour phase
     unsigned long long m_acted, m_present, m_solid;
     uint8_t crash[64];
     int16_t perm[COPO_MAX_SPAWNS];
     int32_t ending;
+    int32_t ntasks;            // LiDAR task list fill
 };
 
 // Full reset of one env by wave 0 (all lanes call; lane n < N owns slot n).
@@ -146,13 +148,17 @@ __device__ __forceinline__ void reset_env_wave0(const SimParams& p, EnvLds& L, u
 }
 
 // neighbour lists + reward reductions (CCEnv / LCFEnv) for agents i = wave, wave+nw, ...; lane = other agent j
-__device__ __forceinline__ void neighbours_phase(const SimParams& p, const EnvLds& L, int e, int wave, int nwaves,
+//
+// The reference orders by d = sqrt_rn(dx^2 + dy^2) in float64 (np.linalg.norm) with ties in slot order and tests
+// `d < radius` (env_wrappers.py:125-158); the same fp64 operations are evaluated here, one sqrt per (i, j) pair.
+__device__ __forceinline__ void neighbours_phase(const SimParams& p, EnvLds& L, int e, int wave, int nwaves,
                                                  int lane, const StepOut& out) {
     const int N = p.N, K = p.K;
     const unsigned long long present = L.m_present;
     const bool pj = (lane < N) && ((present >> lane) & 1ull);
     const double xj = (double)L.x[lane & 63], yj = (double)L.y[lane & 63];
     const size_t base = (size_t)e * N;
+    const double R = (double)p.neighbours_distance, M = (double)p.mf_distance;
     if (wave == 0 && out.glob_rew) {  // LCFEnv.step: sum(r.values()) / len(r.values()) in slot order, fp64
         double gs = 0.0;
         int gc = 0;
@@ -165,17 +171,30 @@ __device__ __forceinline__ void neighbours_phase(const SimParams& p, const EnvLd
         }
         if (lane == 0) out.glob_rew[e] = gc ? (float)(gs / (double)gc) : 0.0f;
     }
+    float* srt = L.sorted[wave & 15];   // per-wave scratch: rewards in list order
     for (int i = wave; i < N; i += nwaves) {
         const bool pi = (present >> i) & 1ull;
+        if (!pi) {   // absent slot: empty list (uniform branch)
+            if (lane == 0) {
+                if (out.nbr_cnt) out.nbr_cnt[base + i] = 0;
+                if (out.mf_cnt) out.mf_cnt[base + i] = 0;
+                if (out.nei_rew) out.nei_rew[base + i] = 0.0f;
+            }
+            if (lane < K) {
+                if (out.nbr_idx) out.nbr_idx[(base + i) * K + lane] = -1;
+                if (out.nbr_dist) out.nbr_dist[(base + i) * K + lane] = 0.0f;
+            }
+            continue;
+        }
         const double dx = (double)L.x[i] - xj, dy = (double)L.y[i] - yj;
         const double d = sqrt(dx * dx + dy * dy);
-        const bool inr = pi && pj && (lane != i) && (d < (double)p.neighbours_distance);
+        const bool in_m = d <= M;
+        const bool inr = pj && (lane != i) && (d < R);
         const unsigned long long mask = __ballot(inr);
         const int cnt = __popcll(mask);
-        const int mfc = __popcll(__ballot(inr && (d <= (double)p.mf_distance)));
+        const int mfc = __popcll(__ballot(inr && in_m));
         // rank of j in i's list: stable order by (d, slot) == python sorted() on an insertion-ordered dict
         int rank = 0;
-        double nsum = 0.0;
         unsigned long long m = mask;
         while (m) {
             const int k = __ffsll((long long)m) - 1;
@@ -184,12 +203,14 @@ __device__ __forceinline__ void neighbours_phase(const SimParams& p, const EnvLd
             rank += (dk < d || (dk == d && k < lane)) ? 1 : 0;
         }
         if (out.nei_rew) {  // mean of neighbour rewards, summed in list order in fp64 (env_wrappers.py:321-325)
-            for (int r = 0; r < cnt; ++r) {
-                const unsigned long long who = __ballot(inr && rank == r);
-                const int j = __ffsll((long long)who) - 1;
-                nsum += (double)L.rew[j];
-            }
+            if (inr) srt[rank] = L.rew[lane];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double nsum = 0.0;
+            for (int r = 0; r < cnt; ++r) nsum += (double)srt[r];
             if (lane == 0) out.nei_rew[base + i] = cnt ? (float)(nsum / (double)cnt) : 0.0f;
+            __builtin_amdgcn_wave_barrier();
         }
         if (lane == 0) {
             if (out.nbr_cnt) out.nbr_cnt[base + i] = cnt;
@@ -251,10 +272,34 @@ __device__ __forceinline__ void ego_navi_obs(const SimParams& p, EnvLds& L, int 
     o[19] = (s.lcf + 1.0f) * 0.5f;
 }
 
+// Ray (origin (x, y), unit direction (dxr, dyr)) against the box of vehicle j: entering distance, or a negative
+// value for a miss.  Box frame mirrored so that the direction is non-negative on both axes; entering / exiting
+// times are fractions n/a compared by cross-multiplication, one IEEE division only for an actual hit (spec 3.4-9).
+__device__ __forceinline__ float ray_box(float rx, float ry, float dxr, float dyr, float cj, float sj, float hl, float hw) {
+    const float ox = -(rx * cj + ry * sj), oy = -(ry * cj - rx * sj);
+    const float ddx = dxr * cj + dyr * sj, ddy = dyr * cj - dxr * sj;
+    const float ax = fabsf(ddx), ay = fabsf(ddy);
+    const float oxs = ddx < 0.0f ? -ox : ox, oys = ddy < 0.0f ? -oy : oy;
+    const float nxe = -(hl + oxs), nxx = hl - oxs, nye = -(hw + oys), nyx = hw - oys;
+    if (!(nxx >= 0.0f && nyx >= 0.0f)) return -1.0f;
+    if (!(nxe * ay <= nyx * ax)) return -1.0f;
+    if (!(nye * ax <= nxx * ay)) return -1.0f;
+    const bool usex = nxe * ay >= nye * ax;
+    const float n = usex ? nxe : nye, a = usex ? ax : ay;
+    return n > 0.0f ? n / a : 0.0f;
+}
+
 // LiDAR + observation write-out, all threads of the workgroup.  Precondition: L.x/y/cs/sn, m_present,
 // m_solid, ego tile are final and visible (caller synchronised).
+//
+// The expensive box test runs on dense lanes: every wave owns 64 consecutive rays, walks their (ray, candidate)
+// pairs with the cheap reject (candidate centre behind the origin / farther than the circumradius from the ray
+// line) and appends the survivors to a small per-wave LDS queue; whenever 64 tasks are queued the whole wave runs
+// the box test on them and folds hits into the per-ray minimum with LDS atomicMin on the float bit pattern
+// (distances are >= 0, so unsigned order == float order and the result is independent of the task order).
 __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, int tid, int nthreads,
                                           float* __restrict__ obs) {
+    extern __shared__ unsigned int dyn[];
     const int N = p.N, O = p.O, NL = p.num_lasers;
     const int wave = tid >> 6, lane = tid & 63, nwaves = nthreads >> 6;
     const float hl = p.hl, hw = p.hw;
@@ -262,6 +307,9 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
     const float range = p.lidar_range;
     const float lim = range + circ;
     const unsigned long long solid = L.m_solid, present = L.m_present;
+    const int total = N * NL;
+    unsigned int* wbest = dyn + wave * 192;       // [64] best distance of this wave's rays (float bits)
+    unsigned int* wq = wbest + 64;                // [128] queued tasks: (local ray << 6) | candidate
     // candidate masks: solid vehicles within range + circumradius of agent i
     for (int i = wave; i < N; i += nwaves) {
         const float rx = L.x[lane] - L.x[i], ry = L.y[lane] - L.y[i];
@@ -277,53 +325,63 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
         if (c < 19) eobs[(size_t)i * O + c] = L.ego[i][c];
         else if (p.enable_lcf) eobs[(size_t)i * O + O - 1] = L.ego[i][19];
     }
-    // rays
-    const int total = N * NL;
-    for (int q = tid; q < total; q += nthreads) {
-        const int i = q / NL, k = q - i * NL;
-        float val = 0.0f;
-        if ((present >> i) & 1ull) {
-            const float x = L.x[i], y = L.y[i], ci = L.cs[i], si = L.sn[i];
+    const unsigned int range_bits = __float_as_uint(range);
+    auto run_tasks = [&](int q0, int n) {   // lanes < n take one queued task each
+        if (lane < n) {
+            const unsigned int tk = wq[lane];
+            const int lr = (int)(tk >> 6), j = (int)(tk & 63u);
+            const int q = q0 + lr;
+            const int i = q / NL, k = q - i * NL;
+            const float ci = L.cs[i], si = L.sn[i];
             const float rc = L.ray[k][0], rs = L.ray[k][1];
-            const float dxr = ci * rc - si * rs;
-            const float dyr = si * rc + ci * rs;
-            float best = range;
-            unsigned long long m = L.cand[i];
-            while (m) {
-                const int j = __ffsll((long long)m) - 1;
+            const float t = ray_box(L.x[j] - L.x[i], L.y[j] - L.y[i], ci * rc - si * rs, si * rc + ci * rs, L.cs[j], L.sn[j], hl, hw);
+            if (t >= 0.0f) atomicMin(&wbest[lr], __float_as_uint(t));
+        }
+    };
+    for (int q0 = wave * 64; q0 < total; q0 += nwaves * 64) {
+        const int q = q0 + lane;
+        const bool live = q < total;
+        const int i = live ? q / NL : 0, k = live ? q - i * NL : 0;
+        const bool pres = live && ((present >> i) & 1ull);
+        unsigned long long m = pres ? L.cand[i] : 0ull;
+        const float x = L.x[i], y = L.y[i], ci = L.cs[i], si = L.sn[i];
+        const float rc = L.ray[k][0], rs = L.ray[k][1];
+        const float dxr = ci * rc - si * rs;
+        const float dyr = si * rc + ci * rs;
+        wbest[lane] = range_bits;
+        int qc = 0;                              // wave-uniform queue fill
+        while (__ballot(m != 0ull)) {
+            bool pass = false;
+            int j = 0;
+            if (m) {
+                j = __ffsll((long long)m) - 1;
                 m &= m - 1;
                 const float rx = L.x[j] - x, ry = L.y[j] - y;
                 const float along = dxr * rx + dyr * ry;
                 const float perp = dxr * ry - dyr * rx;
-                if (along < -circ || fabsf(perp) > circ) continue;
-                const float cj = L.cs[j], sj = L.sn[j];
-                const float ox = -(rx * cj + ry * sj), oy = -(ry * cj - rx * sj);
-                const float ddx = dxr * cj + dyr * sj, ddy = dyr * cj - dxr * sj;
-                float tlo = -1e30f, thi = 1e30f;
-                bool miss = false;
-                if (fabsf(ddx) < 1e-9f) {
-                    if (fabsf(ox) > hl) miss = true;
-                } else {
-                    const float t1 = (-hl - ox) / ddx, t2 = (hl - ox) / ddx;
-                    const float a = t1 < t2 ? t1 : t2, b = t1 < t2 ? t2 : t1;
-                    if (a > tlo) tlo = a;
-                    if (b < thi) thi = b;
-                }
-                if (fabsf(ddy) < 1e-9f) {
-                    if (fabsf(oy) > hw) miss = true;
-                } else {
-                    const float t1 = (-hw - oy) / ddy, t2 = (hw - oy) / ddy;
-                    const float a = t1 < t2 ? t1 : t2, b = t1 < t2 ? t2 : t1;
-                    if (a > tlo) tlo = a;
-                    if (b < thi) thi = b;
-                }
-                if (miss || tlo > thi || thi < 0.0f) continue;
-                const float t = tlo > 0.0f ? tlo : 0.0f;
-                if (t < best) best = t;
+                pass = !(along < -circ || fabsf(perp) > circ);
             }
-            val = best / range;
+            const unsigned long long pm = __ballot(pass);
+            if (pass) wq[qc + __popcll(pm & ((1ull << lane) - 1ull))] = ((unsigned int)lane << 6) | (unsigned int)j;
+            qc += __popcll(pm);
+            if (qc >= 64) {                      // a full wave of box tests
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                run_tasks(q0, 64);
+                __builtin_amdgcn_wave_barrier();
+                const unsigned int carry = (lane < qc - 64) ? wq[64 + lane] : 0u;
+                __builtin_amdgcn_wave_barrier();
+                if (lane < qc - 64) wq[lane] = carry;
+                qc -= 64;
+            }
         }
-        eobs[(size_t)i * O + COPO_EGO_DIM + COPO_NAVI_DIM + k] = val;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        run_tasks(q0, qc);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (live) eobs[(size_t)i * O + COPO_EGO_DIM + COPO_NAVI_DIM + k] = pres ? __uint_as_float(wbest[lane]) / range : 0.0f;
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -395,6 +453,8 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
     const float hl = p.hl, hw = p.hw;
     load_rays(p, L, tid, nthreads);
 
+#define COPO_STAMP(i) do { if (p.dbg && tid == 0) p.dbg[(size_t)e * 8 + (i)] = (long long)clock64(); } while (0)
+    COPO_STAMP(0);
     // ---- P0 (wave 0): timers + bicycle dynamics, poses -> LDS ------------------------------------
     Slot s = Slot{};
     bool acted = false;
@@ -460,6 +520,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
         }
     }
     __syncthreads();
+    COPO_STAMP(1);
 
     // ---- P1 (all waves): collision of acting agent i against every solid slot j (lane) ------------
     {
@@ -481,6 +542,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
     float rew = 0.0f, lcf_row = 0.0f;
     int32_t aid_row = -1;
     bool present = false;
+    COPO_STAMP(2);
     // ---- P2 (wave 0): route projection, termination, reward, respawn ------------------------------
     if (wave == 0) {
         bool term = false;
@@ -596,8 +658,10 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
     }
     __syncthreads();
 
+    COPO_STAMP(3);
     // ---- P3 (all waves): neighbour lists + reward reductions on the post-step (pre-reset) scene ---
     neighbours_phase(p, L, e, wave, nwaves, lane, out);
+    COPO_STAMP(4);
     if (ending) __syncthreads();  // neighbours read the poses that the reset below overwrites
 
     // ---- P4 (wave 0): horizon reset, row outputs, state write-back, ego/navi obs ------------------
@@ -637,8 +701,12 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
     }
     __syncthreads();
 
+    COPO_STAMP(5);
     // ---- P5 (all threads): LiDAR + observation write-out -------------------------------------------
     if (out.obs) obs_phase(p, L, e, tid, nthreads, out.obs);
+    __syncthreads();
+    COPO_STAMP(6);
+#undef COPO_STAMP
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -672,13 +740,15 @@ __global__ void __launch_bounds__(256) neighbours_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------
+static size_t lidar_lds_bytes(int block) { return (size_t)(block / 64) * 192 * sizeof(unsigned int); }   // per-wave ray queue
+
 hipError_t launch_sim_reset(const SimParams& p, const StepOut& out, int block, hipStream_t stream) {
-    hipLaunchKernelGGL(sim_reset_kernel, dim3(p.E), dim3(block), 0, stream, p, out);
+    hipLaunchKernelGGL(sim_reset_kernel, dim3(p.E), dim3(block), lidar_lds_bytes(block), stream, p, out);
     return hipGetLastError();
 }
 
 hipError_t launch_sim_step(const SimParams& p, const float* act, const StepOut& out, int block, hipStream_t stream) {
-    hipLaunchKernelGGL(sim_step_kernel, dim3(p.E), dim3(block), 0, stream, p, act, out);
+    hipLaunchKernelGGL(sim_step_kernel, dim3(p.E), dim3(block), lidar_lds_bytes(block), stream, p, act, out);
     return hipGetLastError();
 }
 

@@ -86,7 +86,7 @@ class VecSampler:
         self.rew3 = z(3, T, E, N)            # native / neighbourhood / global reward heads
         self.glob = z(T, E)
         self.flags = z(T, E, N, dtype=u8)
-        self.nbr_idx, self.nbr_dist = z(T, E, N, K, dtype=i32), z(T, E, N, K)
+        self.nbr_idx = z(T, E, N, K, dtype=i32)     # (distances are not needed by the learner: no nbr_dist output)
         self.nbr_cnt, self.mf_cnt = z(T, E, N, dtype=i32), z(T, E, N, dtype=i32)
         self.lcf, self.agent_id = z(T, E, N), z(T, E, N, dtype=i32)
         self.info = z(T, E, N, 8)
@@ -95,7 +95,7 @@ class VecSampler:
             self._outs.append(sim.make_step_out(dict(
                 obs=self.obs[t + 1], rew=self.rew3[0, t], nei_rew=self.rew3[1, t], glob_rew=self.glob[t],
                 flags=self.flags[t], nbr_idx=self.nbr_idx[t], nbr_cnt=self.nbr_cnt[t], mf_cnt=self.mf_cnt[t],
-                nbr_dist=self.nbr_dist[t], lcf=self.lcf[t], info=self.info[t], agent_id=self.agent_id[t])))
+                lcf=self.lcf[t], info=self.info[t], agent_id=self.agent_id[t])))
         self._reset_out = sim.make_step_out(dict(obs=self.obs[0]))
         self._started = False
         self._loop = GraphedCallable(self._rollout, use_graph and dev.type == "cuda")
@@ -140,7 +140,7 @@ class VecSampler:
             SampleBatch.ACTION_DIST_INPUTS: self.dist_inputs, SampleBatch.REWARDS: self.rew3[0],
             "nei_rewards": self.rew3[1], "global_rewards": self.rew3[2], "rew3": self.rew3,
             SampleBatch.FLAGS: self.flags, "nbr_idx": self.nbr_idx, "nbr_cnt": self.nbr_cnt, "mf_cnt": self.mf_cnt,
-            "nbr_dist": self.nbr_dist, "step_lcf": self.lcf, "infos": self.info, "agent_id": self.agent_id,
+            "step_lcf": self.lcf, "infos": self.info, "agent_id": self.agent_id,
         })
 
 

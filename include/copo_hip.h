@@ -152,6 +152,9 @@ int copo_sim_get_state(copo_sim* sim, float* slot_state, int32_t* env_state, voi
 int copo_sim_set_state(copo_sim* sim, const float* slot_state, const int32_t* env_state, void* stream);
 /* workgroup size of the step kernel: 256, 512 or 1024 (0 = pick from E); tuning knob, results do not depend on it */
 int copo_sim_set_block(copo_sim* sim, int32_t threads);
+/* profiling aid: device buffer [E][8] int64 receiving clock64() stamps at the phase boundaries of the step kernel
+ * (NULL switches it off; results of the step do not depend on it) */
+int copo_sim_set_debug(copo_sim* sim, int64_t* stamps);
 
 /* ---- stateless ops ---- */
 

@@ -371,29 +371,19 @@ static void write_obs(oracle_sim* s, int e, const copo_step_out* out, const uint
                 float along = dxr * rx + dyr * ry;
                 float perp = dxr * ry - dyr * rx;
                 if (along < -circ || fabsf(perp) > circ) continue;
-                /* slab test in j's frame */
+                /* ray vs box j in j's frame, mirrored so that the direction is non-negative on both axes; entering and
+                 * exiting times are fractions n/a compared by cross-multiplication (no division until a hit is known) */
                 float ox = -(rx * cs[j] + ry * sn[j]), oy = -(ry * cs[j] - rx * sn[j]);
                 float ddx = dxr * cs[j] + dyr * sn[j], ddy = dyr * cs[j] - dxr * sn[j];
-                float tlo = -1e30f, thi = 1e30f;
-                int miss = 0;
-                if (fabsf(ddx) < 1e-9f) {
-                    if (fabsf(ox) > hl) miss = 1;
-                } else {
-                    float t1 = (-hl - ox) / ddx, t2 = (hl - ox) / ddx;
-                    float a = t1 < t2 ? t1 : t2, b = t1 < t2 ? t2 : t1;
-                    if (a > tlo) tlo = a;
-                    if (b < thi) thi = b;
-                }
-                if (fabsf(ddy) < 1e-9f) {
-                    if (fabsf(oy) > hw) miss = 1;
-                } else {
-                    float t1 = (-hw - oy) / ddy, t2 = (hw - oy) / ddy;
-                    float a = t1 < t2 ? t1 : t2, b = t1 < t2 ? t2 : t1;
-                    if (a > tlo) tlo = a;
-                    if (b < thi) thi = b;
-                }
-                if (miss || tlo > thi || thi < 0.0f) continue;
-                float t = tlo > 0.0f ? tlo : 0.0f;
+                float ax = fabsf(ddx), ay = fabsf(ddy);
+                float oxs = ddx < 0.0f ? -ox : ox, oys = ddy < 0.0f ? -oy : oy;
+                float nxe = -(hl + oxs), nxx = hl - oxs, nye = -(hw + oys), nyx = hw - oys;
+                if (!(nxx >= 0.0f && nyx >= 0.0f)) continue;            /* box entirely behind the origin on an axis */
+                if (!(nxe * ay <= nyx * ax)) continue;                  /* enter-x after exit-y */
+                if (!(nye * ax <= nxx * ay)) continue;                  /* enter-y after exit-x */
+                int usex = (nxe * ay >= nye * ax);                      /* the later entering plane */
+                float n = usex ? nxe : nye, a = usex ? ax : ay;
+                float t = n > 0.0f ? n / a : 0.0f;                      /* origin inside the box -> 0 */
                 if (t < best) best = t;
             }
             lid[k] = best / range;
