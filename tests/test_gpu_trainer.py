@@ -132,3 +132,39 @@ def test_dict_env_api_matches_reference_surface():
     assert seen_done and seen_spawn and d["__all__"]
     env.set_lcf_dist(0.5, 0.2)
     env.close()
+
+
+@pytest.mark.parametrize("name,algo,map_cls,cfg", [
+    # BASELINE.json configs[2]: CoPO Roundabout, 40 agents, the 128-scene shard one GPU of the 8-GPU run owns
+    ("C3-shard", "copo", "MultiAgentRoundaboutEnv", dict(num_envs=128, env_config=dict(num_agents=40))),
+    # configs[3]: CCPPO mean-field on the Tollgate road, 40 agents, bf16 MLPs (losses / advantages stay fp32)
+    ("C4", "ccppo", "MultiAgentTollgateEnv", dict(num_envs=64, env_config=dict(num_agents=40), fuse_mode="mf",
+                                                   policy_dtype="bfloat16")),
+    # configs[4]: CoPO ParkingLot, 10 agents, 240-beam LiDAR (O = 260), LCF meta-update after every env step
+    ("C5", "copo", "MultiAgentParkingLotEnv", dict(num_envs=256, env_config=dict(num_agents=10, num_lasers=240),
+                                                    train_batch_size=256)),
+])
+def test_baseline_parity_configs_run(name, algo, map_cls, cfg):
+    """The other BASELINE.json configurations (parity-test cases, not bench lines): shapes, dtypes and a few
+    iterations with finite statistics."""
+    from copo_amd.torch_copo import algo_ccppo, algo_copo
+    from copo_amd.torch_copo.utils import env_wrappers as W
+    base = getattr(W, map_cls)
+    if algo == "copo":
+        cls, env = algo_copo.CoPOTrainer, W.get_rllib_compatible_env(W.get_lcf_env(base))
+    else:
+        cls, env = algo_ccppo.CCPPOTrainer, algo_ccppo.get_ccppo_env(base)
+    cfg = dict(cfg, env=env, seed=0)
+    cfg.setdefault("train_batch_size", cfg["num_envs"] * 4)
+    a = cls(config=cfg)
+    if name == "C4":
+        assert a.policy.fused is None and a.policy.autocast_dtype == torch.bfloat16
+        assert a.policy.model.get_centralized_critic_obs_dim() == 2 * 91 + 2
+    if name == "C5":
+        assert a.env.sim.O == 260 and a.sampler.T == 1
+    for _ in range(4):
+        res = a.train()
+    st = res["info"]["learner"]["default"]["learner_stats"]
+    assert all(np.isfinite(v) for v in st.values()), st
+    assert a.sampler.obs.dtype == torch.float32 and float(a.sampler.obs.max()) <= 1.0
+    a.stop()
