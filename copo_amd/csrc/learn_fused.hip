@@ -2,16 +2,17 @@
 //
 // The reference runs the PPO minibatch step through torch autograd (algo_copo.py:311-424 `loss`, RLlib
 // `train_one_step`, torch.optim.Adam): ~250 tiny kernels per 512-row minibatch, launch-bound on any GPU.
-// Here one SGD step is 7 launches over ONE flat fp32 parameter buffer:
+// Here one SGD step is 6 launches over ONE flat fp32 parameter buffer:
 //
 //   F1   h1 = tanh(X W1^T + b1)          grouped over the policy net + up to 3 value nets; X rows gathered by index
 //   F2   h2 = tanh(h1 W2^T + b2)
 //   H    heads (256 -> 4 / 1), the PPO loss terms and their ANALYTIC gradient w.r.t. the head outputs,
-//        dz2 = (dout W3) * (1 - h2^2), per-tile partials of dW3 / db3, loss statistics
+//        dz2 = (dout W3) * (1 - h2^2), per-tile partials of the loss statistics
 //   B2x  dz1 = (dz2 W2) * (1 - h1^2)
-//   B2w  partial dW2 = dz2^T [h1 | 1]    rows split KSPLIT ways across workgroups (fixed split -> deterministic)
-//   B1w  partial dW1 = dz1^T [X  | 1]
-//   R    fold the split / tile partials in a fixed order, then Adam (or store the flat gradient)
+//   Bw   one launch, three GEMMs, rows split KSPLIT ways across workgroups (fixed split -> deterministic):
+//        partial dW3 = dout^T [h2 | 1],  partial dW2 = dz2^T [h1 | 1],  partial dW1 = dz1^T [X | 1]
+//   R    fold the split partials in a fixed order, then Adam (or store the flat gradient); the Adam step counter
+//        is advanced by F1, the minibatch index by R (each by a kernel that does not read it)
 //
 // GEMMs are 64x64 output tiles per 256-thread workgroup, 4 waves x one 32x32 fp32 MFMA accumulator
 // (v_mfma_f32_32x32x2_f32: exact fp32 products at the fp32 vector rate), K staged through LDS in slabs of 32
@@ -31,7 +32,8 @@ namespace copo {
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int TM = 64, TN = 64, TK = 32, LDP = 68;   // LDP: padded LDS row (floats)
-constexpr int HT = 16;                                // rows per workgroup of the head kernel (16 threads per row)
+constexpr int HT = 8;                                 // rows per workgroup of the head kernel
+constexpr int HTPR = 256 / HT;                        // threads per row of the head kernel
 constexpr int MODE_META_BOTH = 3;                     // internal: group 0 = META_NEW on theta, group 1 = META_OLD on theta2
 
 struct FusedArgs {
@@ -69,7 +71,6 @@ __device__ __forceinline__ const copo_net_layout& net_of(const FusedArgs& a, int
 }
 __device__ __forceinline__ float* theta_of(const FusedArgs& a, int g) { return (both(a) && g == 1) ? a.theta2 : a.theta; }
 __device__ __forceinline__ float* grad_of(const FusedArgs& a, int g) { return (both(a) && g == 1) ? a.grad2 : a.grad; }
-__device__ __forceinline__ float* stats_of(const FusedArgs& a, int g) { return (both(a) && g == 1) ? a.stats2 : a.stats; }
 __device__ __forceinline__ int mode_of(const FusedArgs& a, int g) {
     return both(a) ? (g == 0 ? COPO_HEAD_META_NEW : COPO_HEAD_META_OLD) : a.head_mode;
 }
@@ -82,13 +83,16 @@ __device__ __host__ inline size_t ws_h2(const copo_ppo_cfg& c, int g) { return (
 __device__ __host__ inline size_t ws_dz2(const copo_ppo_cfg& c, int g) { return (size_t)(8 + g) * c.mb * c.hidden; }
 __device__ __host__ inline size_t ws_dz1(const copo_ppo_cfg& c, int g) { return (size_t)(12 + g) * c.mb * c.hidden; }
 __device__ __host__ inline int head_tiles(const copo_ppo_cfg& c) { return (c.mb + HT - 1) / HT; }
-__device__ __host__ inline size_t ws_p3_at(const copo_ppo_cfg& c, int g, int tile) {   // [g][tile][out<=4][H+1]
-    return (size_t)16 * c.mb * c.hidden + ((size_t)g * head_tiles(c) + tile) * 4 * (c.hidden + 1);
+__device__ __host__ inline size_t ws_dout(const copo_ppo_cfg& c, int g) {   // [g][mb][4]: d(loss)/d(head outputs)
+    return (size_t)16 * c.mb * c.hidden + (size_t)g * c.mb * 4;
 }
 __device__ __host__ inline size_t ws_split(const copo_ppo_cfg& c, int region, int split) {   // [region][split][n_params]
-    return (size_t)16 * c.mb * c.hidden + (size_t)4 * head_tiles(c) * 4 * (c.hidden + 1) +
-           ((size_t)region * COPO_PPO_MAX_KSPLIT + split) * (size_t)c.n_params;
+    return (size_t)16 * c.mb * c.hidden + (size_t)16 * c.mb + ((size_t)region * COPO_PPO_MAX_KSPLIT + split) * (size_t)c.n_params;
 }
+__device__ __host__ inline size_t ws_stats_at(const copo_ppo_cfg& c, int q) {   // [g * tiles + tile][8]
+    return ws_split(c, 2, 0) + (size_t)q * 8;
+}
+__device__ __host__ inline size_t ws_counter_at(const copo_ppo_cfg& c) { return ws_stats_at(c, 4 * head_tiles(c)); }
 __device__ __forceinline__ int region_of(const FusedArgs& a, int g) { return (both(a) && g == 1) ? 1 : 0; }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -140,16 +144,21 @@ struct GemmCtx {
     const int32_t* srow;               // LDS table of gathered row indices (layer 1)
     int K;          // length of the k-contiguous rows / input width
     int mb, H;
+    int M, astr;    // Bw: output rows (H, or the head's out_dim) and the row stride of the dz operand
     int64_t woff, boff;
 };
 
+struct GemmSmem {
+    int32_t srow[COPO_PPO_MAX_MB];
+    __align__(16) float As[TK][LDP];
+    __align__(16) float Bs[TK][LDP];
+};
+
 template <class Op, bool VEC>
-__global__ void __launch_bounds__(256) gemm_kernel(FusedArgs a, int K) {
-    const int G = a.groups;
-    const int g = blockIdx.z % G, split = blockIdx.z / G, m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
-    __shared__ int32_t srow[COPO_PPO_MAX_MB];
-    __shared__ __align__(16) float As[TK][LDP];
-    __shared__ __align__(16) float Bs[TK][LDP];
+__device__ __forceinline__ void gemm_tile(const FusedArgs& a, int K, int g, int split, int m0, int n0, GemmSmem& sm) {
+    int32_t* srow = sm.srow;
+    float (*As)[LDP] = sm.As;
+    float (*Bs)[LDP] = sm.Bs;
     if (Op::GATHER) {     // row indices of this minibatch once per workgroup (removes a dependent-load chain)
         const int64_t base = kbase(a) * a.c.mb;
         for (int i = threadIdx.x; i < a.c.mb; i += 256) srow[i] = (int32_t)a.rows[base + i];
@@ -225,12 +234,22 @@ __global__ void __launch_bounds__(256) gemm_kernel(FusedArgs a, int K) {
     Op::store_tile(c, m0 + wm * 32 + (lane >> 5) * 4, n0 + wn * 32 + (lane & 31), acc);
 }
 
+template <class Op, bool VEC>
+__global__ void __launch_bounds__(256) gemm_kernel(FusedArgs a, int K) {
+    __shared__ GemmSmem sm;
+    const int G = a.groups;
+    // the first kernel of an SGD step advances the Adam step counter (its only reader is the fold at the end)
+    if (Op::FIRST && a.apply_adam && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+        const_cast<int64_t*>(a.step)[0] += 1;
+    gemm_tile<Op, VEC>(a, K, blockIdx.z % G, blockIdx.z / G, blockIdx.y * TM, blockIdx.x * TN, sm);
+}
+
 #define COPO_ACC_ROW(rbase, j) ((rbase) + ((j) >> 2) * 8 + ((j) & 3))
 
 // ---- layer forward: Y[m][n] = tanh(sum_k X[m][k] W[n][k] + b[n]) --------------------------------------------
 template <int LAYER>
 struct FwdOpT {
-    static constexpr bool A_KCONTIG = true, B_KCONTIG = true, SPLITS_K = false, GATHER = LAYER == 1;
+    static constexpr bool A_KCONTIG = true, B_KCONTIG = true, SPLITS_K = false, GATHER = LAYER == 1, FIRST = LAYER == 1;
     __device__ static __forceinline__ GemmCtx prep(const FusedArgs& a, int g, int, const int32_t* srow) {
         const copo_net_layout L = net_of(a, g);
         GemmCtx c;
@@ -270,7 +289,7 @@ struct FwdOpT {
 
 // ---- B2x: dz1[m][i] = (sum_o dz2[m][o] W2[o][i]) * (1 - h1[m][i]^2) -------------------------------------------
 struct BxOp {
-    static constexpr bool A_KCONTIG = true, B_KCONTIG = false, SPLITS_K = false, GATHER = false;
+    static constexpr bool A_KCONTIG = true, B_KCONTIG = false, SPLITS_K = false, GATHER = false, FIRST = false;
     __device__ static __forceinline__ GemmCtx prep(const FusedArgs& a, int g, int, const int32_t* srow) {
         GemmCtx c;
         c.mb = a.c.mb; c.H = a.c.hidden; c.K = c.H; c.srow = srow;
@@ -308,26 +327,28 @@ struct BxOp {
 };
 
 // ---- Bw: partial dW[o][i] = sum_{m in split} dz[m][o] * [In | 1][m][i]; column i == in_dim is the bias --------
-template <int LAYER>   // 2: dz2 x h1 ; 1: dz1 x X (rows gathered)
+template <int LAYER>   // 3: dout x h2 ; 2: dz2 x h1 ; 1: dz1 x X (rows gathered)
 struct BwOpT {
-    static constexpr bool A_KCONTIG = false, B_KCONTIG = false, SPLITS_K = true, GATHER = LAYER == 1;
+    static constexpr bool A_KCONTIG = false, B_KCONTIG = false, SPLITS_K = true, GATHER = LAYER == 1, FIRST = false;
     __device__ static __forceinline__ GemmCtx prep(const FusedArgs& a, int g, int split, const int32_t* srow) {
         const copo_net_layout L = net_of(a, g);
         GemmCtx c;
         c.mb = a.c.mb; c.H = a.c.hidden; c.srow = srow;
         c.K = GATHER ? L.in_dim : c.H;
-        c.abase = a.ws + (GATHER ? ws_dz1(a.c, g) : ws_dz2(a.c, g));
-        c.bbase = GATHER ? src_of(a, g) : a.ws + ws_h1(a.c, g);
+        c.abase = a.ws + (LAYER == 1 ? ws_dz1(a.c, g) : (LAYER == 2 ? ws_dz2(a.c, g) : ws_dout(a.c, g)));
+        c.bbase = GATHER ? src_of(a, g) : a.ws + (LAYER == 2 ? ws_h1(a.c, g) : ws_h2(a.c, g));
         c.aux = nullptr;
-        c.woff = GATHER ? L.w1 : L.w2;
-        c.boff = GATHER ? L.b1 : L.b2;
+        c.woff = LAYER == 1 ? L.w1 : (LAYER == 2 ? L.w2 : L.w3);
+        c.boff = LAYER == 1 ? L.b1 : (LAYER == 2 ? L.b2 : L.b3);
+        c.M = LAYER == 3 ? L.out_dim : c.H;
+        c.astr = LAYER == 3 ? 4 : c.H;
         c.out = a.ws + ws_split(a.c, region_of(a, g), split);
         return c;
     }
     template <bool VEC>
     __device__ static __forceinline__ float4 lda4(const GemmCtx& c, int o, int m, int mend, int& mask) {   // dz[m][o..o+3]
         const bool ok = m < mend;
-        return ld4<VEC>(c.abase + (size_t)(ok ? m : 0) * c.H, o, c.H, ok, mask);
+        return ld4<VEC>(c.abase + (size_t)(ok ? m : 0) * c.astr, o, c.astr, ok, mask);
     }
     template <bool VEC>
     __device__ static __forceinline__ float4 ldb4(const GemmCtx& c, int m, int i, int mend, int& mask, int& one) {   // [In|1][m][i..]
@@ -342,11 +363,22 @@ struct BwOpT {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int o = COPO_ACC_ROW(rbase, j);
-            if (o < c.H && col <= c.K)
+            if (o < c.M && col <= c.K)
                 c.out[(col == c.K) ? (size_t)c.boff + o : (size_t)c.woff + (size_t)o * c.K + col] = acc[j];
         }
     }
 };
+
+// the three weight-gradient GEMMs in one launch: column tiles [0, nx2) are layer 2, [nx2, nx2 + nx1) layer 1,
+// the rest the head layer (one row tile: out_dim <= 4 rows).  Fewer launches per SGD step, a grid that covers the chip.
+template <bool VEC>
+__global__ void __launch_bounds__(256) gemm_bw_kernel(FusedArgs a, int K, int nx2, int nx1) {
+    __shared__ GemmSmem sm;
+    const int G = a.groups, g = blockIdx.z % G, split = blockIdx.z / G, x = blockIdx.x;
+    if (x < nx2) gemm_tile<BwOpT<2>, VEC>(a, K, g, split, blockIdx.y * TM, x * TN, sm);
+    else if (x < nx2 + nx1) gemm_tile<BwOpT<1>, VEC>(a, K, g, split, blockIdx.y * TM, (x - nx2) * TN, sm);
+    else if (blockIdx.y == 0) gemm_tile<BwOpT<3>, VEC>(a, K, g, split, 0, (x - nx2 - nx1) * TN, sm);
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // head + loss kernel: one workgroup per (16-row tile, net); 16 threads per row
@@ -368,20 +400,27 @@ __global__ void __launch_bounds__(256) head_kernel(FusedArgs a) {
     float* red = douts + HT * 4;         // [8 stats][4 waves]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // row bookkeeping first: these dependent loads (k -> row index -> pack row) overlap the tile load below
-    const int r = tid >> 4, part = tid & 15;
+    const int r = tid / HTPR, part = tid % HTPR;
     const int m = m0 + r;
     const int64_t kb = kbase(a);
     const bool rok = m < c.mb;
     const float wgt = rok ? a.w[kb * c.mb + m] / a.denom[kb] : 0.0f;
     const float* pk = a.pack_src + (size_t)(rok ? a.rows[kb * c.mb + m] : 0) * c.pack_width;
     const float* h2g = a.ws + ws_h2(c, g);
-    for (int r = tid >> 6; r < HT; r += 4)
-        for (int i = lane; i < H; i += 64) h2s[r * (H + 1) + i] = (m0 + r < c.mb) ? h2g[(size_t)(m0 + r) * H + i] : 0.0f;
+    // unconditional loads from clamped rows (a branch around a load drains vmcnt and serialises the tile load)
+    for (int r = tid >> 6; r < HT; r += 4) {
+        const bool ok = m0 + r < c.mb;
+        const float* src = h2g + (size_t)(ok ? m0 + r : 0) * H;
+        for (int i = lane; i < H; i += 64) {
+            const float v = src[i];
+            h2s[r * (H + 1) + i] = ok ? v : 0.0f;
+        }
+    }
     for (int q = tid; q < OD * H; q += 256) w3s[q] = theta[L.w3 + q];
     __syncthreads();
-    // outputs: 16 threads per row, each a sixteenth of the hidden units
+    // outputs: HTPR threads per row, each a slice of the hidden units
     float out[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int i = part; i < H; i += 16) {
+    for (int i = part; i < H; i += HTPR) {
         const float h = h2s[r * (H + 1) + i];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -389,10 +428,8 @@ __global__ void __launch_bounds__(256) head_kernel(FusedArgs a) {
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        out[j] += __shfl_xor(out[j], 1);
-        out[j] += __shfl_xor(out[j], 2);
-        out[j] += __shfl_xor(out[j], 4);
-        out[j] += __shfl_xor(out[j], 8);
+#pragma unroll
+        for (int o = 1; o < HTPR; o <<= 1) out[j] += __shfl_xor(out[j], o);
         if (j < OD) out[j] += theta[L.b3 + j];
     }
     // per-row loss terms and d(loss)/d(out)
@@ -478,10 +515,11 @@ __global__ void __launch_bounds__(256) head_kernel(FusedArgs a) {
         }
     }
     if (part == 0) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) douts[r * 4 + j] = dout[j];
+        // d(loss)/d(outputs): to LDS for dz2 below and to the workspace for the head's weight-gradient GEMM
+        *reinterpret_cast<float4*>(douts + r * 4) = make_float4(dout[0], dout[1], dout[2], dout[3]);
+        if (rok) *reinterpret_cast<float4*>(a.ws + ws_dout(c, g) + (size_t)m * 4) = make_float4(dout[0], dout[1], dout[2], dout[3]);
     }
-    // statistics: wave reduce -> LDS -> one atomic per workgroup and stat
+    // statistics: wave reduce -> LDS -> one partial per workgroup and stat
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         float s = st[k];
@@ -490,113 +528,26 @@ __global__ void __launch_bounds__(256) head_kernel(FusedArgs a) {
         if (lane == 0) red[k * 4 + wave] = s;
     }
     __syncthreads();
-    float* stats = stats_of(a, g);
-    if (tid < 8 && stats) {
-        const float s = (red[tid * 4] + red[tid * 4 + 1]) + (red[tid * 4 + 2] + red[tid * 4 + 3]);
-        if (s != 0.0f) atomicAdd(stats + tid, s);
-    }
-    // dz2 = (dout W3) * (1 - h2^2);  per-tile partial of dW3 / db3
+    if (tid < 8)   // per-tile partial, folded in a fixed order by reduce_adam_kernel
+        a.ws[ws_stats_at(c, g * head_tiles(c) + tile) + tid] = (red[tid * 4] + red[tid * 4 + 1]) + (red[tid * 4 + 2] + red[tid * 4 + 3]);
+    // dz2 = (dout W3) * (1 - h2^2): one hidden column per thread, W3's column in registers, dout rows are LDS
+    // broadcasts.  (dW3 / db3 come out of the weight-gradient GEMM launch: BwOpT<3>.)
     float* dz2 = a.ws + ws_dz2(c, g);
-    for (int rr = tid >> 6; rr < HT; rr += 4) {
-        if (m0 + rr >= c.mb) continue;
-        for (int i = lane; i < H; i += 64) {
-            float s = 0.0f;
+    const int nr = (c.mb - m0 < HT) ? c.mb - m0 : HT;
+    for (int i = tid; i < H; i += 256) {
+        float wc[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (j < OD) s += douts[rr * 4 + j] * w3s[j * H + i];
-            const float h = h2s[rr * (H + 1) + i];
-            dz2[(size_t)(m0 + rr) * H + i] = s * (1.0f - h * h);
-        }
-    }
-    float* p3 = a.ws + ws_p3_at(c, g, tile);
-    for (int j = 0; j < OD; ++j)
-        for (int i = tid; i <= H; i += 256) {
-            float s = 0.0f;
-            for (int rr = 0; rr < HT; ++rr) s += douts[rr * 4 + j] * (i == H ? 1.0f : h2s[rr * (H + 1) + i]);
-            p3[j * (H + 1) + i] = s;
-        }
-}
-
-// fold the split partials (W1, b1, W2, b2) and the head tile partials (W3, b3) in a fixed order, then Adam or
-// gradient store.  grid = (ceil(max tensor / 256), 6 tensors, groups)
-__device__ __forceinline__ float fold_partials(const FusedArgs& a, int g, int t, int e, size_t idx) {
-    const copo_ppo_cfg& c = a.c;
-    const int H = c.hidden;
-    float s = 0.0f;
-    if (t < 4) {
-        const int reg = region_of(a, g);
-        for (int sp = 0; sp < a.ksplit; ++sp) s += a.ws[ws_split(c, reg, sp) + idx];
-    } else {
-        const int tiles = head_tiles(c);
-        const int j = (t == 4) ? e / H : e, i = (t == 4) ? e - j * H : H;
-        for (int tl = 0; tl < tiles; ++tl) s += a.ws[ws_p3_at(c, g, tl) + j * (H + 1) + i];
-    }
-    return s;
-}
-
-__global__ void __launch_bounds__(256) reduce_adam_kernel(FusedArgs a) {
-    const copo_ppo_cfg& c = a.c;
-    const int g = blockIdx.z, t = blockIdx.y, H = c.hidden;
-    const copo_net_layout L = net_of(a, g);
-    const int K1 = L.in_dim, OD = L.out_dim;
-    const int64_t off[6] = {L.w1, L.b1, L.w2, L.b2, L.w3, L.b3};
-    const int sz[6] = {H * K1, H, H * H, H, OD * H, OD};
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (both(a)) {
-        // meta pass: one thread folds BOTH gradients of its element and contributes g_new * g_old to a
-        // per-workgroup partial of the dot product (fixed order -> deterministic), consumed by meta_finish
-        __shared__ double red[4];
-        double prod = 0.0;
-        if (e < sz[t]) {
-            const size_t idx = (size_t)off[t] + e;
-            const float s0 = fold_partials(a, 0, t, e, idx), s1 = fold_partials(a, 1, t, e, idx);
-            a.grad[idx] = s0;
-            a.grad2[idx] = s1;
-            prod = (double)s0 * (double)s1;
-        }
+        for (int j = 0; j < 4; ++j) wc[j] = (j < OD) ? w3s[j * H + i] : 0.0f;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) prod += __shfl_down(prod, o);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = prod;
-        __syncthreads();
-        if (threadIdx.x == 0)
-            a.dot_partials[blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-        return;
+        for (int rr = 0; rr < HT; ++rr) {
+            if (rr < nr) {
+                const float4 d = *reinterpret_cast<const float4*>(douts + rr * 4);
+                const float h = h2s[rr * (H + 1) + i];
+                const float sx = (d.x * wc[0] + d.y * wc[1]) + (d.z * wc[2] + d.w * wc[3]);
+                dz2[(size_t)(m0 + rr) * H + i] = sx * (1.0f - h * h);
+            }
+        }
     }
-    if (e >= sz[t]) return;
-    const size_t idx = (size_t)off[t] + e;
-    const float s = fold_partials(a, g, t, e, idx);
-    if (a.apply_adam) {
-        const float tt = (float)(a.step[0] + 1);
-        const float bc1 = 1.0f - powf(c.beta1, tt), bc2s = sqrtf(1.0f - powf(c.beta2, tt));
-        float m = a.adam_m[idx], v = a.adam_v[idx];
-        m = m + (s - m) * (1.0f - c.beta1);
-        v = v * c.beta2 + s * s * (1.0f - c.beta2);
-        a.adam_m[idx] = m;
-        a.adam_v[idx] = v;
-        a.theta[idx] = a.theta[idx] - (c.lr / bc1) * (m / (sqrtf(v) / bc2s + c.eps));
-    } else {
-        grad_of(a, g)[idx] = s;
-    }
-}
-
-__global__ void bump_kernel(int64_t* step, int64_t* k) {
-    if (step) step[0] += 1;
-    if (k) k[0] += 1;
-}
-
-__global__ void __launch_bounds__(256) adam_flat_kernel(FusedArgs a, long long n) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const copo_ppo_cfg& c = a.c;
-    const float tt = (float)(a.step[0] + 1);
-    const float bc1 = 1.0f - powf(c.beta1, tt), bc2s = sqrtf(1.0f - powf(c.beta2, tt));
-    const float s = a.grad[i];
-    float m = a.adam_m[i], v = a.adam_v[i];
-    m = m + (s - m) * (1.0f - c.beta1);
-    v = v * c.beta2 + s * s * (1.0f - c.beta2);
-    a.adam_m[i] = m;
-    a.adam_v[i] = v;
-    a.theta[i] = a.theta[i] - (c.lr / bc1) * (m / (sqrtf(v) / bc2s + c.eps));
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -629,8 +580,7 @@ __device__ __forceinline__ double block_sum_d(double v, double* red) {
 
 // S = sum_i w_i ((A'_i - mu)/sigma) / D with A' = cos(phi) A_ego + sin(phi) A_nei, phi = (m + s eps) pi/2,
 // m = clamp(tanh p0, +-(1-1e-6)), s = exp(clamp(p1, -20, 2))   (algo_copo.py:155-179, 283-287)
-__global__ void __launch_bounds__(1024) meta_lcf_kernel(MetaArgs a) {
-    __shared__ double red[16];
+__device__ __forceinline__ void meta_lcf_body(const MetaArgs& a, double* red) {
     const int64_t kb = a.kptr ? a.kptr[0] : 0;
     const double p0 = a.lcf_param[0], p1 = a.lcf_param[1];
     const double th = tanh(p0), lim = 1.0 - 1e-6;
@@ -683,8 +633,7 @@ struct MetaFinishArgs {
     int32_t bump_k;
 };
 
-__global__ void __launch_bounds__(1024) meta_finish_kernel(MetaFinishArgs a) {
-    __shared__ double red[16];
+__device__ __forceinline__ void meta_finish_body(const MetaFinishArgs& a, double* red) {
     double s = 0.0;
     if (a.dot_partials) {
         for (int i = threadIdx.x; i < a.n_partials; i += blockDim.x) s += a.dot_partials[i];
@@ -722,12 +671,163 @@ __global__ void __launch_bounds__(1024) meta_finish_kernel(MetaFinishArgs a) {
     }
 }
 
+__global__ void __launch_bounds__(1024) meta_lcf_kernel(MetaArgs a) {
+    __shared__ double red[16];
+    meta_lcf_body(a, red);
+}
+
+__global__ void __launch_bounds__(1024) meta_finish_kernel(MetaFinishArgs a) {
+    __shared__ double red[16];
+    meta_finish_body(a, red);
+}
+
+// fold the split partials in a fixed order, then Adam or gradient store.  Flat 1-D grid over the parameter
+// range [lo, lo + n): every element of the flat buffer folds the same way (sum over the row splits at its own
+// index); padding elements fold zeros.  Workgroup 0 also folds the head kernel's per-tile statistics.
+// With `meta_tail` (single-GPU meta step) the last workgroup to finish also runs the fp64 LCF part and the LCF
+// Adam step (meta_lcf_body / meta_finish_body): the whole meta step is then six launches.
+constexpr int FOLD_EPT = 4;      // elements per thread of the fold (strided by the workgroup size: coalesced)
+
+__global__ void __launch_bounds__(256) reduce_adam_kernel(FusedArgs a, int64_t lo, int n, int meta_tail, MetaArgs ml,
+                                                          MetaFinishArgs mf) {
+    const copo_ppo_cfg& c = a.c;
+    const int tiles = head_tiles(c);
+    const bool two = both(a);
+    size_t idx[FOLD_EPT];
+    bool ok[FOLD_EPT];
+    float s0[FOLD_EPT], s1[FOLD_EPT];
+    // branch-free: every element sums the row-split partials at its own index (the padding slots of those regions
+    // hold zeros); all loads are issued before the first add
+    float v0[FOLD_EPT][COPO_PPO_MAX_KSPLIT], v1[FOLD_EPT][COPO_PPO_MAX_KSPLIT];
+#pragma unroll
+    for (int u = 0; u < FOLD_EPT; ++u) {
+        const int e = (blockIdx.x * FOLD_EPT + u) * 256 + threadIdx.x;
+        ok[u] = e < n;
+        idx[u] = (size_t)lo + (ok[u] ? e : 0);
+#pragma unroll
+        for (int sp = 0; sp < COPO_PPO_MAX_KSPLIT; ++sp) {
+            v0[u][sp] = a.ws[ws_split(c, 0, sp < a.ksplit ? sp : 0) + idx[u]];
+            v1[u][sp] = two ? a.ws[ws_split(c, 1, sp < a.ksplit ? sp : 0) + idx[u]] : 0.0f;
+        }
+    }
+    float am[FOLD_EPT], av[FOLD_EPT], th[FOLD_EPT];
+    const bool adam = !two && a.apply_adam;
+#pragma unroll
+    for (int u = 0; u < FOLD_EPT; ++u) {
+        am[u] = adam ? a.adam_m[idx[u]] : 0.0f;
+        av[u] = adam ? a.adam_v[idx[u]] : 0.0f;
+        th[u] = adam ? a.theta[idx[u]] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < FOLD_EPT; ++u) {
+        s0[u] = s1[u] = 0.0f;
+#pragma unroll
+        for (int sp = 0; sp < COPO_PPO_MAX_KSPLIT; ++sp) {
+            s0[u] += sp < a.ksplit ? v0[u][sp] : 0.0f;
+            s1[u] += sp < a.ksplit ? v1[u][sp] : 0.0f;
+        }
+    }
+    if (blockIdx.x == 0) {
+        // statistics: fixed-order sum of the head kernel's per-tile partials (deterministic, no atomics)
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nq = a.groups * tiles;
+        for (int k = wave; k < 8; k += 4) {
+            float t0 = 0.0f, t1 = 0.0f;
+            for (int q = lane; q < nq; q += 64) {
+                const float v = a.ws[ws_stats_at(c, q) + k];
+                if (two && q >= tiles) t1 += v; else t0 += v;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { t0 += __shfl_down(t0, o); t1 += __shfl_down(t1, o); }
+            if (lane == 0) {
+                if (a.stats) a.stats[k] += t0;
+                if (two && a.stats2) a.stats2[k] += t1;
+            }
+        }
+        // nothing in this kernel reads the minibatch index: advance it here (the meta tail advances it itself)
+        if (threadIdx.x == 0 && a.bump_k && a.kptr && !meta_tail) const_cast<int64_t*>(a.kptr)[0] += 1;
+    }
+    if (!two) {
+        // the Adam step counter was advanced by the first kernel of this step (see FwdOpT<1>): step[0] = t
+        const float tt = adam ? (float)a.step[0] : 1.0f;
+        const float bc1 = 1.0f - powf(c.beta1, tt), bc2s = sqrtf(1.0f - powf(c.beta2, tt));
+#pragma unroll
+        for (int u = 0; u < FOLD_EPT; ++u) {
+            if (!ok[u]) continue;
+            if (adam) {
+                const float g = s0[u];
+                const float m = am[u] + (g - am[u]) * (1.0f - c.beta1);
+                const float v = av[u] * c.beta2 + g * g * (1.0f - c.beta2);
+                a.adam_m[idx[u]] = m;
+                a.adam_v[idx[u]] = v;
+                a.theta[idx[u]] = th[u] - (c.lr / bc1) * (m / (sqrtf(v) / bc2s + c.eps));
+            } else {
+                a.grad[idx[u]] = s0[u];
+            }
+        }
+        return;
+    }
+    // meta pass: one thread folds BOTH gradients of its elements and contributes g_new * g_old to a per-workgroup
+    // partial of the dot product (fixed order -> deterministic), consumed by meta_finish
+    __shared__ double red[16];
+    __shared__ int last_flag;
+    double prod = 0.0;
+#pragma unroll
+    for (int u = 0; u < FOLD_EPT; ++u) {
+        if (ok[u]) {
+            a.grad[idx[u]] = s0[u];
+            a.grad2[idx[u]] = s1[u];
+            prod += (double)s0[u] * (double)s1[u];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) prod += __shfl_down(prod, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = prod;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a.dot_partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (meta_tail) {
+            // the last workgroup to get here sees every partial and statistic of this launch
+            unsigned* done = reinterpret_cast<unsigned*>(a.ws + ws_counter_at(c));
+            __threadfence();
+            const bool last = atomicAdd(done, 1u) == gridDim.x - 1;
+            last_flag = last ? 1 : 0;
+            if (last) *done = 0u;
+        }
+    }
+    if (!meta_tail) return;
+    __syncthreads();
+    if (!last_flag) return;
+    __threadfence();      // acquire: the other workgroups' dot partials and statistics are visible from here on
+    meta_lcf_body(ml, red);
+    __syncthreads();
+    meta_finish_body(mf, red);
+}
+
+__global__ void bump_kernel(int64_t* step, int64_t* k) {
+    if (step) step[0] += 1;
+    if (k) k[0] += 1;
+}
+
+__global__ void __launch_bounds__(256) adam_flat_kernel(FusedArgs a, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const copo_ppo_cfg& c = a.c;
+    const float tt = (float)(a.step[0] + 1);
+    const float bc1 = 1.0f - powf(c.beta1, tt), bc2s = sqrtf(1.0f - powf(c.beta2, tt));
+    const float s = a.grad[i];
+    float m = a.adam_m[i], v = a.adam_v[i];
+    m = m + (s - m) * (1.0f - c.beta1);
+    v = v * c.beta2 + s * s * (1.0f - c.beta2);
+    a.adam_m[i] = m;
+    a.adam_v[i] = v;
+    a.theta[i] = a.theta[i] - (c.lr / bc1) * (m / (sqrtf(v) / bc2s + c.eps));
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------------------
 size_t fused_ws_floats(const copo_ppo_cfg& c) {
-    return (size_t)16 * c.mb * c.hidden + (size_t)4 * head_tiles(c) * 4 * (c.hidden + 1) +
-           (size_t)2 * COPO_PPO_MAX_KSPLIT * (size_t)c.n_params;
+    return ws_counter_at(c) + 4;
 }
 
 static int pick_ksplit(int mb) {
@@ -737,7 +837,9 @@ static int pick_ksplit(int mb) {
     return s;
 }
 
-hipError_t launch_fused_step(FusedArgs a, hipStream_t s) {
+struct MetaTail { MetaArgs lcf; MetaFinishArgs fin; };
+
+hipError_t launch_fused_step(FusedArgs a, hipStream_t s, const MetaTail* mt_ = nullptr) {
     const copo_ppo_cfg& c = a.c;
     a.ksplit = pick_ksplit(c.mb);
     const int G = a.groups, mt = (c.mb + TM - 1) / TM, ht = (c.hidden + TN - 1) / TN;
@@ -761,14 +863,32 @@ hipError_t launch_fused_step(FusedArgs a, hipStream_t s) {
     const size_t lds = (size_t)(HT * (c.hidden + 1) + 4 * c.hidden + HT * 4 + 32) * sizeof(float);
     hipLaunchKernelGGL(head_kernel, dim3(head_tiles(c), G), dim3(256), lds, s, a);
     COPO_GEMM(BxOp, dim3(ht, mt, G), bx, c.hidden);
-    COPO_GEMM(BwOpT<2>, dim3((c.hidden + 1 + TN - 1) / TN, ht, G * a.ksplit), bw2, c.mb);
-    COPO_GEMM(BwOpT<1>, dim3((kmax1 + 1 + TN - 1) / TN, ht, G * a.ksplit), bw1, c.mb);
 #undef COPO_GEMM
-    int maxsz = c.hidden * (kmax1 > c.hidden ? kmax1 : c.hidden);
-    hipLaunchKernelGGL(reduce_adam_kernel, dim3((maxsz + 255) / 256, 6, a.head_mode == MODE_META_BOTH ? 1 : G), dim3(256), 0, s, a);
-    int64_t* st = a.apply_adam ? const_cast<int64_t*>(a.step) : nullptr;
-    int64_t* kp = a.bump_k ? const_cast<int64_t*>(a.kptr) : nullptr;
-    if (st || kp) hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, s, st, kp);
+    {
+        const int nx2 = (c.hidden + 1 + TN - 1) / TN, nx1 = (kmax1 + 1 + TN - 1) / TN;
+        const dim3 grid(nx2 + nx1 + nx2, ht, G * a.ksplit);
+        if (vec) hipLaunchKernelGGL((gemm_bw_kernel<true>), grid, dim3(256), 0, s, a, c.mb, nx2, nx1);
+        else hipLaunchKernelGGL((gemm_bw_kernel<false>), grid, dim3(256), 0, s, a, c.mb, nx2, nx1);
+    }
+    // parameter range the fold covers: every net of this call (the policy only in the meta modes)
+    int64_t lo = c.pol.w1, hi = 0;
+    for (int g = 0; g < (a.head_mode == COPO_HEAD_PPO ? G : 1); ++g) {
+        const int64_t offs[6] = {nets[g]->w1, nets[g]->b1, nets[g]->w2, nets[g]->b2, nets[g]->w3, nets[g]->b3};
+        const int64_t szs[6] = {(int64_t)c.hidden * nets[g]->in_dim, c.hidden, (int64_t)c.hidden * c.hidden, c.hidden,
+                                (int64_t)nets[g]->out_dim * c.hidden, nets[g]->out_dim};
+        for (int t = 0; t < 6; ++t) {
+            lo = offs[t] < lo ? offs[t] : lo;
+            hi = offs[t] + szs[t] > hi ? offs[t] + szs[t] : hi;
+        }
+    }
+    const int n_fold = (int)(hi - lo), fold_blocks = (n_fold + 256 * FOLD_EPT - 1) / (256 * FOLD_EPT);
+    if (a.head_mode == MODE_META_BOTH && fold_blocks > COPO_META_DOT_PARTIALS) return hipErrorInvalidValue;
+    MetaTail tailv{};
+    if (mt_) {
+        tailv = *mt_;
+        tailv.fin.n_partials = fold_blocks;      // only the partials this launch writes
+    }
+    hipLaunchKernelGGL(reduce_adam_kernel, dim3(fold_blocks), dim3(256), 0, s, a, lo, n_fold, mt_ ? 1 : 0, tailv.lcf, tailv.fin);
     return hipGetLastError();
 }
 
@@ -843,6 +963,31 @@ extern "C" int copo_meta_grads_f32(const copo_ppo_cfg* cfg, float* theta, float*
     a.stats = stats_new; a.stats2 = stats_old; a.apply_adam = 0; a.head_mode = MODE_META_BOTH; a.groups = 2;
     a.dot_partials = dot_partials;
     hipError_t e = launch_fused_step(a, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
+}
+
+extern "C" int copo_meta_step_f64(const copo_ppo_cfg* cfg, float* theta, float* theta_target, float* g_new, float* g_old,
+                                  const float* obs_src, const float* pack_src, const int64_t* rows, const float* w,
+                                  const float* denom, float* workspace, float* stats_new, float* stats_old,
+                                  double* dot_partials, int32_t col_adv, int32_t col_nei_adv, const double* eps,
+                                  double* lcf_param, const double* raw_mean_std, double* tail, double* adam_state,
+                                  double lr, double* stats, int64_t* mb_index, int32_t bump_index, void* stream) {
+    int rc = check_cfg(cfg);
+    if (rc != COPO_OK) return rc;
+    if (!theta || !theta_target || !g_new || !g_old || !obs_src || !pack_src || !rows || !w || !denom || !workspace ||
+        !dot_partials || !eps || !lcf_param || !raw_mean_std || !tail || !adam_state)
+        return COPO_ERR_NULL;
+    FusedArgs a;
+    fill_common(a, cfg, obs_src, nullptr, pack_src, rows, w, denom, workspace, mb_index);
+    a.theta = theta; a.theta2 = theta_target; a.grad = g_new; a.grad2 = g_old;
+    a.stats = stats_new; a.stats2 = stats_old; a.apply_adam = 0; a.head_mode = MODE_META_BOTH; a.groups = 2;
+    a.dot_partials = dot_partials;
+    MetaTail mt;
+    mt.lcf = MetaArgs{pack_src, rows, w, denom, eps, mb_index, cfg->mb, cfg->pack_width, col_adv, col_nei_adv, lcf_param,
+                      raw_mean_std, tail};
+    mt.fin = MetaFinishArgs{g_new, g_old, 0, dot_partials, COPO_META_DOT_PARTIALS, tail, lcf_param, adam_state, lr, stats_new,
+                            stats_old, stats, mb_index, (mb_index && bump_index) ? 1 : 0};
+    hipError_t e = launch_fused_step(a, static_cast<hipStream_t>(stream), &mt);
     return e == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
 }
 

@@ -154,6 +154,17 @@ class FusedLearner:
             adam_state.data_ptr(), float(lr), stats_new.data_ptr(), stats_old.data_ptr(), stats.data_ptr(),
             rs["k"].data_ptr(), 1 if bump_index else 0, _capi.current_stream()))
 
+    def meta_step(self, rs, g_new, g_old, stats_new, stats_old, dot_partials, eps_all, lcf_param, raw_mean_std, tail,
+                  col_adv, col_nei_adv, adam_state, lr, stats, bump_index=True):
+        """meta_grads + meta_lcf + meta_finish as one call (single process: nothing to all-reduce in between)."""
+        _capi.check(_capi.lib.copo_meta_step_f64(
+            C.byref(self.cfg), self.flat.flat.data_ptr(), self.target_flat.flat.data_ptr(), g_new.data_ptr(),
+            g_old.data_ptr(), rs["obs"].data_ptr(), rs["pack"].data_ptr(), rs["rows_all"].data_ptr(),
+            rs["w_all"].data_ptr(), rs["denom_all"].data_ptr(), self.workspace.data_ptr(), stats_new.data_ptr(),
+            stats_old.data_ptr(), dot_partials.data_ptr(), int(col_adv), int(col_nei_adv), eps_all.data_ptr(),
+            lcf_param.data_ptr(), raw_mean_std.data_ptr(), tail.data_ptr(), adam_state.data_ptr(), float(lr),
+            stats.data_ptr(), rs["k"].data_ptr(), 1 if bump_index else 0, _capi.current_stream()))
+
     def state(self):
         return dict(adam_m=self.adam_m.clone(), adam_v=self.adam_v.clone(), step=self.step_count.clone())
 

@@ -317,6 +317,14 @@ class CoPOPolicy(CCPPOPolicy):
         mb_["k"].add_(1)
 
     def _meta_step_local(self):
+        if self.fused is not None and not D.is_dist():
+            # single process: gradients, LCF terms, dot product and the LCF Adam step in one call (six launches)
+            mb_, fz = self._meta_bufs, self.fused
+            rs = dict(self._row_sources, **{k: mb_[k] for k in ("rows_all", "w_all", "denom_all", "k")})
+            fz.meta_step(rs, mb_["g_new"], mb_["g_old"], mb_["stats_new"], mb_["stats_old"], mb_["dot_partials"],
+                         mb_["eps_all"], self.model.lcf_parameters.data, self._raw_ms, mb_["tail"], mb_["col_adv"],
+                         mb_["col_nei_adv"], self._lcf_adam, self.config[LCF_LR], mb_["stats"])
+            return
         self._meta_step_a()
         self._meta_step_b()
 

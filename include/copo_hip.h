@@ -270,6 +270,16 @@ int copo_meta_finish_f64(const float* g_new, const float* g_old, int64_t n, cons
                          const double* tail, double* lcf_param, double* adam_state, double lr, float* stats_new,
                          float* stats_old, double* stats, int64_t* mb_index, int32_t bump_index, void* stream);
 
+/* (1)+(2)+(3) in one call for the single-process case (no gradient all-reduce in between): the last workgroup of
+ * the gradient fold runs the LCF part and the LCF Adam step, so a whole meta step (`CoPOPolicy.meta_update`,
+ * algo_copo.py:228-309) is six kernel launches.  Arguments as in the three calls above. */
+int copo_meta_step_f64(const copo_ppo_cfg* cfg, float* theta, float* theta_target, float* g_new, float* g_old,
+                       const float* obs_src, const float* pack_src, const int64_t* rows, const float* w,
+                       const float* denom, float* workspace, float* stats_new, float* stats_old, double* dot_partials,
+                       int32_t col_adv, int32_t col_nei_adv, const double* eps, double* lcf_param,
+                       const double* raw_mean_std, double* tail, double* adam_state, double lr, double* stats,
+                       int64_t* mb_index, int32_t bump_index, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -182,3 +182,39 @@ def test_fused_trainer_iteration_and_graph_replay():
     w = algo.policy.model._hidden_layers[0]._model[0].weight
     assert w.data_ptr() >= algo.policy.fused.flat.flat.data_ptr()      # parameters are views of the flat buffer
     algo.stop()
+
+
+def test_fused_meta_single_call_equals_three_calls():
+    """copo_meta_step_f64 (LCF part + LCF Adam in the last workgroup of the gradient fold) == the three separate
+    calls copo_meta_grads_f32 / copo_meta_lcf_f64 / copo_meta_finish_f64 over several steps (gradients bit for bit)."""
+    R, mb, odim = 1500, 512, 92
+    pols = [_make("copo", "none", odim, fused=True) for _ in range(2)]
+    with torch.no_grad():
+        for p in list(pols[0].model.parameters()) + list(pols[0].target_model.parameters()):
+            if p.dtype == torch.float32:
+                p.add_(torch.randn_like(p) * 0.05)
+    _copy_weights(pols[1], pols[0])
+    batch = _dense_batch(pols[0], R, odim, seed=9)
+    idx = torch.arange(R, device="cuda")
+    for pol in pols:
+        pol.prepare_sgd(batch, R, mb)
+        pol._raw_lcf_adv_mean.fill_(-0.1)
+        pol._raw_lcf_adv_std.fill_(1.5)
+        pol.use_graphs = False
+        torch.manual_seed(1)
+        pol.run_meta(idx, R, [R], mb, 0)
+        torch.manual_seed(2)
+        pol.plan_epoch(idx, R, [R], mb, bufs=pol._meta_bufs)
+        torch.manual_seed(3)
+        pol._meta_bufs["eps_all"].normal_()
+    for _ in range(3):
+        pols[0]._meta_step_a(); pols[0]._meta_step_b()
+        pols[1]._meta_step_local()
+    a, b = pols[0]._meta_bufs, pols[1]._meta_bufs
+    assert int(a["k"]) == 3 and int(b["k"]) == 3
+    for key in ("g_new", "g_old", "stats_new", "stats_old"):
+        assert torch.equal(a[key], b[key]), key
+    # the fp64 reductions run in workgroups of different sizes (512 vs 256 threads): same sums, different order
+    for x, y in ((a["tail"], b["tail"]), (a["stats"], b["stats"]), (pols[0].model.lcf_parameters, pols[1].model.lcf_parameters),
+                 (pols[0]._lcf_adam, pols[1]._lcf_adam)):
+        np.testing.assert_allclose(x.detach().cpu().numpy(), y.detach().cpu().numpy(), rtol=1e-11, atol=1e-14)
