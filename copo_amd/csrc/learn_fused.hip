@@ -31,7 +31,8 @@ namespace copo {
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-constexpr int TM = 64, TN = 64, TK = 32, LDP = 68;   // LDP: padded LDS row (floats)
+constexpr int TM = 64, TN = 64, TK = 128, LDP = 68;  // K slab; LDP: padded LDS row (floats)
+static_assert(TK == 128 && TM == 64 && TN == 64, "the slab load maps below are written for 64 x 128 slabs");
 constexpr int HT = 8;                                 // rows per workgroup of the head kernel
 constexpr int HTPR = 256 / HT;                        // threads per row of the head kernel
 constexpr int MODE_META_BOTH = 3;                     // internal: group 0 = META_NEW on theta, group 1 = META_OLD on theta2
@@ -62,38 +63,60 @@ struct FusedArgs {
     const int64_t* kptr;       // [1] device minibatch index k; NULL -> 0
     int32_t bump_k;            // increment *kptr at the end of this call
     double* dot_partials;      // META_BOTH: per-workgroup partials of <g_new, g_old> (COPO_META_DOT_PARTIALS doubles)
+    int32_t gcap;              // group slabs of the workspace layout (4, or `groups` of a batched meta pass)
+    int32_t nreg;              // gradient regions of the workspace layout
+    int64_t k_first;           // minibatch index offset (batched meta pass: groups 2b, 2b+1 are minibatch k_first + b)
 };
 
-__device__ __forceinline__ int64_t kbase(const FusedArgs& a) { return a.kptr ? a.kptr[0] : 0; }
 __device__ __forceinline__ bool both(const FusedArgs& a) { return a.head_mode == MODE_META_BOTH; }
+// META_BOTH: even groups run the current policy, odd groups the target policy; groups 2b and 2b+1 share minibatch b
+__device__ __forceinline__ bool second(const FusedArgs& a, int g) { return both(a) && (g & 1); }
+__device__ __forceinline__ int64_t kb_of(const FusedArgs& a, int g) {
+    return (a.kptr ? a.kptr[0] : 0) + a.k_first + (both(a) ? (g >> 1) : 0);
+}
 __device__ __forceinline__ const copo_net_layout& net_of(const FusedArgs& a, int g) {
     return (g == 0 || both(a)) ? a.c.pol : a.c.val[g - 1];
 }
-__device__ __forceinline__ float* theta_of(const FusedArgs& a, int g) { return (both(a) && g == 1) ? a.theta2 : a.theta; }
-__device__ __forceinline__ float* grad_of(const FusedArgs& a, int g) { return (both(a) && g == 1) ? a.grad2 : a.grad; }
+__device__ __forceinline__ float* theta_of(const FusedArgs& a, int g) { return second(a, g) ? a.theta2 : a.theta; }
 __device__ __forceinline__ int mode_of(const FusedArgs& a, int g) {
-    return both(a) ? (g == 0 ? COPO_HEAD_META_NEW : COPO_HEAD_META_OLD) : a.head_mode;
+    return both(a) ? ((g & 1) ? COPO_HEAD_META_OLD : COPO_HEAD_META_NEW) : a.head_mode;
 }
 __device__ __forceinline__ bool is_policy(const FusedArgs& a, int g) { return g == 0 || both(a); }
 __device__ __forceinline__ const float* src_of(const FusedArgs& a, int g) { return is_policy(a, g) ? a.obs_src : a.cc_src; }
+__device__ __forceinline__ int region_of(const FusedArgs& a, int g) { return both(a) ? g : 0; }
 
-// workspace layout (floats): 4 activation slabs x 4 groups, head partials, split partials (2 regions)
-__device__ __host__ inline size_t ws_h1(const copo_ppo_cfg& c, int g) { return (size_t)g * c.mb * c.hidden; }
-__device__ __host__ inline size_t ws_h2(const copo_ppo_cfg& c, int g) { return (size_t)(4 + g) * c.mb * c.hidden; }
-__device__ __host__ inline size_t ws_dz2(const copo_ppo_cfg& c, int g) { return (size_t)(8 + g) * c.mb * c.hidden; }
-__device__ __host__ inline size_t ws_dz1(const copo_ppo_cfg& c, int g) { return (size_t)(12 + g) * c.mb * c.hidden; }
+// workspace layout (floats): 4 activation slabs x gcap groups, head output gradients, nreg x KSPLIT gradient
+// regions of n_params floats, per-tile loss statistics, one completion counter
 __device__ __host__ inline int head_tiles(const copo_ppo_cfg& c) { return (c.mb + HT - 1) / HT; }
-__device__ __host__ inline size_t ws_dout(const copo_ppo_cfg& c, int g) {   // [g][mb][4]: d(loss)/d(head outputs)
-    return (size_t)16 * c.mb * c.hidden + (size_t)g * c.mb * 4;
-}
-__device__ __host__ inline size_t ws_split(const copo_ppo_cfg& c, int region, int split) {   // [region][split][n_params]
-    return (size_t)16 * c.mb * c.hidden + (size_t)16 * c.mb + ((size_t)region * COPO_PPO_MAX_KSPLIT + split) * (size_t)c.n_params;
-}
-__device__ __host__ inline size_t ws_stats_at(const copo_ppo_cfg& c, int q) {   // [g * tiles + tile][8]
-    return ws_split(c, 2, 0) + (size_t)q * 8;
-}
-__device__ __host__ inline size_t ws_counter_at(const copo_ppo_cfg& c) { return ws_stats_at(c, 4 * head_tiles(c)); }
-__device__ __forceinline__ int region_of(const FusedArgs& a, int g) { return (both(a) && g == 1) ? 1 : 0; }
+struct WsLay {
+    size_t slab;       // mb * hidden
+    int gcap, nreg, mb, tiles, kcap;
+    size_t n_params;
+    // a layout with more than 4 group slabs is a batched meta pass: no row splits, one partial per region
+    __device__ __host__ WsLay(const copo_ppo_cfg& c, int gcap_, int nreg_)
+        : slab((size_t)c.mb * c.hidden), gcap(gcap_), nreg(nreg_), mb(c.mb), tiles(head_tiles(c)),
+          kcap(gcap_ > 4 ? 1 : COPO_PPO_MAX_KSPLIT), n_params((size_t)c.n_params) {}
+    __device__ __host__ size_t h1(int g) const { return (size_t)g * slab; }
+    __device__ __host__ size_t h2(int g) const { return (size_t)(gcap + g) * slab; }
+    __device__ __host__ size_t dz2(int g) const { return (size_t)(2 * gcap + g) * slab; }
+    __device__ __host__ size_t dz1(int g) const { return (size_t)(3 * gcap + g) * slab; }
+    __device__ __host__ size_t dout(int g) const { return (size_t)4 * gcap * slab + (size_t)g * mb * 4; }      // [g][mb][4]
+    __device__ __host__ size_t split(int region, int sp) const {                                           // [region][split][n_params]
+        return (size_t)4 * gcap * slab + (size_t)gcap * mb * 4 + ((size_t)region * kcap + sp) * n_params;
+    }
+    __device__ __host__ size_t stats(int q) const { return split(nreg, 0) + (size_t)q * 8; }               // [g * tiles + tile][8]
+    __device__ __host__ size_t counter() const { return stats(gcap * tiles); }
+    __device__ __host__ size_t total() const { return counter() + 4; }
+};
+__device__ __forceinline__ WsLay lay(const FusedArgs& a) { return WsLay(a.c, a.gcap, a.nreg); }
+__device__ __forceinline__ size_t ws_h1(const FusedArgs& a, int g) { return lay(a).h1(g); }
+__device__ __forceinline__ size_t ws_h2(const FusedArgs& a, int g) { return lay(a).h2(g); }
+__device__ __forceinline__ size_t ws_dz2(const FusedArgs& a, int g) { return lay(a).dz2(g); }
+__device__ __forceinline__ size_t ws_dz1(const FusedArgs& a, int g) { return lay(a).dz1(g); }
+__device__ __forceinline__ size_t ws_dout(const FusedArgs& a, int g) { return lay(a).dout(g); }
+__device__ __forceinline__ size_t ws_split(const FusedArgs& a, int region, int sp) { return lay(a).split(region, sp); }
+__device__ __forceinline__ size_t ws_stats_at(const FusedArgs& a, int q) { return lay(a).stats(q); }
+__device__ __forceinline__ size_t ws_counter_at(const FusedArgs& a) { return lay(a).counter(); }
 
 // ------------------------------------------------------------------------------------------------------------
 // generic 64x64 tile GEMM:  C[m][n] = sum_k A(m,k) * B(k,n), K staged through LDS in slabs of 32.
@@ -148,19 +171,52 @@ struct GemmCtx {
     int64_t woff, boff;
 };
 
+// LDS of a GEMM workgroup (dynamic): gathered row indices + one K slab of each operand.
+//   k-contiguous operands (4 consecutive k of one row per load):  quad layout [k/4][row][4], pitch QP quads --
+//     float4 stores without bank conflicts, one ds_read_b128 feeds four MFMAs;
+//   row-contiguous operands (4 consecutive rows of one k per load): [k][row], pitch LDP floats.
+constexpr int QP = TM + 1;
+constexpr int OPER_FLOATS = (TK / 4) * QP * 4 > TK * LDP ? (TK / 4) * QP * 4 : TK * LDP;
+constexpr size_t GEMM_LDS_BYTES = (size_t)(COPO_PPO_MAX_MB + 2 * OPER_FLOATS) * sizeof(float);
+
 struct GemmSmem {
-    int32_t srow[COPO_PPO_MAX_MB];
-    __align__(16) float As[TK][LDP];
-    __align__(16) float Bs[TK][LDP];
+    int32_t* srow;
+    float* As;
+    float* Bs;
 };
 
+__device__ __forceinline__ GemmSmem gemm_smem() {
+    extern __shared__ float4 gemm_dyn_lds[];
+    GemmSmem sm;
+    sm.srow = reinterpret_cast<int32_t*>(gemm_dyn_lds);
+    sm.As = reinterpret_cast<float*>(gemm_dyn_lds) + COPO_PPO_MAX_MB;
+    sm.Bs = sm.As + OPER_FLOATS;
+    return sm;
+}
+
+constexpr int NLD = TK * TM / 4 / 256;     // float4 loads per thread, operand and slab
+
+// slab coordinates of load j of this thread.  k-contiguous: 8 lanes cover 128 contiguous bytes of a row;
+// row-contiguous: 16 lanes cover 256 contiguous bytes of one k.
+template <bool KC> __device__ __forceinline__ int ld_row(int tid, int j) { return KC ? (tid >> 3) + 32 * (j & 1) : (tid & 15) * 4; }
+template <bool KC> __device__ __forceinline__ int ld_k(int tid, int j) { return KC ? ((tid & 7) + 8 * (j >> 1)) * 4 : (tid >> 4) + 16 * j; }
+template <bool KC> __device__ __forceinline__ void stash(float* S, int tid, int j, float4 v) {
+    if (KC) *reinterpret_cast<float4*>(S + (((tid & 7) + 8 * (j >> 1)) * QP + ld_row<true>(tid, j)) * 4) = v;
+    else *reinterpret_cast<float4*>(S + ld_k<false>(tid, j) * LDP + ld_row<false>(tid, j)) = v;
+}
+// the four MFMA operand values of quad q for output row/column r of this lane
+template <bool KC> __device__ __forceinline__ float4 frag(const float* S, int q, int r) {
+    if (KC) return *reinterpret_cast<const float4*>(S + (q * QP + r) * 4);
+    return make_float4(S[(4 * q + 0) * LDP + r], S[(4 * q + 1) * LDP + r], S[(4 * q + 2) * LDP + r], S[(4 * q + 3) * LDP + r]);
+}
+
 template <class Op, bool VEC>
-__device__ __forceinline__ void gemm_tile(const FusedArgs& a, int K, int g, int split, int m0, int n0, GemmSmem& sm) {
+__device__ __forceinline__ void gemm_tile(const FusedArgs& a, int K, int g, int split, int m0, int n0, const GemmSmem& sm) {
     int32_t* srow = sm.srow;
-    float (*As)[LDP] = sm.As;
-    float (*Bs)[LDP] = sm.Bs;
+    float* As = sm.As;
+    float* Bs = sm.Bs;
     if (Op::GATHER) {     // row indices of this minibatch once per workgroup (removes a dependent-load chain)
-        const int64_t base = kbase(a) * a.c.mb;
+        const int64_t base = kb_of(a, g) * a.c.mb;
         for (int i = threadIdx.x; i < a.c.mb; i += 256) srow[i] = (int32_t)a.rows[base + i];
         __syncthreads();
     }
@@ -176,56 +232,36 @@ __device__ __forceinline__ void gemm_tile(const FusedArgs& a, int K, int g, int 
     for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    // per-thread slab coordinates: k-contiguous operands -> (row = tid/4, k = 8*(tid%4) + {0,4});
-    //                              row-contiguous operands -> (k = tid/8, row = 8*(tid%8) + {0,4})
-    const int a_r = Op::A_KCONTIG ? (tid >> 2) : ((tid & 7) * 8), a_k = Op::A_KCONTIG ? ((tid & 3) * 8) : (tid >> 3);
-    const int b_r = Op::B_KCONTIG ? (tid >> 2) : ((tid & 7) * 8), b_k = Op::B_KCONTIG ? ((tid & 3) * 8) : (tid >> 3);
-    float4 ra0, ra1, rb0, rb1;
-    int ma0, ma1, mb0, mb1, ob0 = -1, ob1 = -1;
+    constexpr bool AK = Op::A_KCONTIG, BK = Op::B_KCONTIG;
+    float4 ra[NLD], rb[NLD];
+    int ma[NLD], mb_[NLD], ob[NLD];
 #define COPO_FETCH(k0)                                                                                              \
     do {                                                                                                            \
-        if (Op::A_KCONTIG) {                                                                                        \
-            ra0 = Op::template lda4<VEC>(c, m0 + a_r, (k0) + a_k, kend, ma0);                                       \
-            ra1 = Op::template lda4<VEC>(c, m0 + a_r, (k0) + a_k + 4, kend, ma1);                                   \
-        } else {                                                                                                    \
-            ra0 = Op::template lda4<VEC>(c, m0 + a_r, (k0) + a_k, kend, ma0);                                       \
-            ra1 = Op::template lda4<VEC>(c, m0 + a_r + 4, (k0) + a_k, kend, ma1);                                   \
-        }                                                                                                           \
-        if (Op::B_KCONTIG) {                                                                                        \
-            rb0 = Op::template ldb4<VEC>(c, (k0) + b_k, n0 + b_r, kend, mb0, ob0);                                  \
-            rb1 = Op::template ldb4<VEC>(c, (k0) + b_k + 4, n0 + b_r, kend, mb1, ob1);                              \
-        } else {                                                                                                    \
-            rb0 = Op::template ldb4<VEC>(c, (k0) + b_k, n0 + b_r, kend, mb0, ob0);                                  \
-            rb1 = Op::template ldb4<VEC>(c, (k0) + b_k, n0 + b_r + 4, kend, mb1, ob1);                              \
+        _Pragma("unroll") for (int j = 0; j < NLD; ++j) {                                                           \
+            ra[j] = Op::template lda4<VEC>(c, m0 + ld_row<AK>(tid, j), (k0) + ld_k<AK>(tid, j), kend, ma[j]);       \
+            ob[j] = -1;                                                                                             \
+            rb[j] = Op::template ldb4<VEC>(c, (k0) + ld_k<BK>(tid, j), n0 + ld_row<BK>(tid, j), kend, mb_[j], ob[j]); \
         }                                                                                                           \
     } while (0)
     if (kbeg < kend) COPO_FETCH(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += TK) {
-        {   // stash the prefetched registers (masking happens here, after the loads had a whole slab to land)
-            const float4 va0 = apply_mask(ra0, ma0, -1), va1 = apply_mask(ra1, ma1, -1);
-            const float4 vb0 = apply_mask(rb0, mb0, ob0), vb1 = apply_mask(rb1, mb1, ob1);
-            if (Op::A_KCONTIG) {
-                As[a_k + 0][a_r] = va0.x; As[a_k + 1][a_r] = va0.y; As[a_k + 2][a_r] = va0.z; As[a_k + 3][a_r] = va0.w;
-                As[a_k + 4][a_r] = va1.x; As[a_k + 5][a_r] = va1.y; As[a_k + 6][a_r] = va1.z; As[a_k + 7][a_r] = va1.w;
-            } else {
-                *reinterpret_cast<float4*>(&As[a_k][a_r]) = va0;
-                *reinterpret_cast<float4*>(&As[a_k][a_r + 4]) = va1;
-            }
-            if (Op::B_KCONTIG) {
-                Bs[b_k + 0][b_r] = vb0.x; Bs[b_k + 1][b_r] = vb0.y; Bs[b_k + 2][b_r] = vb0.z; Bs[b_k + 3][b_r] = vb0.w;
-                Bs[b_k + 4][b_r] = vb1.x; Bs[b_k + 5][b_r] = vb1.y; Bs[b_k + 6][b_r] = vb1.z; Bs[b_k + 7][b_r] = vb1.w;
-            } else {
-                *reinterpret_cast<float4*>(&Bs[b_k][b_r]) = vb0;
-                *reinterpret_cast<float4*>(&Bs[b_k][b_r + 4]) = vb1;
-            }
+        // stash the prefetched registers (masking happens here, after the loads had a whole slab to land)
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            stash<AK>(As, tid, j, apply_mask(ra[j], ma[j], -1));
+            stash<BK>(Bs, tid, j, apply_mask(rb[j], mb_[j], ob[j]));
         }
         __syncthreads();
         if (k0 + TK < kend) COPO_FETCH(k0 + TK);
-#pragma unroll
-        for (int kk = 0; kk < TK; kk += 2) {
-            const float av = As[kk + (lane >> 5)][wm * 32 + (lane & 31)];
-            const float bv = Bs[kk + (lane >> 5)][wn * 32 + (lane & 31)];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        const int left = kend - k0;
+        const int nq = left >= TK ? TK / 4 : (left + 3) / 4;      // quads of this slab that hold data
+        for (int q = 0; q < nq; q += 2) {
+            const float4 av = frag<AK>(As, q + (lane >> 5), wm * 32 + (lane & 31));
+            const float4 bv = frag<BK>(Bs, q + (lane >> 5), wn * 32 + (lane & 31));
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
         }
         __syncthreads();
     }
@@ -236,7 +272,7 @@ __device__ __forceinline__ void gemm_tile(const FusedArgs& a, int K, int g, int 
 
 template <class Op, bool VEC>
 __global__ void __launch_bounds__(256) gemm_kernel(FusedArgs a, int K) {
-    __shared__ GemmSmem sm;
+    const GemmSmem sm = gemm_smem();
     const int G = a.groups;
     // the first kernel of an SGD step advances the Adam step counter (its only reader is the fold at the end)
     if (Op::FIRST && a.apply_adam && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
@@ -255,11 +291,11 @@ struct FwdOpT {
         GemmCtx c;
         c.mb = a.c.mb; c.H = a.c.hidden; c.srow = srow;
         c.K = GATHER ? L.in_dim : c.H;
-        c.abase = GATHER ? src_of(a, g) : a.ws + ws_h1(a.c, g);
+        c.abase = GATHER ? src_of(a, g) : a.ws + ws_h1(a, g);
         const float* th = theta_of(a, g);
         c.bbase = th + (GATHER ? L.w1 : L.w2);
         c.aux = th + (GATHER ? L.b1 : L.b2);
-        c.out = a.ws + (GATHER ? ws_h1(a.c, g) : ws_h2(a.c, g));
+        c.out = a.ws + (GATHER ? ws_h1(a, g) : ws_h2(a, g));
         c.woff = c.boff = 0;
         return c;
     }
@@ -293,10 +329,10 @@ struct BxOp {
     __device__ static __forceinline__ GemmCtx prep(const FusedArgs& a, int g, int, const int32_t* srow) {
         GemmCtx c;
         c.mb = a.c.mb; c.H = a.c.hidden; c.K = c.H; c.srow = srow;
-        c.abase = a.ws + ws_dz2(a.c, g);
+        c.abase = a.ws + ws_dz2(a, g);
         c.bbase = theta_of(a, g) + net_of(a, g).w2;
-        c.aux = a.ws + ws_h1(a.c, g);
-        c.out = a.ws + ws_dz1(a.c, g);
+        c.aux = a.ws + ws_h1(a, g);
+        c.out = a.ws + ws_dz1(a, g);
         c.woff = c.boff = 0;
         return c;
     }
@@ -335,14 +371,14 @@ struct BwOpT {
         GemmCtx c;
         c.mb = a.c.mb; c.H = a.c.hidden; c.srow = srow;
         c.K = GATHER ? L.in_dim : c.H;
-        c.abase = a.ws + (LAYER == 1 ? ws_dz1(a.c, g) : (LAYER == 2 ? ws_dz2(a.c, g) : ws_dout(a.c, g)));
-        c.bbase = GATHER ? src_of(a, g) : a.ws + (LAYER == 2 ? ws_h1(a.c, g) : ws_h2(a.c, g));
+        c.abase = a.ws + (LAYER == 1 ? ws_dz1(a, g) : (LAYER == 2 ? ws_dz2(a, g) : ws_dout(a, g)));
+        c.bbase = GATHER ? src_of(a, g) : a.ws + (LAYER == 2 ? ws_h1(a, g) : ws_h2(a, g));
         c.aux = nullptr;
         c.woff = LAYER == 1 ? L.w1 : (LAYER == 2 ? L.w2 : L.w3);
         c.boff = LAYER == 1 ? L.b1 : (LAYER == 2 ? L.b2 : L.b3);
         c.M = LAYER == 3 ? L.out_dim : c.H;
         c.astr = LAYER == 3 ? 4 : c.H;
-        c.out = a.ws + ws_split(a.c, region_of(a, g), split);
+        c.out = a.ws + ws_split(a, region_of(a, g), split);
         return c;
     }
     template <bool VEC>
@@ -373,7 +409,7 @@ struct BwOpT {
 // the rest the head layer (one row tile: out_dim <= 4 rows).  Fewer launches per SGD step, a grid that covers the chip.
 template <bool VEC>
 __global__ void __launch_bounds__(256) gemm_bw_kernel(FusedArgs a, int K, int nx2, int nx1) {
-    __shared__ GemmSmem sm;
+    const GemmSmem sm = gemm_smem();
     const int G = a.groups, g = blockIdx.z % G, split = blockIdx.z / G, x = blockIdx.x;
     if (x < nx2) gemm_tile<BwOpT<2>, VEC>(a, K, g, split, blockIdx.y * TM, x * TN, sm);
     else if (x < nx2 + nx1) gemm_tile<BwOpT<1>, VEC>(a, K, g, split, blockIdx.y * TM, (x - nx2) * TN, sm);
@@ -402,11 +438,11 @@ __global__ void __launch_bounds__(256) head_kernel(FusedArgs a) {
     // row bookkeeping first: these dependent loads (k -> row index -> pack row) overlap the tile load below
     const int r = tid / HTPR, part = tid % HTPR;
     const int m = m0 + r;
-    const int64_t kb = kbase(a);
+    const int64_t kb = kb_of(a, g);
     const bool rok = m < c.mb;
     const float wgt = rok ? a.w[kb * c.mb + m] / a.denom[kb] : 0.0f;
     const float* pk = a.pack_src + (size_t)(rok ? a.rows[kb * c.mb + m] : 0) * c.pack_width;
-    const float* h2g = a.ws + ws_h2(c, g);
+    const float* h2g = a.ws + ws_h2(a, g);
     // unconditional loads from clamped rows (a branch around a load drains vmcnt and serialises the tile load)
     for (int r = tid >> 6; r < HT; r += 4) {
         const bool ok = m0 + r < c.mb;
@@ -517,7 +553,7 @@ __global__ void __launch_bounds__(256) head_kernel(FusedArgs a) {
     if (part == 0) {
         // d(loss)/d(outputs): to LDS for dz2 below and to the workspace for the head's weight-gradient GEMM
         *reinterpret_cast<float4*>(douts + r * 4) = make_float4(dout[0], dout[1], dout[2], dout[3]);
-        if (rok) *reinterpret_cast<float4*>(a.ws + ws_dout(c, g) + (size_t)m * 4) = make_float4(dout[0], dout[1], dout[2], dout[3]);
+        if (rok) *reinterpret_cast<float4*>(a.ws + ws_dout(a, g) + (size_t)m * 4) = make_float4(dout[0], dout[1], dout[2], dout[3]);
     }
     // statistics: wave reduce -> LDS -> one partial per workgroup and stat
 #pragma unroll
@@ -529,10 +565,10 @@ __global__ void __launch_bounds__(256) head_kernel(FusedArgs a) {
     }
     __syncthreads();
     if (tid < 8)   // per-tile partial, folded in a fixed order by reduce_adam_kernel
-        a.ws[ws_stats_at(c, g * head_tiles(c) + tile) + tid] = (red[tid * 4] + red[tid * 4 + 1]) + (red[tid * 4 + 2] + red[tid * 4 + 3]);
+        a.ws[ws_stats_at(a, g * head_tiles(c) + tile) + tid] = (red[tid * 4] + red[tid * 4 + 1]) + (red[tid * 4 + 2] + red[tid * 4 + 3]);
     // dz2 = (dout W3) * (1 - h2^2): one hidden column per thread, W3's column in registers, dout rows are LDS
     // broadcasts.  (dW3 / db3 come out of the weight-gradient GEMM launch: BwOpT<3>.)
-    float* dz2 = a.ws + ws_dz2(c, g);
+    float* dz2 = a.ws + ws_dz2(a, g);
     const int nr = (c.mb - m0 < HT) ? c.mb - m0 : HT;
     for (int i = tid; i < H; i += 256) {
         float wc[4];
@@ -706,8 +742,8 @@ __global__ void __launch_bounds__(256) reduce_adam_kernel(FusedArgs a, int64_t l
         idx[u] = (size_t)lo + (ok[u] ? e : 0);
 #pragma unroll
         for (int sp = 0; sp < COPO_PPO_MAX_KSPLIT; ++sp) {
-            v0[u][sp] = a.ws[ws_split(c, 0, sp < a.ksplit ? sp : 0) + idx[u]];
-            v1[u][sp] = two ? a.ws[ws_split(c, 1, sp < a.ksplit ? sp : 0) + idx[u]] : 0.0f;
+            v0[u][sp] = a.ws[ws_split(a, 0, sp < a.ksplit ? sp : 0) + idx[u]];
+            v1[u][sp] = two ? a.ws[ws_split(a, 1, sp < a.ksplit ? sp : 0) + idx[u]] : 0.0f;
         }
     }
     float am[FOLD_EPT], av[FOLD_EPT], th[FOLD_EPT];
@@ -733,7 +769,7 @@ __global__ void __launch_bounds__(256) reduce_adam_kernel(FusedArgs a, int64_t l
         for (int k = wave; k < 8; k += 4) {
             float t0 = 0.0f, t1 = 0.0f;
             for (int q = lane; q < nq; q += 64) {
-                const float v = a.ws[ws_stats_at(c, q) + k];
+                const float v = a.ws[ws_stats_at(a, q) + k];
                 if (two && q >= tiles) t1 += v; else t0 += v;
             }
 #pragma unroll
@@ -787,7 +823,7 @@ __global__ void __launch_bounds__(256) reduce_adam_kernel(FusedArgs a, int64_t l
         a.dot_partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
         if (meta_tail) {
             // the last workgroup to get here sees every partial and statistic of this launch
-            unsigned* done = reinterpret_cast<unsigned*>(a.ws + ws_counter_at(c));
+            unsigned* done = reinterpret_cast<unsigned*>(a.ws + ws_counter_at(a));
             __threadfence();
             const bool last = atomicAdd(done, 1u) == gridDim.x - 1;
             last_flag = last ? 1 : 0;
@@ -801,6 +837,183 @@ __global__ void __launch_bounds__(256) reduce_adam_kernel(FusedArgs a, int64_t l
     meta_lcf_body(ml, red);
     __syncthreads();
     meta_finish_body(mf, red);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// batched LCF meta pass.  The two policy gradients of `meta_update` (algo_copo.py:228-309) depend on the
+// minibatch and on the (fixed) policy / target parameters only -- not on the LCF parameters the meta loop
+// updates -- so the gradient pairs of MANY minibatches are computed in one grouped launch chain (groups 2b, 2b+1 =
+// minibatch b; no row split: the grid is large enough), and the strictly sequential part, the fp64 LCF Adam
+// steps, runs afterwards in a single workgroup (meta_seq_kernel).
+// ------------------------------------------------------------------------------------------------------------
+// grid (fold_blocks, nb): <g_new_b, g_old_b> partials per workgroup, optional gradient export (data-parallel path),
+// loss statistics of both passes.  dot_out [nb][fold_blocks]; stats_out [nb][2][8]; g_out [nb][2][n].
+__global__ void __launch_bounds__(256) meta_batch_fold_kernel(FusedArgs a, int64_t lo, int n, float* g_out, double* dot_out,
+                                                              float* stats_out) {
+    const int b = blockIdx.y, tiles = head_tiles(a.c);
+    float s0[FOLD_EPT], s1[FOLD_EPT];
+    int e[FOLD_EPT];
+#pragma unroll
+    for (int u = 0; u < FOLD_EPT; ++u) {
+        e[u] = (blockIdx.x * FOLD_EPT + u) * 256 + threadIdx.x;
+        const size_t idx = (size_t)lo + (e[u] < n ? e[u] : 0);
+        s0[u] = a.ws[ws_split(a, 2 * b, 0) + idx];
+        s1[u] = a.ws[ws_split(a, 2 * b + 1, 0) + idx];
+    }
+    double prod = 0.0;
+#pragma unroll
+    for (int u = 0; u < FOLD_EPT; ++u) {
+        if (e[u] < n) {
+            prod += (double)s0[u] * (double)s1[u];
+            if (g_out) {
+                g_out[((size_t)b * 2 + 0) * n + e[u]] = s0[u];
+                g_out[((size_t)b * 2 + 1) * n + e[u]] = s1[u];
+            }
+        }
+    }
+    __shared__ double red[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) prod += __shfl_down(prod, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = prod;
+    __syncthreads();
+    if (threadIdx.x == 0) dot_out[(size_t)b * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (blockIdx.x == 0) {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        for (int k = wave; k < 8; k += 4) {
+            float t0 = 0.0f, t1 = 0.0f;
+            for (int q = lane; q < tiles; q += 64) {
+                t0 += a.ws[ws_stats_at(a, (2 * b) * tiles + q) + k];
+                t1 += a.ws[ws_stats_at(a, (2 * b + 1) * tiles + q) + k];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { t0 += __shfl_down(t0, o); t1 += __shfl_down(t1, o); }
+            if (lane == 0) {
+                stats_out[((size_t)b * 2 + 0) * 8 + k] = t0;
+                stats_out[((size_t)b * 2 + 1) * 8 + k] = t1;
+            }
+        }
+    }
+}
+
+// gv[b] = <g_new_b, g_old_b>: from the fold's per-workgroup partials (dot != NULL, n = partials per minibatch) or
+// from exported gradients g [nb][2][n] (after a gradient all-reduce).  grid (nb), fixed summation order.
+__global__ void __launch_bounds__(1024) meta_batch_dot_kernel(const double* dot, const float* g, int64_t n, double* gv) {
+    __shared__ double red[16];
+    const int b = blockIdx.x;
+    double s = 0.0;
+    if (dot) {
+        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) s += dot[(size_t)b * n + i];
+    } else {
+        const float* g0 = g + ((size_t)b * 2 + 0) * n;
+        const float* g1 = g + ((size_t)b * 2 + 1) * n;
+        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) s += (double)g0[i] * (double)g1[i];
+    }
+    const double t = block_sum_d(s, red);
+    if (threadIdx.x == 0) gv[b] = t;
+}
+
+struct MetaSeqArgs {
+    const float* pack_src;      // gather mode (ego_nei == NULL): A_ego / A_nei from pack_src rows
+    const int64_t* rows;        // [n_mb][mb]
+    const float* ego_nei;       // dense mode: [n_seg][n_mb][mb][2]
+    const float* w;             // [n_seg][n_mb][mb]
+    const double* eps;          // [n_seg][n_mb][mb]
+    const float* denom;         // [n_mb]
+    const double* gv;           // [n_mb]
+    const float* stats_in;      // [n_mb][2][8] loss statistics of the two passes
+    int32_t mb, n_mb, n_seg, pack_width, col_adv, col_nei_adv;
+    double* lcf_param;          // [2]
+    const double* raw_mean_std; // [2]
+    double* adam;               // [5]
+    double lr;
+    double* stats;              // [7] accumulated
+};
+
+// all LCF Adam steps of one meta iteration, in minibatch order, in ONE workgroup: per step the fp64 row sums of
+// meta_lcf_body with the current LCF parameters, then meta_finish_body's update -- parameters and Adam state live
+// in LDS between steps.
+__global__ void __launch_bounds__(512) meta_seq_kernel(MetaSeqArgs a) {
+    __shared__ double red[4][8];
+    __shared__ double P[2], AD[5], ST[7];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    if (tid < 2) P[tid] = a.lcf_param[tid];
+    if (tid < 5) AD[tid] = a.adam[tid];
+    if (tid < 7) ST[tid] = 0.0;
+    __syncthreads();
+    const double half_pi = 3.14159265358979323846 / 2.0, lim = 1.0 - 1e-6;
+    const double mu = a.raw_mean_std[0], sigma = a.raw_mean_std[1];
+    const size_t seg_stride = (size_t)a.n_mb * a.mb;
+    for (int k = 0; k < a.n_mb; ++k) {
+        const double p0 = P[0], p1 = P[1];
+        const double th = tanh(p0);
+        const double mean = th > lim ? lim : (th < -lim ? -lim : th);
+        const double dmean = (th >= -lim && th <= lim) ? (1.0 - th * th) : 0.0;
+        const double p1c = p1 > 2.0 ? 2.0 : (p1 < -20.0 ? -20.0 : p1);
+        const double sd = exp(p1c), dsd = (p1 >= -20.0 && p1 <= 2.0) ? sd : 0.0;
+        double s0 = 0.0, s1 = 0.0, sS = 0.0, sA = 0.0;
+        for (int i = tid; i < a.n_seg * a.mb; i += blockDim.x) {
+            const int seg = i / a.mb, m = i - seg * a.mb;
+            const size_t at = seg * seg_stride + (size_t)k * a.mb + m;
+            const double w = (double)a.w[at];
+            if (w == 0.0) continue;
+            double ego, nei;
+            if (a.ego_nei) {
+                ego = (double)a.ego_nei[at * 2];
+                nei = (double)a.ego_nei[at * 2 + 1];
+            } else {
+                const float* pk = a.pack_src + (size_t)a.rows[at] * a.pack_width;
+                ego = (double)pk[a.col_adv];
+                nei = (double)pk[a.col_nei_adv];
+            }
+            const double e = a.eps[at];
+            const double phi = (mean + sd * e) * half_pi;
+            const double cs = cos(phi), sn = sin(phi);
+            const double A = cs * ego + sn * nei;
+            const double dA = (-sn * ego + cs * nei) * half_pi;
+            sS += w * (A - mu) / sigma;
+            sA += w * A;
+            s0 += w * dA * dmean / sigma;
+            s1 += w * dA * e * dsd / sigma;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s0 += __shfl_down(s0, o); s1 += __shfl_down(s1, o); sS += __shfl_down(sS, o); sA += __shfl_down(sA, o);
+        }
+        if (lane == 0) { red[0][wave] = s0; red[1][wave] = s1; red[2][wave] = sS; red[3][wave] = sA; }
+        __syncthreads();
+        if (tid == 0) {
+            double t[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int q = 0; q < 4; ++q)
+                for (int i = 0; i < nw; ++i) t[q] += red[q][i];
+            const double D = (double)a.denom[k];
+            const double tail[4] = {t[0] / D, t[1] / D, t[2] / D, t[3] / D};
+            const double gvk = a.gv[k];
+            const double b1 = 0.9, b2 = 0.999, eps = 1e-8;
+            const double tt = AD[4] + 1.0;
+            const double bc1 = 1.0 - pow(b1, tt), bc2 = 1.0 - pow(b2, tt);
+            for (int j = 0; j < 2; ++j) {
+                const double g = gvk * tail[j];
+                double m = AD[j], v = AD[2 + j];
+                m = m + (g - m) * (1.0 - b1);
+                v = v * b2 + g * g * (1.0 - b2);
+                AD[j] = m;
+                AD[2 + j] = v;
+                P[j] -= (a.lr / bc1) * (m / (sqrt(v) / sqrt(bc2) + eps));
+            }
+            AD[4] = tt;
+            ST[0] += (double)a.stats_in[((size_t)k * 2 + 0) * 8 + 1];
+            ST[1] += (double)a.stats_in[((size_t)k * 2 + 1) * 8 + 1];
+            ST[2] += tail[2];
+            ST[3] += gvk * tail[2];
+            ST[4] += gvk;
+            ST[5] += tail[3];
+            ST[6] += (double)a.stats_in[((size_t)k * 2 + 0) * 8 + 7];
+        }
+        __syncthreads();
+    }
+    if (tid < 2) a.lcf_param[tid] = P[tid];
+    if (tid < 5) a.adam[tid] = AD[tid];
+    if (tid < 7 && a.stats) a.stats[tid] += ST[tid];
 }
 
 __global__ void bump_kernel(int64_t* step, int64_t* k) {
@@ -827,7 +1040,7 @@ __global__ void __launch_bounds__(256) adam_flat_kernel(FusedArgs a, long long n
 // host launchers
 // ------------------------------------------------------------------------------------------------------------
 size_t fused_ws_floats(const copo_ppo_cfg& c) {
-    return ws_counter_at(c) + 4;
+    return WsLay(c, 4, 2).total();
 }
 
 static int pick_ksplit(int mb) {
@@ -839,9 +1052,48 @@ static int pick_ksplit(int mb) {
 
 struct MetaTail { MetaArgs lcf; MetaFinishArgs fin; };
 
-hipError_t launch_fused_step(FusedArgs a, hipStream_t s, const MetaTail* mt_ = nullptr) {
+// the GEMM workgroups use more than the default 64 KB of dynamic LDS (gfx950 has 160 KB per CU)
+template <class F> static hipError_t allow_big_lds(F* f) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
+}
+static hipError_t gemm_lds_attrs() {
+    static hipError_t once = [] {
+        hipError_t e = hipSuccess, r;
+#define COPO_ATTR(K) if ((r = allow_big_lds(K)) != hipSuccess) e = r
+        COPO_ATTR((gemm_kernel<FwdOpT<1>, true>)); COPO_ATTR((gemm_kernel<FwdOpT<1>, false>));
+        COPO_ATTR((gemm_kernel<FwdOpT<2>, true>)); COPO_ATTR((gemm_kernel<FwdOpT<2>, false>));
+        COPO_ATTR((gemm_kernel<BxOp, true>)); COPO_ATTR((gemm_kernel<BxOp, false>));
+        COPO_ATTR((gemm_bw_kernel<true>)); COPO_ATTR((gemm_bw_kernel<false>));
+#undef COPO_ATTR
+        return e;
+    }();
+    return once;
+}
+
+struct MetaBatch { int nb; float* g_out; double* dot_out; float* stats_out; };
+
+// [lo, lo + n): the span of the flat parameter buffer that the first `nets` networks of the layout occupy
+static void fold_range(const copo_ppo_cfg& c, int nets_n, int64_t* lo_out, int* n_out) {
+    const copo_net_layout* nets[4] = {&c.pol, &c.val[0], &c.val[1], &c.val[2]};
+    int64_t lo = c.pol.w1, hi = 0;
+    for (int g = 0; g < nets_n; ++g) {
+        const int64_t offs[6] = {nets[g]->w1, nets[g]->b1, nets[g]->w2, nets[g]->b2, nets[g]->w3, nets[g]->b3};
+        const int64_t szs[6] = {(int64_t)c.hidden * nets[g]->in_dim, c.hidden, (int64_t)c.hidden * c.hidden, c.hidden,
+                                (int64_t)nets[g]->out_dim * c.hidden, nets[g]->out_dim};
+        for (int t = 0; t < 6; ++t) {
+            lo = offs[t] < lo ? offs[t] : lo;
+            hi = offs[t] + szs[t] > hi ? offs[t] + szs[t] : hi;
+        }
+    }
+    *lo_out = lo;
+    *n_out = (int)(hi - lo);
+}
+
+hipError_t launch_fused_step(FusedArgs a, hipStream_t s, const MetaTail* mt_ = nullptr, const MetaBatch* mbatch = nullptr,
+                             int* fold_blocks_out = nullptr, int* n_fold_out = nullptr) {
     const copo_ppo_cfg& c = a.c;
-    a.ksplit = pick_ksplit(c.mb);
+    if (hipError_t e = gemm_lds_attrs(); e != hipSuccess) return e;
+    a.ksplit = mbatch ? 1 : pick_ksplit(c.mb);     // a batched pass fills the chip without splitting rows
     const int G = a.groups, mt = (c.mb + TM - 1) / TM, ht = (c.hidden + TN - 1) / TN;
     int kmax1 = c.pol.in_dim;
     if (a.head_mode == COPO_HEAD_PPO)
@@ -855,8 +1107,8 @@ hipError_t launch_fused_step(FusedArgs a, hipStream_t s, const MetaTail* mt_ = n
         vec = vec && (nets[g]->in_dim % 4 == 0) && (nets[g]->w1 % 4 == 0) && (nets[g]->w2 % 4 == 0);
 #define COPO_GEMM(OP, grid, op, K)                                                                     \
     do {                                                                                               \
-        if (vec) hipLaunchKernelGGL((gemm_kernel<OP, true>), grid, dim3(256), 0, s, a, K);             \
-        else hipLaunchKernelGGL((gemm_kernel<OP, false>), grid, dim3(256), 0, s, a, K);                \
+        if (vec) hipLaunchKernelGGL((gemm_kernel<OP, true>), grid, dim3(256), GEMM_LDS_BYTES, s, a, K);   \
+        else hipLaunchKernelGGL((gemm_kernel<OP, false>), grid, dim3(256), GEMM_LDS_BYTES, s, a, K);      \
     } while (0)
     COPO_GEMM(FwdOpT<1>, dim3(ht, mt, G), f1, kmax1);
     COPO_GEMM(FwdOpT<2>, dim3(ht, mt, G), f2, c.hidden);
@@ -867,22 +1119,22 @@ hipError_t launch_fused_step(FusedArgs a, hipStream_t s, const MetaTail* mt_ = n
     {
         const int nx2 = (c.hidden + 1 + TN - 1) / TN, nx1 = (kmax1 + 1 + TN - 1) / TN;
         const dim3 grid(nx2 + nx1 + nx2, ht, G * a.ksplit);
-        if (vec) hipLaunchKernelGGL((gemm_bw_kernel<true>), grid, dim3(256), 0, s, a, c.mb, nx2, nx1);
-        else hipLaunchKernelGGL((gemm_bw_kernel<false>), grid, dim3(256), 0, s, a, c.mb, nx2, nx1);
+        if (vec) hipLaunchKernelGGL((gemm_bw_kernel<true>), grid, dim3(256), GEMM_LDS_BYTES, s, a, c.mb, nx2, nx1);
+        else hipLaunchKernelGGL((gemm_bw_kernel<false>), grid, dim3(256), GEMM_LDS_BYTES, s, a, c.mb, nx2, nx1);
     }
     // parameter range the fold covers: every net of this call (the policy only in the meta modes)
-    int64_t lo = c.pol.w1, hi = 0;
-    for (int g = 0; g < (a.head_mode == COPO_HEAD_PPO ? G : 1); ++g) {
-        const int64_t offs[6] = {nets[g]->w1, nets[g]->b1, nets[g]->w2, nets[g]->b2, nets[g]->w3, nets[g]->b3};
-        const int64_t szs[6] = {(int64_t)c.hidden * nets[g]->in_dim, c.hidden, (int64_t)c.hidden * c.hidden, c.hidden,
-                                (int64_t)nets[g]->out_dim * c.hidden, nets[g]->out_dim};
-        for (int t = 0; t < 6; ++t) {
-            lo = offs[t] < lo ? offs[t] : lo;
-            hi = offs[t] + szs[t] > hi ? offs[t] + szs[t] : hi;
-        }
-    }
-    const int n_fold = (int)(hi - lo), fold_blocks = (n_fold + 256 * FOLD_EPT - 1) / (256 * FOLD_EPT);
+    int64_t lo;
+    int n_fold;
+    fold_range(c, a.head_mode == COPO_HEAD_PPO ? G : 1, &lo, &n_fold);
+    const int fold_blocks = (n_fold + 256 * FOLD_EPT - 1) / (256 * FOLD_EPT);
     if (a.head_mode == MODE_META_BOTH && fold_blocks > COPO_META_DOT_PARTIALS) return hipErrorInvalidValue;
+    if (fold_blocks_out) *fold_blocks_out = fold_blocks;
+    if (n_fold_out) *n_fold_out = n_fold;
+    if (mbatch) {
+        hipLaunchKernelGGL(meta_batch_fold_kernel, dim3(fold_blocks, mbatch->nb), dim3(256), 0, s, a, lo, n_fold, mbatch->g_out,
+                           mbatch->dot_out, mbatch->stats_out);
+        return hipGetLastError();
+    }
     MetaTail tailv{};
     if (mt_) {
         tailv = *mt_;
@@ -924,6 +1176,7 @@ static void fill_common(FusedArgs& a, const copo_ppo_cfg* cfg, const float* obs_
     a.c = *cfg;
     a.obs_src = obs_src; a.cc_src = cc_src ? cc_src : obs_src; a.pack_src = pack_src;
     a.rows = rows; a.w = w; a.denom = denom; a.ws = workspace; a.kptr = mb_index;
+    a.gcap = 4; a.nreg = 2;
 }
 
 extern "C" int copo_ppo_fused_step_f32(const copo_ppo_cfg* cfg, float* theta, float* adam_m, float* adam_v, float* grad,
@@ -989,6 +1242,81 @@ extern "C" int copo_meta_step_f64(const copo_ppo_cfg* cfg, float* theta, float* 
                             stats_old, stats, mb_index, (mb_index && bump_index) ? 1 : 0};
     hipError_t e = launch_fused_step(a, static_cast<hipStream_t>(stream), &mt);
     return e == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
+}
+
+// ---- batched LCF meta pass --------------------------------------------------------------------------------------
+static size_t batch_ws_base(const copo_ppo_cfg& c, int nb) {     // floats before the fp64 dot-partial scratch (kept even)
+    const int g = 2 * nb > 4 ? 2 * nb : 8;
+    const size_t t = WsLay(c, g, g).total();
+    return (t + 1) & ~(size_t)1;
+}
+static int batch_fold_blocks(const copo_ppo_cfg& c) {
+    int64_t lo;
+    int n;
+    fold_range(c, 1, &lo, &n);
+    return (n + 256 * FOLD_EPT - 1) / (256 * FOLD_EPT);
+}
+
+extern "C" int64_t copo_meta_fold_len(const copo_ppo_cfg* cfg) {
+    if (!cfg) return -1;
+    int64_t lo;
+    int n;
+    fold_range(*cfg, 1, &lo, &n);
+    return n;
+}
+
+extern "C" int64_t copo_meta_batch_workspace_floats(const copo_ppo_cfg* cfg, int32_t nb) {
+    if (!cfg || nb < 1) return -1;
+    return (int64_t)(batch_ws_base(*cfg, nb) + (size_t)2 * nb * batch_fold_blocks(*cfg));
+}
+
+extern "C" int copo_meta_batch_grads_f32(const copo_ppo_cfg* cfg, float* theta, float* theta_target, const float* obs_src,
+                                         const float* pack_src, const int64_t* rows, const float* w, const float* denom,
+                                         float* workspace, int32_t nb_cap, int64_t mb_first, int32_t nb, float* g_out,
+                                         double* gv_out, float* stats_out, void* stream) {
+    int rc = check_cfg(cfg);
+    if (rc != COPO_OK) return rc;
+    if (!theta || !theta_target || !obs_src || !pack_src || !rows || !w || !denom || !workspace || !gv_out || !stats_out)
+        return COPO_ERR_NULL;
+    if (nb < 1 || nb > nb_cap || nb_cap > COPO_META_BATCH_MAX || mb_first < 0) return COPO_ERR_DIM;
+    if ((reinterpret_cast<uintptr_t>(workspace) & 7) != 0) return COPO_ERR_DIM;
+    FusedArgs a;
+    fill_common(a, cfg, obs_src, nullptr, pack_src, rows, w, denom, workspace, nullptr);
+    a.theta = theta; a.theta2 = theta_target; a.apply_adam = 0; a.head_mode = MODE_META_BOTH;
+    a.groups = 2 * nb;
+    a.gcap = a.nreg = 2 * nb_cap > 4 ? 2 * nb_cap : 8;   // > 4: the batched layout (see WsLay); fixed by nb_cap so that
+                                                         // a short last chunk reuses the same (zero-padded) regions
+    a.k_first = mb_first;
+    double* dot = reinterpret_cast<double*>(workspace + batch_ws_base(*cfg, nb_cap));
+    MetaBatch mbt{nb, g_out, dot, stats_out};
+    int fb = 0;
+    hipError_t e = launch_fused_step(a, static_cast<hipStream_t>(stream), nullptr, &mbt, &fb, nullptr);
+    if (e != hipSuccess) return COPO_ERR_DEVICE;
+    hipLaunchKernelGGL(meta_batch_dot_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), dot, nullptr,
+                       (int64_t)fb, gv_out);
+    return hipGetLastError() == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
+}
+
+extern "C" int copo_meta_batch_dot_f64(const float* g, int64_t n, int32_t nb, double* gv_out, void* stream) {
+    if (!g || !gv_out) return COPO_ERR_NULL;
+    if (n < 1 || nb < 1) return COPO_ERR_DIM;
+    hipLaunchKernelGGL(meta_batch_dot_kernel, dim3(nb), dim3(1024), 0, static_cast<hipStream_t>(stream), nullptr, g, n, gv_out);
+    return hipGetLastError() == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
+}
+
+extern "C" int copo_meta_batch_lcf_f64(const float* pack_src, int32_t pack_width, int32_t col_adv, int32_t col_nei_adv,
+                                       const int64_t* rows, const float* ego_nei, int32_t n_seg, const float* w,
+                                       const double* eps, const float* denom, int32_t mb, int32_t n_mb, const double* gv,
+                                       const float* stats_in, double* lcf_param, const double* raw_mean_std,
+                                       double* adam_state, double lr, double* stats, void* stream) {
+    if (!w || !eps || !denom || !gv || !stats_in || !lcf_param || !raw_mean_std || !adam_state) return COPO_ERR_NULL;
+    if (!ego_nei && (!pack_src || !rows)) return COPO_ERR_NULL;
+    if (mb < 1 || n_mb < 0 || n_seg < 1 || (!ego_nei && n_seg != 1)) return COPO_ERR_DIM;
+    if (n_mb == 0) return COPO_OK;
+    MetaSeqArgs a{pack_src, rows, ego_nei, w, eps, denom, gv, stats_in, mb, n_mb, n_seg, pack_width, col_adv, col_nei_adv,
+                  lcf_param, raw_mean_std, adam_state, lr, stats};
+    hipLaunchKernelGGL(meta_seq_kernel, dim3(1), dim3(512), 0, static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
 }
 
 extern "C" int copo_meta_lcf_f64(const float* pack_src, int32_t pack_width, int32_t col_adv, int32_t col_nei_adv,

@@ -103,6 +103,7 @@ class FusedLearner:
         ws = _capi.lib.copo_ppo_workspace_floats(C.byref(c))
         self.workspace = torch.zeros(int(ws), device=dev)
         self.stats = torch.zeros(_capi.PPO_STATS, device=dev)
+        self._batch_ws = None
         self.target_flat = None
 
     def attach_target(self, target_model):
@@ -164,6 +165,38 @@ class FusedLearner:
             stats_old.data_ptr(), dot_partials.data_ptr(), int(col_adv), int(col_nei_adv), eps_all.data_ptr(),
             lcf_param.data_ptr(), raw_mean_std.data_ptr(), tail.data_ptr(), adam_state.data_ptr(), float(lr),
             stats.data_ptr(), rs["k"].data_ptr(), 1 if bump_index else 0, _capi.current_stream()))
+
+    # ---- batched meta pass: many minibatches per launch chain, then the sequential LCF steps in one kernel -------
+    def meta_fold_len(self):
+        return int(_capi.lib.copo_meta_fold_len(C.byref(self.cfg)))
+
+    def meta_batch_grads(self, rs, first, nb, gv, stats_k, g_out=None):
+        """Phase A for minibatches [first, first + nb) of the row tables: gv[first:first+nb], stats_k[first:...]."""
+        if self._batch_ws is None or self._batch_ws[0] < nb:
+            n = int(_capi.lib.copo_meta_batch_workspace_floats(C.byref(self.cfg), int(nb)))
+            self._batch_ws = (nb, torch.zeros(n, dtype=torch.float32, device=self.flat.flat.device))
+        _capi.check(_capi.lib.copo_meta_batch_grads_f32(
+            C.byref(self.cfg), self.flat.flat.data_ptr(), self.target_flat.flat.data_ptr(), rs["obs"].data_ptr(),
+            rs["pack"].data_ptr(), rs["rows_all"].data_ptr(), rs["w_all"].data_ptr(), rs["denom_all"].data_ptr(),
+            self._batch_ws[1].data_ptr(), int(self._batch_ws[0]), int(first), int(nb), None if g_out is None else g_out.data_ptr(),
+            gv[first:].data_ptr(), stats_k[first:].data_ptr(), _capi.current_stream()))
+
+    def meta_batch_dot(self, g, n, nb, gv):
+        _capi.check(_capi.lib.copo_meta_batch_dot_f64(g.data_ptr(), int(n), int(nb), gv.data_ptr(), _capi.current_stream()))
+
+    def meta_batch_lcf(self, rs, n_mb, eps_all, gv, stats_k, lcf_param, raw_mean_std, adam_state, lr, stats, col_adv,
+                       col_nei_adv, dense=None):
+        """Phase B.  dense = (ego_nei [S][n_mb][mb][2], w [S][n_mb][mb], eps [S][n_mb][mb]) replaces the row gather."""
+        if dense is None:
+            args = (rs["pack"].data_ptr(), self.cfg.pack_width, int(col_adv), int(col_nei_adv), rs["rows_all"].data_ptr(),
+                    None, 1, rs["w_all"].data_ptr(), eps_all.data_ptr())
+        else:
+            en, w, eps = dense
+            args = (None, 0, 0, 0, None, en.data_ptr(), int(en.shape[0]), w.data_ptr(), eps.data_ptr())
+        _capi.check(_capi.lib.copo_meta_batch_lcf_f64(
+            *args, rs["denom_all"].data_ptr(), self.cfg.mb, int(n_mb), gv.data_ptr(), stats_k.data_ptr(),
+            lcf_param.data_ptr(), raw_mean_std.data_ptr(), adam_state.data_ptr(), float(lr), stats.data_ptr(),
+            _capi.current_stream()))
 
     def state(self):
         return dict(adam_m=self.adam_m.clone(), adam_v=self.adam_v.clone(), step=self.step_count.clone())

@@ -49,6 +49,8 @@ class CoPOConfig(CCPPOConfig):
         self.use_centralized_critic = False
         self.fuse_mode = "none"
         self.old_value_loss = True
+        # fused learner only: minibatches per batched meta launch chain (0 = one launch chain per minibatch)
+        self.meta_batch_size = 32
         self.update_from_dict({"model": {"custom_model": "copo_model"}})
         # TF-era keys of train_copo.py:43-47 that the torch reference silently ignores
         self.initial_svo_std = None
@@ -328,6 +330,18 @@ class CoPOPolicy(CCPPOPolicy):
         self._meta_step_a()
         self._meta_step_b()
 
+    def _run_meta_batched(self, n_mb, nb):
+        """One meta iteration the batched way: the gradient pairs of `nb` minibatches per launch chain (they do not
+        depend on the LCF parameters), then all `n_mb` sequential LCF Adam steps in one kernel.  Same results as
+        `n_mb` calls of `_meta_step_local`."""
+        mb_, fz = self._meta_bufs, self.fused
+        rs = dict(self._row_sources, **{k: mb_[k] for k in ("rows_all", "w_all", "denom_all")})
+        for c0 in range(0, n_mb, nb):
+            fz.meta_batch_grads(rs, c0, min(nb, n_mb - c0), mb_["gv"], mb_["stats_k"])
+        fz.meta_batch_lcf(rs, n_mb, mb_["eps_all"], mb_["gv"], mb_["stats_k"], self.model.lcf_parameters.data,
+                          self._raw_ms, self._lcf_adam, self.config[LCF_LR], mb_["stats"], mb_["col_adv"],
+                          mb_["col_nei_adv"])
+
     def run_meta(self, valid_idx, B_local, B_all, mb, num_iters):
         """`lcf_num_iters` passes of shuffled minibatches through `meta_update` (algo_copo.py:581-589)."""
         rs = self._row_sources
@@ -357,7 +371,9 @@ class CoPOPolicy(CCPPOPolicy):
                     g_both=g_both, g_new=g_both[:nflat], g_old=g_both[n_pol:], tail=torch.zeros(4, dtype=torch.float64, device=dev),
                     dot_partials=torch.zeros(8192, dtype=torch.float64, device=dev),
                     stats_new=torch.zeros(8, device=dev), stats_old=torch.zeros(8, device=dev),
-                    col_adv=cols[Postprocessing.ADVANTAGES], col_nei_adv=cols[NEI_ADVANTAGE])
+                    col_adv=cols[Postprocessing.ADVANTAGES], col_nei_adv=cols[NEI_ADVANTAGE],
+                    gv=torch.zeros(max_mb, dtype=torch.float64, device=dev),
+                    stats_k=torch.zeros(max_mb, 2, 8, dtype=torch.float32, device=dev))
             self._meta = None
         if self._meta is None:
             if D.is_dist():
@@ -368,9 +384,14 @@ class CoPOPolicy(CCPPOPolicy):
         mbuf = self._meta_bufs
         mbuf["stats"].zero_()
         steps = 0
+        nb_batch = int(self.config.get("meta_batch_size", 32)) if self.fused is not None else 0
         for _ in range(num_iters):
             n_mb = self.plan_epoch(valid_idx, B_local, B_all, mb, bufs=mbuf)
             mbuf["eps_all"].normal_()
+            if nb_batch > 0 and not D.is_dist():
+                self._run_meta_batched(n_mb, nb_batch)
+                steps += n_mb
+                continue
             for _k in range(n_mb):
                 if D.is_dist():
                     self._meta[0]()

@@ -207,6 +207,7 @@ typedef struct copo_net_layout {
 #define COPO_HEAD_META_NEW 1   /* policy net only, loss = mean(-clipped surrogate) with the global advantage */
 #define COPO_HEAD_META_OLD 2   /* policy net only, loss = mean(logp(action))  (target network)           */
 #define COPO_PPO_MAX_MB 1024   /* rows per minibatch supported by the fused learner */
+#define COPO_META_BATCH_MAX 256        /* minibatches per copo_meta_batch_grads_f32 call */
 #define COPO_META_DOT_PARTIALS 8192 /* doubles in the `dot_partials` workspace of the meta update */
 #define COPO_PPO_MAX_KSPLIT 4  /* row splits of the weight-gradient GEMMs (fixed order -> deterministic sums) */
 #define COPO_PPO_STATS 8       /* sums of: total, policy, vf_ego, kl, entropy, vf_nei, vf_glob, advantage  */
@@ -279,6 +280,34 @@ int copo_meta_step_f64(const copo_ppo_cfg* cfg, float* theta, float* theta_targe
                        int32_t col_adv, int32_t col_nei_adv, const double* eps, double* lcf_param,
                        const double* raw_mean_std, double* tail, double* adam_state, double lr, double* stats,
                        int64_t* mb_index, int32_t bump_index, void* stream);
+
+/* ---- batched LCF meta pass ------------------------------------------------------------------------------------
+ * The two policy gradients of `meta_update` depend on the minibatch and on the policy / target parameters, which
+ * the LCF loop (algo_copo.py:581-589) does not change -- only the two LCF parameters move.  So the gradient pairs
+ * of many minibatches are computed in ONE grouped launch chain (phase A), and the sequential fp64 LCF Adam steps
+ * run afterwards in one kernel (phase B).  Results equal the step-by-step calls above.
+ *
+ * Phase A: minibatches mb_first .. mb_first + nb - 1 of the row tables (rows / w [n_mb][mb], denom [n_mb]).
+ *   gv_out [nb] doubles = <g_new, g_old> of each minibatch; stats_out [nb][2][COPO_PPO_STATS] = loss statistics of
+ *   the new-policy / old-policy pass; g_out NULL, or [nb][2][copo_meta_fold_len()] to export the gradients
+ *   (data-parallel: all-reduce them, then copo_meta_batch_dot_f64 recomputes gv).  workspace:
+ *   copo_meta_batch_workspace_floats(cfg, nb_cap) floats, 8-byte aligned, zero-initialised once; nb <= nb_cap. */
+int64_t copo_meta_fold_len(const copo_ppo_cfg* cfg);
+int64_t copo_meta_batch_workspace_floats(const copo_ppo_cfg* cfg, int32_t nb);
+int copo_meta_batch_grads_f32(const copo_ppo_cfg* cfg, float* theta, float* theta_target, const float* obs_src,
+                              const float* pack_src, const int64_t* rows, const float* w, const float* denom,
+                              float* workspace, int32_t nb_cap, int64_t mb_first, int32_t nb, float* g_out,
+                              double* gv_out, float* stats_out, void* stream);
+int copo_meta_batch_dot_f64(const float* g /* [nb][2][n] */, int64_t n, int32_t nb, double* gv_out, void* stream);
+/* Phase B: n_mb sequential LCF Adam steps (minibatch order) in one kernel.  Row inputs either gathered from
+ * pack_src via rows (ego_nei NULL, n_seg 1) or dense: ego_nei [n_seg][n_mb][mb][2] = {A_ego, A_nei} with w / eps
+ * [n_seg][n_mb][mb] (data-parallel: the all-gathered rows of every rank).  gv [n_mb], stats_in [n_mb][2][8] from
+ * phase A; lcf_param / adam_state / stats as in copo_meta_finish_f64. */
+int copo_meta_batch_lcf_f64(const float* pack_src, int32_t pack_width, int32_t col_adv, int32_t col_nei_adv,
+                            const int64_t* rows, const float* ego_nei, int32_t n_seg, const float* w, const double* eps,
+                            const float* denom, int32_t mb, int32_t n_mb, const double* gv, const float* stats_in,
+                            double* lcf_param, const double* raw_mean_std, double* adam_state, double lr, double* stats,
+                            void* stream);
 
 #ifdef __cplusplus
 }

@@ -218,3 +218,39 @@ def test_fused_meta_single_call_equals_three_calls():
     for x, y in ((a["tail"], b["tail"]), (a["stats"], b["stats"]), (pols[0].model.lcf_parameters, pols[1].model.lcf_parameters),
                  (pols[0]._lcf_adam, pols[1]._lcf_adam)):
         np.testing.assert_allclose(x.detach().cpu().numpy(), y.detach().cpu().numpy(), rtol=1e-11, atol=1e-14)
+
+
+@pytest.mark.parametrize("nb", [1, 3, 8])
+def test_batched_meta_pass_equals_sequential_steps(nb):
+    """Phase A (gradient pairs of `nb` minibatches per launch chain) + phase B (all LCF Adam steps in one kernel)
+    == one `meta_update` per minibatch in order (algo_copo.py:581-589): same dot products, same LCF trajectory."""
+    R, mb, odim = 2300, 512, 92                  # 5 minibatches, the last one ragged (252 valid rows)
+    pols = [_make("copo", "none", odim, fused=True) for _ in range(2)]
+    with torch.no_grad():
+        for p in list(pols[0].model.parameters()) + list(pols[0].target_model.parameters()):
+            if p.dtype == torch.float32:
+                p.add_(torch.randn_like(p) * 0.05)
+    _copy_weights(pols[1], pols[0])
+    batch = _dense_batch(pols[0], R, odim, seed=11)
+    idx = torch.arange(R, device="cuda")
+    for pol in pols:
+        pol.prepare_sgd(batch, R, mb)
+        pol._raw_lcf_adv_mean.fill_(0.2)
+        pol._raw_lcf_adv_std.fill_(1.7)
+        pol.use_graphs = False
+    pols[0].config["meta_batch_size"] = 0
+    pols[1].config["meta_batch_size"] = nb
+    outs = []
+    for pol in pols:
+        torch.manual_seed(21)
+        outs.append(pol.run_meta(idx, R, [R], mb, 3))      # 3 meta iterations = 15 LCF steps
+    a, b = pols[0], pols[1]
+    np.testing.assert_allclose(b.model.lcf_parameters.detach().cpu().numpy(), a.model.lcf_parameters.detach().cpu().numpy(),
+                               rtol=1e-6, atol=1e-9)       # row-split vs unsplit fp32 weight-gradient sums
+    np.testing.assert_allclose(b._lcf_adam.cpu().numpy(), a._lcf_adam.cpu().numpy(), rtol=1e-4, atol=1e-18)
+    assert float(a._lcf_adam[4]) == 15.0
+    for k in outs[0]:
+        np.testing.assert_allclose(outs[1][k], outs[0][k], rtol=2e-5, atol=1e-9, err_msg=k)
+    # the dot products of the last iteration, minibatch by minibatch, against the step-by-step gradients
+    gv = b._meta_bufs["gv"][:5].cpu().numpy()
+    assert np.all(np.isfinite(gv)) and np.abs(gv).max() > 0
