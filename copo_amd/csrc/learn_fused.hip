@@ -31,9 +31,9 @@ namespace copo {
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-constexpr int TM = 64, TN = 64, TK = 128, LDP = 68;  // K slab; LDP: padded LDS row (floats)
-static_assert(TK == 128 && TM == 64 && TN == 64, "the slab load maps below are written for 64 x 128 slabs");
-constexpr int HT = 8;                                 // rows per workgroup of the head kernel
+constexpr int TM = 64, TN = 64, TK = 64, LDP = 68;   // K slab; LDP: padded LDS row (floats)
+static_assert((TK == 64 || TK == 128) && TM == 64 && TN == 64, "the slab load maps below are written for 64 x 64/128 slabs");
+constexpr int HT = 16;                                // rows per workgroup of the head / row-pass kernels
 constexpr int HTPR = 256 / HT;                        // threads per row of the head kernel
 constexpr int MODE_META_BOTH = 3;                     // internal: group 0 = META_NEW on theta, group 1 = META_OLD on theta2
 
@@ -65,6 +65,7 @@ struct FusedArgs {
     double* dot_partials;      // META_BOTH: per-workgroup partials of <g_new, g_old> (COPO_META_DOT_PARTIALS doubles)
     int32_t gcap;              // group slabs of the workspace layout (4, or `groups` of a batched meta pass)
     int32_t nreg;              // gradient regions of the workspace layout
+    int32_t dbg;               // timing experiments only (COPO_RP_DBG): phases of the row pass to skip
     int64_t k_first;           // minibatch index offset (batched meta pass: groups 2b, 2b+1 are minibatch k_first + b)
 };
 
@@ -283,6 +284,15 @@ __global__ void __launch_bounds__(256) gemm_kernel(FusedArgs a, int K) {
 #define COPO_ACC_ROW(rbase, j) ((rbase) + ((j) >> 2) * 8 + ((j) & 3))
 
 // ---- layer forward: Y[m][n] = tanh(sum_k X[m][k] W[n][k] + b[n]) --------------------------------------------
+// tanh to ~1e-7 absolute: odd polynomial near zero (no cancellation), 1 - 2 / (exp(2x) + 1) elsewhere; ~12
+// instructions instead of the libm expansion (16 per lane and layer sit on the critical path of every step)
+__device__ __forceinline__ float tanh_fast(float x) {
+    const float x2 = x * x;
+    const float p = x * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * (-0.053968254f + x2 * 0.021869488f))));
+    const float r = 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f);
+    return fabsf(x) < 0.3f ? p : r;
+}
+
 template <int LAYER>
 struct FwdOpT {
     static constexpr bool A_KCONTIG = true, B_KCONTIG = true, SPLITS_K = false, GATHER = LAYER == 1, FIRST = LAYER == 1;
@@ -317,7 +327,7 @@ struct FwdOpT {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int m = COPO_ACC_ROW(rbase, j);
-            const float y = tanhf(acc[j] + bv);
+            const float y = tanh_fast(acc[j] + bv);
             if (cok && m < c.mb) c.out[(size_t)m * c.H + col] = y;
         }
     }
@@ -408,18 +418,136 @@ struct BwOpT {
 // the three weight-gradient GEMMs in one launch: column tiles [0, nx2) are layer 2, [nx2, nx2 + nx1) layer 1,
 // the rest the head layer (one row tile: out_dim <= 4 rows).  Fewer launches per SGD step, a grid that covers the chip.
 template <bool VEC>
-__global__ void __launch_bounds__(256) gemm_bw_kernel(FusedArgs a, int K, int nx2, int nx1) {
+__global__ void __launch_bounds__(256) gemm_bw_kernel(FusedArgs a, int K, int nx2, int nx1, int ny) {
+    // blockIdx.x enumerates the output tiles of the three GEMMs: nx2 * ny of layer 2, nx1 * ny of layer 1, nx2 of the head
     const GemmSmem sm = gemm_smem();
-    const int G = a.groups, g = blockIdx.z % G, split = blockIdx.z / G, x = blockIdx.x;
-    if (x < nx2) gemm_tile<BwOpT<2>, VEC>(a, K, g, split, blockIdx.y * TM, x * TN, sm);
-    else if (x < nx2 + nx1) gemm_tile<BwOpT<1>, VEC>(a, K, g, split, blockIdx.y * TM, (x - nx2) * TN, sm);
-    else if (blockIdx.y == 0) gemm_tile<BwOpT<3>, VEC>(a, K, g, split, 0, (x - nx2 - nx1) * TN, sm);
+    const int G = a.groups, g = blockIdx.y % G, split = blockIdx.y / G;
+    int x = blockIdx.x;
+    if (x < nx2 * ny) { gemm_tile<BwOpT<2>, VEC>(a, K, g, split, (x / nx2) * TM, (x % nx2) * TN, sm); return; }
+    x -= nx2 * ny;
+    if (x < nx1 * ny) { gemm_tile<BwOpT<1>, VEC>(a, K, g, split, (x / nx1) * TM, (x % nx1) * TN, sm); return; }
+    x -= nx1 * ny;
+    gemm_tile<BwOpT<3>, VEC>(a, K, g, split, 0, x * TN, sm);
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // head + loss kernel: one workgroup per (16-row tile, net); 16 threads per row
 // ------------------------------------------------------------------------------------------------------------
 constexpr float kLog2Pi = 1.8378770664093453f;
+
+// loss terms of one row and their analytic gradient w.r.t. the head outputs: PPO surrogate / KL / entropy for the
+// policy net (algo_copo.py:311-424), the clipped value losses for the value nets, the two meta-gradient heads.
+// st: total, policy, vf_ego, kl, entropy, vf_nei, vf_glob, adv  (already weighted by wgt = w / denom)
+struct RowIn {            // the pack columns (and the KL coefficient) the loss terms of one row read
+    float act[2], logp, adv, dist[4], vpred, vtarget, klc;
+};
+
+// issued early (the loads are dependent on the row index and miss L2), consumed by head_row_terms much later
+__device__ __forceinline__ RowIn load_row_in(const FusedArgs& a, int g, int mode, bool policy, const float* pk) {
+    const copo_ppo_cfg& c = a.c;
+    RowIn ri;
+    ri.act[0] = ri.act[1] = ri.logp = ri.adv = ri.vpred = ri.vtarget = ri.klc = 0.0f;
+    ri.dist[0] = ri.dist[1] = ri.dist[2] = ri.dist[3] = 0.0f;
+    if (policy) {
+        ri.act[0] = pk[c.col_actions];
+        ri.act[1] = pk[c.col_actions + 1];
+        if (mode != COPO_HEAD_META_OLD) {
+            ri.adv = pk[mode == COPO_HEAD_META_NEW ? c.col_meta_adv : c.col_adv];
+            ri.logp = pk[c.col_logp];
+            if (mode == COPO_HEAD_PPO && c.use_kl) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ri.dist[j] = pk[c.col_dist + j];
+                ri.klc = a.kl_coeff[0];
+            }
+        }
+    } else {
+        ri.vpred = pk[c.col_vpred[g - 1]];
+        ri.vtarget = pk[c.col_vtarget[g - 1]];
+    }
+    return ri;
+}
+
+__device__ __forceinline__ void head_row_terms(const FusedArgs& a, int g, int mode, bool policy, const RowIn& ri, float wgt,
+                                               const float* out, float* dout, float* st) {
+    const copo_ppo_cfg& c = a.c;
+            if (policy) {
+                const int A = c.act_dim;     // A == 2
+                float logp = 0.f, ent = 0.f, kl = 0.f, z[2], sig[2];
+    #pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float mu = out[j], ls = out[A + j];
+                    sig[j] = expf(ls);
+                    z[j] = (ri.act[j] - mu) / sig[j];
+                    logp += -0.5f * z[j] * z[j] - ls - 0.5f * kLog2Pi;
+                    ent += ls + 0.5f + 0.5f * kLog2Pi;
+                }
+                if (mode == COPO_HEAD_META_OLD) {       // loss = mean(logp) on the target net
+                    st[0] = st[1] = wgt * logp;
+    #pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        dout[j] = wgt * z[j] / sig[j];
+                        dout[A + j] = wgt * (z[j] * z[j] - 1.0f);
+                    }
+                } else {
+                    const float adv = ri.adv;
+                    const float ratio = expf(logp - ri.logp);
+                    const float s1 = adv * ratio;
+                    const float rc = fminf(fmaxf(ratio, 1.0f - c.clip_param), 1.0f + c.clip_param);
+                    const float s2 = adv * rc;
+                    const float surr = fminf(s1, s2);
+                    const bool inside = (ratio >= 1.0f - c.clip_param) && (ratio <= 1.0f + c.clip_param);
+                    const float dsurr_dratio = (inside || s1 < s2) ? adv : 0.0f;
+                    const float dlogp = -dsurr_dratio * ratio;      // d(-surr)/d logp
+                    float dmu[2] = {0.f, 0.f}, dls[2] = {0.f, 0.f};
+                    const bool ppo = mode == COPO_HEAD_PPO;
+                    if (ppo && c.use_kl) {
+    #pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const float mup = ri.dist[j], lsp = ri.dist[A + j];
+                            const float sp = expf(lsp), dm = mup - out[j];
+                            const float q = (sp * sp + dm * dm) / (sig[j] * sig[j]);
+                            kl += out[A + j] - lsp + 0.5f * q - 0.5f;
+                            dmu[j] += ri.klc * (-dm / (sig[j] * sig[j]));
+                            dls[j] += ri.klc * (1.0f - q);
+                        }
+                    }
+    #pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        dmu[j] += dlogp * z[j] / sig[j];
+                        dls[j] += dlogp * (z[j] * z[j] - 1.0f);
+                        if (ppo) dls[j] += -c.entropy_coeff;
+                        dout[j] = wgt * dmu[j];
+                        dout[A + j] = wgt * dls[j];
+                    }
+                    st[1] = wgt * (-surr);
+                    st[3] = wgt * kl;
+                    st[4] = wgt * ent;
+                    st[0] = st[1] + (ppo ? ((c.use_kl ? ri.klc * st[3] : 0.0f) - c.entropy_coeff * st[4]) : 0.0f);
+                    st[7] = wgt * adv;
+                }
+            } else {
+                const float v = out[0];
+                const float vp = ri.vpred, T = ri.vtarget;
+                float l, dv;
+                if (c.old_value_loss) {
+                    const float d1 = v - T, l1 = d1 * d1;
+                    const float dc = fminf(fmaxf(v - vp, -c.vf_clip_param), c.vf_clip_param);
+                    const float d2 = vp + dc - T, l2 = d2 * d2;
+                    const bool pass = (v - vp >= -c.vf_clip_param) && (v - vp <= c.vf_clip_param);
+                    l = fmaxf(l1, l2);
+                    if (l1 > l2) dv = 2.0f * d1;
+                    else if (l2 > l1) dv = pass ? 2.0f * d2 : 0.0f;
+                    else dv = d1 + (pass ? d2 : 0.0f);
+                } else {
+                    const float d1 = v - T, l1 = d1 * d1;
+                    l = fminf(fmaxf(l1, 0.0f), c.vf_clip_param);
+                    dv = (l1 >= 0.0f && l1 <= c.vf_clip_param) ? 2.0f * d1 : 0.0f;
+                }
+                dout[0] = wgt * c.vf_loss_coeff * dv;
+                st[0] = wgt * c.vf_loss_coeff * l;
+                st[g == 1 ? 2 : (g == 2 ? 5 : 6)] = wgt * l;
+            }
+}
 
 __global__ void __launch_bounds__(256) head_kernel(FusedArgs a) {
     extern __shared__ float lds[];
@@ -471,85 +599,7 @@ __global__ void __launch_bounds__(256) head_kernel(FusedArgs a) {
     // per-row loss terms and d(loss)/d(out)
     float st[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // total, policy, vf_ego, kl, entropy, vf_nei, vf_glob, adv
     float dout[4] = {0.f, 0.f, 0.f, 0.f};
-    if (part == 0 && rok) {
-        if (policy) {
-            const int A = c.act_dim;     // A == 2
-            float logp = 0.f, ent = 0.f, kl = 0.f, z[2], sig[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const float mu = out[j], ls = out[A + j];
-                sig[j] = expf(ls);
-                z[j] = (pk[c.col_actions + j] - mu) / sig[j];
-                logp += -0.5f * z[j] * z[j] - ls - 0.5f * kLog2Pi;
-                ent += ls + 0.5f + 0.5f * kLog2Pi;
-            }
-            if (mode == COPO_HEAD_META_OLD) {       // loss = mean(logp) on the target net
-                st[0] = st[1] = wgt * logp;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    dout[j] = wgt * z[j] / sig[j];
-                    dout[A + j] = wgt * (z[j] * z[j] - 1.0f);
-                }
-            } else {
-                const float adv = pk[mode == COPO_HEAD_META_NEW ? c.col_meta_adv : c.col_adv];
-                const float ratio = expf(logp - pk[c.col_logp]);
-                const float s1 = adv * ratio;
-                const float rc = fminf(fmaxf(ratio, 1.0f - c.clip_param), 1.0f + c.clip_param);
-                const float s2 = adv * rc;
-                const float surr = fminf(s1, s2);
-                const bool inside = (ratio >= 1.0f - c.clip_param) && (ratio <= 1.0f + c.clip_param);
-                const float dsurr_dratio = (inside || s1 < s2) ? adv : 0.0f;
-                const float dlogp = -dsurr_dratio * ratio;      // d(-surr)/d logp
-                float dmu[2] = {0.f, 0.f}, dls[2] = {0.f, 0.f};
-                const bool ppo = mode == COPO_HEAD_PPO;
-                if (ppo && c.use_kl) {
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const float mup = pk[c.col_dist + j], lsp = pk[c.col_dist + A + j];
-                        const float sp = expf(lsp), dm = mup - out[j];
-                        const float q = (sp * sp + dm * dm) / (sig[j] * sig[j]);
-                        kl += out[A + j] - lsp + 0.5f * q - 0.5f;
-                        dmu[j] += a.kl_coeff[0] * (-dm / (sig[j] * sig[j]));
-                        dls[j] += a.kl_coeff[0] * (1.0f - q);
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    dmu[j] += dlogp * z[j] / sig[j];
-                    dls[j] += dlogp * (z[j] * z[j] - 1.0f);
-                    if (ppo) dls[j] += -c.entropy_coeff;
-                    dout[j] = wgt * dmu[j];
-                    dout[A + j] = wgt * dls[j];
-                }
-                st[1] = wgt * (-surr);
-                st[3] = wgt * kl;
-                st[4] = wgt * ent;
-                st[0] = st[1] + (ppo ? ((c.use_kl ? a.kl_coeff[0] * st[3] : 0.0f) - c.entropy_coeff * st[4]) : 0.0f);
-                st[7] = wgt * adv;
-            }
-        } else {
-            const float v = out[0];
-            const float vp = pk[c.col_vpred[g - 1]], T = pk[c.col_vtarget[g - 1]];
-            float l, dv;
-            if (c.old_value_loss) {
-                const float d1 = v - T, l1 = d1 * d1;
-                const float dc = fminf(fmaxf(v - vp, -c.vf_clip_param), c.vf_clip_param);
-                const float d2 = vp + dc - T, l2 = d2 * d2;
-                const bool pass = (v - vp >= -c.vf_clip_param) && (v - vp <= c.vf_clip_param);
-                l = fmaxf(l1, l2);
-                if (l1 > l2) dv = 2.0f * d1;
-                else if (l2 > l1) dv = pass ? 2.0f * d2 : 0.0f;
-                else dv = d1 + (pass ? d2 : 0.0f);
-            } else {
-                const float d1 = v - T, l1 = d1 * d1;
-                l = fminf(fmaxf(l1, 0.0f), c.vf_clip_param);
-                dv = (l1 >= 0.0f && l1 <= c.vf_clip_param) ? 2.0f * d1 : 0.0f;
-            }
-            dout[0] = wgt * c.vf_loss_coeff * dv;
-            st[0] = wgt * c.vf_loss_coeff * l;
-            st[g == 1 ? 2 : (g == 2 ? 5 : 6)] = wgt * l;
-        }
-    }
+    if (part == 0 && rok) head_row_terms(a, g, mode, policy, load_row_in(a, g, mode, policy, pk), wgt, out, dout, st);
     if (part == 0) {
         // d(loss)/d(outputs): to LDS for dz2 below and to the workspace for the head's weight-gradient GEMM
         *reinterpret_cast<float4*>(douts + r * 4) = make_float4(dout[0], dout[1], dout[2], dout[3]);
@@ -584,6 +634,315 @@ __global__ void __launch_bounds__(256) head_kernel(FusedArgs a) {
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// row pass: everything of an SGD step that is LOCAL TO A ROW of the minibatch -- both layer forwards, the heads
+// with the loss gradients, and the activation gradients back to layer 1 -- in one kernel, one workgroup per 16 rows
+// and net.  h1 / h2 / dz2 tiles stay in LDS between the phases; the weights stream from L2 straight into the MFMA
+// B operands (v_mfma_f32_16x16x4_f32: lane l supplies A[l & 15][k] and B[k][l & 15] with k = l >> 4, so lane group
+// l >> 4 owns one quarter of K and walks it with float4 loads).  Only the weight gradients (sums over rows)
+// need the second kernel.  Replaces F1, F2, H, B2x: an SGD step is then three launches.
+// ------------------------------------------------------------------------------------------------------------
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// acc[t] += A[16 x K] * W^T for the 16 output columns cb + 16 t + (l & 15); W rows are k-contiguous (forward).
+// K is walked in steps of 32: lane group j = l >> 4 takes k = 32 s + 8 j + {0..7}, so the four lane groups of a row
+// read one whole 128-byte line per step (every line of W is touched exactly once per workgroup).
+// The weights were rewritten by the previous kernel (Adam), so the first touch of every line misses the XCD's L2:
+// a ring of D steps of B operands is kept in flight (D x 8 x NT VGPRs) to cover that latency with MFMA work.
+// kp = K rounded up to a multiple of 32 D; As rows hold zeros beyond K, so the over-read of W is harmless.
+template <int NT, int D>
+__device__ __forceinline__ void rowgemm_fwd(const float* As, int astride, const float* W, int wstride, int kp, int cb, int ln,
+                                            int lj, v4f* acc) {
+    const float* arow = As + ln * astride + 8 * lj;
+    const float* wrow[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wrow[t] = W + (size_t)(cb + 16 * t + ln) * wstride + 8 * lj;
+    const int ns = kp >> 5;                    // multiple of D
+    v4f b[D][2][NT];
+#pragma unroll
+    for (int u = 0; u < D; ++u)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            b[u][0][t] = *reinterpret_cast<const v4f*>(wrow[t] + 32 * u);
+            b[u][1][t] = *reinterpret_cast<const v4f*>(wrow[t] + 32 * u + 4);
+        }
+    for (int s0 = 0; s0 < ns; s0 += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            const int s = s0 + u;
+            const float4 a0 = *reinterpret_cast<const float4*>(arow + 32 * s), a1 = *reinterpret_cast<const float4*>(arow + 32 * s + 4);
+            const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                // keep each quad one 128-bit register tuple: without this the optimiser splits the ring's float4
+                // loads into dword loads, and the 6-bit vmcnt counter saturates long before the ring is in flight
+                asm volatile("" : "+v"(b[u][0][t]), "+v"(b[u][1][t]));
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], b[u][e >> 2][t][e & 3], acc[t], 0, 0, 0);
+            }
+            const int sn = s + D < ns ? s + D : ns - 1;     // refill this slot (clamped: unconditional loads)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                b[u][0][t] = *reinterpret_cast<const v4f*>(wrow[t] + 32 * sn);
+                b[u][1][t] = *reinterpret_cast<const v4f*>(wrow[t] + 32 * sn + 4);
+            }
+        }
+    }
+}
+
+// acc[t] += A[16 x K] * W for output columns cb + NT (l & 15) + t; W is [K][wstride] (backward: W2 as stored).
+// Tile t of a wave holds the columns {cb + NT i + t}: a lane's NT tiles are NT adjacent columns, so its B values of one
+// k are one contiguous load (float4 for NT = 4) and 16 lanes read 16 NT contiguous floats.  Steps of 16 k (lane
+// group j takes k = 16 s + 4 j + {0..3}); ring of D steps in flight.
+template <int NT, int D>
+__device__ __forceinline__ void rowgemm_bwd(const float* As, int astride, const float* W, int wstride, int k, int cb, int ln,
+                                            int lj, v4f* acc) {
+    const float* arow = As + ln * astride + 4 * lj;
+    const float* wcol = W + (size_t)(4 * lj) * wstride + cb + NT * ln;
+    const int ns = k >> 4;                     // multiple of D
+    constexpr int NQ = NT % 4 == 0 ? NT / 4 : 0;
+    if constexpr (NQ > 0) {
+        v4f b[D][4][NQ];
+#pragma unroll
+        for (int u = 0; u < D; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) b[u][e][q] = *reinterpret_cast<const v4f*>(wcol + (size_t)(16 * u + e) * wstride + 4 * q);
+        for (int s0 = 0; s0 < ns; s0 += D) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                const int s = s0 + u;
+                const float4 a4 = *reinterpret_cast<const float4*>(arow + 16 * s);
+                const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) asm volatile("" : "+v"(b[u][e][q]));      // see rowgemm_fwd
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], b[u][e][t >> 2][t & 3], acc[t], 0, 0, 0);
+                const int sn = s + D < ns ? s + D : ns - 1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) b[u][e][q] = *reinterpret_cast<const v4f*>(wcol + (size_t)(16 * sn + e) * wstride + 4 * q);
+            }
+        }
+    } else {
+        float b[D][4][NT];
+#pragma unroll
+        for (int u = 0; u < D; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) b[u][e][t] = wcol[(size_t)(16 * u + e) * wstride + t];
+        for (int s0 = 0; s0 < ns; s0 += D) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                const int s = s0 + u;
+                const float4 a4 = *reinterpret_cast<const float4*>(arow + 16 * s);
+                const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], b[u][e][t], acc[t], 0, 0, 0);
+                const int sn = s + D < ns ? s + D : ns - 1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) b[u][e][t] = wcol[(size_t)(16 * sn + e) * wstride + t];
+            }
+        }
+    }
+}
+
+constexpr int RP_D1 = 4;      // prefetch ring depth of the layer-1 GEMM (its K is padded to 32 * RP_D1)
+__device__ __host__ inline int rowpass_k1p(int in_dim) { return (in_dim + 32 * RP_D1 - 1) / (32 * RP_D1) * (32 * RP_D1); }
+__device__ __host__ inline size_t rowpass_lds_floats(int H, int k1p) {
+    return (size_t)HT * (k1p + 4) + (size_t)3 * HT * (H + 4) + 4 * H + HT * 4 + HT * 8;
+}
+
+__device__ unsigned long long g_rp_stamps[16];
+#define RP_STAMP(i) do { if ((a.dbg & 256) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_rp_stamps[i] = wall_clock64(); } while (0)
+
+// hidden = 16 * NT * WAVES: every wave owns NT column tiles of 16.  Two waves per SIMD (WAVES = 8) overlap one
+// wave's epilogue / load stalls with the other's MFMAs; the MFMA work per SIMD is the same.
+template <int NT, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) rowpass_kernel(FusedArgs a) {
+    extern __shared__ float4 rowpass_lds[];
+    constexpr int H = 16 * NT * WAVES, HP = H + 4, TH = 64 * WAVES, TPR = TH / HT;      // TPR: threads per row (heads)
+    constexpr int DF = NT >= 8 ? 2 : 4, DF2 = H / 32 < DF ? H / 32 : DF;                // prefetch ring depths
+    constexpr int DB = NT >= 8 ? 4 : (H / 16 >= 8 ? 8 : H / 16);
+    static_assert(H % (32 * DF2) == 0 && (H / 16) % DB == 0, "ring depths must divide the step counts");
+    const copo_ppo_cfg& c = a.c;
+    const int g = blockIdx.y, tile = blockIdx.x, m0 = tile * HT;
+    const copo_net_layout L = net_of(a, g);
+    const float* theta = theta_of(a, g);
+    const int mode = mode_of(a, g);
+    const bool policy = is_policy(a, g);
+    const int K1 = L.in_dim, OD = L.out_dim, K1P = rowpass_k1p(K1), XP = K1P + 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 15, lj = lane >> 4, cb = wave * (16 * NT);
+    float* xs = reinterpret_cast<float*>(rowpass_lds);      // [HT][XP]   gathered input rows, zero beyond K1
+    float* h1s = xs + HT * XP;                               // [HT][HP]
+    float* h2s = h1s + HT * HP;                              // [HT][HP]
+    float* dzs = h2s + HT * HP;                              // [HT][HP]   dz2
+    float* w3s = dzs + HT * HP;                              // [4][H]
+    float* douts = w3s + 4 * H;                              // [HT][4]
+    float* sts = douts + HT * 4;                             // [HT][8]    per-row loss statistics
+    // the first kernel of an SGD step advances the Adam step counter (its only reader is the fold at the end)
+    if (a.apply_adam && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) const_cast<int64_t*>(a.step)[0] += 1;
+    RP_STAMP(0);
+    const int64_t kb = kb_of(a, g);
+    // head bookkeeping: TPR threads per row; the dependent loads (k -> row index -> pack row) are issued here and
+    // consumed after both layers
+    const int r = tid / TPR, part = tid % TPR, m = m0 + r;
+    const bool rok = m < c.mb;
+    float wgt = 0.0f;
+    RowIn ri;
+    if (part == 0) {
+        const int64_t prow = a.rows[kb * c.mb + (rok ? m : 0)];
+        wgt = rok ? a.w[kb * c.mb + m] / a.denom[kb] : 0.0f;
+        ri = load_row_in(a, g, mode, policy, a.pack_src + (size_t)prow * c.pack_width);
+    }
+    {   // input tile: rows gathered through the minibatch table, float4 per thread, zeros beyond K1 / mb
+        const float* src = src_of(a, g);
+        const int qn = K1P >> 2;
+        for (int i = tid; i < HT * qn; i += TH) {
+            const int row = i / qn, k = (i - row * qn) * 4;
+            const bool ok = (m0 + row < c.mb) && (k < K1);
+            const int64_t ridx = a.rows[kb * c.mb + (m0 + row < c.mb ? m0 + row : 0)];
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)ridx * K1 + (k < K1 ? k : 0));
+            *reinterpret_cast<float4*>(xs + row * XP + k) = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        for (int i = tid; i < OD * H; i += TH) w3s[i] = theta[L.w3 + i];
+    }
+    __syncthreads();
+    RP_STAMP(1);
+    v4f acc[NT];
+    // ---- layer 1 ----
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
+    if (!(a.dbg & 1)) rowgemm_fwd<NT, DF>(xs, XP, theta + L.w1, K1, K1P, cb, ln, lj, acc);
+    {
+        float* h1g = a.ws + ws_h1(a, g);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int col = cb + 16 * t + ln;
+            const float bv = theta[L.b1 + col];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int i = 4 * lj + rr;
+                const float y = tanh_fast(acc[t][rr] + bv);
+                h1s[i * HP + col] = y;
+                if (m0 + i < c.mb) h1g[(size_t)(m0 + i) * H + col] = y;
+            }
+        }
+    }
+    __syncthreads();
+    RP_STAMP(2);
+    // ---- layer 2 ----
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
+    if (!(a.dbg & 2)) rowgemm_fwd<NT, DF2>(h1s, HP, theta + L.w2, H, H, cb, ln, lj, acc);
+    {
+        float* h2g = a.ws + ws_h2(a, g);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int col = cb + 16 * t + ln;
+            const float bv = theta[L.b2 + col];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int i = 4 * lj + rr;
+                const float y = tanh_fast(acc[t][rr] + bv);
+                h2s[i * HP + col] = y;
+                if (m0 + i < c.mb) h2g[(size_t)(m0 + i) * H + col] = y;
+            }
+        }
+    }
+    __syncthreads();
+    RP_STAMP(3);
+    // ---- heads, loss terms, d(loss)/d(outputs) ----
+    float out[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = part; i < H; i += TPR) {
+        const float h = h2s[r * HP + i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < OD) out[j] += h * w3s[j * H + i];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) out[j] += __shfl_xor(out[j], o);
+    }
+    if (part == 0) {
+        float st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        float dout[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[j] += theta[L.b3 + (j < OD ? j : 0)];
+        if (rok && !(a.dbg & 8)) head_row_terms(a, g, mode, policy, ri, wgt, out, dout, st);
+        *reinterpret_cast<float4*>(douts + r * 4) = make_float4(dout[0], dout[1], dout[2], dout[3]);
+        if (rok) *reinterpret_cast<float4*>(a.ws + ws_dout(a, g) + (size_t)m * 4) = make_float4(dout[0], dout[1], dout[2], dout[3]);
+        *reinterpret_cast<float4*>(sts + r * 8) = make_float4(st[0], st[1], st[2], st[3]);
+        *reinterpret_cast<float4*>(sts + r * 8 + 4) = make_float4(st[4], st[5], st[6], st[7]);
+    }
+    __syncthreads();
+    RP_STAMP(4);
+    if (tid < 8) {       // per-tile partial of the statistics, rows in a fixed order
+        float sv = 0.0f;
+#pragma unroll
+        for (int rr = 0; rr < HT; ++rr) sv += sts[rr * 8 + tid];
+        a.ws[ws_stats_at(a, g * head_tiles(c) + tile) + tid] = sv;
+    }
+    // ---- dz2 = (dout W3) * (1 - h2^2) ----
+    {
+        float* dz2g = a.ws + ws_dz2(a, g);
+        const int nr = (c.mb - m0 < HT) ? c.mb - m0 : HT;
+        for (int i = tid; i < H; i += TH) {
+            float wc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wc[j] = (j < OD) ? w3s[j * H + i] : 0.0f;
+#pragma unroll
+            for (int rr = 0; rr < HT; ++rr) {
+                const float4 d = *reinterpret_cast<const float4*>(douts + rr * 4);
+                const float h = h2s[rr * HP + i];
+                const float v = ((d.x * wc[0] + d.y * wc[1]) + (d.z * wc[2] + d.w * wc[3])) * (1.0f - h * h);
+                dzs[rr * HP + i] = v;
+                if (rr < nr) dz2g[(size_t)(m0 + rr) * H + i] = v;
+            }
+        }
+    }
+    __syncthreads();
+    RP_STAMP(5);
+    // ---- dz1 = (dz2 W2) * (1 - h1^2) ----
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
+    if (!(a.dbg & 4)) rowgemm_bwd<NT, DB>(dzs, HP, theta + L.w2, H, H, cb, ln, lj, acc);
+    {
+        float* dz1g = a.ws + ws_dz1(a, g);
+        // tile t of rowgemm_bwd holds the columns cb + NT * ln + t: a lane stores NT adjacent columns per row
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int i = 4 * lj + rr;
+            if (m0 + i < c.mb) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int col = cb + NT * ln + t;
+                    const float h = h1s[i * HP + col];
+                    dz1g[(size_t)(m0 + i) * H + col] = acc[t][rr] * (1.0f - h * h);
+                }
+            }
+        }
+    }
+    RP_STAMP(9);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1065,12 +1424,21 @@ static hipError_t gemm_lds_attrs() {
         COPO_ATTR((gemm_kernel<BxOp, true>)); COPO_ATTR((gemm_kernel<BxOp, false>));
         COPO_ATTR((gemm_bw_kernel<true>)); COPO_ATTR((gemm_bw_kernel<false>));
 #undef COPO_ATTR
+        for (const void* f : {reinterpret_cast<const void*>(rowpass_kernel<1, 4>), reinterpret_cast<const void*>(rowpass_kernel<2, 4>),
+                              reinterpret_cast<const void*>(rowpass_kernel<2, 8>), reinterpret_cast<const void*>(rowpass_kernel<4, 8>)})
+            if ((r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) != hipSuccess) e = r;
         return e;
     }();
     return once;
 }
 
 struct MetaBatch { int nb; float* g_out; double* dot_out; float* stats_out; };
+
+// COPO_FUSED_ROWPASS=0 keeps the four-kernel activation path (A/B measurements, tests of both paths)
+static const bool g_use_rowpass = [] {
+    const char* e = getenv("COPO_FUSED_ROWPASS");
+    return !(e && e[0] == '0');
+}();
 
 // [lo, lo + n): the span of the flat parameter buffer that the first `nets` networks of the layout occupy
 static void fold_range(const copo_ppo_cfg& c, int nets_n, int64_t* lo_out, int* n_out) {
@@ -1093,7 +1461,8 @@ hipError_t launch_fused_step(FusedArgs a, hipStream_t s, const MetaTail* mt_ = n
                              int* fold_blocks_out = nullptr, int* n_fold_out = nullptr) {
     const copo_ppo_cfg& c = a.c;
     if (hipError_t e = gemm_lds_attrs(); e != hipSuccess) return e;
-    a.ksplit = mbatch ? 1 : pick_ksplit(c.mb);     // a batched pass fills the chip without splitting rows
+    a.ksplit = mbatch ? 1 : pick_ksplit(c.mb);
+    { static const int dbg = [] { const char* e = getenv("COPO_RP_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }     // a batched pass fills the chip without splitting rows
     const int G = a.groups, mt = (c.mb + TM - 1) / TM, ht = (c.hidden + TN - 1) / TN;
     int kmax1 = c.pol.in_dim;
     if (a.head_mode == COPO_HEAD_PPO)
@@ -1110,17 +1479,33 @@ hipError_t launch_fused_step(FusedArgs a, hipStream_t s, const MetaTail* mt_ = n
         if (vec) hipLaunchKernelGGL((gemm_kernel<OP, true>), grid, dim3(256), GEMM_LDS_BYTES, s, a, K);   \
         else hipLaunchKernelGGL((gemm_kernel<OP, false>), grid, dim3(256), GEMM_LDS_BYTES, s, a, K);      \
     } while (0)
-    COPO_GEMM(FwdOpT<1>, dim3(ht, mt, G), f1, kmax1);
-    COPO_GEMM(FwdOpT<2>, dim3(ht, mt, G), f2, c.hidden);
-    const size_t lds = (size_t)(HT * (c.hidden + 1) + 4 * c.hidden + HT * 4 + 32) * sizeof(float);
-    hipLaunchKernelGGL(head_kernel, dim3(head_tiles(c), G), dim3(256), lds, s, a);
-    COPO_GEMM(BxOp, dim3(ht, mt, G), bx, c.hidden);
+    // row pass (one kernel for F1, F2, heads, B2x) when the shapes allow it; else the four separate kernels
+    // shapes with a row-pass instantiation: hidden = 16 * NT * WAVES
+    const int rp_h = c.hidden;
+    const size_t rp_lds = rowpass_lds_floats(c.hidden, rowpass_k1p(kmax1)) * sizeof(float);
+    const bool rowpass = vec && !mbatch && g_use_rowpass && (rp_h == 64 || rp_h == 128 || rp_h == 256 || rp_h == 512) &&
+                         rp_lds <= 150 * 1024;
+    if (rowpass) {
+        const dim3 grid(head_tiles(c), G);
+        switch (rp_h) {
+            case 64: hipLaunchKernelGGL((rowpass_kernel<1, 4>), grid, dim3(256), rp_lds, s, a); break;
+            case 128: hipLaunchKernelGGL((rowpass_kernel<2, 4>), grid, dim3(256), rp_lds, s, a); break;
+            case 256: hipLaunchKernelGGL((rowpass_kernel<2, 8>), grid, dim3(512), rp_lds, s, a); break;
+            default: hipLaunchKernelGGL((rowpass_kernel<4, 8>), grid, dim3(512), rp_lds, s, a); break;
+        }
+    } else {
+        COPO_GEMM(FwdOpT<1>, dim3(ht, mt, G), f1, kmax1);
+        COPO_GEMM(FwdOpT<2>, dim3(ht, mt, G), f2, c.hidden);
+        const size_t lds = (size_t)(HT * (c.hidden + 1) + 4 * c.hidden + HT * 4 + 32) * sizeof(float);
+        hipLaunchKernelGGL(head_kernel, dim3(head_tiles(c), G), dim3(256), lds, s, a);
+        COPO_GEMM(BxOp, dim3(ht, mt, G), bx, c.hidden);
+    }
 #undef COPO_GEMM
     {
         const int nx2 = (c.hidden + 1 + TN - 1) / TN, nx1 = (kmax1 + 1 + TN - 1) / TN;
-        const dim3 grid(nx2 + nx1 + nx2, ht, G * a.ksplit);
-        if (vec) hipLaunchKernelGGL((gemm_bw_kernel<true>), grid, dim3(256), GEMM_LDS_BYTES, s, a, c.mb, nx2, nx1);
-        else hipLaunchKernelGGL((gemm_bw_kernel<false>), grid, dim3(256), GEMM_LDS_BYTES, s, a, c.mb, nx2, nx1);
+        const dim3 grid((nx2 + nx1) * ht + nx2, G * a.ksplit);
+        if (vec) hipLaunchKernelGGL((gemm_bw_kernel<true>), grid, dim3(256), GEMM_LDS_BYTES, s, a, c.mb, nx2, nx1, ht);
+        else hipLaunchKernelGGL((gemm_bw_kernel<false>), grid, dim3(256), GEMM_LDS_BYTES, s, a, c.mb, nx2, nx1, ht);
     }
     // parameter range the fold covers: every net of this call (the policy only in the meta modes)
     int64_t lo;
@@ -1155,6 +1540,10 @@ hipError_t launch_adam_flat(const FusedArgs& a, long long n, hipStream_t s) {
 
 // ---- C ABI ---------------------------------------------------------------------------------------------------
 using namespace copo;
+
+extern "C" int copo_debug_rowpass_stamps(unsigned long long* out16) {
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(copo::g_rp_stamps), 16 * sizeof(unsigned long long)) == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
+}
 
 extern "C" int64_t copo_ppo_workspace_floats(const copo_ppo_cfg* cfg) { return cfg ? (int64_t)fused_ws_floats(*cfg) : -1; }
 

@@ -27,3 +27,16 @@ e1.record()
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 print("fused sgd step: %.1f us gpu, %.1f us host enqueue" % (e0.elapsed_time(e1) * 1e3 / n, (t1 - t0) * 1e6 / n))
+if int(os.environ.get("COPO_RP_DBG", "0")) & 256:
+    import ctypes as C
+    from copo_amd import _capi
+    buf = (C.c_ulonglong * 16)()
+    _capi.lib.copo_debug_rowpass_stamps.argtypes = [C.c_void_p]
+    _capi.lib.copo_debug_rowpass_stamps(buf)
+    t = list(buf)
+    names = ["prologue(loads X,w3)", "F1+tanh", "F2+tanh", "head+loss+stats", "dz2", "Bx+epilogue"]
+    idx = [0, 1, 2, 3, 4, 5, 9]
+    print("rowpass phases of workgroup (0,0), 100 MHz wall clock:")
+    for i, nme in enumerate(names):
+        print("  %-22s %6.2f us" % (nme, (t[idx[i + 1]] - t[idx[i]]) / 100.0))
+    print("  total                  %6.2f us" % ((t[9] - t[0]) / 100.0))
