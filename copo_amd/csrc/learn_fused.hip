@@ -75,6 +75,10 @@ __device__ __forceinline__ bool second(const FusedArgs& a, int g) { return both(
 __device__ __forceinline__ int64_t kb_of(const FusedArgs& a, int g) {
     return (a.kptr ? a.kptr[0] : 0) + a.k_first + (both(a) ? (g >> 1) : 0);
 }
+// The minibatch index is advanced without any grid-wide synchronisation: the first kernel of a step reads k = *kptr and
+// one of its workgroups publishes k + 1 in a workspace slot that kernel never reads; the weight-gradient kernel reads
+// that slot (minus one) and one of its workgroups copies it back to *kptr, which that kernel never reads.
+__device__ __forceinline__ int64_t* knext_slot(const FusedArgs& a);
 __device__ __forceinline__ const copo_net_layout& net_of(const FusedArgs& a, int g) {
     return (g == 0 || both(a)) ? a.c.pol : a.c.val[g - 1];
 }
@@ -107,7 +111,7 @@ struct WsLay {
     }
     __device__ __host__ size_t stats(int q) const { return split(nreg, 0) + (size_t)q * 8; }               // [g * tiles + tile][8]
     __device__ __host__ size_t counter() const { return stats(gcap * tiles); }
-    __device__ __host__ size_t total() const { return counter() + 4; }
+    __device__ __host__ size_t total() const { return counter() + 8; }
 };
 __device__ __forceinline__ WsLay lay(const FusedArgs& a) { return WsLay(a.c, a.gcap, a.nreg); }
 __device__ __forceinline__ size_t ws_h1(const FusedArgs& a, int g) { return lay(a).h1(g); }
@@ -118,6 +122,14 @@ __device__ __forceinline__ size_t ws_dout(const FusedArgs& a, int g) { return la
 __device__ __forceinline__ size_t ws_split(const FusedArgs& a, int region, int sp) { return lay(a).split(region, sp); }
 __device__ __forceinline__ size_t ws_stats_at(const FusedArgs& a, int q) { return lay(a).stats(q); }
 __device__ __forceinline__ size_t ws_counter_at(const FusedArgs& a) { return lay(a).counter(); }
+__device__ __forceinline__ int64_t* knext_slot(const FusedArgs& a) {
+    return reinterpret_cast<int64_t*>(a.ws + ((ws_counter_at(a) + 2 + 1) & ~(size_t)1));      // 8-byte aligned, after the counter
+}
+// duties of the first kernel of a step (one thread): advance the Adam step counter, publish the next minibatch index
+__device__ __forceinline__ void first_kernel_duties(const FusedArgs& a) {
+    if (a.apply_adam) const_cast<int64_t*>(a.step)[0] += 1;
+    knext_slot(a)[0] = (a.kptr ? a.kptr[0] : 0) + 1;
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // generic 64x64 tile GEMM:  C[m][n] = sum_k A(m,k) * B(k,n), K staged through LDS in slabs of 32.
@@ -276,8 +288,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(FusedArgs a, int K) {
     const GemmSmem sm = gemm_smem();
     const int G = a.groups;
     // the first kernel of an SGD step advances the Adam step counter (its only reader is the fold at the end)
-    if (Op::FIRST && a.apply_adam && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
-        const_cast<int64_t*>(a.step)[0] += 1;
+    if (Op::FIRST && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) first_kernel_duties(a);
     gemm_tile<Op, VEC>(a, K, blockIdx.z % G, blockIdx.z / G, blockIdx.y * TM, blockIdx.x * TN, sm);
 }
 
@@ -799,7 +810,7 @@ __global__ void __launch_bounds__(64 * WAVES) rowpass_kernel(FusedArgs a) {
     float* douts = w3s + 4 * H;                              // [HT][4]
     float* sts = douts + HT * 4;                             // [HT][8]    per-row loss statistics
     // the first kernel of an SGD step advances the Adam step counter (its only reader is the fold at the end)
-    if (a.apply_adam && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) const_cast<int64_t*>(a.step)[0] += 1;
+    if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) first_kernel_duties(a);
     RP_STAMP(0);
     const int64_t kb = kb_of(a, g);
     // head bookkeeping: TPR threads per row; the dependent loads (k -> row index -> pack row) are issued here and
@@ -1375,6 +1386,149 @@ __global__ void __launch_bounds__(512) meta_seq_kernel(MetaSeqArgs a) {
     if (tid < 7 && a.stats) a.stats[tid] += ST[tid];
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// weight gradients + Adam in one kernel (PPO / single-head modes).  One workgroup per 32 x 32 tile of dW of one
+// layer and net; the minibatch rows (the K of these GEMMs) are split over the four waves INSIDE the workgroup, so the
+// partial sums meet in LDS, are added in a fixed order, and the same threads apply Adam (or store the gradient):
+// no partial-sum round trip through memory, no separate fold launch.  Operands stream straight from L2 into the
+// MFMA registers -- lane l of v_mfma_f32_32x32x2_f32 supplies dz[m][o0 + (l & 31)] and [In | 1][m][i0 + (l & 31)] for
+// m = k + (l >> 5): 32 lanes read 128 contiguous bytes, nothing is shared between waves, so LDS staging would buy
+// nothing.  Workgroup (0, 0) also folds the loss statistics and hands over the next minibatch index.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int WG_WAVES = 8;       // waves per workgroup = row splits of K inside the workgroup
+constexpr int WG_RING = 32;       // k-pairs of operands in flight per wave (2 loads each: the vmcnt limit)
+constexpr int WG_EPT = 1024 / (64 * WG_WAVES);     // tile elements per thread in the epilogue
+
+__global__ void __launch_bounds__(64 * WG_WAVES) wgrad_adam_kernel(FusedArgs a, int nty, int nx2, int nx1) {
+    __shared__ float red[WG_WAVES][32][33];
+    __shared__ int32_t srow[COPO_PPO_MAX_MB];
+    constexpr int TH = 64 * WG_WAVES;
+    const copo_ppo_cfg& c = a.c;
+    const int g = blockIdx.y, H = c.hidden;
+    const copo_net_layout L = net_of(a, g);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    // tile decode: nx2 * nty tiles of layer 2, nx1 * nty of layer 1, nx2 of the head layer
+    int x = blockIdx.x, layer, o0, i0;
+    if (x < nx2 * nty) { layer = 2; o0 = (x / nx2) * 32; i0 = (x % nx2) * 32; }
+    else if ((x -= nx2 * nty) < nx1 * nty) { layer = 1; o0 = (x / nx1) * 32; i0 = (x % nx1) * 32; }
+    else { x -= nx1 * nty; layer = 3; o0 = 0; i0 = x * 32; }
+    const int K = layer == 1 ? L.in_dim : H;                 // input width; column K of the tile space is the bias
+    const int M = layer == 3 ? L.out_dim : H;                // output rows
+    const int astr = layer == 3 ? 4 : H;
+    const float* dz = a.ws + (layer == 1 ? ws_dz1(a, g) : (layer == 2 ? ws_dz2(a, g) : ws_dout(a, g)));
+    const float* in = layer == 1 ? src_of(a, g) : a.ws + (layer == 2 ? ws_h1(a, g) : ws_h2(a, g));
+    const int64_t woff = layer == 1 ? L.w1 : (layer == 2 ? L.w2 : L.w3), boff = layer == 1 ? L.b1 : (layer == 2 ? L.b2 : L.b3);
+    const bool tile_live = i0 <= K;                          // layer-1 tiles beyond this net's own input width do nothing
+    // Adam state of this thread's elements, requested before anything else (consumed after the GEMM)
+    constexpr int TPRW = 32 / WG_EPT;                        // threads per tile row
+    const int ero = tid / TPRW, erc = (tid % TPRW) * WG_EPT;
+    const int eo = o0 + ero, ei = i0 + erc;
+    size_t eidx[WG_EPT];
+    bool eok[WG_EPT];
+    float em[WG_EPT], ev[WG_EPT], eth[WG_EPT];
+    const bool adam = a.apply_adam != 0;
+#pragma unroll
+    for (int q = 0; q < WG_EPT; ++q) {
+        const int i = ei + q;
+        eok[q] = tile_live && eo < M && i <= K;
+        eidx[q] = !eok[q] ? (size_t)woff : (i == K ? (size_t)boff + eo : (size_t)woff + (size_t)eo * K + i);
+        em[q] = adam ? a.adam_m[eidx[q]] : 0.0f;
+        ev[q] = adam ? a.adam_v[eidx[q]] : 0.0f;
+        eth[q] = adam ? a.theta[eidx[q]] : 0.0f;
+    }
+    const int64_t kb = knext_slot(a)[0] - 1 + a.k_first;      // published by the first kernel of this step
+    if (layer == 1) {
+        for (int i = tid; i < c.mb; i += TH) srow[i] = (int32_t)a.rows[kb * c.mb + i];
+        __syncthreads();
+    }
+    v16f acc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+    if (tile_live) {
+        // rows of this wave: [kbeg, kend), walked two at a time (lane half lh takes row k + lh)
+        const int chunk = (((c.mb + WG_WAVES - 1) / WG_WAVES) + 1) & ~1;
+        const int kbeg = wave * chunk, kend = (kbeg + chunk < c.mb) ? kbeg + chunk : c.mb;
+        const int ns = (kend - kbeg + 1) >> 1;               // k-pairs (may be <= 0)
+        const int ao = o0 + li, bi = i0 + li;
+        const bool a_col = ao < M, b_in = bi < K;
+        const float b_fill = bi == K ? 1.0f : 0.0f;          // the constant-1 bias column / zero padding
+        // running fetch state: fetch number f reads row kbeg + 2 f + lh (rows past kend re-read row kend - 1, masked at use)
+        const bool gather = layer == 1;
+        const int mlast = kend - 1;
+        int fm = kbeg + lh;
+        uint32_t fa = (uint32_t)fm * (uint32_t)astr + (a_col ? ao : 0);
+        uint32_t fb = (uint32_t)fm * (uint32_t)K + (b_in ? bi : 0);
+        const uint32_t fa_last = (uint32_t)mlast * (uint32_t)astr + (a_col ? ao : 0), fb_last = (uint32_t)mlast * (uint32_t)K + (b_in ? bi : 0);
+        const uint32_t bcol = b_in ? bi : 0;
+        float ra[WG_RING], rb[WG_RING];
+        bool rk[WG_RING];
+#define WG_FETCH(u)                                                                        \
+        do {                                                                              \
+            rk[u] = fm <= mlast;                                                          \
+            ra[u] = dz[rk[u] ? fa : fa_last];                                             \
+            rb[u] = in[gather ? (uint32_t)srow[rk[u] ? fm : mlast] * (uint32_t)K + bcol : (rk[u] ? fb : fb_last)]; \
+            fm += 2; fa += 2u * (uint32_t)astr; fb += 2u * (uint32_t)K;                   \
+        } while (0)
+        if (ns > 0) {
+#pragma unroll
+            for (int u = 0; u < WG_RING; ++u) WG_FETCH(u);
+            for (int s0 = 0; s0 < ns; s0 += WG_RING) {
+                const bool more = s0 + WG_RING < ns;         // uniform: only long row ranges loop
+#pragma unroll
+                for (int u = 0; u < WG_RING; ++u) {
+                    // masking happens at use: rows beyond the range / columns beyond the tensors contribute zero
+                    const float av = (rk[u] && a_col) ? ra[u] : 0.0f;
+                    const float bv = b_in ? rb[u] : b_fill;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+                    if (more) WG_FETCH(u);
+                }
+            }
+        }
+#undef WG_FETCH
+    }
+    // wave partials -> LDS; accumulator element j of this lane: row 8 (j / 4) + 4 lh + (j % 4), column li
+#pragma unroll
+    for (int j = 0; j < 16; ++j) red[wave][COPO_ACC_ROW(4 * lh, j)][li] = acc[j];
+    __shared__ float bcs[2];
+    if (tid == 0) {      // Adam bias corrections once per workgroup (two powf are ~200 instructions)
+        const float tt = adam ? (float)a.step[0] : 1.0f;     // advanced by the first kernel of this step
+        bcs[0] = 1.0f - powf(c.beta1, tt);
+        bcs[1] = sqrtf(1.0f - powf(c.beta2, tt));
+    }
+    __syncthreads();
+    {
+        const float bc1 = bcs[0], bc2s = bcs[1];
+#pragma unroll
+        for (int q = 0; q < WG_EPT; ++q) {
+            if (!eok[q]) continue;
+            float gsum = red[0][ero][erc + q];
+#pragma unroll
+            for (int w = 1; w < WG_WAVES; ++w) gsum += red[w][ero][erc + q];
+            if (adam) {
+                const float m = em[q] + (gsum - em[q]) * (1.0f - c.beta1);
+                const float v = ev[q] * c.beta2 + gsum * gsum * (1.0f - c.beta2);
+                a.adam_m[eidx[q]] = m;
+                a.adam_v[eidx[q]] = v;
+                a.theta[eidx[q]] = eth[q] - (c.lr / bc1) * (m / (sqrtf(v) / bc2s + c.eps));
+            } else {
+                a.grad[eidx[q]] = gsum;
+            }
+        }
+    }
+    // workgroup (0, 0) folds the per-tile loss statistics of the previous kernel in a fixed order and hands the next
+    // minibatch index back to *kptr (which no workgroup of this kernel reads)
+    if (blockIdx.x != 0 || blockIdx.y != 0) return;
+    const int tiles = head_tiles(c), nq = a.groups * tiles;
+    for (int k = wave; k < 8; k += WG_WAVES) {
+        float t0 = 0.0f;
+        for (int q = lane; q < nq; q += 64) t0 += a.ws[ws_stats_at(a, q) + k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t0 += __shfl_down(t0, o);
+        if (lane == 0 && a.stats) a.stats[k] += t0;
+    }
+    if (tid == 0 && a.bump_k && a.kptr) const_cast<int64_t*>(a.kptr)[0] = knext_slot(a)[0];
+}
+
 __global__ void bump_kernel(int64_t* step, int64_t* k) {
     if (step) step[0] += 1;
     if (k) k[0] += 1;
@@ -1435,6 +1589,10 @@ static hipError_t gemm_lds_attrs() {
 struct MetaBatch { int nb; float* g_out; double* dot_out; float* stats_out; };
 
 // COPO_FUSED_ROWPASS=0 keeps the four-kernel activation path (A/B measurements, tests of both paths)
+static const bool g_use_wgrad = [] {
+    const char* e = getenv("COPO_FUSED_WGRAD");
+    return !(e && e[0] == '0');
+}();
 static const bool g_use_rowpass = [] {
     const char* e = getenv("COPO_FUSED_ROWPASS");
     return !(e && e[0] == '0');
@@ -1501,6 +1659,12 @@ hipError_t launch_fused_step(FusedArgs a, hipStream_t s, const MetaTail* mt_ = n
         COPO_GEMM(BxOp, dim3(ht, mt, G), bx, c.hidden);
     }
 #undef COPO_GEMM
+    if (!mbatch && a.head_mode != MODE_META_BOTH && g_use_wgrad) {
+        // weight gradients, fold and Adam in one kernel: the SGD step ends here
+        const int nty = (c.hidden + 31) / 32, wx2 = (c.hidden + 1 + 31) / 32, wx1 = (kmax1 + 1 + 31) / 32;
+        hipLaunchKernelGGL(wgrad_adam_kernel, dim3((wx2 + wx1) * nty + wx2, G), dim3(64 * WG_WAVES), 0, s, a, nty, wx2, wx1);
+        return hipGetLastError();
+    }
     {
         const int nx2 = (c.hidden + 1 + TN - 1) / TN, nx1 = (kmax1 + 1 + TN - 1) / TN;
         const dim3 grid((nx2 + nx1) * ht + nx2, G * a.ksplit);
