@@ -41,6 +41,7 @@ struct FusedArgs {
     copo_ppo_cfg c;
     float* theta;
     float* theta2;             // META_BOTH: target-network parameters (group 1)
+    float* theta_t;            // optional mirror of theta with W1 / W2 of every net stored transposed ([in][out])
     float* adam_m;
     float* adam_v;
     float* grad;
@@ -711,67 +712,49 @@ __device__ __forceinline__ void rowgemm_fwd(const float* As, int astride, const 
 // Tile t of a wave holds the columns {cb + NT i + t}: a lane's NT tiles are NT adjacent columns, so its B values of one
 // k are one contiguous load (float4 for NT = 4) and 16 lanes read 16 NT contiguous floats.  Steps of 16 k (lane
 // group j takes k = 16 s + 4 j + {0..3}); ring of D steps in flight.
+typedef float v2f __attribute__((ext_vector_type(2)));
+template <int N> struct ColVec;                 // N adjacent columns of one k as one load
+template <> struct ColVec<1> { typedef float T; static __device__ __forceinline__ float get(const float& v, int) { return v; } };
+template <> struct ColVec<2> { typedef v2f T; static __device__ __forceinline__ float get(const v2f& v, int i) { return v[i]; } };
+template <> struct ColVec<4> { typedef v4f T; static __device__ __forceinline__ float get(const v4f& v, int i) { return v[i]; } };
+
 template <int NT, int D>
 __device__ __forceinline__ void rowgemm_bwd(const float* As, int astride, const float* W, int wstride, int k, int cb, int ln,
                                             int lj, v4f* acc) {
+    constexpr int VW = NT >= 4 ? 4 : NT, NV = NT / VW;     // vector width of a load, loads per k
+    typedef typename ColVec<VW>::T vec_t;
     const float* arow = As + ln * astride + 4 * lj;
     const float* wcol = W + (size_t)(4 * lj) * wstride + cb + NT * ln;
     const int ns = k >> 4;                     // multiple of D
-    constexpr int NQ = NT % 4 == 0 ? NT / 4 : 0;
-    if constexpr (NQ > 0) {
-        v4f b[D][4][NQ];
+    vec_t b[D][4][NV];
 #pragma unroll
-        for (int u = 0; u < D; ++u)
+    for (int u = 0; u < D; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int q = 0; q < NV; ++q) b[u][e][q] = *reinterpret_cast<const vec_t*>(wcol + (size_t)(16 * u + e) * wstride + VW * q);
+    for (int s0 = 0; s0 < ns; s0 += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            const int s = s0 + u;
+            const float4 a4 = *reinterpret_cast<const float4*>(arow + 16 * s);
+            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+            if constexpr (VW > 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int q = 0; q < NV; ++q) asm volatile("" : "+v"(b[u][e][q]));      // one register tuple per load (see rowgemm_fwd)
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) b[u][e][q] = *reinterpret_cast<const v4f*>(wcol + (size_t)(16 * u + e) * wstride + 4 * q);
-        for (int s0 = 0; s0 < ns; s0 += D) {
-#pragma unroll
-            for (int u = 0; u < D; ++u) {
-                const int s = s0 + u;
-                const float4 a4 = *reinterpret_cast<const float4*>(arow + 16 * s);
-                const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) asm volatile("" : "+v"(b[u][e][q]));      // see rowgemm_fwd
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], b[u][e][t >> 2][t & 3], acc[t], 0, 0, 0);
-                const int sn = s + D < ns ? s + D : ns - 1;
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) b[u][e][q] = *reinterpret_cast<const v4f*>(wcol + (size_t)(16 * sn + e) * wstride + 4 * q);
-            }
-        }
-    } else {
-        float b[D][4][NT];
-#pragma unroll
-        for (int u = 0; u < D; ++u)
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], ColVec<VW>::get(b[u][e][t / VW], t % VW), acc[t], 0, 0, 0);
+            const int sn = s + D < ns ? s + D : ns - 1;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) b[u][e][t] = wcol[(size_t)(16 * u + e) * wstride + t];
-        for (int s0 = 0; s0 < ns; s0 += D) {
-#pragma unroll
-            for (int u = 0; u < D; ++u) {
-                const int s = s0 + u;
-                const float4 a4 = *reinterpret_cast<const float4*>(arow + 16 * s);
-                const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], b[u][e][t], acc[t], 0, 0, 0);
-                const int sn = s + D < ns ? s + D : ns - 1;
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) b[u][e][t] = wcol[(size_t)(16 * sn + e) * wstride + t];
-            }
+                for (int q = 0; q < NV; ++q) b[u][e][q] = *reinterpret_cast<const vec_t*>(wcol + (size_t)(16 * sn + e) * wstride + VW * q);
         }
     }
 }
@@ -787,7 +770,9 @@ __device__ unsigned long long g_rp_stamps[16];
 
 // hidden = 16 * NT * WAVES: every wave owns NT column tiles of 16.  Two waves per SIMD (WAVES = 8) overlap one
 // wave's epilogue / load stalls with the other's MFMAs; the MFMA work per SIMD is the same.
-template <int NT, int WAVES>
+// TW: a.theta_t holds W1 / W2 transposed ([in][out]), so the forward B operands are read like the backward ones --
+// 16 lanes per 64 NT contiguous bytes -- instead of one row per lane (the strided pattern costs ~2x in the TA).
+template <int NT, int WAVES, bool TW>
 __global__ void __launch_bounds__(64 * WAVES) rowpass_kernel(FusedArgs a) {
     extern __shared__ float4 rowpass_lds[];
     constexpr int H = 16 * NT * WAVES, HP = H + 4, TH = 64 * WAVES, TPR = TH / HT;      // TPR: threads per row (heads)
@@ -842,12 +827,13 @@ __global__ void __launch_bounds__(64 * WAVES) rowpass_kernel(FusedArgs a) {
     // ---- layer 1 ----
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
-    if (!(a.dbg & 1)) rowgemm_fwd<NT, DF>(xs, XP, theta + L.w1, K1, K1P, cb, ln, lj, acc);
+    if (TW) rowgemm_bwd<NT, DB>(xs, XP, a.theta_t + L.w1, H, K1P, cb, ln, lj, acc);
+    else if (!(a.dbg & 1)) rowgemm_fwd<NT, DF>(xs, XP, theta + L.w1, K1, K1P, cb, ln, lj, acc);
     {
         float* h1g = a.ws + ws_h1(a, g);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int col = cb + 16 * t + ln;
+            const int col = TW ? cb + NT * ln + t : cb + 16 * t + ln;      // tile -> column map of the GEMM flavour used
             const float bv = theta[L.b1 + col];
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
@@ -863,12 +849,13 @@ __global__ void __launch_bounds__(64 * WAVES) rowpass_kernel(FusedArgs a) {
     // ---- layer 2 ----
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
-    if (!(a.dbg & 2)) rowgemm_fwd<NT, DF2>(h1s, HP, theta + L.w2, H, H, cb, ln, lj, acc);
+    if (TW) rowgemm_bwd<NT, DB>(h1s, HP, a.theta_t + L.w2, H, H, cb, ln, lj, acc);
+    else if (!(a.dbg & 2)) rowgemm_fwd<NT, DF2>(h1s, HP, theta + L.w2, H, H, cb, ln, lj, acc);
     {
         float* h2g = a.ws + ws_h2(a, g);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int col = cb + 16 * t + ln;
+            const int col = TW ? cb + NT * ln + t : cb + 16 * t + ln;
             const float bv = theta[L.b2 + col];
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
@@ -1509,10 +1496,28 @@ __global__ void __launch_bounds__(64 * WG_WAVES) wgrad_adam_kernel(FusedArgs a, 
                 const float v = ev[q] * c.beta2 + gsum * gsum * (1.0f - c.beta2);
                 a.adam_m[eidx[q]] = m;
                 a.adam_v[eidx[q]] = v;
-                a.theta[eidx[q]] = eth[q] - (c.lr / bc1) * (m / (sqrtf(v) / bc2s + c.eps));
+                eth[q] = eth[q] - (c.lr / bc1) * (m / (sqrtf(v) / bc2s + c.eps));
+                a.theta[eidx[q]] = eth[q];
             } else {
                 a.grad[eidx[q]] = gsum;
             }
+        }
+    }
+    if (adam && a.theta_t) {
+        // keep the transposed mirror current: the tile goes back through LDS so that the [in][out] rows are written
+        // 32 contiguous floats at a time; biases and the head layer are mirrored as they are
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < WG_EPT; ++q) red[0][ero][erc + q] = eth[q];
+        __syncthreads();
+        for (int e = tid; e < 1024; e += TH) {
+            const int ti = e >> 5, to = e & 31;              // consecutive threads -> consecutive output rows o
+            const int o = o0 + to, i = i0 + ti;
+            if (!tile_live || o >= M || i > K) continue;
+            const float v = red[0][to][ti];
+            if (i == K) a.theta_t[(size_t)boff + o] = v;
+            else if (layer == 3) a.theta_t[(size_t)woff + (size_t)o * K + i] = v;
+            else a.theta_t[(size_t)woff + (size_t)i * M + o] = v;
         }
     }
     // workgroup (0, 0) folds the per-tile loss statistics of the previous kernel in a fixed order and hands the next
@@ -1534,6 +1539,29 @@ __global__ void bump_kernel(int64_t* step, int64_t* k) {
     if (k) k[0] += 1;
 }
 
+// theta_t[w + k * H + n] = theta[w + n * K + k] for one [H][K] weight matrix at offset w (32 x 32 tiles through LDS)
+__global__ void __launch_bounds__(256) transpose_weight_kernel(const float* theta, float* theta_t, int64_t w, int H, int K) {
+    __shared__ float tile[32][33];
+    const int n0 = blockIdx.y * 32, k0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8)
+        if (n0 + r < H && k0 + tx < K) tile[r][tx] = theta[w + (size_t)(n0 + r) * K + k0 + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (k0 + r < K && n0 + tx < H) theta_t[w + (size_t)(k0 + r) * H + n0 + tx] = tile[tx][r];
+}
+
+hipError_t launch_refresh_transposed(const copo_ppo_cfg& c, const float* theta, float* theta_t, hipStream_t s) {
+    hipError_t e = hipMemcpyAsync(theta_t, theta, (size_t)c.n_params * sizeof(float), hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return e;
+    const copo_net_layout* nets[4] = {&c.pol, &c.val[0], &c.val[1], &c.val[2]};
+    for (int g = 0; g <= c.n_value_heads; ++g) {
+        const int H = c.hidden, K1 = nets[g]->in_dim;
+        hipLaunchKernelGGL(transpose_weight_kernel, dim3((K1 + 31) / 32, (H + 31) / 32), dim3(256), 0, s, theta, theta_t, nets[g]->w1, H, K1);
+        hipLaunchKernelGGL(transpose_weight_kernel, dim3((H + 31) / 32, (H + 31) / 32), dim3(256), 0, s, theta, theta_t, nets[g]->w2, H, H);
+    }
+    return hipGetLastError();
+}
+
 __global__ void __launch_bounds__(256) adam_flat_kernel(FusedArgs a, long long n) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -1546,7 +1574,21 @@ __global__ void __launch_bounds__(256) adam_flat_kernel(FusedArgs a, long long n
     v = v * c.beta2 + s * s * (1.0f - c.beta2);
     a.adam_m[i] = m;
     a.adam_v[i] = v;
-    a.theta[i] = a.theta[i] - (c.lr / bc1) * (m / (sqrtf(v) / bc2s + c.eps));
+    const float th = a.theta[i] - (c.lr / bc1) * (m / (sqrtf(v) / bc2s + c.eps));
+    a.theta[i] = th;
+    if (a.theta_t) {     // mirror with W1 / W2 transposed (scattered 4-byte writes: the whole buffer is ~1 MB)
+        long long j = i;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g <= c.n_value_heads) {
+                const copo_net_layout& L = g == 0 ? c.pol : c.val[g - 1];
+                const long long r1 = i - L.w1, r2 = i - L.w2;
+                if (r1 >= 0 && r1 < (long long)c.hidden * L.in_dim) j = L.w1 + (r1 % L.in_dim) * c.hidden + r1 / L.in_dim;
+                if (r2 >= 0 && r2 < (long long)c.hidden * c.hidden) j = L.w2 + (r2 % c.hidden) * c.hidden + r2 / c.hidden;
+            }
+        }
+        a.theta_t[j] = th;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1578,8 +1620,10 @@ static hipError_t gemm_lds_attrs() {
         COPO_ATTR((gemm_kernel<BxOp, true>)); COPO_ATTR((gemm_kernel<BxOp, false>));
         COPO_ATTR((gemm_bw_kernel<true>)); COPO_ATTR((gemm_bw_kernel<false>));
 #undef COPO_ATTR
-        for (const void* f : {reinterpret_cast<const void*>(rowpass_kernel<1, 4>), reinterpret_cast<const void*>(rowpass_kernel<2, 4>),
-                              reinterpret_cast<const void*>(rowpass_kernel<2, 8>), reinterpret_cast<const void*>(rowpass_kernel<4, 8>)})
+        for (const void* f : {reinterpret_cast<const void*>(rowpass_kernel<1, 4, false>), reinterpret_cast<const void*>(rowpass_kernel<2, 4, false>),
+                              reinterpret_cast<const void*>(rowpass_kernel<2, 8, false>), reinterpret_cast<const void*>(rowpass_kernel<4, 8, false>),
+                              reinterpret_cast<const void*>(rowpass_kernel<1, 4, true>), reinterpret_cast<const void*>(rowpass_kernel<2, 4, true>),
+                              reinterpret_cast<const void*>(rowpass_kernel<2, 8, true>), reinterpret_cast<const void*>(rowpass_kernel<4, 8, true>)})
             if ((r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) != hipSuccess) e = r;
         return e;
     }();
@@ -1645,12 +1689,19 @@ hipError_t launch_fused_step(FusedArgs a, hipStream_t s, const MetaTail* mt_ = n
                          rp_lds <= 150 * 1024;
     if (rowpass) {
         const dim3 grid(head_tiles(c), G);
+        const bool tw = a.theta_t != nullptr && a.head_mode != MODE_META_BOTH;
+#define COPO_RP(NT_, W_)                                                                                       \
+        do {                                                                                                   \
+            if (tw) hipLaunchKernelGGL((rowpass_kernel<NT_, W_, true>), grid, dim3(64 * W_), rp_lds, s, a);      \
+            else hipLaunchKernelGGL((rowpass_kernel<NT_, W_, false>), grid, dim3(64 * W_), rp_lds, s, a);        \
+        } while (0)
         switch (rp_h) {
-            case 64: hipLaunchKernelGGL((rowpass_kernel<1, 4>), grid, dim3(256), rp_lds, s, a); break;
-            case 128: hipLaunchKernelGGL((rowpass_kernel<2, 4>), grid, dim3(256), rp_lds, s, a); break;
-            case 256: hipLaunchKernelGGL((rowpass_kernel<2, 8>), grid, dim3(512), rp_lds, s, a); break;
-            default: hipLaunchKernelGGL((rowpass_kernel<4, 8>), grid, dim3(512), rp_lds, s, a); break;
+            case 64: COPO_RP(1, 4); break;
+            case 128: COPO_RP(2, 4); break;
+            case 256: COPO_RP(2, 8); break;
+            default: COPO_RP(4, 8); break;
         }
+#undef COPO_RP
     } else {
         COPO_GEMM(FwdOpT<1>, dim3(ht, mt, G), f1, kmax1);
         COPO_GEMM(FwdOpT<2>, dim3(ht, mt, G), f2, c.hidden);
@@ -1736,7 +1787,8 @@ extern "C" int copo_ppo_fused_step_f32(const copo_ppo_cfg* cfg, float* theta, fl
                                        const float* obs_src, const float* cc_src, const float* pack_src,
                                        const int64_t* rows, const float* w, const float* denom, const float* kl_coeff,
                                        int64_t* step, float* workspace, float* stats, int32_t apply_adam,
-                                       int32_t head_mode, int64_t* mb_index, int32_t bump_index, void* stream) {
+                                       int32_t head_mode, int64_t* mb_index, int32_t bump_index, float* theta_t,
+                                       void* stream) {
     int rc = check_cfg(cfg);
     if (rc != COPO_OK) return rc;
     if (!theta || !obs_src || !pack_src || !rows || !w || !denom || !workspace) return COPO_ERR_NULL;
@@ -1750,8 +1802,16 @@ extern "C" int copo_ppo_fused_step_f32(const copo_ppo_cfg* cfg, float* theta, fl
     a.kl_coeff = kl_coeff; a.step = step; a.stats = stats; a.apply_adam = apply_adam; a.head_mode = head_mode;
     a.groups = (head_mode == COPO_HEAD_PPO) ? 1 + cfg->n_value_heads : 1;
     a.bump_k = (mb_index && bump_index) ? 1 : 0;
+    a.theta_t = theta_t;
     hipError_t e = launch_fused_step(a, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
+}
+
+extern "C" int copo_transpose_weights_f32(const copo_ppo_cfg* cfg, const float* theta, float* theta_t, void* stream) {
+    int rc = check_cfg(cfg);
+    if (rc != COPO_OK) return rc;
+    if (!theta || !theta_t) return COPO_ERR_NULL;
+    return launch_refresh_transposed(*cfg, theta, theta_t, static_cast<hipStream_t>(stream)) == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
 }
 
 extern "C" int copo_meta_grads_f32(const copo_ppo_cfg* cfg, float* theta, float* theta_target, float* g_new, float* g_old,
@@ -1897,7 +1957,7 @@ extern "C" int copo_meta_finish_f64(const float* g_new, const float* g_old, int6
 }
 
 extern "C" int copo_adam_step_f32(const copo_ppo_cfg* cfg, float* theta, float* adam_m, float* adam_v, const float* grad,
-                                  int64_t n, int64_t* step, int64_t* mb_index, void* stream) {
+                                  int64_t n, int64_t* step, int64_t* mb_index, float* theta_t, void* stream) {
     if (!cfg || !theta || !adam_m || !adam_v || !grad || !step) return COPO_ERR_NULL;
     if (n < 0) return COPO_ERR_DIM;
     FusedArgs a;
@@ -1905,6 +1965,7 @@ extern "C" int copo_adam_step_f32(const copo_ppo_cfg* cfg, float* theta, float* 
     a.c = *cfg;
     a.theta = theta; a.adam_m = adam_m; a.adam_v = adam_v; a.grad = const_cast<float*>(grad); a.step = step;
     a.kptr = mb_index; a.bump_k = mb_index ? 1 : 0;
+    a.theta_t = theta_t;
     hipError_t e = launch_adam_flat(a, n, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
 }

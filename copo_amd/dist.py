@@ -4,7 +4,9 @@ towers, algo_copo.py:519-577); the exchange steps below are the build's own (SUR
 
   * per SGD minibatch  : one flat-bucket all-reduce of the gradient sums
   * per iteration      : one all-reduce of the advantage statistics (6 doubles) + row counts
-  * per meta minibatch : one flat bucket [g_new | g_old | dS/dlcf | S | n]  (both gradients BEFORE the dot)
+  * per meta minibatch : one flat bucket [g_new | g_old | dS/dlcf | S | n]  (both gradients BEFORE the dot); the fused
+                         learner batches this: one all-reduce of the gradient pairs of 32 minibatches, one
+                         all-gather of the LCF row terms per meta iteration
 
 Env shards never talk to each other, so nothing else crosses ranks.
 """
@@ -21,17 +23,24 @@ def env_world():
 def init_from_env(device=None):
     """Initialise the default process group from torchrun's env vars (no-op for a single process)."""
     rank, local_rank, world = env_world()
-    if world > 1 and not td.is_initialized():
+    if (world > 1 or _forced()) and not td.is_initialized():
         use_cuda = torch.cuda.is_available() and (device is None or str(device).startswith("cuda"))
         if use_cuda:
             torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29533")
         td.init_process_group(backend="nccl" if use_cuda else "gloo", rank=rank, world_size=world)
     return rank, local_rank, world
 
 
+def _forced():
+    # COPO_FORCE_DIST=1: take the data-parallel code paths with a single rank (exercises them on a one-GPU box)
+    return os.environ.get("COPO_FORCE_DIST", "0") == "1"
+
+
 def is_dist():
-    return td.is_available() and td.is_initialized() and td.get_world_size() > 1
+    return td.is_available() and td.is_initialized() and (td.get_world_size() > 1 or _forced())
 
 
 def world_size():
@@ -52,6 +61,18 @@ def all_reduce_max_(t):
     if is_dist():
         td.all_reduce(t, op=td.ReduceOp.MAX)
     return t
+
+
+def all_gather_into_(out, t):
+    """out [world, *t.shape] <- every rank's t (same shape everywhere)."""
+    if not is_dist():
+        out[0].copy_(t)
+        return out
+    try:
+        td.all_gather_into_tensor(out, t.contiguous())
+    except (RuntimeError, NotImplementedError):
+        td.all_gather([out[i] for i in range(out.shape[0])], t.contiguous())
+    return out
 
 
 def all_gather_int(v, device):

@@ -105,30 +105,46 @@ class FusedLearner:
         self.stats = torch.zeros(_capi.PPO_STATS, device=dev)
         self._batch_ws = None
         self.target_flat = None
+        # mirror of the parameters with W1 / W2 stored [in][out]: coalesced operand reads for the forward passes.  The
+        # kernels keep it current; torch-side writes to the parameters are noticed through the tensor version counter.
+        self.flat_t = torch.zeros(n, device=dev)
+        self._mirror_version = -1
 
     def attach_target(self, target_model):
         """Flat view of the target network (same layout as the model) for the META_OLD pass."""
         self.target_flat = FlatParams(target_model, self.policy.device)
         assert self.target_flat.numel == self.flat.numel
 
+    def sync_mirror(self):
+        """Re-derive the transposed mirror if torch code touched the parameters since the kernels last wrote it
+        (optimiser-free weight loads, checkpoints, tests).  Call outside captured graphs, before replaying them."""
+        v = self.flat.flat._version
+        if v != self._mirror_version:
+            _capi.check(_capi.lib.copo_transpose_weights_f32(C.byref(self.cfg), self.flat.flat.data_ptr(),
+                                                             self.flat_t.data_ptr(), _capi.current_stream()))
+            self._mirror_version = v
+
     def step(self, rs, head_mode=_capi.HEAD_PPO, apply_adam=True, theta=None, grad=None, stats=None, bump_index=True):
         """One fused minibatch pass over the sources bound in `rs` (PPOPolicyBase._row_sources layout)."""
         cc = rs["cc_obs"]
         kl = self.policy.kl_coeff
+        if theta is None and not torch.cuda.is_current_stream_capturing():
+            self.sync_mirror()
         _capi.check(_capi.lib.copo_ppo_fused_step_f32(
             C.byref(self.cfg), (self.flat.flat if theta is None else theta).data_ptr(), self.adam_m.data_ptr(),
             self.adam_v.data_ptr(), (self.grad if grad is None else grad).data_ptr(), rs["obs"].data_ptr(),
             None if cc is None else cc.data_ptr(), rs["pack"].data_ptr(), rs["rows_all"].data_ptr(),
             rs["w_all"].data_ptr(), rs["denom_all"].data_ptr(), kl.data_ptr(), self.step_count.data_ptr(),
             self.workspace.data_ptr(), None if stats is None else stats.data_ptr(), 1 if apply_adam else 0,
-            int(head_mode), rs["k"].data_ptr(), 1 if bump_index else 0, _capi.current_stream()))
+            int(head_mode), rs["k"].data_ptr(), 1 if bump_index else 0,
+            self.flat_t.data_ptr() if theta is None else None, _capi.current_stream()))
 
     def adam(self, rs, grad=None):
         """Adam on the flat buffers after a gradient all-reduce; advances the minibatch index."""
         _capi.check(_capi.lib.copo_adam_step_f32(
             C.byref(self.cfg), self.flat.flat.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr(),
             (self.grad if grad is None else grad).data_ptr(), self.flat.numel, self.step_count.data_ptr(),
-            rs["k"].data_ptr(), _capi.current_stream()))
+            rs["k"].data_ptr(), self.flat_t.data_ptr(), _capi.current_stream()))
 
     # ---- LCF meta update (CoPO) -------------------------------------------------------------------------------
     def meta_grads(self, rs, g_new, g_old, stats_new, stats_old, dot_partials):

@@ -336,11 +336,35 @@ class CoPOPolicy(CCPPOPolicy):
         `n_mb` calls of `_meta_step_local`."""
         mb_, fz = self._meta_bufs, self.fused
         rs = dict(self._row_sources, **{k: mb_[k] for k in ("rows_all", "w_all", "denom_all")})
+        if not D.is_dist():
+            for c0 in range(0, n_mb, nb):
+                fz.meta_batch_grads(rs, c0, min(nb, n_mb - c0), mb_["gv"], mb_["stats_k"])
+            fz.meta_batch_lcf(rs, n_mb, mb_["eps_all"], mb_["gv"], mb_["stats_k"], self.model.lcf_parameters.data,
+                              self._raw_ms, self._lcf_adam, self.config[LCF_LR], mb_["stats"], mb_["col_adv"],
+                              mb_["col_nei_adv"])
+            return
+        # data-parallel: the minibatch gradients are sums over the ranks' rows -> all-reduce the exported gradient pairs
+        # of a whole chunk BEFORE their dot products; the LCF row terms of every rank are gathered once per iteration
+        # and every rank runs the (cheap, sequential) LCF steps on the full rows, so the parameters stay identical.
+        nf, S, mb = fz.meta_fold_len(), D.world_size(), mb_["mb"]
+        if mb_.get("g_chunk") is None or mb_["g_chunk"].shape[0] < nb:
+            mb_["g_chunk"] = torch.zeros(nb, 2, nf, dtype=torch.float32, device=self.device)
         for c0 in range(0, n_mb, nb):
-            fz.meta_batch_grads(rs, c0, min(nb, n_mb - c0), mb_["gv"], mb_["stats_k"])
-        fz.meta_batch_lcf(rs, n_mb, mb_["eps_all"], mb_["gv"], mb_["stats_k"], self.model.lcf_parameters.data,
-                          self._raw_ms, self._lcf_adam, self.config[LCF_LR], mb_["stats"], mb_["col_adv"],
-                          mb_["col_nei_adv"])
+            n = min(nb, n_mb - c0)
+            fz.meta_batch_grads(rs, c0, n, mb_["gv"], mb_["stats_k"], g_out=mb_["g_chunk"])
+            D.all_reduce_sum_(mb_["g_chunk"][:n])
+            fz.meta_batch_dot(mb_["g_chunk"], nf, n, mb_["gv"][c0:])
+        D.all_reduce_sum_(mb_["stats_k"][:n_mb])
+        rows = mb_["rows_all"][:n_mb]
+        pack = self._row_sources["pack"]
+        en = torch.stack([pack[:, mb_["col_adv"]][rows], pack[:, mb_["col_nei_adv"]][rows]], dim=-1).contiguous()
+        en_all = D.all_gather_into_(torch.empty((S,) + tuple(en.shape), dtype=en.dtype, device=self.device), en)
+        w_all = D.all_gather_into_(torch.empty(S, n_mb, mb, dtype=torch.float32, device=self.device),
+                                   mb_["w_all"][:n_mb].contiguous())
+        eps_all = D.all_gather_into_(torch.empty(S, n_mb, mb, dtype=torch.float64, device=self.device),
+                                     mb_["eps_all"][:n_mb].contiguous())
+        fz.meta_batch_lcf(rs, n_mb, None, mb_["gv"], mb_["stats_k"], self.model.lcf_parameters.data, self._raw_ms,
+                          self._lcf_adam, self.config[LCF_LR], mb_["stats"], 0, 0, dense=(en_all, w_all, eps_all))
 
     def run_meta(self, valid_idx, B_local, B_all, mb, num_iters):
         """`lcf_num_iters` passes of shuffled minibatches through `meta_update` (algo_copo.py:581-589)."""
@@ -388,7 +412,7 @@ class CoPOPolicy(CCPPOPolicy):
         for _ in range(num_iters):
             n_mb = self.plan_epoch(valid_idx, B_local, B_all, mb, bufs=mbuf)
             mbuf["eps_all"].normal_()
-            if nb_batch > 0 and not D.is_dist():
+            if nb_batch > 0:
                 self._run_meta_batched(n_mb, nb_batch)
                 steps += n_mb
                 continue

@@ -374,6 +374,7 @@ class PPOPolicyBase:
             else:
                 self._sgd = GraphedCallable(self._fused_local, self.use_graphs)
         fz.stats.zero_()
+        fz.sync_mirror()          # graph replays below do not run python: refresh the transposed weights here if needed
         steps = 0
         for _ in range(num_epochs):
             n_mb = self.plan_epoch(valid_idx, B_local, B_all, mb)

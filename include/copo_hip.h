@@ -235,15 +235,19 @@ int64_t copo_ppo_workspace_floats(const copo_ppo_cfg* cfg);
  * apply_adam = 0: only `grad` (flat, same layout as theta) is written.  stats (may be NULL) accumulates.
  * mb_index (device int64, may be NULL = 0) selects the minibatch k: rows / w are then [n_mb][mb] tables and denom
  * is [n_mb]; bump_index = 1 increments *mb_index at the end, so that a captured hipGraph of this call walks the
- * epoch plan by itself. */
+ * epoch plan by itself.
+ * theta_t (may be NULL): a mirror of theta, same length and offsets, in which W1 and W2 of every net are stored
+ * transposed ([in][out]).  When given, the forward passes read it (coalesced B operands) and the Adam epilogue
+ * keeps it current; create / refresh it with copo_transpose_weights_f32 whenever theta was changed from outside. */
 int copo_ppo_fused_step_f32(const copo_ppo_cfg* cfg, float* theta, float* adam_m, float* adam_v, float* grad,
                             const float* obs_src, const float* cc_src, const float* pack_src, const int64_t* rows,
                             const float* w, const float* denom, const float* kl_coeff, int64_t* step,
                             float* workspace, float* stats, int32_t apply_adam, int32_t head_mode,
-                            int64_t* mb_index, int32_t bump_index, void* stream);
-/* Adam on the flat buffers (the data-parallel path: after the gradient all-reduce) */
+                            int64_t* mb_index, int32_t bump_index, float* theta_t, void* stream);
+int copo_transpose_weights_f32(const copo_ppo_cfg* cfg, const float* theta, float* theta_t, void* stream);
+/* Adam on the flat buffers (the data-parallel path: after the gradient all-reduce); theta_t as above or NULL */
 int copo_adam_step_f32(const copo_ppo_cfg* cfg, float* theta, float* adam_m, float* adam_v, const float* grad,
-                       int64_t n, int64_t* step, int64_t* mb_index, void* stream);
+                       int64_t n, int64_t* step, int64_t* mb_index, float* theta_t, void* stream);
 
 /* ---- LCF meta update (CoPOPolicy.meta_update, algo_copo.py:228-309) in three calls ------------------------------
  * (1) both policy gradients in one grouped pass: g_new = d mean(-clip-surrogate(global adv)) / d theta on the

@@ -168,3 +168,40 @@ def test_baseline_parity_configs_run(name, algo, map_cls, cfg):
     assert all(np.isfinite(v) for v in st.values()), st
     assert a.sampler.obs.dtype == torch.float32 and float(a.sampler.obs.max()) <= 1.0
     a.stop()
+
+
+def test_data_parallel_code_path_single_rank():
+    """COPO_FORCE_DIST=1 takes every data-parallel branch (gradient export + all-reduce + flat Adam, batched meta with
+    exported gradient pairs / gathered LCF rows) with one rank: same training trajectory as the local path."""
+    import subprocess
+    import sys
+    code = r'''
+import json, os, sys, torch
+sys.path.insert(0, os.getcwd())
+from copo_amd import dist as D
+D.init_from_env("cuda")
+from copo_amd.torch_copo.algo_copo import CoPOTrainer
+from copo_amd.torch_copo.utils.env_wrappers import MultiAgentIntersectionEnv, get_lcf_env, get_rllib_compatible_env
+env = get_rllib_compatible_env(get_lcf_env(MultiAgentIntersectionEnv))
+a = CoPOTrainer(config=dict(env=env, env_config=dict(num_agents=12), num_envs=16, train_batch_size=16 * 8,
+                            sgd_minibatch_size=128, num_sgd_iter=2, lcf_num_iters=2, seed=3, meta_batch_size=4,
+                            model={"fcnet_hiddens": [64, 64]}))
+assert a.policy.fused is not None
+for _ in range(3):
+    res = a.train()
+w = a.policy.model._hidden_layers[0]._model[0].weight
+print("RESULT " + json.dumps(dict(dist=D.is_dist(), lcf=a.policy.model.lcf_parameters.tolist(), w=float(w.double().abs().sum()),
+                                  loss=res["info"]["learner"]["default"]["learner_stats"]["total_loss"])))
+'''
+    outs = []
+    for force in ("0", "1"):
+        env = dict(os.environ, COPO_FORCE_DIST=force, MASTER_PORT="29541")
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+        outs.append(__import__("json").loads(line[7:]))
+    assert outs[0]["dist"] is False and outs[1]["dist"] is True
+    np.testing.assert_allclose(outs[1]["lcf"], outs[0]["lcf"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(outs[1]["w"], outs[0]["w"], rtol=1e-5)
+    np.testing.assert_allclose(outs[1]["loss"], outs[0]["loss"], rtol=1e-3, atol=1e-5)
