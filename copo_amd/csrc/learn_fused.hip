@@ -1289,48 +1289,98 @@ struct MetaSeqArgs {
 // all LCF Adam steps of one meta iteration, in minibatch order, in ONE workgroup: per step the fp64 row sums of
 // meta_lcf_body with the current LCF parameters, then meta_finish_body's update -- parameters and Adam state live
 // in LDS between steps.
+constexpr int SEQ_RPT = 8;      // rows per thread whose inputs are prefetched one LCF step ahead
+
 __global__ void __launch_bounds__(512) meta_seq_kernel(MetaSeqArgs a) {
     __shared__ double red[4][8];
     __shared__ double P[2], AD[5], ST[7];
+    __shared__ double DV[4];          // quantities derived from the LCF parameters: mean, d mean / d p0, std, d std / d p1
+    __shared__ double PW[2];          // beta1^t, beta2^t as running products
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-    if (tid < 2) P[tid] = a.lcf_param[tid];
+    const double half_pi = 3.14159265358979323846 / 2.0, lim = 1.0 - 1e-6;
+    // lane j of wave 0 owns LCF parameter j: its Adam state, and the derived quantities every row needs
+    auto derive = [&](int j, double p) {
+        if (j == 0) {
+            const double th = tanh(p);
+            DV[0] = th > lim ? lim : (th < -lim ? -lim : th);
+            DV[1] = (th >= -lim && th <= lim) ? (1.0 - th * th) : 0.0;
+        } else {
+            const double pc = p > 2.0 ? 2.0 : (p < -20.0 ? -20.0 : p);
+            const double sdv = exp(pc);
+            DV[2] = sdv;
+            DV[3] = (p >= -20.0 && p <= 2.0) ? sdv : 0.0;
+        }
+    };
+    if (tid < 2) {
+        P[tid] = a.lcf_param[tid];
+        derive(tid, P[tid]);
+        PW[tid] = pow(tid == 0 ? 0.9 : 0.999, a.adam[4]);
+    }
     if (tid < 5) AD[tid] = a.adam[tid];
     if (tid < 7) ST[tid] = 0.0;
     __syncthreads();
-    const double half_pi = 3.14159265358979323846 / 2.0, lim = 1.0 - 1e-6;
     const double mu = a.raw_mean_std[0], sigma = a.raw_mean_std[1];
     const size_t seg_stride = (size_t)a.n_mb * a.mb;
+    const int total = a.n_seg * a.mb;
+    // row inputs of one LCF step: {A_ego, A_nei, eps, w}; the next step's are requested before this step's math, so
+    // that the (dependent, L2-missing) loads overlap the fp64 work and the reduction
+    float pe[SEQ_RPT], pn[SEQ_RPT], pw[SEQ_RPT];
+    double px[SEQ_RPT];
+    auto fetch = [&](int k, int i, float& ego, float& nei, double& e, float& w) {
+        const int seg = i / a.mb, m = i - seg * a.mb;
+        const size_t at = seg * seg_stride + (size_t)k * a.mb + m;
+        w = a.w[at];
+        e = a.eps[at];
+        if (a.ego_nei) {
+            ego = a.ego_nei[at * 2];
+            nei = a.ego_nei[at * 2 + 1];
+        } else {
+            const float* pk = a.pack_src + (size_t)a.rows[at] * a.pack_width;
+            ego = pk[a.col_adv];
+            nei = pk[a.col_nei_adv];
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < SEQ_RPT; ++j) {
+        const int i = tid + j * blockDim.x;
+        pe[j] = pn[j] = pw[j] = 0.0f;
+        px[j] = 0.0;
+        if (i < total && a.n_mb > 0) fetch(0, i, pe[j], pn[j], px[j], pw[j]);
+    }
     for (int k = 0; k < a.n_mb; ++k) {
-        const double p0 = P[0], p1 = P[1];
-        const double th = tanh(p0);
-        const double mean = th > lim ? lim : (th < -lim ? -lim : th);
-        const double dmean = (th >= -lim && th <= lim) ? (1.0 - th * th) : 0.0;
-        const double p1c = p1 > 2.0 ? 2.0 : (p1 < -20.0 ? -20.0 : p1);
-        const double sd = exp(p1c), dsd = (p1 >= -20.0 && p1 <= 2.0) ? sd : 0.0;
-        double s0 = 0.0, s1 = 0.0, sS = 0.0, sA = 0.0;
-        for (int i = tid; i < a.n_seg * a.mb; i += blockDim.x) {
-            const int seg = i / a.mb, m = i - seg * a.mb;
-            const size_t at = seg * seg_stride + (size_t)k * a.mb + m;
-            const double w = (double)a.w[at];
-            if (w == 0.0) continue;
-            double ego, nei;
-            if (a.ego_nei) {
-                ego = (double)a.ego_nei[at * 2];
-                nei = (double)a.ego_nei[at * 2 + 1];
-            } else {
-                const float* pk = a.pack_src + (size_t)a.rows[at] * a.pack_width;
-                ego = (double)pk[a.col_adv];
-                nei = (double)pk[a.col_nei_adv];
+        float ce[SEQ_RPT], cn[SEQ_RPT], cw[SEQ_RPT];
+        double cx[SEQ_RPT];
+#pragma unroll
+        for (int j = 0; j < SEQ_RPT; ++j) { ce[j] = pe[j]; cn[j] = pn[j]; cw[j] = pw[j]; cx[j] = px[j]; }
+        if (k + 1 < a.n_mb) {
+#pragma unroll
+            for (int j = 0; j < SEQ_RPT; ++j) {
+                const int i = tid + j * blockDim.x;
+                if (i < total) fetch(k + 1, i, pe[j], pn[j], px[j], pw[j]);
             }
-            const double e = a.eps[at];
-            const double phi = (mean + sd * e) * half_pi;
-            const double cs = cos(phi), sn = sin(phi);
+        }
+        const double mean = DV[0], sd = DV[2];
+        // per row only the sums that depend on the row: sum w A', sum w dA'/dphi, sum w eps dA'/dphi; the parameter
+        // dependent factors are applied once per step below
+        double s0 = 0.0, s1 = 0.0, sS = 0.0, sA = 0.0;
+        auto row = [&](double ego, double nei, double e, double w) {
+            if (w == 0.0) return;
+            double cs, sn;
+            sincospi((mean + sd * e) * 0.5, &sn, &cs);        // phi = (mean + sd eps) pi / 2
             const double A = cs * ego + sn * nei;
-            const double dA = (-sn * ego + cs * nei) * half_pi;
-            sS += w * (A - mu) / sigma;
+            const double dA = cs * nei - sn * ego;
             sA += w * A;
-            s0 += w * dA * dmean / sigma;
-            s1 += w * dA * e * dsd / sigma;
+            s0 += w * dA;
+            s1 += w * dA * e;
+        };
+#pragma unroll
+        for (int j = 0; j < SEQ_RPT; ++j)
+            if (tid + j * (int)blockDim.x < total) row((double)ce[j], (double)cn[j], cx[j], (double)cw[j]);
+        for (int i = tid + SEQ_RPT * blockDim.x; i < total; i += blockDim.x) {      // rows beyond the prefetch window
+            float ego, nei, w;
+            double e;
+            fetch(k, i, ego, nei, e, w);
+            row((double)ego, (double)nei, e, (double)w);
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -1338,33 +1388,46 @@ __global__ void __launch_bounds__(512) meta_seq_kernel(MetaSeqArgs a) {
         }
         if (lane == 0) { red[0][wave] = s0; red[1][wave] = s1; red[2][wave] = sS; red[3][wave] = sA; }
         __syncthreads();
-        if (tid == 0) {
-            double t[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int q = 0; q < 4; ++q)
-                for (int i = 0; i < nw; ++i) t[q] += red[q][i];
+        if (wave == 0) {
+            // final sums over the waves (fixed order), one lane per quantity, then broadcast inside the wave
+            double tq = 0.0;
+            if (lane < 4)
+                for (int i = 0; i < nw; ++i) tq += red[lane][i];
             const double D = (double)a.denom[k];
-            const double tail[4] = {t[0] / D, t[1] / D, t[2] / D, t[3] / D};
+            // tail = {dS/dp0, dS/dp1, S, mean A'} with S = (mean A' - mu) / sigma   (red[2] is unused: zero)
+            const double r0 = __shfl(tq, 0), r1 = __shfl(tq, 1), r3 = __shfl(tq, 3);
+            const double t3 = r3 / D, t2 = (t3 - mu) / sigma;
+            const double t0 = r0 * half_pi * DV[1] / (sigma * D), t1 = r1 * half_pi * DV[3] / (sigma * D);
             const double gvk = a.gv[k];
-            const double b1 = 0.9, b2 = 0.999, eps = 1e-8;
-            const double tt = AD[4] + 1.0;
-            const double bc1 = 1.0 - pow(b1, tt), bc2 = 1.0 - pow(b2, tt);
-            for (int j = 0; j < 2; ++j) {
-                const double g = gvk * tail[j];
-                double m = AD[j], v = AD[2 + j];
+            if (lane < 2) {          // Adam on parameter `lane` (fp64, betas 0.9 / 0.999, eps 1e-8), then what the rows need
+                const double b1 = 0.9, b2 = 0.999, eps = 1e-8;
+                const double pw1 = PW[0] * b1, pw2 = PW[1] * b2;       // beta^t with t = step + 1
+                const double bc1 = 1.0 - pw1, bc2 = 1.0 - pw2;
+                const double g = gvk * (lane == 0 ? t0 : t1);
+                double m = AD[lane], v = AD[2 + lane];
                 m = m + (g - m) * (1.0 - b1);
                 v = v * b2 + g * g * (1.0 - b2);
-                AD[j] = m;
-                AD[2 + j] = v;
-                P[j] -= (a.lr / bc1) * (m / (sqrt(v) / sqrt(bc2) + eps));
+                AD[lane] = m;
+                AD[2 + lane] = v;
+                const double pnew = P[lane] - (a.lr / bc1) * (m / (sqrt(v) / sqrt(bc2) + eps));
+                P[lane] = pnew;
+                derive(lane, pnew);
             }
-            AD[4] = tt;
-            ST[0] += (double)a.stats_in[((size_t)k * 2 + 0) * 8 + 1];
-            ST[1] += (double)a.stats_in[((size_t)k * 2 + 1) * 8 + 1];
-            ST[2] += tail[2];
-            ST[3] += gvk * tail[2];
-            ST[4] += gvk;
-            ST[5] += tail[3];
-            ST[6] += (double)a.stats_in[((size_t)k * 2 + 0) * 8 + 7];
+            if (lane == 2) {
+                ST[0] += (double)a.stats_in[((size_t)k * 2 + 0) * 8 + 1];
+                ST[1] += (double)a.stats_in[((size_t)k * 2 + 1) * 8 + 1];
+                ST[2] += t2;
+                ST[3] += gvk * t2;
+                ST[4] += gvk;
+                ST[5] += t3;
+                ST[6] += (double)a.stats_in[((size_t)k * 2 + 0) * 8 + 7];
+            }
+            if (lane == 3) {         // after lanes 0 / 1 read the old products (same wave: program order)
+                const double n1 = PW[0] * 0.9, n2 = PW[1] * 0.999;
+                PW[0] = n1;
+                PW[1] = n2;
+                AD[4] = AD[4] + 1.0;
+            }
         }
         __syncthreads();
     }
