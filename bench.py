@@ -17,6 +17,9 @@ Extra objects on the JSON line:
   roofline      the simulator step kernel (the path's dominant custom kernel): algorithmic bytes
                 (202 + 4*O per present agent slot) / mean launch time measured with HIP events
                 on the launch stream, against the 8 TB/s HBM peak.
+  learner_roofline  one fused SGD step (the two kernels that take most of an iteration): algorithmic flops / mean step
+                time (HIP events), against the dense fp32 MFMA peak.  The step is a chain of two latency-bound launches
+                on a 512-row minibatch, not a throughput GEMM; the fraction says how far from the matrix peak that leaves it.
   cpu_baseline  the same iteration on the host: scalar C oracle simulator + oracle ops + the same torch code
                 on CPU threads ("port"), on a bounded sample.
 """
@@ -33,6 +36,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)
 CPU_BASELINE_THREADS = 8
 
 
@@ -71,6 +75,43 @@ def measure_sim_kernel(trainer, launches=200):
         present += float(((out["flags"] & 0x41) != 0).sum())
     del act
     return e0.elapsed_time(e1) * 1e-3 / launches, present / 16.0
+
+
+def measure_learner_step(trainer, launches=200):
+    """Mean duration of one fused SGD step (row-pass kernel + weight-gradient/Adam kernel: the two launches that
+    take ~65 % of an iteration) with HIP events on the launch stream, and its algorithmic flops: per net
+    2*mb*(K*H + H*H + OD*H) forward, 2*mb*(OD*H + H*H) activation gradients, 2*mb*((K+1)*H + (H+1)*H + (H+1)*OD)
+    weight gradients."""
+    pol = trainer.policy
+    fz = pol.fused
+    if fz is None or pol._row_sources is None:
+        return None
+    c, rs = fz.cfg, pol._row_sources
+    mb, H = c.mb, c.hidden
+    nets = [c.pol] + [c.val[g] for g in range(c.n_value_heads)]
+    flops = 0
+    for L in nets:
+        K, OD = L.in_dim, L.out_dim
+        flops += 2 * mb * (K * H + H * H + OD * H) + 2 * mb * (OD * H + H * H) + 2 * mb * ((K + 1) * H + (H + 1) * H + (H + 1) * OD)
+    n_plan = int(rs["max_mb"])
+    per = max(1, min(launches, n_plan - 1))
+    for _ in range(3):
+        rs["k"].zero_()
+        for _ in range(min(per, 10)):
+            fz.step(rs, stats=fz.stats)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    done, total_ms = 0, 0.0
+    while done < launches:
+        rs["k"].zero_()                      # stay inside the planned minibatch tables
+        e0.record()
+        for _ in range(per):
+            fz.step(rs, stats=fz.stats)
+        e1.record()
+        torch.cuda.synchronize()
+        total_ms += e0.elapsed_time(e1)
+        done += per
+    return total_ms * 1e-3 / done, flops
 
 
 def cpu_baseline(num_envs, num_agents, iters=1):
@@ -181,6 +222,7 @@ def main():
         if os.path.exists(tfile):
             traffic = json.load(open(tfile)).get("bytes_per_launch")
         timers = res["timers"]
+        learner = measure_learner_step(trainer)
         line = {
             "metric": "agent-env-steps/sec (sim+learn), Intersection 40-agent", "value": round(value, 1),
             "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -199,6 +241,13 @@ def main():
                          "traffic": traffic, "us_per_launch": round(k_s * 1e6, 2),
                          "units_per_launch": round(present, 1), "bytes_per_unit": bytes_per_unit},
         }
+        if learner is not None:
+            l_s, l_flops = learner
+            line["learner_roofline"] = {
+                "bound": "mfma", "kernel": "copo::rowpass_kernel + copo::wgrad_adam_kernel (one 512-row SGD step, 4 nets)",
+                "achieved": round(l_flops / l_s * 1e-12, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(l_flops / l_s * 1e-12 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                "us_per_step": round(l_s * 1e6, 2), "flops_per_step": int(l_flops)}
         if world == 1 and not args.no_cpu_baseline:
             v, cdt, n, used = cpu_baseline(args.num_envs, args.num_agents)
             line["cpu_baseline"] = {"value": round(v, 1), "unit": "agent-steps/s", "cores": used, "kind": "port",
