@@ -1,0 +1,68 @@
+"""Vectorised population evaluation on the HIP simulator (the role of `copo/eval.py` + `eval/recoder.py` +
+`eval/evaluate_population.py`): load a population (`.npz` in either reference layout, or this build's trainer
+checkpoint), roll it in E parallel scenes without learning, report the reference's headline evaluation metrics
+(success / crash / out-of-road / max-step rates, episode reward and length, velocity ...).
+
+    python -m copo_amd.eval.evaluate --algo copo --env inter --npz path/to/copo_inter.npz --lcf 0.368 0.088
+"""
+import argparse
+import json
+
+import numpy as np
+
+ENVS = {"inter": "MultiAgentIntersectionEnv", "round": "MultiAgentRoundaboutEnv", "parking": "MultiAgentParkingLotEnv",
+        "tollgate": "MultiAgentTollgateEnv"}
+
+
+def make_eval_trainer(algo, env, num_envs=64, num_agents=40, seed=0, lcf=None, **extra):
+    """A trainer used for its sampler only: same env wrappers, model and observation as training
+    (`get_env`, copo/eval.py:27-76: CoPO populations run in the LCF env with the population's LCF distribution)."""
+    from copo_amd.torch_copo import algo_ccppo, algo_copo, algo_ippo
+    from copo_amd.torch_copo.utils import env_wrappers as W
+    base = getattr(W, ENVS[env])
+    if algo == "copo":
+        cls, e = algo_copo.CoPOTrainer, W.get_rllib_compatible_env(W.get_lcf_env(base))
+    elif algo == "ccppo":
+        cls, e = algo_ccppo.CCPPOTrainer, algo_ccppo.get_ccppo_env(base)
+    else:
+        cls, e = algo_ippo.IPPOTrainer, W.get_rllib_compatible_env(base)
+    cfg = dict(env=e, env_config=dict(num_agents=num_agents), num_envs=num_envs, train_batch_size=num_envs * 25, seed=seed)
+    cfg.update(extra)
+    t = cls(config=cfg)
+    if algo == "copo" and lcf is not None:
+        t.env.set_lcf_dist(float(lcf[0]), float(lcf[1]))
+    return t
+
+
+def evaluate_population(algo, env, weights=None, lcf=None, num_envs=64, num_agents=40, episodes=2000, seed=0, **extra):
+    from .checkpoint_io import load_policy_weights
+    t = make_eval_trainer(algo, env, num_envs, num_agents, seed, lcf, **extra)
+    if weights is not None:
+        load_policy_weights(t.policy.model, weights)
+        if t.policy.fused is not None:
+            t.policy.fused.sync_mirror()
+    res = t.evaluate(num_fragments=1, min_episodes=episodes)
+    t.stop()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--algo", default="copo", choices=["ippo", "ccppo", "copo", "cl"])
+    ap.add_argument("--env", default="inter", choices=sorted(ENVS))
+    ap.add_argument("--npz", default=None, help="population file in the reference's key layout")
+    ap.add_argument("--lcf", type=float, nargs=2, default=None, metavar=("MEAN", "STD"))
+    ap.add_argument("--num-envs", type=int, default=64)
+    ap.add_argument("--num-agents", type=int, default=40)
+    ap.add_argument("--episodes", type=int, default=2000)
+    a = ap.parse_args()
+    w = None
+    if a.npz:
+        with np.load(a.npz) as f:
+            w = {k: f[k] for k in f.files}
+    algo = "ippo" if a.algo == "cl" else a.algo
+    print(json.dumps(evaluate_population(algo, a.env, w, a.lcf, a.num_envs, a.num_agents, a.episodes), indent=1))
+
+
+if __name__ == "__main__":
+    main()

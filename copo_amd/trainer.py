@@ -600,7 +600,38 @@ class VecTrainer:
             cm.update(velocity_mean=vel / na, steering_mean=steer / na, acceleration_mean=acc / na,
                       step_reward_mean=srew / na, cost_mean=cost / na, num_neighbours_mean=nnb / na)
         cm["num_terminated_agents"] = nd
+        cm["num_acting_rows"] = na
         return cm
+
+    def evaluate(self, num_fragments=50, min_episodes=0):
+        """Roll the CURRENT policy without learning and aggregate what `RecorderEnv` reports per population
+        (copo/eval/recoder.py:139-152 success / crash / out / max_step rates, episode reward / length, velocity, ...)
+        over the agents that terminate: `num_fragments` sampler fragments, more until `min_episodes` agents finished."""
+        tot, n_frag = {}, 0
+        while n_frag < num_fragments or tot.get("num_terminated_agents", 0) < min_episodes:
+            cm = self.episode_metrics(self.sampler.sample())
+            nd, na = cm.get("num_terminated_agents", 0.0), cm.get("num_acting_rows", 0.0)
+            for k, v in cm.items():
+                if k in ("num_terminated_agents", "num_acting_rows"):
+                    tot[k] = tot.get(k, 0.0) + v
+                else:      # means -> weighted sums (per terminated agent or per acting row)
+                    w = nd if k in self._EPISODE_KEYS else na
+                    tot[k] = tot.get(k, 0.0) + v * w
+            n_frag += 1
+            if n_frag > 100 * max(1, num_fragments):
+                break
+        out = {}
+        for k, v in tot.items():
+            if k in ("num_terminated_agents", "num_acting_rows"):
+                out[k] = v
+            else:
+                w = tot["num_terminated_agents"] if k in self._EPISODE_KEYS else tot["num_acting_rows"]
+                out[k] = v / w if w > 0 else float("nan")
+        out["env_steps"] = n_frag * self.sampler.T * self.sampler.E
+        return out
+
+    _EPISODE_KEYS = ("success_rate_mean", "crash_rate_mean", "out_of_road_rate_mean", "max_step_rate_mean",
+                     "episode_length_mean", "episode_reward_mean", "route_completion_mean", "episode_cost_mean")
 
     def train(self):
         t0 = time.perf_counter()

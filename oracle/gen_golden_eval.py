@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Golden vectors for the evaluation path, made by EXECUTING the reference's own
+functions (dev container only).  TEST INFRASTRUCTURE.
+
+Reference entry points driven (under /root/reference/copo_code/copo/eval/):
+  get_policy_function.py:56-83    _compute_actions_for_tf_policy     (TF-era key layout `default/fc_1{suffix}/kernel`)
+  get_policy_function.py:86-99    _compute_actions_for_torch_policy  (torch key layout `_hidden_layers.0._model.0.weight`)
+  get_policy_function.py:118-139  get_policy_function                (algo prefix -> layout / suffix)
+  get_policy_function.py:142-198  PolicyFunction.__call__ / process_svo
+
+Inputs: three trained policies the reference ships as data (`best_checkpoints/{ippo,copo,ccppo}_inter.npz`, six arrays
+each) and seeded random observations.  The fixture stores those arrays, the observations and what the reference's
+functions returned for them.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_stubs  # noqa: E402
+
+ref_stubs.install()
+import copo.eval.get_policy_function as G  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+CKPT = os.path.join(os.path.dirname(os.path.abspath(G.__file__)), os.pardir, "best_checkpoints")
+
+
+def main():
+    save = {}
+    rng = np.random.RandomState(7)
+    for name in ("ippo_inter", "copo_inter", "ccppo_inter"):
+        w = dict(np.load(os.path.join(CKPT, name + ".npz")))
+        for k, v in w.items():
+            save["%s/w/%s" % (name, k)] = v
+        f = G.get_policy_function(name, checkpoint_dir_name="best_checkpoints")
+        odim = 92 if name.startswith("copo") else 91
+        obs = rng.uniform(0, 1, size=(24, odim)).astype(np.float32)
+        save[name + "/obs"] = obs
+        if name.startswith("ccppo"):
+            mean = G._compute_actions_for_torch_policy(w, obs, deterministic=True)
+        else:
+            sfx = "_1" if name.startswith("copo") else ""
+            mean = G._compute_actions_for_tf_policy(w, obs, deterministic=True, policy_name="default", layer_name_suffix=sfx)
+        save[name + "/mean"] = mean
+        np.random.seed(11)
+        save[name + "/sampled"] = f(obs)                      # stochastic path under a fixed numpy seed
+        # dict API incl. the LCF ("svo") column of CoPO policies
+        pf = G.PolicyFunction(model_name=name, checkpoint_dir_name="best_checkpoints")
+        base = rng.uniform(0, 1, size=(5, 91)).astype(np.float32)
+        obs_dict = {"agent%d" % i: base[i] for i in range(5)}
+        done = {"agent1": True, "agent3": False}
+        np.random.seed(13)
+        act = pf(obs_dict, done)
+        save[name + "/dict_obs"] = base
+        save[name + "/dict_keys"] = np.array(sorted(act.keys()))
+        save[name + "/dict_actions"] = np.stack([act[k] for k in sorted(act.keys())])
+        if name.startswith("copo"):
+            save[name + "/lcf"] = np.array(G.meta_svo_lookup_table[name])
+            save[name + "/dict_lcf"] = np.array([pf.existing_svo[k] for k in sorted(pf.existing_svo)])
+    np.savez_compressed(os.path.join(OUT, "eval_policy_function.npz"), **save)
+    print("wrote eval_policy_function.npz", os.path.getsize(os.path.join(OUT, "eval_policy_function.npz")))
+
+
+if __name__ == "__main__":
+    if not os.path.isdir(ref_stubs.REFERENCE_ROOT):
+        sys.exit("reference tree not present; fixtures are committed under tests/golden/")
+    main()

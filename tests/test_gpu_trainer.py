@@ -205,3 +205,27 @@ print("RESULT " + json.dumps(dict(dist=D.is_dist(), lcf=a.policy.model.lcf_param
     np.testing.assert_allclose(outs[1]["lcf"], outs[0]["lcf"], rtol=1e-5, atol=1e-8)
     np.testing.assert_allclose(outs[1]["w"], outs[0]["w"], rtol=1e-5)
     np.testing.assert_allclose(outs[1]["loss"], outs[0]["loss"], rtol=1e-3, atol=1e-5)
+
+
+def test_reference_population_in_the_hip_simulator(golden_dir):
+    """f-1 / f-2: a population the reference trained (weights held as data in the eval fixture) is loaded through the
+    reference's `.npz` key layout and rolled in the HIP simulator: the device model's action means on LIVE observations
+    equal the reference-style numpy policy function's, and the evaluation metrics are a proper partition."""
+    from copo_amd.eval import get_policy_function as G
+    from copo_amd.eval.checkpoint_io import load_policy_weights
+    from copo_amd.eval.evaluate import make_eval_trainer
+    gold = np.load(os.path.join(golden_dir, "eval_policy_function.npz"))
+    w = {k[len("copo_inter/w/"):]: gold[k] for k in gold.files if k.startswith("copo_inter/w/")}
+    t = make_eval_trainer("copo", "inter", num_envs=16, num_agents=40, seed=0, lcf=G.meta_svo_lookup_table["copo_inter"])
+    load_policy_weights(t.policy.model, w)
+    res = t.evaluate(num_fragments=2, min_episodes=300)
+    rates = [res[k] for k in ("success_rate_mean", "crash_rate_mean", "out_of_road_rate_mean", "max_step_rate_mean")]
+    assert res["num_terminated_agents"] >= 300 and all(0.0 <= r <= 1.0 for r in rates) and abs(sum(rates) - 1.0) < 1e-9
+    assert abs(t.env.current_lcf_mean - 0.36824979071031544) < 1e-12
+    obs = t.sampler.obs[0].reshape(-1, 92)
+    live = obs[t.sampler.flags[0].reshape(-1) > 0][:256]
+    logits, _ = t.policy.model({"obs": live})
+    ref = G._compute_actions_for_tf_policy(w, live.cpu().numpy(), deterministic=True, policy_name="default", layer_name_suffix="_1")
+    np.testing.assert_allclose(logits[:, :2].detach().cpu().numpy(), ref, rtol=1e-4, atol=1e-5)
+    assert float(live[:, -1].min()) >= 0.0 and float(live[:, -1].max()) <= 1.0      # (lcf + 1) / 2 column
+    t.stop()
