@@ -32,7 +32,8 @@ struct copo_sim {
     int block;
     bool started;
     double lcf_mean, lcf_std, force_lcf;
-    float lcf_host[2];
+    int capacity;              // active agent slots (curriculum), num_agents by default
+    float lcf_host[4];         // {mean, std, capacity, 0}: what the kernels read from p.lcf_dist
     bool lcf_dirty;
     std::vector<void*> allocs;
 };
@@ -94,6 +95,7 @@ extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** o
     s->lcf_mean = cfg->lcf_mean;
     s->lcf_std = cfg->lcf_std;
     s->force_lcf = -100.0;
+    s->capacity = cfg->num_agents;
     s->lcf_dirty = true;
     s->block = pick_block(cfg->num_envs);
     if (hipSetDevice(device) != hipSuccess) {
@@ -128,7 +130,7 @@ extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** o
     if (rc == COPO_OK && (rc = dev_alloc(COPO_STATE_FIELDS * EN * 4, &d)) == COPO_OK) p.state = (float*)d;
     if (rc == COPO_OK && (rc = dev_alloc((size_t)p.E * 16, &d)) == COPO_OK) p.env = (int32_t*)d;
     if (rc == COPO_OK && (rc = dev_alloc((size_t)p.E * 8, &d)) == COPO_OK) p.seeds = (const uint64_t*)d;
-    if (rc == COPO_OK && (rc = dev_alloc(8, &d)) == COPO_OK) p.lcf_dist = (const float*)d;
+    if (rc == COPO_OK && (rc = dev_alloc(16, &d)) == COPO_OK) p.lcf_dist = (const float*)d;
     if (rc == COPO_OK)
         rc = upload(s, cfg->route_segs, (size_t)cfg->n_routes * (COPO_MAX_SEGS + 1) * COPO_SEG_STRIDE, &p.route_segs);
     if (rc == COPO_OK) rc = upload(s, cfg->route_meta, (size_t)cfg->n_routes * 4, &p.route_meta);
@@ -160,7 +162,9 @@ static int flush_lcf(copo_sim* s, hipStream_t st) {
     if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return COPO_OK;
     s->lcf_host[0] = (float)((s->force_lcf != -100.0) ? s->force_lcf : s->lcf_mean);
     s->lcf_host[1] = (float)s->lcf_std;
-    HIP_TRY(hipMemcpyAsync(const_cast<float*>(s->p.lcf_dist), s->lcf_host, 8, hipMemcpyHostToDevice, st));
+    s->lcf_host[2] = (float)s->capacity;
+    s->lcf_host[3] = 0.0f;
+    HIP_TRY(hipMemcpyAsync(const_cast<float*>(s->p.lcf_dist), s->lcf_host, 16, hipMemcpyHostToDevice, st));
     s->lcf_dirty = false;
     return COPO_OK;
 }
@@ -176,6 +180,14 @@ extern "C" int copo_sim_set_lcf_dist(copo_sim* s, double mean, double std) {
         return fail(COPO_ERR_CONFIG, "set_lcf_dist(mean=%g, std=%g): need -1 <= mean <= 1, std > 0", mean, std);
     s->lcf_mean = mean;
     s->lcf_std = std;
+    s->lcf_dirty = true;
+    return COPO_OK;
+}
+
+extern "C" int copo_sim_set_capacity(copo_sim* s, int32_t capacity) {
+    if (!s) return fail(COPO_ERR_NULL, "copo_sim_set_capacity: NULL handle");
+    if (capacity < 1 || capacity > s->p.N) return fail(COPO_ERR_CONFIG, "capacity=%d not in [1, %d]", capacity, s->p.N);
+    s->capacity = capacity;
     s->lcf_dirty = true;
     return COPO_OK;
 }

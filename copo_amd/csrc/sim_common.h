@@ -30,7 +30,7 @@ struct SimParams {
     const float* spawn_s;          // [P]
     const float* ray_cs;           // [num_lasers][2]
     long long* dbg;                // optional [E][8] phase timestamps (clock64) of the step kernel; NULL = off
-    const float* lcf_dist;         // [2] = {mean (force_lcf folded in), std}: device memory so that captured graphs see updates
+    const float* lcf_dist;         // [4] = {mean (force_lcf folded in), std, capacity, 0}: device memory so that captured graphs see updates
 };
 
 using StepOut = copo_step_out;

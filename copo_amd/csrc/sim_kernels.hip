@@ -127,6 +127,12 @@ struct __align__(16) EnvLds {
     int32_t ntasks;            // LiDAR task list fill
 };
 
+// active agent slots: device memory next to the LCF distribution, so that captured graphs see updates
+__device__ __forceinline__ int capacity_of(const SimParams& p) {
+    const int c = (int)p.lcf_dist[2];
+    return c < 1 ? 1 : (c > p.N ? p.N : c);
+}
+
 // Full reset of one env by wave 0 (all lanes call; lane n < N owns slot n).
 __device__ __forceinline__ void reset_env_wave0(const SimParams& p, EnvLds& L, uint64_t seed, uint32_t episode, int lane,
                                                 Slot& s) {
@@ -144,7 +150,10 @@ __device__ __forceinline__ void reset_env_wave0(const SimParams& p, EnvLds& L, u
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if (lane < p.N) spawn_slot(p, seed, episode, lane, (int)L.perm[lane], lane, s);
+    // population capacity (curriculum): slots beyond it start empty and never respawn
+    const int cap = capacity_of(p);
+    if (lane < cap) spawn_slot(p, seed, episode, lane, (int)L.perm[lane], lane, s);
+    else if (lane < p.N) s.status = ST_EMPTY;
 }
 
 // neighbour lists + reward reductions (CCEnv / LCFEnv) for agents i = wave, wave+nw, ...; lane = other agent j
@@ -412,13 +421,14 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_reset_kernel(SimParams
         const uint64_t seed = p.seeds[e];
         s = Slot{};
         reset_env_wave0(p, L, seed, 0u, lane, s);
+        const int cap = capacity_of(p);
         if (lane < N) {
             stage_pose(L, lane, s);
             store_slot(p, e, lane, s);
             L.rew[lane] = 0.0f;
             const size_t o = (size_t)e * N + lane;
             if (out.rew) out.rew[o] = 0.0f;
-            if (out.flags) out.flags[o] = COPO_F_SPAWNED;
+            if (out.flags) out.flags[o] = lane < cap ? COPO_F_SPAWNED : 0;
             if (out.lcf) out.lcf[o] = s.lcf;
             if (out.agent_id) out.agent_id[o] = s.aid;
             if (out.info)
@@ -426,15 +436,15 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_reset_kernel(SimParams
         } else {
             L.x[lane] = 0.0f; L.y[lane] = 0.0f; L.cs[lane] = 1.0f; L.sn[lane] = 0.0f; L.rew[lane] = 0.0f;
         }
-        const unsigned long long all = __ballot(lane < N);
+        const unsigned long long all = __ballot(lane < cap);
         if (lane == 0) {
             L.m_present = all;
             L.m_solid = all;
             L.m_acted = 0ull;
             int32_t* env = p.env + (size_t)e * 4;
-            env[0] = 0; env[1] = 0; env[2] = N; env[3] = 1;
+            env[0] = 0; env[1] = 0; env[2] = cap; env[3] = 1;
         }
-        ego_navi_obs(p, L, lane, s, lane < N);
+        ego_navi_obs(p, L, lane, s, lane < cap);
     }
     __syncthreads();
     neighbours_phase(p, L, e, wave, nwaves, lane, out);
@@ -616,7 +626,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
         present = acted;
         // respawn, serial over eligible slots in slot order; every lane tests its own vehicle
         if (!ending) {
-            unsigned long long elig = __ballot(lane < N && !acted && s.status == ST_EMPTY);
+            unsigned long long elig = __ballot(lane < capacity_of(p) && !acted && s.status == ST_EMPTY);
             while (elig) {
                 const int n = __ffsll((long long)elig) - 1;
                 elig &= elig - 1;
@@ -672,12 +682,13 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
             episode += 1;
             next_aid = 0;
             reset_env_wave0(p, L, seed, (uint32_t)episode, lane, s);
-            next_aid = N;
-            present = lane < N;
-            fl_out |= COPO_F_SPAWNED | COPO_F_ENV_RESET;
-            if (!acted) lcf_out = s.lcf;
+            const int cap = capacity_of(p);
+            next_aid = cap;
+            present = lane < cap;
+            fl_out |= (lane < cap ? COPO_F_SPAWNED : 0) | COPO_F_ENV_RESET;
+            if (!acted && lane < cap) lcf_out = s.lcf;
             if (lane < N) stage_pose(L, lane, s);
-            const unsigned long long all = __ballot(lane < N);
+            const unsigned long long all = __ballot(lane < cap);
             if (lane == 0) {
                 L.m_present = all;
                 L.m_solid = all;

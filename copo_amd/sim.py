@@ -154,6 +154,10 @@ class VecSim:
     def set_force_lcf(self, v):
         self._capi.check(self._capi.lib.copo_sim_set_force_lcf(self._h, float(v)))
 
+    def set_capacity(self, capacity):
+        """Active agent slots (curriculum): takes effect for respawns from the next step, for everything after a reset."""
+        self._capi.check(self._capi.lib.copo_sim_set_capacity(self._h, int(capacity)))
+
     def flush(self):
         """Push pending set_lcf_dist/set_force_lcf values to the device (needed before replaying a captured graph)."""
         self._capi.check(self._capi.lib.copo_sim_flush(self._h, self._stream()))

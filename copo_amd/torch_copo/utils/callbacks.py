@@ -14,6 +14,46 @@ class DefaultCallbacks:
         pass
 
 
+def curriculum_num_agents(target_num_agents, timestep, total_time_step):
+    """Population of the curriculum baseline at `timestep` (algo_ippo/ippo_cl.py:41-66): a quarter of the target per
+    quarter of training, `int(target / 4 * q)`."""
+    q = 1 + sum(1 for k in (1, 2, 3) if timestep > total_time_step / 4 * k)
+    return int(target_num_agents / 4 * q)
+
+
+def get_change_n_callback(total_time_step):
+    """`ChangeNCallback` of the reference (algo_ippo/ippo_cl.py:41-78) for the vectorised trainer: after every
+    training iteration the env-step count decides the population; when it changes, every scene is re-populated
+    (`close_and_reset_num_agents` + reset)."""
+    class ChangeNCallback(MultiAgentDrivingCallbacks):
+        def __init__(self):
+            super(ChangeNCallback, self).__init__()
+            self.target_num_agents = None
+            self.current = None
+            self.total_time_step = total_time_step
+
+        def on_algorithm_init(self, *, algorithm, **kwargs):
+            self.apply(algorithm, 0)          # the first quarter of the population from the first rollout on
+
+        def on_train_result(self, *, algorithm, result, **kwargs):
+            super(ChangeNCallback, self).on_train_result(algorithm=algorithm, result=result, **kwargs)
+            self.apply(algorithm, result["timesteps_total"])
+            result["custom_metrics"]["num_agents_curriculum"] = self.current
+
+        def apply(self, algorithm, timestep):
+            if self.target_num_agents is None:
+                # the reference reads the env class's default population; here that is the simulator's slot count
+                self.target_num_agents = algorithm.env.sim.N
+            n = curriculum_num_agents(self.target_num_agents, timestep, self.total_time_step)
+            if n != self.current:
+                print("Current time step: {}. We are now setting all environments with {} agents!".format(timestep, n))
+                algorithm.env.close_and_reset_num_agents(n)
+                algorithm.sampler.reset()
+                self.current = n
+
+    return ChangeNCallback
+
+
 class MultiAgentDrivingCallbacks(DefaultCallbacks):
     STEP_KEYS = ("velocity", "steering", "step_reward", "acceleration", "cost", "episode_length", "episode_reward",
                  "num_neighbours")

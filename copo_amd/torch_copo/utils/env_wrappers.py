@@ -275,17 +275,20 @@ def get_lcf_env(env_class):
 
 
 def get_change_n_env(env_class):
-    """Curriculum wrapper of the reference (:444-460): re-create the env with another population."""
+    """Curriculum wrapper of the reference (:444-460).  The reference closes the env and constructs it again with
+    another `num_agents`; here the simulator keeps its N slots and only the first `num_agents` of them are populated
+    (`copo_sim_set_capacity`), so rollout buffers, captured graphs and the model stay as they are.  As in the
+    reference, a `reset()` must follow."""
     class ChangeNEnv(env_class):
         def __init__(self, config):
             self._raw_input_config = copy.deepcopy(config)
             super(ChangeNEnv, self).__init__(config)
+            self.current_num_agents = self.sim.N
 
         def close_and_reset_num_agents(self, num_agents):
-            config = copy.deepcopy(self._raw_input_config)
-            self.close()
-            config["num_agents"] = num_agents
-            super(ChangeNEnv, self).__init__(config)
+            num_agents = max(1, min(int(num_agents), self.sim.N))
+            self.sim.set_capacity(num_agents)
+            self.current_num_agents = num_agents
 
     ChangeNEnv.__name__ = ChangeNEnv.__qualname__ = "CL{}".format(env_class.__name__)
     return ChangeNEnv

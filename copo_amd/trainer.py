@@ -523,6 +523,8 @@ class VecTrainer:
         self.sampler = VecSampler(self.env, self.policy, T, use_graph=cfg.get("use_hip_graphs", True))
         self.workers = _LocalWorkerSet(self)
         self._episode_stats = defaultdict(float)
+        if self.callbacks is not None and hasattr(self.callbacks, "on_algorithm_init"):
+            self.callbacks.on_algorithm_init(algorithm=self)
 
     # ---- RLlib-shaped accessors -----------------------------------------------------------------------------
     def get_policy(self, policy_id="default"):

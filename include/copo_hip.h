@@ -145,6 +145,11 @@ int copo_sim_set_lcf_dist(copo_sim* sim, double mean, double std);
 int copo_sim_flush(copo_sim* sim, void* stream);
 /* LCFEnv.set_force_lcf (env_wrappers.py:428-430): v == -100 disables */
 int copo_sim_set_force_lcf(copo_sim* sim, double v);
+/* Population capacity, 1 <= capacity <= num_agents (default): slots >= capacity are left empty by a reset and never
+ * respawn; vehicles already driving in them finish their episode.  With a following copo_sim_reset this is
+ * `ChangeNEnv.close_and_reset_num_agents` of the curriculum baseline (env_wrappers.py:444-460) without re-creating
+ * the simulator.  Device-resident like the LCF distribution (pushed by the next reset / step / flush). */
+int copo_sim_set_capacity(copo_sim* sim, int32_t capacity);
 /* act: [E][N][2] device fp32 (clipped to [-1,1] inside, as RLlib's clip_actions does) */
 int copo_sim_step(copo_sim* sim, const float* act, const copo_step_out* out, void* stream);
 /* raw state access for tests / checkpointing: [COPO_STATE_FIELDS][E][N] fp32 words + [E][4] int32 env words */

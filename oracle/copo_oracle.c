@@ -139,6 +139,7 @@ typedef struct oracle_sim {
     int32_t* env;   /* [E][4] */
     uint64_t* seeds;
     double lcf_mean, lcf_std, force_lcf;
+    int capacity;              /* active agent slots (curriculum); num_agents by default */
 } oracle_sim;
 
 static float* FP(oracle_sim* s, int f, int e) { return s->st + ((size_t)f * s->cfg.num_envs + e) * s->cfg.num_agents; }
@@ -170,6 +171,7 @@ int oracle_sim_create(const copo_sim_cfg* cfg, oracle_sim** out) {
     s->lcf_mean = cfg->lcf_mean;
     s->lcf_std = cfg->lcf_std;
     s->force_lcf = -100.0;
+    s->capacity = cfg->num_agents;
     *out = s;
     return COPO_OK;
 }
@@ -183,6 +185,7 @@ int oracle_sim_destroy(oracle_sim* s) {
 
 int oracle_sim_set_lcf_dist(oracle_sim* s, double mean, double std) { s->lcf_mean = mean; s->lcf_std = std; return COPO_OK; }
 int oracle_sim_set_force_lcf(oracle_sim* s, double v) { s->force_lcf = v; return COPO_OK; }
+int oracle_sim_set_capacity(oracle_sim* s, int capacity) { s->capacity = capacity; return COPO_OK; }
 
 int oracle_sim_get_state(oracle_sim* s, float* slot_state, int32_t* env_state) {
     size_t E = s->cfg.num_envs, N = s->cfg.num_agents;
@@ -242,6 +245,11 @@ static void spawn_agent(oracle_sim* s, int e, int n, int sp) {
     IP(s, S_SPAWNCNT, e)[n] = (int32_t)(cnt + 1);
 }
 
+static int oracle_capacity(const oracle_sim* s) {
+    int c = s->capacity, N = s->cfg.num_agents;
+    return c < 1 ? 1 : (c > N ? N : c);
+}
+
 static void reset_env(oracle_sim* s, int e) {
     const copo_sim_cfg* c = &s->cfg;
     int N = c->num_agents, P = c->n_spawns;
@@ -255,7 +263,12 @@ static void reset_env(oracle_sim* s, int e) {
         int j = i + (int)(h % (uint32_t)(P - i));
         int t = perm[i]; perm[i] = perm[j]; perm[j] = t;
     }
-    for (int n = 0; n < N; ++n) spawn_agent(s, e, n, perm[n]);
+    /* population capacity (curriculum): slots beyond it start empty and never respawn */
+    int cap = oracle_capacity(s);
+    for (int n = 0; n < N; ++n) {
+        if (n < cap) spawn_agent(s, e, n, perm[n]);
+        else IP(s, S_STATUS, e)[n] = ST_EMPTY;
+    }
 }
 
 /* projection of (x,y) on route segment k: returns local arclength, lateral offset (left +), route heading */
@@ -481,8 +494,8 @@ int oracle_sim_reset(oracle_sim* s, const uint64_t* seeds, const copo_step_out* 
         memset(&t, 0, sizeof(t));
         uint8_t present[COPO_MAX_AGENTS];
         for (int n = 0; n < N; ++n) {
-            present[n] = 1;
-            t.fl[n] = COPO_F_SPAWNED;
+            present[n] = n < oracle_capacity(s);
+            t.fl[n] = present[n] ? COPO_F_SPAWNED : 0;
             t.lcf_row[n] = FP(s, S_LCF, e)[n];
             t.aid_row[n] = IP(s, S_AID, e)[n];
         }
@@ -641,6 +654,7 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
         /* 7. respawn (serial in slot order) */
         if (!ending) {
             for (int n = 0; n < N; ++n) {
+                if (n >= oracle_capacity(s)) break;
                 if (t.acted[n] || STA[n] != ST_EMPTY) continue; /* EMPTY with timer 0 only */
                 uint32_t cnt = (uint32_t)IP(s, S_SPAWNCNT, e)[n];
                 for (uint32_t a = 0; a < 3; ++a) {
@@ -674,9 +688,9 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
             env[1] += 1;
             reset_env(s, e);
             for (int n = 0; n < N; ++n) {
-                present[n] = 1;
-                if (out->flags) out->flags[(size_t)e * N + n] |= COPO_F_SPAWNED | COPO_F_ENV_RESET;
-                if (out->lcf && !t.acted[n]) out->lcf[(size_t)e * N + n] = FP(s, S_LCF, e)[n];
+                present[n] = n < oracle_capacity(s);
+                if (out->flags) out->flags[(size_t)e * N + n] |= (present[n] ? COPO_F_SPAWNED : 0) | COPO_F_ENV_RESET;
+                if (out->lcf && !t.acted[n] && present[n]) out->lcf[(size_t)e * N + n] = FP(s, S_LCF, e)[n];
             }
         }
         if (out->obs) write_obs(s, e, out, present);

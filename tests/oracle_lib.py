@@ -106,6 +106,9 @@ class OracleSim:
     def set_force_lcf(self, v):
         lib().oracle_sim_set_force_lcf(self._h, C.c_double(v))
 
+    def set_capacity(self, capacity):
+        lib().oracle_sim_set_capacity(self._h, C.c_int(int(capacity)))
+
     def get_state(self):
         st = np.zeros((STATE_FIELDS, self.E, self.N), np.float32)
         env = np.zeros((self.E, 4), np.int32)

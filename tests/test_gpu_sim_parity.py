@@ -131,3 +131,45 @@ def test_error_codes():
         g.set_lcf_dist(2.0, 0.1)
     with pytest.raises(_capi.CopoError):
         g.set_lcf_dist(0.0, 0.0)
+
+
+def test_population_capacity_bit_exact_and_respected():
+    """Curriculum capacity (copo_sim_set_capacity; `ChangeNEnv.close_and_reset_num_agents`, env_wrappers.py:444-460):
+    HIP == oracle bit for bit through capacity changes at a reset, mid-episode and across the horizon reset; slots
+    beyond the capacity never spawn; vehicles already driving there finish their episode."""
+    import torch
+    import oracle_lib as ol
+    from copo_amd.sim import SimConfig, VecSim
+    E, N = 4, 40
+    cfg = SimConfig(map="intersection", num_envs=E, num_agents=N, horizon=70, nbr_k=8, delay_done=5)
+    g, o = VecSim(cfg), ol.OracleSim(cfg)
+    seeds = np.arange(E, dtype=np.uint64) + np.uint64(77)
+    for s in (g, o):
+        s.set_capacity(10)
+    r = g.reset(seeds)
+    _compare("reset cap 10", r, o.reset(seeds))
+    fl = r["flags"].cpu().numpy()
+    assert (fl[:, :10] & 64).all() and not fl[:, 10:].any()          # COPO_F_SPAWNED only below the capacity
+    rng = np.random.RandomState(5)
+    seen_hi_spawn = False
+    for t in range(230):
+        if t == 50:
+            for s in (g, o):
+                s.set_capacity(30)        # grows mid-episode: slots 10..29 fill through the respawn path
+        if t == 120:
+            for s in (g, o):
+                s.set_capacity(20)        # shrinks: agents in slots 20..29 drive on, then the slots stay empty
+        a = _actions(rng, E, N, t)
+        go, oo = g.step(torch.from_numpy(a).cuda()), o.step(a)
+        _compare("capacity step %d" % t, go, oo)
+        fl = oo["flags"]
+        cap = 10 if t < 50 else (30 if t < 120 else 20)
+        assert not (fl[:, cap:] & 64).any(), t                        # nobody spawns beyond the capacity
+        if 50 <= t < 120:
+            seen_hi_spawn |= bool((fl[:, 10:30] & 64).any())
+    assert seen_hi_spawn
+    st, _ = g.get_state()
+    status = st.cpu().numpy().view(np.int32)[12] & 0xff
+    assert (status[:, 30:] == 0).all()
+    g.close()
+    o.close()

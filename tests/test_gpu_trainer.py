@@ -229,3 +229,28 @@ def test_reference_population_in_the_hip_simulator(golden_dir):
     np.testing.assert_allclose(logits[:, :2].detach().cpu().numpy(), ref, rtol=1e-4, atol=1e-5)
     assert float(live[:, -1].min()) >= 0.0 and float(live[:, -1].max()) <= 1.0      # (lcf + 1) / 2 column
     t.stop()
+
+
+def test_curriculum_baseline_schedule():
+    """f-3: the curriculum baseline (algo_ippo/ippo_cl.py:41-78): a quarter of the target population per quarter of
+    training, applied through `ChangeNEnv.close_and_reset_num_agents` (population capacity of the simulator)."""
+    from copo_amd.torch_copo.algo_ippo import IPPOTrainer
+    from copo_amd.torch_copo.utils.callbacks import curriculum_num_agents, get_change_n_callback
+    from copo_amd.torch_copo.utils.env_wrappers import MultiAgentIntersectionEnv, get_change_n_env, get_rllib_compatible_env
+    assert [curriculum_num_agents(30, t, 1000) for t in (0, 250, 251, 500, 501, 750, 751, 1000)] == [7, 7, 15, 15, 22, 22, 30, 30]
+    env = get_rllib_compatible_env(get_change_n_env(MultiAgentIntersectionEnv))
+    total = 8 * 16 * 8                     # 8 iterations of 16 scenes x 8 steps
+    a = IPPOTrainer(config=dict(env=env, env_config=dict(num_agents=20, horizon=40), num_envs=16, train_batch_size=16 * 8,
+                                sgd_minibatch_size=128, num_sgd_iter=1, seed=0, callbacks=get_change_n_callback(total),
+                                model={"fcnet_hiddens": [64, 64]}))
+    seen = []
+    for it in range(8):
+        res = a.train()
+        n = a.env.current_num_agents
+        seen.append(n)
+        fl = a.sampler.flags.reshape(a.sampler.T, 16, 20)
+        assert not (fl[:, :, n:] & 1).any()          # nobody acts in a slot beyond the (growing) population
+        assert (fl[:, :, :seen[max(0, it - 1)]] & 1).any()
+        assert res["custom_metrics"]["num_agents_curriculum"] == n
+    assert seen == [5, 5, 10, 10, 15, 15, 20, 20], seen     # quarters at 256 / 512 / 768 of 1024 env steps
+    a.stop()
