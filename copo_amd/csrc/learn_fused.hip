@@ -451,24 +451,26 @@ constexpr float kLog2Pi = 1.8378770664093453f;
 // policy net (algo_copo.py:311-424), the clipped value losses for the value nets, the two meta-gradient heads.
 // st: total, policy, vf_ego, kl, entropy, vf_nei, vf_glob, adv  (already weighted by wgt = w / denom)
 struct RowIn {            // the pack columns (and the KL coefficient) the loss terms of one row read
-    float act[2], logp, adv, dist[4], vpred, vtarget, klc;
+    float act0, act1, logp, adv, dist0, dist1, dist2, dist3, vpred, vtarget, klc;     // scalars: stays in registers
 };
 
 // issued early (the loads are dependent on the row index and miss L2), consumed by head_row_terms much later
 __device__ __forceinline__ RowIn load_row_in(const FusedArgs& a, int g, int mode, bool policy, const float* pk) {
     const copo_ppo_cfg& c = a.c;
     RowIn ri;
-    ri.act[0] = ri.act[1] = ri.logp = ri.adv = ri.vpred = ri.vtarget = ri.klc = 0.0f;
-    ri.dist[0] = ri.dist[1] = ri.dist[2] = ri.dist[3] = 0.0f;
+    ri.act0 = ri.act1 = ri.logp = ri.adv = ri.vpred = ri.vtarget = ri.klc = 0.0f;
+    ri.dist0 = ri.dist1 = ri.dist2 = ri.dist3 = 0.0f;
     if (policy) {
-        ri.act[0] = pk[c.col_actions];
-        ri.act[1] = pk[c.col_actions + 1];
+        ri.act0 = pk[c.col_actions];
+        ri.act1 = pk[c.col_actions + 1];
         if (mode != COPO_HEAD_META_OLD) {
             ri.adv = pk[mode == COPO_HEAD_META_NEW ? c.col_meta_adv : c.col_adv];
             ri.logp = pk[c.col_logp];
             if (mode == COPO_HEAD_PPO && c.use_kl) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) ri.dist[j] = pk[c.col_dist + j];
+                ri.dist0 = pk[c.col_dist];
+                ri.dist1 = pk[c.col_dist + 1];
+                ri.dist2 = pk[c.col_dist + 2];
+                ri.dist3 = pk[c.col_dist + 3];
                 ri.klc = a.kl_coeff[0];
             }
         }
@@ -489,7 +491,7 @@ __device__ __forceinline__ void head_row_terms(const FusedArgs& a, int g, int mo
                 for (int j = 0; j < 2; ++j) {
                     const float mu = out[j], ls = out[A + j];
                     sig[j] = expf(ls);
-                    z[j] = (ri.act[j] - mu) / sig[j];
+                    z[j] = ((j == 0 ? ri.act0 : ri.act1) - mu) / sig[j];
                     logp += -0.5f * z[j] * z[j] - ls - 0.5f * kLog2Pi;
                     ent += ls + 0.5f + 0.5f * kLog2Pi;
                 }
@@ -515,7 +517,7 @@ __device__ __forceinline__ void head_row_terms(const FusedArgs& a, int g, int mo
                     if (ppo && c.use_kl) {
     #pragma unroll
                         for (int j = 0; j < 2; ++j) {
-                            const float mup = ri.dist[j], lsp = ri.dist[A + j];
+                            const float mup = j == 0 ? ri.dist0 : ri.dist1, lsp = j == 0 ? ri.dist2 : ri.dist3;
                             const float sp = expf(lsp), dm = mup - out[j];
                             const float q = (sp * sp + dm * dm) / (sig[j] * sig[j]);
                             kl += out[A + j] - lsp + 0.5f * q - 0.5f;
@@ -718,45 +720,63 @@ template <> struct ColVec<1> { typedef float T; static __device__ __forceinline_
 template <> struct ColVec<2> { typedef v2f T; static __device__ __forceinline__ float get(const v2f& v, int i) { return v[i]; } };
 template <> struct ColVec<4> { typedef v4f T; static __device__ __forceinline__ float get(const v4f& v, int i) { return v[i]; } };
 
+// Ring of D steps of B operands for the [K][wstride]-layout GEMM.  `start` issues the first D steps' loads and can be
+// called long before `run` (the loads depend only on the weights): the L2-missing first touch of the weights then
+// overlaps whatever the workgroup does in between (input gather, the previous layer's epilogue, the heads).
 template <int NT, int D>
-__device__ __forceinline__ void rowgemm_bwd(const float* As, int astride, const float* W, int wstride, int k, int cb, int ln,
-                                            int lj, v4f* acc) {
-    constexpr int VW = NT >= 4 ? 4 : NT, NV = NT / VW;     // vector width of a load, loads per k
+struct BRing {
+    static constexpr int VW = NT >= 4 ? 4 : NT, NV = NT / VW;     // vector width of a load, loads per k
     typedef typename ColVec<VW>::T vec_t;
-    const float* arow = As + ln * astride + 4 * lj;
-    const float* wcol = W + (size_t)(4 * lj) * wstride + cb + NT * ln;
-    const int ns = k >> 4;                     // multiple of D
     vec_t b[D][4][NV];
+    const float* wcol;
+    int wstride;
+    __device__ __forceinline__ void start(const float* W, int wstride_, int cb, int ln, int lj) {
+        wstride = wstride_;
+        wcol = W + (size_t)(4 * lj) * wstride + cb + NT * ln;
 #pragma unroll
-    for (int u = 0; u < D; ++u)
+        for (int u = 0; u < D; ++u)
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int q = 0; q < NV; ++q) b[u][e][q] = *reinterpret_cast<const vec_t*>(wcol + (size_t)(16 * u + e) * wstride + VW * q);
-    for (int s0 = 0; s0 < ns; s0 += D) {
+                for (int q = 0; q < NV; ++q) b[u][e][q] = *reinterpret_cast<const vec_t*>(wcol + (size_t)(16 * u + e) * wstride + VW * q);
+    }
+    // acc[t] += A[16 x k] * W for output columns cb + NT (l & 15) + t; k a multiple of 16 D
+    __device__ __forceinline__ void run(const float* As, int astride, int k, int ln, int lj, v4f* acc) {
+        const float* arow = As + ln * astride + 4 * lj;
+        const int ns = k >> 4;
+        for (int s0 = 0; s0 < ns; s0 += D) {
 #pragma unroll
-        for (int u = 0; u < D; ++u) {
-            const int s = s0 + u;
-            const float4 a4 = *reinterpret_cast<const float4*>(arow + 16 * s);
-            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-            if constexpr (VW > 1) {
+            for (int u = 0; u < D; ++u) {
+                const int s = s0 + u;
+                const float4 a4 = *reinterpret_cast<const float4*>(arow + 16 * s);
+                const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+                if constexpr (VW > 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int q = 0; q < NV; ++q) asm volatile("" : "+v"(b[u][e][q]));      // one register tuple per load (see rowgemm_fwd)
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int q = 0; q < NV; ++q) asm volatile("" : "+v"(b[u][e][q]));      // one register tuple per load (see rowgemm_fwd)
+                    for (int t = 0; t < NT; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], ColVec<VW>::get(b[u][e][t / VW], t % VW), acc[t], 0, 0, 0);
+                const int sn = s + D < ns ? s + D : ns - 1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int q = 0; q < NV; ++q) b[u][e][q] = *reinterpret_cast<const vec_t*>(wcol + (size_t)(16 * sn + e) * wstride + VW * q);
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], ColVec<VW>::get(b[u][e][t / VW], t % VW), acc[t], 0, 0, 0);
-            const int sn = s + D < ns ? s + D : ns - 1;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int q = 0; q < NV; ++q) b[u][e][q] = *reinterpret_cast<const vec_t*>(wcol + (size_t)(16 * sn + e) * wstride + VW * q);
         }
     }
+};
+
+template <int NT, int D>
+__device__ __forceinline__ void rowgemm_bwd(const float* As, int astride, const float* W, int wstride, int k, int cb, int ln,
+                                            int lj, v4f* acc) {
+    BRing<NT, D> r;
+    r.start(W, wstride, cb, ln, lj);
+    r.run(As, astride, k, ln, lj, acc);
 }
 
 constexpr int RP_D1 = 4;      // prefetch ring depth of the layer-1 GEMM (its K is padded to 32 * RP_D1)
@@ -797,6 +817,10 @@ __global__ void __launch_bounds__(64 * WAVES) rowpass_kernel(FusedArgs a) {
     // the first kernel of an SGD step advances the Adam step counter (its only reader is the fold at the end)
     if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) first_kernel_duties(a);
     RP_STAMP(0);
+    // TW: the first ring of layer-1 weights is requested before anything else
+    constexpr bool EARLY = NT <= 2;          // two rings in flight fit the register file only for narrow waves
+    BRing<NT, DB> ring1, ring2, ring3;
+    if (TW) ring1.start(a.theta_t + L.w1, H, cb, ln, lj);
     const int64_t kb = kb_of(a, g);
     // head bookkeeping: TPR threads per row; the dependent loads (k -> row index -> pack row) are issued here and
     // consumed after both layers
@@ -827,8 +851,10 @@ __global__ void __launch_bounds__(64 * WAVES) rowpass_kernel(FusedArgs a) {
     // ---- layer 1 ----
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
-    if (TW) rowgemm_bwd<NT, DB>(xs, XP, a.theta_t + L.w1, H, K1P, cb, ln, lj, acc);
-    else if (!(a.dbg & 1)) rowgemm_fwd<NT, DF>(xs, XP, theta + L.w1, K1, K1P, cb, ln, lj, acc);
+    if (TW) {
+        if (EARLY) ring2.start(a.theta_t + L.w2, H, cb, ln, lj);       // layer-2 weights travel while layer 1 computes
+        ring1.run(xs, XP, K1P, ln, lj, acc);
+    } else if (!(a.dbg & 1)) rowgemm_fwd<NT, DF>(xs, XP, theta + L.w1, K1, K1P, cb, ln, lj, acc);
     {
         float* h1g = a.ws + ws_h1(a, g);
 #pragma unroll
@@ -849,8 +875,11 @@ __global__ void __launch_bounds__(64 * WAVES) rowpass_kernel(FusedArgs a) {
     // ---- layer 2 ----
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
-    if (TW) rowgemm_bwd<NT, DB>(h1s, HP, a.theta_t + L.w2, H, H, cb, ln, lj, acc);
-    else if (!(a.dbg & 2)) rowgemm_fwd<NT, DF2>(h1s, HP, theta + L.w2, H, H, cb, ln, lj, acc);
+    if (TW) {
+        if (!EARLY) ring2.start(a.theta_t + L.w2, H, cb, ln, lj);
+        else ring3.start(theta + L.w2, H, cb, ln, lj);      // W2 as stored, for the activation-gradient GEMM below
+        ring2.run(h1s, HP, H, ln, lj, acc);
+    } else if (!(a.dbg & 2)) rowgemm_fwd<NT, DF2>(h1s, HP, theta + L.w2, H, H, cb, ln, lj, acc);
     {
         float* h2g = a.ws + ws_h2(a, g);
 #pragma unroll
@@ -923,7 +952,11 @@ __global__ void __launch_bounds__(64 * WAVES) rowpass_kernel(FusedArgs a) {
     // ---- dz1 = (dz2 W2) * (1 - h1^2) ----
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
-    if (!(a.dbg & 4)) rowgemm_bwd<NT, DB>(dzs, HP, theta + L.w2, H, H, cb, ln, lj, acc);
+    if (TW) {
+        if (!EARLY) ring3.start(theta + L.w2, H, cb, ln, lj);
+        ring3.run(dzs, HP, H, ln, lj, acc);
+    }
+    else if (!(a.dbg & 4)) rowgemm_bwd<NT, DB>(dzs, HP, theta + L.w2, H, H, cb, ln, lj, acc);
     {
         float* dz1g = a.ws + ws_dz1(a, g);
         // tile t of rowgemm_bwd holds the columns cb + NT * ln + t: a lane stores NT adjacent columns per row
