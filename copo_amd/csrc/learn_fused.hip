@@ -835,13 +835,23 @@ __global__ void __launch_bounds__(64 * WAVES) rowpass_kernel(FusedArgs a) {
     }
     {   // input tile: rows gathered through the minibatch table, float4 per thread, zeros beyond K1 / mb
         const float* src = src_of(a, g);
-        const int qn = K1P >> 2;
-        for (int i = tid; i < HT * qn; i += TH) {
-            const int row = i / qn, k = (i - row * qn) * 4;
-            const bool ok = (m0 + row < c.mb) && (k < K1);
-            const int64_t ridx = a.rows[kb * c.mb + (m0 + row < c.mb ? m0 + row : 0)];
-            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)ridx * K1 + (k < K1 ? k : 0));
-            *reinterpret_cast<float4*>(xs + row * XP + k) = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((K1 & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+            const int qn = K1P >> 2;
+            for (int i = tid; i < HT * qn; i += TH) {
+                const int row = i / qn, k = (i - row * qn) * 4;
+                const bool ok = (m0 + row < c.mb) && (k < K1);
+                const int64_t ridx = a.rows[kb * c.mb + (m0 + row < c.mb ? m0 + row : 0)];
+                const float4 v = *reinterpret_cast<const float4*>(src + (size_t)ridx * K1 + (k < K1 ? k : 0));
+                *reinterpret_cast<float4*>(xs + row * XP + k) = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {      // rows that are not 16-byte aligned (e.g. the 91-dim observation): element-wise gather
+            for (int i = tid; i < HT * K1P; i += TH) {
+                const int row = i / K1P, k = i - row * K1P;
+                const bool ok = (m0 + row < c.mb) && (k < K1);
+                const int64_t ridx = a.rows[kb * c.mb + (m0 + row < c.mb ? m0 + row : 0)];
+                const float v = src[(size_t)ridx * K1 + (k < K1 ? k : 0)];
+                xs[row * XP + k] = ok ? v : 0.0f;
+            }
         }
         for (int i = tid; i < OD * H; i += TH) w3s[i] = theta[L.w3 + i];
     }
@@ -1781,11 +1791,17 @@ hipError_t launch_fused_step(FusedArgs a, hipStream_t s, const MetaTail* mt_ = n
     // shapes with a row-pass instantiation: hidden = 16 * NT * WAVES
     const int rp_h = c.hidden;
     const size_t rp_lds = rowpass_lds_floats(c.hidden, rowpass_k1p(kmax1)) * sizeof(float);
-    const bool rowpass = vec && !mbatch && g_use_rowpass && (rp_h == 64 || rp_h == 128 || rp_h == 256 || rp_h == 512) &&
+    // with the transposed mirror the row pass reads no k-contiguous weight rows, so input widths that are not a
+    // multiple of 4 (the 91-dim observation of IPPO / CCPPO) only cost a scalar input gather
+    const bool tw = a.theta_t != nullptr && a.head_mode != MODE_META_BOTH;
+    bool tw_ok = tw && (c.hidden % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.theta) & 15) == 0) &&
+                 ((reinterpret_cast<uintptr_t>(a.theta_t) & 15) == 0) && ((reinterpret_cast<uintptr_t>(a.ws) & 15) == 0);
+    for (int g = 0; g < (a.head_mode == COPO_HEAD_PPO ? G : 1); ++g)
+        tw_ok = tw_ok && (nets[g]->w1 % 4 == 0) && (nets[g]->w2 % 4 == 0);
+    const bool rowpass = (vec || tw_ok) && !mbatch && g_use_rowpass && (rp_h == 64 || rp_h == 128 || rp_h == 256 || rp_h == 512) &&
                          rp_lds <= 150 * 1024;
     if (rowpass) {
         const dim3 grid(head_tiles(c), G);
-        const bool tw = a.theta_t != nullptr && a.head_mode != MODE_META_BOTH;
 #define COPO_RP(NT_, W_)                                                                                       \
         do {                                                                                                   \
             if (tw) hipLaunchKernelGGL((rowpass_kernel<NT_, W_, true>), grid, dim3(64 * W_), rp_lds, s, a);      \

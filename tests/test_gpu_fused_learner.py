@@ -62,9 +62,16 @@ def _copy_weights(dst, src):
     ("ccppo", "mf", 91, {}),
     ("ccppo", "concat", 91, {}),
     ("copo", "none", 260, {}),
+    # other row-pass instantiations (hidden 64 / 128 / 512), a hidden size without one (tile-GEMM path), and
+    # minibatch sizes that are not multiples of the 16-row tiles / the 8-way row split
+    ("copo", "none", 92, dict(hiddens=(64, 64))),
+    ("ippo", "none", 91, dict(hiddens=(128, 128), mb=200)),
+    ("copo", "none", 92, dict(hiddens=(512, 512), mb=1000)),
+    ("ccppo", "mf", 91, dict(hiddens=(48, 48), mb=72)),
 ])
 def test_fused_sgd_matches_torch(name, fuse, odim, over):
-    R, mb = 1500, 512
+    over = dict(over)
+    R, mb = 1500, over.get("mb", 512)
     ref = _make(name, fuse, odim, fused=False, **over)
     fz = _make(name, fuse, odim, fused=True, **over)
     assert fz.fused is not None and ref.fused is None
@@ -101,11 +108,12 @@ def test_fused_sgd_matches_torch(name, fuse, odim, over):
         np.testing.assert_allclose(fs[5:8], st[5:8], rtol=2e-4, atol=1e-5)
     # three real optimisation steps: parameters must track torch.optim.Adam
     ref._row_sources["k"].zero_()
-    for _ in range(3):
+    n_steps = min(3, -(-B // mb))                 # stay inside the planned minibatch tables
+    for _ in range(n_steps):
         ref._forward_backward()
         ref._apply()
         fz.fused.step(fz._row_sources, stats=fz.fused.stats)
-    assert int(fz._row_sources["k"]) == 3 and int(fz.fused.step_count) == 3
+    assert int(fz._row_sources["k"]) == n_steps and int(fz.fused.step_count) == n_steps
     for (n1, p1), (n2, p2) in zip(ref.model.named_parameters(), fz.model.named_parameters()):
         if p1.dtype != torch.float32:
             continue
