@@ -1489,21 +1489,27 @@ __global__ void __launch_bounds__(512) meta_seq_kernel(MetaSeqArgs a) {
 // nothing.  Workgroup (0, 0) also folds the loss statistics and hands over the next minibatch index.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int WG_WAVES = 8;       // waves per workgroup = row splits of K inside the workgroup
-constexpr int WG_RING = 32;       // k-pairs of operands in flight per wave (2 loads each: the vmcnt limit)
-constexpr int WG_EPT = 1024 / (64 * WG_WAVES);     // tile elements per thread in the epilogue
+constexpr int WG_RING = 32;       // k-pairs of operands in flight per wave: the whole row range of a wave at the default minibatch (a second round of loads would expose the L2-miss latency again)
 
+// OT: 32-row output tiles per wave (tile t holds the output rows o0 + OT (l & 31) + t, so a lane's OT dz values of
+// one minibatch row are one contiguous load and the [In | 1] value is shared by OT MFMAs).
+#define WG_STAMP(i) do { if ((a.dbg & 512) && blockIdx.x == 5 && blockIdx.y == 0 && threadIdx.x == 0) g_rp_stamps[i] = wall_clock64(); } while (0)
+
+template <int OT>
 __global__ void __launch_bounds__(64 * WG_WAVES) wgrad_adam_kernel(FusedArgs a, int nty, int nx2, int nx1) {
-    __shared__ float red[WG_WAVES][32][33];
+    extern __shared__ float wg_red[];                        // [WG_WAVES][32 OT][33] partial tiles
     __shared__ int32_t srow[COPO_PPO_MAX_MB];
-    constexpr int TH = 64 * WG_WAVES;
+    constexpr int TH = 64 * WG_WAVES, TO = 32 * OT, EPT = TO * 32 / TH, TPRW = 32 / EPT;
+    typedef typename ColVec<OT>::T avec_t;
+    auto red = [&](int w, int o, int i) -> float& { return wg_red[(w * TO + o) * 33 + i]; };
     const copo_ppo_cfg& c = a.c;
     const int g = blockIdx.y, H = c.hidden;
     const copo_net_layout L = net_of(a, g);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     // tile decode: nx2 * nty tiles of layer 2, nx1 * nty of layer 1, nx2 of the head layer
     int x = blockIdx.x, layer, o0, i0;
-    if (x < nx2 * nty) { layer = 2; o0 = (x / nx2) * 32; i0 = (x % nx2) * 32; }
-    else if ((x -= nx2 * nty) < nx1 * nty) { layer = 1; o0 = (x / nx1) * 32; i0 = (x % nx1) * 32; }
+    if (x < nx2 * nty) { layer = 2; o0 = (x / nx2) * TO; i0 = (x % nx2) * 32; }
+    else if ((x -= nx2 * nty) < nx1 * nty) { layer = 1; o0 = (x / nx1) * TO; i0 = (x % nx1) * 32; }
     else { x -= nx1 * nty; layer = 3; o0 = 0; i0 = x * 32; }
     const int K = layer == 1 ? L.in_dim : H;                 // input width; column K of the tile space is the bias
     const int M = layer == 3 ? L.out_dim : H;                // output rows
@@ -1513,15 +1519,14 @@ __global__ void __launch_bounds__(64 * WG_WAVES) wgrad_adam_kernel(FusedArgs a, 
     const int64_t woff = layer == 1 ? L.w1 : (layer == 2 ? L.w2 : L.w3), boff = layer == 1 ? L.b1 : (layer == 2 ? L.b2 : L.b3);
     const bool tile_live = i0 <= K;                          // layer-1 tiles beyond this net's own input width do nothing
     // Adam state of this thread's elements, requested before anything else (consumed after the GEMM)
-    constexpr int TPRW = 32 / WG_EPT;                        // threads per tile row
-    const int ero = tid / TPRW, erc = (tid % TPRW) * WG_EPT;
+    const int ero = tid / TPRW, erc = (tid % TPRW) * EPT;
     const int eo = o0 + ero, ei = i0 + erc;
-    size_t eidx[WG_EPT];
-    bool eok[WG_EPT];
-    float em[WG_EPT], ev[WG_EPT], eth[WG_EPT];
+    size_t eidx[EPT];
+    bool eok[EPT];
+    float em[EPT], ev[EPT], eth[EPT];
     const bool adam = a.apply_adam != 0;
 #pragma unroll
-    for (int q = 0; q < WG_EPT; ++q) {
+    for (int q = 0; q < EPT; ++q) {
         const int i = ei + q;
         eok[q] = tile_live && eo < M && i <= K;
         eidx[q] = !eok[q] ? (size_t)woff : (i == K ? (size_t)boff + eo : (size_t)woff + (size_t)eo * K + i);
@@ -1529,59 +1534,73 @@ __global__ void __launch_bounds__(64 * WG_WAVES) wgrad_adam_kernel(FusedArgs a, 
         ev[q] = adam ? a.adam_v[eidx[q]] : 0.0f;
         eth[q] = adam ? a.theta[eidx[q]] : 0.0f;
     }
+    WG_STAMP(0);
     const int64_t kb = knext_slot(a)[0] - 1 + a.k_first;      // published by the first kernel of this step
     if (layer == 1) {
         for (int i = tid; i < c.mb; i += TH) srow[i] = (int32_t)a.rows[kb * c.mb + i];
         __syncthreads();
     }
-    v16f acc;
+    v16f acc[OT];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+    for (int t = 0; t < OT; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[t][j] = 0.0f;
     if (tile_live) {
         // rows of this wave: [kbeg, kend), walked two at a time (lane half lh takes row k + lh)
         const int chunk = (((c.mb + WG_WAVES - 1) / WG_WAVES) + 1) & ~1;
         const int kbeg = wave * chunk, kend = (kbeg + chunk < c.mb) ? kbeg + chunk : c.mb;
         const int ns = (kend - kbeg + 1) >> 1;               // k-pairs (may be <= 0)
-        const int ao = o0 + li, bi = i0 + li;
-        const bool a_col = ao < M, b_in = bi < K;
+        const int ao = o0 + OT * li, bi = i0 + li;
+        const bool a_any = ao < M, b_in = bi < K;
+        bool a_col[OT];
+#pragma unroll
+        for (int t = 0; t < OT; ++t) a_col[t] = ao + t < M;
         const float b_fill = bi == K ? 1.0f : 0.0f;          // the constant-1 bias column / zero padding
         // running fetch state: fetch number f reads row kbeg + 2 f + lh (rows past kend re-read row kend - 1, masked at use)
         const bool gather = layer == 1;
         const int mlast = kend - 1;
         int fm = kbeg + lh;
-        uint32_t fa = (uint32_t)fm * (uint32_t)astr + (a_col ? ao : 0);
+        uint32_t fa = (uint32_t)fm * (uint32_t)astr + (a_any ? ao : 0);
         uint32_t fb = (uint32_t)fm * (uint32_t)K + (b_in ? bi : 0);
-        const uint32_t fa_last = (uint32_t)mlast * (uint32_t)astr + (a_col ? ao : 0), fb_last = (uint32_t)mlast * (uint32_t)K + (b_in ? bi : 0);
+        const uint32_t fa_last = (uint32_t)mlast * (uint32_t)astr + (a_any ? ao : 0), fb_last = (uint32_t)mlast * (uint32_t)K + (b_in ? bi : 0);
         const uint32_t bcol = b_in ? bi : 0;
-        float ra[WG_RING], rb[WG_RING];
+        avec_t ra[WG_RING];
+        float rb[WG_RING];
         bool rk[WG_RING];
 #define WG_FETCH(u)                                                                        \
         do {                                                                              \
             rk[u] = fm <= mlast;                                                          \
-            ra[u] = dz[rk[u] ? fa : fa_last];                                             \
+            ra[u] = *reinterpret_cast<const avec_t*>(dz + (rk[u] ? fa : fa_last));        \
             rb[u] = in[gather ? (uint32_t)srow[rk[u] ? fm : mlast] * (uint32_t)K + bcol : (rk[u] ? fb : fb_last)]; \
             fm += 2; fa += 2u * (uint32_t)astr; fb += 2u * (uint32_t)K;                   \
         } while (0)
         if (ns > 0) {
 #pragma unroll
             for (int u = 0; u < WG_RING; ++u) WG_FETCH(u);
+            WG_STAMP(1);
             for (int s0 = 0; s0 < ns; s0 += WG_RING) {
                 const bool more = s0 + WG_RING < ns;         // uniform: only long row ranges loop
 #pragma unroll
                 for (int u = 0; u < WG_RING; ++u) {
                     // masking happens at use: rows beyond the range / columns beyond the tensors contribute zero
-                    const float av = (rk[u] && a_col) ? ra[u] : 0.0f;
                     const float bv = b_in ? rb[u] : b_fill;
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < OT; ++t) {
+                        const float av = (rk[u] && a_col[t]) ? ColVec<OT>::get(ra[u], t) : 0.0f;
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+                    }
                     if (more) WG_FETCH(u);
                 }
             }
         }
 #undef WG_FETCH
     }
-    // wave partials -> LDS; accumulator element j of this lane: row 8 (j / 4) + 4 lh + (j % 4), column li
+    WG_STAMP(2);
+    // wave partials -> LDS; accumulator element j of tile t: output row OT (8 (j / 4) + 4 lh + (j % 4)) + t, column li
 #pragma unroll
-    for (int j = 0; j < 16; ++j) red[wave][COPO_ACC_ROW(4 * lh, j)][li] = acc[j];
+    for (int t = 0; t < OT; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) red(wave, OT * COPO_ACC_ROW(4 * lh, j) + t, li) = acc[t][j];
     __shared__ float bcs[2];
     if (tid == 0) {      // Adam bias corrections once per workgroup (two powf are ~200 instructions)
         const float tt = adam ? (float)a.step[0] : 1.0f;     // advanced by the first kernel of this step
@@ -1589,14 +1608,15 @@ __global__ void __launch_bounds__(64 * WG_WAVES) wgrad_adam_kernel(FusedArgs a, 
         bcs[1] = sqrtf(1.0f - powf(c.beta2, tt));
     }
     __syncthreads();
+    WG_STAMP(3);
     {
         const float bc1 = bcs[0], bc2s = bcs[1];
 #pragma unroll
-        for (int q = 0; q < WG_EPT; ++q) {
+        for (int q = 0; q < EPT; ++q) {
             if (!eok[q]) continue;
-            float gsum = red[0][ero][erc + q];
+            float gsum = red(0, ero, erc + q);
 #pragma unroll
-            for (int w = 1; w < WG_WAVES; ++w) gsum += red[w][ero][erc + q];
+            for (int w = 1; w < WG_WAVES; ++w) gsum += red(w, ero, erc + q);
             if (adam) {
                 const float m = em[q] + (gsum - em[q]) * (1.0f - c.beta1);
                 const float v = ev[q] * c.beta2 + gsum * gsum * (1.0f - c.beta2);
@@ -1609,23 +1629,25 @@ __global__ void __launch_bounds__(64 * WG_WAVES) wgrad_adam_kernel(FusedArgs a, 
             }
         }
     }
+    WG_STAMP(4);
     if (adam && a.theta_t) {
         // keep the transposed mirror current: the tile goes back through LDS so that the [in][out] rows are written
-        // 32 contiguous floats at a time; biases and the head layer are mirrored as they are
+        // contiguously; biases and the head layer are mirrored as they are
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < WG_EPT; ++q) red[0][ero][erc + q] = eth[q];
+        for (int q = 0; q < EPT; ++q) red(0, ero, erc + q) = eth[q];
         __syncthreads();
-        for (int e = tid; e < 1024; e += TH) {
-            const int ti = e >> 5, to = e & 31;              // consecutive threads -> consecutive output rows o
+        for (int e = tid; e < TO * 32; e += TH) {
+            const int ti = e / TO, to = e - ti * TO;         // consecutive threads -> consecutive output rows o
             const int o = o0 + to, i = i0 + ti;
             if (!tile_live || o >= M || i > K) continue;
-            const float v = red[0][to][ti];
+            const float v = red(0, to, ti);
             if (i == K) a.theta_t[(size_t)boff + o] = v;
             else if (layer == 3) a.theta_t[(size_t)woff + (size_t)o * K + i] = v;
             else a.theta_t[(size_t)woff + (size_t)i * M + o] = v;
         }
     }
+    WG_STAMP(5);
     // workgroup (0, 0) folds the per-tile loss statistics of the previous kernel in a fixed order and hands the next
     // minibatch index back to *kptr (which no workgroup of this kernel reads)
     if (blockIdx.x != 0 || blockIdx.y != 0) return;
@@ -1731,6 +1753,7 @@ static hipError_t gemm_lds_attrs() {
                               reinterpret_cast<const void*>(rowpass_kernel<1, 4, true>), reinterpret_cast<const void*>(rowpass_kernel<2, 4, true>),
                               reinterpret_cast<const void*>(rowpass_kernel<2, 8, true>), reinterpret_cast<const void*>(rowpass_kernel<4, 8, true>)})
             if ((r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) != hipSuccess) e = r;
+        if ((r = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_adam_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)) != hipSuccess) e = r;
         return e;
     }();
     return once;
@@ -1739,6 +1762,10 @@ static hipError_t gemm_lds_attrs() {
 struct MetaBatch { int nb; float* g_out; double* dot_out; float* stats_out; };
 
 // COPO_FUSED_ROWPASS=0 keeps the four-kernel activation path (A/B measurements, tests of both paths)
+static const int g_wgrad_ot = [] {          // COPO_WGRAD_OT=2: two 32-row output tiles per wave (measured equal at H = 256)
+    const char* e = getenv("COPO_WGRAD_OT");
+    return (e && e[0] == '2') ? 2 : 1;
+}();
 static const bool g_use_wgrad = [] {
     const char* e = getenv("COPO_FUSED_WGRAD");
     return !(e && e[0] == '0');
@@ -1824,8 +1851,12 @@ hipError_t launch_fused_step(FusedArgs a, hipStream_t s, const MetaTail* mt_ = n
 #undef COPO_GEMM
     if (!mbatch && a.head_mode != MODE_META_BOTH && g_use_wgrad) {
         // weight gradients, fold and Adam in one kernel: the SGD step ends here
-        const int nty = (c.hidden + 31) / 32, wx2 = (c.hidden + 1 + 31) / 32, wx1 = (kmax1 + 1 + 31) / 32;
-        hipLaunchKernelGGL(wgrad_adam_kernel, dim3((wx2 + wx1) * nty + wx2, G), dim3(64 * WG_WAVES), 0, s, a, nty, wx2, wx1);
+        const int ot = g_wgrad_ot;
+        const int nty = (c.hidden + 32 * ot - 1) / (32 * ot), wx2 = (c.hidden + 1 + 31) / 32, wx1 = (kmax1 + 1 + 31) / 32;
+        const dim3 grid((wx2 + wx1) * nty + wx2, G);
+        const size_t lds = (size_t)WG_WAVES * 32 * ot * 33 * sizeof(float);
+        if (ot == 2) hipLaunchKernelGGL((wgrad_adam_kernel<2>), grid, dim3(64 * WG_WAVES), lds, s, a, nty, wx2, wx1);
+        else hipLaunchKernelGGL((wgrad_adam_kernel<1>), grid, dim3(64 * WG_WAVES), lds, s, a, nty, wx2, wx1);
         return hipGetLastError();
     }
     {

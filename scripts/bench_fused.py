@@ -40,3 +40,15 @@ if int(os.environ.get("COPO_RP_DBG", "0")) & 256:
     for i, nme in enumerate(names):
         print("  %-22s %6.2f us" % (nme, (t[idx[i + 1]] - t[idx[i]]) / 100.0))
     print("  total                  %6.2f us" % ((t[9] - t[0]) / 100.0))
+if int(os.environ.get("COPO_RP_DBG", "0")) & 512:
+    import ctypes as C
+    from copo_amd import _capi
+    buf = (C.c_ulonglong * 16)()
+    _capi.lib.copo_debug_rowpass_stamps.argtypes = [C.c_void_p]
+    _capi.lib.copo_debug_rowpass_stamps(buf)
+    t = list(buf)
+    names = ["state loads issued, k, (srow)", "MFMA loop (ring)", "LDS partials + sync", "fold + Adam + stores", "mirror write"]
+    print("wgrad phases of workgroup (5,0), 100 MHz wall clock:")
+    for i, nme in enumerate(names):
+        print("  %-30s %6.2f us" % (nme, (t[i + 1] - t[i]) / 100.0))
+    print("  total                          %6.2f us" % ((t[5] - t[0]) / 100.0))
