@@ -66,6 +66,12 @@ struct FusedArgs {
     double* dot_partials;      // META_BOTH: per-workgroup partials of <g_new, g_old> (COPO_META_DOT_PARTIALS doubles)
     int32_t gcap;              // group slabs of the workspace layout (4, or `groups` of a batched meta pass)
     int32_t nreg;              // gradient regions of the workspace layout
+    // meta row store: the row-local quantities of EVERY row (both policies), computed once per training iteration in
+    // identity row blocks of `mb` rows; the weight-gradient GEMMs of each meta pass then gather from it
+    int64_t identity_rows;     // > 0: minibatch b is the rows [b * mb, (b + 1) * mb) of `identity_rows` rows, weight 1, denom 1
+    const float* ws0;          // row store (WsLay(c, gcap0, gcap0) layout) the GA weight-gradient GEMMs read
+    int32_t gcap0;
+    float* rowstat;            // [gcap0 * mb][2] per-row {loss term, advantage term} of the head kernel (row-store pass)
     int32_t dbg;               // timing experiments only (COPO_RP_DBG): phases of the row pass to skip
     int64_t k_first;           // minibatch index offset (batched meta pass: groups 2b, 2b+1 are minibatch k_first + b)
 };
@@ -80,6 +86,13 @@ __device__ __forceinline__ int64_t kb_of(const FusedArgs& a, int g) {
 // one of its workgroups publishes k + 1 in a workspace slot that kernel never reads; the weight-gradient kernel reads
 // that slot (minus one) and one of its workgroups copies it back to *kptr, which that kernel never reads.
 __device__ __forceinline__ int64_t* knext_slot(const FusedArgs& a);
+// row index / weight of entry m of the minibatch a group works on
+__device__ __forceinline__ int64_t row_of(const FusedArgs& a, int64_t kb, int m) {
+    return a.identity_rows > 0 ? (kb * a.c.mb + m < a.identity_rows ? kb * a.c.mb + m : 0) : a.rows[kb * a.c.mb + m];
+}
+__device__ __forceinline__ float weight_of(const FusedArgs& a, int64_t kb, int m) {
+    return a.identity_rows > 0 ? (kb * a.c.mb + m < a.identity_rows ? 1.0f : 0.0f) : a.w[kb * a.c.mb + m] / a.denom[kb];
+}
 __device__ __forceinline__ const copo_net_layout& net_of(const FusedArgs& a, int g) {
     return (g == 0 || both(a)) ? a.c.pol : a.c.val[g - 1];
 }
@@ -179,6 +192,7 @@ struct GemmCtx {
     const float* __restrict__ aux;     // bias (forward) / h1 (B2x)
     float* __restrict__ out;
     const int32_t* srow;               // LDS table of gathered row indices (layer 1)
+    const int32_t* srow2;              // LDS table of row-store indices (gather-all mode)
     int K;          // length of the k-contiguous rows / input width
     int mb, H;
     int M, astr;    // Bw: output rows (H, or the head's out_dim) and the row stride of the dz operand
@@ -191,10 +205,11 @@ struct GemmCtx {
 //   row-contiguous operands (4 consecutive rows of one k per load): [k][row], pitch LDP floats.
 constexpr int QP = TM + 1;
 constexpr int OPER_FLOATS = (TK / 4) * QP * 4 > TK * LDP ? (TK / 4) * QP * 4 : TK * LDP;
-constexpr size_t GEMM_LDS_BYTES = (size_t)(COPO_PPO_MAX_MB + 2 * OPER_FLOATS) * sizeof(float);
+constexpr size_t GEMM_LDS_BYTES = (size_t)(2 * COPO_PPO_MAX_MB + 2 * OPER_FLOATS) * sizeof(float);
 
 struct GemmSmem {
-    int32_t* srow;
+    int32_t* srow;      // row index into the dense sources (-1: masked entry, gather-all mode)
+    int32_t* srow2;     // row index into the meta row store (gather-all mode)
     float* As;
     float* Bs;
 };
@@ -203,7 +218,8 @@ __device__ __forceinline__ GemmSmem gemm_smem() {
     extern __shared__ float4 gemm_dyn_lds[];
     GemmSmem sm;
     sm.srow = reinterpret_cast<int32_t*>(gemm_dyn_lds);
-    sm.As = reinterpret_cast<float*>(gemm_dyn_lds) + COPO_PPO_MAX_MB;
+    sm.srow2 = sm.srow + COPO_PPO_MAX_MB;
+    sm.As = reinterpret_cast<float*>(gemm_dyn_lds) + 2 * COPO_PPO_MAX_MB;
     sm.Bs = sm.As + OPER_FLOATS;
     return sm;
 }
@@ -230,11 +246,22 @@ __device__ __forceinline__ void gemm_tile(const FusedArgs& a, int K, int g, int 
     float* As = sm.As;
     float* Bs = sm.Bs;
     if (Op::GATHER) {     // row indices of this minibatch once per workgroup (removes a dependent-load chain)
-        const int64_t base = kb_of(a, g) * a.c.mb;
-        for (int i = threadIdx.x; i < a.c.mb; i += 256) srow[i] = (int32_t)a.rows[base + i];
+        const int64_t kb = kb_of(a, g);
+        for (int i = threadIdx.x; i < a.c.mb; i += 256) {
+            const int64_t r = row_of(a, kb, i);
+            if (Op::GATHER_ALL) {
+                // store row of (row r, net g & 1): block (2 (r / mb) + net) of the identity pass, entry r % mb
+                const int blk = (int)(r / a.c.mb);
+                sm.srow2[i] = (2 * blk + (g & 1)) * a.c.mb + (int)(r - (int64_t)blk * a.c.mb);
+                srow[i] = a.w[kb * a.c.mb + i] != 0.0f ? (int32_t)r : -1;
+            } else {
+                srow[i] = (int32_t)r;
+            }
+        }
         __syncthreads();
     }
-    const GemmCtx c = Op::prep(a, g, split, srow);
+    GemmCtx c = Op::prep(a, g, split, srow);
+    c.srow2 = sm.srow2;
     int kbeg = 0, kend = K;
     if (Op::SPLITS_K) {
         const int chunk = ((K + a.ksplit - 1) / a.ksplit + TK - 1) / TK * TK;
@@ -307,7 +334,7 @@ __device__ __forceinline__ float tanh_fast(float x) {
 
 template <int LAYER>
 struct FwdOpT {
-    static constexpr bool A_KCONTIG = true, B_KCONTIG = true, SPLITS_K = false, GATHER = LAYER == 1, FIRST = LAYER == 1;
+    static constexpr bool A_KCONTIG = true, B_KCONTIG = true, SPLITS_K = false, GATHER = LAYER == 1, FIRST = LAYER == 1, GATHER_ALL = false;
     __device__ static __forceinline__ GemmCtx prep(const FusedArgs& a, int g, int, const int32_t* srow) {
         const copo_net_layout L = net_of(a, g);
         GemmCtx c;
@@ -347,7 +374,7 @@ struct FwdOpT {
 
 // ---- B2x: dz1[m][i] = (sum_o dz2[m][o] W2[o][i]) * (1 - h1[m][i]^2) -------------------------------------------
 struct BxOp {
-    static constexpr bool A_KCONTIG = true, B_KCONTIG = false, SPLITS_K = false, GATHER = false, FIRST = false;
+    static constexpr bool A_KCONTIG = true, B_KCONTIG = false, SPLITS_K = false, GATHER = false, FIRST = false, GATHER_ALL = false;
     __device__ static __forceinline__ GemmCtx prep(const FusedArgs& a, int g, int, const int32_t* srow) {
         GemmCtx c;
         c.mb = a.c.mb; c.H = a.c.hidden; c.K = c.H; c.srow = srow;
@@ -385,16 +412,25 @@ struct BxOp {
 };
 
 // ---- Bw: partial dW[o][i] = sum_{m in split} dz[m][o] * [In | 1][m][i]; column i == in_dim is the bias --------
-template <int LAYER>   // 3: dout x h2 ; 2: dz2 x h1 ; 1: dz1 x X (rows gathered)
+// GA (gather-all): dz / h operands come from the meta row store `ws0` through the minibatch's row table instead of
+// this call's own activation slabs; masked table entries (weight 0) contribute nothing.
+template <int LAYER, bool GA = false>   // 3: dout x h2 ; 2: dz2 x h1 ; 1: dz1 x X (rows gathered)
 struct BwOpT {
-    static constexpr bool A_KCONTIG = false, B_KCONTIG = false, SPLITS_K = true, GATHER = LAYER == 1, FIRST = false;
+    static constexpr bool A_KCONTIG = false, B_KCONTIG = false, SPLITS_K = true, GATHER = LAYER == 1 || GA, FIRST = false,
+                          GATHER_ALL = GA;
     __device__ static __forceinline__ GemmCtx prep(const FusedArgs& a, int g, int split, const int32_t* srow) {
         const copo_net_layout L = net_of(a, g);
         GemmCtx c;
         c.mb = a.c.mb; c.H = a.c.hidden; c.srow = srow;
-        c.K = GATHER ? L.in_dim : c.H;
-        c.abase = a.ws + (LAYER == 1 ? ws_dz1(a, g) : (LAYER == 2 ? ws_dz2(a, g) : ws_dout(a, g)));
-        c.bbase = GATHER ? src_of(a, g) : a.ws + (LAYER == 2 ? ws_h1(a, g) : ws_h2(a, g));
+        c.K = LAYER == 1 ? L.in_dim : c.H;
+        if (GA) {
+            const WsLay l0(a.c, a.gcap0, 0);
+            c.abase = a.ws0 + (LAYER == 1 ? l0.dz1(0) : (LAYER == 2 ? l0.dz2(0) : l0.dout(0)));
+            c.bbase = LAYER == 1 ? src_of(a, g) : a.ws0 + (LAYER == 2 ? l0.h1(0) : l0.h2(0));
+        } else {
+            c.abase = a.ws + (LAYER == 1 ? ws_dz1(a, g) : (LAYER == 2 ? ws_dz2(a, g) : ws_dout(a, g)));
+            c.bbase = LAYER == 1 ? src_of(a, g) : a.ws + (LAYER == 2 ? ws_h1(a, g) : ws_h2(a, g));
+        }
         c.aux = nullptr;
         c.woff = LAYER == 1 ? L.w1 : (LAYER == 2 ? L.w2 : L.w3);
         c.boff = LAYER == 1 ? L.b1 : (LAYER == 2 ? L.b2 : L.b3);
@@ -405,14 +441,16 @@ struct BwOpT {
     }
     template <bool VEC>
     __device__ static __forceinline__ float4 lda4(const GemmCtx& c, int o, int m, int mend, int& mask) {   // dz[m][o..o+3]
-        const bool ok = m < mend;
-        return ld4<VEC>(c.abase + (size_t)(ok ? m : 0) * c.astr, o, c.astr, ok, mask);
+        const int mc = m < mend ? m : 0;
+        const bool ok = m < mend && (!GA || c.srow[mc] >= 0);
+        const int r = GA ? c.srow2[mc] : mc;
+        return ld4<VEC>(c.abase + (size_t)(ok ? r : 0) * c.astr, o, c.astr, ok, mask);
     }
     template <bool VEC>
     __device__ static __forceinline__ float4 ldb4(const GemmCtx& c, int m, int i, int mend, int& mask, int& one) {   // [In|1][m][i..]
-        const bool ok = m < mend;
-        const int mc = ok ? m : 0;
-        const int r = GATHER ? c.srow[mc] : mc;
+        const int mc = m < mend ? m : 0;
+        const bool ok = m < mend && (!GA || c.srow[mc] >= 0);
+        const int r = !ok ? 0 : (LAYER == 1 ? c.srow[mc] : (GA ? c.srow2[mc] : mc));
         const int d = c.K - i;             // position of the constant-1 bias column inside this quad, if any
         one = (ok && d >= 0 && d < 4) ? d : -1;
         return ld4<VEC>(c.bbase + (size_t)r * c.K, i, c.K, ok, mask);
@@ -429,17 +467,17 @@ struct BwOpT {
 
 // the three weight-gradient GEMMs in one launch: column tiles [0, nx2) are layer 2, [nx2, nx2 + nx1) layer 1,
 // the rest the head layer (one row tile: out_dim <= 4 rows).  Fewer launches per SGD step, a grid that covers the chip.
-template <bool VEC>
+template <bool VEC, bool GA = false>
 __global__ void __launch_bounds__(256) gemm_bw_kernel(FusedArgs a, int K, int nx2, int nx1, int ny) {
     // blockIdx.x enumerates the output tiles of the three GEMMs: nx2 * ny of layer 2, nx1 * ny of layer 1, nx2 of the head
     const GemmSmem sm = gemm_smem();
     const int G = a.groups, g = blockIdx.y % G, split = blockIdx.y / G;
     int x = blockIdx.x;
-    if (x < nx2 * ny) { gemm_tile<BwOpT<2>, VEC>(a, K, g, split, (x / nx2) * TM, (x % nx2) * TN, sm); return; }
+    if (x < nx2 * ny) { gemm_tile<BwOpT<2, GA>, VEC>(a, K, g, split, (x / nx2) * TM, (x % nx2) * TN, sm); return; }
     x -= nx2 * ny;
-    if (x < nx1 * ny) { gemm_tile<BwOpT<1>, VEC>(a, K, g, split, (x / nx1) * TM, (x % nx1) * TN, sm); return; }
+    if (x < nx1 * ny) { gemm_tile<BwOpT<1, GA>, VEC>(a, K, g, split, (x / nx1) * TM, (x % nx1) * TN, sm); return; }
     x -= nx1 * ny;
-    gemm_tile<BwOpT<3>, VEC>(a, K, g, split, 0, x * TN, sm);
+    gemm_tile<BwOpT<3, GA>, VEC>(a, K, g, split, 0, x * TN, sm);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -582,8 +620,8 @@ __global__ void __launch_bounds__(256) head_kernel(FusedArgs a) {
     const int m = m0 + r;
     const int64_t kb = kb_of(a, g);
     const bool rok = m < c.mb;
-    const float wgt = rok ? a.w[kb * c.mb + m] / a.denom[kb] : 0.0f;
-    const float* pk = a.pack_src + (size_t)(rok ? a.rows[kb * c.mb + m] : 0) * c.pack_width;
+    const float wgt = rok ? weight_of(a, kb, m) : 0.0f;
+    const float* pk = a.pack_src + (size_t)(rok ? row_of(a, kb, m) : 0) * c.pack_width;
     const float* h2g = a.ws + ws_h2(a, g);
     // unconditional loads from clamped rows (a branch around a load drains vmcnt and serialises the tile load)
     for (int r = tid >> 6; r < HT; r += 4) {
@@ -614,6 +652,10 @@ __global__ void __launch_bounds__(256) head_kernel(FusedArgs a) {
     float st[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // total, policy, vf_ego, kl, entropy, vf_nei, vf_glob, adv
     float dout[4] = {0.f, 0.f, 0.f, 0.f};
     if (part == 0 && rok) head_row_terms(a, g, mode, policy, load_row_in(a, g, mode, policy, pk), wgt, out, dout, st);
+    if (part == 0 && rok && a.rowstat) {     // row-store pass: the per-row terms the meta passes regroup by minibatch
+        a.rowstat[((size_t)g * c.mb + m) * 2 + 0] = st[1];
+        a.rowstat[((size_t)g * c.mb + m) * 2 + 1] = st[7];
+    }
     if (part == 0) {
         // d(loss)/d(outputs): to LDS for dz2 below and to the workspace for the head's weight-gradient GEMM
         *reinterpret_cast<float4*>(douts + r * 4) = make_float4(dout[0], dout[1], dout[2], dout[3]);
@@ -1277,7 +1319,7 @@ __global__ void __launch_bounds__(256) meta_batch_fold_kernel(FusedArgs a, int64
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = prod;
     __syncthreads();
     if (threadIdx.x == 0) dot_out[(size_t)b * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-    if (blockIdx.x == 0) {
+    if (blockIdx.x == 0 && stats_out) {
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
         for (int k = wave; k < 8; k += 4) {
             float t0 = 0.0f, t1 = 0.0f;
@@ -1297,7 +1339,8 @@ __global__ void __launch_bounds__(256) meta_batch_fold_kernel(FusedArgs a, int64
 
 // gv[b] = <g_new_b, g_old_b>: from the fold's per-workgroup partials (dot != NULL, n = partials per minibatch) or
 // from exported gradients g [nb][2][n] (after a gradient all-reduce).  grid (nb), fixed summation order.
-__global__ void __launch_bounds__(1024) meta_batch_dot_kernel(const double* dot, const float* g, int64_t n, double* gv) {
+__global__ void __launch_bounds__(1024) meta_batch_dot_kernel(const double* dot, const float* g, int64_t n, double* gv,
+                                                              const float* denom = nullptr) {
     __shared__ double red[16];
     const int b = blockIdx.x;
     double s = 0.0;
@@ -1309,7 +1352,38 @@ __global__ void __launch_bounds__(1024) meta_batch_dot_kernel(const double* dot,
         for (int64_t i = threadIdx.x; i < n; i += blockDim.x) s += (double)g0[i] * (double)g1[i];
     }
     const double t = block_sum_d(s, red);
-    if (threadIdx.x == 0) gv[b] = t;
+    // row-store path: the gradients were summed with unit row weights; both carry the factor 1 / D_b
+    const double sc = denom ? 1.0 / ((double)denom[b] * (double)denom[b]) : 1.0;
+    if (threadIdx.x == 0) gv[b] = t * sc;
+}
+
+// per-minibatch loss statistics from the per-row terms of the row store: stats_out[b][net][1] = sum_m w rowstat[.][0] / D_b,
+// stats_out[b][net][7] = sum_m w rowstat[.][1] / D_b (fixed order), everything else 0.  grid (nb), 256 threads.
+__global__ void __launch_bounds__(256) meta_rowstat_kernel(FusedArgs a, int64_t k_first, const float* denom, float* stats_out) {
+    __shared__ double red[16];
+    const int b = blockIdx.x, mb = a.c.mb;
+    const int64_t kb = k_first + b;
+    double s[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    for (int m = threadIdx.x; m < mb; m += blockDim.x) {
+        if (a.w[kb * mb + m] == 0.0f) continue;
+        const int64_t r = a.rows[kb * mb + m];
+        const int64_t blk = r / mb, loc = r - blk * mb;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const float* q = a.rowstat + (((size_t)2 * blk + n) * mb + loc) * 2;
+            s[n][0] += (double)q[0];
+            s[n][1] += (double)q[1];
+        }
+    }
+    const double D = (double)denom[kb];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const double t0 = block_sum_d(s[n][0], red), t1 = block_sum_d(s[n][1], red);
+        if (threadIdx.x < 8) {
+            const int k = threadIdx.x;
+            stats_out[((size_t)b * 2 + n) * 8 + k] = k == 1 ? (float)(t0 / D) : (k == 7 ? (float)(t1 / D) : 0.0f);
+        }
+    }
 }
 
 struct MetaSeqArgs {
@@ -1747,6 +1821,7 @@ static hipError_t gemm_lds_attrs() {
         COPO_ATTR((gemm_kernel<FwdOpT<2>, true>)); COPO_ATTR((gemm_kernel<FwdOpT<2>, false>));
         COPO_ATTR((gemm_kernel<BxOp, true>)); COPO_ATTR((gemm_kernel<BxOp, false>));
         COPO_ATTR((gemm_bw_kernel<true>)); COPO_ATTR((gemm_bw_kernel<false>));
+        COPO_ATTR((gemm_bw_kernel<true, true>)); COPO_ATTR((gemm_bw_kernel<false, true>));
 #undef COPO_ATTR
         for (const void* f : {reinterpret_cast<const void*>(rowpass_kernel<1, 4, false>), reinterpret_cast<const void*>(rowpass_kernel<2, 4, false>),
                               reinterpret_cast<const void*>(rowpass_kernel<2, 8, false>), reinterpret_cast<const void*>(rowpass_kernel<4, 8, false>),
@@ -1759,7 +1834,9 @@ static hipError_t gemm_lds_attrs() {
     return once;
 }
 
-struct MetaBatch { int nb; float* g_out; double* dot_out; float* stats_out; };
+// part: 0 = the whole chain; 1 = row-local kernels only (fill the meta row store); 2 = weight-gradient GEMMs that
+// gather from the row store + fold (a meta pass over precomputed rows)
+struct MetaBatch { int nb; float* g_out; double* dot_out; float* stats_out; int part; };
 
 // COPO_FUSED_ROWPASS=0 keeps the four-kernel activation path (A/B measurements, tests of both paths)
 static const int g_wgrad_ot = [] {          // COPO_WGRAD_OT=2: two 32-row output tiles per wave (measured equal at H = 256)
@@ -1825,6 +1902,8 @@ hipError_t launch_fused_step(FusedArgs a, hipStream_t s, const MetaTail* mt_ = n
                  ((reinterpret_cast<uintptr_t>(a.theta_t) & 15) == 0) && ((reinterpret_cast<uintptr_t>(a.ws) & 15) == 0);
     for (int g = 0; g < (a.head_mode == COPO_HEAD_PPO ? G : 1); ++g)
         tw_ok = tw_ok && (nets[g]->w1 % 4 == 0) && (nets[g]->w2 % 4 == 0);
+    const int part = mbatch ? mbatch->part : 0;
+    if (part == 2) vec = vec && ((reinterpret_cast<uintptr_t>(a.ws0) & 15) == 0);
     const bool rowpass = (vec || tw_ok) && !mbatch && g_use_rowpass && (rp_h == 64 || rp_h == 128 || rp_h == 256 || rp_h == 512) &&
                          rp_lds <= 150 * 1024;
     if (rowpass) {
@@ -1841,7 +1920,7 @@ hipError_t launch_fused_step(FusedArgs a, hipStream_t s, const MetaTail* mt_ = n
             default: COPO_RP(4, 8); break;
         }
 #undef COPO_RP
-    } else {
+    } else if (part != 2) {
         COPO_GEMM(FwdOpT<1>, dim3(ht, mt, G), f1, kmax1);
         COPO_GEMM(FwdOpT<2>, dim3(ht, mt, G), f2, c.hidden);
         const size_t lds = (size_t)(HT * (c.hidden + 1) + 4 * c.hidden + HT * 4 + 32) * sizeof(float);
@@ -1849,6 +1928,7 @@ hipError_t launch_fused_step(FusedArgs a, hipStream_t s, const MetaTail* mt_ = n
         COPO_GEMM(BxOp, dim3(ht, mt, G), bx, c.hidden);
     }
 #undef COPO_GEMM
+    if (part == 1) return hipGetLastError();
     if (!mbatch && a.head_mode != MODE_META_BOTH && g_use_wgrad) {
         // weight gradients, fold and Adam in one kernel: the SGD step ends here
         const int ot = g_wgrad_ot;
@@ -1862,7 +1942,10 @@ hipError_t launch_fused_step(FusedArgs a, hipStream_t s, const MetaTail* mt_ = n
     {
         const int nx2 = (c.hidden + 1 + TN - 1) / TN, nx1 = (kmax1 + 1 + TN - 1) / TN;
         const dim3 grid((nx2 + nx1) * ht + nx2, G * a.ksplit);
-        if (vec) hipLaunchKernelGGL((gemm_bw_kernel<true>), grid, dim3(256), GEMM_LDS_BYTES, s, a, c.mb, nx2, nx1, ht);
+        if (part == 2) {
+            if (vec) hipLaunchKernelGGL((gemm_bw_kernel<true, true>), grid, dim3(256), GEMM_LDS_BYTES, s, a, c.mb, nx2, nx1, ht);
+            else hipLaunchKernelGGL((gemm_bw_kernel<false, true>), grid, dim3(256), GEMM_LDS_BYTES, s, a, c.mb, nx2, nx1, ht);
+        } else if (vec) hipLaunchKernelGGL((gemm_bw_kernel<true>), grid, dim3(256), GEMM_LDS_BYTES, s, a, c.mb, nx2, nx1, ht);
         else hipLaunchKernelGGL((gemm_bw_kernel<false>), grid, dim3(256), GEMM_LDS_BYTES, s, a, c.mb, nx2, nx1, ht);
     }
     // parameter range the fold covers: every net of this call (the policy only in the meta modes)
@@ -2044,12 +2127,72 @@ extern "C" int copo_meta_batch_grads_f32(const copo_ppo_cfg* cfg, float* theta, 
                                                          // a short last chunk reuses the same (zero-padded) regions
     a.k_first = mb_first;
     double* dot = reinterpret_cast<double*>(workspace + batch_ws_base(*cfg, nb_cap));
-    MetaBatch mbt{nb, g_out, dot, stats_out};
+    MetaBatch mbt{nb, g_out, dot, stats_out, 0};
     int fb = 0;
     hipError_t e = launch_fused_step(a, static_cast<hipStream_t>(stream), nullptr, &mbt, &fb, nullptr);
     if (e != hipSuccess) return COPO_ERR_DEVICE;
     hipLaunchKernelGGL(meta_batch_dot_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), dot, nullptr,
                        (int64_t)fb, gv_out);
+    return hipGetLastError() == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
+}
+
+// ---- meta row store: row-local quantities once per training iteration, regrouped by every meta pass ---------------
+static int rows_blocks(const copo_ppo_cfg& c, int64_t n_rows) { return (int)((n_rows + c.mb - 1) / c.mb); }
+static int rows_gcap(const copo_ppo_cfg& c, int64_t n_rows) {
+    const int g = 2 * rows_blocks(c, n_rows);
+    return g > 4 ? g : 8;
+}
+
+extern "C" int64_t copo_meta_rows_workspace_floats(const copo_ppo_cfg* cfg, int64_t n_rows) {
+    if (!cfg || n_rows < 1) return -1;
+    return (int64_t)WsLay(*cfg, rows_gcap(*cfg, n_rows), 0).total();      // activation slabs only: no gradient regions
+}
+
+extern "C" int copo_meta_rows_f32(const copo_ppo_cfg* cfg, float* theta, float* theta_target, const float* obs_src,
+                                  const float* pack_src, int64_t n_rows, float* rows_ws, float* rowstat, void* stream) {
+    int rc = check_cfg(cfg);
+    if (rc != COPO_OK) return rc;
+    if (!theta || !theta_target || !obs_src || !pack_src || !rows_ws || !rowstat) return COPO_ERR_NULL;
+    if (n_rows < 1 || 2 * rows_blocks(*cfg, n_rows) > 65535) return COPO_ERR_DIM;
+    FusedArgs a;
+    fill_common(a, cfg, obs_src, nullptr, pack_src, nullptr, nullptr, nullptr, rows_ws, nullptr);
+    a.theta = theta; a.theta2 = theta_target; a.apply_adam = 0; a.head_mode = MODE_META_BOTH;
+    a.groups = 2 * rows_blocks(*cfg, n_rows);
+    a.gcap = rows_gcap(*cfg, n_rows);
+    a.nreg = 0;
+    a.identity_rows = n_rows;
+    a.rowstat = rowstat;
+    MetaBatch mbt{a.groups / 2, nullptr, nullptr, nullptr, 1};
+    hipError_t e = launch_fused_step(a, static_cast<hipStream_t>(stream), nullptr, &mbt, nullptr, nullptr);
+    return e == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
+}
+
+extern "C" int copo_meta_batch_wgrads_f32(const copo_ppo_cfg* cfg, const float* obs_src, const int64_t* rows, const float* w,
+                                          const float* denom, const float* rows_ws, int64_t n_rows, const float* rowstat,
+                                          float* workspace, int32_t nb_cap, int64_t mb_first, int32_t nb, float* g_out,
+                                          double* gv_out, float* stats_out, void* stream) {
+    int rc = check_cfg(cfg);
+    if (rc != COPO_OK) return rc;
+    if (!obs_src || !rows || !w || !denom || !rows_ws || !rowstat || !workspace || !gv_out || !stats_out) return COPO_ERR_NULL;
+    if (nb < 1 || nb > nb_cap || nb_cap > COPO_META_BATCH_MAX || mb_first < 0 || n_rows < 1) return COPO_ERR_DIM;
+    if ((reinterpret_cast<uintptr_t>(workspace) & 7) != 0) return COPO_ERR_DIM;
+    FusedArgs a;
+    fill_common(a, cfg, obs_src, nullptr, nullptr, rows, w, denom, workspace, nullptr);
+    a.apply_adam = 0; a.head_mode = MODE_META_BOTH;
+    a.groups = 2 * nb;
+    a.gcap = a.nreg = 2 * nb_cap > 4 ? 2 * nb_cap : 8;
+    a.k_first = mb_first;
+    a.ws0 = rows_ws;
+    a.gcap0 = rows_gcap(*cfg, n_rows);
+    a.rowstat = const_cast<float*>(rowstat);
+    double* dot = reinterpret_cast<double*>(workspace + batch_ws_base(*cfg, nb_cap));
+    MetaBatch mbt{nb, g_out, dot, nullptr, 2};
+    int fb = 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipError_t e = launch_fused_step(a, st, nullptr, &mbt, &fb, nullptr);
+    if (e != hipSuccess) return COPO_ERR_DEVICE;
+    hipLaunchKernelGGL(meta_rowstat_kernel, dim3(nb), dim3(256), 0, st, a, mb_first, denom, stats_out);
+    hipLaunchKernelGGL(meta_batch_dot_kernel, dim3(nb), dim3(256), 0, st, dot, nullptr, (int64_t)fb, gv_out, denom + mb_first);
     return hipGetLastError() == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
 }
 

@@ -104,6 +104,7 @@ class FusedLearner:
         self.workspace = torch.zeros(int(ws), device=dev)
         self.stats = torch.zeros(_capi.PPO_STATS, device=dev)
         self._batch_ws = None
+        self._rows_ws = None
         self.target_flat = None
         # mirror of the parameters with W1 / W2 stored [in][out]: coalesced operand reads for the forward passes.  The
         # kernels keep it current; torch-side writes to the parameters are noticed through the tensor version counter.
@@ -196,6 +197,34 @@ class FusedLearner:
             rs["pack"].data_ptr(), rs["rows_all"].data_ptr(), rs["w_all"].data_ptr(), rs["denom_all"].data_ptr(),
             self._batch_ws[1].data_ptr(), int(self._batch_ws[0]), int(first), int(nb), None if g_out is None else g_out.data_ptr(),
             gv[first:].data_ptr(), stats_k[first:].data_ptr(), _capi.current_stream()))
+
+    def _ensure_batch_ws(self, nb):
+        if self._batch_ws is None or self._batch_ws[0] < nb:
+            n = int(_capi.lib.copo_meta_batch_workspace_floats(C.byref(self.cfg), int(nb)))
+            self._batch_ws = (nb, torch.zeros(n, dtype=torch.float32, device=self.flat.flat.device))
+
+    def meta_rows(self, rs):
+        """Row store of one training iteration: the row-local part of phase A for every row of the dense sources, once."""
+        n_rows = int(rs["max_rows"])
+        if self._rows_ws is None or self._rows_ws[0] != n_rows:
+            n = int(_capi.lib.copo_meta_rows_workspace_floats(C.byref(self.cfg), n_rows))
+            blocks = -(-n_rows // self.cfg.mb)
+            dev = self.flat.flat.device
+            self._rows_ws = (n_rows, torch.zeros(n, dtype=torch.float32, device=dev),
+                             torch.zeros(2 * blocks * self.cfg.mb, 2, dtype=torch.float32, device=dev))
+        _capi.check(_capi.lib.copo_meta_rows_f32(
+            C.byref(self.cfg), self.flat.flat.data_ptr(), self.target_flat.flat.data_ptr(), rs["obs"].data_ptr(),
+            rs["pack"].data_ptr(), n_rows, self._rows_ws[1].data_ptr(), self._rows_ws[2].data_ptr(), _capi.current_stream()))
+
+    def meta_batch_wgrads(self, rs, first, nb, gv, stats_k, g_out=None):
+        """Phase A of minibatches [first, first + nb) on top of the row store (`meta_rows` must have run)."""
+        self._ensure_batch_ws(nb)
+        _capi.check(_capi.lib.copo_meta_batch_wgrads_f32(
+            C.byref(self.cfg), rs["obs"].data_ptr(), rs["rows_all"].data_ptr(), rs["w_all"].data_ptr(),
+            rs["denom_all"].data_ptr(), self._rows_ws[1].data_ptr(), int(self._rows_ws[0]), self._rows_ws[2].data_ptr(),
+            self._batch_ws[1].data_ptr(), int(self._batch_ws[0]), int(first), int(nb),
+            None if g_out is None else g_out.data_ptr(), gv[first:].data_ptr(), stats_k[first:].data_ptr(),
+            _capi.current_stream()))
 
     def meta_batch_dot(self, g, n, nb, gv):
         _capi.check(_capi.lib.copo_meta_batch_dot_f64(g.data_ptr(), int(n), int(nb), gv.data_ptr(), _capi.current_stream()))

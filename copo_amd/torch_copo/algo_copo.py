@@ -51,6 +51,8 @@ class CoPOConfig(CCPPOConfig):
         self.old_value_loss = True
         # fused learner only: minibatches per batched meta launch chain (0 = one launch chain per minibatch)
         self.meta_batch_size = 32
+        # fused learner only: compute the row-local part of the meta gradients once per iteration (row store)
+        self.meta_row_store = True
         self.update_from_dict({"model": {"custom_model": "copo_model"}})
         # TF-era keys of train_copo.py:43-47 that the torch reference silently ignores
         self.initial_svo_std = None
@@ -336,12 +338,18 @@ class CoPOPolicy(CCPPOPolicy):
         `n_mb` calls of `_meta_step_local`."""
         mb_, fz = self._meta_bufs, self.fused
         rs = dict(self._row_sources, **{k: mb_[k] for k in ("rows_all", "w_all", "denom_all")})
+        # with the row store (filled once per training iteration by run_meta) a pass only redoes the weight-gradient GEMMs
+        grads = fz.meta_batch_wgrads if self._meta_row_store else fz.meta_batch_grads
+        pack = self._row_sources["pack"]
         if not D.is_dist():
             for c0 in range(0, n_mb, nb):
-                fz.meta_batch_grads(rs, c0, min(nb, n_mb - c0), mb_["gv"], mb_["stats_k"])
-            fz.meta_batch_lcf(rs, n_mb, mb_["eps_all"], mb_["gv"], mb_["stats_k"], self.model.lcf_parameters.data,
-                              self._raw_ms, self._lcf_adam, self.config[LCF_LR], mb_["stats"], mb_["col_adv"],
-                              mb_["col_nei_adv"])
+                grads(rs, c0, min(nb, n_mb - c0), mb_["gv"], mb_["stats_k"])
+            # the sequential kernel streams dense {A_ego, A_nei} rows instead of chasing row indices into the pack
+            rows = mb_["rows_all"][:n_mb]
+            en = torch.stack([pack[:, mb_["col_adv"]][rows], pack[:, mb_["col_nei_adv"]][rows]], dim=-1).unsqueeze(0)
+            fz.meta_batch_lcf(rs, n_mb, None, mb_["gv"], mb_["stats_k"], self.model.lcf_parameters.data, self._raw_ms,
+                              self._lcf_adam, self.config[LCF_LR], mb_["stats"], 0, 0,
+                              dense=(en.contiguous(), mb_["w_all"][:n_mb].unsqueeze(0), mb_["eps_all"][:n_mb].unsqueeze(0)))
             return
         # data-parallel: the minibatch gradients are sums over the ranks' rows -> all-reduce the exported gradient pairs
         # of a whole chunk BEFORE their dot products; the LCF row terms of every rank are gathered once per iteration
@@ -351,12 +359,13 @@ class CoPOPolicy(CCPPOPolicy):
             mb_["g_chunk"] = torch.zeros(nb, 2, nf, dtype=torch.float32, device=self.device)
         for c0 in range(0, n_mb, nb):
             n = min(nb, n_mb - c0)
-            fz.meta_batch_grads(rs, c0, n, mb_["gv"], mb_["stats_k"], g_out=mb_["g_chunk"])
+            grads(rs, c0, n, mb_["gv"], mb_["stats_k"], g_out=mb_["g_chunk"])
             D.all_reduce_sum_(mb_["g_chunk"][:n])
             fz.meta_batch_dot(mb_["g_chunk"], nf, n, mb_["gv"][c0:])
+            if self._meta_row_store:          # exported gradients carry unit row weights: both factors 1 / D_k
+                mb_["gv"][c0:c0 + n].div_(mb_["denom_all"][c0:c0 + n].double() ** 2)
         D.all_reduce_sum_(mb_["stats_k"][:n_mb])
         rows = mb_["rows_all"][:n_mb]
-        pack = self._row_sources["pack"]
         en = torch.stack([pack[:, mb_["col_adv"]][rows], pack[:, mb_["col_nei_adv"]][rows]], dim=-1).contiguous()
         en_all = D.all_gather_into_(torch.empty((S,) + tuple(en.shape), dtype=en.dtype, device=self.device), en)
         w_all = D.all_gather_into_(torch.empty(S, n_mb, mb, dtype=torch.float32, device=self.device),
@@ -409,6 +418,10 @@ class CoPOPolicy(CCPPOPolicy):
         mbuf["stats"].zero_()
         steps = 0
         nb_batch = int(self.config.get("meta_batch_size", 32)) if self.fused is not None else 0
+        self._meta_row_store = nb_batch > 0 and bool(self.config.get("meta_row_store", True)) and num_iters > 1 \
+            and mb == rs["mb"]
+        if self._meta_row_store:
+            self.fused.meta_rows(rs)
         for _ in range(num_iters):
             n_mb = self.plan_epoch(valid_idx, B_local, B_all, mb, bufs=mbuf)
             mbuf["eps_all"].normal_()

@@ -308,6 +308,21 @@ int copo_meta_batch_grads_f32(const copo_ppo_cfg* cfg, float* theta, float* thet
                               float* workspace, int32_t nb_cap, int64_t mb_first, int32_t nb, float* g_out,
                               double* gv_out, float* stats_out, void* stream);
 int copo_meta_batch_dot_f64(const float* g /* [nb][2][n] */, int64_t n, int32_t nb, double* gv_out, void* stream);
+/* Row store.  Everything of phase A that is local to a ROW (both forward passes, the loss gradients, the activation
+ * gradients -- with unit row weight) does not depend on how a meta pass groups the rows into minibatches, and the
+ * `lcf_num_iters` passes of one training iteration regroup the same rows.  copo_meta_rows_f32 computes it once for rows
+ * [0, n_rows) of the dense sources into rows_ws (copo_meta_rows_workspace_floats floats) + rowstat [2 * ceil(n_rows / mb)
+ * * mb][2]; copo_meta_batch_wgrads_f32 is then phase A of one chunk of minibatches: only the weight-gradient GEMMs,
+ * gathering their operands from the row store through the minibatch row tables, the dot products (scaled by
+ * 1 / denom^2) and the loss statistics regrouped from rowstat.  Same results as copo_meta_batch_grads_f32.
+ * Exported gradients (g_out) carry unit row weights: divide by denom before use. */
+int64_t copo_meta_rows_workspace_floats(const copo_ppo_cfg* cfg, int64_t n_rows);
+int copo_meta_rows_f32(const copo_ppo_cfg* cfg, float* theta, float* theta_target, const float* obs_src,
+                       const float* pack_src, int64_t n_rows, float* rows_ws, float* rowstat, void* stream);
+int copo_meta_batch_wgrads_f32(const copo_ppo_cfg* cfg, const float* obs_src, const int64_t* rows, const float* w,
+                               const float* denom, const float* rows_ws, int64_t n_rows, const float* rowstat,
+                               float* workspace, int32_t nb_cap, int64_t mb_first, int32_t nb, float* g_out,
+                               double* gv_out, float* stats_out, void* stream);
 /* Phase B: n_mb sequential LCF Adam steps (minibatch order) in one kernel.  Row inputs either gathered from
  * pack_src via rows (ego_nei NULL, n_seg 1) or dense: ego_nei [n_seg][n_mb][mb][2] = {A_ego, A_nei} with w / eps
  * [n_seg][n_mb][mb] (data-parallel: the all-gathered rows of every rank).  gv [n_mb], stats_in [n_mb][2][8] from

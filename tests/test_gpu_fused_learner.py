@@ -228,8 +228,8 @@ def test_fused_meta_single_call_equals_three_calls():
         np.testing.assert_allclose(x.detach().cpu().numpy(), y.detach().cpu().numpy(), rtol=1e-11, atol=1e-14)
 
 
-@pytest.mark.parametrize("nb", [1, 3, 8])
-def test_batched_meta_pass_equals_sequential_steps(nb):
+@pytest.mark.parametrize("nb,store", [(1, False), (3, False), (8, False), (3, True), (8, True)])
+def test_batched_meta_pass_equals_sequential_steps(nb, store):
     """Phase A (gradient pairs of `nb` minibatches per launch chain) + phase B (all LCF Adam steps in one kernel)
     == one `meta_update` per minibatch in order (algo_copo.py:581-589): same dot products, same LCF trajectory."""
     R, mb, odim = 2300, 512, 92                  # 5 minibatches, the last one ragged (252 valid rows)
@@ -248,6 +248,7 @@ def test_batched_meta_pass_equals_sequential_steps(nb):
         pol.use_graphs = False
     pols[0].config["meta_batch_size"] = 0
     pols[1].config["meta_batch_size"] = nb
+    pols[1].config["meta_row_store"] = store      # row-local part once per iteration, passes only regroup it
     outs = []
     for pol in pols:
         torch.manual_seed(21)
