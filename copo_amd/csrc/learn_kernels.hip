@@ -268,4 +268,62 @@ hipError_t launch_lcf_mix_apply(const float* mixed, const float* glob_adv, const
     return hipGetLastError();
 }
 
+// ---- minibatch plan of one SGD epoch ------------------------------------------------------------------------
+// rows [n_mb][mb] / w [n_mb][mb] / denom [n_mb] from a permutation of this rank's valid rows: minibatch k takes
+// size_k = q + (k < r) consecutive entries of the shuffled list (q, r = divmod(B_local, n_mb)); the denominators add
+// the same split of every rank's row count.  One launch instead of ~20 tensor ops per epoch.
+struct PlanArgs {
+    const int64_t* valid_idx;   // [B_local]
+    const int64_t* perm;        // [B_local] permutation of 0 .. B_local - 1
+    int64_t B_local;
+    int32_t n_mb, mb, world;
+    int64_t B_all[16];          // every rank's valid-row count (by value: no device round trip)
+    int64_t* rows;
+    float* w;
+    float* denom;
+    int64_t* k_index;           // reset to 0
+};
+
+__global__ void __launch_bounds__(256) plan_epoch_kernel(PlanArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)a.n_mb * a.mb;
+    if (i == 0 && a.k_index) a.k_index[0] = 0;
+    if (i < a.n_mb) {
+        double d = 0.0;
+        for (int r = 0; r < a.world; ++r) d += (double)(a.B_all[r] / a.n_mb + (i < a.B_all[r] % a.n_mb ? 1 : 0));
+        a.denom[i] = (float)(d > 1.0 ? d : 1.0);
+    }
+    if (i >= total) return;
+    const int k = (int)(i / a.mb), j = (int)(i - (int64_t)k * a.mb);
+    const int64_t q = a.B_local / a.n_mb, r = a.B_local % a.n_mb;
+    const int64_t start = k * q + (k < r ? k : r), size = q + (k < r ? 1 : 0);
+    const bool in = j < size && a.B_local > 0;
+    int64_t row = 0;
+    if (in) {
+        int64_t pos = start + j;
+        pos = pos < a.B_local ? pos : a.B_local - 1;
+        row = a.valid_idx[a.perm[pos]];
+    }
+    a.rows[i] = row;
+    a.w[i] = in ? 1.0f : 0.0f;
+}
+
+hipError_t launch_plan_epoch(const PlanArgs& a, hipStream_t s) {
+    const int64_t total = (int64_t)a.n_mb * a.mb;
+    hipLaunchKernelGGL(plan_epoch_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 }  // namespace copo
+
+extern "C" int copo_plan_epoch(const int64_t* valid_idx, const int64_t* perm, int64_t B_local, int32_t n_mb, int32_t mb,
+                               const int64_t* B_all_host, int32_t world, int64_t* rows, float* w, float* denom,
+                               int64_t* mb_index, void* stream) {
+    if (!rows || !w || !denom || !B_all_host || (B_local > 0 && (!valid_idx || !perm))) return COPO_ERR_NULL;
+    if (B_local < 0 || n_mb < 1 || mb < 1 || world < 1 || world > 16) return COPO_ERR_DIM;
+    copo::PlanArgs a;
+    a.valid_idx = valid_idx; a.perm = perm; a.B_local = B_local; a.n_mb = n_mb; a.mb = mb; a.world = world;
+    for (int r = 0; r < 16; ++r) a.B_all[r] = r < world ? B_all_host[r] : 0;
+    a.rows = rows; a.w = w; a.denom = denom; a.k_index = mb_index;
+    return copo::launch_plan_epoch(a, static_cast<hipStream_t>(stream)) == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
+}

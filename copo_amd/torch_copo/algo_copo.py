@@ -422,8 +422,9 @@ class CoPOPolicy(CCPPOPolicy):
             and mb == rs["mb"]
         if self._meta_row_store:
             self.fused.meta_rows(rs)
-        for _ in range(num_iters):
-            n_mb = self.plan_epoch(valid_idx, B_local, B_all, mb, bufs=mbuf)
+        perms = self.draw_perms(num_iters, B_local)
+        for it in range(num_iters):
+            n_mb = self.plan_epoch(valid_idx, B_local, B_all, mb, bufs=mbuf, perm=None if perms is None else perms[it])
             mbuf["eps_all"].normal_()
             if nb_batch > 0:
                 self._run_meta_batched(n_mb, nb_batch)

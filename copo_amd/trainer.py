@@ -322,13 +322,30 @@ class PPOPolicyBase:
         self._forward_backward()
         self._apply()
 
-    def plan_epoch(self, valid_idx, B_local, B_all, mb, bufs=None):
+    def draw_perms(self, n, B_local):
+        """Hook for pre-drawn permutations (one per SGD epoch / meta pass).  Batched draws (a segmented argsort, or one
+        flat 64-bit radix sort of segment-tagged keys) measured no faster than one `torch.randperm` per epoch on MI355X,
+        so plan_epoch draws its own."""
+        return None
+
+    def plan_epoch(self, valid_idx, B_local, B_all, mb, bufs=None, perm=None):
         """Shuffle this rank's valid rows and cut them into `n_mb` near-equal static-shape minibatches
         (n_mb from the LARGEST rank so that every rank issues the same number of collectives).
         `bufs` = dict(rows_all, w_all, denom_all, k); default: the SGD buffers."""
         rs = self._row_sources if bufs is None else bufs
         n_mb = max(1, math.ceil(max(B_all) / mb))
         dev = self.device
+        if dev.type == "cuda" and len(B_all) <= 16:
+            # one kernel builds the tables from the permutation (same tables as the tensor code below)
+            import ctypes as C
+            from . import _capi
+            rp = perm if perm is not None else (torch.randperm(B_local, device=dev) if B_local > 0 else valid_idx)
+            ball = (C.c_int64 * len(B_all))(*[int(b) for b in B_all])
+            _capi.check(_capi.lib.copo_plan_epoch(
+                valid_idx.data_ptr() if B_local > 0 else None, rp.data_ptr() if B_local > 0 else None, int(B_local),
+                int(n_mb), int(mb), ball, len(B_all), rs["rows_all"].data_ptr(), rs["w_all"].data_ptr(),
+                rs["denom_all"].data_ptr(), rs["k"].data_ptr(), _capi.current_stream()))
+            return n_mb
         perm = valid_idx[torch.randperm(B_local, device=dev)] if B_local > 0 else valid_idx
         q, r = divmod(B_local, n_mb)
         k = torch.arange(n_mb, device=dev)
@@ -376,8 +393,9 @@ class PPOPolicyBase:
         fz.stats.zero_()
         fz.sync_mirror()          # graph replays below do not run python: refresh the transposed weights here if needed
         steps = 0
-        for _ in range(num_epochs):
-            n_mb = self.plan_epoch(valid_idx, B_local, B_all, mb)
+        perms = self.draw_perms(num_epochs, B_local)
+        for ep in range(num_epochs):
+            n_mb = self.plan_epoch(valid_idx, B_local, B_all, mb, perm=None if perms is None else perms[ep])
             for _k in range(n_mb):
                 if D.is_dist():
                     self._sgd[0]()
@@ -406,8 +424,9 @@ class PPOPolicyBase:
                 self._sgd = GraphedCallable(self._sgd_step_local, self.use_graphs)
         rs["stats"].zero_()
         steps = 0
-        for _ in range(num_epochs):
-            n_mb = self.plan_epoch(valid_idx, B_local, B_all, mb)
+        perms = self.draw_perms(num_epochs, B_local)
+        for ep in range(num_epochs):
+            n_mb = self.plan_epoch(valid_idx, B_local, B_all, mb, perm=None if perms is None else perms[ep])
             for _k in range(n_mb):
                 if D.is_dist():
                     self._sgd[0]()

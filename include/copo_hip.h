@@ -198,6 +198,15 @@ int copo_lcf_mix_partial_f32(const float* adv, const float* nei_adv, const float
 int copo_lcf_mix_apply_f32(const float* mixed, const float* glob_adv, const uint8_t* valid, int64_t B,
                            const double* stats, float* norm_adv, float* glob_adv_std, void* stream);
 
+/* Minibatch plan of one SGD epoch (the static-shape replacement of RLlib's shuffled minibatch iterator used by
+ * `train_one_step`, algo_copo.py:555-558): from a permutation `perm` of this rank's B_local valid rows `valid_idx`,
+ * minibatch k takes q + (k < r) consecutive entries of the shuffled list (q, r = divmod(B_local, n_mb)); rows / w are
+ * [n_mb][mb] (padding: row 0, weight 0), denom[k] = number of rows of minibatch k over ALL ranks (B_all: HOST array of
+ * `world` counts), *mb_index (may be NULL) is reset to 0. */
+int copo_plan_epoch(const int64_t* valid_idx, const int64_t* perm, int64_t B_local, int32_t n_mb, int32_t mb,
+                    const int64_t* B_all_host, int32_t world, int64_t* rows, float* w, float* denom, int64_t* mb_index,
+                    void* stream);
+
 /* ---- fused minibatch learner --------------------------------------------------------------------------------
  * Replaces, for one static-shape minibatch, `Policy.loss` + autograd + Adam of the reference
  * (algo_ippo.py:78-172, algo_ccppo.py:376-472, algo_copo.py:311-424; RLlib train_one_step, algo_copo.py:555-558)

@@ -263,3 +263,42 @@ def test_batched_meta_pass_equals_sequential_steps(nb, store):
     # the dot products of the last iteration, minibatch by minibatch, against the step-by-step gradients
     gv = b._meta_bufs["gv"][:5].cpu().numpy()
     assert np.all(np.isfinite(gv)) and np.abs(gv).max() > 0
+
+
+@pytest.mark.parametrize("B,B_all,mb", [(1337, [1337], 512), (1000, [1000, 700, 1290], 256), (0, [0, 40], 64), (5, [5], 512)])
+def test_plan_epoch_kernel_tables(B, B_all, mb):
+    """copo_plan_epoch == the tensor formulation of the epoch plan (shuffled valid rows cut into near-equal static
+    minibatches; denominators over all ranks), for ragged, multi-rank and empty-rank cases."""
+    import math
+    pol = _make("ippo", "none", 91, fused=True, hiddens=(64, 64), mb=mb)
+    R = 3000
+    batch = _dense_batch(pol, R, 91, seed=1)
+    pol.prepare_sgd(batch, R, mb)
+    valid_idx = torch.arange(R, device="cuda")[torch.randperm(R, device="cuda")][:B].sort().values.contiguous()
+    n_mb_exp = max(1, math.ceil(max(B_all) / mb))
+    rs = pol._row_sources
+    if rs["rows_all"].shape[0] < n_mb_exp:       # tables are normally sized by prepare_sgd from the largest rank
+        for k, dt in (("rows_all", torch.int64), ("w_all", torch.float32)):
+            rs[k] = torch.zeros(n_mb_exp, mb, dtype=dt, device="cuda")
+        rs["denom_all"] = torch.ones(n_mb_exp, device="cuda")
+    rs["k"].fill_(7)
+    torch.manual_seed(123)
+    n_mb = pol.plan_epoch(valid_idx, B, B_all, mb)
+    assert n_mb == n_mb_exp and int(rs["k"]) == 0
+    torch.manual_seed(123)
+    perm = valid_idx[torch.randperm(B, device="cuda")] if B > 0 else valid_idx
+    q, r = divmod(B, n_mb)
+    rows = np.zeros((n_mb, mb), np.int64)
+    w = np.zeros((n_mb, mb), np.float32)
+    pn = perm.cpu().numpy()
+    for k in range(n_mb):
+        start, size = k * q + min(k, r), q + (1 if k < r else 0)
+        rows[k, :size] = pn[start:start + size]
+        w[k, :size] = 1.0
+    denom = np.zeros(n_mb)
+    for Br in B_all:
+        qq, rr = divmod(Br, n_mb)
+        denom += qq + (np.arange(n_mb) < rr)
+    np.testing.assert_array_equal(rs["rows_all"][:n_mb].cpu().numpy(), rows)
+    np.testing.assert_array_equal(rs["w_all"][:n_mb].cpu().numpy(), w)
+    np.testing.assert_array_equal(rs["denom_all"][:n_mb].cpu().numpy(), np.maximum(denom, 1.0).astype(np.float32))
