@@ -1029,6 +1029,128 @@ __global__ void __launch_bounds__(64 * WAVES) rowpass_kernel(FusedArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// forward-only pass of the same nets for rollouts and the dense postprocess: 16 dense rows per workgroup and net,
+// both layers through the transposed weight mirror (see rowpass_kernel), heads on the vector ALUs.  Net 0 (policy)
+// can sample: action = mean + exp(log_std) * eps, its log-probability and the clipped action the simulator takes.
+// ------------------------------------------------------------------------------------------------------------
+struct FwdArgs {
+    copo_ppo_cfg c;
+    const float* theta;
+    const float* theta_t;
+    const float* obs_src;     // [n_rows][pol.in_dim]
+    const float* cc_src;      // [n_rows][val.in_dim] (value nets)
+    int64_t n_rows;
+    int32_t first_net, n_nets;
+    float* values;            // [n_nets][n_rows]: output 0 of value nets (slot of a policy net unused)
+    float* dist_inputs;       // policy: [n_rows][4] or NULL
+    const float* eps;         // policy: [n_rows][2] standard normal draws, or NULL = no sampling
+    float* action;            // [n_rows][2]
+    float* logp;              // [n_rows]
+    float* clipped;           // [n_rows][2] or NULL
+};
+
+template <int NT, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) mlp_fwd_kernel(FwdArgs a) {
+    extern __shared__ float4 fwd_lds[];
+    constexpr int H = 16 * NT * WAVES, HP = H + 4, TH = 64 * WAVES, TPR = TH / HT;
+    constexpr int DB = NT >= 8 ? 4 : (H / 16 >= 8 ? 8 : H / 16);
+    const copo_ppo_cfg& c = a.c;
+    const int g = a.first_net + blockIdx.y;
+    const int64_t m0 = (int64_t)blockIdx.x * HT;
+    const copo_net_layout L = g == 0 ? c.pol : c.val[g - 1];
+    const float* src = g == 0 ? a.obs_src : a.cc_src;
+    const int K1 = L.in_dim, OD = L.out_dim, K1P = rowpass_k1p(K1), XP = K1P + 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 15, lj = lane >> 4, cb = wave * (16 * NT);
+    float* xs = reinterpret_cast<float*>(fwd_lds);     // [HT][XP]
+    float* h1s = xs + HT * XP;                          // [HT][HP]
+    float* h2s = h1s + HT * HP;                         // [HT][HP]
+    float* w3s = h2s + HT * HP;                         // [4][H]
+    BRing<NT, DB> ring;
+    ring.start(a.theta_t + L.w1, H, cb, ln, lj);
+    if ((K1 & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const int qn = K1P >> 2;
+        for (int i = tid; i < HT * qn; i += TH) {
+            const int row = i / qn, k = (i - row * qn) * 4;
+            const bool ok = (m0 + row < a.n_rows) && (k < K1);
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)(m0 + row < a.n_rows ? m0 + row : 0) * K1 + (k < K1 ? k : 0));
+            *reinterpret_cast<float4*>(xs + row * XP + k) = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    } else {
+        for (int i = tid; i < HT * K1P; i += TH) {
+            const int row = i / K1P, k = i - row * K1P;
+            const bool ok = (m0 + row < a.n_rows) && (k < K1);
+            const float v = src[(size_t)(m0 + row < a.n_rows ? m0 + row : 0) * K1 + (k < K1 ? k : 0)];
+            xs[row * XP + k] = ok ? v : 0.0f;
+        }
+    }
+    for (int i = tid; i < OD * H; i += TH) w3s[i] = a.theta[L.w3 + i];
+    __syncthreads();
+    v4f acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
+    ring.run(xs, XP, K1P, ln, lj, acc);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int col = cb + NT * ln + t;
+        const float bv = a.theta[L.b1 + col];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) h1s[(4 * lj + rr) * HP + col] = tanh_fast(acc[t][rr] + bv);
+    }
+    ring.start(a.theta_t + L.w2, H, cb, ln, lj);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
+    ring.run(h1s, HP, H, ln, lj, acc);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int col = cb + NT * ln + t;
+        const float bv = a.theta[L.b2 + col];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) h2s[(4 * lj + rr) * HP + col] = tanh_fast(acc[t][rr] + bv);
+    }
+    __syncthreads();
+    const int r = tid / TPR, part = tid % TPR;
+    const int64_t m = m0 + r;
+    float out[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = part; i < H; i += TPR) {
+        const float h = h2s[r * HP + i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < OD) out[j] += h * w3s[j * H + i];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) out[j] += __shfl_xor(out[j], o);
+    }
+    if (part != 0 || m >= a.n_rows) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[j] += a.theta[L.b3 + (j < OD ? j : 0)];
+    if (g != 0) {
+        a.values[(size_t)blockIdx.y * a.n_rows + m] = out[0];
+        return;
+    }
+    if (a.dist_inputs) *reinterpret_cast<float4*>(a.dist_inputs + (size_t)m * 4) = make_float4(out[0], out[1], out[2], out[3]);
+    if (a.eps) {       // TorchDiagGaussian.sample / logp (RLlib): mean + std * eps, -0.5 sum z^2 - sum log_std - log(2 pi)
+        float act[2], lp = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float sd = expf(out[2 + j]);
+            act[j] = out[j] + sd * a.eps[(size_t)m * 2 + j];
+            const float z = (act[j] - out[j]) / sd;
+            lp += -0.5f * z * z - out[2 + j] - 0.5f * kLog2Pi;
+        }
+        a.action[(size_t)m * 2] = act[0];
+        a.action[(size_t)m * 2 + 1] = act[1];
+        a.logp[m] = lp;
+        if (a.clipped) {
+            a.clipped[(size_t)m * 2] = fminf(fmaxf(act[0], -1.0f), 1.0f);
+            a.clipped[(size_t)m * 2 + 1] = fminf(fmaxf(act[1], -1.0f), 1.0f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // LCF meta update tail (fp64, like the reference's float64 lcf_parameters)
 // ------------------------------------------------------------------------------------------------------------
 struct MetaArgs {
@@ -1828,6 +1950,9 @@ static hipError_t gemm_lds_attrs() {
                               reinterpret_cast<const void*>(rowpass_kernel<1, 4, true>), reinterpret_cast<const void*>(rowpass_kernel<2, 4, true>),
                               reinterpret_cast<const void*>(rowpass_kernel<2, 8, true>), reinterpret_cast<const void*>(rowpass_kernel<4, 8, true>)})
             if ((r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) != hipSuccess) e = r;
+        for (const void* f : {reinterpret_cast<const void*>(mlp_fwd_kernel<1, 4>), reinterpret_cast<const void*>(mlp_fwd_kernel<2, 4>),
+                              reinterpret_cast<const void*>(mlp_fwd_kernel<2, 8>), reinterpret_cast<const void*>(mlp_fwd_kernel<4, 8>)})
+            if ((r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) != hipSuccess) e = r;
         if ((r = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_adam_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)) != hipSuccess) e = r;
         return e;
     }();
@@ -2031,6 +2156,40 @@ extern "C" int copo_ppo_fused_step_f32(const copo_ppo_cfg* cfg, float* theta, fl
     a.theta_t = theta_t;
     hipError_t e = launch_fused_step(a, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
+}
+
+extern "C" int copo_mlp_forward_f32(const copo_ppo_cfg* cfg, const float* theta, const float* theta_t, const float* obs_src,
+                                    const float* cc_src, int64_t n_rows, int32_t first_net, int32_t n_nets, float* values,
+                                    float* dist_inputs, const float* eps, float* action, float* logp, float* clipped,
+                                    void* stream) {
+    int rc = check_cfg(cfg);
+    if (rc != COPO_OK) return rc;
+    if (!theta || !theta_t || !obs_src) return COPO_ERR_NULL;
+    if (n_rows < 1 || first_net < 0 || n_nets < 1 || first_net + n_nets > 1 + cfg->n_value_heads) return COPO_ERR_DIM;
+    if (first_net + n_nets > 1 && !values) return COPO_ERR_NULL;
+    if (first_net == 0 && eps && (!action || !logp)) return COPO_ERR_NULL;
+    const int H = cfg->hidden;
+    if (!(H == 64 || H == 128 || H == 256 || H == 512) || (reinterpret_cast<uintptr_t>(theta_t) & 15) != 0) return COPO_ERR_DIM;
+    if (gemm_lds_attrs() != hipSuccess) return COPO_ERR_DEVICE;
+    int kmax = 0;
+    const copo_net_layout* nets[4] = {&cfg->pol, &cfg->val[0], &cfg->val[1], &cfg->val[2]};
+    for (int g = first_net; g < first_net + n_nets; ++g) {
+        kmax = nets[g]->in_dim > kmax ? nets[g]->in_dim : kmax;
+        if (nets[g]->w1 % 4 != 0 || nets[g]->w2 % 4 != 0) return COPO_ERR_DIM;
+    }
+    const size_t lds = ((size_t)HT * (rowpass_k1p(kmax) + 4) + (size_t)2 * HT * (H + 4) + 4 * H) * sizeof(float);
+    if (lds > 150 * 1024) return COPO_ERR_DIM;
+    FwdArgs a{*cfg, theta, theta_t, obs_src, cc_src ? cc_src : obs_src, n_rows, first_net, n_nets, values, dist_inputs, eps,
+              action, logp, clipped};
+    const dim3 grid((unsigned)((n_rows + HT - 1) / HT), n_nets);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (H) {
+        case 64: hipLaunchKernelGGL((mlp_fwd_kernel<1, 4>), grid, dim3(256), lds, st, a); break;
+        case 128: hipLaunchKernelGGL((mlp_fwd_kernel<2, 4>), grid, dim3(256), lds, st, a); break;
+        case 256: hipLaunchKernelGGL((mlp_fwd_kernel<2, 8>), grid, dim3(512), lds, st, a); break;
+        default: hipLaunchKernelGGL((mlp_fwd_kernel<4, 8>), grid, dim3(512), lds, st, a); break;
+    }
+    return hipGetLastError() == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
 }
 
 extern "C" int copo_transpose_weights_f32(const copo_ppo_cfg* cfg, const float* theta, float* theta_t, void* stream) {

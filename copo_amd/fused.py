@@ -125,6 +125,30 @@ class FusedLearner:
                                                              self.flat_t.data_ptr(), _capi.current_stream()))
             self._mirror_version = v
 
+    @property
+    def can_forward(self):
+        """The forward-only kernel covers this layout (hidden 64 / 128 / 256 / 512)."""
+        return self.cfg.hidden in (64, 128, 256, 512)
+
+    def act(self, obs, eps, action, logp, dist_inputs, clipped=None):
+        """Policy forward + sampling for dense obs [R, O] into caller-owned tensors (rollouts)."""
+        R = obs.shape[0]
+        _capi.check(_capi.lib.copo_mlp_forward_f32(
+            C.byref(self.cfg), self.flat.flat.data_ptr(), self.flat_t.data_ptr(), obs.data_ptr(), None, R, 0, 1, None,
+            dist_inputs.data_ptr(), eps.data_ptr(), action.data_ptr(), logp.data_ptr(),
+            None if clipped is None else clipped.data_ptr(), _capi.current_stream()))
+
+    def values(self, obs, cc_obs, out=None):
+        """[n_value_heads, R] critic values for dense rows (postprocess)."""
+        R, nv = obs.shape[0], int(self.cfg.n_value_heads)
+        if out is None:
+            out = torch.empty(nv, R, dtype=torch.float32, device=obs.device)
+        _capi.check(_capi.lib.copo_mlp_forward_f32(
+            C.byref(self.cfg), self.flat.flat.data_ptr(), self.flat_t.data_ptr(), obs.data_ptr(),
+            None if cc_obs is None else cc_obs.data_ptr(), R, 1, nv, out.data_ptr(), None, None, None, None, None,
+            _capi.current_stream()))
+        return out
+
     def step(self, rs, head_mode=_capi.HEAD_PPO, apply_adam=True, theta=None, grad=None, stats=None, bump_index=True):
         """One fused minibatch pass over the sources bound in `rs` (PPOPolicyBase._row_sources layout)."""
         cc = rs["cc_obs"]

@@ -116,12 +116,17 @@ class VecSampler:
         sim, pol = self.sim, self.policy
         EN = self.E * self.N
         lib, h, stream = sim._capi.lib, sim._h, sim._stream()
+        fz = pol.fused if (pol.fused is not None and pol.fused.can_forward and pol.config.get("use_fused_inference", True)) else None
         for t in range(self.T):
-            a, lp, di = pol.compute_actions(self.obs[t].view(EN, self.O), self.eps[t].view(EN, 2))
-            self.actions[t].view(EN, 2).copy_(a)
-            self.logp[t].view(EN).copy_(lp)
-            self.dist_inputs[t].view(EN, 4).copy_(di)
-            torch.clamp(a.view(self.E, self.N, 2), -1.0, 1.0, out=self.clipped[t])
+            if fz is not None:        # one kernel: both layers, head, sampling, log-probability, clipping
+                fz.act(self.obs[t].view(EN, self.O), self.eps[t].view(EN, 2), self.actions[t], self.logp[t],
+                       self.dist_inputs[t], self.clipped[t])
+            else:
+                a, lp, di = pol.compute_actions(self.obs[t].view(EN, self.O), self.eps[t].view(EN, 2))
+                self.actions[t].view(EN, 2).copy_(a)
+                self.logp[t].view(EN).copy_(lp)
+                self.dist_inputs[t].view(EN, 4).copy_(di)
+                torch.clamp(a.view(self.E, self.N, 2), -1.0, 1.0, out=self.clipped[t])
             sim._capi.check(lib.copo_sim_step(h, self.clipped[t].data_ptr(), C.byref(self._outs[t]), stream))
 
     def sample(self):
@@ -132,6 +137,8 @@ class VecSampler:
             self.obs[0].copy_(self.obs[self.T])
         self.eps.normal_()
         self.sim.flush()
+        if self.policy.fused is not None:
+            self.policy.fused.sync_mirror()      # the captured rollout reads the transposed weight mirror
         self._loop()
         self.env_steps_total += self.T * self.E
         self.rew3[2].copy_(self.glob.unsqueeze(-1).expand(self.T, self.E, self.N))
@@ -476,7 +483,14 @@ class PPOPolicyBase:
         cc = self.critic_obs_dense(b)
         b["centralized_critic_obs"] = cc
         H = self.gae_heads()
-        vals = self.value_heads_dense(cc.reshape(T * M, -1)).reshape(H, T, M).contiguous()
+        fz = self.fused
+        if fz is not None and fz.can_forward and self.config.get("use_fused_inference", True) and \
+                int(fz.cfg.n_value_heads) == H:
+            fz.sync_mirror()
+            cc_flat = cc.reshape(T * M, -1)
+            vals = fz.values(obs.reshape(T * M, -1), None if cc_flat.data_ptr() == obs.data_ptr() else cc_flat).view(H, T, M)
+        else:
+            vals = self.value_heads_dense(cc.reshape(T * M, -1)).reshape(H, T, M).contiguous()
         rew = b["rew3"][:H].reshape(H, T, M)
         flags = b[SampleBatch.FLAGS].reshape(T, M)
         adv, tgt = torch.empty_like(vals), torch.empty_like(vals)

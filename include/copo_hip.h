@@ -259,6 +259,15 @@ int copo_ppo_fused_step_f32(const copo_ppo_cfg* cfg, float* theta, float* adam_m
                             float* workspace, float* stats, int32_t apply_adam, int32_t head_mode,
                             int64_t* mb_index, int32_t bump_index, float* theta_t, void* stream);
 int copo_transpose_weights_f32(const copo_ppo_cfg* cfg, const float* theta, float* theta_t, void* stream);
+/* Forward-only pass of nets [first_net, first_net + n_nets) of the layout (0 = policy, 1.. = value nets) over n_rows
+ * DENSE rows: `model.forward` / `central_value_function` / `get_nei_value` / `get_global_value` of the reference's
+ * models (algo_ccppo.py:74-219, algo_copo.py:96-182) for rollouts and the dense postprocess.  values [n_nets][n_rows]
+ * (row of a policy net unused); for the policy net optionally dist_inputs [n_rows][4], and with eps [n_rows][2]
+ * (standard normal draws) the sampled action, its log-probability and the action clipped to [-1, 1].  Needs the
+ * transposed mirror theta_t and hidden in {64, 128, 256, 512}. */
+int copo_mlp_forward_f32(const copo_ppo_cfg* cfg, const float* theta, const float* theta_t, const float* obs_src,
+                         const float* cc_src, int64_t n_rows, int32_t first_net, int32_t n_nets, float* values,
+                         float* dist_inputs, const float* eps, float* action, float* logp, float* clipped, void* stream);
 /* Adam on the flat buffers (the data-parallel path: after the gradient all-reduce); theta_t as above or NULL */
 int copo_adam_step_f32(const copo_ppo_cfg* cfg, float* theta, float* adam_m, float* adam_v, const float* grad,
                        int64_t n, int64_t* step, int64_t* mb_index, float* theta_t, void* stream);

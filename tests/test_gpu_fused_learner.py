@@ -302,3 +302,40 @@ def test_plan_epoch_kernel_tables(B, B_all, mb):
     np.testing.assert_array_equal(rs["rows_all"][:n_mb].cpu().numpy(), rows)
     np.testing.assert_array_equal(rs["w_all"][:n_mb].cpu().numpy(), w)
     np.testing.assert_array_equal(rs["denom_all"][:n_mb].cpu().numpy(), np.maximum(denom, 1.0).astype(np.float32))
+
+
+@pytest.mark.parametrize("name,fuse,odim,over", [
+    ("copo", "none", 92, {}),
+    ("ippo", "none", 91, dict(hiddens=(128, 128))),
+    ("ccppo", "mf", 91, {}),
+    ("ccppo", "concat", 91, dict(hiddens=(64, 64))),
+])
+def test_forward_kernel_matches_torch_models(name, fuse, odim, over):
+    """copo_mlp_forward_f32 (rollout inference + dense value heads) == the torch modules: logits, sampled action,
+    log-probability, clipped action, every critic head; ragged row count."""
+    pol = _make(name, fuse, odim, fused=True, **over)
+    with torch.no_grad():
+        for p in pol.model.parameters():
+            if p.dtype == torch.float32:
+                p.add_(torch.randn_like(p) * 0.05)
+    fz = pol.fused
+    assert fz.can_forward
+    fz.sync_mirror()
+    R = 1000 + 7
+    g = torch.Generator(device="cuda").manual_seed(4)
+    obs = torch.rand(R, odim, device="cuda", generator=g)
+    eps = torch.randn(R, 2, device="cuda", generator=g)
+    a_ref, lp_ref, di_ref = pol.compute_actions(obs, eps)
+    a, lp, di, cl = (torch.empty(R, 2, device="cuda"), torch.empty(R, device="cuda"), torch.empty(R, 4, device="cuda"),
+                     torch.empty(R, 2, device="cuda"))
+    fz.act(obs, eps, a, lp, di, cl)
+    np.testing.assert_allclose(di.cpu().numpy(), di_ref.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(a.cpu().numpy(), a_ref.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(lp.cpu().numpy(), lp_ref.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    assert torch.equal(cl, a.clamp(-1.0, 1.0))
+    cdim = pol.model.value_input_dim()
+    cc = obs if cdim == odim else torch.cat([obs, torch.randn(R, cdim - odim, device="cuda", generator=g) * 0.5], 1).contiguous()
+    v_ref = pol.value_heads_dense(cc)
+    v = fz.values(obs, None if cc is obs else cc)
+    assert v.shape == v_ref.shape
+    np.testing.assert_allclose(v.cpu().numpy(), v_ref.cpu().numpy(), rtol=5e-5, atol=5e-6)
