@@ -268,6 +268,52 @@ hipError_t launch_lcf_mix_apply(const float* mixed, const float* glob_adv, const
     return hipGetLastError();
 }
 
+// ---- episode metrics -------------------------------------------------------------------------------------------
+// The sums `MultiAgentDrivingCallbacks` needs (utils/callbacks.py:48-110) over the rows of one iteration, in one
+// workgroup (fixed order -> deterministic): out[0..7] over rows that acted AND terminated = {count, arrive, crash,
+// out_of_road, max_step, sum info[5], sum info[6], sum info[7]}; out[8..14] over rows that acted = {count,
+// sum info[0..4], sum neighbour count}.
+__global__ void __launch_bounds__(1024) episode_metrics_kernel(const uint8_t* flags, const float* info, const int32_t* nbr_cnt,
+                                                               int64_t R, double* out) {
+    __shared__ double red[16][15];
+    double s[15];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) s[k] = 0.0;
+    for (int64_t i = threadIdx.x; i < R; i += blockDim.x) {
+        const unsigned f = flags[i];
+        if (!(f & COPO_F_ACTED)) continue;
+        const float* q = info + i * COPO_INFO_DIM;
+        s[8] += 1.0;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) s[9 + k] += (double)q[k];
+        s[14] += (double)nbr_cnt[i];
+        if (f & COPO_F_DONE) {
+            s[0] += 1.0;
+            s[1] += (f & COPO_F_ARRIVE) ? 1.0 : 0.0;
+            s[2] += (f & COPO_F_CRASH) ? 1.0 : 0.0;
+            s[3] += (f & COPO_F_OUT) ? 1.0 : 0.0;
+            s[4] += (f & COPO_F_MAXSTEP) ? 1.0 : 0.0;
+            s[5] += (double)q[5];
+            s[6] += (double)q[6];
+            s[7] += (double)q[7];
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 15; ++k) {
+        double v = s[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 15) {
+        double v = 0.0;
+        for (int w = 0; w < nw; ++w) v += red[w][threadIdx.x];
+        out[threadIdx.x] = v;
+    }
+}
+
 // ---- minibatch plan of one SGD epoch ------------------------------------------------------------------------
 // rows [n_mb][mb] / w [n_mb][mb] / denom [n_mb] from a permutation of this rank's valid rows: minibatch k takes
 // size_k = q + (k < r) consecutive entries of the shuffled list (q, r = divmod(B_local, n_mb)); the denominators add
@@ -315,6 +361,15 @@ hipError_t launch_plan_epoch(const PlanArgs& a, hipStream_t s) {
 }
 
 }  // namespace copo
+
+extern "C" int copo_episode_metrics(const uint8_t* flags, const float* info, const int32_t* nbr_cnt, int64_t n_rows,
+                                    double* out15, void* stream) {
+    if (!flags || !info || !nbr_cnt || !out15) return COPO_ERR_NULL;
+    if (n_rows < 0) return COPO_ERR_DIM;
+    hipLaunchKernelGGL(copo::episode_metrics_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), flags, info,
+                       nbr_cnt, n_rows, out15);
+    return hipGetLastError() == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
+}
 
 extern "C" int copo_plan_epoch(const int64_t* valid_idx, const int64_t* perm, int64_t B_local, int32_t n_mb, int32_t mb,
                                const int64_t* B_all_host, int32_t world, int64_t* rows, float* w, float* denom,

@@ -611,20 +611,35 @@ class VecTrainer:
         """Device-side reduction of the terminal flags / info of this iteration's rows: the quantities
         `MultiAgentDrivingCallbacks` derives from info dicts (utils/callbacks.py:48-110), aggregated over the
         agents that terminated in this iteration."""
-        flags = batch[SampleBatch.FLAGS].reshape(-1).to(torch.int32)
+        fl8 = batch[SampleBatch.FLAGS].reshape(-1)
         info = batch["infos"].reshape(-1, 8)
-        acted = (flags & F_ACTED) > 0
-        done = ((flags & F_DONE) > 0) & acted
+        nbr = batch["nbr_cnt"].reshape(-1)
+        if fl8.is_cuda and fl8.dtype == torch.uint8 and nbr.dtype == torch.int32 and info.dtype == torch.float32:
+            from . import _capi       # one kernel, one host read
+            fl8, info, nbr = fl8.contiguous(), info.contiguous(), nbr.contiguous()
+            sums = torch.empty(15, dtype=torch.float64, device=fl8.device)
+            _capi.check(_capi.lib.copo_episode_metrics(fl8.data_ptr(), info.data_ptr(), nbr.data_ptr(), fl8.numel(),
+                                                       sums.data_ptr(), _capi.current_stream()))
+        else:
+            flags = fl8.to(torch.int32)
+            acted = (flags & F_ACTED) > 0
+            done = ((flags & F_DONE) > 0) & acted
+            sums = self._episode_sums_torch(flags, info, acted, done, nbr)
+        D.all_reduce_sum_(sums)
+        return self._metrics_from_sums(sums)
+
+    def _episode_sums_torch(self, flags, info, acted, done, nbr):
         f64 = torch.float64
-        sums = torch.stack([
+        return torch.stack([
             done.sum().to(f64), ((flags & F_ARRIVE) > 0)[done].sum().to(f64), ((flags & F_CRASH) > 0)[done].sum().to(f64),
             ((flags & F_OUT) > 0)[done].sum().to(f64), ((flags & F_MAXSTEP) > 0)[done].sum().to(f64),
             info[done, 5].sum().to(f64), info[done, 6].sum().to(f64), info[done, 7].sum().to(f64),
             acted.sum().to(f64), info[acted, 0].sum().to(f64), info[acted, 1].sum().to(f64), info[acted, 2].sum().to(f64),
             info[acted, 3].sum().to(f64), info[acted, 4].sum().to(f64),
-            batch["nbr_cnt"].reshape(-1)[acted].sum().to(f64),
+            nbr[acted].sum().to(f64),
         ])
-        D.all_reduce_sum_(sums)
+
+    def _metrics_from_sums(self, sums):
         (nd, arr, crash, out, maxs, ep_len, ep_rew, rc, na, vel, steer, acc, srew, cost, nnb) = sums.tolist()
         cm = {}
         if nd > 0:

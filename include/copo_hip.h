@@ -198,6 +198,13 @@ int copo_lcf_mix_partial_f32(const float* adv, const float* nei_adv, const float
 int copo_lcf_mix_apply_f32(const float* mixed, const float* glob_adv, const uint8_t* valid, int64_t B,
                            const double* stats, float* norm_adv, float* glob_adv_std, void* stream);
 
+/* Sums behind `MultiAgentDrivingCallbacks.on_episode_end / on_train_result` (utils/callbacks.py:48-110) over the
+ * n_rows rows of one iteration (flags u8, info [n_rows][COPO_INFO_DIM], nbr_cnt i32): out15[0..7] over rows that acted
+ * and terminated = {count, arrive, crash, out_of_road, max_step, sum info[5], info[6], info[7]}, out15[8..14] over rows
+ * that acted = {count, sum info[0..4], sum nbr_cnt}. */
+int copo_episode_metrics(const uint8_t* flags, const float* info, const int32_t* nbr_cnt, int64_t n_rows, double* out15,
+                         void* stream);
+
 /* Minibatch plan of one SGD epoch (the static-shape replacement of RLlib's shuffled minibatch iterator used by
  * `train_one_step`, algo_copo.py:555-558): from a permutation `perm` of this rank's B_local valid rows `valid_idx`,
  * minibatch k takes q + (k < r) consecutive entries of the shuffled list (q, r = divmod(B_local, n_mb)); rows / w are

@@ -254,3 +254,23 @@ def test_curriculum_baseline_schedule():
         assert res["custom_metrics"]["num_agents_curriculum"] == n
     assert seen == [5, 5, 10, 10, 15, 15, 20, 20], seen     # quarters at 256 / 512 / 768 of 1024 env steps
     a.stop()
+
+
+def test_episode_metrics_kernel_equals_tensor_code():
+    """copo_episode_metrics == the masked tensor reductions it replaces (utils/callbacks.py:48-110 quantities)."""
+    from copo_amd.torch_copo.algo_ippo import IPPOTrainer
+    from copo_amd.torch_copo.utils.env_wrappers import MultiAgentIntersectionEnv, get_rllib_compatible_env
+    a = IPPOTrainer(config=dict(env=get_rllib_compatible_env(MultiAgentIntersectionEnv), env_config=dict(num_agents=20, horizon=30),
+                                num_envs=16, train_batch_size=16 * 40, sgd_minibatch_size=128, num_sgd_iter=1, seed=0,
+                                model={"fcnet_hiddens": [64, 64]}))
+    a.train()
+    b = a._last_batch
+    got = a.episode_metrics(b)
+    flags = b[SampleBatch.FLAGS].reshape(-1).to(torch.int32)
+    acted = (flags & 1) > 0
+    done = ((flags & 2) > 0) & acted
+    ref = a._metrics_from_sums(a._episode_sums_torch(flags, b["infos"].reshape(-1, 8), acted, done, b["nbr_cnt"].reshape(-1)))
+    assert got["num_terminated_agents"] > 0 and set(got) == set(ref)
+    for k in ref:
+        assert abs(got[k] - ref[k]) <= 1e-6 * max(1.0, abs(ref[k])), (k, got[k], ref[k])
+    a.stop()
