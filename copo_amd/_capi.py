@@ -103,7 +103,7 @@ _SIGS = {
     "copo_meta_step_f64": (C.c_int, [C.POINTER(PpoCfg)] + [C.c_void_p] * 13 + [C.c_int32, C.c_int32] + [C.c_void_p] * 5 +
                            [C.c_double, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "copo_episode_metrics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
-    "copo_plan_epoch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32] +
+    "copo_plan_epoch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32] +
                         [C.c_void_p] * 5),
     "copo_meta_fold_len": (C.c_int64, [C.POINTER(PpoCfg)]),
     "copo_meta_batch_workspace_floats": (C.c_int64, [C.POINTER(PpoCfg), C.c_int32]),

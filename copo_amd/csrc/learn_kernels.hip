@@ -318,9 +318,33 @@ __global__ void __launch_bounds__(1024) episode_metrics_kernel(const uint8_t* fl
 // rows [n_mb][mb] / w [n_mb][mb] / denom [n_mb] from a permutation of this rank's valid rows: minibatch k takes
 // size_k = q + (k < r) consecutive entries of the shuffled list (q, r = divmod(B_local, n_mb)); the denominators add
 // the same split of every rank's row count.  One launch instead of ~20 tensor ops per epoch.
+// Keyed pseudo-random permutation of [0, n): a 4-round Feistel network on the next even power-of-two domain with
+// cycle walking (values >= n are encrypted again; expected < 4 walks).  A bijection for every key, O(1) memory, no sort.
+__device__ __forceinline__ uint32_t perm_mix(uint32_t x) {
+    x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t feistel_perm(uint32_t i, uint32_t n, uint32_t half, const uint32_t* key) {
+    const uint32_t mask = (1u << half) - 1u;
+    uint32_t x = i;
+    do {
+        uint32_t l = x >> half, r = x & mask;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t t = l ^ (perm_mix(r ^ key[k]) & mask);
+            l = r;
+            r = t;
+        }
+        x = (l << half) | r;
+    } while (x >= n);
+    return x;
+}
+
 struct PlanArgs {
     const int64_t* valid_idx;   // [B_local]
-    const int64_t* perm;        // [B_local] permutation of 0 .. B_local - 1
+    const int64_t* perm;        // [B_local] permutation of 0 .. B_local - 1, or NULL: keyed Feistel permutation
+    uint32_t key[4];
+    uint32_t half;              // half the (even) bit width of the Feistel domain
     int64_t B_local;
     int32_t n_mb, mb, world;
     int64_t B_all[16];          // every rank's valid-row count (by value: no device round trip)
@@ -348,7 +372,7 @@ __global__ void __launch_bounds__(256) plan_epoch_kernel(PlanArgs a) {
     if (in) {
         int64_t pos = start + j;
         pos = pos < a.B_local ? pos : a.B_local - 1;
-        row = a.valid_idx[a.perm[pos]];
+        row = a.valid_idx[a.perm ? a.perm[pos] : (int64_t)feistel_perm((uint32_t)pos, (uint32_t)a.B_local, a.half, a.key)];
     }
     a.rows[i] = row;
     a.w[i] = in ? 1.0f : 0.0f;
@@ -371,12 +395,16 @@ extern "C" int copo_episode_metrics(const uint8_t* flags, const float* info, con
     return hipGetLastError() == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
 }
 
-extern "C" int copo_plan_epoch(const int64_t* valid_idx, const int64_t* perm, int64_t B_local, int32_t n_mb, int32_t mb,
-                               const int64_t* B_all_host, int32_t world, int64_t* rows, float* w, float* denom,
-                               int64_t* mb_index, void* stream) {
-    if (!rows || !w || !denom || !B_all_host || (B_local > 0 && (!valid_idx || !perm))) return COPO_ERR_NULL;
-    if (B_local < 0 || n_mb < 1 || mb < 1 || world < 1 || world > 16) return COPO_ERR_DIM;
+extern "C" int copo_plan_epoch(const int64_t* valid_idx, const int64_t* perm, const uint32_t* key4_host, int64_t B_local,
+                               int32_t n_mb, int32_t mb, const int64_t* B_all_host, int32_t world, int64_t* rows, float* w,
+                               float* denom, int64_t* mb_index, void* stream) {
+    if (!rows || !w || !denom || !B_all_host || (B_local > 0 && (!valid_idx || (!perm && !key4_host)))) return COPO_ERR_NULL;
+    if (B_local < 0 || B_local > 0x7fffffffLL || n_mb < 1 || mb < 1 || world < 1 || world > 16) return COPO_ERR_DIM;
     copo::PlanArgs a;
+    int bits = 1;
+    while ((1LL << bits) < B_local) ++bits;
+    a.half = (uint32_t)((bits + 1) / 2);
+    for (int k = 0; k < 4; ++k) a.key[k] = key4_host ? key4_host[k] : 0u;
     a.valid_idx = valid_idx; a.perm = perm; a.B_local = B_local; a.n_mb = n_mb; a.mb = mb; a.world = world;
     for (int r = 0; r < 16; ++r) a.B_all[r] = r < world ? B_all_host[r] : 0;
     a.rows = rows; a.w = w; a.denom = denom; a.k_index = mb_index;

@@ -346,10 +346,17 @@ class PPOPolicyBase:
             # one kernel builds the tables from the permutation (same tables as the tensor code below)
             import ctypes as C
             from . import _capi
-            rp = perm if perm is not None else (torch.randperm(B_local, device=dev) if B_local > 0 else valid_idx)
+            # shuffle: an explicit permutation if given, else a keyed in-kernel permutation (keys from torch's CPU
+            # generator: reproducible under torch.manual_seed, no device sort); "shuffle": "randperm" keeps torch.randperm
+            key = None
+            if perm is None and B_local > 0:
+                if self.config.get("shuffle", "feistel") == "randperm":
+                    perm = torch.randperm(B_local, device=dev)
+                else:
+                    key = (C.c_uint32 * 4)(*[int(v) for v in torch.randint(0, 2 ** 31 - 1, (4,)).tolist()])
             ball = (C.c_int64 * len(B_all))(*[int(b) for b in B_all])
             _capi.check(_capi.lib.copo_plan_epoch(
-                valid_idx.data_ptr() if B_local > 0 else None, rp.data_ptr() if B_local > 0 else None, int(B_local),
+                valid_idx.data_ptr() if B_local > 0 else None, None if perm is None else perm.data_ptr(), key, int(B_local),
                 int(n_mb), int(mb), ball, len(B_all), rs["rows_all"].data_ptr(), rs["w_all"].data_ptr(),
                 rs["denom_all"].data_ptr(), rs["k"].data_ptr(), _capi.current_stream()))
             return n_mb

@@ -209,10 +209,11 @@ int copo_episode_metrics(const uint8_t* flags, const float* info, const int32_t*
  * `train_one_step`, algo_copo.py:555-558): from a permutation `perm` of this rank's B_local valid rows `valid_idx`,
  * minibatch k takes q + (k < r) consecutive entries of the shuffled list (q, r = divmod(B_local, n_mb)); rows / w are
  * [n_mb][mb] (padding: row 0, weight 0), denom[k] = number of rows of minibatch k over ALL ranks (B_all: HOST array of
- * `world` counts), *mb_index (may be NULL) is reset to 0. */
-int copo_plan_epoch(const int64_t* valid_idx, const int64_t* perm, int64_t B_local, int32_t n_mb, int32_t mb,
-                    const int64_t* B_all_host, int32_t world, int64_t* rows, float* w, float* denom, int64_t* mb_index,
-                    void* stream);
+ * `world` counts), *mb_index (may be NULL) is reset to 0.  perm NULL: the shuffle is a keyed pseudo-random permutation
+ * computed in the kernel (4-round Feistel network with cycle walking, key4_host = four 32-bit words on the HOST). */
+int copo_plan_epoch(const int64_t* valid_idx, const int64_t* perm, const uint32_t* key4_host, int64_t B_local, int32_t n_mb,
+                    int32_t mb, const int64_t* B_all_host, int32_t world, int64_t* rows, float* w, float* denom,
+                    int64_t* mb_index, void* stream);
 
 /* ---- fused minibatch learner --------------------------------------------------------------------------------
  * Replaces, for one static-shape minibatch, `Policy.loss` + autograd + Adam of the reference

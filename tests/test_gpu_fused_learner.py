@@ -282,6 +282,19 @@ def test_plan_epoch_kernel_tables(B, B_all, mb):
             rs[k] = torch.zeros(n_mb_exp, mb, dtype=dt, device="cuda")
         rs["denom_all"] = torch.ones(n_mb_exp, device="cuda")
     rs["k"].fill_(7)
+    # default shuffle: keyed in-kernel permutation -- every valid row exactly once, reproducible, key-dependent
+    got = []
+    for seed in (5, 5, 6):
+        torch.manual_seed(seed)
+        n_mb = pol.plan_epoch(valid_idx, B, B_all, mb)
+        sel = rs["rows_all"][:n_mb][rs["w_all"][:n_mb] > 0]
+        assert sorted(sel.tolist()) == valid_idx.tolist()
+        got.append(sel.clone())
+    assert torch.equal(got[0], got[1]) and (B < 50 or not torch.equal(got[0], got[2]))
+    if B > 200:       # not the identity, and spread: neighbours in the shuffled list are not neighbours in the input
+        pos = torch.searchsorted(valid_idx, got[0])
+        assert float((pos[1:] - pos[:-1]).abs().float().mean()) > B / 10
+    pol.config["shuffle"] = "randperm"
     torch.manual_seed(123)
     n_mb = pol.plan_epoch(valid_idx, B, B_all, mb)
     assert n_mb == n_mb_exp and int(rs["k"]) == 0
