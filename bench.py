@@ -256,6 +256,13 @@ def main():
                                               "(host has %d)" % (n, cdt, used, os.cpu_count() or 0)}
     trainer.stop()
     if rank == 0:
+        # libraries that write through C stdio (RCCL's start-up banner) sit in a buffer when stdout is a pipe and would
+        # otherwise be flushed AFTER the result at exit: push them out first so that the JSON is the last line
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(line), flush=True)
 
 

@@ -30,7 +30,10 @@ def init_from_env(device=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world == 1:
             os.environ.setdefault("MASTER_PORT", "29533")
-        td.init_process_group(backend="nccl" if use_cuda else "gloo", rank=rank, world_size=world)
+        # COPO_DIST_BACKEND=gloo: CUDA tensors over gloo (staged through the host) -- lets several ranks share ONE GPU,
+        # which RCCL refuses; used by the two-rank test of the fused data-parallel path on a single-GPU box
+        backend = os.environ.get("COPO_DIST_BACKEND") or ("nccl" if use_cuda else "gloo")
+        td.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
 

@@ -274,3 +274,50 @@ def test_episode_metrics_kernel_equals_tensor_code():
     for k in ref:
         assert abs(got[k] - ref[k]) <= 1e-6 * max(1.0, abs(ref[k])), (k, got[k], ref[k])
     a.stop()
+
+
+def test_two_ranks_fused_data_parallel_on_one_gpu():
+    """Two real ranks (gloo over CUDA tensors, both on cuda:0 -- RCCL would refuse to share a device) through the fused
+    data-parallel path: gradient all-reduce + flat Adam per minibatch, batched meta pass with exported gradient pairs,
+    gathered LCF rows.  Ranks own different scenes, must take the same number of steps and end with identical parameters."""
+    import subprocess
+    import sys
+    code = r'''
+import json, os, sys, torch
+sys.path.insert(0, os.getcwd())
+from copo_amd import dist as D
+rank, _, world = D.init_from_env("cuda")
+import torch.distributed as td
+from copo_amd.torch_copo.algo_copo import CoPOTrainer
+from copo_amd.torch_copo.utils.env_wrappers import MultiAgentIntersectionEnv, get_lcf_env, get_rllib_compatible_env
+env = get_rllib_compatible_env(get_lcf_env(MultiAgentIntersectionEnv))
+a = CoPOTrainer(config=dict(env=env, env_config=dict(num_agents=12), num_envs=8 + 4 * rank, train_batch_size=(8 + 4 * rank) * 8,
+                            sgd_minibatch_size=128, num_sgd_iter=2, lcf_num_iters=2, seed=3, meta_batch_size=4,
+                            model={"fcnet_hiddens": [64, 64]}))
+assert a.policy.fused is not None and D.is_dist() and world == 2
+for _ in range(3):
+    res = a.train()
+flat = a.policy.fused.flat.flat
+sig = torch.stack([flat.double().sum(), flat.double().abs().sum(), a.policy.model.lcf_parameters[0].double(),
+                   a.policy.model.lcf_parameters[1].double(), torch.tensor(float(a.policy.num_grad_updates), dtype=torch.float64, device="cuda")])
+both = [torch.zeros_like(sig) for _ in range(2)]
+td.all_gather(both, sig)
+if rank == 0:
+    print("RESULT " + json.dumps(dict(r0=both[0].tolist(), r1=both[1].tolist(), steps=res["agent_timesteps_total"],
+                                      loss=res["info"]["learner"]["default"]["learner_stats"]["total_loss"])))
+a.stop()
+td.destroy_process_group()
+'''
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29561",
+                   COPO_DIST_BACKEND="gloo", COPO_FORCE_DIST="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                      cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    line = [ln for ln in outs[0][0].splitlines() if ln.startswith("RESULT ")][-1]
+    r = __import__("json").loads(line[7:])
+    assert r["r0"] == r["r1"], r                      # bit-identical parameters, LCF parameters and step counts
+    assert np.isfinite(r["loss"]) and r["steps"] > 0 and r["r0"][4] > 0
