@@ -418,8 +418,9 @@ class CoPOPolicy(CCPPOPolicy):
         mbuf["stats"].zero_()
         steps = 0
         nb_batch = int(self.config.get("meta_batch_size", 32)) if self.fused is not None else 0
+        # the row store costs 8 H bytes per row and net; beyond ~1M rows recomputing per pass is the better trade
         self._meta_row_store = nb_batch > 0 and bool(self.config.get("meta_row_store", True)) and num_iters > 1 \
-            and mb == rs["mb"]
+            and mb == rs["mb"] and int(rs["max_rows"]) <= int(self.config.get("meta_row_store_max_rows", 1 << 20))
         if self._meta_row_store:
             self.fused.meta_rows(rs)
         perms = self.draw_perms(num_iters, B_local)
