@@ -125,7 +125,7 @@ struct WsLay {
     }
     __device__ __host__ size_t stats(int q) const { return split(nreg, 0) + (size_t)q * 8; }               // [g * tiles + tile][8]
     __device__ __host__ size_t counter() const { return stats(gcap * tiles); }
-    __device__ __host__ size_t total() const { return counter() + 8; }
+    __device__ __host__ size_t total() const { return counter() + 8; }       // counter, pad, two int64 hand-over slots
 };
 __device__ __forceinline__ WsLay lay(const FusedArgs& a) { return WsLay(a.c, a.gcap, a.nreg); }
 __device__ __forceinline__ size_t ws_h1(const FusedArgs& a, int g) { return lay(a).h1(g); }
@@ -141,6 +141,9 @@ __device__ __forceinline__ int64_t* knext_slot(const FusedArgs& a) {
 }
 // duties of the first kernel of a step (one thread): advance the Adam step counter, publish the next minibatch index
 __device__ __forceinline__ void first_kernel_duties(const FusedArgs& a) {
+    // [1]: the Adam step this minibatch will be applied with -- read by a deferred copo_adam_step_f32 (data-parallel:
+    // gradient all-reduce in between), which then advances *step itself
+    if (a.step) knext_slot(a)[1] = a.step[0] + 1;
     if (a.apply_adam) const_cast<int64_t*>(a.step)[0] += 1;
     knext_slot(a)[0] = (a.kptr ? a.kptr[0] : 0) + 1;
 }
@@ -1886,11 +1889,18 @@ hipError_t launch_refresh_transposed(const copo_ppo_cfg& c, const float* theta, 
     return hipGetLastError();
 }
 
-__global__ void __launch_bounds__(256) adam_flat_kernel(FusedArgs a, long long n) {
+// slots != 0: the step number and the next minibatch index were published by the gradient pass (first_kernel_duties);
+// workgroup 0 hands them to *step / *kptr, which no workgroup of this kernel reads -> no trailing 1-thread launch.
+__global__ void __launch_bounds__(256) adam_flat_kernel(FusedArgs a, long long n, int slots) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
     const copo_ppo_cfg& c = a.c;
-    const float tt = (float)(a.step[0] + 1);
+    const int64_t tnext = slots ? knext_slot(a)[1] : a.step[0] + 1;
+    if (slots && i == 0) {
+        const_cast<int64_t*>(a.step)[0] = tnext;
+        if (a.bump_k && a.kptr) const_cast<int64_t*>(a.kptr)[0] = knext_slot(a)[0];
+    }
+    if (i >= n) return;
+    const float tt = (float)tnext;
     const float bc1 = 1.0f - powf(c.beta1, tt), bc2s = sqrtf(1.0f - powf(c.beta2, tt));
     const float s = a.grad[i];
     float m = a.adam_m[i], v = a.adam_v[i];
@@ -1902,13 +1912,20 @@ __global__ void __launch_bounds__(256) adam_flat_kernel(FusedArgs a, long long n
     a.theta[i] = th;
     if (a.theta_t) {     // mirror with W1 / W2 transposed (scattered 4-byte writes: the whole buffer is ~1 MB)
         long long j = i;
+        const uint32_t H = (uint32_t)c.hidden;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             if (g <= c.n_value_heads) {
                 const copo_net_layout& L = g == 0 ? c.pol : c.val[g - 1];
                 const long long r1 = i - L.w1, r2 = i - L.w2;
-                if (r1 >= 0 && r1 < (long long)c.hidden * L.in_dim) j = L.w1 + (r1 % L.in_dim) * c.hidden + r1 / L.in_dim;
-                if (r2 >= 0 && r2 < (long long)c.hidden * c.hidden) j = L.w2 + (r2 % c.hidden) * c.hidden + r2 / c.hidden;
+                if (r1 >= 0 && r1 < (long long)H * L.in_dim) {
+                    const uint32_t q = (uint32_t)r1 / (uint32_t)L.in_dim;
+                    j = L.w1 + (long long)(((uint32_t)r1 - q * (uint32_t)L.in_dim) * H + q);
+                }
+                if (r2 >= 0 && r2 < (long long)H * H) {
+                    const uint32_t q = (uint32_t)r2 / H;
+                    j = L.w2 + (long long)(((uint32_t)r2 - q * H) * H + q);
+                }
             }
         }
         a.theta_t[j] = th;
@@ -2096,9 +2113,11 @@ hipError_t launch_fused_step(FusedArgs a, hipStream_t s, const MetaTail* mt_ = n
 }
 
 hipError_t launch_adam_flat(const FusedArgs& a, long long n, hipStream_t s) {
-    hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, n);
-    hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, s, const_cast<int64_t*>(a.step),
-                       a.bump_k ? const_cast<int64_t*>(a.kptr) : nullptr);
+    const int slots = a.ws != nullptr;
+    hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, n, slots);
+    if (!slots)
+        hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, s, const_cast<int64_t*>(a.step),
+                           a.bump_k ? const_cast<int64_t*>(a.kptr) : nullptr);
     return hipGetLastError();
 }
 
@@ -2402,7 +2421,8 @@ extern "C" int copo_meta_finish_f64(const float* g_new, const float* g_old, int6
 }
 
 extern "C" int copo_adam_step_f32(const copo_ppo_cfg* cfg, float* theta, float* adam_m, float* adam_v, const float* grad,
-                                  int64_t n, int64_t* step, int64_t* mb_index, float* theta_t, void* stream) {
+                                  int64_t n, int64_t* step, int64_t* mb_index, float* theta_t, float* workspace,
+                                  void* stream) {
     if (!cfg || !theta || !adam_m || !adam_v || !grad || !step) return COPO_ERR_NULL;
     if (n < 0) return COPO_ERR_DIM;
     FusedArgs a;
@@ -2411,6 +2431,8 @@ extern "C" int copo_adam_step_f32(const copo_ppo_cfg* cfg, float* theta, float* 
     a.theta = theta; a.adam_m = adam_m; a.adam_v = adam_v; a.grad = const_cast<float*>(grad); a.step = step;
     a.kptr = mb_index; a.bump_k = mb_index ? 1 : 0;
     a.theta_t = theta_t;
+    a.ws = workspace;        // non-NULL: step number / next index come from the slots the gradient pass published
+    a.gcap = 4; a.nreg = 2;
     hipError_t e = launch_adam_flat(a, n, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
 }

@@ -169,7 +169,7 @@ class FusedLearner:
         _capi.check(_capi.lib.copo_adam_step_f32(
             C.byref(self.cfg), self.flat.flat.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr(),
             (self.grad if grad is None else grad).data_ptr(), self.flat.numel, self.step_count.data_ptr(),
-            rs["k"].data_ptr(), self.flat_t.data_ptr(), _capi.current_stream()))
+            rs["k"].data_ptr(), self.flat_t.data_ptr(), self.workspace.data_ptr(), _capi.current_stream()))
 
     # ---- LCF meta update (CoPO) -------------------------------------------------------------------------------
     def meta_grads(self, rs, g_new, g_old, stats_new, stats_old, dot_partials):

@@ -395,13 +395,19 @@ class PPOPolicyBase:
     def _fused_apply(self):
         self.fused.adam(self._row_sources)
 
+    def _fused_apply_then_grads(self):
+        """Adam of the previous minibatch + gradient pass of the next one: one graph launch between two all-reduces."""
+        self.fused.adam(self._row_sources)
+        self.fused.step(self._row_sources, apply_adam=False, stats=self.fused.stats, bump_index=False)
+
     def run_sgd_fused(self, valid_idx, B_local, B_all, mb, num_epochs):
         fz = self.fused
         assert mb == fz.cfg.mb, "fused learner was built for minibatch %d" % fz.cfg.mb
         if self._sgd is None:
             if D.is_dist():
                 self._sgd = (GraphedCallable(self._fused_grads, self.use_graphs),
-                             GraphedCallable(self._fused_apply, self.use_graphs))
+                             GraphedCallable(self._fused_apply, self.use_graphs),
+                             GraphedCallable(self._fused_apply_then_grads, self.use_graphs))
             else:
                 self._sgd = GraphedCallable(self._fused_local, self.use_graphs)
         fz.stats.zero_()
@@ -412,9 +418,12 @@ class PPOPolicyBase:
             n_mb = self.plan_epoch(valid_idx, B_local, B_all, mb, perm=None if perms is None else perms[ep])
             for _k in range(n_mb):
                 if D.is_dist():
-                    self._sgd[0]()
+                    # two host calls per minibatch: [Adam of the previous one + this gradient pass], all-reduce; the
+                    # last Adam of the epoch is flushed before the next plan resets the minibatch index
+                    self._sgd[0 if _k == 0 else 2]()
                     D.all_reduce_sum_(fz.grad)
-                    self._sgd[1]()
+                    if _k == n_mb - 1:
+                        self._sgd[1]()
                 else:
                     self._sgd()
                 steps += 1

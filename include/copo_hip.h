@@ -276,9 +276,12 @@ int copo_transpose_weights_f32(const copo_ppo_cfg* cfg, const float* theta, floa
 int copo_mlp_forward_f32(const copo_ppo_cfg* cfg, const float* theta, const float* theta_t, const float* obs_src,
                          const float* cc_src, int64_t n_rows, int32_t first_net, int32_t n_nets, float* values,
                          float* dist_inputs, const float* eps, float* action, float* logp, float* clipped, void* stream);
-/* Adam on the flat buffers (the data-parallel path: after the gradient all-reduce); theta_t as above or NULL */
+/* Adam on the flat buffers (the data-parallel path: after the gradient all-reduce); theta_t as above or NULL.
+ * workspace: the workspace of the copo_ppo_fused_step_f32(apply_adam = 0, `step` given) call that produced `grad` --
+ * that call published the step number and the next minibatch index there, so this one needs no trailing counter
+ * launch -- or NULL: *step + 1 is used and both counters are advanced by a separate 1-thread kernel. */
 int copo_adam_step_f32(const copo_ppo_cfg* cfg, float* theta, float* adam_m, float* adam_v, const float* grad,
-                       int64_t n, int64_t* step, int64_t* mb_index, float* theta_t, void* stream);
+                       int64_t n, int64_t* step, int64_t* mb_index, float* theta_t, float* workspace, void* stream);
 
 /* ---- LCF meta update (CoPOPolicy.meta_update, algo_copo.py:228-309) in three calls ------------------------------
  * (1) both policy gradients in one grouped pass: g_new = d mean(-clip-surrogate(global adv)) / d theta on the
