@@ -2,25 +2,26 @@
 //
 // The reference runs the PPO minibatch step through torch autograd (algo_copo.py:311-424 `loss`, RLlib
 // `train_one_step`, torch.optim.Adam): ~250 tiny kernels per 512-row minibatch, launch-bound on any GPU.
-// Here one SGD step is 6 launches over ONE flat fp32 parameter buffer:
+// Everything here works on ONE flat fp32 parameter buffer (+ a mirror with W1 / W2 transposed).
 //
-//   F1   h1 = tanh(X W1^T + b1)          grouped over the policy net + up to 3 value nets; X rows gathered by index
-//   F2   h2 = tanh(h1 W2^T + b2)
-//   H    heads (256 -> 4 / 1), the PPO loss terms and their ANALYTIC gradient w.r.t. the head outputs,
-//        dz2 = (dout W3) * (1 - h2^2), per-tile partials of the loss statistics
-//   B2x  dz1 = (dz2 W2) * (1 - h1^2)
-//   Bw   one launch, three GEMMs, rows split KSPLIT ways across workgroups (fixed split -> deterministic):
-//        partial dW3 = dout^T [h2 | 1],  partial dW2 = dz2^T [h1 | 1],  partial dW1 = dz1^T [X | 1]
-//   R    fold the split partials in a fixed order, then Adam (or store the flat gradient); the Adam step counter
-//        is advanced by F1, the minibatch index by R (each by a kernel that does not read it)
+// Contents, in file order:
+//   1. FusedArgs, group / workspace-layout helpers (WsLay), counter hand-over slots
+//   2. tile-GEMM engine (gemm_tile: 64x64 tiles, K slabs through LDS, v_mfma_f32_32x32x2_f32) and its operand functors
+//        FwdOpT<1|2>  h = tanh(X W^T + b)            BxOp  dz1 = (dz2 W2) (1 - h1^2)
+//        BwOpT<l, GA> partial dW_l = dz^T [In | 1]   (GA: operands gathered from the meta row store)
+//      -- the path of shapes without a row-pass instantiation, of the batched meta pass and of the row store
+//   3. head_row_terms (PPO / value / meta loss terms + analytic gradient), head_kernel
+//   4. rowpass_kernel: layers 1-2, heads, dz2, dz1 of 16 rows in one workgroup (v_mfma_f32_16x16x4_f32, weights
+//      streamed through BRing register rings); mlp_fwd_kernel: its forward-only sibling (rollouts, critic heads)
+//   5. LCF meta kernels: meta_lcf / meta_finish (step by step), meta_batch_fold / dot / rowstat, meta_seq (all LCF
+//      Adam steps of a pass in one workgroup)
+//   6. reduce_adam_kernel (fold of row-split partials + Adam; legacy two-net meta step), wgrad_adam_kernel (weight
+//      gradients + fold + Adam in one kernel), adam_flat_kernel (after a gradient all-reduce), transposes
+//   7. launch_fused_step and the C ABI
 //
-// GEMMs are 64x64 output tiles per 256-thread workgroup, 4 waves x one 32x32 fp32 MFMA accumulator
-// (v_mfma_f32_32x32x2_f32: exact fp32 products at the fp32 vector rate), K staged through LDS in slabs of 32
-// with register prefetch of the next slab.
-//
-// The LCF meta update (algo_copo.py:228-309) reuses the same kernels in a 2-group mode: group 0 = current policy
-// with loss mean(-clipped surrogate(global advantage)), group 1 = target policy with loss mean(logp); two tiny
-// kernels then evaluate the fp64 LCF terms and apply <g_new, g_old> * dS/dlcf with Adam on the two LCF scalars.
+// One PPO minibatch step = rowpass_kernel + wgrad_adam_kernel (2 launches).  One LCF meta pass over n_mb minibatches =
+// ceil(n_mb / 32) x [gemm_bw_kernel<GA> + fold + rowstat + dot] + meta_seq_kernel, on top of a row store computed once
+// per training iteration (F1, F2, head, Bx over all rows).  DESIGN.md section 4 has the measurements.
 #include <cstring>
 
 #include "sim_common.h"
