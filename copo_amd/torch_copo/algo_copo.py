@@ -147,6 +147,8 @@ class CoPOPolicy(CCPPOPolicy):
         self._lcf_adam = torch.zeros(5, dtype=torch.float64, device=self.device)         # fused path: m0 m1 v0 v1 step
         self._meta = None
         self._meta_bufs = None
+        self._meta_side = None
+        self._meta_keep = []
 
     # ---- dense postprocess: three critic heads ----------------------------------------------------------
     def gae_heads(self):
@@ -347,9 +349,7 @@ class CoPOPolicy(CCPPOPolicy):
             # the sequential kernel streams dense {A_ego, A_nei} rows instead of chasing row indices into the pack
             rows = mb_["rows_all"][:n_mb]
             en = torch.stack([pack[:, mb_["col_adv"]][rows], pack[:, mb_["col_nei_adv"]][rows]], dim=-1).unsqueeze(0)
-            fz.meta_batch_lcf(rs, n_mb, None, mb_["gv"], mb_["stats_k"], self.model.lcf_parameters.data, self._raw_ms,
-                              self._lcf_adam, self.config[LCF_LR], mb_["stats"], 0, 0,
-                              dense=(en.contiguous(), mb_["w_all"][:n_mb].unsqueeze(0), mb_["eps_all"][:n_mb].unsqueeze(0)))
+            self._meta_lcf_async(n_mb, en.contiguous(), mb_["w_all"][:n_mb].unsqueeze(0), mb_["eps_all"][:n_mb].unsqueeze(0))
             return
         # data-parallel: the minibatch gradients are sums over the ranks' rows -> all-reduce the exported gradient pairs
         # of a whole chunk BEFORE their dot products; the LCF row terms of every rank are gathered once per iteration
@@ -372,8 +372,25 @@ class CoPOPolicy(CCPPOPolicy):
                                    mb_["w_all"][:n_mb].contiguous())
         eps_all = D.all_gather_into_(torch.empty(S, n_mb, mb, dtype=torch.float64, device=self.device),
                                      mb_["eps_all"][:n_mb].contiguous())
-        fz.meta_batch_lcf(rs, n_mb, None, mb_["gv"], mb_["stats_k"], self.model.lcf_parameters.data, self._raw_ms,
-                          self._lcf_adam, self.config[LCF_LR], mb_["stats"], 0, 0, dense=(en_all, w_all, eps_all))
+        self._meta_lcf_async(n_mb, en_all, w_all, eps_all)
+
+    def _meta_lcf_async(self, n_mb, en, w, eps):
+        """Phase B of this pass on a side stream: the sequential LCF kernel keeps ONE compute unit busy for ~0.4 ms, and
+        the next pass's gradient GEMMs do not depend on the LCF parameters -- so they run meanwhile on the main stream.
+        Everything the kernel reads is private to the pass (fresh tensors / copies); run_meta joins the stream."""
+        mb_, fz = self._meta_bufs, self.fused
+        if self._meta_side is None:
+            self._meta_side = torch.cuda.Stream(device=self.device)
+        priv = dict(gv=mb_["gv"][:n_mb].clone(), stats_k=mb_["stats_k"][:n_mb].clone(), denom=mb_["denom_all"][:n_mb].clone(),
+                    en=en, w=w.clone(), eps=eps.clone())
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self._meta_side):
+            self._meta_side.wait_event(ev)
+            fz.meta_batch_lcf(dict(denom_all=priv["denom"]), n_mb, None, priv["gv"], priv["stats_k"],
+                              self.model.lcf_parameters.data, self._raw_ms, self._lcf_adam, self.config[LCF_LR], mb_["stats"],
+                              0, 0, dense=(priv["en"], priv["w"], priv["eps"]))
+        self._meta_keep.append(priv)            # alive until the side stream has been joined
 
     def run_meta(self, valid_idx, B_local, B_all, mb, num_iters):
         """`lcf_num_iters` passes of shuffled minibatches through `meta_update` (algo_copo.py:581-589)."""
@@ -443,6 +460,9 @@ class CoPOPolicy(CCPPOPolicy):
                 else:
                     self._meta()
                 steps += 1
+        if self._meta_side is not None:
+            torch.cuda.current_stream().wait_stream(self._meta_side)
+        self._meta_keep.clear()
         m = self.model
         vals = (mbuf["stats"] / max(1, steps)).tolist()
         out = dict(zip(self.META_KEYS, vals))
