@@ -6,7 +6,7 @@ array-level interface; `copo_amd.torch_copo.utils.env_wrappers` layers the refer
 """
 import ctypes as C
 import math
-from dataclasses import asdict, dataclass, field
+from dataclasses import dataclass, field
 
 import numpy as np
 

@@ -7,9 +7,8 @@ HIP gather kernel here (`copo_cc_fuse_{mf,concat}_f32`), applied to all [T, E, N
 """
 import torch
 
-from copo_amd.engine import Box, Postprocessing, SampleBatch, reduce_mean_valid_fn
-from copo_amd.torch_copo.algo_ippo import (FullyConnectedModel, IPPOConfig, IPPOPolicy, IPPOTrainer,
-                                           clipped_value_loss)
+from copo_amd.engine import SampleBatch
+from copo_amd.torch_copo.algo_ippo import FullyConnectedModel, IPPOConfig, IPPOPolicy, IPPOTrainer
 
 CENTRALIZED_CRITIC_OBS = "centralized_critic_obs"
 COUNTERFACTUAL = "counterfactual"

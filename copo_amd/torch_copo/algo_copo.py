@@ -11,7 +11,6 @@ steps are static-shape (hipGraph-capturable) minibatches; on several GPUs both m
 all-reduced BEFORE their dot product.
 """
 import math
-from collections import defaultdict
 
 import numpy as np
 import torch
@@ -20,8 +19,7 @@ import torch.nn as nn
 from copo_amd import dist as D
 from copo_amd.engine import (LEARNER_STATS_KEY, NUM_AGENT_STEPS_SAMPLED, NUM_ENV_STEPS_SAMPLED, Postprocessing,
                              SampleBatch, build_mlp, reduce_mean_valid_fn)
-from copo_amd.torch_copo.algo_ccppo import (CENTRALIZED_CRITIC_OBS, COUNTERFACTUAL, CCModel, CCPPOConfig, CCPPOPolicy,
-                                            CCPPOTrainer)
+from copo_amd.torch_copo.algo_ccppo import CENTRALIZED_CRITIC_OBS, CCModel, CCPPOConfig, CCPPOPolicy, CCPPOTrainer
 from copo_amd.torch_copo.algo_ippo import clipped_value_loss
 from copo_amd.trainer import GraphedCallable
 
@@ -282,7 +280,6 @@ class CoPOPolicy(CCPPOPolicy):
     def _meta_step_a_fused(self):
         """Both policy gradients from the fused HIP learner (head modes META_NEW / META_OLD, no Adam), the
         two-scalar LCF part in torch fp64."""
-        from copo_amd import _capi
         mb_, fz = self._meta_bufs, self.fused
         rs = dict(self._row_sources, **{k: mb_[k] for k in ("rows_all", "w_all", "denom_all", "k")})
         fz.meta_grads(rs, mb_["g_new"], mb_["g_old"], mb_["stats_new"], mb_["stats_old"], mb_["dot_partials"])

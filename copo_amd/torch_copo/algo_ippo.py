@@ -7,8 +7,7 @@ by a thin host loop over the HIP simulator and torch-ROCm: see `copo_amd/trainer
 import torch
 import torch.nn as nn
 
-from copo_amd.engine import (AlgorithmConfig, Box, Postprocessing, SampleBatch, TorchDiagGaussian, build_mlp,
-                             reduce_mean_valid_fn)
+from copo_amd.engine import AlgorithmConfig, Box, Postprocessing, SampleBatch, build_mlp, reduce_mean_valid_fn
 from copo_amd.trainer import PPOPolicyBase, VecTrainer
 
 

@@ -9,7 +9,6 @@ import csv
 import json
 import os
 import pickle
-import time
 
 import numpy as np
 

@@ -1,5 +1,5 @@
 """Train CoPO / IPPO on the HIP simulator for a given env-step budget and print the learning curve."""
-import argparse, json, os, sys, time
+import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from copo_amd.torch_copo.algo_copo import CoPOTrainer
 from copo_amd.torch_copo.algo_ippo import IPPOTrainer

@@ -10,7 +10,6 @@ import os
 import sys
 import tempfile
 
-import numpy as np
 import pytest
 import torch
 import torch.multiprocessing as mp

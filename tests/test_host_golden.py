@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from copo_amd.engine import Box, Postprocessing, SampleBatch, TorchDiagGaussian, expand_grid, grid_search
+from copo_amd.engine import Box, SampleBatch, TorchDiagGaussian, expand_grid, grid_search
 from copo_amd.torch_copo import algo_ccppo as C
 from copo_amd.torch_copo import algo_copo as A
 from copo_amd.torch_copo import algo_ippo as I
