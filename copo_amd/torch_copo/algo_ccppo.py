@@ -134,3 +134,22 @@ class CCPPOTrainer(IPPOTrainer):
     def get_default_policy_class(self, config):
         assert config["framework"] == "torch"
         return CCPPOPolicy
+
+
+# ========== Test scripts ==========
+def _test(stop=2000, local_dir=None):
+    """The reference's `_test()` (algo_ccppo.py:485-528): a tiny configuration through `train()`, "does it run" end to end."""
+    from copo_amd.torch_copo.utils.callbacks import MultiAgentDrivingCallbacks
+    from copo_amd.torch_copo.utils.env_wrappers import MultiAgentIntersectionEnv
+    from copo_amd.torch_copo.utils.train import train
+    from copo_amd.torch_copo.utils.utils import get_train_parser
+    args, _ = get_train_parser().parse_known_args()
+    config = dict(env=get_ccppo_env(MultiAgentIntersectionEnv), env_config=dict(num_agents=8), num_envs=4, train_batch_size=100,
+                  rollout_fragment_length=20, sgd_minibatch_size=30, fuse_mode="mf")
+    return train(CCPPOTrainer, config=config, checkpoint_freq=0, keep_checkpoints_num=0, stop={"timesteps_total": stop},
+                 num_gpus=args.num_gpus, num_seeds=1, max_failures=0, exp_name=args.exp_name or "test_ccppo",
+                 custom_callback=MultiAgentDrivingCallbacks, test_mode=True, local_mode=True, local_dir=local_dir)
+
+
+if __name__ == "__main__":
+    _test()

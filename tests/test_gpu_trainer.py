@@ -321,3 +321,21 @@ td.destroy_process_group()
     r = __import__("json").loads(line[7:])
     assert r["r0"] == r["r1"], r                      # bit-identical parameters, LCF parameters and step counts
     assert np.isfinite(r["loss"]) and r["steps"] > 0 and r["r0"][4] > 0
+
+
+@pytest.mark.parametrize("mod", ["algo_ippo", "algo_ccppo", "algo_copo"])
+def test_reference_style_smoke_mains(mod, tmp_path):
+    """The `_test()` mains of the reference (algo_*.py: train_batch_size 100, fragment 20, minibatch 30, test mode)
+    run end to end through `train()` and leave a progress.csv."""
+    import importlib
+    import sys
+    m = importlib.import_module("copo_amd.torch_copo." + mod)
+    argv, sys.argv = sys.argv, [mod]
+    try:
+        m._test(stop=600, local_dir=str(tmp_path))
+    finally:
+        sys.argv = argv
+    found = [os.path.join(r, f) for r, _, fs in os.walk(tmp_path) for f in fs if f == "progress.csv"]
+    assert len(found) == 1
+    rows = open(found[0]).read().strip().splitlines()
+    assert len(rows) >= 3 and "timesteps_total" in rows[0]
