@@ -17,10 +17,6 @@ namespace copo {
 // ------------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ const float* seg_ptr(const SimParams& p, int route, int k) {
-    return p.route_segs + ((size_t)route * (COPO_MAX_SEGS + 1) + k) * COPO_SEG_STRIDE;
-}
-
 __device__ __forceinline__ void project_seg(const float* __restrict__ g, float x, float y, float& sl, float& lat,
                                             float& thr) {
     const float gx = g[0], gy = g[1], gc = g[2], gs = g[3], kap = g[5], th0 = g[7];
@@ -85,13 +81,13 @@ __device__ __forceinline__ void store_slot(const SimParams& p, int e, int n, con
 }
 
 // Spawn a fresh agent into this lane's slot at spawn point sp (spec 3.6).  `aid` is the env-wide id.
-__device__ __forceinline__ void spawn_slot(const SimParams& p, uint64_t seed, uint32_t episode, int n, int sp,
-                                           int32_t aid, Slot& s) {
+__device__ __forceinline__ void spawn_slot(const SimParams& p, const float* rsegs, const int32_t* stab, const float* sps,
+                                           uint64_t seed, uint32_t episode, int n, int sp, int32_t aid, Slot& s) {
     const uint32_t cnt = (uint32_t)s.spawncnt;
     const uint32_t h = hash_rng(seed, (uint32_t)n, cnt, episode, RNG_ROUTE);
-    const int route = p.spawn_tab[sp * 4 + 0] + (int)(h % (uint32_t)p.spawn_tab[sp * 4 + 1]);
-    const float* g = seg_ptr(p, route, 0);
-    const float s0 = p.spawn_s[sp];
+    const int route = stab[sp * 4 + 0] + (int)(h % (uint32_t)stab[sp * 4 + 1]);
+    const float* g = rsegs + (size_t)route * (COPO_MAX_SEGS + 1) * COPO_SEG_STRIDE;
+    const float s0 = sps[sp];
     s.x = g[0] + g[2] * s0;
     s.y = g[1] + g[3] * s0;
     s.th = g[7];
@@ -123,9 +119,22 @@ struct __align__(16) EnvLds {
     unsigned long long m_acted, m_present, m_solid;
     uint8_t crash[64];
     int16_t perm[COPO_MAX_SPAWNS];
+    const float* rsegs;        // route segment records: the LDS copy of the step kernel (small maps) or global memory
+    const float* rmeta;        // route meta records, same
+    const int32_t* stab;       // spawn table, same
+    const float* sps;          // spawn offsets, same
     int32_t ending;
     int32_t ntasks;            // LiDAR task list fill
 };
+
+// segment record k of a route (COPO_SEG_STRIDE floats), through whichever copy of the tables this workgroup uses
+__device__ __forceinline__ const float* seg_ptr(const EnvLds& L, int route, int k) {
+    return L.rsegs + ((size_t)route * (COPO_MAX_SEGS + 1) + k) * COPO_SEG_STRIDE;
+}
+constexpr int ROUTE_LDS_MAX_BYTES = 12 * 1024;
+__device__ __host__ inline int route_table_floats(int n_routes) {
+    return n_routes * ((COPO_MAX_SEGS + 1) * COPO_SEG_STRIDE + 4);
+}
 
 // active agent slots: device memory next to the LCF distribution, so that captured graphs see updates
 __device__ __forceinline__ int capacity_of(const SimParams& p) {
@@ -152,7 +161,7 @@ __device__ __forceinline__ void reset_env_wave0(const SimParams& p, EnvLds& L, u
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     // population capacity (curriculum): slots beyond it start empty and never respawn
     const int cap = capacity_of(p);
-    if (lane < cap) spawn_slot(p, seed, episode, lane, (int)L.perm[lane], lane, s);
+    if (lane < cap) spawn_slot(p, L.rsegs, L.stab, L.sps, seed, episode, lane, (int)L.perm[lane], lane, s);
     else if (lane < p.N) s.status = ST_EMPTY;
 }
 
@@ -245,10 +254,10 @@ __device__ __forceinline__ void ego_navi_obs(const SimParams& p, EnvLds& L, int 
         return;
     }
     const int route = s.route & 0xffff, seg = s.route >> 16;
-    const float* meta = p.route_meta + route * 4;
+    const float* meta = L.rmeta + route * 4;
     const float total = meta[0], latl = meta[1], latr = meta[2];
     const int nseg = (int)meta[3];
-    const float* g = seg_ptr(p, route, seg);
+    const float* g = seg_ptr(L, route, seg);
     float sl, lat, thr;
     project_seg(g, s.x, s.y, sl, lat, thr);
     const float psi = wrap_pi(s.th - thr);
@@ -267,8 +276,8 @@ __device__ __forceinline__ void ego_navi_obs(const SimParams& p, EnvLds& L, int 
     for (int j = 0; j < 2; ++j) {
         int kk = seg + j;
         if (kk > nseg - 1) kk = nseg - 1;
-        const float* gk = seg_ptr(p, route, kk);
-        const float* gn = seg_ptr(p, route, kk + 1);
+        const float* gk = seg_ptr(L, route, kk);
+        const float* gn = seg_ptr(L, route, kk + 1);
         const float rx = gn[0] - s.x, ry = gn[1] - s.y;
         const float fx = rx * cs + ry * sn, fy = ry * cs - rx * sn;
         float* q = o + COPO_EGO_DIM + 5 * j;
@@ -416,6 +425,13 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_reset_kernel(SimParams
     const int wave = tid >> 6, lane = tid & 63, nwaves = nthreads >> 6;
     const int N = p.N;
     load_rays(p, L, tid, nthreads);
+    if (tid == 0) {
+        L.rsegs = p.route_segs;
+        L.rmeta = p.route_meta;
+        L.stab = p.spawn_tab;
+        L.sps = p.spawn_s;
+    }
+    __syncthreads();
     Slot s;
     if (wave == 0) {
         const uint64_t seed = p.seeds[e];
@@ -462,6 +478,28 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
     const int N = p.N;
     const float hl = p.hl, hw = p.hw;
     load_rays(p, L, tid, nthreads);
+    {   // route tables: a few KB read on every step by the projection / navigation code -> LDS copy when they fit
+        // (the waves that idle during P0 do the copy; the barrier after P0 publishes it)
+        extern __shared__ unsigned int dyn[];
+        const int nseg_f = p.n_routes * (COPO_MAX_SEGS + 1) * COPO_SEG_STRIDE, nmeta_f = p.n_routes * 4;
+        const int ntab = p.n_spawns * 4, nsp = p.n_spawns;
+        const bool stage = (nseg_f + nmeta_f) * (int)sizeof(float) <= ROUTE_LDS_MAX_BYTES;
+        float* rl = reinterpret_cast<float*>(dyn + (nthreads >> 6) * 192);
+        int32_t* tl = reinterpret_cast<int32_t*>(rl + nseg_f + nmeta_f);
+        float* sl = reinterpret_cast<float*>(tl + ntab);
+        if (stage) {
+            for (int q = tid; q < nseg_f; q += nthreads) rl[q] = p.route_segs[q];
+            for (int q = tid; q < nmeta_f; q += nthreads) rl[nseg_f + q] = p.route_meta[q];
+            for (int q = tid; q < ntab; q += nthreads) tl[q] = p.spawn_tab[q];
+            for (int q = tid; q < nsp; q += nthreads) sl[q] = p.spawn_s[q];
+        }
+        if (tid == 0) {
+            L.rsegs = stage ? rl : p.route_segs;
+            L.rmeta = stage ? rl + nseg_f : p.route_meta;
+            L.stab = stage ? tl : p.spawn_tab;
+            L.sps = stage ? sl : p.spawn_s;
+        }
+    }
 
 #define COPO_STAMP(i) do { if (p.dbg && tid == 0) p.dbg[(size_t)e * 8 + (i)] = (long long)clock64(); } while (0)
     COPO_STAMP(0);
@@ -561,22 +599,22 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
         if (acted) {
             const int route = s.route & 0xffff;
             int seg = s.route >> 16;
-            const float* meta = p.route_meta + route * 4;
+            const float* meta = L.rmeta + route * 4;
             const float total = meta[0], latl = meta[1], latr = meta[2];
             const int nseg = (int)meta[3];
-            const float* g = seg_ptr(p, route, seg);
+            const float* g = seg_ptr(L, route, seg);
             float sl, lat, thr;
             project_seg(g, s.x, s.y, sl, lat, thr);
             for (int it = 0; it < 2; ++it) {
                 if (sl > g[4] && seg < nseg - 1) {
                     seg += 1;
-                    g = seg_ptr(p, route, seg);
+                    g = seg_ptr(L, route, seg);
                     project_seg(g, s.x, s.y, sl, lat, thr);
                 }
             }
             if (sl < 0.0f && seg > 0) {
                 seg -= 1;
-                g = seg_ptr(p, route, seg);
+                g = seg_ptr(L, route, seg);
                 project_seg(g, s.x, s.y, sl, lat, thr);
             }
             const float prog = g[6] + sl;
@@ -634,15 +672,15 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
                 for (uint32_t a = 0; a < 3; ++a) {
                     const uint32_t hh = hash_rng(seed, (uint32_t)n, cnt, (uint32_t)t_env, RNG_SPAWN + a);
                     const int sp = (int)(hh % (uint32_t)p.n_spawns);
-                    const float* g = seg_ptr(p, p.spawn_tab[sp * 4], 0);
-                    const float s0 = p.spawn_s[sp];
+                    const float* g = seg_ptr(L, L.stab[sp * 4], 0);
+                    const float s0 = L.sps[sp];
                     const float sx = g[0] + g[2] * s0, sy = g[1] + g[3] * s0;
                     const float dx = s.x - sx, dy = s.y - sy;
                     const bool blk = (lane < N) && ((s.status & 0xff) != ST_EMPTY) &&
                                      (dx * dx + dy * dy < p.spawn_clearance * p.spawn_clearance);
                     if (__ballot(blk) == 0ull) {
                         if (lane == n) {
-                            spawn_slot(p, seed, (uint32_t)episode, n, sp, next_aid, s);
+                            spawn_slot(p, L.rsegs, L.stab, L.sps, seed, (uint32_t)episode, n, sp, next_aid, s);
                             present = true;
                             fl = COPO_F_SPAWNED;
                             lcf_row = s.lcf;
@@ -752,6 +790,10 @@ __global__ void __launch_bounds__(256) neighbours_kernel(const float* __restrict
 // host launchers
 // ------------------------------------------------------------------------------------------------
 static size_t lidar_lds_bytes(int block) { return (size_t)(block / 64) * 192 * sizeof(unsigned int); }   // per-wave ray queue
+static size_t route_lds_bytes(const SimParams& p) {      // LDS copy of the route tables when they are small
+    const size_t b = (size_t)route_table_floats(p.n_routes) * sizeof(float);
+    return b <= (size_t)ROUTE_LDS_MAX_BYTES ? b + (size_t)p.n_spawns * 5 * sizeof(float) : 0;      // + spawn table and offsets
+}
 
 hipError_t launch_sim_reset(const SimParams& p, const StepOut& out, int block, hipStream_t stream) {
     hipLaunchKernelGGL(sim_reset_kernel, dim3(p.E), dim3(block), lidar_lds_bytes(block), stream, p, out);
@@ -759,7 +801,7 @@ hipError_t launch_sim_reset(const SimParams& p, const StepOut& out, int block, h
 }
 
 hipError_t launch_sim_step(const SimParams& p, const float* act, const StepOut& out, int block, hipStream_t stream) {
-    hipLaunchKernelGGL(sim_step_kernel, dim3(p.E), dim3(block), lidar_lds_bytes(block), stream, p, act, out);
+    hipLaunchKernelGGL(sim_step_kernel, dim3(p.E), dim3(block), lidar_lds_bytes(block) + route_lds_bytes(p), stream, p, act, out);
     return hipGetLastError();
 }
 
