@@ -1,6 +1,8 @@
 """Fused HIP minibatch learner (copo_ppo_fused_step_f32) vs the torch implementation of the same step --
 which itself is pinned to the reference's `loss` / `meta_update` golden vectors by tests/test_host_golden.py.
 Compared: loss statistics, every parameter gradient, parameters and Adam moments after real steps."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -352,3 +354,46 @@ def test_forward_kernel_matches_torch_models(name, fuse, odim, over):
     v = fz.values(obs, None if cc is obs else cc)
     assert v.shape == v_ref.shape
     np.testing.assert_allclose(v.cpu().numpy(), v_ref.cpu().numpy(), rtol=5e-5, atol=5e-6)
+
+
+@pytest.mark.parametrize("tag,name,fuse,over", [
+    ("ippo", "ippo", "none", {}),
+    ("ccppo_mf", "ccppo", "mf", {}),
+    ("ccppo_concat", "ccppo", "concat", {}),
+    ("copo", "copo", "none", {}),
+    ("copo_newvf", "copo", "none", dict(old_value_loss=False, vf_clip_param=10.0)),
+    ("copo_nokl", "copo", "none", dict(kl_coeff=0.0)),
+])
+def test_fused_gradients_vs_reference_golden(golden_dir, tag, name, fuse, over):
+    """The HIP learner against the REFERENCE's own outputs (tests/golden/loss_*.npz, recorded from
+    IPPOPolicy.loss / CCPPOPolicy.loss / CoPOPolicy.loss + autograd, algo_ippo.py:78-172, algo_ccppo.py:376-472,
+    algo_copo.py:311-424): total loss, tower statistics and every parameter gradient of one 96-row batch."""
+    g = np.load(os.path.join(golden_dir, "loss_%s.npz" % tag))
+    B, odim = g["in_obs"].shape
+    pol = _make(name, fuse, odim, fused=True, hiddens=(32, 32), mb=B, **over)
+    assert pol.fused is not None
+    pol.model.load_state_dict({k[2:]: torch.as_tensor(g[k]) for k in g.files if k.startswith("w_")}, strict=True)
+    b = SampleBatch({k[3:]: torch.as_tensor(g[k]).cuda() for k in g.files if k.startswith("in_") and g[k].ndim >= 1})
+    b[SampleBatch.FLAGS] = torch.ones(B, dtype=torch.uint8, device="cuda")
+    pol.prepare_sgd(b, B, B)
+    rs = pol._row_sources
+    rs["rows_all"][0].copy_(torch.arange(B, device="cuda"))
+    rs["w_all"][0].fill_(1.0)
+    rs["denom_all"][0] = float(B)
+    rs["k"].zero_()
+    fz = pol.fused
+    fz.stats.zero_()
+    fz.step(rs, apply_adam=False, stats=fz.stats, bump_index=False)
+    off = fz.flat.offset
+    for pname, p in pol.model.named_parameters():
+        ref = g["out_grad_" + pname]
+        if p.dtype != torch.float32 or ref.size == 0:
+            continue
+        got = fz.grad[off[id(p)]:off[id(p)] + p.numel()].view_as(p).cpu().numpy()
+        np.testing.assert_allclose(got, ref, rtol=5e-4, atol=2e-6, err_msg=pname)
+    st = fz.stats.tolist()               # total, policy, vf_ego, kl, entropy, vf_nei, vf_glob, adv
+    np.testing.assert_allclose(st[0], float(g["out_total_loss"]), rtol=2e-5, atol=1e-6)
+    for idx, key in ((1, "mean_policy_loss"), (2, "mean_vf_loss"), (3, "mean_kl_loss"), (4, "mean_entropy"),
+                     (5, "mean_nei_vf_loss"), (6, "mean_global_vf_loss")):
+        if "out_stat_" + key in g.files:
+            np.testing.assert_allclose(st[idx], float(g["out_stat_" + key]), rtol=2e-5, atol=1e-6, err_msg=key)
