@@ -397,3 +397,54 @@ def test_fused_gradients_vs_reference_golden(golden_dir, tag, name, fuse, over):
                      (5, "mean_nei_vf_loss"), (6, "mean_global_vf_loss")):
         if "out_stat_" + key in g.files:
             np.testing.assert_allclose(st[idx], float(g["out_stat_" + key]), rtol=2e-5, atol=1e-6, err_msg=key)
+
+
+@pytest.mark.parametrize("store", [False, True])
+def test_batched_meta_loop_vs_reference_golden(golden_dir, store):
+    """The LCF half of the REFERENCE's CoPOTrainer.training_step (algo_copo.py:581-613; tests/golden/training_step.npz:
+    5 passes x 3 unshuffled minibatches of a 1200-row batch, the reference's own eps draws) through the batched HIP
+    meta pass (with and without the row store): final LCF parameters and the (mean, std) pushed to the envs."""
+    g = np.load(os.path.join(golden_dir, "training_step.npz"))
+    B, odim = g["in_obs"].shape
+    mb = 512
+    pol = _make("copo", "none", odim, fused=True, hiddens=(32, 32), mb=mb)
+    pol.model.load_state_dict({k[2:]: torch.as_tensor(g[k]) for k in g.files if k.startswith("w_")}, strict=True)
+    pol.target_model.load_state_dict({k[3:]: torch.as_tensor(g[k]) for k in g.files if k.startswith("wt_")}, strict=True)
+    pol.fused.target_flat.flat.copy_(pol.fused.target_flat.flat)          # (views: weights are already in the flat buffers)
+    b = SampleBatch({k[3:]: torch.as_tensor(g[k]).cuda() for k in g.files
+                     if k.startswith("in_") and g[k].dtype.kind in "fiu" and g[k].ndim >= 1})
+    b["global_advantages"] = torch.as_tensor(g["out_global_advantages"]).cuda()
+    b[SampleBatch.FLAGS] = torch.ones(B, dtype=torch.uint8, device="cuda")
+    pol.prepare_sgd(b, B, mb)
+    ms = g["out_raw_mean_std"]
+    pol._raw_lcf_adv_mean.fill_(float(np.float32(ms[0])))
+    pol._raw_lcf_adv_std.fill_(float(np.float32(ms[1])))
+    pol.use_graphs = False
+    pol.config["meta_row_store"] = store
+    idx = torch.arange(B, device="cuda")
+    pol.run_meta(idx, B, [B], mb, 0)                   # allocate the meta buffers
+    mbuf, fz = pol._meta_bufs, pol.fused
+    n_mb = -(-B // mb)
+    for k in range(n_mb):                              # the reference walks the batch in order: minibatch k = rows [512 k, ...)
+        n = min(mb, B - k * mb)
+        mbuf["rows_all"][k].zero_()
+        mbuf["rows_all"][k, :n] = torch.arange(k * mb, k * mb + n, device="cuda")
+        mbuf["w_all"][k].zero_()
+        mbuf["w_all"][k, :n] = 1.0
+        mbuf["denom_all"][k] = float(n)
+    pol._meta_row_store = store
+    if store:
+        fz.meta_rows(pol._row_sources)
+    torch.manual_seed(int(g["in_torch_seed"]))
+    mbuf["stats"].zero_()
+    for _ in range(5):
+        mbuf["eps_all"].zero_()
+        for k in range(n_mb):
+            n = min(mb, B - k * mb)
+            mbuf["eps_all"][k, :n] = torch.randn(n, dtype=torch.float64).cuda()     # the draws Normal.rsample makes
+        pol._run_meta_batched(n_mb, 2)                 # chunks of 2 + 1 minibatches
+    torch.cuda.current_stream().wait_stream(pol._meta_side)
+    pol._meta_keep.clear()
+    np.testing.assert_allclose(pol.model.lcf_parameters.detach().cpu().numpy(), g["out_lcf_parameters"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose([pol.model.lcf_mean.item(), pol.model.lcf_std.item()], g["out_env_lcf_dist"], rtol=1e-6, atol=1e-9)
+    assert float(pol._lcf_adam[4]) == 15.0
