@@ -11,6 +11,7 @@ steps are static-shape (hipGraph-capturable) minibatches; on several GPUs both m
 all-reduced BEFORE their dot product.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -461,11 +462,13 @@ class CoPOPolicy(CCPPOPolicy):
             torch.cuda.current_stream().wait_stream(self._meta_side)
         self._meta_keep.clear()
         m = self.model
-        vals = (mbuf["stats"] / max(1, steps)).tolist()
-        out = dict(zip(self.META_KEYS, vals))
-        lm, ls = float(m.lcf_mean.item()), float(m.lcf_std.item())
-        out.update(lcf=lm, lcf_deg=lm * 90, lcf_param=float(m.lcf_parameters[0].item()), lcf_std=ls, lcf_std_deg=ls * 90,
-                   lcf_std_param=float(m.lcf_parameters[1].item()))
+        # one device -> host read for everything this iteration reports about the meta update
+        host = torch.cat([mbuf["stats"] / max(1, steps), m.lcf_mean.reshape(1).double(), m.lcf_std.reshape(1).double(),
+                          m.lcf_parameters.detach().double().reshape(-1), self._raw_ms.double().reshape(-1)]).tolist()
+        nk = len(self.META_KEYS)
+        out = dict(zip(self.META_KEYS, host[:nk]))
+        lm, ls, p0, p1, self._raw_host = host[nk], host[nk + 1], host[nk + 2], host[nk + 3], (host[nk + 4], host[nk + 5])
+        out.update(lcf=lm, lcf_deg=lm * 90, lcf_param=p0, lcf_std=ls, lcf_std_deg=ls * 90, lcf_std_param=p1)
         return out
 
     def update_old_policy(self):
@@ -483,11 +486,12 @@ class CoPOPolicy(CCPPOPolicy):
         assert self.model.lcf_parameters.size() == lcf_parameters.size()
         with torch.no_grad():
             self.model.lcf_parameters.data.copy_(lcf_parameters)
-        new_mean = self.model.lcf_mean.item()
-        assert abs(new_mean - lcf_mean) < 1e-5, (new_mean, lcf_mean)
-        if lcf_std is not None:
-            new_std = self.model.lcf_std.item()
-            assert abs(new_std - lcf_std) < 1e-5, (new_std, lcf_std)
+        if os.environ.get("COPO_CHECK_ASSIGN_LCF", "0") == "1":     # the reference's sanity check costs two device reads
+            new_mean = self.model.lcf_mean.item()
+            assert abs(new_mean - lcf_mean) < 1e-5, (new_mean, lcf_mean)
+            if lcf_std is not None:
+                new_std = self.model.lcf_std.item()
+                assert abs(new_std - lcf_std) < 1e-5, (new_std, lcf_std)
 
     def get_state(self):
         st = super().get_state()
@@ -603,8 +607,8 @@ class CoPOTrainer(CCPPOTrainer):
             w.foreach_env(lambda e: e.set_lcf_dist(mean=lcf_mean, std=lcf_std))
 
         self.workers.foreach_worker_with_id(_update_lcf_2)
-        fetches = dict(raw_lcf_adv_mean_value=float(pol._raw_lcf_adv_mean.item()),
-                       raw_lcf_adv_std_value=float(pol._raw_lcf_adv_std.item()))
+        raw = getattr(pol, "_raw_host", None) or (float(pol._raw_lcf_adv_mean.item()), float(pol._raw_lcf_adv_std.item()))
+        fetches = dict(raw_lcf_adv_mean_value=float(raw[0]), raw_lcf_adv_std_value=float(raw[1]))
         fetches.update(meta)
         train_results["default"]["custom_metrics"]["meta_update"] = fetches
         for policy_id, info in train_results.items():
