@@ -21,7 +21,7 @@ EGO_DIM = 9
 NAVI_DIM = 10
 INFO_DIM = 8
 STATE_FIELDS = 16
-LCF_STATS_DOUBLES = 8 + 6 * 256
+LCF_STATS_DOUBLES = 8 + 6 * 2048
 ABI_VERSION = 1
 
 F_ACTED, F_DONE, F_ARRIVE, F_CRASH, F_OUT, F_MAXSTEP, F_SPAWNED, F_ENV_RESET = (1 << i for i in range(8))

@@ -181,28 +181,54 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// four elements per thread and iteration (float4 loads when the arrays are 16-byte aligned), no branch around the
+// loads; per-workgroup partials in a fixed layout, folded by one wave per statistic -> deterministic
+constexpr int kLcfBlocks = 2048;
+
+__device__ __forceinline__ void lcf_ld4(const float* p, long long i, long long B, bool vec, float (&v)[4]) {
+    if (vec && i + 4 <= B) {
+        const float4 q = *reinterpret_cast<const float4*>(p + i);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = p[i + u < B ? i + u : B - 1];
+    }
+}
+
 __global__ void __launch_bounds__(256) lcf_mix_partial_kernel(const float* __restrict__ adv,
                                                               const float* __restrict__ nei,
                                                               const float* __restrict__ glob,
                                                               const float* __restrict__ lcf,
-                                                              const uint8_t* __restrict__ valid, long long B,
+                                                              const uint8_t* __restrict__ valid, long long B, int vec,
                                                               float* __restrict__ mixed, double* __restrict__ stats) {
     __shared__ double red[4][6];
     double a[6] = {0, 0, 0, 0, 0, 0};
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += stride) {
-        if (valid && !valid[i]) {
-            mixed[i] = 0.0f;
-            continue;
+    const long long stride = (long long)gridDim.x * blockDim.x * 4;
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < B; i += stride) {
+        float va[4], vn[4], vg[4], vl[4], m[4];
+        lcf_ld4(adv, i, B, vec, va);
+        lcf_ld4(nei, i, B, vec, vn);
+        lcf_ld4(glob, i, B, vec, vg);
+        lcf_ld4(lcf, i, B, vec, vl);
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ok[u] = i + u < B && (!valid || valid[i + u < B ? i + u : B - 1]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float sn, cs;
+            sincos_det(vl[u] * kHalfPi, sn, cs);
+            m[u] = ok[u] ? cs * va[u] + sn * vn[u] : 0.0f;
+            const double w = ok[u] ? 1.0 : 0.0, g = ok[u] ? (double)vg[u] : 0.0;
+            a[0] += w; a[1] += (double)m[u]; a[2] += (double)m[u] * (double)m[u];
+            a[3] += w; a[4] += g; a[5] += g * g;
         }
-        const float ang = lcf[i] * kHalfPi;
-        float sn, cs;
-        sincos_det(ang, sn, cs);
-        const float m = cs * adv[i] + sn * nei[i];
-        mixed[i] = m;
-        const double g = (double)glob[i];
-        a[0] += 1.0; a[1] += (double)m; a[2] += (double)m * (double)m;
-        a[3] += 1.0; a[4] += g; a[5] += g * g;
+        if (vec && i + 4 <= B) {
+            *reinterpret_cast<float4*>(mixed + i) = make_float4(m[0], m[1], m[2], m[3]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i + u < B) mixed[i + u] = m[u];
+        }
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
@@ -217,18 +243,17 @@ __global__ void __launch_bounds__(256) lcf_mix_partial_kernel(const float* __res
     }
 }
 
-__global__ void lcf_mix_fold_kernel(double* __restrict__ stats, int nblocks) {
-    const int k = threadIdx.x;
-    if (k < 6) {
-        double s = 0.0;
-        for (int b = 0; b < nblocks; ++b) s += stats[8 + 6 * b + k];
-        stats[k] = s;
-    }
+__global__ void __launch_bounds__(384) lcf_mix_fold_kernel(double* __restrict__ stats, int nblocks) {
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;       // one wave per statistic, fixed order
+    double s = 0.0;
+    for (int b = lane; b < nblocks; b += 64) s += stats[8 + 6 * b + k];
+    s = wave_sum(s);
+    if (lane == 0) stats[k] = s;
 }
 
 __global__ void __launch_bounds__(256) lcf_mix_apply_kernel(const float* __restrict__ mixed,
                                                             const float* __restrict__ glob,
-                                                            const uint8_t* __restrict__ valid, long long B,
+                                                            const uint8_t* __restrict__ valid, long long B, int vec,
                                                             const double* __restrict__ stats,
                                                             float* __restrict__ norm_adv, float* __restrict__ glob_std) {
     const double m0 = stats[1] / stats[0], v0 = stats[2] / stats[0] - m0 * m0;
@@ -236,34 +261,49 @@ __global__ void __launch_bounds__(256) lcf_mix_apply_kernel(const float* __restr
     double s0 = sqrt(v0 > 0 ? v0 : 0), s1 = sqrt(v1 > 0 ? v1 : 0);
     if (s0 < 1e-4) s0 = 1e-4;
     if (s1 < 1e-4) s1 = 1e-4;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += stride) {
-        if (valid && !valid[i]) {
-            norm_adv[i] = 0.0f;
-            glob_std[i] = 0.0f;
-            continue;
+    const long long stride = (long long)gridDim.x * blockDim.x * 4;
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < B; i += stride) {
+        float vm[4], vg[4], o0[4], o1[4];
+        lcf_ld4(mixed, i, B, vec, vm);
+        lcf_ld4(glob, i, B, vec, vg);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool ok = i + u < B && (!valid || valid[i + u < B ? i + u : B - 1]);
+            o0[u] = ok ? (float)(((double)vm[u] - m0) / s0) : 0.0f;
+            o1[u] = ok ? (float)(((double)vg[u] - m1) / s1) : 0.0f;
         }
-        norm_adv[i] = (float)(((double)mixed[i] - m0) / s0);
-        glob_std[i] = (float)(((double)glob[i] - m1) / s1);
+        if (vec && i + 4 <= B) {
+            *reinterpret_cast<float4*>(norm_adv + i) = make_float4(o0[0], o0[1], o0[2], o0[3]);
+            *reinterpret_cast<float4*>(glob_std + i) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i + u < B) { norm_adv[i + u] = o0[u]; glob_std[i + u] = o1[u]; }
+        }
     }
 }
 
-constexpr int kLcfBlocks = 256;
+static int lcf_aligned(const void* a, const void* b, const void* c, const void* d) {
+    return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
+             reinterpret_cast<uintptr_t>(d)) & 15) == 0;
+}
 
 hipError_t launch_lcf_mix_partial(const float* adv, const float* nei_adv, const float* glob_adv, const float* lcf,
                                   const uint8_t* valid, int64_t B, float* mixed, double* stats, hipStream_t stream) {
+    const int vec = lcf_aligned(adv, nei_adv, glob_adv, lcf) && ((reinterpret_cast<uintptr_t>(mixed) & 15) == 0);
     hipLaunchKernelGGL(lcf_mix_partial_kernel, dim3(kLcfBlocks), dim3(256), 0, stream, adv, nei_adv, glob_adv, lcf,
-                       valid, (long long)B, mixed, stats);
-    hipLaunchKernelGGL(lcf_mix_fold_kernel, dim3(1), dim3(64), 0, stream, stats, kLcfBlocks);
+                       valid, (long long)B, vec, mixed, stats);
+    hipLaunchKernelGGL(lcf_mix_fold_kernel, dim3(1), dim3(384), 0, stream, stats, kLcfBlocks);
     return hipGetLastError();
 }
 
 hipError_t launch_lcf_mix_apply(const float* mixed, const float* glob_adv, const uint8_t* valid, int64_t B,
                                 const double* stats, float* norm_adv, float* glob_std, hipStream_t stream) {
-    int grid = (int)((B + 255) / 256);
-    if (grid > 2048) grid = 2048;
+    const int vec = lcf_aligned(mixed, glob_adv, norm_adv, glob_std);
+    int grid = (int)((B + 1023) / 1024);
+    if (grid > 4096) grid = 4096;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(lcf_mix_apply_kernel, dim3(grid), dim3(256), 0, stream, mixed, glob_adv, valid, (long long)B,
+    hipLaunchKernelGGL(lcf_mix_apply_kernel, dim3(grid), dim3(256), 0, stream, mixed, glob_adv, valid, (long long)B, vec,
                        stats, norm_adv, glob_std);
     return hipGetLastError();
 }

@@ -44,7 +44,7 @@ extern "C" {
 #define COPO_NAVI_DIM 10
 #define COPO_INFO_DIM 8
 #define COPO_STATE_FIELDS 16
-#define COPO_LCF_STATS_DOUBLES (8 + 6 * 256) /* size of the `stats` workspace of copo_lcf_mix_* */
+#define COPO_LCF_STATS_DOUBLES (8 + 6 * 2048) /* size of the `stats` workspace of copo_lcf_mix_* */
 
 /* per-slot step flags (uint8 bitfield), the device-side equivalent of the info dict keys consumed by
  * utils/callbacks.py:63-91 (arrive_dest / crash / out_of_road / max_step) plus row bookkeeping. */
