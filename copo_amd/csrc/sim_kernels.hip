@@ -114,8 +114,8 @@ struct __align__(16) EnvLds {
     float x[64], y[64], cs[64], sn[64], rew[64];
     float ego[64][20];
     float ray[COPO_MAX_LASERS][2];
-    unsigned long long cand[64];
-    float sorted[16][64];      // per-wave scratch of the neighbour phase
+    uint8_t plist[64], slist[64];   // slots of the present agents / solid vehicles, ascending (LiDAR pair list)
+    uint8_t ncnt[64];          // neighbour-list lengths (neighbour phase)
     unsigned long long m_acted, m_present, m_solid;
     uint8_t crash[64];
     int16_t perm[COPO_MAX_SPAWNS];
@@ -124,7 +124,6 @@ struct __align__(16) EnvLds {
     const int32_t* stab;       // spawn table, same
     const float* sps;          // spawn offsets, same
     int32_t ending;
-    int32_t ntasks;            // LiDAR task list fill
 };
 
 // segment record k of a route (COPO_SEG_STRIDE floats), through whichever copy of the tables this workgroup uses
@@ -132,6 +131,11 @@ __device__ __forceinline__ const float* seg_ptr(const EnvLds& L, int route, int 
     return L.rsegs + ((size_t)route * (COPO_MAX_SEGS + 1) + k) * COPO_SEG_STRIDE;
 }
 constexpr int ROUTE_LDS_MAX_BYTES = 12 * 1024;
+// dynamic LDS: [slots][rays] LiDAR minima, then the route-table copy
+// (the neighbour phase borrows it for its [slots][slots] list-order rewards)
+__device__ __host__ inline int lidar_lds_words(int n_agents, int n_lasers) {
+    return (n_agents * (n_lasers > n_agents ? n_lasers : n_agents) + 3) & ~3;
+}
 __device__ __host__ inline int route_table_floats(int n_routes) {
     return n_routes * ((COPO_MAX_SEGS + 1) * COPO_SEG_STRIDE + 4);
 }
@@ -189,14 +193,15 @@ __device__ __forceinline__ void neighbours_phase(const SimParams& p, EnvLds& L, 
         }
         if (lane == 0) out.glob_rew[e] = gc ? (float)(gs / (double)gc) : 0.0f;
     }
-    float* srt = L.sorted[wave & 15];   // per-wave scratch: rewards in list order
+    extern __shared__ unsigned int dyn[];
+    float* srt = reinterpret_cast<float*>(dyn);   // [N][N] rewards in list order (aliases the LiDAR minima of P5)
     for (int i = wave; i < N; i += nwaves) {
         const bool pi = (present >> i) & 1ull;
         if (!pi) {   // absent slot: empty list (uniform branch)
             if (lane == 0) {
                 if (out.nbr_cnt) out.nbr_cnt[base + i] = 0;
                 if (out.mf_cnt) out.mf_cnt[base + i] = 0;
-                if (out.nei_rew) out.nei_rew[base + i] = 0.0f;
+                L.ncnt[i] = 0;
             }
             if (lane < K) {
                 if (out.nbr_idx) out.nbr_idx[(base + i) * K + lane] = -1;
@@ -220,19 +225,11 @@ __device__ __forceinline__ void neighbours_phase(const SimParams& p, EnvLds& L, 
             const double dk = __shfl(d, k);
             rank += (dk < d || (dk == d && k < lane)) ? 1 : 0;
         }
-        if (out.nei_rew) {  // mean of neighbour rewards, summed in list order in fp64 (env_wrappers.py:321-325)
-            if (inr) srt[rank] = L.rew[lane];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            double nsum = 0.0;
-            for (int r = 0; r < cnt; ++r) nsum += (double)srt[r];
-            if (lane == 0) out.nei_rew[base + i] = cnt ? (float)(nsum / (double)cnt) : 0.0f;
-            __builtin_amdgcn_wave_barrier();
-        }
+        if (out.nei_rew && inr) srt[i * N + rank] = L.rew[lane];
         if (lane == 0) {
             if (out.nbr_cnt) out.nbr_cnt[base + i] = cnt;
             if (out.mf_cnt) out.mf_cnt[base + i] = mfc;
+            L.ncnt[i] = (uint8_t)cnt;
         }
         if (inr && rank < K) {
             if (out.nbr_idx) out.nbr_idx[(base + i) * K + rank] = lane;
@@ -242,6 +239,15 @@ __device__ __forceinline__ void neighbours_phase(const SimParams& p, EnvLds& L, 
             if (out.nbr_idx) out.nbr_idx[(base + i) * K + lane] = -1;
             if (out.nbr_dist) out.nbr_dist[(base + i) * K + lane] = 0.0f;
         }
+    }
+    __syncthreads();
+    // mean of neighbour rewards, summed in list order in fp64 (env_wrappers.py:321-325): one lane per agent, on a
+    // wave that the caller's next (wave 0) phase does not need
+    if (out.nei_rew && wave == (nwaves > 1 ? 1 : 0) && lane < N) {
+        const int cnt = L.ncnt[lane];
+        double nsum = 0.0;
+        for (int r = 0; r < cnt; ++r) nsum += (double)srt[lane * N + r];
+        out.nei_rew[base + lane] = cnt ? (float)(nsum / (double)cnt) : 0.0f;
     }
 }
 
@@ -307,14 +313,34 @@ __device__ __forceinline__ float ray_box(float rx, float ry, float dxr, float dy
     return n > 0.0f ? n / a : 0.0f;
 }
 
+// Bearing of (u, v) in (-pi, pi], absolute error < 1e-5 rad.  NOT part of the deterministic spec: it only sizes the
+// conservative ray window below, every hit/miss decision stays with ray_box.
+__device__ __forceinline__ float atan2_window(float v, float u) {
+    const float au = fabsf(u), av = fabsf(v);
+    const float mx = fmaxf(fmaxf(au, av), 1e-30f), mn = fminf(au, av);
+    const float z = mn * __builtin_amdgcn_rcpf(mx), z2 = z * z;
+    float q = __builtin_fmaf(z2, -0.01172120f, 0.05265332f);
+    q = __builtin_fmaf(z2, q, -0.11643287f);
+    q = __builtin_fmaf(z2, q, 0.19354346f);
+    q = __builtin_fmaf(z2, q, -0.33262347f);
+    q = __builtin_fmaf(z2, q, 0.99997726f);
+    q = q * z;
+    if (av > au) q = 1.57079633f - q;
+    if (u < 0.0f) q = 3.14159265f - q;
+    return v < 0.0f ? -q : q;
+}
+
 // LiDAR + observation write-out, all threads of the workgroup.  Precondition: L.x/y/cs/sn, m_present,
 // m_solid, ego tile are final and visible (caller synchronised).
 //
-// The expensive box test runs on dense lanes: every wave owns 64 consecutive rays, walks their (ray, candidate)
-// pairs with the cheap reject (candidate centre behind the origin / farther than the circumradius from the ray
-// line) and appends the survivors to a small per-wave LDS queue; whenever 64 tasks are queued the whole wave runs
-// the box test on them and folds hits into the per-ray minimum with LDS atomicMin on the float bit pattern
-// (distances are >= 0, so unsigned order == float order and the result is independent of the task order).
+// Pair-driven: a ray of agent i can only touch vehicle j inside the angular window bearing(j) +- asin(circumradius /
+// distance) of i's ray fan, so the work list is (present agent, solid vehicle) pairs expanded to the few rays of their
+// window -- ~6 box tests per pair instead of one reject test per (ray, vehicle).  One lane per pair computes the
+// window (a superset, with a 4 mrad margin over < 1e-4 rad of approximation error); a wave scan of the window sizes
+// numbers the box tests, lanes find their (pair, ray) by a 6-step search over the scanned counts, and hits fold into
+// the per-ray minimum with LDS atomicMin on the float bit pattern (distances are >= 0, so unsigned order == float
+// order and the result does not depend on the task order).  Rays outside every window keep `range`, exactly what
+// the exhaustive test of the oracle gives them.
 __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, int tid, int nthreads,
                                           float* __restrict__ obs) {
     extern __shared__ unsigned int dyn[];
@@ -325,17 +351,15 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
     const float range = p.lidar_range;
     const float lim = range + circ;
     const unsigned long long solid = L.m_solid, present = L.m_present;
-    const int total = N * NL;
-    unsigned int* wbest = dyn + wave * 192;       // [64] best distance of this wave's rays (float bits)
-    unsigned int* wq = wbest + 64;                // [128] queued tasks: (local ray << 6) | candidate
-    // candidate masks: solid vehicles within range + circumradius of agent i
-    for (int i = wave; i < N; i += nwaves) {
-        const float rx = L.x[lane] - L.x[i], ry = L.y[lane] - L.y[i];
-        const bool c = (lane < N) && (lane != i) && ((solid >> lane) & 1ull) && !(rx * rx + ry * ry > lim * lim);
-        const unsigned long long m = __ballot(c);
-        if (lane == 0) L.cand[i] = m;
+    const int np = __popcll(present), ns = __popcll(solid);
+    unsigned int* best = dyn;                     // [np][NL] nearest entry distance (float bits) per ray
+    const unsigned int range_bits = __float_as_uint(range);
+    if (wave == 0) {                              // slot lists of the present agents / the solid vehicles
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        if ((present >> lane) & 1ull) L.plist[__popcll(present & lt)] = (uint8_t)lane;
+        if ((solid >> lane) & 1ull) L.slist[__popcll(solid & lt)] = (uint8_t)lane;
     }
-    __syncthreads();
+    for (int q = tid; q < np * NL; q += nthreads) best[q] = range_bits;
     float* eobs = obs + (size_t)e * N * O;
     // ego / navigation / lcf columns
     for (int q = tid; q < N * 20; q += nthreads) {
@@ -343,63 +367,73 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
         if (c < 19) eobs[(size_t)i * O + c] = L.ego[i][c];
         else if (p.enable_lcf) eobs[(size_t)i * O + O - 1] = L.ego[i][19];
     }
-    const unsigned int range_bits = __float_as_uint(range);
-    auto run_tasks = [&](int q0, int n) {   // lanes < n take one queued task each
-        if (lane < n) {
-            const unsigned int tk = wq[lane];
-            const int lr = (int)(tk >> 6), j = (int)(tk & 63u);
-            const int q = q0 + lr;
-            const int i = q / NL, k = q - i * NL;
-            const float ci = L.cs[i], si = L.sn[i];
-            const float rc = L.ray[k][0], rs = L.ray[k][1];
-            const float t = ray_box(L.x[j] - L.x[i], L.y[j] - L.y[i], ci * rc - si * rs, si * rc + ci * rs, L.cs[j], L.sn[j], hl, hw);
-            if (t >= 0.0f) atomicMin(&wbest[lr], __float_as_uint(t));
-        }
-    };
-    for (int q0 = wave * 64; q0 < total; q0 += nwaves * 64) {
-        const int q = q0 + lane;
-        const bool live = q < total;
-        const int i = live ? q / NL : 0, k = live ? q - i * NL : 0;
-        const bool pres = live && ((present >> i) & 1ull);
-        unsigned long long m = pres ? L.cand[i] : 0ull;
-        const float x = L.x[i], y = L.y[i], ci = L.cs[i], si = L.sn[i];
-        const float rc = L.ray[k][0], rs = L.ray[k][1];
-        const float dxr = ci * rc - si * rs;
-        const float dyr = si * rc + ci * rs;
-        wbest[lane] = range_bits;
-        int qc = 0;                              // wave-uniform queue fill
-        while (__ballot(m != 0ull)) {
-            bool pass = false;
-            int j = 0;
-            if (m) {
-                j = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const float rx = L.x[j] - x, ry = L.y[j] - y;
-                const float along = dxr * rx + dyr * ry;
-                const float perp = dxr * ry - dyr * rx;
-                pass = !(along < -circ || fabsf(perp) > circ);
-            }
-            const unsigned long long pm = __ballot(pass);
-            if (pass) wq[qc + __popcll(pm & ((1ull << lane) - 1ull))] = ((unsigned int)lane << 6) | (unsigned int)j;
-            qc += __popcll(pm);
-            if (qc >= 64) {                      // a full wave of box tests
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                run_tasks(q0, 64);
-                __builtin_amdgcn_wave_barrier();
-                const unsigned int carry = (lane < qc - 64) ? wq[64 + lane] : 0u;
-                __builtin_amdgcn_wave_barrier();
-                if (lane < qc - 64) wq[lane] = carry;
-                qc -= 64;
+    __syncthreads();
+    const int ncombo = np * ns;
+    const float inv_ns = 1.0f / (float)(ns > 0 ? ns : 1);
+    const float rays_per_rad = (float)NL * 0.159154943f;
+    for (int c0 = wave * 64; c0 < ncombo; c0 += nwaves * 64) {
+        const int c = c0 + lane;
+        const bool live = c < ncombo;
+        const int ip = live ? (int)(((float)c + 0.5f) * inv_ns) : 0;
+        const int i = L.plist[ip], j = L.slist[live ? c - ip * ns : 0];
+        const float dx = L.x[j] - L.x[i], dy = L.y[j] - L.y[i];
+        const float d2 = dx * dx + dy * dy;
+        int klo = 0, cnt = 0;
+        if (live && j != i && !(d2 > lim * lim)) {
+            if (d2 <= circ * circ * 1.002f) {
+                cnt = NL;                         // origin inside the circumcircle: any ray may hit
+            } else {
+                const float ci = L.cs[i], si = L.sn[i];
+                const float phi = atan2_window(ci * dy - si * dx, ci * dx + si * dy);
+                const float x = circ * __builtin_amdgcn_rsqf(d2);
+                const float w = x + 0.5708f * x * x * x + 0.004f;     // >= asin(x) + margin
+                const int lo = (int)ceilf((phi - w) * rays_per_rad), hi = (int)floorf((phi + w) * rays_per_rad);
+                cnt = hi - lo + 1;
+                cnt = cnt < 0 ? 0 : (cnt > NL ? NL : cnt);
+                klo = lo < 0 ? lo + NL : lo;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        run_tasks(q0, qc);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (live) eobs[(size_t)i * O + COPO_EGO_DIM + COPO_NAVI_DIM + k] = pres ? __uint_as_float(wbest[lane]) / range : 0.0f;
-        __builtin_amdgcn_wave_barrier();
+        const unsigned int pk = (unsigned int)j | ((unsigned int)klo << 6) | ((unsigned int)cnt << 14) | ((unsigned int)ip << 22);
+        int incl = cnt;                           // inclusive scan of the window sizes
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        const int total = __shfl(incl, 63);
+        for (int t0 = 0; t0 < total; t0 += 64) {
+            const int t = t0 + lane;
+            int sl = 0;                           // first lane whose inclusive count exceeds t
+#pragma unroll
+            for (int step = 32; step; step >>= 1) {
+                const int v = __shfl(incl, sl + step - 1);
+                if (v <= t) sl += step;
+            }
+            const unsigned int spk = (unsigned int)__shfl((int)pk, sl);
+            const int sincl = __shfl(incl, sl);
+            if (t < total) {
+                const int sj = (int)(spk & 63u), scnt = (int)((spk >> 14) & 255u), sip = (int)(spk >> 22);
+                int k = (int)((spk >> 6) & 255u) + (t - (sincl - scnt));
+                if (k >= NL) k -= NL;
+                const int si_ = L.plist[sip];
+                const float ci = L.cs[si_], si = L.sn[si_];
+                const float rc = L.ray[k][0], rs = L.ray[k][1];
+                const float tt = ray_box(L.x[sj] - L.x[si_], L.y[sj] - L.y[si_], ci * rc - si * rs, si * rc + ci * rs, L.cs[sj], L.sn[sj], hl, hw);
+                if (tt >= 0.0f) atomicMin(&best[sip * NL + k], __float_as_uint(tt));
+            }
+        }
+    }
+    __syncthreads();
+    const int nrays = N * NL;
+    const float inv_nl = 1.0f / (float)NL;
+    for (int q = tid; q < nrays; q += nthreads) {
+        const int i = (int)(((float)q + 0.5f) * inv_nl), k = q - i * NL;
+        float val = 0.0f;
+        if ((present >> i) & 1ull) {
+            const int ip = __popcll(present & ((1ull << i) - 1ull));
+            val = __uint_as_float(best[ip * NL + k]) / range;
+        }
+        eobs[(size_t)i * O + COPO_EGO_DIM + COPO_NAVI_DIM + k] = val;
     }
 }
 
@@ -464,6 +498,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_reset_kernel(SimParams
     }
     __syncthreads();
     neighbours_phase(p, L, e, wave, nwaves, lane, out);
+    __syncthreads();   // the list-order sums read the LDS words that the LiDAR minima reuse
     if (out.obs) obs_phase(p, L, e, tid, nthreads, out.obs);
 }
 
@@ -484,7 +519,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
         const int nseg_f = p.n_routes * (COPO_MAX_SEGS + 1) * COPO_SEG_STRIDE, nmeta_f = p.n_routes * 4;
         const int ntab = p.n_spawns * 4, nsp = p.n_spawns;
         const bool stage = (nseg_f + nmeta_f) * (int)sizeof(float) <= ROUTE_LDS_MAX_BYTES;
-        float* rl = reinterpret_cast<float*>(dyn + (nthreads >> 6) * 192);
+        float* rl = reinterpret_cast<float*>(dyn + lidar_lds_words(p.N, p.num_lasers));
         int32_t* tl = reinterpret_cast<int32_t*>(rl + nseg_f + nmeta_f);
         float* sl = reinterpret_cast<float*>(tl + ntab);
         if (stage) {
@@ -575,10 +610,15 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
         const unsigned long long ma = L.m_acted, ms = L.m_solid;
         const float xj = L.x[lane], yj = L.y[lane], cj = L.cs[lane], sj = L.sn[lane];
         const bool sol = (ms >> lane) & 1ull;
+        const float near2 = 4.0f * (hl * hl + hw * hw) * 1.001f;
         for (int i = wave; i < N; i += nwaves) {
             bool hit = false;
-            if ((ma >> i) & 1ull)
-                hit = sol && (lane != i) && obb_overlap(L.x[i], L.y[i], L.cs[i], L.sn[i], xj, yj, cj, sj, hl, hw);
+            if ((ma >> i) & 1ull) {   // boxes farther apart than two circumradii cannot overlap: skip the SAT test
+                const float xi = L.x[i], yi = L.y[i];
+                const float ddx = xj - xi, ddy = yj - yi;
+                const bool near = sol && (lane != i) && (ddx * ddx + ddy * ddy <= near2);
+                if (__ballot(near)) hit = near && obb_overlap(xi, yi, L.cs[i], L.sn[i], xj, yj, cj, sj, hl, hw);
+            }
             const unsigned long long m = __ballot(hit);
             if (lane == 0) L.crash[i] = m ? 1 : 0;
         }
@@ -664,20 +704,35 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
         present = acted;
         // respawn, serial over eligible slots in slot order; every lane tests its own vehicle
         if (!ending) {
-            unsigned long long elig = __ballot(lane < capacity_of(p) && !acted && s.status == ST_EMPTY);
-            while (elig) {
-                const int n = __ffsll((long long)elig) - 1;
-                elig &= elig - 1;
-                const uint32_t cnt = (uint32_t)__shfl(s.spawncnt, n);
+            const bool mine = lane < capacity_of(p) && !acted && s.status == ST_EMPTY;
+            unsigned long long elig = __ballot(mine);
+            // the three hashed spawn points of every eligible slot depend on (seed, slot, spawn count, t) only: all
+            // lanes draw theirs at once, the serial part below only tests them against the vehicles on the road
+            int spc[3] = {0, 0, 0};
+            float sxc[3] = {0.0f, 0.0f, 0.0f}, syc[3] = {0.0f, 0.0f, 0.0f};
+            if (mine) {
+#pragma unroll
                 for (uint32_t a = 0; a < 3; ++a) {
-                    const uint32_t hh = hash_rng(seed, (uint32_t)n, cnt, (uint32_t)t_env, RNG_SPAWN + a);
+                    const uint32_t hh = hash_rng(seed, (uint32_t)lane, (uint32_t)s.spawncnt, (uint32_t)t_env, RNG_SPAWN + a);
                     const int sp = (int)(hh % (uint32_t)p.n_spawns);
                     const float* g = seg_ptr(L, L.stab[sp * 4], 0);
                     const float s0 = L.sps[sp];
-                    const float sx = g[0] + g[2] * s0, sy = g[1] + g[3] * s0;
+                    spc[a] = sp;
+                    sxc[a] = g[0] + g[2] * s0;
+                    syc[a] = g[1] + g[3] * s0;
+                }
+            }
+            const float clear2 = p.spawn_clearance * p.spawn_clearance;
+            while (elig) {
+                const int n = __ffsll((long long)elig) - 1;
+                elig &= elig - 1;
+#pragma unroll
+                for (uint32_t a = 0; a < 3; ++a) {
+                    const float sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sxc[a]), n));
+                    const float sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(syc[a]), n));
+                    const int sp = spc[a];
                     const float dx = s.x - sx, dy = s.y - sy;
-                    const bool blk = (lane < N) && ((s.status & 0xff) != ST_EMPTY) &&
-                                     (dx * dx + dy * dy < p.spawn_clearance * p.spawn_clearance);
+                    const bool blk = (lane < N) && ((s.status & 0xff) != ST_EMPTY) && (dx * dx + dy * dy < clear2);
                     if (__ballot(blk) == 0ull) {
                         if (lane == n) {
                             spawn_slot(p, L.rsegs, L.stab, L.sps, seed, (uint32_t)episode, n, sp, next_aid, s);
@@ -710,7 +765,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
     // ---- P3 (all waves): neighbour lists + reward reductions on the post-step (pre-reset) scene ---
     neighbours_phase(p, L, e, wave, nwaves, lane, out);
     COPO_STAMP(4);
-    if (ending) __syncthreads();  // neighbours read the poses that the reset below overwrites
+    // (neighbours_phase ends with a workgroup barrier: the reset below may overwrite the poses it read)
 
     // ---- P4 (wave 0): horizon reset, row outputs, state write-back, ego/navi obs ------------------
     if (wave == 0) {
@@ -789,25 +844,35 @@ __global__ void __launch_bounds__(256) neighbours_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------
-static size_t lidar_lds_bytes(int block) { return (size_t)(block / 64) * 192 * sizeof(unsigned int); }   // per-wave ray queue
+static size_t lidar_lds_bytes(const SimParams& p) { return (size_t)lidar_lds_words(p.N, p.num_lasers) * sizeof(unsigned int); }
+static hipError_t sim_lds_attrs() {              // 64 slots x 256 rays + route tables exceed the default 64 KB
+    static hipError_t once = [] {
+        hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(sim_reset_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void*>(sim_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        return a != hipSuccess ? a : b;
+    }();
+    return once;
+}
 static size_t route_lds_bytes(const SimParams& p) {      // LDS copy of the route tables when they are small
     const size_t b = (size_t)route_table_floats(p.n_routes) * sizeof(float);
     return b <= (size_t)ROUTE_LDS_MAX_BYTES ? b + (size_t)p.n_spawns * 5 * sizeof(float) : 0;      // + spawn table and offsets
 }
 
 hipError_t launch_sim_reset(const SimParams& p, const StepOut& out, int block, hipStream_t stream) {
-    hipLaunchKernelGGL(sim_reset_kernel, dim3(p.E), dim3(block), lidar_lds_bytes(block), stream, p, out);
+    if (hipError_t a = sim_lds_attrs(); a != hipSuccess) return a;
+    hipLaunchKernelGGL(sim_reset_kernel, dim3(p.E), dim3(block), lidar_lds_bytes(p), stream, p, out);
     return hipGetLastError();
 }
 
 hipError_t launch_sim_step(const SimParams& p, const float* act, const StepOut& out, int block, hipStream_t stream) {
-    hipLaunchKernelGGL(sim_step_kernel, dim3(p.E), dim3(block), lidar_lds_bytes(block) + route_lds_bytes(p), stream, p, act, out);
+    if (hipError_t a = sim_lds_attrs(); a != hipSuccess) return a;
+    hipLaunchKernelGGL(sim_step_kernel, dim3(p.E), dim3(block), lidar_lds_bytes(p) + route_lds_bytes(p), stream, p, act, out);
     return hipGetLastError();
 }
 
 hipError_t launch_neighbours(const float* pos, const uint8_t* present, const float* rew, const SimParams& p,
                              const StepOut& out, hipStream_t stream) {
-    hipLaunchKernelGGL(neighbours_kernel, dim3(p.E), dim3(256), 0, stream, pos, present, rew, p, out);
+    hipLaunchKernelGGL(neighbours_kernel, dim3(p.E), dim3(256), (size_t)p.N * p.N * sizeof(float), stream, pos, present, rew, p, out);
     return hipGetLastError();
 }
 
