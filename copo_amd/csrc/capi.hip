@@ -108,7 +108,7 @@ extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** o
     p.enable_lcf = cfg->enable_lcf; p.horizon = cfg->horizon; p.delay_done = cfg->delay_done;
     p.respawn_cooldown = cfg->respawn_cooldown; p.substeps = cfg->substeps;
     p.n_routes = cfg->n_routes; p.n_spawns = cfg->n_spawns;
-    p.lidar_task_cap = cfg->num_agents * cfg->num_lasers < 8192 ? cfg->num_agents * cfg->num_lasers : 8192;
+    { const char* e = getenv("COPO_SIM_SKIP"); p.dbg_skip = e ? atoi(e) : 0; }   // profiling only: see sim_common.h
     p.lidar_range = cfg->lidar_range; p.neighbours_distance = cfg->neighbours_distance; p.mf_distance = cfg->mf_distance;
     p.dt = cfg->dt; p.hl = cfg->veh_half_len; p.hw = cfg->veh_half_wid; p.wheelbase = cfg->wheelbase;
     p.max_steer = cfg->max_steer; p.max_speed = cfg->max_speed; p.acc_max = cfg->acc_max; p.brake_max = cfg->brake_max;

@@ -17,7 +17,8 @@ enum : uint32_t { RNG_ROUTE = 1, RNG_LCF1 = 2, RNG_LCF2 = 3, RNG_SPAWN = 4, RNG_
 struct SimParams {
     int32_t E, N, O, K, num_lasers, enable_lcf, horizon, delay_done, respawn_cooldown, substeps;
     int32_t n_routes, n_spawns;
-    int32_t lidar_task_cap;        // entries of the LDS (ray, candidate) task list of the LiDAR pass
+    int32_t dbg_skip;              // profiling only (env COPO_SIM_SKIP): 1 no neighbour phase, 2 no LiDAR box tests, 4 no LiDAR
+                                   // write-out, 8 no ego/navigation block, 16 collision phase twice; results are then wrong
     float lidar_range, neighbours_distance, mf_distance, dt, hl, hw, wheelbase, max_steer, max_speed;
     float acc_max, brake_max, drag, spawn_clearance;
     float driving_reward, speed_reward, success_reward, crash_penalty, out_penalty, arrive_margin, lane_width;

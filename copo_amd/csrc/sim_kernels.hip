@@ -116,6 +116,8 @@ struct __align__(16) EnvLds {
     float ray[COPO_MAX_LASERS][2];
     uint8_t plist[64], slist[64];   // slots of the present agents / solid vehicles, ascending (LiDAR pair list)
     uint8_t ncnt[64];          // neighbour-list lengths (neighbour phase)
+    uint8_t alist[64], clist[64];   // acting agents / solid vehicles before the step's terminations (collision pairs)
+    int32_t rowbase[64];       // first LiDAR minimum of a present slot's fan, -1 for an absent slot
     unsigned long long m_acted, m_present, m_solid;
     uint8_t crash[64];
     int16_t perm[COPO_MAX_SPAWNS];
@@ -222,7 +224,8 @@ __device__ __forceinline__ void neighbours_phase(const SimParams& p, EnvLds& L, 
         while (m) {
             const int k = __ffsll((long long)m) - 1;
             m &= m - 1;
-            const double dk = __shfl(d, k);
+            const double dk = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(d), k),
+                                               __builtin_amdgcn_readlane(__double2loint(d), k));   // k is wave-uniform
             rank += (dk < d || (dk == d && k < lane)) ? 1 : 0;
         }
         if (out.nei_rew && inr) srt[i * N + rank] = L.rew[lane];
@@ -345,7 +348,7 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
                                           float* __restrict__ obs) {
     extern __shared__ unsigned int dyn[];
     const int N = p.N, O = p.O, NL = p.num_lasers;
-    const int wave = tid >> 6, lane = tid & 63, nwaves = nthreads >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nwaves = nthreads >> 6;
     const float hl = p.hl, hw = p.hw;
     const float circ = sqrtf(hl * hl + hw * hw);
     const float range = p.lidar_range;
@@ -356,8 +359,10 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
     const unsigned int range_bits = __float_as_uint(range);
     if (wave == 0) {                              // slot lists of the present agents / the solid vehicles
         const unsigned long long lt = (1ull << lane) - 1ull;
-        if ((present >> lane) & 1ull) L.plist[__popcll(present & lt)] = (uint8_t)lane;
+        const int ip = __popcll(present & lt);
+        if ((present >> lane) & 1ull) L.plist[ip] = (uint8_t)lane;
         if ((solid >> lane) & 1ull) L.slist[__popcll(solid & lt)] = (uint8_t)lane;
+        L.rowbase[lane] = ((present >> lane) & 1ull) ? ip * NL : -1;
     }
     for (int q = tid; q < np * NL; q += nthreads) best[q] = range_bits;
     float* eobs = obs + (size_t)e * N * O;
@@ -371,7 +376,7 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
     const int ncombo = np * ns;
     const float inv_ns = 1.0f / (float)(ns > 0 ? ns : 1);
     const float rays_per_rad = (float)NL * 0.159154943f;
-    for (int c0 = wave * 64; c0 < ncombo; c0 += nwaves * 64) {
+    for (int c0 = wave * 64; c0 < ((p.dbg_skip & 2) ? 0 : ncombo); c0 += nwaves * 64) {
         const int c = c0 + lane;
         const bool live = c < ncombo;
         const int ip = live ? (int)(((float)c + 0.5f) * inv_ns) : 0;
@@ -426,14 +431,12 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
     __syncthreads();
     const int nrays = N * NL;
     const float inv_nl = 1.0f / (float)NL;
-    for (int q = tid; q < nrays; q += nthreads) {
+    for (int q = tid; q < ((p.dbg_skip & 4) ? 0 : nrays); q += nthreads) {
         const int i = (int)(((float)q + 0.5f) * inv_nl), k = q - i * NL;
+        const int rb = L.rowbase[i];
         float val = 0.0f;
-        if ((present >> i) & 1ull) {
-            const int ip = __popcll(present & ((1ull << i) - 1ull));
-            val = __uint_as_float(best[ip * NL + k]) / range;
-        }
-        eobs[(size_t)i * O + COPO_EGO_DIM + COPO_NAVI_DIM + k] = val;
+        if (rb >= 0) val = __uint_as_float(best[rb + k]) / range;
+        eobs[i * O + (COPO_EGO_DIM + COPO_NAVI_DIM) + k] = val;
     }
 }
 
@@ -456,7 +459,7 @@ __device__ __forceinline__ void load_rays(const SimParams& p, EnvLds& L, int tid
 __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_reset_kernel(SimParams p, StepOut out) {
     __shared__ EnvLds L;
     const int e = blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
-    const int wave = tid >> 6, lane = tid & 63, nwaves = nthreads >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nwaves = nthreads >> 6;
     const int N = p.N;
     load_rays(p, L, tid, nthreads);
     if (tid == 0) {
@@ -509,7 +512,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
                                                                       StepOut out) {
     __shared__ EnvLds L;
     const int e = blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
-    const int wave = tid >> 6, lane = tid & 63, nwaves = nthreads >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nwaves = nthreads >> 6;
     const int N = p.N;
     const float hl = p.hl, hw = p.hw;
     load_rays(p, L, tid, nthreads);
@@ -595,7 +598,12 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
             L.x[lane] = 0.0f; L.y[lane] = 0.0f; L.cs[lane] = 1.0f; L.sn[lane] = 0.0f;
         }
         const unsigned long long ma = __ballot(acted);
-        const unsigned long long ms = __ballot(lane < N && (s.status & 0xff) != ST_EMPTY);
+        const bool sol0 = lane < N && (s.status & 0xff) != ST_EMPTY;
+        const unsigned long long ms = __ballot(sol0);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        if (acted) L.alist[__popcll(ma & lt)] = (uint8_t)lane;
+        if (sol0) L.clist[__popcll(ms & lt)] = (uint8_t)lane;
+        L.crash[lane] = 0;
         if (lane == 0) {
             L.m_acted = ma;
             L.m_solid = ms;
@@ -605,22 +613,21 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
     __syncthreads();
     COPO_STAMP(1);
 
-    // ---- P1 (all waves): collision of acting agent i against every solid slot j (lane) ------------
-    {
-        const unsigned long long ma = L.m_acted, ms = L.m_solid;
-        const float xj = L.x[lane], yj = L.y[lane], cj = L.cs[lane], sj = L.sn[lane];
-        const bool sol = (ms >> lane) & 1ull;
-        const float near2 = 4.0f * (hl * hl + hw * hw) * 1.001f;
-        for (int i = wave; i < N; i += nwaves) {
-            bool hit = false;
-            if ((ma >> i) & 1ull) {   // boxes farther apart than two circumradii cannot overlap: skip the SAT test
-                const float xi = L.x[i], yi = L.y[i];
-                const float ddx = xj - xi, ddy = yj - yi;
-                const bool near = sol && (lane != i) && (ddx * ddx + ddy * ddy <= near2);
-                if (__ballot(near)) hit = near && obb_overlap(xi, yi, L.cs[i], L.sn[i], xj, yj, cj, sj, hl, hw);
-            }
-            const unsigned long long m = __ballot(hit);
-            if (lane == 0) L.crash[i] = m ? 1 : 0;
+    // ---- P1 (all waves): collision of every (acting agent, solid vehicle) pair, one lane per pair -----
+    for (int rep = 0; rep < ((p.dbg_skip & 16) ? 2 : 1); ++rep) {
+        const int na = __popcll(L.m_acted), nc = __popcll(L.m_solid);
+        const int npair = na * nc;
+        const float inv_nc = 1.0f / (float)(nc > 0 ? nc : 1);
+        const float near2 = 4.0f * (hl * hl + hw * hw) * 1.001f;   // farther apart than two circumradii: no overlap
+        for (int c0 = wave * 64; c0 < npair; c0 += nwaves * 64) {
+            const int c = c0 + lane;
+            const bool live = c < npair;
+            const int ia = live ? (int)(((float)c + 0.5f) * inv_nc) : 0;
+            const int i = L.alist[ia], j = L.clist[live ? c - ia * nc : 0];
+            const float xi = L.x[i], yi = L.y[i], xj = L.x[j], yj = L.y[j];
+            const float ddx = xj - xi, ddy = yj - yi;
+            const bool near = live && (i != j) && (ddx * ddx + ddy * ddy <= near2);
+            if (near && obb_overlap(xi, yi, L.cs[i], L.sn[i], xj, yj, L.cs[j], L.sn[j], hl, hw)) L.crash[i] = 1;
         }
     }
     __syncthreads();
@@ -763,7 +770,8 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
 
     COPO_STAMP(3);
     // ---- P3 (all waves): neighbour lists + reward reductions on the post-step (pre-reset) scene ---
-    neighbours_phase(p, L, e, wave, nwaves, lane, out);
+    if (!(p.dbg_skip & 1)) neighbours_phase(p, L, e, wave, nwaves, lane, out);
+    else __syncthreads();
     COPO_STAMP(4);
     // (neighbours_phase ends with a workgroup barrier: the reset below may overwrite the poses it read)
 
@@ -801,7 +809,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
             env[1] = episode;
             env[2] = next_aid;
         }
-        ego_navi_obs(p, L, lane, s, present);
+        if (!(p.dbg_skip & 8)) ego_navi_obs(p, L, lane, s, present);
     }
     __syncthreads();
 
@@ -821,7 +829,7 @@ __global__ void __launch_bounds__(256) neighbours_kernel(const float* __restrict
                                                          const float* __restrict__ rew, SimParams p, StepOut out) {
     __shared__ EnvLds L;
     const int e = blockIdx.x, tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63, nwaves = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nwaves = blockDim.x >> 6;
     const int N = p.N;
     if (wave == 0) {
         bool pr = false;
