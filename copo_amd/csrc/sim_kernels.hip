@@ -112,15 +112,12 @@ __device__ __forceinline__ void spawn_slot(const SimParams& p, const float* rseg
 
 struct __align__(16) EnvLds {
     float x[64], y[64], cs[64], sn[64], rew[64];
-    float ego[64][20];
-    float ray[COPO_MAX_LASERS][2];
     uint8_t plist[64], slist[64];   // slots of the present agents / solid vehicles, ascending (LiDAR pair list)
     uint8_t ncnt[64];          // neighbour-list lengths (neighbour phase)
     uint8_t alist[64], clist[64];   // acting agents / solid vehicles before the step's terminations (collision pairs)
     int32_t rowbase[64];       // first LiDAR minimum of a present slot's fan, -1 for an absent slot
     unsigned long long m_acted, m_present, m_solid;
     uint8_t crash[64];
-    int16_t perm[COPO_MAX_SPAWNS];
     const float* rsegs;        // route segment records: the LDS copy of the step kernel (small maps) or global memory
     const float* rmeta;        // route meta records, same
     const int32_t* stab;       // spawn table, same
@@ -134,9 +131,20 @@ __device__ __forceinline__ const float* seg_ptr(const EnvLds& L, int route, int 
 }
 constexpr int ROUTE_LDS_MAX_BYTES = 12 * 1024;
 // dynamic LDS: [slots][rays] LiDAR minima, then the route-table copy
-// (the neighbour phase borrows it for its [slots][slots] list-order rewards)
+// (the neighbour phase borrows it for its [slots][slots] list-order rewards and a reset for its spawn permutation);
+// then the ray direction table, then the route-table copy
 __device__ __host__ inline int lidar_lds_words(int n_agents, int n_lasers) {
-    return (n_agents * (n_lasers > n_agents ? n_lasers : n_agents) + 3) & ~3;
+    const int a = n_agents * n_lasers, b = n_agents * n_agents + COPO_MAX_SPAWNS / 2;
+    return ((a > b ? a : b) + 3) & ~3;
+}
+__device__ __host__ inline int ray_lds_words(int n_lasers) { return (2 * n_lasers + 3) & ~3; }
+__device__ __forceinline__ float* lds_rays(const SimParams& p) {
+    extern __shared__ unsigned int dyn[];
+    return reinterpret_cast<float*>(dyn + lidar_lds_words(p.N, p.num_lasers));
+}
+__device__ __forceinline__ int16_t* lds_perm(const SimParams& p) {
+    extern __shared__ unsigned int dyn[];
+    return reinterpret_cast<int16_t*>(dyn + p.N * p.N);
 }
 __device__ __host__ inline int route_table_floats(int n_routes) {
     return n_routes * ((COPO_MAX_SEGS + 1) * COPO_SEG_STRIDE + 4);
@@ -151,15 +159,16 @@ __device__ __forceinline__ int capacity_of(const SimParams& p) {
 // Full reset of one env by wave 0 (all lanes call; lane n < N owns slot n).
 __device__ __forceinline__ void reset_env_wave0(const SimParams& p, EnvLds& L, uint64_t seed, uint32_t episode, int lane,
                                                 Slot& s) {
+    int16_t* perm = lds_perm(p);
     if (lane == 0) {
         const int P = p.n_spawns;
-        for (int i = 0; i < P; ++i) L.perm[i] = (int16_t)i;
+        for (int i = 0; i < P; ++i) perm[i] = (int16_t)i;
         for (int i = 0; i < p.N; ++i) {
             const uint32_t h = hash_rng(seed, (uint32_t)i, episode, 0u, RNG_PERM);
             const int j = i + (int)(h % (uint32_t)(P - i));
-            const int16_t t = L.perm[i];
-            L.perm[i] = L.perm[j];
-            L.perm[j] = t;
+            const int16_t t = perm[i];
+            perm[i] = perm[j];
+            perm[j] = t;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -167,7 +176,7 @@ __device__ __forceinline__ void reset_env_wave0(const SimParams& p, EnvLds& L, u
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     // population capacity (curriculum): slots beyond it start empty and never respawn
     const int cap = capacity_of(p);
-    if (lane < cap) spawn_slot(p, L.rsegs, L.stab, L.sps, seed, episode, lane, (int)L.perm[lane], lane, s);
+    if (lane < cap) spawn_slot(p, L.rsegs, L.stab, L.sps, seed, episode, lane, (int)perm[lane], lane, s);
     else if (lane < p.N) s.status = ST_EMPTY;
 }
 
@@ -255,11 +264,15 @@ __device__ __forceinline__ void neighbours_phase(const SimParams& p, EnvLds& L, 
 }
 
 // ego + navigation block of the observation for this lane's slot -> LDS tile
-__device__ __forceinline__ void ego_navi_obs(const SimParams& p, EnvLds& L, int lane, const Slot& s, bool present) {
-    float* o = L.ego[lane];
+// (written straight to the observation row of the slot: 19 leading columns + the LCF column at the end)
+__device__ __forceinline__ void ego_navi_obs(const SimParams& p, EnvLds& L, int lane, const Slot& s, bool present,
+                                             float* __restrict__ row) {
+    if (!row) return;
+    float o[20];
     if (!present) {
 #pragma unroll
-        for (int k = 0; k < 20; ++k) o[k] = 0.0f;
+        for (int k = 0; k < 19; ++k) row[k] = 0.0f;
+        if (p.enable_lcf) row[p.O - 1] = 0.0f;
         return;
     }
     const int route = s.route & 0xffff, seg = s.route >> 16;
@@ -297,6 +310,9 @@ __device__ __forceinline__ void ego_navi_obs(const SimParams& p, EnvLds& L, int 
         q[4] = (j == 0) ? clipf(s.prog / total, 0.0f, 1.0f) : ((kk == nseg - 1) ? 1.0f : 0.0f);
     }
     o[19] = (s.lcf + 1.0f) * 0.5f;
+#pragma unroll
+    for (int k = 0; k < 19; ++k) row[k] = o[k];
+    if (p.enable_lcf) row[p.O - 1] = o[19];
 }
 
 // Ray (origin (x, y), unit direction (dxr, dyr)) against the box of vehicle j: entering distance, or a negative
@@ -366,12 +382,7 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
     }
     for (int q = tid; q < np * NL; q += nthreads) best[q] = range_bits;
     float* eobs = obs + (size_t)e * N * O;
-    // ego / navigation / lcf columns
-    for (int q = tid; q < N * 20; q += nthreads) {
-        const int i = q / 20, c = q - i * 20;
-        if (c < 19) eobs[(size_t)i * O + c] = L.ego[i][c];
-        else if (p.enable_lcf) eobs[(size_t)i * O + O - 1] = L.ego[i][19];
-    }
+    const float* __restrict__ rays = lds_rays(p);
     __syncthreads();
     const int ncombo = np * ns;
     const float inv_ns = 1.0f / (float)(ns > 0 ? ns : 1);
@@ -422,7 +433,7 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
                 if (k >= NL) k -= NL;
                 const int si_ = L.plist[sip];
                 const float ci = L.cs[si_], si = L.sn[si_];
-                const float rc = L.ray[k][0], rs = L.ray[k][1];
+                const float rc = rays[2 * k], rs = rays[2 * k + 1];
                 const float tt = ray_box(L.x[sj] - L.x[si_], L.y[sj] - L.y[si_], ci * rc - si * rs, si * rc + ci * rs, L.cs[sj], L.sn[sj], hl, hw);
                 if (tt >= 0.0f) atomicMin(&best[sip * NL + k], __float_as_uint(tt));
             }
@@ -450,7 +461,8 @@ __device__ __forceinline__ void stage_pose(EnvLds& L, int lane, const Slot& s) {
 }
 
 __device__ __forceinline__ void load_rays(const SimParams& p, EnvLds& L, int tid, int nthreads) {
-    for (int q = tid; q < p.num_lasers * 2; q += nthreads) (&L.ray[0][0])[q] = p.ray_cs[q];
+    float* rays = lds_rays(p);
+    for (int q = tid; q < p.num_lasers * 2; q += nthreads) rays[q] = p.ray_cs[q];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -497,7 +509,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_reset_kernel(SimParams
             int32_t* env = p.env + (size_t)e * 4;
             env[0] = 0; env[1] = 0; env[2] = cap; env[3] = 1;
         }
-        ego_navi_obs(p, L, lane, s, lane < cap);
+        ego_navi_obs(p, L, lane, s, lane < cap, (out.obs && lane < N) ? out.obs + ((size_t)e * N + lane) * p.O : nullptr);
     }
     __syncthreads();
     neighbours_phase(p, L, e, wave, nwaves, lane, out);
@@ -522,7 +534,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
         const int nseg_f = p.n_routes * (COPO_MAX_SEGS + 1) * COPO_SEG_STRIDE, nmeta_f = p.n_routes * 4;
         const int ntab = p.n_spawns * 4, nsp = p.n_spawns;
         const bool stage = (nseg_f + nmeta_f) * (int)sizeof(float) <= ROUTE_LDS_MAX_BYTES;
-        float* rl = reinterpret_cast<float*>(dyn + lidar_lds_words(p.N, p.num_lasers));
+        float* rl = reinterpret_cast<float*>(dyn + lidar_lds_words(p.N, p.num_lasers) + ray_lds_words(p.num_lasers));
         int32_t* tl = reinterpret_cast<int32_t*>(rl + nseg_f + nmeta_f);
         float* sl = reinterpret_cast<float*>(tl + ntab);
         if (stage) {
@@ -809,7 +821,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
             env[1] = episode;
             env[2] = next_aid;
         }
-        if (!(p.dbg_skip & 8)) ego_navi_obs(p, L, lane, s, present);
+        if (!(p.dbg_skip & 8)) ego_navi_obs(p, L, lane, s, present, (out.obs && lane < N) ? out.obs + ((size_t)e * N + lane) * p.O : nullptr);
     }
     __syncthreads();
 
@@ -852,7 +864,7 @@ __global__ void __launch_bounds__(256) neighbours_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------
-static size_t lidar_lds_bytes(const SimParams& p) { return (size_t)lidar_lds_words(p.N, p.num_lasers) * sizeof(unsigned int); }
+static size_t lidar_lds_bytes(const SimParams& p) { return (size_t)(lidar_lds_words(p.N, p.num_lasers) + ray_lds_words(p.num_lasers)) * sizeof(unsigned int); }
 static hipError_t sim_lds_attrs() {              // 64 slots x 256 rays + route tables exceed the default 64 KB
     static hipError_t once = [] {
         hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(sim_reset_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
