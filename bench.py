@@ -16,7 +16,9 @@ statistics / meta gradients are all-reduced over RCCL.
 Extra objects on the JSON line:
   roofline      the simulator step kernel (the path's dominant custom kernel): algorithmic bytes
                 (202 + 4*O per present agent slot) / mean launch time measured with HIP events
-                on the launch stream, against the 8 TB/s HBM peak.
+                on the launch stream, against the 8 TB/s HBM peak.  At the workload's 256 scenes a launch is one
+                workgroup per compute unit (latency-bound); `saturated` repeats the measurement on 16 384 scenes
+                (present slots, and all slot rows: absent slots still write their zero rows).
   learner_roofline  one fused SGD step (the two kernels that take most of an iteration): algorithmic flops / mean step
                 time (HIP events), against the dense fp32 MFMA peak.  The step is a chain of two latency-bound launches
                 on a 512-row minibatch, not a throughput GEMM; the fraction says how far from the matrix peak that leaves it.
@@ -75,6 +77,32 @@ def measure_sim_kernel(trainer, launches=200):
         present += float(((out["flags"] & 0x41) != 0).sum())
     del act
     return e0.elapsed_time(e1) * 1e-3 / launches, present / 16.0
+
+
+def measure_sim_kernel_saturated(trainer, scenes=16384, launches=60):
+    """The same kernel on enough scenes to fill the chip (at 256 scenes a launch is one workgroup per
+    compute unit and latency-bound, so the bandwidth fraction is also reported at a saturating scene count)."""
+    from copo_amd.sim import SimConfig, VecSim
+    src = trainer.env.sim
+    sim = VecSim(SimConfig(map=src.cfg.map, num_envs=scenes, num_agents=src.N, num_lasers=src.cfg.num_lasers,
+                           enable_lcf=src.cfg.enable_lcf), with_info=False)
+    sim.reset()
+    gen = torch.Generator(device=sim.device).manual_seed(1)
+    acts = [torch.stack([torch.randn(scenes, sim.N, device=sim.device, generator=gen) * 0.1,
+                         torch.rand(scenes, sim.N, device=sim.device, generator=gen)], -1).contiguous() for _ in range(4)]
+    for i in range(40):
+        sim.step(acts[i % 4])
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(launches):
+        out = sim.step(acts[i % 4])
+    e1.record()
+    torch.cuda.synchronize()
+    present = float(((out["flags"] & 0x41) != 0).sum())
+    k_s = e0.elapsed_time(e1) * 1e-3 / launches
+    sim.close()
+    return k_s, present, scenes * sim.N
 
 
 def measure_learner_step(trainer, launches=200):
@@ -223,6 +251,7 @@ def main():
             traffic = json.load(open(tfile)).get("bytes_per_launch")
         timers = res["timers"]
         learner = measure_learner_step(trainer)
+        sat_s, sat_present, sat_slots = measure_sim_kernel_saturated(trainer)
         line = {
             "metric": "agent-env-steps/sec (sim+learn), Intersection 40-agent", "value": round(value, 1),
             "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -239,7 +268,13 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "copo::sim_step_kernel", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                          "traffic": traffic, "us_per_launch": round(k_s * 1e6, 2),
-                         "units_per_launch": round(present, 1), "bytes_per_unit": bytes_per_unit},
+                         "units_per_launch": round(present, 1), "bytes_per_unit": bytes_per_unit,
+                         "saturated": {"scenes": sat_slots // sim.N, "us_per_launch": round(sat_s * 1e6, 1),
+                                       "present_slots": round(sat_present), "slot_rows_written": sat_slots,
+                                       "achieved_present": round(sat_present * bytes_per_unit / sat_s * 1e-9, 1),
+                                       "achieved_rows_written": round(sat_slots * bytes_per_unit / sat_s * 1e-9, 1),
+                                       "frac_present": round(sat_present * bytes_per_unit / sat_s * 1e-9 / HBM_PEAK_GBPS, 4),
+                                       "frac_rows_written": round(sat_slots * bytes_per_unit / sat_s * 1e-9 / HBM_PEAK_GBPS, 4)}},
         }
         if learner is not None:
             l_s, l_flops = learner
@@ -264,6 +299,7 @@ def main():
         except Exception:
             pass
         print(json.dumps(line), flush=True)
+    D.shutdown()
 
 
 if __name__ == "__main__":

@@ -217,7 +217,8 @@ hipError_t launch_fused_step(FusedArgs a, hipStream_t s, const MetaTail* mt_ = n
 
 hipError_t launch_adam_flat(const FusedArgs& a, long long n, hipStream_t s) {
     const int slots = a.ws != nullptr;
-    hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, n, slots);
+    const int n_tiles = a.theta_t ? adam_tile_count(a.c) : 0;
+    hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)(n_tiles + (n + 256 * ADAM_EPT - 1) / (256 * ADAM_EPT))), dim3(256), 0, s, a, n, slots, n_tiles);
     if (!slots)
         hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, s, const_cast<int64_t*>(a.step),
                            a.bump_k ? const_cast<int64_t*>(a.kptr) : nullptr);

@@ -98,3 +98,13 @@ def broadcast_module_(module, src=0):
 def barrier():
     if is_dist():
         td.barrier()
+
+
+def shutdown():
+    """Tear the process group down (quietens the exit-time warning of ProcessGroupNCCL); safe to call when not initialised."""
+    import torch.distributed as td
+    try:
+        if td.is_available() and td.is_initialized():
+            td.destroy_process_group()
+    except Exception:
+        pass
