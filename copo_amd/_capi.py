@@ -55,6 +55,8 @@ class SimCfg(C.Structure):
         ("n_routes", C.c_int32), ("n_spawns", C.c_int32),
         ("route_segs", C.c_void_p), ("route_meta", C.c_void_p), ("spawn_tab", C.c_void_p), ("spawn_s", C.c_void_p),
         ("ray_cs", C.c_void_p),
+        ("add_traffic_light", C.c_int32), ("traffic_light_interval", C.c_int32), ("comm_size", C.c_int32),
+        ("comm_neighbours", C.c_int32), ("add_pos_in_comm", C.c_int32), ("map_bbox", C.c_float * 4),
     ]
 
 

@@ -61,8 +61,12 @@ extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** o
                     COPO_MAX_AGENTS);
     if (cfg->num_lasers < 1 || cfg->num_lasers > COPO_MAX_LASERS)
         return fail(COPO_ERR_DIM, "num_lasers=%d out of 1..%d", cfg->num_lasers, COPO_MAX_LASERS);
-    const int O = COPO_EGO_DIM + COPO_NAVI_DIM + cfg->num_lasers + (cfg->enable_lcf ? 1 : 0);
-    if (cfg->obs_dim != O) return fail(COPO_ERR_DIM, "obs_dim=%d but 9+10+lasers(+1 lcf)=%d", cfg->obs_dim, O);
+    if (cfg->comm_size < 0 || cfg->comm_size > 64 || (cfg->comm_size > 0 && (cfg->comm_neighbours < 1 || cfg->comm_neighbours > COPO_MAX_AGENTS)))
+        return fail(COPO_ERR_CONFIG, "comm_size=%d comm_neighbours=%d", cfg->comm_size, cfg->comm_neighbours);
+    if (cfg->add_traffic_light && (cfg->traffic_light_interval < 1 || !(cfg->map_bbox[1] > cfg->map_bbox[0]) || !(cfg->map_bbox[3] > cfg->map_bbox[2])))
+        return fail(COPO_ERR_CONFIG, "add_traffic_light needs traffic_light_interval >= 1 and a non-empty map_bbox");
+    const int O = COPO_OBS_DIM(cfg);
+    if (cfg->obs_dim != O) return fail(COPO_ERR_DIM, "obs_dim=%d but 9+10+lasers(+3 traffic light)(+1 lcf)(+comm)=%d", cfg->obs_dim, O);
     if (cfg->nbr_k < 1 || cfg->nbr_k > COPO_MAX_AGENTS) return fail(COPO_ERR_DIM, "nbr_k=%d out of 1..64", cfg->nbr_k);
     if (cfg->n_routes < 1 || cfg->n_routes > COPO_MAX_ROUTES || cfg->n_spawns < cfg->num_agents ||
         cfg->n_spawns > COPO_MAX_SPAWNS)
@@ -108,6 +112,20 @@ extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** o
     p.enable_lcf = cfg->enable_lcf; p.horizon = cfg->horizon; p.delay_done = cfg->delay_done;
     p.respawn_cooldown = cfg->respawn_cooldown; p.substeps = cfg->substeps;
     p.n_routes = cfg->n_routes; p.n_spawns = cfg->n_spawns;
+    {   // observation row: [ego | navigation | lasers | traffic light | lcf | messages]
+        int col = COPO_EGO_DIM + COPO_NAVI_DIM + cfg->num_lasers;
+        p.col_tl = cfg->add_traffic_light ? col : -1;
+        col += cfg->add_traffic_light ? 3 : 0;
+        p.col_lcf = cfg->enable_lcf ? col : -1;
+        col += cfg->enable_lcf ? 1 : 0;
+        p.col_comm = cfg->comm_size > 0 ? col : -1;
+        p.act_dim = COPO_ACT_DIM(cfg);
+        p.tl_interval = cfg->traffic_light_interval > 0 ? cfg->traffic_light_interval : 1;
+        p.comm_size = cfg->comm_size > 0 ? cfg->comm_size : 0;
+        p.comm_nb = cfg->comm_size > 0 ? cfg->comm_neighbours : 0;
+        p.comm_pos = cfg->add_pos_in_comm ? 1 : 0;
+        for (int k = 0; k < 4; ++k) p.bbox[k] = cfg->map_bbox[k];
+    }
     { const char* e = getenv("COPO_SIM_SKIP"); p.dbg_skip = e ? atoi(e) : 0; }   // profiling only: see sim_common.h
     p.lidar_range = cfg->lidar_range; p.neighbours_distance = cfg->neighbours_distance; p.mf_distance = cfg->mf_distance;
     p.dt = cfg->dt; p.hl = cfg->veh_half_len; p.hw = cfg->veh_half_wid; p.wheelbase = cfg->wheelbase;

@@ -22,6 +22,9 @@ struct SimParams {
     float lidar_range, neighbours_distance, mf_distance, dt, hl, hw, wheelbase, max_steer, max_speed;
     float acc_max, brake_max, drag, spawn_clearance;
     float driving_reward, speed_reward, success_reward, crash_penalty, out_penalty, arrive_margin, lane_width;
+    // observation / action extensions (copo_sim_cfg): columns are -1 when the block is off
+    int32_t act_dim, tl_interval, comm_size, comm_nb, comm_pos, col_tl, col_lcf, col_comm;
+    float bbox[4];
     float* state;                  // [COPO_STATE_FIELDS][E][N] 32-bit words
     int32_t* env;                  // [E][4] = {t_env, episode, next_aid, started}
     const uint64_t* seeds;         // [E]
@@ -38,6 +41,7 @@ using StepOut = copo_step_out;
 
 hipError_t launch_sim_reset(const SimParams& p, const StepOut& out, int block, hipStream_t stream);
 hipError_t launch_sim_step(const SimParams& p, const float* act, const StepOut& out, int block, hipStream_t stream);
+// stateless neighbour op: no communication block
 hipError_t launch_neighbours(const float* pos, const uint8_t* present, const float* rew, const SimParams& p,
                              const StepOut& out, hipStream_t stream);
 

@@ -184,9 +184,17 @@ __device__ __forceinline__ void reset_env_wave0(const SimParams& p, EnvLds& L, u
 //
 // The reference orders by d = sqrt_rn(dx^2 + dy^2) in float64 (np.linalg.norm) with ties in slot order and tests
 // `d < radius` (env_wrappers.py:125-158); the same fp64 operations are evaluated here, one sqrt per (i, j) pair.
+//
+// Communication (CCEnv.step :102-118, LCFEnv.step :362-371): the message columns of agent i hold the comm actions of
+// its `comm_nb` nearest neighbours (zeros for a neighbour that was not given an action this step, for a missing
+// neighbour, and everywhere after a reset: `fresh`), optionally followed by the neighbour's relative position.
+template <bool EXT>
 __device__ __forceinline__ void neighbours_phase(const SimParams& p, EnvLds& L, int e, int wave, int nwaves,
-                                                 int lane, const StepOut& out) {
+                                                 int lane, const StepOut& out, const float* __restrict__ act = nullptr,
+                                                 unsigned long long acted_mask = 0ull, bool fresh = true) {
     const int N = p.N, K = p.K;
+    const bool comm = EXT && p.col_comm >= 0 && out.obs != nullptr;
+    const int CS = p.comm_size, CD = p.comm_size + 3 * p.comm_pos;
     const unsigned long long present = L.m_present;
     const bool pj = (lane < N) && ((present >> lane) & 1ull);
     const double xj = (double)L.x[lane & 63], yj = (double)L.y[lane & 63];
@@ -214,6 +222,10 @@ __device__ __forceinline__ void neighbours_phase(const SimParams& p, EnvLds& L, 
                 if (out.mf_cnt) out.mf_cnt[base + i] = 0;
                 L.ncnt[i] = 0;
             }
+            if (comm && lane < p.comm_nb) {
+                float* q = out.obs + (base + i) * p.O + p.col_comm + lane * CD;
+                for (int k = 0; k < CD; ++k) q[k] = 0.0f;
+            }
             if (lane < K) {
                 if (out.nbr_idx) out.nbr_idx[(base + i) * K + lane] = -1;
                 if (out.nbr_dist) out.nbr_dist[(base + i) * K + lane] = 0.0f;
@@ -238,6 +250,31 @@ __device__ __forceinline__ void neighbours_phase(const SimParams& p, EnvLds& L, 
             rank += (dk < d || (dk == d && k < lane)) ? 1 : 0;
         }
         if (out.nei_rew && inr) srt[i * N + rank] = L.rew[lane];
+        if (comm) {
+            float* row = out.obs + (base + i) * p.O + p.col_comm;
+            if (inr && rank < p.comm_nb) {
+                float* q = row + rank * CD;
+                const bool spoke = !fresh && ((acted_mask >> lane) & 1ull) && act != nullptr;
+                for (int k = 0; k < CS; ++k) q[k] = spoke ? act[(base + lane) * p.act_dim + 2 + k] : 0.0f;
+                if (p.comm_pos) {
+                    float ex[3] = {0.0f, 0.0f, 0.0f};
+                    if (spoke) {   // neighbour relative to ego in the ego frame, float64 like the reference's numpy
+                        const double ci = (double)L.cs[i], si = (double)L.sn[i];
+                        const double lon = (-dx) * ci + (-dy) * si, lat = (-dy) * ci - (-dx) * si;
+                        const double dis = sqrt(lon * lon + lat * lat);
+                        const double v[3] = {dis / 20.0, (lon / dis + 1.0) / 2.0, (lat / dis + 1.0) / 2.0};   // 0/0 = NaN for d == 0, as numpy
+#pragma unroll
+                        for (int k = 0; k < 3; ++k)
+                            ex[k] = v[k] != v[k] ? __uint_as_float(0x7fc00000u) : (float)(v[k] < 0.0 ? 0.0 : (v[k] > 1.0 ? 1.0 : v[k]));
+                    }
+                    q[CS] = ex[0]; q[CS + 1] = ex[1]; q[CS + 2] = ex[2];
+                }
+            }
+            if (lane >= cnt && lane < p.comm_nb) {
+                float* q = row + lane * CD;
+                for (int k = 0; k < CD; ++k) q[k] = 0.0f;
+            }
+        }
         if (lane == 0) {
             if (out.nbr_cnt) out.nbr_cnt[base + i] = cnt;
             if (out.mf_cnt) out.mf_cnt[base + i] = mfc;
@@ -265,15 +302,27 @@ __device__ __forceinline__ void neighbours_phase(const SimParams& p, EnvLds& L, 
 
 // ego + navigation block of the observation for this lane's slot -> LDS tile
 // (written straight to the observation row of the slot: 19 leading columns + the LCF column at the end)
+// `counter` = env steps since the last reset (the traffic-light clock, env_wrappers.py:258-265,280,317).
+template <bool EXT>
 __device__ __forceinline__ void ego_navi_obs(const SimParams& p, EnvLds& L, int lane, const Slot& s, bool present,
-                                             float* __restrict__ row) {
+                                             float* __restrict__ row, int counter) {
     if (!row) return;
     float o[20];
     if (!present) {
 #pragma unroll
         for (int k = 0; k < 19; ++k) row[k] = 0.0f;
-        if (p.enable_lcf) row[p.O - 1] = 0.0f;
+        if (p.col_lcf >= 0) row[p.col_lcf] = 0.0f;
+        if (EXT && p.col_tl >= 0) { row[p.col_tl] = 0.0f; row[p.col_tl + 1] = 0.0f; row[p.col_tl + 2] = 0.0f; }
         return;
+    }
+    if (EXT && p.col_tl >= 0) {   // clip([message, x', y'], 0, 1) in python float64 arithmetic, cast to fp32
+        const int I = p.tl_interval;
+        const double inc = (double)(counter % I) / (double)I * 0.1;
+        const double msg = (((counter / I) % 2) == 1) ? 0.0 + inc : 1.0 - inc;
+        const double b0 = (double)p.bbox[0], b1 = (double)p.bbox[1], b2 = (double)p.bbox[2], b3 = (double)p.bbox[3];
+        const double v[3] = {msg, ((double)s.x - b0) / (b1 - b0), ((double)s.y - b2) / (b3 - b2)};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) row[p.col_tl + k] = (float)(v[k] < 0.0 ? 0.0 : (v[k] > 1.0 ? 1.0 : v[k]));
     }
     const int route = s.route & 0xffff, seg = s.route >> 16;
     const float* meta = L.rmeta + route * 4;
@@ -312,7 +361,7 @@ __device__ __forceinline__ void ego_navi_obs(const SimParams& p, EnvLds& L, int 
     o[19] = (s.lcf + 1.0f) * 0.5f;
 #pragma unroll
     for (int k = 0; k < 19; ++k) row[k] = o[k];
-    if (p.enable_lcf) row[p.O - 1] = o[19];
+    if (p.col_lcf >= 0) row[p.col_lcf] = o[19];
 }
 
 // Ray (origin (x, y), unit direction (dxr, dyr)) against the box of vehicle j: entering distance, or a negative
@@ -468,6 +517,7 @@ __device__ __forceinline__ void load_rays(const SimParams& p, EnvLds& L, int tid
 // ------------------------------------------------------------------------------------------------
 // reset kernel
 // ------------------------------------------------------------------------------------------------
+template <bool EXT>   // EXT: the traffic-light / communication observation blocks are compiled in (copo_sim_cfg extensions)
 __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_reset_kernel(SimParams p, StepOut out) {
     __shared__ EnvLds L;
     const int e = blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
@@ -509,10 +559,10 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_reset_kernel(SimParams
             int32_t* env = p.env + (size_t)e * 4;
             env[0] = 0; env[1] = 0; env[2] = cap; env[3] = 1;
         }
-        ego_navi_obs(p, L, lane, s, lane < cap, (out.obs && lane < N) ? out.obs + ((size_t)e * N + lane) * p.O : nullptr);
+        ego_navi_obs<EXT>(p, L, lane, s, lane < cap, (out.obs && lane < N) ? out.obs + ((size_t)e * N + lane) * p.O : nullptr, 0);
     }
     __syncthreads();
-    neighbours_phase(p, L, e, wave, nwaves, lane, out);
+    neighbours_phase<EXT>(p, L, e, wave, nwaves, lane, out);
     __syncthreads();   // the list-order sums read the LDS words that the LiDAR minima reuse
     if (out.obs) obs_phase(p, L, e, tid, nthreads, out.obs);
 }
@@ -520,6 +570,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_reset_kernel(SimParams
 // ------------------------------------------------------------------------------------------------
 // step kernel
 // ------------------------------------------------------------------------------------------------
+template <bool EXT>
 __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams p, const float* __restrict__ act,
                                                                       StepOut out) {
     __shared__ EnvLds L;
@@ -575,8 +626,14 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
                 s.status = ST_EMPTY | ((tm - 1) << 8);
             }
             if (acted) {
-                const float2 a = reinterpret_cast<const float2*>(act)[(size_t)e * N + lane];
-                float a0 = a.x, a1 = a.y;
+                float a0, a1;
+                if (EXT) {
+                    const float* ap = act + ((size_t)e * N + lane) * p.act_dim;
+                    a0 = ap[0]; a1 = ap[1];
+                } else {
+                    const float2 a = reinterpret_cast<const float2*>(act)[(size_t)e * N + lane];
+                    a0 = a.x; a1 = a.y;
+                }
                 if (!(a0 == a0)) a0 = 0.0f;
                 if (!(a1 == a1)) a1 = 0.0f;
                 a0 = clipf(a0, -1.0f, 1.0f);
@@ -782,7 +839,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
 
     COPO_STAMP(3);
     // ---- P3 (all waves): neighbour lists + reward reductions on the post-step (pre-reset) scene ---
-    if (!(p.dbg_skip & 1)) neighbours_phase(p, L, e, wave, nwaves, lane, out);
+    if (!(p.dbg_skip & 1)) neighbours_phase<EXT>(p, L, e, wave, nwaves, lane, out, act, L.m_acted, ending);
     else __syncthreads();
     COPO_STAMP(4);
     // (neighbours_phase ends with a workgroup barrier: the reset below may overwrite the poses it read)
@@ -821,7 +878,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
             env[1] = episode;
             env[2] = next_aid;
         }
-        if (!(p.dbg_skip & 8)) ego_navi_obs(p, L, lane, s, present, (out.obs && lane < N) ? out.obs + ((size_t)e * N + lane) * p.O : nullptr);
+        if (!(p.dbg_skip & 8)) ego_navi_obs<EXT>(p, L, lane, s, present, (out.obs && lane < N) ? out.obs + ((size_t)e * N + lane) * p.O : nullptr, ending ? 0 : t_env + 1);
     }
     __syncthreads();
 
@@ -858,18 +915,23 @@ __global__ void __launch_bounds__(256) neighbours_kernel(const float* __restrict
         if (lane == 0) L.m_present = m;
     }
     __syncthreads();
-    neighbours_phase(p, L, e, wave, nwaves, lane, out);
+    neighbours_phase<false>(p, L, e, wave, nwaves, lane, out);
 }
 
 // ------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------
 static size_t lidar_lds_bytes(const SimParams& p) { return (size_t)(lidar_lds_words(p.N, p.num_lasers) + ray_lds_words(p.num_lasers)) * sizeof(unsigned int); }
+static bool sim_has_ext(const SimParams& p) { return p.col_tl >= 0 || p.col_comm >= 0; }
 static hipError_t sim_lds_attrs() {              // 64 slots x 256 rays + route tables exceed the default 64 KB
     static hipError_t once = [] {
-        hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(sim_reset_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void*>(sim_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        return a != hipSuccess ? a : b;
+        hipError_t r = hipSuccess;
+        for (const void* f : {reinterpret_cast<const void*>(sim_reset_kernel<false>), reinterpret_cast<const void*>(sim_reset_kernel<true>),
+                              reinterpret_cast<const void*>(sim_step_kernel<false>), reinterpret_cast<const void*>(sim_step_kernel<true>)}) {
+            const hipError_t a = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            if (a != hipSuccess) r = a;
+        }
+        return r;
     }();
     return once;
 }
@@ -880,13 +942,15 @@ static size_t route_lds_bytes(const SimParams& p) {      // LDS copy of the rout
 
 hipError_t launch_sim_reset(const SimParams& p, const StepOut& out, int block, hipStream_t stream) {
     if (hipError_t a = sim_lds_attrs(); a != hipSuccess) return a;
-    hipLaunchKernelGGL(sim_reset_kernel, dim3(p.E), dim3(block), lidar_lds_bytes(p), stream, p, out);
+    if (sim_has_ext(p)) hipLaunchKernelGGL(sim_reset_kernel<true>, dim3(p.E), dim3(block), lidar_lds_bytes(p), stream, p, out);
+    else hipLaunchKernelGGL(sim_reset_kernel<false>, dim3(p.E), dim3(block), lidar_lds_bytes(p), stream, p, out);
     return hipGetLastError();
 }
 
 hipError_t launch_sim_step(const SimParams& p, const float* act, const StepOut& out, int block, hipStream_t stream) {
     if (hipError_t a = sim_lds_attrs(); a != hipSuccess) return a;
-    hipLaunchKernelGGL(sim_step_kernel, dim3(p.E), dim3(block), lidar_lds_bytes(p) + route_lds_bytes(p), stream, p, act, out);
+    if (sim_has_ext(p)) hipLaunchKernelGGL(sim_step_kernel<true>, dim3(p.E), dim3(block), lidar_lds_bytes(p) + route_lds_bytes(p), stream, p, act, out);
+    else hipLaunchKernelGGL(sim_step_kernel<false>, dim3(p.E), dim3(block), lidar_lds_bytes(p) + route_lds_bytes(p), stream, p, act, out);
     return hipGetLastError();
 }
 

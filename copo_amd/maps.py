@@ -169,6 +169,49 @@ def tollgate(length=140.0, lanes=3, lane_width=LANE_WIDTH, spawns_per_lane=7, sp
     return b.finish()
 
 
+def _lane_change(shift, radius):
+    """Two opposite arcs that move a lane centreline `shift` metres to the left (negative: to the right)."""
+    if abs(shift) < 1e-9:
+        return []
+    phi = math.acos(1.0 - abs(shift) / (2.0 * radius))
+    k = math.copysign(1.0 / radius, shift)
+    return [(radius * phi, k), (radius * phi, -k)]
+
+
+def bottleneck(approach=60.0, neck=30.0, lanes_wide=4, lanes_narrow=2, lane_width=LANE_WIDTH, taper_radius=40.0,
+               spawns_per_lane=5, spawn_gap=9.0):
+    """Two-direction road that narrows from `lanes_wide` to `lanes_narrow` lanes per direction and widens again
+    (MetaDrive's MultiAgentBottleneckEnv, 20 agents: eval/evaluate_population.py:118-124).  Entry lane i merges into neck
+    lane i * narrow // wide and leaves on one of the exit lanes that neck lane feeds; the corridor of a route is the
+    neck's (the narrowest part)."""
+    b = _Builder("bottleneck", 20, approach + neck + 40.0)
+    w = lane_width
+    per = lanes_wide // lanes_narrow
+    assert per * lanes_narrow == lanes_wide, "lanes_wide must be a multiple of lanes_narrow"
+    offs = [2.0 + spawn_gap * k for k in range(spawns_per_lane)]
+
+    def run(shift):     # longitudinal length of a lane change
+        return 2.0 * taper_radius * math.sin(math.acos(1.0 - abs(shift) / (2.0 * taper_radius)))
+
+    # the widest lateral move fixes the taper zone: every route pads its straights so that all necks span the same x
+    taper = max(run(w * (0.5 + lane) - w * (0.5 + lane // per)) for lane in range(lanes_wide))
+    x0 = -(approach + taper + neck * 0.5)
+    for direction in range(2):
+        q = direction * math.pi
+        for lane in range(lanes_wide):
+            a_in = w * (0.5 + lane)
+            j = lane // per
+            a_neck = w * (0.5 + j)
+            routes = []
+            for k in range(j * per, (j + 1) * per):
+                a_out = w * (0.5 + k)
+                routes.append([(approach + taper - run(a_in - a_neck), 0.0)] + _lane_change(a_in - a_neck, taper_radius) +
+                              [(neck, 0.0)] + _lane_change(a_neck - a_out, taper_radius) +
+                              [(approach + taper - run(a_neck - a_out), 0.0)])
+            b.add_entry(_rot(x0, -a_in, 0.0, q), routes, a_neck, w * lanes_narrow - a_neck, offs)
+    return b.finish()
+
+
 def parkinglot(spaces=8, aisle_half=40.0, lane_width=LANE_WIDTH, turn_radius=5.0, depth=6.0):
     """Aisle along x with `spaces` perpendicular parking spaces; agents leave spaces or drive into them."""
     b = _Builder("parkinglot", 10, aisle_half + 10.0)
@@ -206,7 +249,19 @@ def parkinglot(spaces=8, aisle_half=40.0, lane_width=LANE_WIDTH, turn_radius=5.0
     return b.finish()
 
 
-MAP_BUILDERS = dict(intersection=intersection, roundabout=roundabout, tollgate=tollgate, parkinglot=parkinglot)
+MAP_BUILDERS = dict(intersection=intersection, roundabout=roundabout, tollgate=tollgate, parkinglot=parkinglot,
+                    bottleneck=bottleneck)
+
+
+def bounding_box(tables: MapTables, step=2.0):
+    """(x_min, x_max, y_min, y_max) of the road network: route centrelines widened by their corridor.  Stands in for
+    MetaDrive's `road_network.get_bounding_box()` (env_wrappers.py:268), used by the traffic-light columns."""
+    lo, hi = np.array([np.inf, np.inf]), np.array([-np.inf, -np.inf])
+    for r in range(tables.n_routes):
+        pts = route_points(tables, r, step)
+        pad = float(max(tables.route_meta[r, 1], tables.route_meta[r, 2]))
+        lo, hi = np.minimum(lo, pts.min(0) - pad), np.maximum(hi, pts.max(0) + pad)
+    return float(lo[0]), float(hi[0]), float(lo[1]), float(hi[1])
 
 
 def ray_table(num_lasers):

@@ -52,6 +52,12 @@ class SimConfig:
     lcf_mean: float = 0.0
     lcf_std: float = 0.1               # env_wrappers.py:176
     start_seed: int = 5000
+    # observation / action extensions of CCEnv / LCFEnv (env_wrappers.py:44-46); off by default like the reference
+    add_traffic_light: bool = False
+    traffic_light_interval: int = 30
+    comm_size: int = 0                 # > 0 = communication on (comm_method != "none"): actions carry 2 + comm_size floats
+    comm_neighbours: int = 4
+    add_pos_in_comm: bool = False
 
     def tables(self):
         return _maps.MAP_BUILDERS[self.map](**self.map_kwargs)
@@ -62,8 +68,18 @@ class SimConfig:
         return t, int(n)
 
     @property
+    def comm_dim(self):
+        return (self.comm_size + (3 if self.add_pos_in_comm else 0)) if self.comm_size > 0 else 0
+
+    @property
     def obs_dim(self):
-        return EGO_DIM + NAVI_DIM + self.num_lasers + (1 if self.enable_lcf else 0)
+        """[9 ego | 10 navigation | lasers | 3 traffic light | 1 lcf | comm_neighbours x comm_dim] (COPO_OBS_DIM)."""
+        return (EGO_DIM + NAVI_DIM + self.num_lasers + (3 if self.add_traffic_light else 0) + (1 if self.enable_lcf else 0)
+                + (self.comm_neighbours * self.comm_dim if self.comm_size > 0 else 0))
+
+    @property
+    def act_dim(self):
+        return 2 + max(0, self.comm_size)
 
 
 def fill_cfg_struct(cfg: SimConfig, struct_cls):
@@ -80,6 +96,11 @@ def fill_cfg_struct(cfg: SimConfig, struct_cls):
               "speed_reward", "success_reward", "crash_penalty", "out_penalty", "arrive_margin", "lane_width"):
         setattr(c, k, float(getattr(cfg, k)))
     c.lcf_mean, c.lcf_std = float(cfg.lcf_mean), float(cfg.lcf_std)
+    c.add_traffic_light, c.traffic_light_interval = int(bool(cfg.add_traffic_light)), int(cfg.traffic_light_interval)
+    c.comm_size, c.comm_neighbours = max(0, int(cfg.comm_size)), int(cfg.comm_neighbours)
+    c.add_pos_in_comm = int(bool(cfg.add_pos_in_comm))
+    for k, v in enumerate(_maps.bounding_box(t)):
+        c.map_bbox[k] = float(v)
     keep = dict(
         route_segs=np.ascontiguousarray(t.route_segs, np.float32), route_meta=np.ascontiguousarray(t.route_meta, np.float32),
         spawn_tab=np.ascontiguousarray(t.spawn_tab, np.int32), spawn_s=np.ascontiguousarray(t.spawn_s, np.float32),
@@ -103,6 +124,7 @@ class VecSim:
         self.cfg = cfg
         self.tables, self.N = cfg.resolved()
         self.E, self.O, self.K = cfg.num_envs, cfg.obs_dim, min(cfg.nbr_k, 64)
+        self.A = cfg.act_dim
         self.device = torch.device("cuda", device)
         struct, self._keep = fill_cfg_struct(cfg, _capi.SimCfg)
         h = C.c_void_p()
@@ -142,8 +164,8 @@ class VecSim:
         return self.out if out is None else out
 
     def step(self, act, out=None):
-        """act: [E, N, 2] fp32 cuda tensor.  Returns the dict of output tensors (overwritten every step)."""
-        assert act.is_cuda and act.dtype == self._torch.float32 and act.is_contiguous() and act.numel() == self.E * self.N * 2
+        """act: [E, N, 2 (+ comm_size)] fp32 cuda tensor.  Returns the dict of output tensors (overwritten every step)."""
+        assert act.is_cuda and act.dtype == self._torch.float32 and act.is_contiguous() and act.numel() == self.E * self.N * self.A
         so = self._step_out if out is None else self.make_step_out(out)
         self._capi.check(self._capi.lib.copo_sim_step(self._h, act.data_ptr(), C.byref(so), self._stream()))
         return self.out if out is None else out

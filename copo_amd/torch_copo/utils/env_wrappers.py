@@ -57,6 +57,7 @@ class MultiAgentMetaDrive:
         self.config = cfg
         sim_kwargs = {k: v for k, v in cfg.items() if k in SIM_KEYS and k not in ("enable_lcf",)}
         sim_kwargs["enable_lcf"] = bool(self.ENABLE_LCF and cfg.get("enable_copo", True))
+        sim_kwargs.update(type(self)._extension_kwargs(cfg))
         if "lcf_normal_std" in cfg:
             sim_kwargs["lcf_std"] = float(cfg["lcf_normal_std"])
         self.sim_config = SimConfig(**sim_kwargs)
@@ -73,13 +74,30 @@ class MultiAgentMetaDrive:
 
     # ---- spaces --------------------------------------------------------------------------------------------
     @classmethod
+    def _extension_kwargs(cls, cfg):
+        """SimConfig fields of the communication channel / traffic-light message (CCEnv config keys, env_wrappers.py:
+        44-46).  The observation is only extended by LCFEnv.step in the reference (:331-337, 362-371)."""
+        comm = dict(cfg.get("communication") or {})
+        on = comm.get("comm_method", "none") != "none"
+        tl = bool(cfg.get("add_traffic_light", False))
+        if (on or tl) and not cls.ENABLE_LCF:
+            raise NotImplementedError("communication / traffic-light observations are appended by LCFEnv.step: use get_lcf_env")
+        return dict(add_traffic_light=tl, traffic_light_interval=int(cfg.get("traffic_light_interval", 30)),
+                    comm_size=int(comm.get("comm_size", 4)) if on else 0, comm_neighbours=int(comm.get("comm_neighbours", 4)),
+                    add_pos_in_comm=bool(comm.get("add_pos_in_comm", False)))
+
+    @classmethod
     def spaces_for(cls, env_config):
         cfg = cls.default_config()
         cfg.update(env_config or {})
         lcf = bool(cls.ENABLE_LCF and cfg.get("enable_copo", True))
+        ext = cls._extension_kwargs(cfg)
+        cdim = ext["comm_size"] + (3 if ext["add_pos_in_comm"] else 0)
         odim = 9 + 10 + int(cfg.get("num_lasers", 72)) + (1 if lcf else 0)
+        if lcf:    # LCFObs.observation_space (env_wrappers.py:225-247): the extra columns are declared with enable_copo only
+            odim += (3 if ext["add_traffic_light"] else 0) + (ext["comm_neighbours"] * cdim if ext["comm_size"] else 0)
         # LCFEnv widens the space to [-1, 1] (env_wrappers.py:241-244); MetaDrive's own obs are in [0, 1]
-        return Box(-1.0 if lcf else 0.0, 1.0, (odim,)), Box(-1.0, 1.0, (2,))
+        return Box(-1.0 if lcf else 0.0, 1.0, (odim,)), Box(-1.0, 1.0, (2 + ext["comm_size"],))
 
     @property
     def observation_space(self):
@@ -139,10 +157,10 @@ class MultiAgentMetaDrive:
         import torch
         assert self.num_envs == 1 and self._slot_ids is not None, "call reset() first"
         N, F = self.num_agents, _capi
-        act = np.zeros((1, N, 2), np.float32)
+        act = np.zeros((1, N, self.sim.A), np.float32)
         for s, a in enumerate(self._slot_ids):
             if a is not None:
-                act[0, s] = np.asarray(actions[a], np.float32)[:2]
+                act[0, s] = np.asarray(actions[a], np.float32)[:self.sim.A]
         out = self.sim.step(torch.from_numpy(act).to(self.sim.device))
         h = {k: v[0].cpu().numpy() for k, v in out.items() if v is not None}
         flags = h["flags"]
@@ -179,6 +197,13 @@ class MultiAgentMetaDrive:
                             coordinated_rewards=coord, native_rewards=r[a])
                 if not self.config.get("return_native_reward", True):
                     r[a] = coord
+                sc = self.sim_config
+                if sc.comm_size > 0:     # CCEnv.step :102-118 (+ the zero padding of LCFEnv.step :363-369) / :373-384
+                    cd, c0 = sc.comm_dim, sc.obs_dim - sc.comm_neighbours * sc.comm_dim
+                    info["comm_current_obs"] = [h["obs"][s][c0 + q * cd:c0 + (q + 1) * cd].copy() for q in range(sc.comm_neighbours)]
+                    last = getattr(self, "_last_obs", None) or {}
+                    nb = info["neighbours"][:sc.comm_neighbours]
+                    info["nei_obs"] = [last.get(n) for n in nb] + [None] * (sc.comm_neighbours - len(nb)) + [None]
             i[a] = info
             if d[a]:
                 self._just_terminated[a] = s
@@ -186,6 +211,7 @@ class MultiAgentMetaDrive:
             for a, s in spawned.items():     # respawned agents: first obs, zero reward, empty info (MetaDrive)
                 o[a], r[a], d[a], i[a] = h["obs"][s], 0.0, False, {}
         d["__all__"] = env_reset
+        self._last_obs = dict(o)
         after = [None] * N
         for s in range(N):
             if flags[s] & F.F_SPAWNED:
@@ -217,6 +243,10 @@ class MultiAgentParkingLotEnv(MultiAgentMetaDrive):
     MAP = "parkinglot"
 
 
+class MultiAgentBottleneckEnv(MultiAgentMetaDrive):
+    MAP = "bottleneck"
+
+
 class CCEnv:
     """Mixin: neighbour lists in `info` (`neighbours`, `neighbours_distance`, `all_agents`), radius
     `neighbours_distance` (strict <), sorted by distance with ties in slot order (env_wrappers.py:89-158)."""
@@ -232,8 +262,6 @@ class CCEnv:
 
     def __init__(self, *args, **kwargs):
         super(CCEnv, self).__init__(*args, **kwargs)
-        assert self.config["communication"]["comm_method"] == "none", "communication channel is not built"
-        assert not self.config["add_traffic_light"], "traffic-light message is not built"
 
 
 class LCFEnv(CCEnv):
@@ -292,6 +320,77 @@ def get_change_n_env(env_class):
 
     ChangeNEnv.__name__ = ChangeNEnv.__qualname__ = "CL{}".format(env_class.__name__)
     return ChangeNEnv
+
+
+def get_latent_env(env_class):
+    """`enable_latent` / `latent_dim`: a per-(seed, agent) latent vector registered by the caller is PREPENDED to every
+    observation, zeros while nothing is registered (env_wrappers.py:474-556).  Dict API: `register_latent({seed:
+    {agent_name: vector}})`; vector API: `register_latent_tensor([E, N, latent_dim])`, concatenated on the device."""
+    class LatentEnv(env_class):
+        @classmethod
+        def default_config(cls):
+            config = super(LatentEnv, cls).default_config()
+            config.update(dict(enable_latent=False, latent_dim=-1))
+            return config
+
+        def __init__(self, config=None):
+            super(LatentEnv, self).__init__(config)
+            self.latent_dict = None
+            self._latent_tensor = None
+            self._global_seed = None
+
+        @classmethod
+        def spaces_for(cls, env_config):
+            o, a = super(LatentEnv, cls).spaces_for(env_config)
+            cfg = cls.default_config()
+            cfg.update(env_config or {})
+            if not cfg["enable_latent"]:
+                return o, a
+            return Box(float("-inf"), float("+inf"), (o.shape[0] + int(cfg["latent_dim"]),)), a
+
+        def register_latent(self, latent_dict):
+            self.latent_dict = latent_dict
+
+        def register_latent_tensor(self, latent):
+            assert tuple(latent.shape) == (self.num_envs, self.num_agents, int(self.config["latent_dim"]))
+            self._latent_tensor = latent
+
+        def _add_latent(self, obs, agent_name):
+            if not self.config["enable_latent"]:
+                return obs
+            if self.latent_dict is None:
+                latent = np.zeros(self.config["latent_dim"])
+            else:
+                latent = self.latent_dict[self._global_seed][agent_name]
+            return np.concatenate([latent, obs], axis=-1)
+
+        def reset(self, force_seed=None):
+            self._global_seed = self.config.get("start_seed", 5000) if force_seed is None else force_seed
+            return {k: self._add_latent(o, k) for k, o in super(LatentEnv, self).reset(force_seed).items()}
+
+        def step(self, action):
+            o, r, d, i = super(LatentEnv, self).step(action)
+            return {k: self._add_latent(v, k) for k, v in o.items()}, r, d, i
+
+        def _vec_latent(self, out):
+            if not self.config["enable_latent"]:
+                return out
+            import torch
+            obs = out["obs"]
+            lat = self._latent_tensor if self._latent_tensor is not None else \
+                torch.zeros(self.num_envs, self.num_agents, int(self.config["latent_dim"]), device=obs.device)
+            out = dict(out)
+            out["obs"] = torch.cat([lat.to(obs.dtype), obs], -1)
+            return out
+
+        def vec_reset(self, seeds=None):
+            return self._vec_latent(super(LatentEnv, self).vec_reset(seeds))
+
+        def vec_step(self, actions):
+            return self._vec_latent(super(LatentEnv, self).vec_step(actions))
+
+    LatentEnv.__name__ = LatentEnv.__qualname__ = env_class.__name__
+    return LatentEnv
 
 
 def get_rllib_compatible_env(env_class, return_class=False):

@@ -75,7 +75,7 @@ typedef struct copo_sim_cfg {
     int32_t num_envs;          /* E */
     int32_t num_agents;        /* N slots per env, <= COPO_MAX_AGENTS */
     int32_t num_lasers;        /* LiDAR beams (72; 240 for config C5) */
-    int32_t obs_dim;           /* O = 9 + 10 + num_lasers (+1 when enable_lcf) */
+    int32_t obs_dim;           /* O = 9 + 10 + num_lasers (+1 when enable_lcf) (+ extensions below): COPO_OBS_DIM() */
     int32_t nbr_k;             /* neighbour ids stored per slot (<= N-1) */
     int32_t enable_lcf;        /* 1: LCFEnv (append (lcf+1)/2 to obs, sample LCF at spawn); 0: CCEnv only */
     int32_t horizon;           /* env steps per episode (MetaDrive `horizon`, 1000) */
@@ -107,7 +107,24 @@ typedef struct copo_sim_cfg {
     const int32_t* spawn_tab;  /* [n_spawns][4] = {first_route, n_route_choices, 0, 0} */
     const float* spawn_s;      /* [n_spawns] longitudinal offset of the spawn pose on its routes */
     const float* ray_cs;       /* [num_lasers][2] = {cos, sin}(2*pi*k/num_lasers) */
+    /* optional observation / action extensions of CCEnv / LCFEnv (env_wrappers.py:44-46, 89-118, 258-272, 331-337,
+     * 362-371); all zero = off.  Observation row: [9 ego | 10 navigation | lasers | 3 traffic light | 1 lcf |
+     * comm_neighbours x (comm_size + 3 if add_pos_in_comm)], see COPO_OBS_DIM(). */
+    int32_t add_traffic_light;      /* append clip([message(t), x', y'], 0, 1): env_wrappers.py:258-272 */
+    int32_t traffic_light_interval; /* steps per phase (30) */
+    int32_t comm_size;              /* > 0: communication on -- actions are [2 + comm_size] floats per slot */
+    int32_t comm_neighbours;        /* nearest neighbours whose message is appended (4) */
+    int32_t add_pos_in_comm;        /* 1: each message is followed by [d/20, (lon/d+1)/2, (lat/d+1)/2] clipped to [0,1] */
+    float map_bbox[4];              /* {x_min, x_max, y_min, y_max} of the road network (traffic-light position columns) */
 } copo_sim_cfg;
+
+/* Observation length of a configuration (the value obs_dim must hold):
+ * 9 + 10 + lasers + (3 if add_traffic_light) + (1 if enable_lcf) + comm_neighbours * (comm_size + 3 * add_pos_in_comm). */
+#define COPO_OBS_DIM(c)                                                                                      \
+    (COPO_EGO_DIM + COPO_NAVI_DIM + (c)->num_lasers + ((c)->add_traffic_light ? 3 : 0) + ((c)->enable_lcf ? 1 : 0) + \
+     ((c)->comm_size > 0 ? (c)->comm_neighbours * ((c)->comm_size + ((c)->add_pos_in_comm ? 3 : 0)) : 0))
+/* floats per slot of the action array: steering, throttle, then the message */
+#define COPO_ACT_DIM(c) (2 + ((c)->comm_size > 0 ? (c)->comm_size : 0))
 
 typedef struct copo_sim copo_sim;
 

@@ -155,7 +155,9 @@ int oracle_sim_create(const copo_sim_cfg* cfg, oracle_sim** out) {
     if (!cfg || !out) return COPO_ERR_NULL;
     if (cfg->num_agents < 1 || cfg->num_agents > COPO_MAX_AGENTS || cfg->num_envs < 1) return COPO_ERR_DIM;
     if (cfg->num_lasers < 1 || cfg->num_lasers > COPO_MAX_LASERS) return COPO_ERR_DIM;
-    if (cfg->obs_dim != COPO_EGO_DIM + COPO_NAVI_DIM + cfg->num_lasers + (cfg->enable_lcf ? 1 : 0)) return COPO_ERR_DIM;
+    if (cfg->obs_dim != COPO_OBS_DIM(cfg)) return COPO_ERR_DIM;
+    if (cfg->comm_size < 0 || (cfg->comm_size > 0 && (cfg->comm_neighbours < 1 || cfg->comm_neighbours > COPO_MAX_AGENTS))) return COPO_ERR_CONFIG;
+    if (cfg->add_traffic_light && (cfg->traffic_light_interval < 1 || !(cfg->map_bbox[1] > cfg->map_bbox[0]) || !(cfg->map_bbox[3] > cfg->map_bbox[2]))) return COPO_ERR_CONFIG;
     if (cfg->n_spawns < cfg->num_agents || cfg->n_spawns > COPO_MAX_SPAWNS || cfg->nbr_k < 1 || cfg->nbr_k > COPO_MAX_AGENTS) return COPO_ERR_CONFIG;
     oracle_sim* s = (oracle_sim*)calloc(1, sizeof(oracle_sim));
     s->cfg = *cfg;
@@ -301,6 +303,10 @@ typedef struct step_tmp {
     float rew[COPO_MAX_AGENTS], acc[COPO_MAX_AGENTS], lcf_row[COPO_MAX_AGENTS];
     int32_t aid_row[COPO_MAX_AGENTS];
     float cs[COPO_MAX_AGENTS], sn[COPO_MAX_AGENTS];
+    /* communication (env_wrappers.py:102-118): full sorted neighbour lists of this step; fresh = reset observation */
+    int nb_ids[COPO_MAX_AGENTS][COPO_MAX_AGENTS];
+    int nb_cnt[COPO_MAX_AGENTS];
+    int fresh;
 } step_tmp;
 
 /* SAT overlap of two identical-size OBBs */
@@ -316,7 +322,43 @@ static int obb_overlap(float xi, float yi, float ci, float si, float xj, float y
     return 1;
 }
 
-static void write_obs(oracle_sim* s, int e, const copo_step_out* out, const uint8_t* present) {
+/* LCFEnv._traffic_light_msg + get_agent_traffic_light_msg (env_wrappers.py:258-272), python float64 arithmetic */
+static void traffic_light_cols(const copo_sim_cfg* c, int counter, float x, float y, float* o) {
+    int I = c->traffic_light_interval;
+    double inc = (double)(counter % I) / (double)I * 0.1;
+    double msg = (((counter / I) % 2) == 1) ? 0.0 + inc : 1.0 - inc;
+    double b0 = (double)c->map_bbox[0], b1 = (double)c->map_bbox[1], b2 = (double)c->map_bbox[2], b3 = (double)c->map_bbox[3];
+    double v[3] = {msg, ((double)x - b0) / (b1 - b0), ((double)y - b2) / (b3 - b2)};
+    for (int k = 0; k < 3; ++k) o[k] = (float)(v[k] < 0.0 ? 0.0 : (v[k] > 1.0 ? 1.0 : v[k]));
+}
+
+static float nan_canon(void) { union { uint32_t u; float f; } v; v.u = 0x7fc00000u; return v.f; }
+#define NAN_CANON nan_canon()   /* one bit pattern for NaN on every platform (np.clip lets NaN through) */
+/* Message columns of agent i (CCEnv.step :102-118 + LCFEnv.step :362-371): the comm actions of its first
+ * `comm_nb` neighbours (ids[0..cnt), nearest first); zeros for a neighbour that was given no action this step, for a
+ * missing neighbour and -- `fresh` -- in a reset observation (:297-303).  act rows are [2 + CS] floats per slot. */
+static void comm_cols(int CS, int comm_nb, int add_pos, int fresh, const int* ids, int cnt, const uint8_t* acted,
+                      const float* act, const float* px, const float* py, int i, float csi, float sni, float* q0) {
+    int CD = CS + (add_pos ? 3 : 0), AD = 2 + CS;
+    for (int r = 0; r < comm_nb; ++r) {
+        float* q = q0 + r * CD;
+        for (int k = 0; k < CD; ++k) q[k] = 0.0f;
+        if (fresh || r >= cnt) continue;
+        int nn = ids[r];
+        if (!acted[nn]) continue;    /* `n in comm_actions`: only agents that were given an action */
+        for (int k = 0; k < CS; ++k) q[k] = act[(size_t)nn * AD + 2 + k];
+        if (add_pos) {               /* neighbour relative to ego in the ego frame; numpy float64 arithmetic */
+            double dx = (double)px[nn] - (double)px[i], dy = (double)py[nn] - (double)py[i];
+            double lon = dx * (double)csi + dy * (double)sni, lat2 = dy * (double)csi - dx * (double)sni;
+            double dis = sqrt(lon * lon + lat2 * lat2);
+            double ex[3] = {dis / 20.0, (lon / dis + 1.0) / 2.0, (lat2 / dis + 1.0) / 2.0};   /* 0/0 = NaN for d == 0, as numpy */
+            for (int k = 0; k < 3; ++k) q[CS + k] = ex[k] != ex[k] ? NAN_CANON : (float)(ex[k] < 0.0 ? 0.0 : (ex[k] > 1.0 ? 1.0 : ex[k]));
+        }
+    }
+}
+
+static void write_obs(oracle_sim* s, int e, const copo_step_out* out, const uint8_t* present, const step_tmp* t,
+                      const float* act) {
     const copo_sim_cfg* c = &s->cfg;
     int N = c->num_agents, O = c->obs_dim, L = c->num_lasers;
     float hl = c->veh_half_len, hw = c->veh_half_wid;
@@ -401,14 +443,22 @@ static void write_obs(oracle_sim* s, int e, const copo_step_out* out, const uint
             }
             lid[k] = best / range;
         }
-        if (c->enable_lcf) o[O - 1] = (FP(s, S_LCF, e)[i] + 1.0f) * 0.5f;
+        int col = COPO_EGO_DIM + COPO_NAVI_DIM + L;
+        if (c->add_traffic_light) {     /* counter = steps since the last reset (env word 0 is already advanced) */
+            traffic_light_cols(c, s->env[e * 4], x, y, o + col);
+            col += 3;
+        }
+        if (c->enable_lcf) o[col++] = (FP(s, S_LCF, e)[i] + 1.0f) * 0.5f;
+        if (c->comm_size > 0)
+            comm_cols(c->comm_size, c->comm_neighbours, c->add_pos_in_comm, t->fresh, t->nb_ids[i], t->nb_cnt[i], t->acted,
+                      act ? act + (size_t)e * N * (2 + c->comm_size) : NULL, FP(s, S_X, e), FP(s, S_Y, e), i, cs[i], sn[i], o + col);
     }
 }
 
 /* neighbour lists + reward reductions for one env on an explicit present set (fp64 distances) */
 static void neighbours_env(const float* px, const float* py, const uint8_t* present, const float* rew, int N, int K,
                            float radius, float mf, int32_t* nbr_idx, int32_t* nbr_cnt, int32_t* mf_cnt, float* nbr_dist,
-                           float* nei_rew, float* glob_rew) {
+                           float* nei_rew, float* glob_rew, int (*full_ids)[COPO_MAX_AGENTS], int* full_cnt) {
     double gsum = 0.0;
     int gcnt = 0;
     for (int i = 0; i < N; ++i)
@@ -432,6 +482,10 @@ static void neighbours_env(const float* px, const float* py, const uint8_t* pres
             }
         }
         if (nbr_cnt) nbr_cnt[i] = cnt;
+        if (full_cnt) {
+            full_cnt[i] = cnt;
+            for (int k = 0; k < cnt; ++k) full_ids[i][k] = ids[k];
+        }
         int m = 0;
         for (int k = 0; k < cnt; ++k)
             if (ds[k] <= (double)mf) m++; else break;
@@ -458,7 +512,34 @@ int oracle_neighbours(const float* pos, const uint8_t* present, const float* rew
         neighbours_env(px, py, present + (size_t)e * N, rew ? rew + (size_t)e * N : NULL, N, K, radius, mf_distance,
                        nbr_idx ? nbr_idx + (size_t)e * N * K : NULL, nbr_cnt ? nbr_cnt + (size_t)e * N : NULL,
                        mf_cnt ? mf_cnt + (size_t)e * N : NULL, nbr_dist ? nbr_dist + (size_t)e * N * K : NULL,
-                       (rew && nei_rew) ? nei_rew + (size_t)e * N : NULL, (rew && glob_rew) ? glob_rew + e : NULL);
+                       (rew && nei_rew) ? nei_rew + (size_t)e * N : NULL, (rew && glob_rew) ? glob_rew + e : NULL, NULL, NULL);
+    }
+    return COPO_OK;
+}
+
+/* Stateless form of the observation extensions of one scene (what write_obs appends), for the golden vectors
+ * captured from the reference's LCFEnv: neighbour lists on `pos` over the present set, then the columns. */
+int oracle_obs_extensions(const float* pos, const float* cs_sn, const uint8_t* present, const uint8_t* acted,
+                          const float* act, int32_t N, float radius, int32_t counter, int32_t interval, const float* bbox,
+                          int32_t add_tl, int32_t comm_size, int32_t comm_nb, int32_t add_pos, int32_t fresh, float* tl_out,
+                          float* comm_out) {
+    if (N > COPO_MAX_AGENTS) return COPO_ERR_DIM;
+    float px[COPO_MAX_AGENTS] = {0}, py[COPO_MAX_AGENTS] = {0};
+    static int ids[COPO_MAX_AGENTS][COPO_MAX_AGENTS];
+    int cnt[COPO_MAX_AGENTS];
+    for (int i = 0; i < N; ++i) { px[i] = pos[2 * i]; py[i] = pos[2 * i + 1]; }
+    neighbours_env(px, py, present, NULL, N, 1, radius, 10.0f, NULL, NULL, NULL, NULL, NULL, NULL, ids, cnt);
+    copo_sim_cfg c;
+    memset(&c, 0, sizeof(c));
+    c.traffic_light_interval = interval;
+    for (int k = 0; k < 4; ++k) c.map_bbox[k] = bbox[k];
+    int CD = comm_size + (add_pos ? 3 : 0);
+    for (int i = 0; i < N; ++i) {
+        if (!present[i]) continue;
+        if (add_tl) traffic_light_cols(&c, counter, px[i], py[i], tl_out + 3 * i);
+        if (comm_size > 0)
+            comm_cols(comm_size, comm_nb, add_pos, fresh, ids[i], cnt[i], acted, act, px, py, i, cs_sn[2 * i], cs_sn[2 * i + 1],
+                      comm_out + (size_t)i * comm_nb * CD);
     }
     return COPO_OK;
 }
@@ -471,7 +552,7 @@ static void emit_outputs(oracle_sim* s, int e, const copo_step_out* out, step_tm
     neighbours_env(FP(s, S_X, e), FP(s, S_Y, e), present, t->rew, N, K, c->neighbours_distance, c->mf_distance,
                    out->nbr_idx ? out->nbr_idx + b * K : NULL, out->nbr_cnt ? out->nbr_cnt + b : NULL,
                    out->mf_cnt ? out->mf_cnt + b : NULL, out->nbr_dist ? out->nbr_dist + b * K : NULL,
-                   out->nei_rew ? out->nei_rew + b : NULL, out->glob_rew ? out->glob_rew + e : NULL);
+                   out->nei_rew ? out->nei_rew + b : NULL, out->glob_rew ? out->glob_rew + e : NULL, t->nb_ids, t->nb_cnt);
     for (int n = 0; n < N; ++n) {
         if (out->rew) out->rew[b + n] = t->rew[n];
         if (out->flags) out->flags[b + n] = t->fl[n];
@@ -501,7 +582,8 @@ int oracle_sim_reset(oracle_sim* s, const uint64_t* seeds, const copo_step_out* 
         }
         emit_outputs(s, e, out, &t, present);
         if (out->info) memset(out->info + (size_t)e * N * COPO_INFO_DIM, 0, sizeof(float) * N * COPO_INFO_DIM);
-        if (out->obs) write_obs(s, e, out, present);
+        t.fresh = 1;
+        if (out->obs) write_obs(s, e, out, present, &t, NULL);
     }
     return COPO_OK;
 }
@@ -534,7 +616,8 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
             t.lcf_row[n] = FP(s, S_LCF, e)[n];
             t.aid_row[n] = t.acted[n] ? IP(s, S_AID, e)[n] : -1;
             if (!t.acted[n]) continue;
-            float a0 = act[((size_t)e * N + n) * 2], a1 = act[((size_t)e * N + n) * 2 + 1];
+            const int AD = COPO_ACT_DIM(c);
+            float a0 = act[((size_t)e * N + n) * AD], a1 = act[((size_t)e * N + n) * AD + 1];
             if (!(a0 == a0)) a0 = 0.0f;
             if (!(a1 == a1)) a1 = 0.0f;
             a0 = o_clip(a0, -1.0f, 1.0f);
@@ -692,8 +775,9 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
                 if (out->flags) out->flags[(size_t)e * N + n] |= (present[n] ? COPO_F_SPAWNED : 0) | COPO_F_ENV_RESET;
                 if (out->lcf && !t.acted[n] && present[n]) out->lcf[(size_t)e * N + n] = FP(s, S_LCF, e)[n];
             }
+            t.fresh = 1;
         }
-        if (out->obs) write_obs(s, e, out, present);
+        if (out->obs) write_obs(s, e, out, present, &t, act);
     }
     return COPO_OK;
 }

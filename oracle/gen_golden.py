@@ -18,6 +18,7 @@ Reference entry points driven here (all under /root/reference/copo_code/copo/tor
   algo_copo.py:228-309           CoPOPolicy.meta_update
   algo_copo.py:516-661           CoPOTrainer.training_step
   algo_copo.py:96-182, algo_ccppo.py:55-219   model construction / parameter counts
+  utils/env_wrappers.py:89-118, 258-303, 315-337, 360-371   traffic-light message + communication channel (f-4)
 
 Vectors that flow through the 3P restatements in ref_stubs.py (TorchDiagGaussian, compute_advantages,
 discount_cumsum, standardized) pin the reference code GIVEN those restatements.
@@ -739,6 +740,106 @@ def gen_callbacks():
     print("callbacks.npz", {k: float(v) for k, v in ep.custom_metrics.items() if "rate" in k})
 
 
+# --------------------------------------------------------------------------------------
+# f-4: traffic-light message + communication channel of CCEnv / LCFEnv (env_wrappers.py:89-118, 258-303, 315-337, 360-371)
+# --------------------------------------------------------------------------------------
+class _VehH:
+    """Vehicle with a heading.  `projection` restates MetaDrive's BaseVehicle.projection (3P, absent): the vector in
+    the vehicle frame (longitudinal, lateral-left)."""
+
+    def __init__(self, p, th):
+        self.position = np.asarray(p, dtype=np.float64)
+        self.c, self.s = float(np.float32(np.cos(th))), float(np.float32(np.sin(th)))   # fp32 (cos, sin) like the build's state
+
+    def projection(self, v):
+        return (v[0] * self.c + v[1] * self.s, v[1] * self.c - v[0] * self.s)
+
+
+class FakeBaseExt(FakeBase):
+    BBOX = (-80.0, 90.0, -70.0, 75.0)
+
+    def __init__(self, config=None):
+        super().__init__(config)
+        box = self.BBOX
+        self.engine = SimpleNamespace(current_map=SimpleNamespace(road_network=SimpleNamespace(get_bounding_box=lambda: box)))
+
+    def _veh(self, d):
+        return {n: (_VehH(p[:2], p[2]) if p is not None else None) for n, p in d.items()}
+
+    def _get_reset_return(self):
+        s = self.script
+        self.vehicles_including_just_terminated = self._veh(s["reset_pos"])
+        return {n: np.array(o, dtype=np.float32) for n, o in s["reset_obs"].items()}
+
+    def step(self, actions):
+        st = self.script["steps"][self.tick]
+        self.tick += 1
+        self.vehicles_including_just_terminated = self._veh(st["pos"])
+        o = {n: np.array(v, dtype=np.float32) for n, v in st["obs"].items()}
+        return o, dict(st["rew"]), dict(st["done"]), {n: {} for n in o}
+
+
+LCF_EXT = W.get_lcf_env(FakeBaseExt)
+
+
+def gen_obs_extensions():
+    """Scripted scenes through the reference's LCFEnv with the traffic light / communication switched on: the extended
+    observations of reset() and of T steps, with agents that are present but were given no action (fresh respawns)."""
+    rng = np.random.RandomState(77)
+    cfgs = [dict(tl=1, cs=0, nb=4, pos=0), dict(tl=0, cs=4, nb=4, pos=0), dict(tl=1, cs=3, nb=2, pos=1),
+            dict(tl=1, cs=4, nb=6, pos=1), dict(tl=0, cs=2, nb=3, pos=1)]
+    save = {"n_cases": len(cfgs), "bbox": np.asarray(FakeBaseExt.BBOX, np.float32), "base_dim": 91}
+    N, T, OB = 12, 9, 91
+    names = ["agent%d" % k for k in range(N)]
+    for c, cf in enumerate(cfgs):
+        interval = 4
+        env = LCF_EXT(dict(neighbours_distance=40, add_traffic_light=bool(cf["tl"]), traffic_light_interval=interval,
+                           communication=dict(comm_method="broadcast" if cf["cs"] else "none", comm_size=cf["cs"] or 4,
+                                              comm_neighbours=cf["nb"], add_pos_in_comm=bool(cf["pos"]))))
+        CS = cf["cs"]
+        CD = CS + (3 if cf["pos"] else 0)
+        pos = f32r(rng.uniform(-45, 45, (T + 1, N, 2)))
+        pos[:, 1] = pos[:, 0] + f32r([[3.0, 0.0]])       # a pair that stays close
+        pos[2, 5] = pos[2, 4]                             # coincident pair at one step (d == 0)
+        th = f32r(rng.uniform(-np.pi, np.pi, (T + 1, N)))
+        present = rng.uniform(size=(T + 1, N)) > 0.2
+        present[:, :3] = True
+        acted = present & (rng.uniform(size=(T + 1, N)) > 0.25)     # present but not acted = fresh respawn
+        acted[0] = False
+        act = f32r(rng.uniform(-1, 1, (T + 1, N, 2 + CS)))
+        base = rng.uniform(0, 1, (T + 1, N, OB)).astype(np.float32)
+        O = OB + (3 if cf["tl"] else 0) + 1 + (cf["nb"] * CD if CS else 0)
+        out = np.zeros((T + 1, N, O), np.float32)
+
+        def pd(t):
+            return {names[k]: ((pos[t, k, 0], pos[t, k, 1], th[t, k]) if present[t, k] else None) for k in range(N)}
+
+        script = dict(reset_pos=pd(0), reset_obs={names[k]: base[0, k] for k in range(N) if present[0, k]}, steps=[
+            dict(pos=pd(t), obs={names[k]: base[t, k] for k in range(N) if present[t, k]},
+                 rew={names[k]: 0.0 for k in range(N) if present[t, k]},
+                 done={names[k]: False for k in range(N) if present[t, k]}) for t in range(1, T + 1)])
+        env.load(script)
+        ref_stubs.reseed_env_rng(c)
+        o = env._get_reset_return()
+        for k in range(N):
+            if present[0, k]:
+                assert o[names[k]].dtype == np.float32 and len(o[names[k]]) == O, (len(o[names[k]]), O)
+                out[0, k] = o[names[k]]
+        for t in range(1, T + 1):
+            actions = {names[k]: act[t, k].astype(np.float32) for k in range(N) if acted[t, k]}
+            o, r, d, i = env.step(actions)
+            for k in range(N):
+                if present[t, k]:
+                    assert o[names[k]].dtype == np.float32 and len(o[names[k]]) == O
+                    out[t, k] = o[names[k]]
+        for k, v in dict(tl=cf["tl"], cs=CS, nb=cf["nb"], pos=cf["pos"], interval=interval, positions=pos.astype(np.float32),
+                         heading_cs=np.stack([np.cos(th).astype(np.float32), np.sin(th).astype(np.float32)], -1),
+                         present=present, acted=acted, act=act.astype(np.float32), ext=out[..., OB:]).items():
+            save["c%d_%s" % (c, k)] = np.asarray(v)
+    np.savez_compressed(os.path.join(OUT, "obs_extensions.npz"), **save)
+    print("obs_extensions.npz: %d cases, %d bytes" % (len(cfgs), os.path.getsize(os.path.join(OUT, "obs_extensions.npz"))))
+
+
 if __name__ == "__main__":
     if not os.path.isdir(ref_stubs.REFERENCE_ROOT):
         sys.exit("reference tree not present; fixtures are committed under tests/golden/")
@@ -751,5 +852,6 @@ if __name__ == "__main__":
     gen_meta_update()
     gen_training_step()
     gen_callbacks()
+    gen_obs_extensions()
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("total fixture bytes:", tot)

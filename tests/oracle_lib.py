@@ -36,6 +36,8 @@ class SimCfg(C.Structure):
         ("n_routes", C.c_int32), ("n_spawns", C.c_int32),
         ("route_segs", C.c_void_p), ("route_meta", C.c_void_p), ("spawn_tab", C.c_void_p), ("spawn_s", C.c_void_p),
         ("ray_cs", C.c_void_p),
+        ("add_traffic_light", C.c_int32), ("traffic_light_interval", C.c_int32), ("comm_size", C.c_int32),
+        ("comm_neighbours", C.c_int32), ("add_pos_in_comm", C.c_int32), ("map_bbox", C.c_float * 4),
     ]
 
 
@@ -95,7 +97,7 @@ class OracleSim:
 
     def step(self, act):
         act = np.ascontiguousarray(act, np.float32)
-        assert act.size == self.E * self.N * 2
+        assert act.size == self.E * self.N * self.cfg.act_dim
         rc = lib().oracle_sim_step(self._h, _p(act), C.byref(self._so))
         assert rc == 0, rc
         return self.out
@@ -152,6 +154,22 @@ def gae3(rew, val, flags, gamma, lam):
     rc = lib().oracle_gae3(_p(rew), _p(val), _p(flags), T, M, H, g, C.c_double(lam), _p(adv), _p(tgt))
     assert rc == 0, rc
     return adv, tgt
+
+
+def obs_extensions(pos, heading_cs, present, acted, act, radius, counter, interval, bbox, add_tl, comm_size, comm_nb,
+                   add_pos, fresh):
+    """Stateless traffic-light / message columns of one scene: (tl [N][3], comm [N][comm_nb * comm_dim])."""
+    pos, hcs = np.ascontiguousarray(pos, np.float32), np.ascontiguousarray(heading_cs, np.float32)
+    pres, acd = np.ascontiguousarray(present, np.uint8), np.ascontiguousarray(acted, np.uint8)
+    act, bbox = np.ascontiguousarray(act, np.float32), np.ascontiguousarray(bbox, np.float32)
+    N = pos.shape[0]
+    cd = comm_size + (3 if add_pos else 0)
+    tl, comm = np.zeros((N, 3), np.float32), np.zeros((N, max(1, comm_nb * cd)), np.float32)
+    rc = lib().oracle_obs_extensions(_p(pos), _p(hcs), _p(pres), _p(acd), _p(act), N, C.c_float(radius), int(counter),
+                                     int(interval), _p(bbox), int(add_tl), int(comm_size), int(comm_nb), int(add_pos),
+                                     int(fresh), _p(tl), _p(comm))
+    assert rc == 0, rc
+    return tl, comm[:, :comm_nb * cd]
 
 
 def cc_fuse(mode, obs, act, flags, nbr_idx, cnt, counterfactual=True, num_neighbours=4):

@@ -148,3 +148,58 @@ def test_lcf_sampling_matches_reference_distribution(golden_dir):
         for edge in (-1.0, 1.0):
             assert abs((lcf == edge).mean() - (ref == edge).mean()) < 0.03
         s.close()
+
+
+def test_observation_extension_spaces_and_oracle_rollout():
+    """f-4 host surface: CCEnv's `communication` / `add_traffic_light` keys size the spaces like LCFObs /
+    CCEnv.action_space (env_wrappers.py:71-87, 225-247); the oracle simulator runs with the blocks on."""
+    from copo_amd.torch_copo.utils import env_wrappers as W
+    lcf_env = W.get_lcf_env(W.MultiAgentBottleneckEnv)
+    comm = dict(comm_method="broadcast", comm_size=4, comm_neighbours=4, add_pos_in_comm=True)
+    o, a = lcf_env.spaces_for({})
+    assert o.shape == (92,) and a.shape == (2,)
+    o, a = lcf_env.spaces_for(dict(add_traffic_light=True, communication=comm))
+    assert o.shape == (91 + 1 + 4 * 7 + 3,) and a.shape == (2 + 4,) and float(o.low[0]) == -1.0
+    o, a = lcf_env.spaces_for(dict(communication=dict(comm, comm_method="none")))
+    assert o.shape == (92,) and a.shape == (2,)
+    with pytest.raises(NotImplementedError):
+        W.get_ccenv(W.MultiAgentIntersectionEnv).spaces_for(dict(add_traffic_light=True))
+    lat = W.get_latent_env(lcf_env)
+    assert lat.spaces_for(dict(enable_latent=True, latent_dim=6))[0].shape == (98,) and lat.spaces_for({})[0].shape == (92,)
+    assert lat.default_config()["latent_dim"] == -1 and not lat.default_config()["enable_latent"]
+
+    cfg = SimConfig(map="bottleneck", num_envs=2, num_agents=20, horizon=60, add_traffic_light=True, traffic_light_interval=6,
+                    comm_size=3, comm_neighbours=2, add_pos_in_comm=True)
+    assert cfg.obs_dim == 91 + 3 + 1 + 2 * 6 and cfg.act_dim == 5
+    s = ol.OracleSim(cfg)
+    out = s.reset()
+    assert np.all(out["obs"][..., 91] == 1.0) and not out["obs"][..., 95:].any()      # message(0) = 1, no comm after a reset
+    rng = np.random.RandomState(0)
+    spoke = 0
+    for t in range(1, 130):
+        a = np.concatenate([rng.normal(0, 0.05, (2, 20, 1)), rng.uniform(0.3, 1, (2, 20, 1)), rng.uniform(-1, 1, (2, 20, 3))], -1)
+        out = s.step(a.astype(np.float32))
+        f = out["flags"]
+        present = (f & 0x41) > 0
+        c = t % 60            # steps since the last horizon reset
+        msg = (c % 6) / 6 * 0.1 if (c // 6) % 2 == 1 else 1 - (c % 6) / 6 * 0.1
+        np.testing.assert_array_equal(out["obs"][..., 91][present], np.float32(msg))
+        tlpos = out["obs"][..., 92:94][present]
+        assert np.all((tlpos > 0) & (tlpos < 1))
+        comm_block = out["obs"][..., 95:]
+        assert np.all(np.abs(comm_block) <= 1) and not comm_block[~present].any()
+        if c == 0:
+            assert not comm_block.any()
+        # first message block == the comm action of the nearest neighbour if it acted this step
+        for e in range(2):
+            for n in np.nonzero(present[e])[0]:
+                if out["nbr_cnt"][e, n] > 0 and c != 0:
+                    j = out["nbr_idx"][e, n, 0]
+                    want = a[e, j, 2:].astype(np.float32) if (f[e, j] & 1) else np.zeros(3, np.float32)
+                    np.testing.assert_array_equal(comm_block[e, n, :3], want)
+                    spoke += int(f[e, j] & 1)
+    assert spoke > 100
+    s.close()
+    bad = SimConfig(map="intersection", num_envs=1, num_agents=4, add_traffic_light=True, traffic_light_interval=0)
+    with pytest.raises(AssertionError):
+        ol.OracleSim(bad)

@@ -41,6 +41,7 @@ def _actions(rng, E, N, t):
     ("parkinglot", 10, 5, 240, 150, 512),
     ("tollgate", 40, 2, 72, 120, 64),
     ("intersection", 4, 3, 72, 150, 128),
+    ("bottleneck", 20, 4, 72, 200, 256),
 ])
 def test_rollout_bit_exact(map_name, N, E, lasers, steps, block):
     import torch
@@ -173,3 +174,32 @@ def test_population_capacity_bit_exact_and_respected():
     assert (status[:, 30:] == 0).all()
     g.close()
     o.close()
+
+
+@pytest.mark.parametrize("tl,comm,pos,lcf,nb", [(True, 0, False, True, 4), (False, 4, False, True, 4), (True, 3, True, True, 2),
+                                                (True, 4, True, False, 6)])
+def test_observation_extensions_bit_exact(tl, comm, pos, lcf, nb):
+    """f-4: traffic-light columns, communication channel (messages of the nearest neighbours, optional relative
+    position) -- same bits as the oracle through horizon resets, respawns and set_lcf_dist."""
+    import torch
+    import oracle_lib as ol
+    from copo_amd.sim import SimConfig, VecSim
+    E, N = 4, 24
+    cfg = SimConfig(map="intersection", num_envs=E, num_agents=N, horizon=70, nbr_k=8, delay_done=5, enable_lcf=lcf,
+                    add_traffic_light=tl, traffic_light_interval=7, comm_size=comm, comm_neighbours=nb, add_pos_in_comm=pos)
+    assert cfg.obs_dim == 91 + (3 if tl else 0) + (1 if lcf else 0) + (nb * (comm + (3 if pos else 0)) if comm else 0)
+    g, o = VecSim(cfg), ol.OracleSim(cfg)
+    seeds = np.arange(E, dtype=np.uint64) * np.uint64(104729) + np.uint64(5000)
+    _compare("reset", g.reset(seeds), o.reset(seeds))
+    rng = np.random.RandomState(11)
+    seen_msg = False
+    for t in range(180):
+        a = np.concatenate([_actions(rng, E, N, t), rng.uniform(-1, 1, (E, N, comm)).astype(np.float32)], -1)
+        go = g.step(torch.from_numpy(a).cuda())
+        oo = o.step(a)
+        _compare("step %d" % t, go, oo)
+        if comm:
+            base = 91 + (3 if tl else 0) + (1 if lcf else 0)
+            seen_msg = seen_msg or bool(np.abs(oo["obs"][..., base:]).max() > 0)
+    assert seen_msg or not comm
+    g.close()

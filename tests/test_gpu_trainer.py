@@ -143,6 +143,8 @@ def test_dict_env_api_matches_reference_surface():
     # configs[4]: CoPO ParkingLot, 10 agents, 240-beam LiDAR (O = 260), LCF meta-update after every env step
     ("C5", "copo", "MultiAgentParkingLotEnv", dict(num_envs=256, env_config=dict(num_agents=10, num_lasers=240),
                                                     train_batch_size=256)),
+    # f-4: the Bottleneck map (20 agents, eval/evaluate_population.py:118-124)
+    ("Bottleneck", "copo", "MultiAgentBottleneckEnv", dict(num_envs=32, env_config=dict(num_agents=20))),
 ])
 def test_baseline_parity_configs_run(name, algo, map_cls, cfg):
     """The other BASELINE.json configurations (parity-test cases, not bench lines): shapes, dtypes and a few
@@ -339,3 +341,54 @@ def test_reference_style_smoke_mains(mod, tmp_path):
     assert len(found) == 1
     rows = open(found[0]).read().strip().splitlines()
     assert len(rows) >= 3 and "timesteps_total" in rows[0]
+
+
+def test_extension_wrappers_through_the_dict_api():
+    """f-4: traffic-light message, communication channel and latent wrapper through reset()/step(dict) of
+    get_latent_env(get_lcf_env(MultiAgentBottleneckEnv)) -- shapes, the message clock, who hears whom, info keys."""
+    from copo_amd.torch_copo.utils import env_wrappers as W
+    cls = W.get_latent_env(W.get_lcf_env(W.MultiAgentBottleneckEnv))
+    comm = dict(comm_method="broadcast", comm_size=3, comm_neighbours=2, add_pos_in_comm=True)
+    conf = dict(num_agents=12, horizon=40, add_traffic_light=True, traffic_light_interval=5, communication=comm,
+                enable_latent=True, latent_dim=4)
+    env = cls(conf)
+    O = 4 + 91 + 3 + 1 + 2 * 6
+    assert env.observation_space["agent0"].shape == (O,) and env.action_space["agent0"].shape == (5,)
+    o = env.reset(force_seed=3)
+    assert all(v.shape == (O,) and not v[:4].any() for v in o.values())           # no latent registered: zeros
+    assert all(v[4 + 91] == 1.0 and not v[4 + 95:].any() for v in o.values())     # message(0) = 1; no comm after reset
+    rng = np.random.RandomState(0)
+    heard = 0
+    for t in range(1, 40):
+        acts = {k: np.concatenate([[0.0, 0.8], rng.uniform(-1, 1, 3)]).astype(np.float32) for k in env.vehicles}
+        o, r, d, i = env.step(acts)
+        msg = (t % 5) / 5 * 0.1 if (t // 5) % 2 == 1 else 1 - (t % 5) / 5 * 0.1
+        for k in acts:
+            assert o[k].shape == (O,) and o[k][4 + 91] == np.float32(msg)
+            inf = i[k]
+            assert len(inf["comm_current_obs"]) == 2 and len(inf["nei_obs"]) == 3 and inf["nei_obs"][-1] is None
+            for q, n in enumerate(inf["neighbours"][:2]):
+                blk = o[k][4 + 95 + 6 * q: 4 + 95 + 6 * (q + 1)]
+                np.testing.assert_array_equal(blk, inf["comm_current_obs"][q])
+                if n in acts:                      # the neighbour was given an action this step: its message arrives
+                    np.testing.assert_array_equal(blk[:3], acts[n][2:])
+                    assert np.all((blk[3:] >= 0) & (blk[3:] <= 1))
+                    heard += 1
+                else:
+                    assert not blk.any()
+            for q in range(len(inf["neighbours"]), 2):
+                assert not o[k][4 + 95 + 6 * q: 4 + 95 + 6 * (q + 1)].any()
+    assert heard > 20
+    env.register_latent({3: {"agent%d" % a: np.full(4, a, np.float32) for a in range(200)}})
+    o, r, d, i = env.step({k: np.zeros(5, np.float32) for k in env.vehicles})
+    assert all(np.all(v[:4] == int(k[5:])) for k, v in o.items())
+    env.close()
+    # vector API: latent tensor concatenated on the device
+    venv = cls(dict(conf, num_envs=3))
+    out = venv.vec_reset()
+    assert out["obs"].shape == (3, 12, O) and not out["obs"][..., :4].any()
+    lat = torch.arange(3 * 12 * 4, device="cuda", dtype=torch.float32).view(3, 12, 4)
+    venv.register_latent_tensor(lat)
+    out = venv.vec_step(torch.zeros(3, 12, 5, device="cuda"))
+    assert torch.equal(out["obs"][..., :4], lat) and out["obs"].shape == (3, 12, O)
+    venv.close()

@@ -140,3 +140,38 @@ def test_lcf_mix_vs_reference(golden_dir):
     mean = stats[1] / stats[0]
     np.testing.assert_allclose([mean, np.sqrt(stats[2] / stats[0] - mean ** 2)], g["out_raw_mean_std"], rtol=1e-5)
     assert abs(norm.mean()) < 1e-6 and abs(norm.std() - 1) < 1e-5
+
+
+def test_observation_extensions_vs_reference(golden_dir):
+    """f-4: traffic-light message + communication channel, executed through the reference's LCFEnv on scripted
+    scenes (reset + 9 steps, absent / freshly spawned agents, a coincident pair): env_wrappers.py:89-118, 258-303,
+    315-337, 360-371.  Layout after the 91 base columns: [3 traffic light | lcf | comm_neighbours x comm_dim]."""
+    g = np.load(os.path.join(golden_dir, "obs_extensions.npz"))
+    nan_seen = False
+    for c in range(int(g["n_cases"])):
+        tl, cs, nb, pos_on, interval = (int(g["c%d_%s" % (c, k)]) for k in ("tl", "cs", "nb", "pos", "interval"))
+        P, H, pres, acted, act, ext = (g["c%d_%s" % (c, k)] for k in ("positions", "heading_cs", "present", "acted", "act", "ext"))
+        cd = cs + (3 if pos_on else 0)
+        for t in range(P.shape[0]):
+            otl, ocomm = ol.obs_extensions(P[t], H[t], pres[t], acted[t], act[t], 40.0, t, interval, g["bbox"], tl, cs, nb,
+                                           pos_on, fresh=(t == 0))
+            m = pres[t].astype(bool)
+            col = 0
+            if tl:
+                assert np.array_equal(otl[m], ext[t][m, :3]), (c, t)
+                col = 3
+            assert np.all((ext[t][m, col] >= 0) & (ext[t][m, col] <= 1))       # the (lcf + 1) / 2 column
+            if cs:
+                ref = ext[t][m, col + 1:]
+                got = ocomm[m]
+                assert ref.shape == got.shape == (m.sum(), nb * cd)
+                msg = np.concatenate([np.arange(r * cd, r * cd + cs) for r in range(nb)])
+                assert np.array_equal(got[:, msg], ref[:, msg]), (c, t)       # messages: copied bits
+                if pos_on:
+                    rel = np.setdiff1d(np.arange(nb * cd), msg)
+                    assert np.array_equal(np.isnan(got[:, rel]), np.isnan(ref[:, rel])), (c, t)
+                    np.testing.assert_allclose(got[:, rel], ref[:, rel], rtol=2e-7, atol=1e-7, equal_nan=True)
+                if t == 0:
+                    assert not got.any()
+        nan_seen = nan_seen or bool(np.isnan(ext).any())
+    assert nan_seen       # the coincident pair (d == 0 -> 0/0) went through the reference at least once
