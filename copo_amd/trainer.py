@@ -565,6 +565,11 @@ class VecTrainer:
         device = resolve_device(cfg.get("device"))
         env_config.setdefault("device", device.index or 0)
         self.env = env_cls(env_config)
+        if self.env.sim.A != 2:
+            self.env.close()
+            raise NotImplementedError(
+                "communication widens the action to 2 + comm_size floats; the trainers (like the reference's, whose scripts "
+                "keep comm_method='none') drive [steering, throttle] only -- use the env API for the channel")
         pol_cls = self.get_default_policy_class(cfg)
         self.policy = pol_cls(cfg.observation_space, cfg.action_space, cfg)
         E = self.env.sim.E
