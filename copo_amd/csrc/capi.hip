@@ -51,7 +51,8 @@ static int upload(copo_sim* s, const T* host, size_t count, const T** dev) {
     return COPO_OK;
 }
 
-static int pick_block(int E) { return E <= 512 ? 1024 : (E <= 2048 ? 512 : 256); }
+// measured (scripts/bench_sim.py, 40 slots): one scene per CU or fewer -> 16 waves per scene; two per CU -> 8; beyond -> 4
+static int pick_block(int E) { return E <= 256 ? 1024 : (E <= 512 ? 512 : 256); }
 
 extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** out) {
     if (!cfg || !out) return fail(COPO_ERR_NULL, "copo_sim_create: cfg/out is NULL");
