@@ -133,8 +133,8 @@ hipError_t launch_fused_step(FusedArgs a, hipStream_t s, const MetaTail* mt_ = n
         vec = vec && (nets[g]->in_dim % 4 == 0) && (nets[g]->w1 % 4 == 0) && (nets[g]->w2 % 4 == 0);
 #define COPO_GEMM(OP, grid, op, K)                                                                     \
     do {                                                                                               \
-        if (vec) hipLaunchKernelGGL((gemm_kernel<OP, true>), grid, dim3(256), GEMM_LDS_BYTES, s, a, K);   \
-        else hipLaunchKernelGGL((gemm_kernel<OP, false>), grid, dim3(256), GEMM_LDS_BYTES, s, a, K);      \
+        if (vec) hipLaunchKernelGGL((gemm_kernel<OP, true>), grid, dim3(256), gemm_lds_bytes(a.c.mb), s, a, K);   \
+        else hipLaunchKernelGGL((gemm_kernel<OP, false>), grid, dim3(256), gemm_lds_bytes(a.c.mb), s, a, K);      \
     } while (0)
     // row pass (one kernel for F1, F2, heads, B2x) when the shapes allow it; else the four separate kernels
     // shapes with a row-pass instantiation: hidden = 16 * NT * WAVES
@@ -188,10 +188,10 @@ hipError_t launch_fused_step(FusedArgs a, hipStream_t s, const MetaTail* mt_ = n
         const int nx2 = (c.hidden + 1 + TN - 1) / TN, nx1 = (kmax1 + 1 + TN - 1) / TN;
         const dim3 grid((nx2 + nx1) * ht + nx2, G * a.ksplit);
         if (part == 2) {
-            if (vec) hipLaunchKernelGGL((gemm_bw_kernel<true, true>), grid, dim3(256), GEMM_LDS_BYTES, s, a, c.mb, nx2, nx1, ht);
-            else hipLaunchKernelGGL((gemm_bw_kernel<false, true>), grid, dim3(256), GEMM_LDS_BYTES, s, a, c.mb, nx2, nx1, ht);
-        } else if (vec) hipLaunchKernelGGL((gemm_bw_kernel<true>), grid, dim3(256), GEMM_LDS_BYTES, s, a, c.mb, nx2, nx1, ht);
-        else hipLaunchKernelGGL((gemm_bw_kernel<false>), grid, dim3(256), GEMM_LDS_BYTES, s, a, c.mb, nx2, nx1, ht);
+            if (vec) hipLaunchKernelGGL((gemm_bw_kernel<true, true>), grid, dim3(256), gemm_lds_bytes(a.c.mb), s, a, c.mb, nx2, nx1, ht);
+            else hipLaunchKernelGGL((gemm_bw_kernel<false, true>), grid, dim3(256), gemm_lds_bytes(a.c.mb), s, a, c.mb, nx2, nx1, ht);
+        } else if (vec) hipLaunchKernelGGL((gemm_bw_kernel<true>), grid, dim3(256), gemm_lds_bytes(a.c.mb), s, a, c.mb, nx2, nx1, ht);
+        else hipLaunchKernelGGL((gemm_bw_kernel<false>), grid, dim3(256), gemm_lds_bytes(a.c.mb), s, a, c.mb, nx2, nx1, ht);
     }
     // parameter range the fold covers: every net of this call (the policy only in the meta modes)
     int64_t lo;
