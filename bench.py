@@ -299,7 +299,8 @@ def main():
         except Exception:
             pass
         print(json.dumps(line), flush=True)
-    D.shutdown()
+    if world == 1:
+        D.shutdown()      # single process: quiet exit; several ranks leave the group the way torchrun expects (at exit)
 
 
 if __name__ == "__main__":
