@@ -222,10 +222,6 @@ __device__ __forceinline__ void neighbours_phase(const SimParams& p, EnvLds& L, 
                 if (out.mf_cnt) out.mf_cnt[base + i] = 0;
                 L.ncnt[i] = 0;
             }
-            if (comm && lane < p.comm_nb) {
-                float* q = out.obs + (base + i) * p.O + p.col_comm + lane * CD;
-                for (int k = 0; k < CD; ++k) q[k] = 0.0f;
-            }
             if (lane < K) {
                 if (out.nbr_idx) out.nbr_idx[(base + i) * K + lane] = -1;
                 if (out.nbr_dist) out.nbr_dist[(base + i) * K + lane] = 0.0f;
@@ -305,16 +301,13 @@ __device__ __forceinline__ void neighbours_phase(const SimParams& p, EnvLds& L, 
 // `counter` = env steps since the last reset (the traffic-light clock, env_wrappers.py:258-265,280,317).
 template <bool EXT>
 __device__ __forceinline__ void ego_navi_obs(const SimParams& p, EnvLds& L, int lane, const Slot& s, bool present,
-                                             float* __restrict__ row, int counter) {
-    if (!row) return;
-    float o[20];
-    if (!present) {
-#pragma unroll
-        for (int k = 0; k < 19; ++k) row[k] = 0.0f;
-        if (p.col_lcf >= 0) row[p.col_lcf] = 0.0f;
-        if (EXT && p.col_tl >= 0) { row[p.col_tl] = 0.0f; row[p.col_tl + 1] = 0.0f; row[p.col_tl + 2] = 0.0f; }
-        return;
+                                             float* __restrict__ row, int counter, bool zero_comm) {
+    if (!row || !present) return;     // the observation row of an absent slot is not written (copo_step_out.obs)
+    if (EXT && zero_comm && p.col_comm >= 0) {   // reset observation: no messages (the neighbour phase of a step that ends an
+        const int n = p.comm_nb * (p.comm_size + 3 * p.comm_pos);     // episode ran on the scene BEFORE the reset)
+        for (int k = 0; k < n; ++k) row[p.col_comm + k] = 0.0f;
     }
+    float o[20];
     if (EXT && p.col_tl >= 0) {   // clip([message, x', y'], 0, 1) in python float64 arithmetic, cast to fp32
         const int I = p.tl_interval;
         const double inc = (double)(counter % I) / (double)I * 0.1;
@@ -494,9 +487,7 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
     for (int q = tid; q < ((p.dbg_skip & 4) ? 0 : nrays); q += nthreads) {
         const int i = (int)(((float)q + 0.5f) * inv_nl), k = q - i * NL;
         const int rb = L.rowbase[i];
-        float val = 0.0f;
-        if (rb >= 0) val = __uint_as_float(best[rb + k]) / range;
-        eobs[i * O + (COPO_EGO_DIM + COPO_NAVI_DIM) + k] = val;
+        if (rb >= 0) eobs[i * O + (COPO_EGO_DIM + COPO_NAVI_DIM) + k] = __uint_as_float(best[rb + k]) / range;
     }
 }
 
@@ -559,7 +550,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_reset_kernel(SimParams
             int32_t* env = p.env + (size_t)e * 4;
             env[0] = 0; env[1] = 0; env[2] = cap; env[3] = 1;
         }
-        ego_navi_obs<EXT>(p, L, lane, s, lane < cap, (out.obs && lane < N) ? out.obs + ((size_t)e * N + lane) * p.O : nullptr, 0);
+        ego_navi_obs<EXT>(p, L, lane, s, lane < cap, (out.obs && lane < N) ? out.obs + ((size_t)e * N + lane) * p.O : nullptr, 0, true);
     }
     __syncthreads();
     neighbours_phase<EXT>(p, L, e, wave, nwaves, lane, out);
@@ -878,7 +869,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
             env[1] = episode;
             env[2] = next_aid;
         }
-        if (!(p.dbg_skip & 8)) ego_navi_obs<EXT>(p, L, lane, s, present, (out.obs && lane < N) ? out.obs + ((size_t)e * N + lane) * p.O : nullptr, ending ? 0 : t_env + 1);
+        if (!(p.dbg_skip & 8)) ego_navi_obs<EXT>(p, L, lane, s, present, (out.obs && lane < N) ? out.obs + ((size_t)e * N + lane) * p.O : nullptr, ending ? 0 : t_env + 1, ending);
     }
     __syncthreads();
 

@@ -130,7 +130,9 @@ typedef struct copo_sim copo_sim;
 
 /* outputs of one vectorised env step; any pointer except obs may be NULL to skip that output */
 typedef struct copo_step_out {
-    float* obs;          /* [E][N][O]   obs AFTER the step (the next policy input)                        */
+    float* obs;          /* [E][N][O]   obs AFTER the step (the next policy input); rows of slots that hold no
+                                         agent (neither ACTED nor SPAWNED) are NOT written -- the reference has no
+                                         dict entry for them, and not streaming ~half of the rows halves the traffic */
     float* rew;          /* [E][N]      native reward of the acting agent (return_native_reward=True)     */
     float* nei_rew;      /* [E][N]      env_wrappers.py:321-325                                           */
     float* glob_rew;     /* [E]         env_wrappers.py:313                                               */

@@ -372,10 +372,7 @@ static void write_obs(oracle_sim* s, int e, const copo_step_out* out, const uint
     }
     for (int i = 0; i < N; ++i) {
         float* o = out->obs + ((size_t)e * N + i) * O;
-        if (!present[i]) {
-            for (int k = 0; k < O; ++k) o[k] = 0.0f;
-            continue;
-        }
+        if (!present[i]) continue;      /* no agent, no row: the slot's observation bytes are left as they are */
         float x = FP(s, S_X, e)[i], y = FP(s, S_Y, e)[i], th = FP(s, S_TH, e)[i];
         int rw = IP(s, S_ROUTE, e)[i];
         int route = rw & 0xffff, seg = rw >> 16;

@@ -105,8 +105,12 @@ def test_state_roundtrip_and_determinism():
     g.set_state(st, env)
     for a, r in zip(acts[30:], ref):
         out = g.step(a)
+        present = (out["flags"] & 0x41) != 0          # rows of slots without an agent are not written (copo_step_out.obs)
         for k, v in r.items():
-            assert torch.equal(out[k], v), k
+            if k == "obs":
+                assert torch.equal(out[k][present], v[present]), k
+            else:
+                assert torch.equal(out[k], v), k
 
 
 def test_error_codes():
