@@ -374,6 +374,25 @@ __device__ __forceinline__ float ray_box(float rx, float ry, float dxr, float dy
     return n > 0.0f ? n / a : 0.0f;
 }
 
+// Wave64 inclusive scans on the DPP network (row shifts 1/2/4/8, then row_bcast:15 / :31 -- the gfx9 sequence):
+// six VALU operations, no LDS traffic (a __shfl_up ladder is six ds_bpermute round trips).
+template <bool MAX>
+__device__ __forceinline__ int wave_scan_incl(int v) {
+#define COPO_SCAN_STEP(ctrl, rmask)                                                       \
+    {                                                                                     \
+        const int t = __builtin_amdgcn_update_dpp(0, v, ctrl, rmask, 0xf, false);         \
+        v = MAX ? (t > v ? t : v) : v + t;                                                \
+    }
+    COPO_SCAN_STEP(0x111, 0xf)   // row_shr:1
+    COPO_SCAN_STEP(0x112, 0xf)   // row_shr:2
+    COPO_SCAN_STEP(0x114, 0xf)   // row_shr:4
+    COPO_SCAN_STEP(0x118, 0xf)   // row_shr:8
+    COPO_SCAN_STEP(0x142, 0xa)   // row_bcast:15 -> rows 1, 3
+    COPO_SCAN_STEP(0x143, 0xc)   // row_bcast:31 -> rows 2, 3
+#undef COPO_SCAN_STEP
+    return v;                    // identity 0: counts and (lane + 1) markers are non-negative
+}
+
 // Bearing of (u, v) in (-pi, pi], absolute error < 1e-5 rad.  NOT part of the deterministic spec: it only sizes the
 // conservative ray window below, every hit/miss decision stays with ray_box.
 __device__ __forceinline__ float atan2_window(float v, float u) {
@@ -398,7 +417,8 @@ __device__ __forceinline__ float atan2_window(float v, float u) {
 // distance) of i's ray fan, so the work list is (present agent, solid vehicle) pairs expanded to the few rays of their
 // window -- ~6 box tests per pair instead of one reject test per (ray, vehicle).  One lane per pair computes the
 // window (a superset, with a 4 mrad margin over < 1e-4 rad of approximation error); a wave scan of the window sizes
-// numbers the box tests, lanes find their (pair, ray) by a 6-step search over the scanned counts, and hits fold into
+// numbers the box tests; the pair that owns box test t is found with head flags (every pair marks the slot of its
+// first test in a 64-entry LDS strip of the wave, a max-scan spreads the marks), and hits fold into
 // the per-ray minimum with LDS atomicMin on the float bit pattern (distances are >= 0, so unsigned order == float
 // order and the result does not depend on the task order).  Rays outside every window keep `range`, exactly what
 // the exhaustive test of the oracle gives them.
@@ -425,6 +445,7 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
     for (int q = tid; q < np * NL; q += nthreads) best[q] = range_bits;
     float* eobs = obs + (size_t)e * N * O;
     const float* __restrict__ rays = lds_rays(p);
+    int* wtag = reinterpret_cast<int*>(dyn + lidar_lds_words(p.N, p.num_lasers) + ray_lds_words(p.num_lasers)) + wave * 64;
     __syncthreads();
     const int ncombo = np * ns;
     const float inv_ns = 1.0f / (float)(ns > 0 ? ns : 1);
@@ -452,21 +473,25 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
             }
         }
         const unsigned int pk = (unsigned int)j | ((unsigned int)klo << 6) | ((unsigned int)cnt << 14) | ((unsigned int)ip << 22);
-        int incl = cnt;                           // inclusive scan of the window sizes
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(incl, off);
-            if (lane >= off) incl += t;
-        }
-        const int total = __shfl(incl, 63);
+        const int incl = wave_scan_incl<false>(cnt);      // inclusive scan of the window sizes
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        const int excl = incl - cnt;                      // index of this pair's first box test
+        int carry = 0;                                    // (lane + 1) of the pair that owns the last test of the previous batch
         for (int t0 = 0; t0 < total; t0 += 64) {
             const int t = t0 + lane;
-            int sl = 0;                           // first lane whose inclusive count exceeds t
-#pragma unroll
-            for (int step = 32; step; step >>= 1) {
-                const int v = __shfl(incl, sl + step - 1);
-                if (v <= t) sl += step;
-            }
+            // head flags: the pair whose first test falls into this batch marks that slot with lane + 1; a max-scan
+            // spreads the marks over the tests that follow (marks grow with the position)
+            wtag[lane] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (cnt > 0 && excl >= t0 && excl < t0 + 64) wtag[excl - t0] = lane + 1;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            int own = wave_scan_incl<true>(wtag[lane]);
+            own = own > carry ? own : carry;
+            carry = __builtin_amdgcn_readlane(own, 63);
+            __builtin_amdgcn_wave_barrier();
+            const int sl = own > 0 ? own - 1 : 0;
             const unsigned int spk = (unsigned int)__shfl((int)pk, sl);
             const int sincl = __shfl(incl, sl);
             if (t < total) {
@@ -576,7 +601,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
         const int nseg_f = p.n_routes * (COPO_MAX_SEGS + 1) * COPO_SEG_STRIDE, nmeta_f = p.n_routes * 4;
         const int ntab = p.n_spawns * 4, nsp = p.n_spawns;
         const bool stage = (nseg_f + nmeta_f) * (int)sizeof(float) <= ROUTE_LDS_MAX_BYTES;
-        float* rl = reinterpret_cast<float*>(dyn + lidar_lds_words(p.N, p.num_lasers) + ray_lds_words(p.num_lasers));
+        float* rl = reinterpret_cast<float*>(dyn + lidar_lds_words(p.N, p.num_lasers) + ray_lds_words(p.num_lasers) + (nthreads >> 6) * 64);
         int32_t* tl = reinterpret_cast<int32_t*>(rl + nseg_f + nmeta_f);
         float* sl = reinterpret_cast<float*>(tl + ntab);
         if (stage) {
@@ -912,7 +937,10 @@ __global__ void __launch_bounds__(256) neighbours_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------
-static size_t lidar_lds_bytes(const SimParams& p) { return (size_t)(lidar_lds_words(p.N, p.num_lasers) + ray_lds_words(p.num_lasers)) * sizeof(unsigned int); }
+// [slots][rays] minima, ray table, one 64-entry strip per wave (box-test owners)
+static size_t lidar_lds_bytes(const SimParams& p, int block) {
+    return (size_t)(lidar_lds_words(p.N, p.num_lasers) + ray_lds_words(p.num_lasers) + (block / 64) * 64) * sizeof(unsigned int);
+}
 static bool sim_has_ext(const SimParams& p) { return p.col_tl >= 0 || p.col_comm >= 0; }
 static hipError_t sim_lds_attrs() {              // 64 slots x 256 rays + route tables exceed the default 64 KB
     static hipError_t once = [] {
@@ -933,15 +961,15 @@ static size_t route_lds_bytes(const SimParams& p) {      // LDS copy of the rout
 
 hipError_t launch_sim_reset(const SimParams& p, const StepOut& out, int block, hipStream_t stream) {
     if (hipError_t a = sim_lds_attrs(); a != hipSuccess) return a;
-    if (sim_has_ext(p)) hipLaunchKernelGGL(sim_reset_kernel<true>, dim3(p.E), dim3(block), lidar_lds_bytes(p), stream, p, out);
-    else hipLaunchKernelGGL(sim_reset_kernel<false>, dim3(p.E), dim3(block), lidar_lds_bytes(p), stream, p, out);
+    if (sim_has_ext(p)) hipLaunchKernelGGL(sim_reset_kernel<true>, dim3(p.E), dim3(block), lidar_lds_bytes(p, block), stream, p, out);
+    else hipLaunchKernelGGL(sim_reset_kernel<false>, dim3(p.E), dim3(block), lidar_lds_bytes(p, block), stream, p, out);
     return hipGetLastError();
 }
 
 hipError_t launch_sim_step(const SimParams& p, const float* act, const StepOut& out, int block, hipStream_t stream) {
     if (hipError_t a = sim_lds_attrs(); a != hipSuccess) return a;
-    if (sim_has_ext(p)) hipLaunchKernelGGL(sim_step_kernel<true>, dim3(p.E), dim3(block), lidar_lds_bytes(p) + route_lds_bytes(p), stream, p, act, out);
-    else hipLaunchKernelGGL(sim_step_kernel<false>, dim3(p.E), dim3(block), lidar_lds_bytes(p) + route_lds_bytes(p), stream, p, act, out);
+    if (sim_has_ext(p)) hipLaunchKernelGGL(sim_step_kernel<true>, dim3(p.E), dim3(block), lidar_lds_bytes(p, block) + route_lds_bytes(p), stream, p, act, out);
+    else hipLaunchKernelGGL(sim_step_kernel<false>, dim3(p.E), dim3(block), lidar_lds_bytes(p, block) + route_lds_bytes(p), stream, p, act, out);
     return hipGetLastError();
 }
 

@@ -207,3 +207,42 @@ def test_observation_extensions_bit_exact(tl, comm, pos, lcf, nb):
             seen_msg = seen_msg or bool(np.abs(oo["obs"][..., base:]).max() > 0)
     assert seen_msg or not comm
     g.close()
+
+
+@pytest.mark.parametrize("spread,lasers", [(3.0, 72), (8.0, 72), (20.0, 240), (45.0, 30)])
+def test_lidar_windows_on_crafted_dense_scenes(spread, lasers):
+    """The pair-driven LiDAR tests only the rays inside a conservative angular window of every vehicle.  Scenes the
+    rollouts never produce -- vehicles piled on top of each other (origin inside another circumcircle: full window),
+    grazing distances, every heading -- must still give the oracle's bits (its loop tests every ray against every box)."""
+    import torch
+    import oracle_lib as ol
+    from copo_amd.sim import SimConfig, VecSim
+    E, N = 16, 40
+    cfg = SimConfig(map="intersection", num_envs=E, num_agents=N, num_lasers=lasers, horizon=500, nbr_k=8)
+    g, o = VecSim(cfg), ol.OracleSim(cfg)
+    seeds = np.arange(E, dtype=np.uint64) + np.uint64(9)
+    g.reset(seeds)
+    o.reset(seeds)
+    rng = np.random.RandomState(int(spread * 10) + lasers)
+    st, env = o.get_state()
+    st = st.copy()
+    # fields 0..2 = x, y, heading: scatter every vehicle around a few cluster centres, some exactly coincident
+    centres = rng.uniform(-30, 30, (E, 4, 2))
+    which = rng.randint(0, 4, (E, N))
+    xy = centres[np.arange(E)[:, None], which] + rng.normal(0, spread, (E, N, 2))
+    xy[:, 1] = xy[:, 0]                                  # coincident pair
+    xy[:, 2] = xy[:, 0] + [2.4320, 0.0]                  # about one circumradius away
+    xy[:, 3] = xy[:, 0] + [0.0, 4.864]                   # about two
+    st[0], st[1] = xy[..., 0].astype(np.float32), xy[..., 1].astype(np.float32)
+    st[2] = rng.uniform(-np.pi, np.pi, (E, N)).astype(np.float32)
+    o.set_state(st, env)
+    g.set_state(torch.from_numpy(st).cuda(), torch.from_numpy(env).cuda())
+    for t in range(3):
+        a = np.zeros((E, N, 2), np.float32)
+        a[..., 1] = -1.0                                   # brake: the piles stay piles
+        go, oo = g.step(torch.from_numpy(a).cuda()), o.step(a)
+        _compare("crafted step %d" % t, go, oo)
+    hits = oo["obs"][..., 19:19 + lasers][(oo["flags"] & 0x41) != 0]
+    assert (hits < 1.0).mean() > 0.05                               # plenty of returns to compare
+    g.close()
+    o.close()
