@@ -169,7 +169,8 @@ int copo_sim_set_force_lcf(copo_sim* sim, double v);
  * `ChangeNEnv.close_and_reset_num_agents` of the curriculum baseline (env_wrappers.py:444-460) without re-creating
  * the simulator.  Device-resident like the LCF distribution (pushed by the next reset / step / flush). */
 int copo_sim_set_capacity(copo_sim* sim, int32_t capacity);
-/* act: [E][N][2] device fp32 (clipped to [-1,1] inside, as RLlib's clip_actions does) */
+/* act: [E][N][COPO_ACT_DIM] device fp32: steering, throttle (clipped to [-1,1] inside, as RLlib's clip_actions does),
+ * then the comm_size message floats when the communication channel is on (passed through unclipped, like the reference) */
 int copo_sim_step(copo_sim* sim, const float* act, const copo_step_out* out, void* stream);
 /* raw state access for tests / checkpointing: [COPO_STATE_FIELDS][E][N] fp32 words + [E][4] int32 env words */
 int copo_sim_get_state(copo_sim* sim, float* slot_state, int32_t* env_state, void* stream);
