@@ -98,18 +98,27 @@ __global__ void __launch_bounds__(256) cc_fuse_mf_kernel(const float* __restrict
     int m = cnt[row];
     if (m > K) m = K;
     const int W = O + (cf ? A : 0);  // fused columns: O obs then A act
+    // neighbour q of the list is decoded by lane q once (index -> ACTED flag of its row); the column loops below only
+    // broadcast the surviving row numbers, so no dependent index / flag loads sit in front of the row reads
+    long long jr = 0;
+    bool ok = false;
+    if (lane < m) {
+        const int j = nbr_idx[(size_t)row * K + lane];
+        if (j >= 0) {
+            jr = r0 + j;
+            ok = (flags[jr] & COPO_F_ACTED) != 0;
+        }
+    }
+    const unsigned long long live = __ballot(ok);
+    const int got = __popcll(live);
+    const int jlo = (int)jr;             // rows fit 31 bits in every configuration this op is launched with (checked on the host)
     for (int k0 = 0; k0 < W; k0 += 64) {
         const int k = k0 + lane;
         float sum = 0.0f;
-        int got = 0;
-        for (int q = 0; q < m; ++q) {
-            const int j = nbr_idx[(size_t)row * K + q];
-            if (j < 0) continue;
-            const long long jr = r0 + j;
-            if (!(flags[jr] & COPO_F_ACTED)) continue;
-            if (k < O) sum += obs[(size_t)jr * O + k];
-            else if (k < W) sum += act[(size_t)jr * A + (k - O)];
-            got++;
+        for (unsigned long long mq = live; mq; mq &= mq - 1) {      // list order: the oracle adds in this order
+            const size_t r = (size_t)__builtin_amdgcn_readlane(jlo, __ffsll((long long)mq) - 1);
+            if (k < O) sum += obs[r * O + k];
+            else if (k < W) sum += act[r * A + (k - O)];
         }
         if (k < W) o[O + k] = got > 0 ? sum / (float)got : 0.0f;
     }
