@@ -13,6 +13,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no built library (artefacts are git-ignored): build it once instead of failing at import
+    lib = os.path.join(ROOT, "copo_amd", "lib", "libcopo_hip.so")
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(ROOT, "copo_amd", "csrc")], check=True)
 
 
 @pytest.fixture(scope="session")
