@@ -18,7 +18,8 @@ Extra objects on the JSON line:
                 (202 + 4*O per present agent slot) / mean launch time measured with HIP events
                 on the launch stream, against the 8 TB/s HBM peak.  At the workload's 256 scenes a launch is one
                 workgroup per compute unit (latency-bound); `saturated` repeats the measurement on 16 384 scenes
-                (present slots, and all slot rows: absent slots still write their zero rows).
+                (`frac_present`: slots that hold an agent x 570 B, the algorithmic figure; `frac_all_slots`: every slot
+                stepped x 570 B, an upper bound -- an empty slot only moves its state and flags).
   learner_roofline  one fused SGD step (the two kernels that take most of an iteration): algorithmic flops / mean step
                 time (HIP events), against the dense fp32 MFMA peak.  The step is a chain of two latency-bound launches
                 on a 512-row minibatch, not a throughput GEMM; the fraction says how far from the matrix peak that leaves it.
@@ -270,11 +271,11 @@ def main():
                          "traffic": traffic, "us_per_launch": round(k_s * 1e6, 2),
                          "units_per_launch": round(present, 1), "bytes_per_unit": bytes_per_unit,
                          "saturated": {"scenes": sat_slots // sim.N, "us_per_launch": round(sat_s * 1e6, 1),
-                                       "present_slots": round(sat_present), "slot_rows_written": sat_slots,
+                                       "present_slots": round(sat_present), "slots_stepped": sat_slots,
                                        "achieved_present": round(sat_present * bytes_per_unit / sat_s * 1e-9, 1),
-                                       "achieved_rows_written": round(sat_slots * bytes_per_unit / sat_s * 1e-9, 1),
+                                       "achieved_all_slots": round(sat_slots * bytes_per_unit / sat_s * 1e-9, 1),
                                        "frac_present": round(sat_present * bytes_per_unit / sat_s * 1e-9 / HBM_PEAK_GBPS, 4),
-                                       "frac_rows_written": round(sat_slots * bytes_per_unit / sat_s * 1e-9 / HBM_PEAK_GBPS, 4)}},
+                                       "frac_all_slots": round(sat_slots * bytes_per_unit / sat_s * 1e-9 / HBM_PEAK_GBPS, 4)}},
         }
         if learner is not None:
             l_s, l_flops = learner
