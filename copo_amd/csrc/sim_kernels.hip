@@ -472,7 +472,8 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
                 klo = lo < 0 ? lo + NL : lo;
             }
         }
-        const unsigned int pk = (unsigned int)j | ((unsigned int)klo << 6) | ((unsigned int)cnt << 14) | ((unsigned int)ip << 22);
+        // j: 6 bits, klo: 8 (< 256 rays), cnt: 9 (up to 256), ip: 6
+        const unsigned int pk = (unsigned int)j | ((unsigned int)klo << 6) | ((unsigned int)cnt << 14) | ((unsigned int)ip << 23);
         const int incl = wave_scan_incl<false>(cnt);      // inclusive scan of the window sizes
         const int total = __builtin_amdgcn_readlane(incl, 63);
         const int excl = incl - cnt;                      // index of this pair's first box test
@@ -495,7 +496,7 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
             const unsigned int spk = (unsigned int)__shfl((int)pk, sl);
             const int sincl = __shfl(incl, sl);
             if (t < total) {
-                const int sj = (int)(spk & 63u), scnt = (int)((spk >> 14) & 255u), sip = (int)(spk >> 22);
+                const int sj = (int)(spk & 63u), scnt = (int)((spk >> 14) & 511u), sip = (int)(spk >> 23);
                 int k = (int)((spk >> 6) & 255u) + (t - (sincl - scnt));
                 if (k >= NL) k -= NL;
                 const int si_ = L.plist[sip];

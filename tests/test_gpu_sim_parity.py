@@ -209,7 +209,7 @@ def test_observation_extensions_bit_exact(tl, comm, pos, lcf, nb):
     g.close()
 
 
-@pytest.mark.parametrize("spread,lasers", [(3.0, 72), (8.0, 72), (20.0, 240), (45.0, 30)])
+@pytest.mark.parametrize("spread,lasers", [(3.0, 72), (8.0, 72), (20.0, 240), (45.0, 30), (2.0, 256)])
 def test_lidar_windows_on_crafted_dense_scenes(spread, lasers):
     """The pair-driven LiDAR tests only the rays inside a conservative angular window of every vehicle.  Scenes the
     rollouts never produce -- vehicles piled on top of each other (origin inside another circumcircle: full window),
@@ -244,5 +244,28 @@ def test_lidar_windows_on_crafted_dense_scenes(spread, lasers):
         _compare("crafted step %d" % t, go, oo)
     hits = oo["obs"][..., 19:19 + lasers][(oo["flags"] & 0x41) != 0]
     assert (hits < 1.0).mean() > 0.05                               # plenty of returns to compare
+    g.close()
+    o.close()
+
+
+def test_maximum_population_bit_exact():
+    """64 slots per scene (COPO_MAX_AGENTS): every lane of wave 0 owns a vehicle, 4096 LiDAR pairs, full-width masks."""
+    import torch
+    import oracle_lib as ol
+    from copo_amd.sim import SimConfig, VecSim
+    E, N = 3, 64
+    cfg = SimConfig(map="intersection", map_kwargs=dict(spawns_per_lane=8, spawn_gap=7.0), num_envs=E, num_agents=N, horizon=60,
+                    nbr_k=16, delay_done=4, spawn_clearance=5.0)
+    g, o = VecSim(cfg), ol.OracleSim(cfg)
+    seeds = np.arange(E, dtype=np.uint64) + np.uint64(31)
+    _compare("reset", g.reset(seeds), o.reset(seeds))
+    rng = np.random.RandomState(8)
+    most = 0
+    for t in range(150):
+        a = _actions(rng, E, N, t + 1)
+        go, oo = g.step(torch.from_numpy(a).cuda()), o.step(a)
+        _compare("N=64 step %d" % t, go, oo)
+        most = max(most, int(((oo["flags"] & 0x41) != 0).sum(1).max()))
+    assert most == 64
     g.close()
     o.close()
