@@ -15,7 +15,7 @@ for name, calls, total, avg, pct in rows[:n]:
 try:
     shapes = list(con.execute(
         "select name, grid_x / workgroup_x as wgs, workgroup_x, count(*), avg(duration) / 1000.0, sum(duration) / 1000.0 "
-        "from kernels where name like '%sim_step%' or name like '%sim_reset%' group by name, wgs, workgroup_x order by name, wgs"))
+        "from kernels where name like '%sim_step%' or name like '%sim_reset%' or name like '%mlp_fwd%' group by name, wgs, workgroup_x order by name, wgs"))
     if shapes:
         print("per launch shape (workgroups x threads):")
         for name, wgs, wx, calls, avg, total in shapes:
