@@ -96,6 +96,8 @@ _SIGS = {
     "copo_transpose_weights_f32": (C.c_int, [C.POINTER(PpoCfg), C.c_void_p, C.c_void_p, C.c_void_p]),
     "copo_mlp_forward_f32": (C.c_int, [C.POINTER(PpoCfg)] + [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_int32] +
                              [C.c_void_p] * 7),
+    "copo_mlp_forward_rows_f32": (C.c_int, [C.POINTER(PpoCfg)] + [C.c_void_p] * 5 + [C.c_int64, C.c_int64, C.c_int32, C.c_int32] +
+                                  [C.c_void_p] * 2),
     "copo_adam_step_f32": (C.c_int, [C.POINTER(PpoCfg)] + [C.c_void_p] * 4 + [C.c_int64] + [C.c_void_p] * 5),
     "copo_meta_grads_f32": (C.c_int, [C.POINTER(PpoCfg)] + [C.c_void_p] * 15),
     "copo_meta_lcf_f64": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 4 + [C.c_int32] +

@@ -281,13 +281,14 @@ extern "C" int copo_ppo_fused_step_f32(const copo_ppo_cfg* cfg, float* theta, fl
     return e == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
 }
 
-extern "C" int copo_mlp_forward_f32(const copo_ppo_cfg* cfg, const float* theta, const float* theta_t, const float* obs_src,
-                                    const float* cc_src, int64_t n_rows, int32_t first_net, int32_t n_nets, float* values,
-                                    float* dist_inputs, const float* eps, float* action, float* logp, float* clipped,
-                                    void* stream) {
+static int mlp_forward(const copo_ppo_cfg* cfg, const float* theta, const float* theta_t, const float* obs_src,
+                       const float* cc_src, int64_t n_rows, int32_t first_net, int32_t n_nets, float* values,
+                       float* dist_inputs, const float* eps, float* action, float* logp, float* clipped,
+                       const int64_t* rows, int64_t n_out, void* stream) {
     int rc = check_cfg(cfg);
     if (rc != COPO_OK) return rc;
     if (!theta || !theta_t || !obs_src) return COPO_ERR_NULL;
+    if (rows && n_out < 1) return COPO_ERR_DIM;
     if (n_rows < 1 || first_net < 0 || n_nets < 1 || first_net + n_nets > 1 + cfg->n_value_heads) return COPO_ERR_DIM;
     if (first_net + n_nets > 1 && !values) return COPO_ERR_NULL;
     if (first_net == 0 && eps && (!action || !logp)) return COPO_ERR_NULL;
@@ -303,7 +304,7 @@ extern "C" int copo_mlp_forward_f32(const copo_ppo_cfg* cfg, const float* theta,
     const size_t lds = ((size_t)HT * (rowpass_k1p(kmax) + 4) + (size_t)2 * HT * (H + 4) + 4 * H) * sizeof(float);
     if (lds > 150 * 1024) return COPO_ERR_DIM;
     FwdArgs a{*cfg, theta, theta_t, obs_src, cc_src ? cc_src : obs_src, n_rows, first_net, n_nets, values, dist_inputs, eps,
-              action, logp, clipped};
+              action, logp, clipped, rows, rows ? n_out : n_rows};
     const dim3 grid((unsigned)((n_rows + HT - 1) / HT), n_nets);
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (H) {
@@ -313,6 +314,22 @@ extern "C" int copo_mlp_forward_f32(const copo_ppo_cfg* cfg, const float* theta,
         default: hipLaunchKernelGGL((mlp_fwd_kernel<4, 8>), grid, dim3(512), lds, st, a); break;
     }
     return hipGetLastError() == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
+}
+
+extern "C" int copo_mlp_forward_f32(const copo_ppo_cfg* cfg, const float* theta, const float* theta_t, const float* obs_src,
+                                    const float* cc_src, int64_t n_rows, int32_t first_net, int32_t n_nets, float* values,
+                                    float* dist_inputs, const float* eps, float* action, float* logp, float* clipped,
+                                    void* stream) {
+    return mlp_forward(cfg, theta, theta_t, obs_src, cc_src, n_rows, first_net, n_nets, values, dist_inputs, eps, action, logp,
+                       clipped, nullptr, n_rows, stream);
+}
+
+extern "C" int copo_mlp_forward_rows_f32(const copo_ppo_cfg* cfg, const float* theta, const float* theta_t,
+                                         const float* obs_src, const float* cc_src, const int64_t* rows, int64_t n_rows,
+                                         int64_t n_src_rows, int32_t first_net, int32_t n_nets, float* values, void* stream) {
+    if (!rows) return COPO_ERR_NULL;
+    return mlp_forward(cfg, theta, theta_t, obs_src, cc_src, n_rows, first_net, n_nets, values, nullptr, nullptr, nullptr, nullptr,
+                       nullptr, rows, n_src_rows, stream);
 }
 
 extern "C" int copo_transpose_weights_f32(const copo_ppo_cfg* cfg, const float* theta, float* theta_t, void* stream) {

@@ -138,9 +138,18 @@ class FusedLearner:
             dist_inputs.data_ptr(), eps.data_ptr(), action.data_ptr(), logp.data_ptr(),
             None if clipped is None else clipped.data_ptr(), _capi.current_stream()))
 
-    def values(self, obs, cc_obs, out=None):
-        """[n_value_heads, R] critic values for dense rows (postprocess)."""
+    def values(self, obs, cc_obs, out=None, rows=None):
+        """[n_value_heads, R] critic values for dense rows (postprocess); with `rows` (int64 indices) only those rows are
+        computed, the others stay 0."""
         R, nv = obs.shape[0], int(self.cfg.n_value_heads)
+        if rows is not None:
+            out = torch.zeros(nv, R, dtype=torch.float32, device=obs.device) if out is None else out
+            if rows.numel() > 0:
+                _capi.check(_capi.lib.copo_mlp_forward_rows_f32(
+                    C.byref(self.cfg), self.flat.flat.data_ptr(), self.flat_t.data_ptr(), obs.data_ptr(),
+                    None if cc_obs is None else cc_obs.data_ptr(), rows.data_ptr(), int(rows.numel()), R, 1, nv, out.data_ptr(),
+                    _capi.current_stream()))
+            return out
         if out is None:
             out = torch.empty(nv, R, dtype=torch.float32, device=obs.device)
         _capi.check(_capi.lib.copo_mlp_forward_f32(

@@ -504,7 +504,13 @@ class PPOPolicyBase:
                 int(fz.cfg.n_value_heads) == H:
             fz.sync_mirror()
             cc_flat = cc.reshape(T * M, -1)
-            vals = fz.values(obs.reshape(T * M, -1), None if cc_flat.data_ptr() == obs.data_ptr() else cc_flat).view(H, T, M)
+            # only rows that hold an acting agent have a value the GAE scan reads (about half of the slots): the row list
+            # is the one `valid_rows` needs anyway (the iteration's single host sync), kept on the batch for it
+            valid = (b[SampleBatch.FLAGS].reshape(-1) & F_ACTED).bool()
+            idx = valid.nonzero(as_tuple=False).view(-1)
+            b["_valid"], b["_valid_idx"] = valid, idx
+            vals = fz.values(obs.reshape(T * M, -1), None if cc_flat.data_ptr() == obs.data_ptr() else cc_flat,
+                             rows=idx).view(H, T, M)
         else:
             vals = self.value_heads_dense(cc.reshape(T * M, -1)).reshape(H, T, M).contiguous()
         rew = b["rew3"][:H].reshape(H, T, M)
@@ -593,6 +599,8 @@ class VecTrainer:
         return batch
 
     def valid_rows(self, batch):
+        if "_valid_idx" in batch:                          # already listed by the dense postprocess
+            return batch["_valid"], batch["_valid_idx"], int(batch["_valid_idx"].numel())
         flags = batch[SampleBatch.FLAGS].reshape(-1)
         valid = (flags & F_ACTED).bool()
         idx = valid.nonzero(as_tuple=False).view(-1)       # the one host sync of an iteration

@@ -296,6 +296,12 @@ int copo_transpose_weights_f32(const copo_ppo_cfg* cfg, const float* theta, floa
 int copo_mlp_forward_f32(const copo_ppo_cfg* cfg, const float* theta, const float* theta_t, const float* obs_src,
                          const float* cc_src, int64_t n_rows, int32_t first_net, int32_t n_nets, float* values,
                          float* dist_inputs, const float* eps, float* action, float* logp, float* clipped, void* stream);
+/* The same pass over a LIST of rows: launch row m reads row rows[m] of the sources ([n_src_rows][..]) and writes
+ * values[net][rows[m]] (values is [n_nets][n_src_rows]; entries of unlisted rows are left alone).  The dense postprocess
+ * of a rollout buffer uses it with the rows that hold an agent -- about half of the slots. */
+int copo_mlp_forward_rows_f32(const copo_ppo_cfg* cfg, const float* theta, const float* theta_t, const float* obs_src,
+                              const float* cc_src, const int64_t* rows, int64_t n_rows, int64_t n_src_rows,
+                              int32_t first_net, int32_t n_nets, float* values, void* stream);
 /* Adam on the flat buffers (the data-parallel path: after the gradient all-reduce); theta_t as above or NULL.
  * workspace: the workspace of the copo_ppo_fused_step_f32(apply_adam = 0, `step` given) call that produced `grad` --
  * that call published the step number and the next minibatch index there, so this one needs no trailing counter

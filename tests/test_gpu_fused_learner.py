@@ -354,6 +354,14 @@ def test_forward_kernel_matches_torch_models(name, fuse, odim, over):
     v = fz.values(obs, None if cc is obs else cc)
     assert v.shape == v_ref.shape
     np.testing.assert_allclose(v.cpu().numpy(), v_ref.cpu().numpy(), rtol=5e-5, atol=5e-6)
+    # the row-list form (copo_mlp_forward_rows_f32): same bits on the listed rows, unlisted rows untouched (zeros)
+    rows = torch.randperm(R, device="cuda", generator=g)[:R // 2 + 3].sort().values
+    vr = fz.values(obs, None if cc is obs else cc, rows=rows)
+    assert torch.equal(vr[:, rows], v[:, rows])
+    rest = torch.ones(R, dtype=torch.bool, device="cuda")
+    rest[rows] = False
+    assert not vr[:, rest].any()
+    assert not fz.values(obs, None if cc is obs else cc, rows=rows[:0]).any()
 
 
 @pytest.mark.parametrize("tag,name,fuse,over", [
