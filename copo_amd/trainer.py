@@ -389,6 +389,13 @@ class PPOPolicyBase:
     def _fused_local(self):
         self.fused.step(self._row_sources, stats=self.fused.stats)
 
+    # minibatch steps per captured graph (the device-side minibatch counter walks the plan by itself)
+    SGD_CHAIN = int(os.environ.get("COPO_SGD_CHAIN", "16"))
+
+    def _fused_local_chain(self):
+        for _ in range(self.SGD_CHAIN):
+            self.fused.step(self._row_sources, stats=self.fused.stats)
+
     def _fused_grads(self):
         self.fused.step(self._row_sources, apply_adam=False, stats=self.fused.stats, bump_index=False)
 
@@ -410,13 +417,21 @@ class PPOPolicyBase:
                              GraphedCallable(self._fused_apply_then_grads, self.use_graphs))
             else:
                 self._sgd = GraphedCallable(self._fused_local, self.use_graphs)
+                self._sgd_chain = GraphedCallable(self._fused_local_chain, self.use_graphs)
         fz.stats.zero_()
         fz.sync_mirror()          # graph replays below do not run python: refresh the transposed weights here if needed
         steps = 0
         perms = self.draw_perms(num_epochs, B_local)
         for ep in range(num_epochs):
             n_mb = self.plan_epoch(valid_idx, B_local, B_all, mb, perm=None if perms is None else perms[ep])
-            for _k in range(n_mb):
+            _k0 = 0
+            if not D.is_dist() and self.use_graphs:
+                # most of an epoch in graphs of SGD_CHAIN steps: fewer graph launches, no gap between their kernels
+                while _k0 + self.SGD_CHAIN <= n_mb:
+                    self._sgd_chain()
+                    _k0 += self.SGD_CHAIN
+                    steps += self.SGD_CHAIN
+            for _k in range(_k0, n_mb):
                 if D.is_dist():
                     # two host calls per minibatch: [Adam of the previous one + this gradient pass], all-reduce; the
                     # last Adam of the epoch is flushed before the next plan resets the minibatch index
