@@ -21,7 +21,7 @@ Extra objects on the JSON line:
                 (`frac_present`: slots that hold an agent x 570 B, the algorithmic figure; `frac_all_slots`: every slot
                 stepped x 570 B, an upper bound -- an empty slot only moves its state and flags).
   learner_roofline  one fused SGD step (the two kernels that take most of an iteration): algorithmic flops / mean step
-                time (HIP events), against the dense fp32 MFMA peak.  The step is a chain of two latency-bound launches
+                time (HIP events over the trainer's captured 16-step graphs), against the dense fp32 MFMA peak.  The step is a chain of two latency-bound launches
                 on a 512-row minibatch, not a throughput GEMM; the fraction says how far from the matrix peak that leaves it.
   cpu_baseline  the same iteration on the host: scalar C oracle simulator + oracle ops + the same torch code
                 on CPU threads ("port"), on a bounded sample.
@@ -123,11 +123,18 @@ def measure_learner_step(trainer, launches=200):
         K, OD = L.in_dim, L.out_dim
         flops += 2 * mb * (K * H + H * H + OD * H) + 2 * mb * (OD * H + H * H) + 2 * mb * ((K + 1) * H + (H + 1) * H + (H + 1) * OD)
     n_plan = int(rs["max_mb"])
-    per = max(1, min(launches, n_plan - 1))
+    # the way the trainer launches it: captured graphs of SGD_CHAIN steps (eager single launches otherwise)
+    chain = getattr(pol, "_sgd_chain", None)
+    n_chain = int(getattr(pol, "SGD_CHAIN", 1))
+    if chain is not None and chain.graph is not None and n_plan - 1 >= n_chain:
+        unit, run = n_chain, chain
+    else:
+        unit, run = 1, (lambda: fz.step(rs, stats=fz.stats))
+    per = max(1, min(launches, n_plan - 1) // unit)
     for _ in range(3):
         rs["k"].zero_()
-        for _ in range(min(per, 10)):
-            fz.step(rs, stats=fz.stats)
+        for _ in range(min(per, 3)):
+            run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     done, total_ms = 0, 0.0
@@ -135,11 +142,11 @@ def measure_learner_step(trainer, launches=200):
         rs["k"].zero_()                      # stay inside the planned minibatch tables
         e0.record()
         for _ in range(per):
-            fz.step(rs, stats=fz.stats)
+            run()
         e1.record()
         torch.cuda.synchronize()
         total_ms += e0.elapsed_time(e1)
-        done += per
+        done += per * unit
     return total_ms * 1e-3 / done, flops
 
 
