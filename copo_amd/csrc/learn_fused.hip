@@ -212,6 +212,9 @@ hipError_t launch_fused_step(FusedArgs a, hipStream_t s, const MetaTail* mt_ = n
         tailv.fin.n_partials = fold_blocks;      // only the partials this launch writes
     }
     hipLaunchKernelGGL(reduce_adam_kernel, dim3(fold_blocks), dim3(256), 0, s, a, lo, n_fold, mt_ ? 1 : 0, tailv.lcf, tailv.fin);
+    // this Adam does not write the transposed mirror (the fused weight-gradient kernel does): bring it up to date, or
+    // the next row pass would read stale weights
+    if (a.apply_adam && a.theta_t && a.head_mode == COPO_HEAD_PPO) return launch_refresh_transposed(c, a.theta, a.theta_t, s);
     return hipGetLastError();
 }
 
