@@ -185,7 +185,8 @@ hipError_t launch_fused_step(FusedArgs a, hipStream_t s, const MetaTail* mt_ = n
         return hipGetLastError();
     }
     {
-        const int nx2 = (c.hidden + 1 + TN - 1) / TN, nx1 = (kmax1 + 1 + TN - 1) / TN;
+        // layers 2 / 3: no tile for the bias column alone when the hidden width fills whole tiles (BwOpT::bias_by_rowsum)
+        const int nx2 = (c.hidden % TN == 0) ? c.hidden / TN : (c.hidden + 1 + TN - 1) / TN, nx1 = (kmax1 + 1 + TN - 1) / TN;
         const dim3 grid((nx2 + nx1) * ht + nx2, G * a.ksplit);
         if (part == 2) {
             if (vec) hipLaunchKernelGGL((gemm_bw_kernel<true, true>), grid, dim3(256), gemm_lds_bytes(a.c.mb), s, a, c.mb, nx2, nx1, ht);
