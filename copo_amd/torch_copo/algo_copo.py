@@ -20,7 +20,8 @@ import torch.nn as nn
 from copo_amd import dist as D
 from copo_amd.engine import (LEARNER_STATS_KEY, NUM_AGENT_STEPS_SAMPLED, NUM_ENV_STEPS_SAMPLED, Postprocessing,
                              SampleBatch, build_mlp, reduce_mean_valid_fn)
-from copo_amd.torch_copo.algo_ccppo import CENTRALIZED_CRITIC_OBS, CCModel, CCPPOConfig, CCPPOPolicy, CCPPOTrainer
+from copo_amd.torch_copo.algo_ccppo import (CENTRALIZED_CRITIC_OBS, COUNTERFACTUAL, CCModel, CCPPOConfig, CCPPOPolicy,  # noqa: F401
+                                            CCPPOTrainer)
 from copo_amd.torch_copo.algo_ippo import clipped_value_loss
 from copo_amd.trainer import GraphedCallable
 

@@ -242,3 +242,32 @@ def test_callbacks_vs_reference(golden_dir):
     for k in g.files:
         if k.startswith("res_"):
             np.testing.assert_allclose(result[k[4:]], g[k], rtol=1e-12, err_msg=k)
+
+
+def test_module_surface_of_the_reference():
+    """the names a `train_*.py`-shaped script imports from `copo.torch_copo` exist under the same module
+    paths, and the four launch scripts import (their __main__ blocks are guarded)."""
+    import importlib
+    want = {
+        "algo_copo": ["CoPOConfig", "CoPOModel", "CoPOPolicy", "CoPOTrainer", "NEI_REWARDS", "NEI_VALUES", "NEI_ADVANTAGE",
+                      "NEI_TARGET", "LCF_LR", "GLOBAL_VALUES", "GLOBAL_REWARDS", "GLOBAL_ADVANTAGES", "GLOBAL_TARGET",
+                      "USE_CENTRALIZED_CRITIC", "CENTRALIZED_CRITIC_OBS", "COUNTERFACTUAL", "USE_DISTRIBUTIONAL_LCF"],
+        "algo_ccppo": ["CCPPOConfig", "CCModel", "CCPPOPolicy", "CCPPOTrainer", "get_ccppo_env", "get_centralized_critic_obs_dim",
+                       "CENTRALIZED_CRITIC_OBS", "COUNTERFACTUAL"],
+        "algo_ippo": ["IPPOConfig", "IPPOPolicy", "IPPOTrainer"],
+        "utils.env_wrappers": ["get_lcf_env", "get_ccenv", "get_rllib_compatible_env", "get_latent_env", "get_change_n_env",
+                               "MultiAgentIntersectionEnv", "MultiAgentRoundaboutEnv", "MultiAgentTollgateEnv",
+                               "MultiAgentBottleneckEnv", "MultiAgentParkingLotEnv", "CCEnv", "LCFEnv"],
+        "utils.train": ["train"],
+        "utils.utils": ["get_train_parser"],
+        "utils.callbacks": ["MultiAgentDrivingCallbacks"],
+    }
+    for mod, names in want.items():
+        m = importlib.import_module("copo_amd.torch_copo." + mod)
+        for n in names:
+            assert hasattr(m, n), (mod, n)
+    for script in ("train_copo", "train_ippo", "train_ccppo", "train_cl"):
+        importlib.import_module("copo_amd.torch_copo." + script)
+    p = importlib.import_module("copo_amd.torch_copo.utils.utils").get_train_parser()
+    a = p.parse_args(["--exp-name", "x", "--num-gpus", "0", "--num-seeds", "1", "--test"])
+    assert a.exp_name == "x" and a.test
