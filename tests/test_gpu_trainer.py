@@ -392,3 +392,17 @@ def test_extension_wrappers_through_the_dict_api():
     out = venv.vec_step(torch.zeros(3, 12, 5, device="cuda"))
     assert torch.equal(out["obs"][..., :4], lat) and out["obs"].shape == (3, 12, O)
     venv.close()
+
+
+@pytest.mark.parametrize("script", ["train_copo", "train_ippo", "train_ccppo", "train_cl"])
+def test_launch_scripts_run(script, tmp_path):
+    """`python -m copo_amd.torch_copo.train_*.py --test` (the reference's launch scripts, train_copo.py:11-65 etc.) start,
+    train to a small step budget and exit cleanly."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "copo_amd.torch_copo." + script, "--exp-name", "t", "--test", "--num-envs", "8",
+                        "--stop", "3000"], cwd=str(tmp_path), env=dict(os.environ, PYTHONPATH=root), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "timesteps_total" in r.stdout
