@@ -24,6 +24,18 @@ from copo_amd.sim import SimConfig, VecSim
 
 _ENV_REGISTRY = {}
 
+# info / batch keys of the communication branch (env_wrappers.py:11-27)
+COMM_ACTIONS = "comm_actions"
+COMM_PREV_ACTIONS = "comm_prev_actions"
+COMM_PREV_OBS = "comm_prev_obs"
+COMM_CURRENT_OBS = "comm_current_obs"
+COMM_PREV_2_OBS = "comm_prev_2_obs"
+COMM_LOGITS = "comm_logits"
+COMM_LOG_PROB = "comm_log_prob"
+ENV_PREV_OBS = "env_prev_obs"
+COMM_METHOD = "comm_method"
+NEI_OBS = "nei_obs"
+
 SIM_KEYS = {f for f in SimConfig.__dataclass_fields__}  # env_config keys forwarded verbatim to the simulator
 
 

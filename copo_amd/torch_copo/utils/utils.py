@@ -1,7 +1,13 @@
 """CLI / misc helpers with the reference's names (`copo/torch_copo/utils/utils.py:182-235`); no Ray underneath."""
 import argparse
+import copy
+import datetime
+import json
 import logging
+import numbers
 import os
+
+import numpy as np
 
 
 def get_train_parser():
@@ -41,3 +47,55 @@ def pretty_print(result):
         except (TypeError, ValueError):
             return str(v)
     return json.dumps(clean(result), indent=2, sort_keys=True)
+
+
+def deep_update(original, new_dict, new_keys_allowed=False, allow_new_subkey_list=None, override_all_if_type_changes=None):
+    """Recursive in-place update of a config dict with the semantics of the reference's helper (utils/utils.py:64-108):
+    unknown keys raise unless allowed; for top-level keys in `allow_new_subkey_list` new sub-keys may appear; for keys in
+    `override_all_if_type_changes` a changed `type` entry replaces the whole sub-dict."""
+    sub_ok, by_type = set(allow_new_subkey_list or ()), set(override_all_if_type_changes or ())
+    for key, new in new_dict.items():
+        if key not in original and not new_keys_allowed:
+            raise Exception("Unknown config parameter `{}` ".format(key))
+        old = original.get(key)
+        if not (isinstance(old, dict) and isinstance(new, dict)):
+            original[key] = new
+        elif key in by_type and "type" in new and "type" in old and new["type"] != old["type"]:
+            original[key] = new
+        else:
+            deep_update(old, new, True if key in sub_ok else new_keys_allowed)
+    return original
+
+
+def merge_dicts(d1, d2):
+    """A new dict: deep copy of d1 deep-updated with d2, new keys allowed (utils/utils.py:50-61)."""
+    return deep_update(copy.deepcopy(d1), d2, True, [])
+
+
+def get_time_str():
+    return datetime.datetime.now().strftime("%Y-%m-%d_%H%M")
+
+
+class SafeJSONEncoder(json.JSONEncoder):
+    """JSON encoder for result dicts: numpy arrays -> lists, numpy scalars -> python numbers, NaN -> `nan_str`, anything
+    else that does not serialise -> its string (utils/utils.py:155-179)."""
+
+    def __init__(self, nan_str="null", **kwargs):
+        super().__init__(**kwargs)
+        self.nan_str = nan_str
+
+    def default(self, value):
+        try:
+            if isinstance(value, np.ndarray):
+                return value.tolist()
+            if isinstance(value, np.bool_):
+                return bool(value)
+            if np.isnan(value):
+                return self.nan_str
+            if isinstance(value, numbers.Integral):
+                return int(value)
+            if isinstance(value, numbers.Number):
+                return float(value)
+            return super().default(value)
+        except Exception:
+            return str(value)

@@ -257,9 +257,11 @@ def test_module_surface_of_the_reference():
         "algo_ippo": ["IPPOConfig", "IPPOPolicy", "IPPOTrainer"],
         "utils.env_wrappers": ["get_lcf_env", "get_ccenv", "get_rllib_compatible_env", "get_latent_env", "get_change_n_env",
                                "MultiAgentIntersectionEnv", "MultiAgentRoundaboutEnv", "MultiAgentTollgateEnv",
-                               "MultiAgentBottleneckEnv", "MultiAgentParkingLotEnv", "CCEnv", "LCFEnv"],
+                               "MultiAgentBottleneckEnv", "MultiAgentParkingLotEnv", "CCEnv", "LCFEnv", "COMM_ACTIONS",
+                               "COMM_CURRENT_OBS", "COMM_METHOD", "NEI_OBS", "ENV_PREV_OBS"],
         "utils.train": ["train"],
-        "utils.utils": ["get_train_parser"],
+        "utils.utils": ["get_train_parser", "initialize_ray", "setup_logger", "merge_dicts", "deep_update", "get_time_str",
+                        "SafeJSONEncoder"],
         "utils.callbacks": ["MultiAgentDrivingCallbacks"],
     }
     for mod, names in want.items():
@@ -271,3 +273,9 @@ def test_module_surface_of_the_reference():
     p = importlib.import_module("copo_amd.torch_copo.utils.utils").get_train_parser()
     a = p.parse_args(["--exp-name", "x", "--num-gpus", "0", "--num-seeds", "1", "--test"])
     assert a.exp_name == "x" and a.test
+    from copo_amd.torch_copo.utils.utils import deep_update, merge_dicts
+    base = dict(x=1, m=dict(a=1, b=2))
+    assert merge_dicts(base, dict(m=dict(b=3, c=4), y=2)) == dict(x=1, m=dict(a=1, b=3, c=4), y=2) and base["m"] == dict(a=1, b=2)
+    with pytest.raises(Exception):
+        deep_update(dict(x=1), dict(z=2))
+    assert deep_update(dict(m=dict(type="a", p=1)), dict(m=dict(type="b")), False, None, ["m"]) == dict(m=dict(type="b"))
