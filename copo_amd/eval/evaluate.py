@@ -11,7 +11,46 @@ import json
 import numpy as np
 
 ENVS = {"inter": "MultiAgentIntersectionEnv", "round": "MultiAgentRoundaboutEnv", "parking": "MultiAgentParkingLotEnv",
-        "tollgate": "MultiAgentTollgateEnv"}
+        "tollgate": "MultiAgentTollgateEnv", "bottle": "MultiAgentBottleneckEnv"}
+
+
+_SCENE_OF = (("Roundabout", "MultiAgentRoundaboutEnv", "Round"), ("Intersection", "MultiAgentIntersectionEnv", "Inter"),
+             ("Parking", "MultiAgentParkingLotEnv", "Parking"), ("Bottle", "MultiAgentBottleneckEnv", "Bottle"),
+             ("Tollgate", "MultiAgentTollgateEnv", "Tollgate"))
+
+
+def get_env(env, should_wrap_copo_env, should_wrap_cc_env, svo_mean=0.0, svo_std=0.0):
+    """(RecorderEnv(single-scene env), short scene name) from an RLlib env name, as `copo/eval.py:27-64` builds it: the
+    CoPO env gets the population's LCF distribution, the CC env only the neighbour lists."""
+    from copo_amd.torch_copo.utils import env_wrappers as W
+    from .recoder import RecorderEnv
+    for needle, cls_name, short in _SCENE_OF:
+        if needle in env:
+            break
+    else:
+        raise ValueError()
+    cls = getattr(W, cls_name)
+    if should_wrap_copo_env:
+        assert should_wrap_cc_env is False
+        e = W.get_lcf_env(cls)({})
+        e.set_lcf_dist(float(svo_mean), max(float(svo_std), 1e-6))
+    elif should_wrap_cc_env:
+        e = W.get_ccenv(cls)({})
+    else:
+        e = cls({})
+    return RecorderEnv(e), short
+
+
+def get_env_and_start_seed(trial_path):
+    """(env name, start seed, params) of a Tune trial folder (`params.json`), copo/eval.py:67-80."""
+    import os
+    path = os.path.join(trial_path, "params.json")
+    assert os.path.isfile(path)
+    with open(path, "r") as f:
+        param = json.load(f)
+    if "env_config" not in param:
+        raise ValueError()
+    return param["env"], param["env_config"]["start_seed"], param
 
 
 def make_eval_trainer(algo, env, num_envs=64, num_agents=40, seed=0, lcf=None, **extra):

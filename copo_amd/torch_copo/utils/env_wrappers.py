@@ -148,8 +148,22 @@ class MultiAgentMetaDrive:
 
     @property
     def vehicles(self):
-        """Active agents: {agent_id: slot}."""
-        return {} if self._slot_ids is None else {a: s for s, a in enumerate(self._slot_ids) if a is not None}
+        """Active agents: {agent_id: vehicle view} with `.position` (x, y), `.heading_theta`, `.speed` (m/s) and `.slot`, as
+        far as the reference's wrappers and `RecorderEnv` look into MetaDrive's vehicle objects."""
+        if self._slot_ids is None or getattr(self, "_episode_over", False):
+            return {}          # after done["__all__"] MetaDrive has no vehicle left until reset()
+        return {a: self._vehicle_view(s) for s, a in enumerate(self._slot_ids) if a is not None}
+
+    def _vehicle_view(self, slot):
+        from types import SimpleNamespace
+        st = self._last_state
+        return SimpleNamespace(slot=slot, position=np.array([st[0, slot], st[1, slot]], np.float64),
+                               heading_theta=float(st[2, slot]), speed=float(st[3, slot]))
+
+    def _fetch_state(self):
+        st, _ = self.sim.get_state()
+        self._last_state = st[:, 0].cpu().numpy()          # [fields][N] of scene 0
+        return st
 
     @property
     def vehicles_including_just_terminated(self):
@@ -162,6 +176,9 @@ class MultiAgentMetaDrive:
         ids = self._ids(out)
         self._slot_ids = ["agent%d" % a for a in ids]
         self._just_terminated = {}
+        self._episode_energy = {}
+        self._episode_over = False
+        self._fetch_state()
         obs = out["obs"][0].cpu().numpy()
         return {a: obs[s] for s, a in enumerate(self._slot_ids)}
 
@@ -177,8 +194,10 @@ class MultiAgentMetaDrive:
         h = {k: v[0].cpu().numpy() for k, v in out.items() if v is not None}
         flags = h["flags"]
         env_reset = bool((flags & F.F_ENV_RESET).any())
-        st, _ = self.sim.get_state()
-        aid_now = st[14, 0].cpu().numpy().view(np.int32)
+        self._episode_over = False
+        terminated_view = {a: v for a, v in self.vehicles.items()}      # poses before the step, for agents that end in it
+        self._fetch_state()
+        aid_now = self._last_state[14].view(np.int32)
         before = list(self._slot_ids)
         acting = {before[s]: s for s in range(N) if flags[s] & F.F_ACTED}
         spawned = {"agent%d" % aid_now[s]: s for s in range(N) if flags[s] & F.F_SPAWNED}
@@ -202,6 +221,14 @@ class MultiAgentMetaDrive:
                 out_of_road=bool(f & F.F_OUT), max_step=bool(f & F.F_MAXSTEP), velocity=float(inf[0]),
                 steering=float(inf[1]), acceleration=float(inf[2]), step_reward=float(inf[3]), cost=float(inf[4]),
                 episode_length=int(inf[5]), episode_reward=float(inf[6]), route_completion=float(inf[7]))
+            # evaluation-side keys of MetaDrive's info that `RecorderEnv` reads (eval/recoder.py:136-138,153).  Energy is a
+            # build-defined proxy: traction work of the bicycle model, 1100 kg, kJ per step -- MetaDrive's own consumption
+            # model is not in the reference tree
+            v_ms = float(inf[0]) / 3.6
+            e_step = 1.1 * max(float(inf[2]), 0.0) * v_ms * float(self.sim_config.dt)
+            self._episode_energy[a] = self._episode_energy.get(a, 0.0) + e_step
+            info.update(step_energy=e_step, episode_energy=self._episode_energy[a],
+                        raw_action=np.asarray(actions.get(a, (0.0, 0.0)), np.float32)[:2].copy())
             if self.ENABLE_LCF:
                 lcf, nei_r = float(h["lcf"][s]), float(h["nei_rew"][s])
                 coord = math.cos(lcf * math.pi / 2) * r[a] + math.sin(lcf * math.pi / 2) * nei_r
@@ -218,7 +245,7 @@ class MultiAgentMetaDrive:
                     info["nei_obs"] = [last.get(n) for n in nb] + [None] * (sc.comm_neighbours - len(nb)) + [None]
             i[a] = info
             if d[a]:
-                self._just_terminated[a] = s
+                self._just_terminated[a] = terminated_view.get(a)
         if not env_reset:
             for a, s in spawned.items():     # respawned agents: first obs, zero reward, empty info (MetaDrive)
                 o[a], r[a], d[a], i[a] = h["obs"][s], 0.0, False, {}
@@ -231,6 +258,9 @@ class MultiAgentMetaDrive:
             elif (flags[s] & F.F_ACTED) and not (flags[s] & F.F_DONE):
                 after[s] = before[s]
         self._slot_ids = after
+        for a in [a for a, done in d.items() if a != "__all__" and done]:
+            self._episode_energy.pop(a, None)
+        self._episode_over = env_reset
         if env_reset:                        # the sim auto-reset: first obs of the next episode, if the caller goes on
             self._auto_reset_obs = {after[s]: h["obs"][s] for s in range(N)}
         return o, r, d, i

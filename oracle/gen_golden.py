@@ -19,6 +19,7 @@ Reference entry points driven here (all under /root/reference/copo_code/copo/tor
   algo_copo.py:516-661           CoPOTrainer.training_step
   algo_copo.py:96-182, algo_ccppo.py:55-219   model construction / parameter counts
   utils/env_wrappers.py:89-118, 258-303, 315-337, 360-371   traffic-light message + communication channel (f-4)
+  ../eval/recoder.py:16-349      DistanceMap / RecorderEnv episode statistics (f-1)
 
 Vectors that flow through the 3P restatements in ref_stubs.py (TorchDiagGaussian, compute_advantages,
 discount_cumsum, standardized) pin the reference code GIVEN those restatements.
@@ -840,6 +841,105 @@ def gen_obs_extensions():
     print("obs_extensions.npz: %d cases, %d bytes" % (len(cfgs), os.path.getsize(os.path.join(OUT, "obs_extensions.npz"))))
 
 
+# --------------------------------------------------------------------------------------
+# f-1: RecorderEnv episode statistics (copo/eval/recoder.py:73-349) on a scripted info stream
+# --------------------------------------------------------------------------------------
+RECORDER_INFO_KEYS = ("velocity", "steering", "step_reward", "acceleration", "cost", "episode_length", "episode_reward",
+                      "step_energy", "episode_energy")
+
+
+def make_recorder_stream(seed, T=60, N=9):
+    """Arrays of a scripted episode: who is present at every step, who is on its first observation (no transition info
+    yet), who terminates and how, positions, rewards and the per-step info columns."""
+    rng = np.random.RandomState(seed)
+    # lives: a slot holds one agent at a time; an agent appears (first observation, empty info), acts for a while and
+    # terminates (done) -- every agent terminates by the last step, like MetaDrive's horizon does
+    present, first, done = (np.zeros((T, N), bool) for _ in range(3))
+    aid = np.full((T, N), -1, np.int64)
+    next_id = 0
+    for n in range(N):
+        t = int(rng.randint(0, 4))
+        while t < T - 1:
+            end = min(T - 1, t + int(rng.randint(2, 25)))
+            present[t:end + 1, n] = True
+            first[t, n] = t > 0 or rng.uniform() < 0.5
+            done[end, n] = True
+            aid[t:end + 1, n] = next_id
+            next_id += 1
+            t = end + 1 + int(rng.randint(0, 3))
+    kind = rng.randint(0, 4, (T, N))                          # 0 arrive, 1 crash, 2 out, 3 max step
+    pos = rng.uniform(-30, 30, (T, N, 2))
+    rew = rng.normal(0.5, 1.0, (T, N))
+    info = {k: rng.uniform(0, 5, (T, N)) for k in RECORDER_INFO_KEYS}
+    info["cost"] = (rng.uniform(size=(T, N)) < 0.1).astype(np.float64)
+    info["episode_length"] = np.floor(rng.uniform(1, 200, (T, N)))
+    raw = rng.uniform(-1, 1, (T, N, 2))
+    return dict(present=present, first=first, done=done, aid=aid, kind=kind, pos=pos, rew=rew, raw_action=raw, **info)
+
+
+class _ScriptedStreamEnv:
+    """Dict-API env that plays a `make_recorder_stream` script (what RecorderEnv wraps)."""
+
+    def __init__(self, script):
+        self.s, self.t, self.vehicles = script, 0, {}
+        self.N = script["present"].shape[1]
+
+    def reset(self):
+        self.t = 0
+        return {}
+
+    def close(self):
+        pass
+
+    def step(self, actions):
+        s, t = self.s, self.t
+        o, r, d, i = {}, {}, {}, {}
+        self.vehicles = {}
+        for n in range(self.N):
+            if not s["present"][t, n]:
+                continue
+            k = "agent%d" % s["aid"][t, n]
+            self.vehicles[k] = SimpleNamespace(position=s["pos"][t, n])
+            o[k], r[k], d[k] = np.zeros(3, np.float32), float(s["rew"][t, n]), bool(s["done"][t, n])
+            if s["first"][t, n]:
+                i[k] = {}
+                continue
+            i[k] = {key: float(s[key][t, n]) for key in RECORDER_INFO_KEYS}
+            i[k]["raw_action"] = s["raw_action"][t, n]
+            if d[k]:
+                kd = int(s["kind"][t, n])
+                i[k].update(arrive_dest=kd == 0, crash=kd == 1, out_of_road=kd == 2)
+        d["__all__"] = t == s["present"].shape[0] - 1
+        self.t += 1
+        return o, r, d, i
+
+
+def gen_recorder():
+    import copo.eval.recoder as R
+    save = {"n_cases": 3}
+    for c in range(3):
+        script = make_recorder_stream(100 + c, T=40 + 15 * c, N=6 + 3 * c)
+        env = R.RecorderEnv(_ScriptedStreamEnv(script), eval_config=dict(neighbours_distance=[20, 35, 12][c]))
+        env.reset()
+        step_results = []
+        for t in range(script["present"].shape[0]):
+            _, _, d, _ = env.step({})
+            if t in (5, 17):
+                step_results.append(env.get_step_result())
+        assert d["__all__"]
+        res = env.get_episode_result()
+        for k, v in script.items():
+            save["c%d_in_%s" % (c, k)] = np.asarray(v)
+        save["c%d_in_distance" % c] = np.asarray([20, 35, 12][c])
+        save["c%d_keys" % c] = np.asarray(sorted(res))
+        save["c%d_vals" % c] = np.asarray([float(res[k]) for k in sorted(res)], np.float64)
+        for q, sr in enumerate(step_results):
+            save["c%d_step%d_keys" % (c, q)] = np.asarray(sorted(sr))
+            save["c%d_step%d_vals" % (c, q)] = np.asarray([float(sr[k]) for k in sorted(sr)], np.float64)
+    np.savez_compressed(os.path.join(OUT, "recorder.npz"), **save)
+    print("recorder.npz:", os.path.getsize(os.path.join(OUT, "recorder.npz")), "bytes;", len(res), "episode statistics")
+
+
 if __name__ == "__main__":
     if not os.path.isdir(ref_stubs.REFERENCE_ROOT):
         sys.exit("reference tree not present; fixtures are committed under tests/golden/")
@@ -853,5 +953,6 @@ if __name__ == "__main__":
     gen_training_step()
     gen_callbacks()
     gen_obs_extensions()
+    gen_recorder()
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("total fixture bytes:", tot)

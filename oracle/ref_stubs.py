@@ -305,6 +305,38 @@ def install():
     spaces.Dict = DictSpace
     gym.spaces = spaces
 
+    class Wrapper:       # gym.Wrapper restated (3P): holds `env`, forwards reset / step / close, exposes `unwrapped`
+        def __init__(self, env):
+            self.env = env
+
+        def reset(self, *a, **k):
+            return self.env.reset(*a, **k)
+
+        def step(self, *a, **k):
+            return self.env.step(*a, **k)
+
+        def close(self):
+            return self.env.close()
+
+        @property
+        def unwrapped(self):
+            return getattr(self.env, "unwrapped", self.env)
+
+    gym.Wrapper = Wrapper
+
+    import ray.rllib.utils as rutils
+
+    def deep_update(original, new_dict, new_keys_allowed=False, allow_new_subkey_list=None, override_all_if_type_changes=None):
+        # ray.rllib.utils.deep_update restated (3P): recursive dict update
+        for k, v in new_dict.items():
+            if isinstance(original.get(k), dict) and isinstance(v, dict):
+                deep_update(original[k], v, True)
+            else:
+                original[k] = v
+        return original
+
+    rutils.deep_update = deep_update
+
     import ray.rllib.env as renv
     renv.MultiAgentEnv = type("MultiAgentEnv", (object,), {"__init__": lambda self, *a, **k: None})
 

@@ -86,3 +86,76 @@ def test_population_loads_into_the_torch_models(gold, name, kind, odim, tmp_path
     pf = CK.get_policy_function_from_checkpoint("ccppo", ck, deterministic=True)
     act = pf({"a": gold[name + "/obs"][0], "b": gold[name + "/obs"][1]}, {})
     np.testing.assert_allclose(np.stack([act["a"], act["b"]]), gold[name + "/mean"][:2], rtol=2e-5, atol=2e-6)
+
+
+class _ScriptedStream:
+    """Dict-API env that replays the arrays of tests/golden/recorder.npz (what the reference's RecorderEnv wrapped when
+    the fixture was recorded)."""
+    INFO = ("velocity", "steering", "step_reward", "acceleration", "cost", "episode_length", "episode_reward", "step_energy",
+            "episode_energy")
+
+    def __init__(self, g, c):
+        self.s = {k[len("c%d_in_" % c):]: g[k] for k in g.files if k.startswith("c%d_in_" % c)}
+        self.t, self.vehicles = 0, {}
+
+    def reset(self):
+        self.t = 0
+        return {}
+
+    def close(self):
+        pass
+
+    def step(self, actions):
+        from types import SimpleNamespace
+        s, t = self.s, self.t
+        o, r, d, i = {}, {}, {}, {}
+        self.vehicles = {}
+        for n in range(s["present"].shape[1]):
+            if not s["present"][t, n]:
+                continue
+            k = "agent%d" % s["aid"][t, n]
+            self.vehicles[k] = SimpleNamespace(position=s["pos"][t, n])
+            o[k], r[k], d[k] = np.zeros(3, np.float32), float(s["rew"][t, n]), bool(s["done"][t, n])
+            if s["first"][t, n]:
+                i[k] = {}
+                continue
+            i[k] = {key: float(s[key][t, n]) for key in self.INFO}
+            i[k]["raw_action"] = s["raw_action"][t, n]
+            if d[k]:
+                kd = int(s["kind"][t, n])
+                i[k].update(arrive_dest=kd == 0, crash=kd == 1, out_of_road=kd == 2)
+        d["__all__"] = t == s["present"].shape[0] - 1
+        self.t += 1
+        return o, r, d, i
+
+
+def test_recorder_env_vs_reference(golden_dir):
+    """f-1: `RecorderEnv.get_episode_result / get_step_result` and `DistanceMap` (copo/eval/recoder.py:16-349): the 31
+    episode statistics the reference computed on three scripted episodes (agents appearing, acting, terminating with
+    every outcome; neighbourhoods of 12 / 20 / 35 m)."""
+    from copo_amd.eval.recoder import DistanceMap, RecorderEnv
+    g = np.load(os.path.join(golden_dir, "recorder.npz"))
+    for c in range(int(g["n_cases"])):
+        env = RecorderEnv(_ScriptedStream(g, c), eval_config=dict(neighbours_distance=float(g["c%d_in_distance" % c])))
+        env.reset()
+        T = g["c%d_in_present" % c].shape[0]
+        q = 0
+        for t in range(T):
+            _, _, d, _ = env.step({})
+            if t in (5, 17):
+                sr = env.get_step_result()
+                assert sorted(sr) == list(g["c%d_step%d_keys" % (c, q)])
+                np.testing.assert_allclose([float(sr[k]) for k in sorted(sr)], g["c%d_step%d_vals" % (c, q)], rtol=1e-12, atol=1e-12)
+                q += 1
+        assert d["__all__"]
+        res = env.get_episode_result()
+        assert sorted(res) == list(g["c%d_keys" % c]) and len(res) == 31
+        np.testing.assert_allclose([float(res[k]) for k in sorted(res)], g["c%d_vals" % c], rtol=1e-12, atol=1e-12)
+    # the survey's known-answer scene (a0 (0,0), a1 (3,4), a2 (30,0), a3 (100,0)) through the evaluation-side distance map
+    from types import SimpleNamespace
+    dm = DistanceMap()
+    dm.update_distance_map({k: SimpleNamespace(position=p) for k, p in
+                            zip(["a0", "a1", "a2", "a3"], [(0, 0), (3, 4), (30, 0), (100, 0)])})
+    assert dm.find_in_range("a0", 40) == ["a1", "a2"] and dm.find_in_range("a2", 40) == ["a1", "a0"] and dm.find_in_range("a3", 40) == []
+    own, nei, cnt = dm.get_rewards(dict(a0=1.0, a1=2.0, a2=3.0, a3=4.0), 40)
+    assert (nei["a0"], nei["a1"], nei["a2"], nei["a3"]) == (2.5, 2.0, 1.5, 4.0) and cnt["a3"] == 0

@@ -406,3 +406,32 @@ def test_launch_scripts_run(script, tmp_path):
                        text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "timesteps_total" in r.stdout
+
+
+def test_evaluate_once_through_recorder_env(tmp_path):
+    """f-1: `evaluate_once` + `get_make_env` + `RecorderEnv` on the HIP simulator's dict API: a freshly exported IPPO
+    population (the reference's `.npz` layout) rolls two episodes and yields the 31-column evaluation rows."""
+    from copo_amd.eval.checkpoint_io import export_policy_npz
+    from copo_amd.eval.evaluate_population import evaluate_once, get_make_env
+    from copo_amd.torch_copo import algo_ippo
+    from copo_amd.torch_copo.utils import env_wrappers as W
+    a = algo_ippo.IPPOTrainer(config=dict(env=W.get_rllib_compatible_env(W.MultiAgentIntersectionEnv),
+                                          env_config=dict(num_agents=30), num_envs=8, train_batch_size=64, seed=0))
+    os.makedirs(tmp_path / "best_checkpoints")
+    export_policy_npz(a.policy.model, str(tmp_path / "best_checkpoints" / "ippo_inter.npz"), layout="tf")
+    a.stop()
+    make_env = get_make_env("inter")
+    env = make_env()
+    assert env.observation_space["agent0"].shape == (91,) and env.eval_config["neighbours_distance"] == 20
+    env.close()
+
+    def short_env():      # 120-step episodes keep the test quick; the scene is the default 30-agent Intersection otherwise
+        from copo_amd.eval.recoder import RecorderEnv
+        return RecorderEnv(W.MultiAgentIntersectionEnv(dict(num_agents=30, crash_done=True, horizon=120)))
+
+    df = evaluate_once("ippo_inter", short_env, num_episodes=2, root=str(tmp_path), out_dir=str(tmp_path / "res"), verbose=False)
+    assert len(df) == 2 and os.path.isfile(tmp_path / "res" / "ippo_inter.csv")
+    for col in ("success_rate", "crash_rate", "out_rate", "velocity_step_mean_episode_mean", "energy_step_mean_episode_mean",
+                "episode_reward_mean", "episode_cost_sum", "num_agents_total", "svo_estimate_deg_mean", "episode"):
+        assert col in df.columns and np.isfinite(df[col]).all(), col
+    assert (df["num_agents_total"] >= 30).all() and ((df["success_rate"] + df["crash_rate"] + df["out_rate"]) <= 1.0 + 1e-9).all()
