@@ -396,6 +396,17 @@ class PPOPolicyBase:
         for _ in range(self.SGD_CHAIN):
             self.fused.step(self._row_sources, stats=self.fused.stats)
 
+    # data-parallel path, opt-in (COPO_DIST_CHAIN=K): K x [gradient pass, all-reduce, Adam] captured in one graph, the
+    # collective included.  torch.distributed + RCCL capture and replay it on this stack (scripts/micro/nccl_graph_probe.py,
+    # one rank); it stays off by default until it has run on a multi-GPU node.
+    DIST_CHAIN = int(os.environ.get("COPO_DIST_CHAIN", "0"))
+
+    def _fused_dist_chain(self):
+        for _ in range(self.DIST_CHAIN):
+            self.fused.step(self._row_sources, apply_adam=False, stats=self.fused.stats, bump_index=False)
+            D.all_reduce_sum_(self.fused.grad)
+            self.fused.adam(self._row_sources)
+
     def _fused_grads(self):
         self.fused.step(self._row_sources, apply_adam=False, stats=self.fused.stats, bump_index=False)
 
@@ -415,6 +426,7 @@ class PPOPolicyBase:
                 self._sgd = (GraphedCallable(self._fused_grads, self.use_graphs),
                              GraphedCallable(self._fused_apply, self.use_graphs),
                              GraphedCallable(self._fused_apply_then_grads, self.use_graphs))
+                self._sgd_dist_chain = GraphedCallable(self._fused_dist_chain, self.use_graphs) if self.DIST_CHAIN > 0 else None
             else:
                 self._sgd = GraphedCallable(self._fused_local, self.use_graphs)
                 self._sgd_chain = GraphedCallable(self._fused_local_chain, self.use_graphs)
@@ -431,11 +443,16 @@ class PPOPolicyBase:
                     self._sgd_chain()
                     _k0 += self.SGD_CHAIN
                     steps += self.SGD_CHAIN
+            if D.is_dist() and self.use_graphs and getattr(self, "_sgd_dist_chain", None) is not None:
+                while _k0 + self.DIST_CHAIN <= n_mb:
+                    self._sgd_dist_chain()
+                    _k0 += self.DIST_CHAIN
+                    steps += self.DIST_CHAIN
             for _k in range(_k0, n_mb):
                 if D.is_dist():
                     # two host calls per minibatch: [Adam of the previous one + this gradient pass], all-reduce; the
                     # last Adam of the epoch is flushed before the next plan resets the minibatch index
-                    self._sgd[0 if _k == 0 else 2]()
+                    self._sgd[0 if _k == _k0 else 2]()
                     D.all_reduce_sum_(fz.grad)
                     if _k == n_mb - 1:
                         self._sgd[1]()
