@@ -249,8 +249,59 @@ def parkinglot(spaces=8, aisle_half=40.0, lane_width=LANE_WIDTH, turn_radius=5.0
     return b.finish()
 
 
+def pgmap(sequence="SCS", seed=0, lanes=2, lane_width=LANE_WIDTH, lead=50.0, spawns_per_lane=5, spawn_gap=9.0):
+    """Two-way road assembled from a block sequence, in the manner of MetaDrive's procedurally generated maps (the
+    `MultiAgentMetaDrive` env of train_all_copo_dist.py:10,30): `S` = straight of 40-80 m, `C` = curve of radius 30-60 m
+    through 30-90 degrees to a random side; an int `sequence` draws that many blocks.  Everything random comes from
+    `seed`, so a (sequence, seed) pair names one map.  `lead` metres of straight road at both ends hold the spawn points;
+    vehicles enter at one end and leave at the other.  Junction blocks (ramps, roundabouts, intersections inside a chain)
+    are not generated."""
+    rng = np.random.RandomState(int(seed))
+    if isinstance(sequence, (int, np.integer)):
+        sequence = "".join("SC"[int(rng.randint(2))] for _ in range(int(sequence)))
+    centre, heading = [], 0.0
+    for ch in str(sequence):
+        if ch == "S":
+            centre.append((float(rng.uniform(40.0, 80.0)), 0.0))
+        elif ch == "C":
+            radius, ang = float(rng.uniform(30.0, 60.0)), math.radians(float(rng.uniform(30.0, 90.0)))
+            side = 1.0 if rng.rand() < 0.5 else -1.0
+            if abs(heading + side * ang) > math.radians(120.0):     # keep the chain from folding back over itself
+                side = -side
+            heading += side * ang
+            centre.append((radius * ang, side / radius))
+        else:
+            raise ValueError("pgmap block %r: only S (straight) and C (curve) are generated" % ch)
+    if len(centre) + 2 > MAX_SEGS:
+        raise ValueError("pgmap: %d blocks + 2 lead pieces > %d route segments" % (len(centre), MAX_SEGS))
+    chain = [(lead, 0.0)] + centre + [(lead, 0.0)]
+    rec, total, nseg = build_route(0.0, 0.0, 0.0, chain)
+    xe, ye, the = float(rec[nseg][0]), float(rec[nseg][1]), float(rec[nseg][7])
+    # shift the road so that the midpoint of its two ends is the origin (scenes are centred like the other maps)
+    ox, oy = -0.5 * xe, -0.5 * ye
+    b = _Builder("pgmap", 20, 0.5 * total)
+    w = lane_width
+    offs = [2.0 + spawn_gap * k for k in range(spawns_per_lane)]
+    if offs[-1] >= lead:
+        raise ValueError("pgmap: spawn points do not fit on the %.0f m lead" % lead)
+
+    def offset_right(pieces, a):       # the lane `a` metres to the right of a centre line
+        return [(ln * (1.0 + k * a), k / (1.0 + k * a)) for ln, k in pieces]
+
+    for direction in range(2):
+        if direction == 0:
+            x, y, th, pieces = ox, oy, 0.0, chain
+        else:
+            x, y, th, pieces = xe + ox, ye + oy, the + math.pi, [(ln, -k) for ln, k in reversed(chain)]
+        for lane in range(lanes):
+            a = w * (0.5 + lane)
+            pose = (x + a * math.sin(th), y - a * math.cos(th), th)
+            b.add_entry(pose, [offset_right(pieces, a)], a, w * lanes - a, offs)
+    return b.finish()
+
+
 MAP_BUILDERS = dict(intersection=intersection, roundabout=roundabout, tollgate=tollgate, parkinglot=parkinglot,
-                    bottleneck=bottleneck)
+                    bottleneck=bottleneck, pgmap=pgmap)
 
 
 def bounding_box(tables: MapTables, step=2.0):

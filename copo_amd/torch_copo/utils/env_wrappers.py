@@ -20,6 +20,7 @@ import numpy as np
 
 from copo_amd import _capi
 from copo_amd.engine import Box, DictSpace
+from copo_amd.maps import MAP_BUILDERS
 from copo_amd.sim import SimConfig, VecSim
 
 _ENV_REGISTRY = {}
@@ -54,7 +55,7 @@ def lookup_env(name_or_cls):
 class MultiAgentMetaDrive:
     """Vectorised multi-agent driving env.  `config` keys: every `SimConfig` field plus the reference's
     `num_agents`, `start_seed`, `horizon`, `neighbours_distance`, ... (unknown keys are kept in `.config`)."""
-    MAP = "intersection"
+    MAP = "pgmap"        # the base class is MetaDrive's procedurally generated road (train_all_copo_dist.py:10,30)
     ENABLE_LCF = False
     WRAPS_CC = False
 
@@ -66,6 +67,12 @@ class MultiAgentMetaDrive:
     def __init__(self, config=None):
         cfg = type(self).default_config()
         cfg.update(config or {})
+        if isinstance(cfg["map"], int) or cfg["map"] not in MAP_BUILDERS:
+            # MetaDrive's `map` config key: a block count or a block-sequence string -> one seeded PG road
+            kw = dict(cfg.get("map_kwargs") or {})
+            kw.setdefault("sequence", cfg["map"])
+            kw.setdefault("seed", int(cfg.get("start_seed", 0)))
+            cfg["map"], cfg["map_kwargs"] = "pgmap", kw
         self.config = cfg
         sim_kwargs = {k: v for k, v in cfg.items() if k in SIM_KEYS and k not in ("enable_lcf",)}
         sim_kwargs["enable_lcf"] = bool(self.ENABLE_LCF and cfg.get("enable_copo", True))

@@ -67,6 +67,30 @@ def test_map_tables(name):
     assert d.min() > 3.0
 
 
+def test_generated_roads_are_seeded_and_drivable():
+    """PG road (the `MultiAgentMetaDrive` base env): a (sequence, seed) pair names one map, opposite carriageways stay a
+    lane width apart through every block, and lane-keeping agents reach the far end in the oracle simulator."""
+    a, b, c = maps.pgmap("SCSC", 3), maps.pgmap("SCSC", 3), maps.pgmap("SCSC", 4)
+    assert np.array_equal(a.route_segs, b.route_segs) and not np.array_equal(a.route_segs, c.route_segs)
+    assert maps.pgmap(4, 9).n_routes == 4 and maps.pgmap(4, 9, lanes=3).n_routes == 6
+    with pytest.raises(ValueError):
+        maps.pgmap("SXS", 0)
+    with pytest.raises(ValueError):
+        maps.pgmap(7, 0)                      # 7 blocks + 2 leads > MAX_SEGS
+    for seq, seed in [("CCC", 1), ("SCSCSC", 3), (6, 7)]:
+        t = maps.pgmap(seq, seed)
+        fwd = maps.route_points(t, 0, 0.5)[:, :2]
+        rev = maps.route_points(t, 2, 0.5)[:, :2]
+        d = np.linalg.norm(fwd[:, None] - rev[None], axis=-1).min(1)
+        assert 3.49 < d.min() and d.max() < 3.52          # inner lanes of the two directions: one lane width apart
+    cfg = SimConfig(map="pgmap", map_kwargs=dict(sequence="SCS", seed=5), num_envs=2, num_agents=12, horizon=400)
+    s, hist = _rollout(cfg, 380)
+    flags = np.stack([h["flags"] for h in hist])
+    assert ((flags & 4) > 0).sum() > 0, "lane keeping must bring some vehicles to the end of a generated road"
+    assert ((flags & 16) > 0).sum() <= ((flags & 4) > 0).sum(), "more vehicles leave the road than arrive"
+    s.close()
+
+
 def _rollout(cfg, steps, seed=0, policy="cruise"):
     s = ol.OracleSim(cfg)
     o = s.reset()

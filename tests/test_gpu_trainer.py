@@ -145,6 +145,8 @@ def test_dict_env_api_matches_reference_surface():
                                                     train_batch_size=256)),
     # f-4: the Bottleneck map (20 agents, eval/evaluate_population.py:118-124)
     ("Bottleneck", "copo", "MultiAgentBottleneckEnv", dict(num_envs=32, env_config=dict(num_agents=20))),
+    # f-4: the procedurally generated road of the base env (train_all_copo_dist.py:30), MetaDrive's `map` key = block count
+    ("PG", "copo", "MultiAgentMetaDrive", dict(num_envs=32, env_config=dict(map=4, start_seed=5000))),
 ])
 def test_baseline_parity_configs_run(name, algo, map_cls, cfg):
     """The other BASELINE.json configurations (parity-test cases, not bench lines): shapes, dtypes and a few
@@ -164,6 +166,8 @@ def test_baseline_parity_configs_run(name, algo, map_cls, cfg):
         assert a.policy.model.get_centralized_critic_obs_dim() == 2 * 91 + 2
     if name == "C5":
         assert a.env.sim.O == 260 and a.sampler.T == 1
+    if name == "PG":
+        assert a.env.sim.cfg.map == "pgmap" and a.env.sim.cfg.map_kwargs == dict(sequence=4, seed=5000) and a.env.sim.N == 20
     for _ in range(4):
         res = a.train()
     st = res["info"]["learner"]["default"]["learner_stats"]
