@@ -23,16 +23,28 @@ T = max(1, -(-2000 // a.num_envs))
 algo = cls(config=dict(env=env, env_config=dict(num_agents=a.num_agents), num_envs=a.num_envs, train_batch_size=T * a.num_envs,
                        seed=0, callbacks=MultiAgentDrivingCallbacks))
 t0 = time.time()
-print("# %s %s E=%d N=%d: iter env_steps agent_steps wall_s success crash out max_step ep_reward lcf kl" % (a.algo, a.map, a.num_envs, a.num_agents))
+print("# %s %s E=%d N=%d: iter env_steps agent_steps wall_s success crash out max_step ep_reward lcf kl agents_finished velocity_m_s episode_len (rates over the agents that finished since the previous line)" % (a.algo, a.map, a.num_envs, a.num_agents))
+KEYS = ("success_rate_mean", "crash_rate_mean", "out_of_road_rate_mean", "max_step_rate_mean", "episode_reward_mean")
+win = dict.fromkeys(KEYS, 0.0)      # rates over ALL agents that terminated since the last printed line
+win_n = 0.0
 while True:
     r = algo.train()
     it = r["training_iteration"]
+    cm = r["custom_metrics"]
+    nd = cm.get("num_terminated_agents", 0.0)
+    if nd > 0:
+        win_n += nd
+        for k in KEYS:
+            win[k] += cm[k] * nd
     if it % a.every == 0 or r["timesteps_total"] >= a.stop:
         mu = r["info"]["learner"]["default"]["custom_metrics"].get("meta_update", {})
         st = r["info"]["learner"]["default"]["learner_stats"]
-        print("%4d %8d %9d %6.1f  %.3f %.3f %.3f %.3f  %7.2f  %+.4f %.4f" % (
-            it, r["timesteps_total"], r["agent_timesteps_total"], time.time() - t0, r["success"], r["crash"], r["out"],
-            r["max_step"], r["episode_reward_mean"], mu.get("lcf", float("nan")), st["kl"]), flush=True)
+        m = [win[k] / win_n if win_n > 0 else float("nan") for k in KEYS]
+        print("%4d %8d %9d %6.1f  %.3f %.3f %.3f %.3f  %7.2f  %+.4f %.4f  %d %.2f %.0f" % (
+            it, r["timesteps_total"], r["agent_timesteps_total"], time.time() - t0, m[0], m[1], m[2], m[3], m[4],
+            mu.get("lcf", float("nan")), st["kl"], int(win_n), cm.get("velocity_mean", float("nan")),
+            cm.get("episode_length_mean", float("nan"))), flush=True)
+        win, win_n = dict.fromkeys(KEYS, 0.0), 0.0
     if r["timesteps_total"] >= a.stop:
         break
 algo.stop()
