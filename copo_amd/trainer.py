@@ -56,7 +56,9 @@ class GraphedCallable:
             torch.cuda.current_stream().wait_stream(s)
             return
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # with a process group alive its watchdog thread polls events while we capture: thread-local capture mode keeps
+        # another thread's runtime calls from invalidating this thread's capture
+        with torch.cuda.graph(g, capture_error_mode="thread_local" if D.is_dist() else "global"):
             self.fn()
         self.graph = g
         g.replay()
