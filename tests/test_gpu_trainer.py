@@ -135,6 +135,9 @@ def test_dict_env_api_matches_reference_surface():
 
 
 @pytest.mark.parametrize("name,algo,map_cls,cfg", [
+    # BASELINE.json configs[0]: IPPO Intersection, 4 agents, one scene (the reference's own CPU-runnable case, train_ippo.py)
+    ("C1", "ippo", "MultiAgentIntersectionEnv", dict(num_envs=1, env_config=dict(num_agents=4), train_batch_size=200,
+                                                      sgd_minibatch_size=64)),
     # BASELINE.json configs[2]: CoPO Roundabout, 40 agents, the 128-scene shard one GPU of the 8-GPU run owns
     ("C3-shard", "copo", "MultiAgentRoundaboutEnv", dict(num_envs=128, env_config=dict(num_agents=40))),
     # configs[3]: CCPPO mean-field on the Tollgate road, 40 agents, bf16 MLPs (losses / advantages stay fp32)
@@ -143,6 +146,8 @@ def test_dict_env_api_matches_reference_surface():
     # configs[4]: CoPO ParkingLot, 10 agents, 240-beam LiDAR (O = 260), LCF meta-update after every env step
     ("C5", "copo", "MultiAgentParkingLotEnv", dict(num_envs=256, env_config=dict(num_agents=10, num_lasers=240),
                                                     train_batch_size=256)),
+    ("C5-full", "copo", "MultiAgentParkingLotEnv", dict(num_envs=4096, env_config=dict(num_agents=10, num_lasers=240),
+                                                         train_batch_size=4096)),
     # f-4: the Bottleneck map (20 agents, eval/evaluate_population.py:118-124)
     ("Bottleneck", "copo", "MultiAgentBottleneckEnv", dict(num_envs=32, env_config=dict(num_agents=20))),
     # f-4: the procedurally generated road of the base env (train_all_copo_dist.py:30), MetaDrive's `map` key = block count
@@ -151,11 +156,13 @@ def test_dict_env_api_matches_reference_surface():
 def test_baseline_parity_configs_run(name, algo, map_cls, cfg):
     """The other BASELINE.json configurations (parity-test cases, not bench lines): shapes, dtypes and a few
     iterations with finite statistics."""
-    from copo_amd.torch_copo import algo_ccppo, algo_copo
+    from copo_amd.torch_copo import algo_ccppo, algo_copo, algo_ippo
     from copo_amd.torch_copo.utils import env_wrappers as W
     base = getattr(W, map_cls)
     if algo == "copo":
         cls, env = algo_copo.CoPOTrainer, W.get_rllib_compatible_env(W.get_lcf_env(base))
+    elif algo == "ippo":
+        cls, env = algo_ippo.IPPOTrainer, W.get_rllib_compatible_env(base)
     else:
         cls, env = algo_ccppo.CCPPOTrainer, algo_ccppo.get_ccppo_env(base)
     cfg = dict(cfg, env=env, seed=0)
@@ -164,7 +171,9 @@ def test_baseline_parity_configs_run(name, algo, map_cls, cfg):
     if name == "C4":
         assert a.policy.fused is None and a.policy.autocast_dtype == torch.bfloat16
         assert a.policy.model.get_centralized_critic_obs_dim() == 2 * 91 + 2
-    if name == "C5":
+    if name == "C1":
+        assert a.env.sim.O == 91 and a.env.sim.N == 4 and a.sampler.T == 200 and a.policy.fused is not None
+    if name.startswith("C5"):
         assert a.env.sim.O == 260 and a.sampler.T == 1
     if name == "PG":
         assert a.env.sim.cfg.map == "pgmap" and a.env.sim.cfg.map_kwargs == dict(sequence=4, seed=5000) and a.env.sim.N == 20
