@@ -270,3 +270,44 @@ def test_maximum_population_bit_exact():
     assert most == 64
     g.close()
     o.close()
+
+
+@pytest.mark.parametrize("name,map_name,N,E,lasers,steps", [
+    ("C2", "intersection", 40, 256, 72, 120),        # BASELINE configs[1], the bench workload
+    ("C3", "roundabout", 40, 1024, 72, 60),          # configs[2], all 1024 scenes on one GPU
+    ("C5", "parkinglot", 10, 4096, 240, 60),         # configs[4], 240 beams
+    ("saturated", "intersection", 40, 16384, 72, 30),   # the scene count of the saturated roofline figure
+])
+def test_full_size_configs_on_sampled_scenes(name, map_name, N, E, lasers, steps):
+    """BASELINE.json's full sizes: scenes never interact and a scene's random streams hang on its seed alone, so the oracle
+    steps a SAMPLE of the scenes (first, last, a few in between) with the same seeds and actions and must reproduce those
+    scenes of the full-size HIP rollout bit for bit; over all scenes, the outputs must not depend on the workgroup size."""
+    import torch
+    import oracle_lib as ol
+    from copo_amd.sim import SimConfig, VecSim
+    kw = dict(map=map_name, num_agents=N, num_lasers=lasers, horizon=40, delay_done=5)
+    pick = np.unique(np.r_[0, E - 1, np.random.RandomState(E).randint(0, E, 4)])
+    g, g2, o = VecSim(SimConfig(num_envs=E, **kw)), VecSim(SimConfig(num_envs=E, **kw)), ol.OracleSim(SimConfig(num_envs=len(pick), **kw))
+    g2.set_block(256 if E <= 256 else 1024)          # the other launch shape than the default for this scene count
+    seeds = np.arange(E, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(77)
+
+    def sub(out):
+        return {k: v[torch.from_numpy(pick).to(v.device)] for k, v in out.items() if k in OUT_KEYS}
+
+    go, go2 = g.reset(seeds), g2.reset(seeds)
+    _compare("%s reset" % name, sub(go), o.reset(seeds[pick]))
+    gen = torch.Generator(device="cuda").manual_seed(E)
+    for t in range(steps):
+        a = torch.stack([torch.randn(E, N, device="cuda", generator=gen) * 0.12,
+                         torch.rand(E, N, device="cuda", generator=gen) * 1.2 - 0.2], -1).contiguous()
+        go, go2 = g.step(a), g2.step(a)
+        _compare("%s step %d" % (name, t), sub(go), o.step(a[torch.from_numpy(pick).cuda()].cpu().numpy()))
+        for k in OUT_KEYS:
+            present = ((go["flags"] & 0x41) != 0)
+            x, y = go[k], go2[k]
+            if k == "obs":                     # rows of absent slots are not written (copo_hip.h)
+                x, y = x[present], y[present]
+            assert torch.equal(x.view(torch.uint8) if x.dtype != torch.float32 else x.view(torch.int32),
+                               y.view(torch.uint8) if y.dtype != torch.float32 else y.view(torch.int32)), (name, t, k)
+    for s in (g, g2, o):
+        s.close()
