@@ -143,6 +143,8 @@ def test_dict_env_api_matches_reference_surface():
     # configs[3]: CCPPO mean-field on the Tollgate road, 40 agents, bf16 MLPs (losses / advantages stay fp32)
     ("C4", "ccppo", "MultiAgentTollgateEnv", dict(num_envs=64, env_config=dict(num_agents=40), fuse_mode="mf",
                                                    policy_dtype="bfloat16")),
+    ("C4-full", "ccppo", "MultiAgentTollgateEnv", dict(num_envs=512, env_config=dict(num_agents=40), fuse_mode="mf",
+                                                        policy_dtype="bfloat16", train_batch_size=1024)),
     # configs[4]: CoPO ParkingLot, 10 agents, 240-beam LiDAR (O = 260), LCF meta-update after every env step
     ("C5", "copo", "MultiAgentParkingLotEnv", dict(num_envs=256, env_config=dict(num_agents=10, num_lasers=240),
                                                     train_batch_size=256)),
@@ -168,7 +170,7 @@ def test_baseline_parity_configs_run(name, algo, map_cls, cfg):
     cfg = dict(cfg, env=env, seed=0)
     cfg.setdefault("train_batch_size", cfg["num_envs"] * 4)
     a = cls(config=cfg)
-    if name == "C4":
+    if name.startswith("C4"):
         assert a.policy.fused is None and a.policy.autocast_dtype == torch.bfloat16
         assert a.policy.model.get_centralized_critic_obs_dim() == 2 * 91 + 2
     if name == "C1":
