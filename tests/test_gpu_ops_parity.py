@@ -167,6 +167,24 @@ def test_cc_fuse_vs_oracle(mode, cf):
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
+@pytest.mark.parametrize("mode,cf", [("mf", True), ("concat", True)])
+def test_cc_fuse_at_the_bench_batch(mode, cf):
+    """BASELINE configs[1]: one rollout fragment of the bench workload, 8 steps x 256 scenes x 40 slots = 81,920 rows."""
+    import oracle_lib as ol
+    rng = np.random.RandomState(12)
+    R, N, O, A, K = 8 * 256, 40, 92, 2, 8
+    obs = rng.uniform(-1, 1, (R, N, O)).astype(np.float32)
+    act = rng.normal(0, 1, (R, N, A)).astype(np.float32)
+    flags = (rng.uniform(size=(R, N)) > 0.4).astype(np.uint8)
+    cnt = rng.randint(0, 12, (R, N))
+    others = np.argsort(rng.uniform(size=(R, N, N - 1)), axis=-1)[..., :K].astype(np.int32)     # K distinct others per row
+    others += (others >= np.arange(N)[None, :, None])                                           # skip the row's own slot
+    nbr_idx = np.where(np.arange(K)[None, None, :] < np.minimum(cnt, K)[..., None], others, -1).astype(np.int32)
+    a = hip_cc_fuse(mode, obs, act, flags, nbr_idx, cnt, cf)
+    b = ol.cc_fuse(mode, obs, act, flags, nbr_idx, cnt, cf)
+    assert a.shape[0] * a.shape[1] == 81920 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
 def hip_lcf_mix(adv, nei, glob, lcf, valid=None):
     import torch
     from copo_amd import _capi
