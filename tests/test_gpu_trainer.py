@@ -450,3 +450,28 @@ def test_evaluate_once_through_recorder_env(tmp_path):
                 "episode_reward_mean", "episode_cost_sum", "num_agents_total", "svo_estimate_deg_mean", "episode"):
         assert col in df.columns and np.isfinite(df[col]).all(), col
     assert (df["num_agents_total"] >= 30).all() and ((df["success_rate"] + df["crash_rate"] + df["out_rate"]) <= 1.0 + 1e-9).all()
+
+
+def test_bench_harness_with_two_ranks_on_one_gpu():
+    """bench.py the way the driver launches it for N > 1 (one process per rank, env rendezvous), here two ranks sharing
+    cuda:0 over gloo: both ranks reach the barriers, rank 0 alone prints ONE JSON line whose value counts both shards."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29571",
+                   COPO_DIST_BACKEND="gloo", COPO_FORCE_DIST="0")
+        procs.append(subprocess.Popen([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--num-envs", "32"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=root))
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    lines0 = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
+    assert len(lines0) == 1 and not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]
+    r = json.loads(lines0[0])
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["config"]["parallelism"] == "dp2" and "cpu_baseline" not in r
+    per_rank_iter = r["config"]["agent_steps_per_iter"]
+    assert abs(r["value"] * r["ms_per_step"] * 1e-3 - 2 * per_rank_iter) <= 1e-3 * 2 * per_rank_iter    # both shards counted
+    assert outs[0][0].strip().splitlines()[-1] == lines0[0]        # the JSON is the last line of stdout
