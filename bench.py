@@ -150,6 +150,41 @@ def measure_learner_step(trainer, launches=200):
     return total_ms * 1e-3 / done, flops
 
 
+def measure_phases(trainer, iters=4):
+    """Synchronised wall clock around the phases of a few extra iterations (outside the timed region, single process only):
+    rollout + postprocess, PPO epochs, LCF meta passes -- the sample_throughput / learn_throughput split of SURVEY 8d."""
+    acc = {}
+
+    def wrap(obj, name, label):
+        f = getattr(obj, name)
+
+        def g(*a, **k):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = f(*a, **k)
+            torch.cuda.synchronize()
+            acc[label] = acc.get(label, 0.0) + time.perf_counter() - t0
+            return r
+        setattr(obj, name, g)
+        return obj, name, f
+
+    saved = [wrap(trainer, "collect", "sample"), wrap(trainer.policy, "run_sgd", "sgd"), wrap(trainer, "train", "iteration")]
+    if hasattr(trainer.policy, "run_meta"):
+        saved.append(wrap(trainer.policy, "run_meta", "meta"))
+    a0 = trainer._counters["num_agent_steps_sampled"]
+    for _ in range(iters):
+        trainer.train()
+    rows = (trainer._counters["num_agent_steps_sampled"] - a0) / iters
+    for obj, name, f in saved:
+        setattr(obj, name, f)
+    ms = {k: v / iters * 1e3 for k, v in acc.items()}
+    learn = ms.get("sgd", 0.0) + ms.get("meta", 0.0)
+    return {"sample_ms": round(ms.get("sample", 0.0), 3), "sgd_ms": round(ms.get("sgd", 0.0), 3), "meta_ms": round(ms.get("meta", 0.0), 3),
+            "iteration_ms": round(ms.get("iteration", 0.0), 3), "agent_steps_per_iter": round(rows, 1),
+            "sample_throughput": round(rows / max(ms.get("sample", 0.0), 1e-9) * 1e3, 1),
+            "learn_throughput": round(rows / max(learn, 1e-9) * 1e3, 1), "unit": "agent-steps/s (phase alone, synchronised)"}
+
+
 def cpu_baseline(num_envs, num_agents, iters=1):
     """The same iteration on the host: C oracle simulator (scalar, 1 thread) + oracle GAE / LCF-mix + the build's
     own torch learner on CPU threads.  Test infrastructure used as the measured CPU port, never as product."""
@@ -291,6 +326,8 @@ def main():
                 "achieved": round(l_flops / l_s * 1e-12, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(l_flops / l_s * 1e-12 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
                 "us_per_step": round(l_s * 1e6, 2), "flops_per_step": int(l_flops)}
+        if world == 1:
+            line["phases"] = measure_phases(trainer)
         if world == 1 and not args.no_cpu_baseline:
             v, cdt, n, used = cpu_baseline(args.num_envs, args.num_agents)
             line["cpu_baseline"] = {"value": round(v, 1), "unit": "agent-steps/s", "cores": used, "kind": "port",
