@@ -11,18 +11,10 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcopo_hip.so")
 
-MAX_AGENTS = 64
-MAX_SEGS = 8
-SEG_STRIDE = 8
-MAX_LASERS = 256
-MAX_SPAWNS = 256
-MAX_ROUTES = 128
-EGO_DIM = 9
-NAVI_DIM = 10
-INFO_DIM = 8
-STATE_FIELDS = 16
+from ._abi import (ABI_VERSION, INFO_DIM, LINE_STRIDE, MAX_AGENTS, MAX_LASERS, MAX_LINES, MAX_ROUTES, MAX_SAFE,  # noqa: F401
+                   MAX_SEGS, MAX_SPAWNS, NAVI_DIM, SEG_STRIDE, STATE_DIM, STATE_FIELDS, SimCfg, StepOut)
+
 LCF_STATS_DOUBLES = 8 + 6 * 2048
-ABI_VERSION = 1
 
 F_ACTED, F_DONE, F_ARRIVE, F_CRASH, F_OUT, F_MAXSTEP, F_SPAWNED, F_ENV_RESET = (1 << i for i in range(8))
 I_VELOCITY, I_STEERING, I_ACCELERATION, I_STEP_REWARD, I_COST, I_EPISODE_LENGTH, I_EPISODE_REWARD, \
@@ -36,34 +28,6 @@ class CopoError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("%s (%d): %s" % (ERR_NAMES.get(code, "?"), code, msg))
         self.code = code
-
-
-class SimCfg(C.Structure):
-    """Mirror of `copo_sim_cfg`."""
-    _fields_ = [
-        ("num_envs", C.c_int32), ("num_agents", C.c_int32), ("num_lasers", C.c_int32), ("obs_dim", C.c_int32),
-        ("nbr_k", C.c_int32), ("enable_lcf", C.c_int32), ("horizon", C.c_int32), ("delay_done", C.c_int32),
-        ("respawn_cooldown", C.c_int32), ("substeps", C.c_int32),
-        ("lidar_range", C.c_float), ("neighbours_distance", C.c_float), ("mf_distance", C.c_float),
-        ("dt", C.c_float), ("veh_half_len", C.c_float), ("veh_half_wid", C.c_float), ("wheelbase", C.c_float),
-        ("max_steer", C.c_float), ("max_speed", C.c_float), ("acc_max", C.c_float), ("brake_max", C.c_float),
-        ("drag", C.c_float), ("spawn_clearance", C.c_float),
-        ("driving_reward", C.c_float), ("speed_reward", C.c_float), ("success_reward", C.c_float),
-        ("crash_penalty", C.c_float), ("out_penalty", C.c_float), ("arrive_margin", C.c_float),
-        ("lane_width", C.c_float),
-        ("lcf_mean", C.c_double), ("lcf_std", C.c_double),
-        ("n_routes", C.c_int32), ("n_spawns", C.c_int32),
-        ("route_segs", C.c_void_p), ("route_meta", C.c_void_p), ("spawn_tab", C.c_void_p), ("spawn_s", C.c_void_p),
-        ("ray_cs", C.c_void_p),
-        ("add_traffic_light", C.c_int32), ("traffic_light_interval", C.c_int32), ("comm_size", C.c_int32),
-        ("comm_neighbours", C.c_int32), ("add_pos_in_comm", C.c_int32), ("map_bbox", C.c_float * 4),
-    ]
-
-
-class StepOut(C.Structure):
-    """Mirror of `copo_step_out` (device pointers, 0 = skip)."""
-    _fields_ = [(n, C.c_void_p) for n in ("obs", "rew", "nei_rew", "glob_rew", "flags", "nbr_idx", "nbr_cnt", "mf_cnt",
-                                          "nbr_dist", "lcf", "info", "agent_id")]
 
 
 class NetLayout(C.Structure):

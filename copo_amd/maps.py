@@ -1,35 +1,56 @@
-"""Route-table maps for the vectorised simulator (build-defined scenes).
+"""Road-network maps for the vectorised simulator.
 
-The reference gets its maps from MetaDrive's PG block library (`MultiAgent{Intersection,Roundabout,
-Tollgate,ParkingLot}Env`, train_copo.py:1-2), whose source is not in the reference tree.  Here a map is
-pure data consumed by `libcopo_hip.so`: a set of routes, each a start pose followed by (length,
-curvature) pieces, and a set of spawn points on the first (straight) piece of the routes.
+The reference gets its maps from MetaDrive 0.2.5's PG block library (`MultiAgent{Intersection,Roundabout,Tollgate,
+Bottleneck,ParkingLot}Env`, train_copo.py:1-2), whose source is not in the reference tree.  What is rebuilt here is the
+*structure* those environments hand to the observation / reward code, in the form the kernels consume:
 
-A vehicle's road is the corridor `[-lat_right, +lat_left]` around its route centreline, so maps with
-different topology differ only in these tables -- the HIP kernel is map-agnostic.
+* a map is a directed graph of ROADS; a road is one geometric primitive (a straight or a circular arc, like MetaDrive's
+  StraightLane / CircularLane) carrying `lanes` parallel lanes.  The primitive stored is the centre line of lane 0 (the
+  leftmost lane); lane i lies `i * lane_width` to its right (concentric for arcs);
+* vehicles spawn in slots on the SPAWN ROADS and are sent to the far end of the reverse of a random spawn road
+  (MetaDrive's `_update_destination_for`: `-choice(spawn_roads)`), over the breadth-first shortest road sequence;
+* a ROUTE = that road sequence.  `route_segs[r][k]` is one road of route r (COPO_SEG_STRIDE floats, see `SEG_*`),
+  including what the navigation observation needs per road (the check point at the road's end, the three curve features).
+
+Geometry pinned by self-consistency: the Intersection (turn radius 10, two lanes: right turns of radius 10 / 13.5, left
+turns 17 / 20.5, crossing 30.5 m, U-turn 1.75 / 5.25) and the Roundabout (exit radius 10, inner radius 30, angle 70 deg)
+follow the published block formulas; `tests/test_abi_and_sim_cpu.py` checks that the roundabout's ring closes to < 1 mm
+when every arm is built from its own entry, which only happens for the right connecting radius.
+Coordinates are right-handed (x east, y north, headings counter-clockwise); "left" is +lateral.
 """
 import math
+from collections import OrderedDict, deque
 from dataclasses import dataclass, field
 from typing import List, Tuple
 
 import numpy as np
 
-MAX_SEGS = 8          # COPO_MAX_SEGS
-SEG_STRIDE = 8        # COPO_SEG_STRIDE
-MAX_ARC = math.radians(100.0)  # arcs are split so that the in-kernel atan2 never wraps
+MAX_SEGS = 12         # COPO_MAX_SEGS: roads per route (a full turn of the roundabout is 11)
+SEG_STRIDE = 16       # COPO_SEG_STRIDE
 LANE_WIDTH = 3.5
+# columns of a segment (road) record
+(SEG_X0, SEG_Y0, SEG_COS, SEG_SIN, SEG_LEN, SEG_KAPPA, SEG_S0, SEG_TH0, SEG_CKX, SEG_CKY, SEG_LANES, SEG_F_RADIUS,
+ SEG_RADIUS, SEG_F_ANGLE, SEG_UMX, SEG_UMY) = range(16)
+
+NAVI_RADIUS_NORM = 60.0   # MetaDrive BlockParameterSpace.CURVE radius max; the feature divides by (this + lanes * width)
+NAVI_ANGLE_NORM = 135.0   # ... CURVE angle max (degrees)
+RESPAWN_REGION_LONGITUDE = 8.0   # MetaDrive SpawnManager: slot pitch and the box that must be free for a respawn
+RESPAWN_REGION_LATERAL = 3.0
+ENTRANCE_LENGTH = 10.0           # FirstPGBlock: the first 10 m of the first block are not a spawn road
 
 
 @dataclass
 class MapTables:
     name: str
-    route_segs: np.ndarray   # [R][MAX_SEGS+1][8] f32: x0, y0, cos0, sin0, len, kappa, s_start, theta0
-    route_meta: np.ndarray   # [R][4] f32: total_len, lat_left, lat_right, nseg
-    spawn_tab: np.ndarray    # [P][4] i32: first_route, n_choices, 0, 0
-    spawn_s: np.ndarray      # [P] f32
+    route_segs: np.ndarray   # [R][MAX_SEGS+1][SEG_STRIDE] f32
+    route_meta: np.ndarray   # [R][4] f32: total_len (lane-0 line), nseg, lanes of the final road, 0
+    spawn_tab: np.ndarray    # [P][4] i32: first_route, n_destinations, lane, safe (1 = a respawn place)
+    spawn_s: np.ndarray      # [P] f32 longitudinal position of the slot on the spawn road
     default_num_agents: int
+    lane_width: float = LANE_WIDTH
     extent: float = 100.0
     entries: List[Tuple[int, int]] = field(default_factory=list)
+    lines: np.ndarray = None  # [n][8] f32 lane-line primitives for the side / lane-line detectors (see `Net.lines`)
 
     @property
     def n_routes(self):
@@ -44,218 +65,354 @@ def _wrap(a):
     return (a + math.pi) % (2 * math.pi) - math.pi
 
 
-def build_route(x, y, th, pieces):
-    """Integrate (length, kappa) pieces from pose (x, y, th) in float64; returns [MAX_SEGS+1][8] + length."""
-    split = []
-    for ln, kap in pieces:
-        if ln <= 1e-9:
-            continue
-        n = 1 if kap == 0 else max(1, int(math.ceil(abs(kap) * ln / MAX_ARC)))
-        split += [(ln / n, kap)] * n
-    if len(split) > MAX_SEGS:
-        raise ValueError("route needs %d segments > MAX_SEGS" % len(split))
-    rec = np.zeros((MAX_SEGS + 1, SEG_STRIDE), np.float64)
-    s = 0.0
-    for k, (ln, kap) in enumerate(split):
-        rec[k] = [x, y, math.cos(th), math.sin(th), ln, kap, s, _wrap(th)]
-        if kap == 0:
-            x, y = x + math.cos(th) * ln, y + math.sin(th) * ln
-        else:
-            r = 1.0 / kap
-            x, y = x + r * (math.sin(th + kap * ln) - math.sin(th)), y - r * (math.cos(th + kap * ln) - math.cos(th))
-            th = th + kap * ln
-        s += ln
-    for k in range(len(split), MAX_SEGS + 1):   # terminal record(s): end pose, zero length
-        rec[k] = [x, y, math.cos(th), math.sin(th), 0.0, 0.0, s, _wrap(th)]
-    return rec, s, len(split)
+def advance(pose, length, kappa):
+    """Pose after `length` metres of constant curvature `kappa` (float64)."""
+    x, y, th = pose
+    if kappa == 0:
+        return x + math.cos(th) * length, y + math.sin(th) * length, th
+    r = 1.0 / kappa
+    return (x + r * (math.sin(th + kappa * length) - math.sin(th)),
+            y - r * (math.cos(th + kappa * length) - math.cos(th)), th + kappa * length)
 
 
-def _rot(x, y, th, q):
-    c, s = math.cos(q), math.sin(q)
-    return c * x - s * y, s * x + c * y, th + q
+def shift(pose, left):
+    """Pose moved `left` metres to its left (negative: to the right)."""
+    x, y, th = pose
+    return x - math.sin(th) * left, y + math.cos(th) * left, th
+
+
+def reverse(pose):
+    return pose[0], pose[1], pose[2] + math.pi
+
+
+# lane-line kinds for the detectors (MetaDrive: the side detector sees continuous lines, the lane-line detector both)
+LINE_BROKEN, LINE_CONTINUOUS = 1.0, 2.0
+
+
+class Net:
+    """Directed road graph.  A road (a, b) = (lane-0 start pose, length, kappa of the lane-0 line, lanes)."""
+
+    def __init__(self, lane_width=LANE_WIDTH):
+        self.w = lane_width
+        self.roads = OrderedDict()
+        self.adj = OrderedDict()
+        self.lines = []          # [x0, y0, theta0, length, kappa, kind, 0, 0]
+
+    def add(self, a, b, pose, length, kappa, lanes, left_line=LINE_CONTINUOUS, right_line=LINE_CONTINUOUS,
+            inner_line=LINE_BROKEN):
+        """`pose` is the start of lane 0's centre line.  Line kinds: 0 = none (inside junctions)."""
+        assert (a, b) not in self.roads, (a, b)
+        self.roads[(a, b)] = (tuple(float(v) for v in pose), float(length), float(kappa), int(lanes))
+        self.adj.setdefault(a, []).append(b)
+        self.adj.setdefault(b, [])
+        w = self.w
+        for i in range(lanes + 1):   # boundary i lies (i - 0.5) * w to the right of lane 0
+            kind = left_line if i == 0 else (right_line if i == lanes else inner_line)
+            if kind:
+                a_off = -(i - 0.5) * w
+                p = shift(pose, a_off)
+                k = kappa / (1.0 - kappa * a_off) if kappa else 0.0
+                ln = length * (1.0 - kappa * a_off) if kappa else length
+                self.lines.append([p[0], p[1], p[2], ln, k, kind, 0.0, 0.0])
+        return advance(pose, length, kappa)
+
+    def end_pose(self, a, b):
+        pose, ln, k, _ = self.roads[(a, b)]
+        return advance(pose, ln, k)
+
+    def adverse(self, a, b, na, nb, **kw):
+        """CreateAdverseRoad: the opposite carriageway of road (a, b) as road (na, nb): same lane count, lane 0 next to
+        lane 0, i.e. the lane-0 lines are one lane width apart."""
+        pose, ln, k, lanes = self.roads[(a, b)]
+        end = advance(pose, ln, k)
+        start = reverse(shift(end, self.w))
+        kr = -k / (1.0 - k * self.w) if k else 0.0
+        lr = ln * (1.0 - k * self.w) if k else ln
+        return self.add(na, nb, start, lr, kr, lanes, **kw)
+
+    def bfs(self, src, dst):
+        """Node list of the shortest path by number of roads (ties: insertion order, as a queue-based search gives)."""
+        prev, q = {src: None}, deque([src])
+        while q:
+            u = q.popleft()
+            if u == dst:
+                break
+            for v in self.adj.get(u, []):
+                if v not in prev:
+                    prev[v] = u
+                    q.append(v)
+        if dst not in prev:
+            raise ValueError("no route %s -> %s" % (src, dst))
+        path = [dst]
+        while prev[path[-1]] is not None:
+            path.append(prev[path[-1]])
+        return path[::-1]
+
+
+def road_record(pose, length, kappa, lanes, s_start, w):
+    """One SEG_STRIDE record (float64) for a road whose lane-0 line starts at `pose`."""
+    x, y, th = pose
+    rec = np.zeros(SEG_STRIDE, np.float64)
+    rec[[SEG_X0, SEG_Y0, SEG_COS, SEG_SIN, SEG_LEN, SEG_KAPPA, SEG_S0, SEG_TH0]] = [
+        x, y, math.cos(th), math.sin(th), length, kappa, s_start, _wrap(th)]
+    end = advance(pose, length, kappa)
+    ck = shift(end, -(lanes / 2.0 - 0.5) * w)          # end of the road, lateral middle (Navigation check point)
+    rec[SEG_CKX], rec[SEG_CKY], rec[SEG_LANES] = ck[0], ck[1], lanes
+    if kappa == 0:
+        rec[SEG_F_RADIUS], rec[SEG_RADIUS], rec[SEG_F_ANGLE] = 0.0, 0.0, 0.5
+        rec[SEG_UMX], rec[SEG_UMY] = 1.0, 0.0
+    else:
+        radius, ang = 1.0 / abs(kappa), abs(kappa) * length
+        rec[SEG_F_RADIUS] = min(1.0, radius / (NAVI_RADIUS_NORM + lanes * w))
+        rec[SEG_RADIUS] = radius                        # (the direction feature is the sign of kappa: + = left)
+        rec[SEG_F_ANGLE] = min(1.0, (math.degrees(ang) / NAVI_ANGLE_NORM + 1.0) / 2.0)
+        sg = 1.0 if kappa > 0 else -1.0
+        # unit vector from the arc's centre to its mid point: the start radial -sg*n0 turned by sg*ang/2
+        ux, uy = sg * math.sin(th), -sg * math.cos(th)
+        c, s = math.cos(sg * ang / 2.0), math.sin(sg * ang / 2.0)
+        rec[SEG_UMX], rec[SEG_UMY] = c * ux - s * uy, s * ux + c * uy
+    return rec
 
 
 class _Builder:
-    def __init__(self, name, default_num_agents, extent):
-        self.name, self.n, self.extent = name, default_num_agents, extent
+    def __init__(self, name, net, default_num_agents, extent):
+        self.name, self.net, self.n, self.extent = name, net, default_num_agents, extent
         self.routes, self.meta, self.spawn_tab, self.spawn_s, self.entries = [], [], [], [], []
 
-    def add_entry(self, pose, route_pieces, lat_left, lat_right, spawn_offsets):
-        """One entry lane: `route_pieces` is a list of piece-lists (one per destination)."""
+    def add_route(self, nodes):
+        net, w = self.net, self.net.w
+        if len(nodes) - 1 > MAX_SEGS:
+            raise ValueError("route needs %d roads > MAX_SEGS" % (len(nodes) - 1))
+        rec = np.zeros((MAX_SEGS + 1, SEG_STRIDE), np.float64)
+        s, lanes = 0.0, 1
+        for k in range(len(nodes) - 1):
+            pose, ln, kap, lanes = net.roads[(nodes[k], nodes[k + 1])]
+            rec[k] = road_record(pose, ln, kap, lanes, s, w)
+            s += ln
+        end = net.end_pose(nodes[-2], nodes[-1])
+        nseg = len(nodes) - 1
+        for k in range(nseg, MAX_SEGS + 1):     # terminal record(s): end pose, zero length
+            rec[k] = road_record(end, 0.0, 0.0, lanes, s, w)
+        self.routes.append(rec)
+        self.meta.append([s, nseg, lanes, 0.0])
+
+    def add_spawn_road(self, road, destinations, slot_longs, safe_only_first=True, lanes=None):
+        """Routes from `road` (a, b) to every destination node; slots on each of its lanes at `slot_longs`."""
+        net = self.net
         first = len(self.routes)
-        seg0 = None
-        for pieces in route_pieces:
-            rec, total, nseg = build_route(*pose, pieces)
-            if rec[0][5] != 0.0:
-                raise ValueError("the first piece of a route must be straight (spawn pieces)")
-            seg0 = rec[0][4] if seg0 is None else min(seg0, rec[0][4])
-            self.routes.append(rec)
-            self.meta.append([total, lat_left, lat_right, nseg])
-        for s0 in spawn_offsets:
-            if s0 >= seg0:
-                raise ValueError("spawn offset %.1f beyond the first straight piece %.1f" % (s0, seg0))
-            self.spawn_tab.append([first, len(route_pieces), 0, 0])
-            self.spawn_s.append(s0)
-        self.entries.append((first, len(route_pieces)))
+        for d in destinations:
+            nodes = [road[0]] + net.bfs(road[1], d)
+            self.add_route(nodes)
+        n_l = net.roads[road][3] if lanes is None else lanes
+        if slot_longs and max(slot_longs) >= net.roads[road][1]:
+            raise ValueError("spawn slot beyond the spawn road")
+        for lane in range(n_l):
+            for j, s0 in enumerate(slot_longs):
+                self.spawn_tab.append([first, len(destinations), lane, 1 if (j == 0 or not safe_only_first) else 0])
+                self.spawn_s.append(s0)
+        self.entries.append((first, len(destinations)))
 
     def finish(self):
         return MapTables(
             self.name, np.asarray(self.routes, np.float64).astype(np.float32),
             np.asarray(self.meta, np.float64).astype(np.float32), np.asarray(self.spawn_tab, np.int32),
-            np.asarray(self.spawn_s, np.float32), self.n, self.extent, self.entries)
+            np.asarray(self.spawn_s, np.float32), self.n, self.net.w, self.extent, self.entries,
+            np.asarray(self.net.lines, np.float64).astype(np.float32).reshape(-1, 8))
 
 
-def intersection(exit_length=60.0, box=12.0, lane_width=LANE_WIDTH, spawns_per_lane=5, spawn_gap=9.0):
-    """4-way, 2 lanes per direction.  Inner lane: left + straight; outer lane: straight + right."""
-    b = _Builder("intersection", 30, box + exit_length)
-    J, L, w = box, exit_length, lane_width
-    offs = [2.0 + spawn_gap * k for k in range(spawns_per_lane)]
-    for arm in range(4):
-        q = arm * math.pi / 2
-        for lane in range(2):
-            a = w * (0.5 + lane)
-            pose = _rot(-(J + L), -a, 0.0, q)
-            straight = [(L, 0.0), (2 * J, 0.0), (L, 0.0)]
-            left = [(L, 0.0), ((J + a) * math.pi / 2, 1.0 / (J + a)), (L, 0.0)]
-            right = [(L, 0.0), ((J - a) * math.pi / 2, -1.0 / (J - a)), (L, 0.0)]
-            if lane == 0:
-                b.add_entry(pose, [left, straight], w * 0.5, w * 1.5, offs)
-            else:
-                b.add_entry(pose, [straight, right], w * 1.5, w * 0.5, offs)
+def spawn_slots(exit_length):
+    """SpawnManager._auto_fill_spawn_roads_randomly: floor(L / 8) slots, pitch L / slots, the first at 4 m."""
+    eff = exit_length - ENTRANCE_LENGTH
+    n = int(math.floor(eff / RESPAWN_REGION_LONGITUDE))
+    return [RESPAWN_REGION_LONGITUDE / 2 + j * (eff / n) for j in range(n)]
+
+
+def intersection(exit_length=60.0, radius=10.0, lanes=2, lane_width=LANE_WIDTH, u_turn=True):
+    """MAIntersectionMap: FirstPGBlock + InterSection(radius 10), `lanes` lanes per direction, every entry lane may turn
+    left / go straight / turn right, U-turns at the stop line when lanes > 1.  Arm 0 is the first block (entry road
+    50 m = exit_length - 10, its exit road as well), the other arms are 60 m."""
+    w, n = lane_width, lanes
+    net = Net(w)
+    half = radius + (2 * n - 1) * w / 2.0                # stop lines are this far from the junction centre
+    cx, cy = exit_length + half, w / 2.0                 # MetaDrive's frame: entry lane 0 of arm 0 runs along y = 0
+    r_right0 = radius + (n - 1) * w                      # lane 0 of a right turn (the rightmost lane has `radius`)
+    r_left0 = radius + n * w
+    arm_len = [exit_length - ENTRANCE_LENGTH] + [exit_length] * 3
+    for a in range(4):
+        psi = math.pi + a * math.pi / 2                  # outward direction of arm a (0 west, 1 south, 2 east, 3 north)
+        h = psi + math.pi
+        stop = (cx + half * math.cos(psi), cy + half * math.sin(psi), h)           # on the arm's axis, heading in
+        entry0 = shift(advance(stop, -arm_len[a], 0.0), -w / 2.0)
+        net.add("in%d" % a, "stop%d" % a, entry0, arm_len[a], 0.0, n)
+        exit0 = shift((stop[0], stop[1], psi), -w / 2.0)
+        net.add("out%d" % a, "end%d" % a, exit0, arm_len[a], 0.0, n)
+    for a in range(4):
+        e = net.end_pose("in%d" % a, "stop%d" % a)
+        net.add("stop%d" % a, "out%d" % ((a + 1) % 4), e, r_right0 * math.pi / 2, -1.0 / r_right0, n, 0, LINE_CONTINUOUS, 0)
+        net.add("stop%d" % a, "out%d" % ((a + 2) % 4), e, 2 * half, 0.0, n, 0, 0, 0)
+        net.add("stop%d" % a, "out%d" % ((a + 3) % 4), e, r_left0 * math.pi / 2, 1.0 / r_left0, n, 0, 0, 0)
+        if u_turn and n > 1:
+            net.add("stop%d" % a, "out%d" % a, e, (w / 2) * math.pi, 2.0 / w, n, 0, 0, 0)
+    b = _Builder("intersection", net, 30, half + exit_length)
+    slots = spawn_slots(exit_length)
+    dests = [d for d in range(4)]
+    for a in range(4):
+        ds = ["end%d" % d for d in dests if (d != a or (u_turn and n > 1))]
+        b.add_spawn_road(("in%d" % a, "stop%d" % a), ds, slots)
     return b.finish()
 
 
-def roundabout(exit_length=60.0, ring_radius=16.0, entry_radius=12.0, lane_width=LANE_WIDTH, spawns_per_lane=5,
-               spawn_gap=9.0):
-    """4-arm, 2-lane counter-clockwise ring.  Inner lane: straight + left; outer lane: right + straight."""
-    w, re_ = lane_width, entry_radius
-    geo = []
-    for lane in range(2):
-        a, R = w * (0.5 + lane), ring_radius + w * lane
-        xc = -math.sqrt((R + re_) ** 2 - (a + re_) ** 2)
-        geo.append((a, R, xc, math.asin(-xc / (R + re_))))
-    x_start = -(exit_length + max(-g[2] for g in geo))
-    b = _Builder("roundabout", 40, -x_start)
-    offs = [2.0 + spawn_gap * k for k in range(spawns_per_lane)]
-    for arm in range(4):
-        q = arm * math.pi / 2
-        for lane in range(2):
-            a, R, xc, al = geo[lane]
-            pose = _rot(x_start, -a, 0.0, q)
-            lead = xc - x_start
-
-            def route(k):
-                return [(lead, 0.0), (al * re_, -1.0 / re_), ((2 * al + (k - 2) * math.pi / 2) * R, 1.0 / R),
-                        (al * re_, -1.0 / re_), (lead, 0.0)]
-
-            if lane == 0:
-                b.add_entry(pose, [route(2), route(3)], w * 0.5, w * 1.5, offs)
-            else:
-                b.add_entry(pose, [route(1), route(2)], w * 1.5, w * 0.5, offs)
+def roundabout(exit_length=60.0, exit_radius=10.0, inner_radius=30.0, angle_deg=70.0, lanes=2, lane_width=LANE_WIDTH):
+    """MARoundaboutMap: FirstPGBlock + Roundabout(exit radius 10, inner radius 30, angle 70).  Per arm: entry bend (right,
+    `exit_radius` on the rightmost lane, `angle`), ring arc (left, radius_big, 2*angle - 90), exit bend (right), exit
+    straight; consecutive arms are joined by a ring arc of 180 - 2*angle whose radius `beneath / cos(angle) - exit_radius`
+    is the one that closes the ring."""
+    w, n = lane_width, lanes
+    net = Net(w)
+    ang = math.radians(angle_deg)
+    r_big = (2 * n - 1) * w + inner_radius                 # rightmost lane of the ring arcs
+    beneath = (2 * n - 1) * w / 2.0 + exit_radius
+    r_join = beneath / math.cos(ang) - exit_radius
+    lane0 = lambda r_rightmost, left_turn: (r_rightmost - (n - 1) * w) if left_turn else (r_rightmost + (n - 1) * w)
+    r_e0, r_b0, r_j0 = lane0(exit_radius, False), lane0(r_big, True), lane0(r_join, True)
+    arm_len = [exit_length - ENTRANCE_LENGTH] + [exit_length] * 3
+    entry0 = (ENTRANCE_LENGTH, 0.0, 0.0)                   # lane 0 of the first block's spawn road
+    for a in range(4):
+        e = net.add("in%d" % a, "stop%d" % a, entry0, arm_len[a], 0.0, n)
+        p = net.add("stop%d" % a, "r%da" % a, e, r_e0 * ang, -1.0 / r_e0, n, LINE_BROKEN, LINE_CONTINUOUS)
+        p1 = net.add("r%da" % a, "r%db" % a, p, r_b0 * (2 * ang - math.pi / 2), 1.0 / r_b0, n, LINE_CONTINUOUS, LINE_BROKEN)
+        p2 = net.add("r%db" % a, "out%d" % a, p1, r_e0 * ang, -1.0 / r_e0, n, LINE_BROKEN, LINE_CONTINUOUS)
+        nxt = (a + 1) % 4
+        net.add("out%d" % a, "end%d" % nxt, p2, arm_len[nxt], 0.0, n)
+        net.add("r%db" % a, "r%da" % nxt, p1, r_j0 * (math.pi - 2 * ang), 1.0 / r_j0, n, LINE_CONTINUOUS, LINE_BROKEN)
+        # the next arm's entry is the adverse carriageway of this exit (lane 0 one lane width to the left, reversed)
+        entry0 = reverse(shift(advance(p2, arm_len[nxt], 0.0), w))
+    b = _Builder("roundabout", net, 40, 120.0)
+    slots = spawn_slots(exit_length)
+    for a in range(4):
+        # arm a's traffic leaves through "end<d>"; end<a> (its own arm) means a full turn of the ring
+        b.add_spawn_road(("in%d" % a, "stop%d" % a), ["end%d" % d for d in range(4)], slots)
     return b.finish()
 
 
-def tollgate(length=140.0, lanes=3, lane_width=LANE_WIDTH, spawns_per_lane=7, spawn_gap=9.0):
-    """Two-direction straight road with `lanes` lanes each way (the gate itself is not modelled yet)."""
-    b = _Builder("tollgate", 40, length / 2)
+def _wave(net, a, mid, b, pose, shift_left, length, lanes, **kw):
+    """Two opposite arcs that move a road `shift_left` metres sideways over `length` metres (MetaDrive's
+    create_wave_lanes); a straight if there is nothing to move."""
+    if abs(shift_left) < 1e-9:
+        p = net.add(a, mid, pose, length / 2, 0.0, lanes, **kw)
+        return net.add(mid, b, p, length / 2, 0.0, lanes, **kw)
+    # two arcs of angle phi and radius r: lateral = 2 r (1 - cos phi), longitudinal = 2 r sin phi
+    phi = 2.0 * math.atan2(abs(shift_left), length)
+    r = length / (2.0 * math.sin(phi))
+    k = math.copysign(1.0 / r, shift_left)
+    p = net.add(a, mid, pose, r * phi, k, lanes, **kw)
+    return net.add(mid, b, p, r * phi, -k, lanes, **kw)
+
+
+def bottleneck(exit_length=60.0, bottle_lanes=4, neck_lanes=1, neck_length=20.0, taper=20.0, lane_width=LANE_WIDTH):
+    """MABottleneckMap: a two-way road that narrows from `bottle_lanes` to `neck_lanes` lanes per direction and widens
+    again (20 agents, eval/evaluate_population.py:118-124).  The leftmost `neck_lanes` lanes run straight into the neck;
+    every other entry lane has its own one-lane S-curve into the neck's last lane, and out again on the far side."""
     w = lane_width
-    offs = [2.0 + spawn_gap * k for k in range(spawns_per_lane)]
-    for direction in range(2):
-        q = direction * math.pi
-        for lane in range(lanes):
-            a = w * (0.5 + lane)
-            pose = _rot(-length / 2, -a, 0.0, q)
-            b.add_entry(pose, [[(length * 0.5, 0.0), (length * 0.5, 0.0)]], a, w * lanes - a, offs)
+    net = Net(w)
+    total = 2 * (exit_length + taper) + neck_length
+    for d in range(2):
+        o = (0.0, 0.0, 0.0) if d == 0 else reverse(shift((total, 0.0, 0.0), w))
+        e = net.add("in%d" % d, "w%d" % d, shift(o, 0.0), exit_length, 0.0, bottle_lanes)
+        net.add("w%d" % d, "n%d" % d, e, taper, 0.0, neck_lanes, LINE_CONTINUOUS, 0)
+        for lane in range(neck_lanes, bottle_lanes):
+            start = shift(e, -lane * w)
+            _wave(net, "w%d" % d, "w%d_%d" % (d, lane), "n%d" % d, start, (lane - (neck_lanes - 1)) * w, taper, 1,
+                  left_line=0, right_line=LINE_CONTINUOUS if lane == bottle_lanes - 1 else 0)
+        e2 = net.add("n%d" % d, "m%d" % d, advance(e, taper, 0.0), neck_length, 0.0, neck_lanes)
+        e3 = net.add("m%d" % d, "x%d" % d, e2, taper, 0.0, neck_lanes, LINE_CONTINUOUS, 0)
+        net.add("x%d" % d, "end%d" % d, e3, exit_length, 0.0, bottle_lanes)
+    b = _Builder("bottleneck", net, 20, total / 2)
+    slots = spawn_slots(exit_length + ENTRANCE_LENGTH)
+    for d in range(2):
+        b.add_spawn_road(("in%d" % d, "w%d" % d), ["end%d" % d], slots)
     return b.finish()
 
 
-def _lane_change(shift, radius):
-    """Two opposite arcs that move a lane centreline `shift` metres to the left (negative: to the right)."""
-    if abs(shift) < 1e-9:
-        return []
-    phi = math.acos(1.0 - abs(shift) / (2.0 * radius))
-    k = math.copysign(1.0 / radius, shift)
-    return [(radius * phi, k), (radius * phi, -k)]
-
-
-def bottleneck(approach=60.0, neck=30.0, lanes_wide=4, lanes_narrow=2, lane_width=LANE_WIDTH, taper_radius=40.0,
-               spawns_per_lane=5, spawn_gap=9.0):
-    """Two-direction road that narrows from `lanes_wide` to `lanes_narrow` lanes per direction and widens again
-    (MetaDrive's MultiAgentBottleneckEnv, 20 agents: eval/evaluate_population.py:118-124).  Entry lane i merges into neck
-    lane i * narrow // wide and leaves on one of the exit lanes that neck lane feeds; the corridor of a route is the
-    neck's (the narrowest part)."""
-    b = _Builder("bottleneck", 20, approach + neck + 40.0)
+def tollgate(exit_length=70.0, lanes=3, toll_lanes=8, toll_length=10.0, taper=30.0, lane_width=LANE_WIDTH):
+    """MATollGateMap: a `lanes`-lane two-way road that fans out into `toll_lanes` booths and closes again (40 agents).
+    The fan is modelled as one road whose corridor is `toll_lanes` wide; the booth logic (a vehicle must spend
+    `min_pass_steps` inside a booth) is the simulator's `toll` option."""
     w = lane_width
-    per = lanes_wide // lanes_narrow
-    assert per * lanes_narrow == lanes_wide, "lanes_wide must be a multiple of lanes_narrow"
-    offs = [2.0 + spawn_gap * k for k in range(spawns_per_lane)]
-
-    def run(shift):     # longitudinal length of a lane change
-        return 2.0 * taper_radius * math.sin(math.acos(1.0 - abs(shift) / (2.0 * taper_radius)))
-
-    # the widest lateral move fixes the taper zone: every route pads its straights so that all necks span the same x
-    taper = max(run(w * (0.5 + lane) - w * (0.5 + lane // per)) for lane in range(lanes_wide))
-    x0 = -(approach + taper + neck * 0.5)
-    for direction in range(2):
-        q = direction * math.pi
-        for lane in range(lanes_wide):
-            a_in = w * (0.5 + lane)
-            j = lane // per
-            a_neck = w * (0.5 + j)
-            routes = []
-            for k in range(j * per, (j + 1) * per):
-                a_out = w * (0.5 + k)
-                routes.append([(approach + taper - run(a_in - a_neck), 0.0)] + _lane_change(a_in - a_neck, taper_radius) +
-                              [(neck, 0.0)] + _lane_change(a_neck - a_out, taper_radius) +
-                              [(approach + taper - run(a_neck - a_out), 0.0)])
-            b.add_entry(_rot(x0, -a_in, 0.0, q), routes, a_neck, w * lanes_narrow - a_neck, offs)
+    net = Net(w)
+    total = 2 * (exit_length + taper) + toll_length
+    for d in range(2):
+        o = (0.0, 0.0, 0.0) if d == 0 else reverse(shift((total, 0.0, 0.0), w))
+        e = net.add("in%d" % d, "f%d" % d, o, exit_length, 0.0, lanes)
+        e = net.add("f%d" % d, "t%d" % d, e, taper, 0.0, toll_lanes, LINE_CONTINUOUS, LINE_CONTINUOUS, 0)
+        e = net.add("t%d" % d, "g%d" % d, e, toll_length, 0.0, toll_lanes, LINE_CONTINUOUS, LINE_CONTINUOUS, LINE_CONTINUOUS)
+        e = net.add("g%d" % d, "x%d" % d, e, taper, 0.0, toll_lanes, LINE_CONTINUOUS, LINE_CONTINUOUS, 0)
+        net.add("x%d" % d, "end%d" % d, e, exit_length, 0.0, lanes)
+    b = _Builder("tollgate", net, 40, total / 2)
+    slots = spawn_slots(exit_length + ENTRANCE_LENGTH)
+    for d in range(2):
+        b.add_spawn_road(("in%d" % d, "f%d" % d), ["end%d" % d], slots)
     return b.finish()
 
 
-def parkinglot(spaces=8, aisle_half=40.0, lane_width=LANE_WIDTH, turn_radius=5.0, depth=6.0):
-    """Aisle along x with `spaces` perpendicular parking spaces; agents leave spaces or drive into them."""
-    b = _Builder("parkinglot", 10, aisle_half + 10.0)
+def parkinglot(spaces=8, exit_length=20.0, lane_width=LANE_WIDTH, turn_radius=4.0, depth=6.0, pitch=7.0):
+    """MAParkingLotMap (10 agents, `parking_space_num=8`): a two-way one-lane aisle with `spaces` perpendicular parking
+    spaces.  Vehicles start in a space and leave through either end of the aisle, or enter at an end and drive into a
+    space."""
     w, r = lane_width, turn_radius
+    net = Net(w)
     per_side = spaces // 2
-    xs = [(-per_side / 2 + 0.5 + k) * 7.0 for k in range(per_side)]
-    spots = [(x, +1) for x in xs] + [(x, -1) for x in xs]   # side +1: above the aisle, -1: below
-    for x0, side in spots:                                   # out of a space, then east or west along the aisle
-        th = -side * math.pi / 2                             # heading towards the aisle
-        y_start = side * (w + depth + r)
-        routes = []
-        for go_east in (True, False):
-            # lane centre y for travelling east is -w/2, for west +w/2
-            y_lane = -w / 2 if go_east else w / 2
-            turn_left = (side > 0) == go_east                # from above heading -y: east (+x) is a left turn
-            lead = abs(y_start - y_lane) - r
-            kap = (1.0 if turn_left else -1.0) / r
-            x_after = x0 + (r if go_east else -r)
-            run = (aisle_half - x_after) if go_east else (x_after + aisle_half)
-            routes.append([(lead, 0.0), (r * math.pi / 2, kap), (run, 0.0)])
-        b.add_entry((x0, y_start, th), routes, w * 0.5, w * 0.5, [0.5])
-    for go_east in (True, False):                            # from an entrance into one of the spaces
-        q = 0.0 if go_east else math.pi
-        y_lane = -w / 2 if go_east else w / 2
-        routes = []
-        for x0, side in spots:
-            turn_left = (side > 0) == go_east
-            x_turn = x0 - r if go_east else x0 + r
-            lead = (x_turn + aisle_half) if go_east else (aisle_half - x_turn)
-            y_end = side * (w + depth + r)
-            tail = abs(y_end - y_lane) - r
-            routes.append([(lead, 0.0), (r * math.pi / 2, (1.0 if turn_left else -1.0) / r), (tail, 0.0)])
-        x_s = -aisle_half if go_east else aisle_half
-        b.add_entry((x_s, y_lane, q), routes, w * 0.5, w * 0.5, [1.0, 8.0, 15.0])
+    span = per_side * pitch
+    half = span / 2 + exit_length
+    # aisle: east-bound lane y = -w/2 ("E"), west-bound y = +w/2 ("W"), cut at every space's turn points
+    xs = [(-per_side / 2 + 0.5 + k) * pitch for k in range(per_side)]
+    spots = [(x, +1) for x in xs] + [(x, -1) for x in xs]      # +1: north of the aisle
+    cuts = sorted(set([-half, half] + [x - r for x in xs] + [x + r for x in xs]))
+    for i in range(len(cuts) - 1):
+        net.add("E%d" % i, "E%d" % (i + 1), (cuts[i], -w / 2, 0.0), cuts[i + 1] - cuts[i], 0.0, 1)
+    for i in range(len(cuts) - 1, 0, -1):
+        net.add("W%d" % i, "W%d" % (i - 1), (cuts[i], w / 2, math.pi), cuts[i] - cuts[i - 1], 0.0, 1)
+    ci = {c: i for i, c in enumerate(cuts)}
+    for s, (x0, side) in enumerate(spots):
+        y_far = side * (w + depth + r)
+        p = net.add("P%d" % s, "P%dx" % s, (x0, y_far, -side * math.pi / 2), abs(y_far) - r - w / 2, 0.0, 1)
+        for east in (True, False):
+            y_lane = -w / 2 if east else w / 2
+            left = (side > 0) == east
+            kap = (1.0 if left else -1.0) / r
+            # out of the space onto the aisle: the lead ends r short of the NEAR lane line; the far lane needs w more
+            lead_extra = abs(y_far - y_lane) - r - (abs(y_far) - r - w / 2)
+            q = advance(p, lead_extra, 0.0)
+            mid = "P%d%s" % (s, "e" if east else "w")
+            if lead_extra > 1e-9:
+                net.add("P%dx" % s, mid, p, lead_extra, 0.0, 1, 0, 0, 0)
+                src = mid
+            else:
+                src = "P%dx" % s
+            net.add(src, ("E%d" % ci[x0 + r]) if east else ("W%d" % ci[x0 - r]), q, r * math.pi / 2, kap, 1, 0, 0, 0)
+            # from the aisle into the space
+            x_turn = x0 - r if east else x0 + r
+            node = ("E%d" if east else "W%d") % ci[x_turn]
+            t = net.add(node, "Q%d%s" % (s, "e" if east else "w"), (x_turn, y_lane, 0.0 if east else math.pi),
+                        r * math.pi / 2, kap, 1, 0, 0, 0)
+            net.add("Q%d%s" % (s, "e" if east else "w"), "S%d%s" % (s, "e" if east else "w"), t, abs(y_far - y_lane) - r, 0.0, 1)
+    b = _Builder("parkinglot", net, 10, half + 10.0)
+    last = len(cuts) - 1
+    for s in range(len(spots)):          # parked vehicles leave through the east or the west end
+        b.add_spawn_road(("P%d" % s, "P%dx" % s), ["E%d" % last, "W0"], [0.5], safe_only_first=False)
+    for east in (True, False):           # arriving vehicles park in one of the spaces
+        road = ("E0", "E1") if east else ("W%d" % last, "W%d" % (last - 1))
+        b.add_spawn_road(road, ["S%d%s" % (s, "e" if east else "w") for s in range(len(spots))],
+                         [RESPAWN_REGION_LONGITUDE / 2], safe_only_first=False)
     return b.finish()
 
 
-def pgmap(sequence="SCS", seed=0, lanes=2, lane_width=LANE_WIDTH, lead=50.0, spawns_per_lane=5, spawn_gap=9.0):
+def pgmap(sequence="SCS", seed=0, lanes=2, lane_width=LANE_WIDTH, lead=50.0):
     """Two-way road assembled from a block sequence, in the manner of MetaDrive's procedurally generated maps (the
     `MultiAgentMetaDrive` env of train_all_copo_dist.py:10,30): `S` = straight of 40-80 m, `C` = curve of radius 30-60 m
     through 30-90 degrees to a random side; an int `sequence` draws that many blocks.  Everything random comes from
-    `seed`, so a (sequence, seed) pair names one map.  `lead` metres of straight road at both ends hold the spawn points;
-    vehicles enter at one end and leave at the other.  Junction blocks (ramps, roundabouts, intersections inside a chain)
-    are not generated."""
+    `seed`, so a (sequence, seed) pair names one map.  `lead` metres of straight road at both ends hold the spawn slots;
+    vehicles enter at one end and leave at the other.  Junction blocks are not generated."""
     rng = np.random.RandomState(int(seed))
     if isinstance(sequence, (int, np.integer)):
         sequence = "".join("SC"[int(rng.randint(2))] for _ in range(int(sequence)))
@@ -272,31 +429,38 @@ def pgmap(sequence="SCS", seed=0, lanes=2, lane_width=LANE_WIDTH, lead=50.0, spa
             centre.append((radius * ang, side / radius))
         else:
             raise ValueError("pgmap block %r: only S (straight) and C (curve) are generated" % ch)
-    if len(centre) + 2 > MAX_SEGS:
-        raise ValueError("pgmap: %d blocks + 2 lead pieces > %d route segments" % (len(centre), MAX_SEGS))
     chain = [(lead, 0.0)] + centre + [(lead, 0.0)]
-    rec, total, nseg = build_route(0.0, 0.0, 0.0, chain)
-    xe, ye, the = float(rec[nseg][0]), float(rec[nseg][1]), float(rec[nseg][7])
-    # shift the road so that the midpoint of its two ends is the origin (scenes are centred like the other maps)
-    ox, oy = -0.5 * xe, -0.5 * ye
-    b = _Builder("pgmap", 20, 0.5 * total)
+    if len(chain) > MAX_SEGS:
+        raise ValueError("pgmap: %d blocks + 2 lead pieces > %d route segments" % (len(centre), MAX_SEGS))
     w = lane_width
-    offs = [2.0 + spawn_gap * k for k in range(spawns_per_lane)]
-    if offs[-1] >= lead:
-        raise ValueError("pgmap: spawn points do not fit on the %.0f m lead" % lead)
-
-    def offset_right(pieces, a):       # the lane `a` metres to the right of a centre line
-        return [(ln * (1.0 + k * a), k / (1.0 + k * a)) for ln, k in pieces]
-
-    for direction in range(2):
-        if direction == 0:
-            x, y, th, pieces = ox, oy, 0.0, chain
-        else:
-            x, y, th, pieces = xe + ox, ye + oy, the + math.pi, [(ln, -k) for ln, k in reversed(chain)]
-        for lane in range(lanes):
-            a = w * (0.5 + lane)
-            pose = (x + a * math.sin(th), y - a * math.cos(th), th)
-            b.add_entry(pose, [offset_right(pieces, a)], a, w * lanes - a, offs)
+    net = Net(w)
+    # centre line (the yellow line) from the origin; forward lane 0 is w/2 to its right
+    pose = (0.0, 0.0, 0.0)
+    fwd = []
+    for k, (ln, kap) in enumerate(chain):
+        a = -w / 2.0
+        p0 = shift(pose, a)
+        k0 = kap / (1.0 - kap * a) if kap else 0.0
+        l0 = ln * (1.0 - kap * a) if kap else ln
+        net.add("f%d" % k, "f%d" % (k + 1), p0, l0, k0, lanes)
+        fwd.append((k, ln, kap, pose))
+        pose = advance(pose, ln, kap)
+    for k, ln, kap, p in reversed(fwd):
+        net.adverse("f%d" % k, "f%d" % (k + 1), "b%d" % (k + 1), "b%d" % k)
+    xe, ye = pose[0], pose[1]
+    # centre the scene like the other maps: shift every road by minus the midpoint of the two ends
+    ox, oy = -0.5 * xe, -0.5 * ye
+    for key, (pp, ln, kap, nl) in list(net.roads.items()):
+        net.roads[key] = ((pp[0] + ox, pp[1] + oy, pp[2]), ln, kap, nl)
+    for ln_ in net.lines:
+        ln_[0] += ox
+        ln_[1] += oy
+    total = sum(ln for ln, _ in chain)
+    b = _Builder("pgmap", net, 20, 0.5 * total)
+    slots = spawn_slots(lead + ENTRANCE_LENGTH)
+    nb = len(chain)
+    b.add_spawn_road(("f0", "f1"), ["f%d" % nb], slots)
+    b.add_spawn_road(("b%d" % nb, "b%d" % (nb - 1)), ["b0"], slots)
     return b.finish()
 
 
@@ -305,33 +469,37 @@ MAP_BUILDERS = dict(intersection=intersection, roundabout=roundabout, tollgate=t
 
 
 def bounding_box(tables: MapTables, step=2.0):
-    """(x_min, x_max, y_min, y_max) of the road network: route centrelines widened by their corridor.  Stands in for
+    """(x_min, x_max, y_min, y_max) of the road network: lane-0 lines widened by their lanes.  Stands in for
     MetaDrive's `road_network.get_bounding_box()` (env_wrappers.py:268), used by the traffic-light columns."""
     lo, hi = np.array([np.inf, np.inf]), np.array([-np.inf, -np.inf])
     for r in range(tables.n_routes):
         pts = route_points(tables, r, step)
-        pad = float(max(tables.route_meta[r, 1], tables.route_meta[r, 2]))
+        pad = float(tables.route_segs[r, :, SEG_LANES].max()) * tables.lane_width
         lo, hi = np.minimum(lo, pts.min(0) - pad), np.maximum(hi, pts.max(0) + pad)
     return float(lo[0]), float(hi[0]), float(lo[1]), float(hi[1])
 
 
-def ray_table(num_lasers):
-    ang = 2.0 * np.pi * np.arange(num_lasers, dtype=np.float64) / num_lasers
+def ray_table(num_lasers, clockwise=True, offset_deg=0.0):
+    """Unit vectors of detector beams in the vehicle frame (forward, left): beam 0 is turned `offset_deg` from the
+    heading, beam k another k * 360 / n degrees -- CLOCKWISE by default: MetaDrive 0.2.5 adds k * step to the heading in
+    its y-down frame (LiDAR: offset 0; side and lane-line detectors: offset 90)."""
+    ang = math.radians(offset_deg) + 2.0 * np.pi * np.arange(num_lasers, dtype=np.float64) / num_lasers
+    if clockwise:
+        ang = -ang
     return np.stack([np.cos(ang), np.sin(ang)], axis=1).astype(np.float32)
 
 
-def route_points(tables: MapTables, route: int, step=1.0):
-    """Polyline of a route centreline (float64, for tests/plots)."""
+def route_points(tables: MapTables, route: int, step=1.0, lateral=0.0):
+    """Polyline of a route's lane-0 line (float64, for tests/plots); `lateral` metres to the left of it."""
     pts = []
-    nseg = int(tables.route_meta[route, 3])
+    nseg = int(tables.route_meta[route, 1])
     for k in range(nseg):
-        x0, y0, c0, s0, ln, kap, _, th0 = tables.route_segs[route, k].astype(np.float64)
-        for s in np.arange(0.0, ln, step):
-            if kap == 0:
-                pts.append((x0 + c0 * s, y0 + s0 * s))
-            else:
-                r = 1.0 / kap
-                pts.append((x0 + r * (math.sin(th0 + kap * s) - math.sin(th0)),
-                            y0 - r * (math.cos(th0 + kap * s) - math.cos(th0))))
-    pts.append(tuple(tables.route_segs[route, nseg, :2].astype(np.float64)))
+        rec = tables.route_segs[route, k].astype(np.float64)
+        pose = (rec[SEG_X0], rec[SEG_Y0], rec[SEG_TH0])
+        for s in np.arange(0.0, rec[SEG_LEN], step):
+            p = shift(advance(pose, s, rec[SEG_KAPPA]), lateral)
+            pts.append((p[0], p[1]))
+    rec = tables.route_segs[route, nseg].astype(np.float64)
+    p = shift((rec[SEG_X0], rec[SEG_Y0], rec[SEG_TH0]), lateral)
+    pts.append((p[0], p[1]))
     return np.asarray(pts)

@@ -12,7 +12,14 @@ import numpy as np
 
 from . import maps as _maps
 
-EGO_DIM, NAVI_DIM = 9, 10
+STATE_DIM, NAVI_DIM = 6, 10
+
+# per-map observation options of MetaDrive 0.2.5's multi-agent environments (first-layer shapes of the reference's
+# best_checkpoints: Intersection / Roundabout / ParkingLot 91, Bottleneck 96, Tollgate 156; +1 LCF column for CoPO)
+MAP_OBS_DEFAULTS = dict(
+    bottleneck=dict(side_lasers=4, side_range=20.0, lane_line_lasers=4, lane_line_range=20.0),
+    tollgate=dict(side_lasers=72, side_range=20.0, lane_line_lasers=4, lane_line_range=20.0, navi_dim=0, toll_dim=2),
+)
 
 
 @dataclass
@@ -27,21 +34,22 @@ class SimConfig:
     enable_lcf: bool = True
     horizon: int = 1000
     delay_done: int = 25
-    respawn_cooldown: int = 1
+    respawn_cooldown: int = 0
     substeps: int = 5
     lidar_range: float = 40.0
     neighbours_distance: float = 40.0  # env_wrappers.py:168
     mf_distance: float = 10.0          # algo_ccppo.py:43
     dt: float = 0.1
-    veh_half_len: float = 2.25
-    veh_half_wid: float = 0.925
-    wheelbase: float = 2.7
+    veh_half_len: float = 2.2575       # MetaDrive DefaultVehicle 4.515 x 1.852 m
+    veh_half_wid: float = 0.926
+    wheelbase: float = 2.4686          # front 1.05234 + rear 1.4166
     max_steer: float = math.radians(40.0)
     max_speed: float = 80.0 / 3.6
-    acc_max: float = 6.0
-    brake_max: float = 9.0
-    drag: float = 0.05
-    spawn_clearance: float = 7.5
+    acc_max: float = 2.9               # 4 wheels x max_engine_force 800 N / 1100 kg
+    brake_gain: float = 27.0           # 4 wheels x max_brake_force 150 N s per 0.02 s physics step / 1100 kg ...
+    brake_max: float = 8.8             # ... limited by tyre friction 0.9 g
+    spawn_region_len: float = 8.0      # SpawnManager.RESPAWN_REGION_LONGITUDE / LATERAL
+    spawn_region_wid: float = 3.0
     driving_reward: float = 1.0
     speed_reward: float = 0.1
     success_reward: float = 10.0
@@ -52,12 +60,28 @@ class SimConfig:
     lcf_mean: float = 0.0
     lcf_std: float = 0.1               # env_wrappers.py:176
     start_seed: int = 5000
+    lidar_clockwise: bool = True       # beam k is turned k * 360 / n degrees clockwise of the heading (MetaDrive 0.2.5)
     # observation / action extensions of CCEnv / LCFEnv (env_wrappers.py:44-46); off by default like the reference
     add_traffic_light: bool = False
     traffic_light_interval: int = 30
     comm_size: int = 0                 # > 0 = communication on (comm_method != "none"): actions carry 2 + comm_size floats
     comm_neighbours: int = 4
     add_pos_in_comm: bool = False
+    # MetaDrive's optional detectors; None = the map's default (MAP_OBS_DEFAULTS)
+    side_lasers: int = None
+    lane_line_lasers: int = None
+    side_range: float = None
+    lane_line_range: float = None
+    navi_dim: int = None
+    toll_dim: int = None
+    toll_min_steps: int = 30
+
+    def __post_init__(self):
+        d = MAP_OBS_DEFAULTS.get(self.map, {})
+        for k, dflt in (("side_lasers", 0), ("lane_line_lasers", 0), ("side_range", 20.0), ("lane_line_range", 20.0),
+                        ("navi_dim", NAVI_DIM), ("toll_dim", 0)):
+            if getattr(self, k) is None:
+                setattr(self, k, d.get(k, dflt))
 
     def tables(self):
         return _maps.MAP_BUILDERS[self.map](**self.map_kwargs)
@@ -72,14 +96,39 @@ class SimConfig:
         return (self.comm_size + (3 if self.add_pos_in_comm else 0)) if self.comm_size > 0 else 0
 
     @property
+    def ego_dim(self):
+        return (self.side_lasers or 2) + STATE_DIM + (self.lane_line_lasers or 1)
+
+    @property
     def obs_dim(self):
-        """[9 ego | 10 navigation | lasers | 3 traffic light | 1 lcf | comm_neighbours x comm_dim] (COPO_OBS_DIM)."""
-        return (EGO_DIM + NAVI_DIM + self.num_lasers + (3 if self.add_traffic_light else 0) + (1 if self.enable_lcf else 0)
-                + (self.comm_neighbours * self.comm_dim if self.comm_size > 0 else 0))
+        """[side | 6 state | lane | navigation | lasers | toll | 3 traffic light | 1 lcf | comm] (COPO_OBS_DIM)."""
+        return (self.ego_dim + self.navi_dim + self.num_lasers + self.toll_dim + (3 if self.add_traffic_light else 0)
+                + (1 if self.enable_lcf else 0) + (self.comm_neighbours * self.comm_dim if self.comm_size > 0 else 0))
+
+    @property
+    def lcf_col(self):
+        """Column of the (lcf + 1) / 2 entry (-1 without LCF)."""
+        if not self.enable_lcf:
+            return -1
+        return self.ego_dim + self.navi_dim + self.num_lasers + self.toll_dim + (3 if self.add_traffic_light else 0)
 
     @property
     def act_dim(self):
         return 2 + max(0, self.comm_size)
+
+
+def line_table(lines):
+    """[n][8] = x0, y0, theta0, length, kappa, kind -> [n][COPO_LINE_STRIDE] records of the detectors."""
+    out = np.zeros((len(lines), 12), np.float64)
+    for i, (x0, y0, th, ln, kap, kind, _, _) in enumerate(np.asarray(lines, np.float64)):
+        out[i, :7] = [kind, x0, y0, math.cos(th), math.sin(th), ln, kap]
+        if kap != 0.0:
+            sg, r, ang = (1.0 if kap > 0 else -1.0), 1.0 / abs(kap), abs(kap) * ln
+            cx, cy = x0 - sg * r * math.sin(th), y0 + sg * r * math.cos(th)
+            ux, uy = sg * math.sin(th), -sg * math.cos(th)
+            c, s = math.cos(sg * ang / 2.0), math.sin(sg * ang / 2.0)
+            out[i, 7:] = [cx, cy, c * ux - s * uy, s * ux + c * uy, math.cos(ang / 2.0)]
+    return out.astype(np.float32)
 
 
 def fill_cfg_struct(cfg: SimConfig, struct_cls):
@@ -92,20 +141,27 @@ def fill_cfg_struct(cfg: SimConfig, struct_cls):
     c.enable_lcf = 1 if cfg.enable_lcf else 0
     c.horizon, c.delay_done, c.respawn_cooldown, c.substeps = cfg.horizon, cfg.delay_done, cfg.respawn_cooldown, cfg.substeps
     for k in ("lidar_range", "neighbours_distance", "mf_distance", "dt", "veh_half_len", "veh_half_wid", "wheelbase",
-              "max_steer", "max_speed", "acc_max", "brake_max", "drag", "spawn_clearance", "driving_reward",
-              "speed_reward", "success_reward", "crash_penalty", "out_penalty", "arrive_margin", "lane_width"):
+              "max_steer", "max_speed", "acc_max", "brake_gain", "brake_max", "spawn_region_len", "spawn_region_wid",
+              "driving_reward", "speed_reward", "success_reward", "crash_penalty", "out_penalty", "arrive_margin",
+              "lane_width", "side_range", "lane_line_range"):
         setattr(c, k, float(getattr(cfg, k)))
     c.lcf_mean, c.lcf_std = float(cfg.lcf_mean), float(cfg.lcf_std)
     c.add_traffic_light, c.traffic_light_interval = int(bool(cfg.add_traffic_light)), int(cfg.traffic_light_interval)
     c.comm_size, c.comm_neighbours = max(0, int(cfg.comm_size)), int(cfg.comm_neighbours)
     c.add_pos_in_comm = int(bool(cfg.add_pos_in_comm))
+    c.side_lasers, c.lane_line_lasers = int(cfg.side_lasers), int(cfg.lane_line_lasers)
+    c.navi_dim, c.toll_dim, c.toll_min_steps = int(cfg.navi_dim), int(cfg.toll_dim), int(cfg.toll_min_steps)
     for k, v in enumerate(_maps.bounding_box(t)):
         c.map_bbox[k] = float(v)
+    assert abs(t.lane_width - cfg.lane_width) < 1e-6, "the map was built for another lane width"
     keep = dict(
         route_segs=np.ascontiguousarray(t.route_segs, np.float32), route_meta=np.ascontiguousarray(t.route_meta, np.float32),
         spawn_tab=np.ascontiguousarray(t.spawn_tab, np.int32), spawn_s=np.ascontiguousarray(t.spawn_s, np.float32),
-        ray_cs=_maps.ray_table(cfg.num_lasers))
-    c.n_routes, c.n_spawns = t.n_routes, t.n_spawns
+        ray_cs=_maps.ray_table(cfg.num_lasers, clockwise=cfg.lidar_clockwise),
+        lines=line_table(t.lines),
+        side_cs=_maps.ray_table(max(1, cfg.side_lasers), offset_deg=90.0),
+        lane_line_cs=_maps.ray_table(max(1, cfg.lane_line_lasers), offset_deg=90.0))
+    c.n_routes, c.n_spawns, c.n_lines = t.n_routes, t.n_spawns, len(keep["lines"])
     for k, v in keep.items():
         setattr(c, k, v.ctypes.data)
     return c, keep

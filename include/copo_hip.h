@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define COPO_ABI_VERSION 1
+#define COPO_ABI_VERSION 2
 
 #define COPO_OK 0
 #define COPO_ERR_NULL (-1)      /* required pointer is NULL */
@@ -35,12 +35,15 @@ extern "C" {
 #define COPO_ERR_CONFIG (-5)    /* inconsistent configuration / map tables */
 
 #define COPO_MAX_AGENTS 64      /* slots per env (one wave64 owns an env's agents) */
-#define COPO_MAX_SEGS 8         /* segments per route */
-#define COPO_SEG_STRIDE 8       /* floats per segment record  */
+#define COPO_MAX_SEGS 12        /* roads per route (a full turn of the roundabout is 11) */
+#define COPO_SEG_STRIDE 16      /* floats per road record */
 #define COPO_MAX_LASERS 256
-#define COPO_MAX_SPAWNS 256     /* spawn points per map */
+#define COPO_MAX_SPAWNS 256     /* spawn slots per map */
+#define COPO_MAX_SAFE 32        /* respawn places (spawn slots with the `safe` mark) per map */
 #define COPO_MAX_ROUTES 128
-#define COPO_EGO_DIM 9
+#define COPO_MAX_LINES 128      /* lane-line primitives per map (side / lane-line detectors) */
+#define COPO_LINE_STRIDE 12
+#define COPO_STATE_DIM 6        /* heading, speed, steering, last action x2, yaw rate */
 #define COPO_NAVI_DIM 10
 #define COPO_INFO_DIM 8
 #define COPO_STATE_FIELDS 16
@@ -62,40 +65,55 @@ extern "C" {
 #define COPO_I_STEERING 1
 #define COPO_I_ACCELERATION 2
 #define COPO_I_STEP_REWARD 3
-#define COPO_I_COST 4
+#define COPO_I_COST 4           /* 1 on a crash (MetaDrive's multi-agent default: out_of_road_cost = 0) */
 #define COPO_I_EPISODE_LENGTH 5
 #define COPO_I_EPISODE_REWARD 6
 #define COPO_I_ROUTE_COMPLETION 7
 
-/* Segment record, COPO_SEG_STRIDE floats: {x0, y0, cos0, sin0, length, kappa, s_start, theta0}.
- * A route has nseg real segments followed by one terminal record (length 0) holding the end pose.  */
+/* Road record, COPO_SEG_STRIDE floats.  A road is one primitive (straight or arc) carrying `lanes` lanes; the record
+ * describes the centre line of lane 0, the LEFTMOST lane -- lane i lies i * lane_width to its right:
+ *   0 x0, 1 y0, 2 cos0, 3 sin0   start pose            4 length      5 kappa (signed: + = counter-clockwise)
+ *   6 s_start (route arc length at the start)           7 theta0
+ *   8 ckx, 9 cky   navigation check point: the end of the road at its lateral middle
+ *  10 lanes       11 radius feature of the navigation block, 12 radius (0 for a straight), 13 angle feature
+ *  14 umx, 15 umy unit vector from an arc's centre to its mid point (projection without a wrap inside the arc)
+ * A route has nseg roads followed by one terminal record (length 0) holding the end pose. */
+#define COPO_SEG_CKX 8
+#define COPO_SEG_LANES 10
+#define COPO_SEG_FEAT 11
+#define COPO_SEG_UMX 14
+
+/* Lane-line primitive, COPO_LINE_STRIDE floats (side detector: continuous lines; lane-line detector: all lines):
+ *   0 kind (1 broken, 2 continuous), 1 x0, 2 y0, 3 cos0, 4 sin0, 5 length, 6 kappa, 7 cx, 8 cy (arc centre),
+ *   9 umx, 10 umy (centre -> arc mid point), 11 cos(half the arc angle) */
 
 typedef struct copo_sim_cfg {
     /* population */
     int32_t num_envs;          /* E */
     int32_t num_agents;        /* N slots per env, <= COPO_MAX_AGENTS */
     int32_t num_lasers;        /* LiDAR beams (72; 240 for config C5) */
-    int32_t obs_dim;           /* O = 9 + 10 + num_lasers (+1 when enable_lcf) (+ extensions below): COPO_OBS_DIM() */
+    int32_t obs_dim;           /* COPO_OBS_DIM() */
     int32_t nbr_k;             /* neighbour ids stored per slot (<= N-1) */
     int32_t enable_lcf;        /* 1: LCFEnv (append (lcf+1)/2 to obs, sample LCF at spawn); 0: CCEnv only */
     int32_t horizon;           /* env steps per episode (MetaDrive `horizon`, 1000) */
-    int32_t delay_done;        /* steps a crashed vehicle lingers as an obstacle (MetaDrive `delay_done`) */
-    int32_t respawn_cooldown;  /* min steps a slot stays empty before re-use (>= 1) */
+    int32_t delay_done;        /* steps a crashed / out-of-road vehicle lingers as an obstacle (MetaDrive `delay_done`) */
+    int32_t respawn_cooldown;  /* steps a slot stays empty before re-use (0: MetaDrive respawns in the same step) */
     int32_t substeps;          /* physics sub-steps per env step (5) */
     /* radii */
     float lidar_range;         /* m */
     float neighbours_distance; /* env_wrappers.py:40,168 (strict <) */
     float mf_distance;         /* algo_ccppo.py:43,283 (prefix of the sorted list with d <= mf) */
-    /* vehicle + bicycle model */
+    /* vehicle + kinematic bicycle model (centre-referenced, slip angle from the steering angle) */
     float dt;                  /* env step seconds (0.1) */
     float veh_half_len, veh_half_wid, wheelbase;
     float max_steer;           /* rad */
     float max_speed;           /* m/s */
-    float acc_max, brake_max, drag;
-    float spawn_clearance;     /* m: spawn point must be this far from every solid vehicle */
-    /* reward (MetaDrive-style, build-defined) */
+    float acc_max;             /* m/s^2 at full throttle (engine force cut above max_speed) */
+    float brake_gain, brake_max; /* deceleration = min(brake_gain * |a1|, brake_max) for a1 < 0 */
+    float spawn_region_len, spawn_region_wid; /* the box that must hold no vehicle for a respawn (8 x 3 m) */
+    /* reward (MetaDrive multi-agent scheme) */
     float driving_reward, speed_reward, success_reward, crash_penalty, out_penalty;
-    float arrive_margin;       /* m before route end that counts as arrival */
+    float arrive_margin;       /* arrival: within +- this of the end of the final road */
     float lane_width;
     /* LCF distribution at creation (LCFEnv.current_lcf_mean/std, env_wrappers.py:200-201) */
     double lcf_mean, lcf_std;
@@ -103,25 +121,41 @@ typedef struct copo_sim_cfg {
     int32_t n_routes;
     int32_t n_spawns;
     const float* route_segs;   /* [n_routes][COPO_MAX_SEGS + 1][COPO_SEG_STRIDE] */
-    const float* route_meta;   /* [n_routes][4] = {total_len, lat_left, lat_right, nseg} */
-    const int32_t* spawn_tab;  /* [n_spawns][4] = {first_route, n_route_choices, 0, 0} */
-    const float* spawn_s;      /* [n_spawns] longitudinal offset of the spawn pose on its routes */
-    const float* ray_cs;       /* [num_lasers][2] = {cos, sin}(2*pi*k/num_lasers) */
+    const float* route_meta;   /* [n_routes][4] = {total_len, nseg, 0, 0} */
+    const int32_t* spawn_tab;  /* [n_spawns][4] = {first_route, n_destinations, lane, safe} */
+    const float* spawn_s;      /* [n_spawns] longitudinal position of the slot on its spawn road */
+    const float* ray_cs;       /* [num_lasers][2] = beam directions in the vehicle frame (forward, left) */
     /* optional observation / action extensions of CCEnv / LCFEnv (env_wrappers.py:44-46, 89-118, 258-272, 331-337,
-     * 362-371); all zero = off.  Observation row: [9 ego | 10 navigation | lasers | 3 traffic light | 1 lcf |
-     * comm_neighbours x (comm_size + 3 if add_pos_in_comm)], see COPO_OBS_DIM(). */
+     * 362-371); all zero = off. */
     int32_t add_traffic_light;      /* append clip([message(t), x', y'], 0, 1): env_wrappers.py:258-272 */
     int32_t traffic_light_interval; /* steps per phase (30) */
     int32_t comm_size;              /* > 0: communication on -- actions are [2 + comm_size] floats per slot */
     int32_t comm_neighbours;        /* nearest neighbours whose message is appended (4) */
     int32_t add_pos_in_comm;        /* 1: each message is followed by [d/20, (lon/d+1)/2, (lat/d+1)/2] clipped to [0,1] */
     float map_bbox[4];              /* {x_min, x_max, y_min, y_max} of the road network (traffic-light position columns) */
+    /* MetaDrive's optional detectors (Bottleneck: 4 + 4 beams -> O = 96; Tollgate: 72 + 4 beams, no navigation block,
+     * two toll columns -> O = 156).  0 beams = the two / one lateral-distance columns of the default observation. */
+    int32_t side_lasers;            /* side detector beams (continuous lines), first beam 90 deg clockwise of the heading */
+    int32_t lane_line_lasers;       /* lane-line detector beams (all lines) */
+    float side_range, lane_line_range;
+    int32_t navi_dim;               /* 10, or 0 (Tollgate) */
+    int32_t toll_dim;               /* 0, or 2 (Tollgate: in-booth mark, waited fraction) */
+    int32_t toll_min_steps;         /* steps a vehicle has to spend in a booth (30) */
+    int32_t n_lines;
+    const float* lines;             /* [n_lines][COPO_LINE_STRIDE] (HOST) */
+    const float* side_cs;           /* [side_lasers][2] beam directions in the vehicle frame (forward, left) (HOST) */
+    const float* lane_line_cs;      /* [lane_line_lasers][2] (HOST) */
 } copo_sim_cfg;
 
-/* Observation length of a configuration (the value obs_dim must hold):
- * 9 + 10 + lasers + (3 if add_traffic_light) + (1 if enable_lcf) + comm_neighbours * (comm_size + 3 * add_pos_in_comm). */
-#define COPO_OBS_DIM(c)                                                                                      \
-    (COPO_EGO_DIM + COPO_NAVI_DIM + (c)->num_lasers + ((c)->add_traffic_light ? 3 : 0) + ((c)->enable_lcf ? 1 : 0) + \
+/* Observation row: [side block | heading, speed, steering, last action x2, yaw rate | lane-line block | navigation |
+ * lasers | toll | 3 traffic light | 1 lcf | comm_neighbours x (comm_size + 3 if add_pos_in_comm)], where the side block
+ * is side_lasers beams or the 2 lateral-distance columns and the lane-line block lane_line_lasers beams or 1 column. */
+#define COPO_SIDE_DIM(c) ((c)->side_lasers > 0 ? (c)->side_lasers : 2)
+#define COPO_LANE_DIM(c) ((c)->lane_line_lasers > 0 ? (c)->lane_line_lasers : 1)
+#define COPO_EGO_DIM(c) (COPO_SIDE_DIM(c) + COPO_STATE_DIM + COPO_LANE_DIM(c))
+#define COPO_OBS_DIM(c)                                                                                       \
+    (COPO_EGO_DIM(c) + (c)->navi_dim + (c)->num_lasers + (c)->toll_dim + ((c)->add_traffic_light ? 3 : 0) +     \
+     ((c)->enable_lcf ? 1 : 0) +                                                                              \
      ((c)->comm_size > 0 ? (c)->comm_neighbours * ((c)->comm_size + ((c)->add_pos_in_comm ? 3 : 0)) : 0))
 /* floats per slot of the action array: steering, throttle, then the message */
 #define COPO_ACT_DIM(c) (2 + ((c)->comm_size > 0 ? (c)->comm_size : 0))

@@ -123,9 +123,14 @@ enum { RNG_ROUTE = 1, RNG_LCF1 = 2, RNG_LCF2 = 3, RNG_SPAWN = 4, RNG_PERM = 16 }
 
 /* state field indices: [COPO_STATE_FIELDS][E][N] 32-bit words */
 enum {
-    S_X = 0, S_Y, S_TH, S_V, S_STEER, S_THROTTLE, S_YAWRATE, S_PROG, S_LAT, S_LCF, S_EPREW, S_ROUTE /* route | seg<<16 */,
-    S_STATUS /* status | timer<<8 */, S_AGE, S_AID, S_SPAWNCNT
+    S_X = 0, S_Y, S_TH, S_V, S_STEER /* action of this step */, S_THROTTLE, S_PSTEER /* action of the step before */,
+    S_PTHROTTLE, S_YAWRATE, S_PROG, S_LCF, S_EPREW, S_ROUTE /* route | road << 16 */,
+    S_STATUS /* status | timer << 8 | age << 16 */, S_AID, S_SPAWNCNT /* spawn count | toll wait << 16 */
 };
+#define ST_STATUS(w) ((w) & 0xff)
+#define ST_TIMER(w) (((w) >> 8) & 0xff)
+#define ST_AGE(w) ((int)((uint32_t)(w) >> 16))
+#define ST_PACK(st, tm, age) ((int32_t)((uint32_t)(st) | ((uint32_t)(tm) << 8) | ((uint32_t)(age) << 16)))
 /* env words: [E][4] int32 = {t_env, episode, next_aid, started} */
 
 typedef struct oracle_sim {
@@ -135,11 +140,16 @@ typedef struct oracle_sim {
     int32_t* spawn_tab;
     float* spawn_s;
     float* ray_cs;
+    float* lines;
     float* st;      /* [16][E][N] */
     int32_t* env;   /* [E][4] */
     uint64_t* seeds;
     double lcf_mean, lcf_std, force_lcf;
     int capacity;              /* active agent slots (curriculum); num_agents by default */
+    /* constants derived once, in float, exactly as the kernel derives them */
+    float inv_w, inv_range, inv_vnorm, inv_dt, inv_side_range, inv_lane_range;
+    int safe_ids[COPO_MAX_SAFE];
+    int n_safe;
 } oracle_sim;
 
 static float* FP(oracle_sim* s, int f, int e) { return s->st + ((size_t)f * s->cfg.num_envs + e) * s->cfg.num_agents; }
@@ -151,14 +161,21 @@ static void* dup_mem(const void* p, size_t n) {
     return q;
 }
 
+int oracle_sim_destroy(oracle_sim* s);
+
 int oracle_sim_create(const copo_sim_cfg* cfg, oracle_sim** out) {
     if (!cfg || !out) return COPO_ERR_NULL;
     if (cfg->num_agents < 1 || cfg->num_agents > COPO_MAX_AGENTS || cfg->num_envs < 1) return COPO_ERR_DIM;
     if (cfg->num_lasers < 1 || cfg->num_lasers > COPO_MAX_LASERS) return COPO_ERR_DIM;
+    if (cfg->side_lasers < 0 || cfg->side_lasers > COPO_MAX_LASERS || cfg->lane_line_lasers < 0 || cfg->lane_line_lasers > COPO_MAX_LASERS) return COPO_ERR_DIM;
+    if (cfg->navi_dim != 0 && cfg->navi_dim != COPO_NAVI_DIM) return COPO_ERR_CONFIG;
+    if (cfg->toll_dim != 0 && cfg->toll_dim != 2) return COPO_ERR_CONFIG;
     if (cfg->obs_dim != COPO_OBS_DIM(cfg)) return COPO_ERR_DIM;
     if (cfg->comm_size < 0 || (cfg->comm_size > 0 && (cfg->comm_neighbours < 1 || cfg->comm_neighbours > COPO_MAX_AGENTS))) return COPO_ERR_CONFIG;
     if (cfg->add_traffic_light && (cfg->traffic_light_interval < 1 || !(cfg->map_bbox[1] > cfg->map_bbox[0]) || !(cfg->map_bbox[3] > cfg->map_bbox[2]))) return COPO_ERR_CONFIG;
     if (cfg->n_spawns < cfg->num_agents || cfg->n_spawns > COPO_MAX_SPAWNS || cfg->nbr_k < 1 || cfg->nbr_k > COPO_MAX_AGENTS) return COPO_ERR_CONFIG;
+    if (cfg->n_lines < 0 || cfg->n_lines > COPO_MAX_LINES || ((cfg->side_lasers || cfg->lane_line_lasers) && !cfg->lines)) return COPO_ERR_CONFIG;
+    if (cfg->delay_done > 255 || cfg->respawn_cooldown > 255 || cfg->horizon > 65535) return COPO_ERR_CONFIG;
     oracle_sim* s = (oracle_sim*)calloc(1, sizeof(oracle_sim));
     s->cfg = *cfg;
     size_t E = cfg->num_envs, N = cfg->num_agents;
@@ -167,6 +184,7 @@ int oracle_sim_create(const copo_sim_cfg* cfg, oracle_sim** out) {
     s->spawn_tab = dup_mem(cfg->spawn_tab, sizeof(int32_t) * cfg->n_spawns * 4);
     s->spawn_s = dup_mem(cfg->spawn_s, sizeof(float) * cfg->n_spawns);
     s->ray_cs = dup_mem(cfg->ray_cs, sizeof(float) * cfg->num_lasers * 2);
+    s->lines = dup_mem(cfg->lines, sizeof(float) * cfg->n_lines * COPO_LINE_STRIDE);
     s->st = (float*)calloc(COPO_STATE_FIELDS * E * N, 4);
     s->env = (int32_t*)calloc(E * 4, 4);
     s->seeds = (uint64_t*)calloc(E, 8);
@@ -174,13 +192,25 @@ int oracle_sim_create(const copo_sim_cfg* cfg, oracle_sim** out) {
     s->lcf_std = cfg->lcf_std;
     s->force_lcf = -100.0;
     s->capacity = cfg->num_agents;
+    s->inv_w = 1.0f / cfg->lane_width;
+    s->inv_range = 1.0f / cfg->lidar_range;
+    s->inv_vnorm = 1.0f / (cfg->max_speed * 3.6f + 1.0f);
+    s->inv_dt = 1.0f / cfg->dt;
+    s->inv_side_range = cfg->side_lasers ? 1.0f / cfg->side_range : 0.0f;
+    s->inv_lane_range = cfg->lane_line_lasers ? 1.0f / cfg->lane_line_range : 0.0f;
+    for (int p = 0; p < cfg->n_spawns; ++p)
+        if (s->spawn_tab[p * 4 + 3]) {
+            if (s->n_safe >= COPO_MAX_SAFE) { oracle_sim_destroy(s); return COPO_ERR_CONFIG; }
+            s->safe_ids[s->n_safe++] = p;
+        }
+    if (s->n_safe < 1) { oracle_sim_destroy(s); return COPO_ERR_CONFIG; }
     *out = s;
     return COPO_OK;
 }
 
 int oracle_sim_destroy(oracle_sim* s) {
     if (!s) return COPO_ERR_NULL;
-    free(s->route_segs); free(s->route_meta); free(s->spawn_tab); free(s->spawn_s); free(s->ray_cs);
+    free(s->route_segs); free(s->route_meta); free(s->spawn_tab); free(s->spawn_s); free(s->ray_cs); free(s->lines);
     free(s->st); free(s->env); free(s->seeds); free(s);
     return COPO_OK;
 }
@@ -207,30 +237,38 @@ static const float* SEG(oracle_sim* s, int route, int k) {
     return s->route_segs + ((size_t)route * (COPO_MAX_SEGS + 1) + k) * COPO_SEG_STRIDE;
 }
 
-/* spawn a fresh agent into slot n of env e at spawn point sp */
+/* pose of spawn slot sp: on lane `lane` of the spawn road (road 0 of its routes), `spawn_s` metres in */
+static void spawn_pose(oracle_sim* s, int sp, float* x, float* y) {
+    const float* g = SEG(s, s->spawn_tab[sp * 4 + 0], 0);
+    float s0 = s->spawn_s[sp];
+    float off = (float)s->spawn_tab[sp * 4 + 2] * s->cfg.lane_width;
+    *x = g[0] + g[2] * s0 + g[3] * off;
+    *y = g[1] + g[3] * s0 - g[2] * off;
+}
+
+/* spawn a fresh agent into slot n of env e at spawn slot sp: MetaDrive's reset / `_respawn_single_vehicle` +
+ * `_update_destination_for` (destination = the far end of the reverse of a random spawn road) */
 static void spawn_agent(oracle_sim* s, int e, int n, int sp) {
     const copo_sim_cfg* c = &s->cfg;
     int32_t* env = s->env + e * 4;
     uint64_t seed = s->seeds[e];
-    uint32_t cnt = (uint32_t)IP(s, S_SPAWNCNT, e)[n];
+    uint32_t cnt = (uint32_t)IP(s, S_SPAWNCNT, e)[n] & 0xffffu;
     uint32_t epi = (uint32_t)env[1];
     uint32_t h = o_hash(seed, (uint32_t)n, cnt, epi, RNG_ROUTE);
     int route = s->spawn_tab[sp * 4 + 0] + (int)(h % (uint32_t)s->spawn_tab[sp * 4 + 1]);
     const float* g = SEG(s, route, 0);
-    float s0 = s->spawn_s[sp];
-    FP(s, S_X, e)[n] = g[0] + g[2] * s0;
-    FP(s, S_Y, e)[n] = g[1] + g[3] * s0;
+    spawn_pose(s, sp, &FP(s, S_X, e)[n], &FP(s, S_Y, e)[n]);
     FP(s, S_TH, e)[n] = g[7];
     FP(s, S_V, e)[n] = 0.0f;
     FP(s, S_STEER, e)[n] = 0.0f;
     FP(s, S_THROTTLE, e)[n] = 0.0f;
+    FP(s, S_PSTEER, e)[n] = 0.0f;
+    FP(s, S_PTHROTTLE, e)[n] = 0.0f;
     FP(s, S_YAWRATE, e)[n] = 0.0f;
-    FP(s, S_PROG, e)[n] = s0;
-    FP(s, S_LAT, e)[n] = 0.0f;
+    FP(s, S_PROG, e)[n] = s->spawn_s[sp];
     FP(s, S_EPREW, e)[n] = 0.0f;
     IP(s, S_ROUTE, e)[n] = route;
-    IP(s, S_STATUS, e)[n] = ST_ALIVE;
-    IP(s, S_AGE, e)[n] = 0;
+    IP(s, S_STATUS, e)[n] = ST_PACK(ST_ALIVE, 0, 0);
     IP(s, S_AID, e)[n] = env[2];
     env[2] += 1;
     float lcf = 0.0f;
@@ -244,7 +282,7 @@ static void spawn_agent(oracle_sim* s, int e, int n, int sp) {
         lcf = o_clip(mean + (float)s->lcf_std * z, -1.0f, 1.0f);
     }
     FP(s, S_LCF, e)[n] = lcf;
-    IP(s, S_SPAWNCNT, e)[n] = (int32_t)(cnt + 1);
+    IP(s, S_SPAWNCNT, e)[n] = (int32_t)((cnt + 1) & 0xffffu);
 }
 
 static int oracle_capacity(const oracle_sim* s) {
@@ -252,6 +290,8 @@ static int oracle_capacity(const oracle_sim* s) {
     return c < 1 ? 1 : (c > N ? N : c);
 }
 
+/* reset: `num_agents` distinct spawn slots drawn from ALL slots of the spawn roads (SpawnManager: a respawn later
+ * only uses the `safe` slot at the far end of every lane) */
 static void reset_env(oracle_sim* s, int e) {
     const copo_sim_cfg* c = &s->cfg;
     int N = c->num_agents, P = c->n_spawns;
@@ -269,32 +309,34 @@ static void reset_env(oracle_sim* s, int e) {
     int cap = oracle_capacity(s);
     for (int n = 0; n < N; ++n) {
         if (n < cap) spawn_agent(s, e, n, perm[n]);
-        else IP(s, S_STATUS, e)[n] = ST_EMPTY;
+        else IP(s, S_STATUS, e)[n] = ST_PACK(ST_EMPTY, 0, 0);
     }
 }
 
-/* projection of (x,y) on route segment k: returns local arclength, lateral offset (left +), route heading */
-static void project_seg(const float* g, float x, float y, float* sl, float* lat, float* thr) {
+/* Projection of (x, y) with heading (ch, sh) on road g (its lane-0 line): arc length from the road's start, lateral
+ * offset (left +), and sin(heading - lane direction).  Arcs measure the angle from their MID point (g[14], g[15]), so
+ * nothing wraps inside an arc of up to 360 degrees. */
+static void project_seg(const float* g, float x, float y, float ch, float sh, float* sl, float* lat, float* sinpsi) {
     float dx = x - g[0], dy = y - g[1];
     float kap = g[5];
     if (kap == 0.0f) {
         *sl = dx * g[2] + dy * g[3];
         *lat = dy * g[2] - dx * g[3];
-        *thr = g[7];
+        *sinpsi = sh * g[2] - ch * g[3];
     } else {
         float sg = kap > 0.0f ? 1.0f : -1.0f;
-        float R = 1.0f / fabsf(kap);
-        /* centre = p0 + sg*R*n0, n0 = (-sin0, cos0); u0 = -sg*n0 */
+        float R = g[12];
+        /* centre = p0 + sg*R*n0, n0 = (-sin0, cos0) */
         float cx = g[0] - sg * R * g[3], cy = g[1] + sg * R * g[2];
         float ex = x - cx, ey = y - cy;
-        float ux = sg * g[3], uy = -sg * g[2];
         float rho = sqrtf(ex * ex + ey * ey);
-        float dotp = ux * ex + uy * ey;
-        float crs = ux * ey - uy * ex;
+        float dotp = g[14] * ex + g[15] * ey;
+        float crs = g[14] * ey - g[15] * ex;
         float ang = o_atan2f(sg * crs, dotp);
-        *sl = ang * R;
+        *sl = ang * R + 0.5f * g[4];
         *lat = sg * (R - rho);
-        *thr = o_wrap_pi(g[7] + kap * (*sl));
+        /* left normal of the lane at the vehicle = -sg * e / rho */
+        *sinpsi = rho > 0.0f ? (-sg * (ch * ex + sh * ey)) / rho : 0.0f;
     }
 }
 
@@ -309,16 +351,17 @@ typedef struct step_tmp {
     int fresh;
 } step_tmp;
 
-/* SAT overlap of two identical-size OBBs */
-static int obb_overlap(float xi, float yi, float ci, float si, float xj, float yj, float cj, float sj, float hl, float hw) {
+/* SAT overlap of two oriented boxes: centre, heading unit vector, half length / half width each */
+static int obb_overlap2(float xi, float yi, float ci, float si, float ai, float bi,
+                        float xj, float yj, float cj, float sj, float aj, float bj) {
     float dx = xj - xi, dy = yj - yi;
     float cc = fabsf(ci * cj + si * sj), ss = fabsf(ci * sj - si * cj);
     /* axes of i */
-    if (fabsf(dx * ci + dy * si) > hl + hl * cc + hw * ss) return 0;
-    if (fabsf(dy * ci - dx * si) > hw + hl * ss + hw * cc) return 0;
+    if (fabsf(dx * ci + dy * si) > ai + aj * cc + bj * ss) return 0;
+    if (fabsf(dy * ci - dx * si) > bi + aj * ss + bj * cc) return 0;
     /* axes of j */
-    if (fabsf(dx * cj + dy * sj) > hl + hl * cc + hw * ss) return 0;
-    if (fabsf(dy * cj - dx * sj) > hw + hl * ss + hw * cc) return 0;
+    if (fabsf(dx * cj + dy * sj) > aj + ai * cc + bi * ss) return 0;
+    if (fabsf(dy * cj - dx * sj) > bj + ai * ss + bi * cc) return 0;
     return 1;
 }
 
@@ -357,59 +400,129 @@ static void comm_cols(int CS, int comm_nb, int add_pos, int fresh, const int* id
     }
 }
 
+/* One detector beam (MetaDrive SideDetector / LaneLineDetector: a ray test against the lane-line bodies): smallest
+ * t in [0, range] at which the ray (x, y) + t (dx, dy) meets a line primitive of kind >= min_kind, or `range`.
+ * Straight pieces are decided by cross-multiplied comparisons (one division, for a hit that improves the minimum);
+ * arcs by the two roots of the circle equation, each accepted if its point lies within the arc's angular extent. */
+static float detector_ray(const oracle_sim* s, float x, float y, float dx, float dy, float range, float min_kind) {
+    float best = range;
+    for (int l = 0; l < s->cfg.n_lines; ++l) {
+        const float* L = s->lines + (size_t)l * COPO_LINE_STRIDE;
+        if (L[0] < min_kind) continue;
+        if (L[6] == 0.0f) {
+            float rx = L[1] - x, ry = L[2] - y;
+            float den = dx * L[4] - dy * L[3];
+            if (den == 0.0f) continue;
+            float sd = den > 0.0f ? 1.0f : -1.0f;
+            float ad = den * sd;
+            float tn = (rx * L[4] - ry * L[3]) * sd;
+            float un = (rx * dy - ry * dx) * sd;
+            if (!(tn >= 0.0f && un >= 0.0f && un <= L[5] * ad && tn < best * ad)) continue;
+            best = tn / ad;
+        } else {
+            float R = 1.0f / fabsf(L[6]);
+            float mx = x - L[7], my = y - L[8];
+            float b = mx * dx + my * dy;
+            float cq = mx * mx + my * my - R * R;
+            float disc = b * b - cq;
+            if (!(disc >= 0.0f)) continue;
+            float sq = sqrtf(disc);
+            for (int r = 0; r < 2; ++r) {
+                float tt = r == 0 ? -b - sq : -b + sq;
+                if (!(tt >= 0.0f && tt < best)) continue;
+                float hx = mx + tt * dx, hy = my + tt * dy;
+                if (hx * L[9] + hy * L[10] >= R * L[11]) { best = tt; break; }
+            }
+        }
+    }
+    return best;
+}
+
+/* Observation rows of the slots in `present` (MetaDrive 0.2.5 LidarStateObservation layout):
+ *   [side block | heading, speed, steering, last action x2, yaw rate | lane block | navigation | LiDAR | extensions] */
 static void write_obs(oracle_sim* s, int e, const copo_step_out* out, const uint8_t* present, const step_tmp* t,
                       const float* act) {
     const copo_sim_cfg* c = &s->cfg;
     int N = c->num_agents, O = c->obs_dim, L = c->num_lasers;
     float hl = c->veh_half_len, hw = c->veh_half_wid;
     float circ = sqrtf(hl * hl + hw * hw);
+    float w = c->lane_width;
     float cs[COPO_MAX_AGENTS], sn[COPO_MAX_AGENTS];
     uint8_t solid[COPO_MAX_AGENTS];
     for (int j = 0; j < N; ++j) {
-        int st = IP(s, S_STATUS, e)[j] & 0xff;
+        int st = ST_STATUS(IP(s, S_STATUS, e)[j]);
         solid[j] = (st == ST_ALIVE || st == ST_WRECK);
         o_sincosf(FP(s, S_TH, e)[j], &sn[j], &cs[j]);
     }
     for (int i = 0; i < N; ++i) {
         float* o = out->obs + ((size_t)e * N + i) * O;
         if (!present[i]) continue;      /* no agent, no row: the slot's observation bytes are left as they are */
-        float x = FP(s, S_X, e)[i], y = FP(s, S_Y, e)[i], th = FP(s, S_TH, e)[i];
+        float x = FP(s, S_X, e)[i], y = FP(s, S_Y, e)[i];
         int rw = IP(s, S_ROUTE, e)[i];
         int route = rw & 0xffff, seg = rw >> 16;
         const float* meta = s->route_meta + route * 4;
-        int nseg = (int)meta[3];
+        int nseg = (int)meta[1];
         const float* g = SEG(s, route, seg);
-        float sl, lat, thr;
-        project_seg(g, x, y, &sl, &lat, &thr);
-        float psi = o_wrap_pi(th - thr);
-        float W = meta[1] + meta[2];
-        /* ego block */
-        o[0] = o_clip((meta[1] - lat) / W, 0.0f, 1.0f);
-        o[1] = o_clip((lat + meta[2]) / W, 0.0f, 1.0f);
-        o[2] = o_clip(0.5f + psi / PI_F, 0.0f, 1.0f);
-        o[3] = o_clip(FP(s, S_V, e)[i] / c->max_speed, 0.0f, 1.0f);
-        o[4] = o_clip(0.5f + 0.5f * FP(s, S_STEER, e)[i], 0.0f, 1.0f);
-        o[5] = o_clip(0.5f + 0.5f * FP(s, S_STEER, e)[i], 0.0f, 1.0f);   /* last action[0] == applied steering */
-        o[6] = o_clip(0.5f + 0.5f * FP(s, S_THROTTLE, e)[i], 0.0f, 1.0f);
-        o[7] = o_clip(0.5f + 0.5f * FP(s, S_YAWRATE, e)[i], 0.0f, 1.0f);
-        o[8] = o_clip(0.5f + 0.5f * lat / c->lane_width, 0.0f, 1.0f);
-        /* navigation block: checkpoints at the end of the current and of the next segment */
-        for (int j = 0; j < 2; ++j) {
-            int kk = seg + j;
-            if (kk > nseg - 1) kk = nseg - 1;
-            const float* gk = SEG(s, route, kk);
-            const float* gn = SEG(s, route, kk + 1);
-            float rx = gn[0] - x, ry = gn[1] - y;
-            float fx = rx * cs[i] + ry * sn[i], fy = ry * cs[i] - rx * sn[i];
-            float* q = o + COPO_EGO_DIM + 5 * j;
-            q[0] = o_clip(0.5f + fx * 0.01f, 0.0f, 1.0f);
-            q[1] = o_clip(0.5f + fy * 0.01f, 0.0f, 1.0f);
-            q[2] = o_clip(0.5f + gk[5] * 5.0f, 0.0f, 1.0f);
-            q[3] = o_clip(gk[4] * 0.01f, 0.0f, 1.0f);
-            q[4] = (j == 0) ? o_clip(FP(s, S_PROG, e)[i] / meta[0], 0.0f, 1.0f) : ((kk == nseg - 1) ? 1.0f : 0.0f);
+        float sl, lat, sinpsi;
+        project_seg(g, x, y, cs[i], sn[i], &sl, &lat, &sinpsi);
+        float lanes = g[COPO_SEG_LANES];
+        float lif = floorf(0.5f - lat * s->inv_w);
+        lif = lif < 0.0f ? 0.0f : (lif > lanes - 1.0f ? lanes - 1.0f : lif);
+        float left = 0.5f * w - lat;            /* distance to the left edge of the road (of the current route) */
+        float right = lanes * w - left;
+        int col = 0;
+        if (c->side_lasers > 0) {
+            for (int k = 0; k < c->side_lasers; ++k) {
+                float a = c->side_cs[2 * k], b = c->side_cs[2 * k + 1];
+                float dx = cs[i] * a - sn[i] * b, dy = sn[i] * a + cs[i] * b;
+                o[col++] = detector_ray(s, x, y, dx, dy, c->side_range, 2.0f) * s->inv_side_range;
+            }
+        } else {
+            float tw = (lanes + 1.0f) * w;      /* StateObservation: (lane_num + 1) * lane_width */
+            o[col++] = o_clip(left / tw, 0.0f, 1.0f);
+            o[col++] = o_clip(right / tw, 0.0f, 1.0f);
         }
+        o[col++] = o_clip(0.5f - 0.5f * sinpsi, 0.0f, 1.0f);        /* heading_diff: cos to the lane's RIGHT normal */
+        o[col++] = o_clip((FP(s, S_V, e)[i] * 3.6f + 1.0f) * s->inv_vnorm, 0.0f, 1.0f);
+        o[col++] = o_clip(0.5f + FP(s, S_STEER, e)[i] * (1.0f / 120.0f), 0.0f, 1.0f);  /* (steering / MAX_STEERING(60) + 1) / 2 */
+        o[col++] = o_clip(0.5f + 0.5f * FP(s, S_PSTEER, e)[i], 0.0f, 1.0f);    /* last_current_action[0]: the step before */
+        o[col++] = o_clip(0.5f + 0.5f * FP(s, S_PTHROTTLE, e)[i], 0.0f, 1.0f);
+        o[col++] = o_clip(fabsf(FP(s, S_YAWRATE, e)[i]), 0.0f, 1.0f);          /* |heading change| / 0.1 */
+        if (c->lane_line_lasers > 0) {
+            for (int k = 0; k < c->lane_line_lasers; ++k) {
+                float a = c->lane_line_cs[2 * k], b = c->lane_line_cs[2 * k + 1];
+                float dx = cs[i] * a - sn[i] * b, dy = sn[i] * a + cs[i] * b;
+                o[col++] = detector_ray(s, x, y, dx, dy, c->lane_line_range, 1.0f) * s->inv_lane_range;
+            }
+        } else {
+            float latr = -(lat + lif * w);      /* offset in the vehicle's lane, right +; MAX_LANE_WIDTH 4.5 */
+            o[col++] = o_clip(0.5f + latr * (1.0f / 4.5f), 0.0f, 1.0f);
+        }
+        /* navigation block: check points at the end of the current road and of the next one (the current one again on
+         * the final road), Navigation._get_info_for_checkpoint */
+        if (c->navi_dim)
+            for (int j = 0; j < 2; ++j) {
+                int kk = seg + j;
+                if (kk > nseg - 1) kk = nseg - 1;
+                const float* gk = SEG(s, route, kk);
+                float vx = gk[COPO_SEG_CKX] - x, vy = gk[COPO_SEG_CKX + 1] - y;
+                float nrm = sqrtf(vx * vx + vy * vy);
+                if (nrm > 50.0f) {
+                    float sc = 50.0f / nrm;
+                    vx = vx * sc;
+                    vy = vy * sc;
+                }
+                float fwd = vx * cs[i] + vy * sn[i], rhs = vx * sn[i] - vy * cs[i];
+                float* q = o + col;
+                q[0] = o_clip(0.5f + fwd * 0.01f, 0.0f, 1.0f);
+                q[1] = o_clip(0.5f + rhs * 0.01f, 0.0f, 1.0f);
+                q[2] = gk[COPO_SEG_FEAT];
+                q[3] = gk[5] == 0.0f ? 0.5f : (gk[5] < 0.0f ? 1.0f : 0.0f);
+                q[4] = gk[COPO_SEG_FEAT + 2];
+                col += 5;
+            }
         /* LiDAR */
-        float* lid = o + COPO_EGO_DIM + COPO_NAVI_DIM;
+        float* lid = o + col;
         float range = c->lidar_range;
         for (int k = 0; k < L; ++k) {
             float dxr = cs[i] * s->ray_cs[2 * k] - sn[i] * s->ray_cs[2 * k + 1];
@@ -435,12 +548,12 @@ static void write_obs(oracle_sim* s, int e, const copo_step_out* out, const uint
                 if (!(nye * ax <= nxx * ay)) continue;                  /* enter-y after exit-x */
                 int usex = (nxe * ay >= nye * ax);                      /* the later entering plane */
                 float n = usex ? nxe : nye, a = usex ? ax : ay;
-                float t = n > 0.0f ? n / a : 0.0f;                      /* origin inside the box -> 0 */
-                if (t < best) best = t;
+                float tt = n > 0.0f ? n / a : 0.0f;                     /* origin inside the box -> 0 */
+                if (tt < best) best = tt;
             }
-            lid[k] = best / range;
+            lid[k] = best * s->inv_range;
         }
-        int col = COPO_EGO_DIM + COPO_NAVI_DIM + L;
+        col += L;
         if (c->add_traffic_light) {     /* counter = steps since the last reset (env word 0 is already advanced) */
             traffic_light_cols(c, s->env[e * 4], x, y, o + col);
             col += 3;
@@ -590,6 +703,7 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
     int E = c->num_envs, N = c->num_agents;
     float hl = c->veh_half_len, hw = c->veh_half_wid;
     float h = c->dt / (float)c->substeps;
+    float w = c->lane_width;
     for (int e = 0; e < E; ++e) {
         int32_t* env = s->env + e * 4;
         if (!env[3]) return COPO_ERR_STATE;
@@ -599,16 +713,17 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
         int32_t* STA = IP(s, S_STATUS, e);
         /* 0. timers of non-alive slots */
         for (int n = 0; n < N; ++n) {
-            int st = STA[n] & 0xff, tm = STA[n] >> 8;
+            int st = ST_STATUS(STA[n]), tm = ST_TIMER(STA[n]);
             t.acted[n] = (st == ST_ALIVE);
             if (st == ST_WRECK) {
                 tm -= 1;
-                if (tm <= 0) STA[n] = ST_EMPTY | (c->respawn_cooldown << 8); else STA[n] = ST_WRECK | (tm << 8);
+                if (tm <= 0) STA[n] = ST_PACK(ST_EMPTY, c->respawn_cooldown, 0); else STA[n] = ST_PACK(ST_WRECK, tm, 0);
             } else if (st == ST_EMPTY && tm > 0) {
-                STA[n] = ST_EMPTY | ((tm - 1) << 8);
+                STA[n] = ST_PACK(ST_EMPTY, tm - 1, 0);
             }
         }
-        /* 1. bicycle dynamics for acting slots */
+        /* 1. kinematic bicycle for acting slots: steering angle a0 * max_steer held over the step, slip angle of the
+         *    body centre beta = atan(tan(delta) / 2), engine 4 x max_engine_force / mass, brake friction-limited */
         for (int n = 0; n < N; ++n) {
             t.lcf_row[n] = FP(s, S_LCF, e)[n];
             t.aid_row[n] = t.acted[n] ? IP(s, S_AID, e)[n] : -1;
@@ -622,26 +737,33 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
             float delta = a0 * c->max_steer;
             float sd, cd;
             o_sincosf(delta, &sd, &cd);
-            float tan_over_L = (sd / cd) / c->wheelbase;
+            float tand = sd / cd;
+            float tb = 0.5f * tand;
+            float cb = 1.0f / sqrtf(1.0f + tb * tb), sb = tb * cb;
+            float yawk = (tand / c->wheelbase) * cb;
+            float brake = -a1 * c->brake_gain;
+            if (brake > c->brake_max) brake = c->brake_max;
             float x = X[n], y = Y[n], th = TH[n], v = V[n];
             float v0 = v, th0 = th;
             for (int k = 0; k < c->substeps; ++k) {
-                float a = a1 >= 0.0f ? a1 * c->acc_max * (1.0f - v / c->max_speed) : a1 * c->brake_max;
-                a = a - c->drag * v;
+                float a = a1 >= 0.0f ? (v < c->max_speed ? a1 * c->acc_max : 0.0f) : -brake;
                 v = v + a * h;
                 if (v < 0.0f) v = 0.0f;
                 float sn, cs;
                 o_sincosf(th, &sn, &cs);
-                x = x + v * cs * h;
-                y = y + v * sn * h;
-                th = o_wrap_pi(th + v * tan_over_L * h);
+                float dxh = cs * cb - sn * sb, dyh = sn * cb + cs * sb;
+                x = x + v * dxh * h;
+                y = y + v * dyh * h;
+                th = o_wrap_pi(th + v * yawk * h);
             }
             X[n] = x; Y[n] = y; TH[n] = th; V[n] = v;
+            FP(s, S_PSTEER, e)[n] = FP(s, S_STEER, e)[n];
+            FP(s, S_PTHROTTLE, e)[n] = FP(s, S_THROTTLE, e)[n];
             FP(s, S_STEER, e)[n] = a0;
             FP(s, S_THROTTLE, e)[n] = a1;
-            FP(s, S_YAWRATE, e)[n] = o_wrap_pi(th - th0) / c->dt;
-            t.acc[n] = (v - v0) / c->dt;
-            IP(s, S_AGE, e)[n] += 1;
+            FP(s, S_YAWRATE, e)[n] = o_wrap_pi(th - th0) * s->inv_dt;
+            t.acc[n] = (v - v0) * s->inv_dt;
+            STA[n] = ST_PACK(ST_ALIVE, 0, ST_AGE(STA[n]) + 1);
         }
         /* 2. heading unit vectors of all slots */
         for (int n = 0; n < N; ++n) o_sincosf(TH[n], &t.sn[n], &t.cs[n]);
@@ -653,9 +775,8 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
             crash_any[n] = 0;
             if (!t.acted[n]) continue;
             for (int j = 0; j < N; ++j) {
-                int stj = STA[j] & 0xff;
-                if (j == n || stj == ST_EMPTY) continue;
-                if (obb_overlap(X[n], Y[n], t.cs[n], t.sn[n], X[j], Y[j], t.cs[j], t.sn[j], hl, hw)) crash_any[n] = 1;
+                if (j == n || ST_STATUS(STA[j]) == ST_EMPTY) continue;
+                if (obb_overlap2(X[n], Y[n], t.cs[n], t.sn[n], hl, hw, X[j], Y[j], t.cs[j], t.sn[j], hl, hw)) crash_any[n] = 1;
             }
         }
         for (int n = 0; n < N; ++n) {
@@ -666,32 +787,38 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
             int rw = IP(s, S_ROUTE, e)[n];
             int route = rw & 0xffff, seg = rw >> 16;
             const float* meta = s->route_meta + route * 4;
-            int nseg = (int)meta[3];
-            float sl, lat, thr;
+            int nseg = (int)meta[1];
+            float sl, lat, sinpsi;
             const float* g = SEG(s, route, seg);
-            project_seg(g, X[n], Y[n], &sl, &lat, &thr);
-            for (int it = 0; it < 2; ++it) {
+            project_seg(g, X[n], Y[n], t.cs[n], t.sn[n], &sl, &lat, &sinpsi);
+            for (int it = 0; it < 2; ++it) {        /* Navigation.update_localization: on to the next road */
                 if (sl > g[4] && seg < nseg - 1) {
                     seg += 1;
                     g = SEG(s, route, seg);
-                    project_seg(g, X[n], Y[n], &sl, &lat, &thr);
+                    project_seg(g, X[n], Y[n], t.cs[n], t.sn[n], &sl, &lat, &sinpsi);
                 }
             }
             if (sl < 0.0f && seg > 0) {
                 seg -= 1;
                 g = SEG(s, route, seg);
-                project_seg(g, X[n], Y[n], &sl, &lat, &thr);
+                project_seg(g, X[n], Y[n], t.cs[n], t.sn[n], &sl, &lat, &sinpsi);
             }
             float prog = g[6] + sl;
             float prev = FP(s, S_PROG, e)[n];
             IP(s, S_ROUTE, e)[n] = route | (seg << 16);
             FP(s, S_PROG, e)[n] = prog;
-            FP(s, S_LAT, e)[n] = lat;
-            int arrive = (prog >= meta[0] - c->arrive_margin) && (lat <= meta[1]) && (lat >= -meta[2]);
-            int out_of_road = (lat > meta[1]) || (lat < -meta[2]) || (prog < -5.0f);
+            float lanes = g[COPO_SEG_LANES];
+            float lif = floorf(0.5f - lat * s->inv_w);
+            lif = lif < 0.0f ? 0.0f : (lif > lanes - 1.0f ? lanes - 1.0f : lif);
+            float left = 0.5f * w - lat, right = lanes * w - left;
+            int on_road = (left >= 0.0f) && (right >= 0.0f);
+            /* _is_arrive_destination: within +-5 m of the end of the final road, anywhere across it */
+            int arrive = (seg == nseg - 1) && (sl > g[4] - c->arrive_margin) && (sl < g[4] + c->arrive_margin) && on_road;
+            int out_of_road = !on_road;         /* vehicle.out_of_route (out_of_route_done) */
             int crash = crash_any[n];
-            float lf = o_clip(1.0f - 2.0f * fabsf(lat) / c->lane_width, 0.0f, 1.0f);
-            float r = c->driving_reward * (prog - prev) * lf + c->speed_reward * (V[n] / c->max_speed);
+            /* reward_function: longitudinal movement on the vehicle's lane (lane i of an arc is 1 + kappa * i * w longer
+             * than lane 0) + speed term; use_lateral is off in 0.2.5 */
+            float r = c->driving_reward * ((prog - prev) * (1.0f + g[5] * (lif * w))) + c->speed_reward * (V[n] / c->max_speed);
             uint8_t fl = COPO_F_ACTED;
             if (arrive) { r = c->success_reward; fl |= COPO_F_ARRIVE; }
             else if (out_of_road) { r = -c->out_penalty; }
@@ -712,8 +839,8 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
                 q[COPO_I_STEERING] = FP(s, S_STEER, e)[n];
                 q[COPO_I_ACCELERATION] = t.acc[n];
                 q[COPO_I_STEP_REWARD] = r;
-                q[COPO_I_COST] = (crash || out_of_road) ? 1.0f : 0.0f;
-                q[COPO_I_EPISODE_LENGTH] = (float)IP(s, S_AGE, e)[n];
+                q[COPO_I_COST] = crash ? 1.0f : 0.0f;
+                q[COPO_I_EPISODE_LENGTH] = (float)ST_AGE(STA[n]);
                 q[COPO_I_EPISODE_REWARD] = FP(s, S_EPREW, e)[n];
                 q[COPO_I_ROUTE_COMPLETION] = o_clip(prog / meta[0], 0.0f, 1.0f);
             }
@@ -721,43 +848,50 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
         if (out->info)
             for (int n = 0; n < N; ++n)
                 if (!t.acted[n]) memset(out->info + ((size_t)e * N + n) * COPO_INFO_DIM, 0, sizeof(float) * COPO_INFO_DIM);
-        /* 6. status update of terminated slots */
+        /* 6. status update of terminated slots: a vehicle that arrived leaves at once, every other one stays as a static
+         *    obstacle for `delay_done` steps (AgentManager.finish(ignore_delay_done = success)) */
         for (int n = 0; n < N; ++n) {
             if (!term[n]) continue;
-            if ((t.fl[n] & COPO_F_CRASH) && !(t.fl[n] & (COPO_F_ARRIVE | COPO_F_OUT)) && c->delay_done > 0)
-                STA[n] = ST_WRECK | (c->delay_done << 8);
+            if (!(t.fl[n] & COPO_F_ARRIVE) && (t.fl[n] & (COPO_F_CRASH | COPO_F_OUT)) && c->delay_done > 0)
+                STA[n] = ST_PACK(ST_WRECK, c->delay_done, 0);
             else
-                STA[n] = ST_EMPTY | (c->respawn_cooldown << 8);
+                STA[n] = ST_PACK(ST_EMPTY, c->respawn_cooldown, 0);
         }
         uint8_t present[COPO_MAX_AGENTS];
         for (int n = 0; n < N; ++n) present[n] = t.acted[n];
-        /* 7. respawn (serial in slot order) */
+        /* 7. respawn (serial in slot order): a random one of the SAFE places whose 8 x 3 m region holds no vehicle
+         *    (SpawnManager.get_available_respawn_places), each place at most once per step */
         if (!ending) {
+            uint32_t used = 0;
             for (int n = 0; n < N; ++n) {
                 if (n >= oracle_capacity(s)) break;
-                if (t.acted[n] || STA[n] != ST_EMPTY) continue; /* EMPTY with timer 0 only */
-                uint32_t cnt = (uint32_t)IP(s, S_SPAWNCNT, e)[n];
-                for (uint32_t a = 0; a < 3; ++a) {
-                    uint32_t hh = o_hash(s->seeds[e], (uint32_t)n, cnt, (uint32_t)env[0], RNG_SPAWN + a);
-                    int sp = (int)(hh % (uint32_t)c->n_spawns);
-                    int route0 = s->spawn_tab[sp * 4];
-                    const float* g = SEG(s, route0, 0);
-                    float sx = g[0] + g[2] * s->spawn_s[sp], sy = g[1] + g[3] * s->spawn_s[sp];
+                if (t.acted[n] || STA[n] != ST_PACK(ST_EMPTY, 0, 0)) continue;
+                int freep[COPO_MAX_SAFE], nfree = 0;
+                for (int q = 0; q < s->n_safe; ++q) {
+                    if (used & (1u << q)) continue;
+                    int sp = s->safe_ids[q];
+                    const float* g = SEG(s, s->spawn_tab[sp * 4], 0);
+                    float sx, sy;
+                    spawn_pose(s, sp, &sx, &sy);
                     int blocked = 0;
                     for (int j = 0; j < N; ++j) {
-                        if ((STA[j] & 0xff) == ST_EMPTY) continue;
-                        float dx = X[j] - sx, dy = Y[j] - sy;
-                        if (dx * dx + dy * dy < c->spawn_clearance * c->spawn_clearance) blocked = 1;
+                        if (ST_STATUS(STA[j]) == ST_EMPTY) continue;
+                        if (obb_overlap2(sx, sy, g[2], g[3], 0.5f * c->spawn_region_len, 0.5f * c->spawn_region_wid,
+                                         X[j], Y[j], t.cs[j], t.sn[j], hl, hw)) blocked = 1;
                     }
-                    if (!blocked) {
-                        spawn_agent(s, e, n, sp);
-                        present[n] = 1;
-                        t.newly[n] = 1;
-                        t.fl[n] = COPO_F_SPAWNED;
-                        t.lcf_row[n] = FP(s, S_LCF, e)[n];
-                        break;
-                    }
+                    if (!blocked) freep[nfree++] = q;
                 }
+                if (nfree == 0) break;          /* nowhere to go this step: everybody still waiting keeps waiting */
+                uint32_t cnt = (uint32_t)IP(s, S_SPAWNCNT, e)[n] & 0xffffu;
+                uint32_t hh = o_hash(s->seeds[e], (uint32_t)n, cnt, (uint32_t)env[0], RNG_SPAWN);
+                int q = freep[hh % (uint32_t)nfree];
+                used |= 1u << q;
+                spawn_agent(s, e, n, s->safe_ids[q]);
+                o_sincosf(TH[n], &t.sn[n], &t.cs[n]);
+                present[n] = 1;
+                t.newly[n] = 1;
+                t.fl[n] = COPO_F_SPAWNED;
+                t.lcf_row[n] = FP(s, S_LCF, e)[n];
             }
         }
         /* 8. neighbour lists, reward reductions, row outputs (on the pre-reset scene) */

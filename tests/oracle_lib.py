@@ -20,33 +20,7 @@ def build(force=False):
     return LIB
 
 
-class SimCfg(C.Structure):
-    _fields_ = [
-        ("num_envs", C.c_int32), ("num_agents", C.c_int32), ("num_lasers", C.c_int32), ("obs_dim", C.c_int32),
-        ("nbr_k", C.c_int32), ("enable_lcf", C.c_int32), ("horizon", C.c_int32), ("delay_done", C.c_int32),
-        ("respawn_cooldown", C.c_int32), ("substeps", C.c_int32),
-        ("lidar_range", C.c_float), ("neighbours_distance", C.c_float), ("mf_distance", C.c_float),
-        ("dt", C.c_float), ("veh_half_len", C.c_float), ("veh_half_wid", C.c_float), ("wheelbase", C.c_float),
-        ("max_steer", C.c_float), ("max_speed", C.c_float), ("acc_max", C.c_float), ("brake_max", C.c_float),
-        ("drag", C.c_float), ("spawn_clearance", C.c_float),
-        ("driving_reward", C.c_float), ("speed_reward", C.c_float), ("success_reward", C.c_float),
-        ("crash_penalty", C.c_float), ("out_penalty", C.c_float), ("arrive_margin", C.c_float),
-        ("lane_width", C.c_float),
-        ("lcf_mean", C.c_double), ("lcf_std", C.c_double),
-        ("n_routes", C.c_int32), ("n_spawns", C.c_int32),
-        ("route_segs", C.c_void_p), ("route_meta", C.c_void_p), ("spawn_tab", C.c_void_p), ("spawn_s", C.c_void_p),
-        ("ray_cs", C.c_void_p),
-        ("add_traffic_light", C.c_int32), ("traffic_light_interval", C.c_int32), ("comm_size", C.c_int32),
-        ("comm_neighbours", C.c_int32), ("add_pos_in_comm", C.c_int32), ("map_bbox", C.c_float * 4),
-    ]
-
-
-OUT_FIELDS = ("obs", "rew", "nei_rew", "glob_rew", "flags", "nbr_idx", "nbr_cnt", "mf_cnt", "nbr_dist", "lcf", "info",
-              "agent_id")
-
-
-class StepOut(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in OUT_FIELDS]
+from copo_amd._abi import STEP_OUT_FIELDS as OUT_FIELDS, SimCfg, StepOut  # noqa: E402
 
 
 _lib = None
