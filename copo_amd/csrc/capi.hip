@@ -66,8 +66,12 @@ extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** o
         return fail(COPO_ERR_CONFIG, "comm_size=%d comm_neighbours=%d", cfg->comm_size, cfg->comm_neighbours);
     if (cfg->add_traffic_light && (cfg->traffic_light_interval < 1 || !(cfg->map_bbox[1] > cfg->map_bbox[0]) || !(cfg->map_bbox[3] > cfg->map_bbox[2])))
         return fail(COPO_ERR_CONFIG, "add_traffic_light needs traffic_light_interval >= 1 and a non-empty map_bbox");
+    if (cfg->side_lasers < 0 || cfg->side_lasers > COPO_MAX_LASERS || cfg->lane_line_lasers < 0 || cfg->lane_line_lasers > COPO_MAX_LASERS)
+        return fail(COPO_ERR_DIM, "side_lasers=%d lane_line_lasers=%d out of 0..%d", cfg->side_lasers, cfg->lane_line_lasers, COPO_MAX_LASERS);
+    if ((cfg->navi_dim != 0 && cfg->navi_dim != COPO_NAVI_DIM) || (cfg->toll_dim != 0 && cfg->toll_dim != 2))
+        return fail(COPO_ERR_CONFIG, "navi_dim=%d (0 or %d) toll_dim=%d (0 or 2)", cfg->navi_dim, COPO_NAVI_DIM, cfg->toll_dim);
     const int O = COPO_OBS_DIM(cfg);
-    if (cfg->obs_dim != O) return fail(COPO_ERR_DIM, "obs_dim=%d but 9+10+lasers(+3 traffic light)(+1 lcf)(+comm)=%d", cfg->obs_dim, O);
+    if (cfg->obs_dim != O) return fail(COPO_ERR_DIM, "obs_dim=%d but the configured blocks add up to %d (COPO_OBS_DIM)", cfg->obs_dim, O);
     if (cfg->nbr_k < 1 || cfg->nbr_k > COPO_MAX_AGENTS) return fail(COPO_ERR_DIM, "nbr_k=%d out of 1..64", cfg->nbr_k);
     if (cfg->n_routes < 1 || cfg->n_routes > COPO_MAX_ROUTES || cfg->n_spawns < cfg->num_agents ||
         cfg->n_spawns > COPO_MAX_SPAWNS)
@@ -75,24 +79,31 @@ extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** o
                     cfg->n_spawns, COPO_MAX_SPAWNS);
     if (!cfg->route_segs || !cfg->route_meta || !cfg->spawn_tab || !cfg->spawn_s || !cfg->ray_cs)
         return fail(COPO_ERR_NULL, "copo_sim_create: a map table pointer is NULL");
-    if (cfg->substeps < 1 || cfg->horizon < 1 || cfg->respawn_cooldown < 1 || cfg->delay_done < 0 ||
-        cfg->delay_done > (1 << 20))
-        return fail(COPO_ERR_CONFIG, "substeps/horizon/respawn_cooldown must be >= 1, delay_done >= 0");
+    if (cfg->n_lines < 0 || cfg->n_lines > COPO_MAX_LINES ||
+        ((cfg->side_lasers || cfg->lane_line_lasers) && (!cfg->lines || (cfg->side_lasers && !cfg->side_cs) || (cfg->lane_line_lasers && !cfg->lane_line_cs))))
+        return fail(COPO_ERR_CONFIG, "detectors need the line table and their beam tables (n_lines=%d, max %d)", cfg->n_lines, COPO_MAX_LINES);
+    if (cfg->substeps < 1 || cfg->horizon < 1 || cfg->horizon > 65535 || cfg->respawn_cooldown < 0 || cfg->respawn_cooldown > 255 ||
+        cfg->delay_done < 0 || cfg->delay_done > 255)
+        return fail(COPO_ERR_CONFIG, "substeps >= 1, 1 <= horizon <= 65535, 0 <= respawn_cooldown, delay_done <= 255");
     if (!(cfg->lcf_std > 0.0) || cfg->lcf_mean < -1.0 || cfg->lcf_mean > 1.0)
         return fail(COPO_ERR_CONFIG, "lcf_mean must be in [-1,1] and lcf_std > 0 (env_wrappers.py:195,425-426)");
     for (int r = 0; r < cfg->n_routes; ++r) {
-        const int nseg = (int)cfg->route_meta[r * 4 + 3];
-        if (nseg < 1 || nseg > COPO_MAX_SEGS) return fail(COPO_ERR_CONFIG, "route %d has %d segments", r, nseg);
+        const int nseg = (int)cfg->route_meta[r * 4 + 1];
+        if (nseg < 1 || nseg > COPO_MAX_SEGS) return fail(COPO_ERR_CONFIG, "route %d has %d roads", r, nseg);
     }
+    std::vector<int32_t> safe;
     for (int s = 0; s < cfg->n_spawns; ++s) {
         const int r0 = cfg->spawn_tab[s * 4], nc = cfg->spawn_tab[s * 4 + 1];
         if (r0 < 0 || nc < 1 || r0 + nc > cfg->n_routes) return fail(COPO_ERR_CONFIG, "spawn %d: bad route range", s);
         for (int r = r0; r < r0 + nc; ++r) {
             const float* g = cfg->route_segs + (size_t)r * (COPO_MAX_SEGS + 1) * COPO_SEG_STRIDE;
-            if (g[5] != 0.0f || !(cfg->spawn_s[s] < g[4]))
-                return fail(COPO_ERR_CONFIG, "spawn %d must lie on the straight first segment of route %d", s, r);
+            if (g[5] != 0.0f || !(cfg->spawn_s[s] < g[4]) || cfg->spawn_tab[s * 4 + 2] < 0 || (float)cfg->spawn_tab[s * 4 + 2] >= g[COPO_SEG_LANES])
+                return fail(COPO_ERR_CONFIG, "spawn %d must lie on a lane of the straight first road of route %d", s, r);
         }
+        if (cfg->spawn_tab[s * 4 + 3]) safe.push_back(s);
     }
+    if (safe.empty() || safe.size() > COPO_MAX_SAFE)
+        return fail(COPO_ERR_CONFIG, "%zu respawn places (spawn slots marked safe): need 1..%d", safe.size(), COPO_MAX_SAFE);
     copo_sim* s = new (std::nothrow) copo_sim();
     if (!s) return fail(COPO_ERR_DEVICE, "out of host memory");
     s->device = device;
@@ -113,8 +124,16 @@ extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** o
     p.enable_lcf = cfg->enable_lcf; p.horizon = cfg->horizon; p.delay_done = cfg->delay_done;
     p.respawn_cooldown = cfg->respawn_cooldown; p.substeps = cfg->substeps;
     p.n_routes = cfg->n_routes; p.n_spawns = cfg->n_spawns;
-    {   // observation row: [ego | navigation | lasers | traffic light | lcf | messages]
-        int col = COPO_EGO_DIM + COPO_NAVI_DIM + cfg->num_lasers;
+    {   // observation row: [side | state | lane | navigation | lasers | toll | traffic light | lcf | messages]
+        p.side_lasers = cfg->side_lasers; p.lane_lasers = cfg->lane_line_lasers; p.navi_dim = cfg->navi_dim;
+        p.toll_dim = cfg->toll_dim; p.toll_min_steps = cfg->toll_min_steps;
+        p.col_state = COPO_SIDE_DIM(cfg);
+        p.col_lane = p.col_state + COPO_STATE_DIM;
+        p.col_navi = p.col_lane + COPO_LANE_DIM(cfg);
+        p.col_lidar = p.col_navi + cfg->navi_dim;
+        int col = p.col_lidar + cfg->num_lasers;
+        p.col_toll = cfg->toll_dim ? col : -1;
+        col += cfg->toll_dim;
         p.col_tl = cfg->add_traffic_light ? col : -1;
         col += cfg->add_traffic_light ? 3 : 0;
         p.col_lcf = cfg->enable_lcf ? col : -1;
@@ -127,14 +146,27 @@ extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** o
         p.comm_pos = cfg->add_pos_in_comm ? 1 : 0;
         for (int k = 0; k < 4; ++k) p.bbox[k] = cfg->map_bbox[k];
     }
-    { const char* e = getenv("COPO_SIM_SKIP"); p.dbg_skip = e ? atoi(e) : 0; }   // profiling only: see sim_common.h
     p.lidar_range = cfg->lidar_range; p.neighbours_distance = cfg->neighbours_distance; p.mf_distance = cfg->mf_distance;
     p.dt = cfg->dt; p.hl = cfg->veh_half_len; p.hw = cfg->veh_half_wid; p.wheelbase = cfg->wheelbase;
-    p.max_steer = cfg->max_steer; p.max_speed = cfg->max_speed; p.acc_max = cfg->acc_max; p.brake_max = cfg->brake_max;
-    p.drag = cfg->drag; p.spawn_clearance = cfg->spawn_clearance;
+    p.max_steer = cfg->max_steer; p.max_speed = cfg->max_speed; p.acc_max = cfg->acc_max; p.brake_gain = cfg->brake_gain;
+    p.brake_max = cfg->brake_max;
+    p.region_hl = 0.5f * cfg->spawn_region_len; p.region_hw = 0.5f * cfg->spawn_region_wid;
     p.driving_reward = cfg->driving_reward; p.speed_reward = cfg->speed_reward; p.success_reward = cfg->success_reward;
     p.crash_penalty = cfg->crash_penalty; p.out_penalty = cfg->out_penalty; p.arrive_margin = cfg->arrive_margin;
     p.lane_width = cfg->lane_width;
+    p.side_range = cfg->side_range; p.lane_range = cfg->lane_line_range;
+    // derived constants: single float operations (this file is compiled with -ffp-contract=off), as in the oracle
+    p.inv_w = 1.0f / cfg->lane_width;
+    p.inv_range = 1.0f / cfg->lidar_range;
+    p.inv_vnorm = 1.0f / (cfg->max_speed * 3.6f + 1.0f);
+    p.inv_dt = 1.0f / cfg->dt;
+    p.inv_side_range = cfg->side_lasers ? 1.0f / cfg->side_range : 0.0f;
+    p.inv_lane_range = cfg->lane_line_lasers ? 1.0f / cfg->lane_line_range : 0.0f;
+    p.inv_toll = cfg->toll_dim ? 1.0f / (float)(cfg->toll_min_steps > 0 ? cfg->toll_min_steps : 1) : 0.0f;
+    p.h_sub = cfg->dt / (float)cfg->substeps;
+    p.ray_sign = (cfg->num_lasers > 2 && cfg->ray_cs[3] < 0.0f) ? -1.0f : 1.0f;   // the beam table's sense of rotation
+    p.n_safe = (int32_t)safe.size();
+    p.n_lines = (cfg->side_lasers || cfg->lane_line_lasers) ? cfg->n_lines : 0;
     int rc = COPO_OK;
     const size_t EN = (size_t)p.E * p.N;
     void* d = nullptr;
@@ -156,6 +188,10 @@ extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** o
     if (rc == COPO_OK) rc = upload(s, cfg->spawn_tab, (size_t)cfg->n_spawns * 4, &p.spawn_tab);
     if (rc == COPO_OK) rc = upload(s, cfg->spawn_s, (size_t)cfg->n_spawns, &p.spawn_s);
     if (rc == COPO_OK) rc = upload(s, cfg->ray_cs, (size_t)cfg->num_lasers * 2, &p.ray_cs);
+    if (rc == COPO_OK) rc = upload(s, safe.data(), safe.size(), &p.safe_ids);
+    if (rc == COPO_OK && p.n_lines) rc = upload(s, cfg->lines, (size_t)cfg->n_lines * COPO_LINE_STRIDE, &p.lines);
+    if (rc == COPO_OK && cfg->side_lasers) rc = upload(s, cfg->side_cs, (size_t)cfg->side_lasers * 2, &p.side_cs);
+    if (rc == COPO_OK && cfg->lane_line_lasers) rc = upload(s, cfg->lane_line_cs, (size_t)cfg->lane_line_lasers * 2, &p.lane_cs);
     if (rc != COPO_OK) {
         for (void* a : s->allocs) (void)hipFree(a);
         delete s;

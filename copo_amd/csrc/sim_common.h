@@ -16,12 +16,17 @@ enum : uint32_t { RNG_ROUTE = 1, RNG_LCF1 = 2, RNG_LCF2 = 3, RNG_SPAWN = 4, RNG_
 // Kernel parameter block (passed by value).  All pointers are device pointers owned by the handle.
 struct SimParams {
     int32_t E, N, O, K, num_lasers, enable_lcf, horizon, delay_done, respawn_cooldown, substeps;
-    int32_t n_routes, n_spawns;
-    int32_t dbg_skip;              // profiling only (env COPO_SIM_SKIP): 1 no neighbour phase, 2 no LiDAR box tests, 4 no LiDAR
-                                   // write-out, 8 no ego/navigation block, 16 collision phase twice; results are then wrong
+    int32_t n_routes, n_spawns, n_safe, n_lines;
+    int32_t side_lasers, lane_lasers, navi_dim, toll_dim, toll_min_steps;
     float lidar_range, neighbours_distance, mf_distance, dt, hl, hw, wheelbase, max_steer, max_speed;
-    float acc_max, brake_max, drag, spawn_clearance;
+    float acc_max, brake_gain, brake_max, region_hl, region_hw;
     float driving_reward, speed_reward, success_reward, crash_penalty, out_penalty, arrive_margin, lane_width;
+    float side_range, lane_range;
+    float ray_sign;                // +1: beam k is turned k steps counter-clockwise of the heading, -1: clockwise (MetaDrive)
+    // constants derived once on the host, in float, exactly as the oracle derives them
+    float inv_w, inv_range, inv_vnorm, inv_dt, inv_side_range, inv_lane_range, inv_toll, h_sub;
+    // observation row layout: [side block | 6 state | lane block | navigation | lasers | toll | traffic light | lcf | comm]
+    int32_t col_state, col_lane, col_navi, col_lidar, col_toll;
     // observation / action extensions (copo_sim_cfg): columns are -1 when the block is off
     int32_t act_dim, tl_interval, comm_size, comm_nb, comm_pos, col_tl, col_lcf, col_comm;
     float bbox[4];
@@ -32,7 +37,11 @@ struct SimParams {
     const float* route_meta;       // [R][4]
     const int32_t* spawn_tab;      // [P][4]
     const float* spawn_s;          // [P]
+    const int32_t* safe_ids;       // [n_safe] spawn slots that are respawn places
     const float* ray_cs;           // [num_lasers][2]
+    const float* side_cs;          // [side_lasers][2]
+    const float* lane_cs;          // [lane_lasers][2]
+    const float* lines;            // [n_lines][COPO_LINE_STRIDE]
     long long* dbg;                // optional [E][8] phase timestamps (clock64) of the step kernel; NULL = off
     const float* lcf_dist;         // [4] = {mean (force_lcf folded in), std, capacity, 0}: device memory so that captured graphs see updates
 };

@@ -17,85 +17,100 @@ namespace copo {
 // ------------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void project_seg(const float* __restrict__ g, float x, float y, float& sl, float& lat,
-                                            float& thr) {
-    const float gx = g[0], gy = g[1], gc = g[2], gs = g[3], kap = g[5], th0 = g[7];
+// Projection of (x, y) with heading (ch, sh) on road g (its lane-0 line): arc length from the road's start, lateral
+// offset (left +) and sin(heading - lane direction).  Arcs measure the angle from their mid point (g[14], g[15]).
+__device__ __forceinline__ void project_seg(const float* __restrict__ g, float x, float y, float ch, float sh, float& sl,
+                                            float& lat, float& sinpsi) {
+    const float gx = g[0], gy = g[1], gc = g[2], gs = g[3], kap = g[5];
     const float dx = x - gx, dy = y - gy;
     if (kap == 0.0f) {
         sl = dx * gc + dy * gs;
         lat = dy * gc - dx * gs;
-        thr = th0;
+        sinpsi = sh * gc - ch * gs;
     } else {
         const float sg = kap > 0.0f ? 1.0f : -1.0f;
-        const float R = 1.0f / fabsf(kap);
+        const float R = g[12];
         const float cx = gx - sg * R * gs, cy = gy + sg * R * gc;
         const float ex = x - cx, ey = y - cy;
-        const float ux = sg * gs, uy = -sg * gc;
         const float rho = sqrtf(ex * ex + ey * ey);
-        const float dotp = ux * ex + uy * ey;
-        const float crs = ux * ey - uy * ex;
+        const float umx = g[14], umy = g[15];
+        const float dotp = umx * ex + umy * ey;
+        const float crs = umx * ey - umy * ex;
         const float ang = atan2_det(sg * crs, dotp);
-        sl = ang * R;
+        sl = ang * R + 0.5f * g[4];
         lat = sg * (R - rho);
-        thr = wrap_pi(th0 + kap * sl);
+        sinpsi = rho > 0.0f ? (-sg * (ch * ex + sh * ey)) / rho : 0.0f;
     }
 }
 
-__device__ __forceinline__ bool obb_overlap(float xi, float yi, float ci, float si, float xj, float yj, float cj,
-                                            float sj, float hl, float hw) {
+// SAT overlap of two oriented boxes (centre, heading unit vector, half length, half width each)
+__device__ __forceinline__ bool obb_overlap2(float xi, float yi, float ci, float si, float ai, float bi, float xj, float yj,
+                                             float cj, float sj, float aj, float bj) {
     const float dx = xj - xi, dy = yj - yi;
     const float cc = fabsf(ci * cj + si * sj), ss = fabsf(ci * sj - si * cj);
-    if (fabsf(dx * ci + dy * si) > hl + hl * cc + hw * ss) return false;
-    if (fabsf(dy * ci - dx * si) > hw + hl * ss + hw * cc) return false;
-    if (fabsf(dx * cj + dy * sj) > hl + hl * cc + hw * ss) return false;
-    if (fabsf(dy * cj - dx * sj) > hw + hl * ss + hw * cc) return false;
+    if (fabsf(dx * ci + dy * si) > ai + aj * cc + bj * ss) return false;
+    if (fabsf(dy * ci - dx * si) > bi + aj * ss + bj * cc) return false;
+    if (fabsf(dx * cj + dy * sj) > aj + ai * cc + bi * ss) return false;
+    if (fabsf(dy * cj - dx * sj) > bj + ai * ss + bi * cc) return false;
     return true;
 }
 
 // Slot state held in the registers of lane n of wave 0.
+//   status word: status | timer << 8 | age << 16;  spawncnt word: spawn count | toll wait << 16
 struct Slot {
-    float x, y, th, v, steer, throttle, yawrate, prog, lat, lcf, eprew;
-    int32_t route, status, age, aid, spawncnt;
+    float x, y, th, v, steer, throttle, psteer, pthrottle, yawrate, prog, lcf, eprew;
+    int32_t route, status, aid, spawncnt;
 };
+__device__ __forceinline__ int st_status(int32_t w) { return w & 0xff; }
+__device__ __forceinline__ int st_timer(int32_t w) { return (w >> 8) & 0xff; }
+__device__ __forceinline__ int st_age(int32_t w) { return (int)((uint32_t)w >> 16); }
+__device__ __forceinline__ int32_t st_pack(int st, int tm, int age) {
+    return (int32_t)((uint32_t)st | ((uint32_t)tm << 8) | ((uint32_t)age << 16));
+}
 
 __device__ __forceinline__ void load_slot(const SimParams& p, int e, int n, Slot& s) {
     const size_t EN = (size_t)p.E * p.N, o = (size_t)e * p.N + n;
     const float* st = p.state;
     s.x = st[0 * EN + o]; s.y = st[1 * EN + o]; s.th = st[2 * EN + o]; s.v = st[3 * EN + o];
-    s.steer = st[4 * EN + o]; s.throttle = st[5 * EN + o]; s.yawrate = st[6 * EN + o]; s.prog = st[7 * EN + o];
-    s.lat = st[8 * EN + o]; s.lcf = st[9 * EN + o]; s.eprew = st[10 * EN + o];
+    s.steer = st[4 * EN + o]; s.throttle = st[5 * EN + o]; s.psteer = st[6 * EN + o]; s.pthrottle = st[7 * EN + o];
+    s.yawrate = st[8 * EN + o]; s.prog = st[9 * EN + o]; s.lcf = st[10 * EN + o]; s.eprew = st[11 * EN + o];
     const int32_t* si = reinterpret_cast<const int32_t*>(st);
-    s.route = si[11 * EN + o]; s.status = si[12 * EN + o]; s.age = si[13 * EN + o]; s.aid = si[14 * EN + o];
-    s.spawncnt = si[15 * EN + o];
+    s.route = si[12 * EN + o]; s.status = si[13 * EN + o]; s.aid = si[14 * EN + o]; s.spawncnt = si[15 * EN + o];
 }
 
 __device__ __forceinline__ void store_slot(const SimParams& p, int e, int n, const Slot& s) {
     const size_t EN = (size_t)p.E * p.N, o = (size_t)e * p.N + n;
     float* st = p.state;
     st[0 * EN + o] = s.x; st[1 * EN + o] = s.y; st[2 * EN + o] = s.th; st[3 * EN + o] = s.v;
-    st[4 * EN + o] = s.steer; st[5 * EN + o] = s.throttle; st[6 * EN + o] = s.yawrate; st[7 * EN + o] = s.prog;
-    st[8 * EN + o] = s.lat; st[9 * EN + o] = s.lcf; st[10 * EN + o] = s.eprew;
+    st[4 * EN + o] = s.steer; st[5 * EN + o] = s.throttle; st[6 * EN + o] = s.psteer; st[7 * EN + o] = s.pthrottle;
+    st[8 * EN + o] = s.yawrate; st[9 * EN + o] = s.prog; st[10 * EN + o] = s.lcf; st[11 * EN + o] = s.eprew;
     int32_t* si = reinterpret_cast<int32_t*>(st);
-    si[11 * EN + o] = s.route; si[12 * EN + o] = s.status; si[13 * EN + o] = s.age; si[14 * EN + o] = s.aid;
-    si[15 * EN + o] = s.spawncnt;
+    si[12 * EN + o] = s.route; si[13 * EN + o] = s.status; si[14 * EN + o] = s.aid; si[15 * EN + o] = s.spawncnt;
 }
 
-// Spawn a fresh agent into this lane's slot at spawn point sp (spec 3.6).  `aid` is the env-wide id.
+// pose of spawn slot sp: lane `stab[sp][2]` of the spawn road (road 0 of its routes), `sps[sp]` metres in
+__device__ __forceinline__ void spawn_pose(const SimParams& p, const float* rsegs, const int32_t* stab, const float* sps,
+                                           int sp, float& x, float& y) {
+    const float* g = rsegs + (size_t)stab[sp * 4 + 0] * (COPO_MAX_SEGS + 1) * COPO_SEG_STRIDE;
+    const float s0 = sps[sp];
+    const float off = (float)stab[sp * 4 + 2] * p.lane_width;
+    x = g[0] + g[2] * s0 + g[3] * off;
+    y = g[1] + g[3] * s0 - g[2] * off;
+}
+
+// Spawn a fresh agent into this lane's slot at spawn slot sp.  `aid` is the env-wide id.
 __device__ __forceinline__ void spawn_slot(const SimParams& p, const float* rsegs, const int32_t* stab, const float* sps,
                                            uint64_t seed, uint32_t episode, int n, int sp, int32_t aid, Slot& s) {
-    const uint32_t cnt = (uint32_t)s.spawncnt;
+    const uint32_t cnt = (uint32_t)s.spawncnt & 0xffffu;
     const uint32_t h = hash_rng(seed, (uint32_t)n, cnt, episode, RNG_ROUTE);
     const int route = stab[sp * 4 + 0] + (int)(h % (uint32_t)stab[sp * 4 + 1]);
     const float* g = rsegs + (size_t)route * (COPO_MAX_SEGS + 1) * COPO_SEG_STRIDE;
-    const float s0 = sps[sp];
-    s.x = g[0] + g[2] * s0;
-    s.y = g[1] + g[3] * s0;
+    spawn_pose(p, rsegs, stab, sps, sp, s.x, s.y);
     s.th = g[7];
-    s.v = 0.0f; s.steer = 0.0f; s.throttle = 0.0f; s.yawrate = 0.0f;
-    s.prog = s0; s.lat = 0.0f; s.eprew = 0.0f;
+    s.v = 0.0f; s.steer = 0.0f; s.throttle = 0.0f; s.psteer = 0.0f; s.pthrottle = 0.0f; s.yawrate = 0.0f;
+    s.prog = sps[sp]; s.eprew = 0.0f;
     s.route = route;
-    s.status = ST_ALIVE;
-    s.age = 0;
+    s.status = st_pack(ST_ALIVE, 0, 0);
     s.aid = aid;
     float lcf = 0.0f;
     if (p.enable_lcf) {
@@ -107,7 +122,7 @@ __device__ __forceinline__ void spawn_slot(const SimParams& p, const float* rseg
         lcf = clipf(p.lcf_dist[0] + p.lcf_dist[1] * z, -1.0f, 1.0f);
     }
     s.lcf = lcf;
-    s.spawncnt = (int32_t)(cnt + 1);
+    s.spawncnt = (int32_t)((cnt + 1) & 0xffffu);
 }
 
 struct __align__(16) EnvLds {
@@ -118,6 +133,7 @@ struct __align__(16) EnvLds {
     int32_t rowbase[64];       // first LiDAR minimum of a present slot's fan, -1 for an absent slot
     unsigned long long m_acted, m_present, m_solid;
     uint8_t crash[64];
+    float spx[COPO_MAX_SAFE], spy[COPO_MAX_SAFE], spc[COPO_MAX_SAFE], spsn[COPO_MAX_SAFE];   // respawn places: pose
     const float* rsegs;        // route segment records: the LDS copy of the step kernel (small maps) or global memory
     const float* rmeta;        // route meta records, same
     const int32_t* stab;       // spawn table, same
@@ -129,7 +145,7 @@ struct __align__(16) EnvLds {
 __device__ __forceinline__ const float* seg_ptr(const EnvLds& L, int route, int k) {
     return L.rsegs + ((size_t)route * (COPO_MAX_SEGS + 1) + k) * COPO_SEG_STRIDE;
 }
-constexpr int ROUTE_LDS_MAX_BYTES = 12 * 1024;
+constexpr int ROUTE_LDS_MAX_BYTES = 16 * 1024;
 // dynamic LDS: [slots][rays] LiDAR minima, then the route-table copy
 // (the neighbour phase borrows it for its [slots][slots] list-order rewards and a reset for its spawn permutation);
 // then the ray direction table, then the route-table copy
@@ -177,7 +193,7 @@ __device__ __forceinline__ void reset_env_wave0(const SimParams& p, EnvLds& L, u
     // population capacity (curriculum): slots beyond it start empty and never respawn
     const int cap = capacity_of(p);
     if (lane < cap) spawn_slot(p, L.rsegs, L.stab, L.sps, seed, episode, lane, (int)perm[lane], lane, s);
-    else if (lane < p.N) s.status = ST_EMPTY;
+    else if (lane < p.N) s.status = st_pack(ST_EMPTY, 0, 0);
 }
 
 // neighbour lists + reward reductions (CCEnv / LCFEnv) for agents i = wave, wave+nw, ...; lane = other agent j
@@ -296,9 +312,10 @@ __device__ __forceinline__ void neighbours_phase(const SimParams& p, EnvLds& L, 
     }
 }
 
-// ego + navigation block of the observation for this lane's slot -> LDS tile
-// (written straight to the observation row of the slot: 19 leading columns + the LCF column at the end)
-// `counter` = env steps since the last reset (the traffic-light clock, env_wrappers.py:258-265,280,317).
+// State + navigation blocks of the observation of this lane's slot (MetaDrive 0.2.5 StateObservation.vehicle_state +
+// Navigation._get_info_for_checkpoint), written straight to the slot's observation row; the detector / LiDAR columns
+// are filled by obs_phase.  `counter` = env steps since the last reset (the traffic-light clock,
+// env_wrappers.py:258-265,280,317).
 template <bool EXT>
 __device__ __forceinline__ void ego_navi_obs(const SimParams& p, EnvLds& L, int lane, const Slot& s, bool present,
                                              float* __restrict__ row, int counter, bool zero_comm) {
@@ -307,7 +324,6 @@ __device__ __forceinline__ void ego_navi_obs(const SimParams& p, EnvLds& L, int 
         const int n = p.comm_nb * (p.comm_size + 3 * p.comm_pos);     // episode ran on the scene BEFORE the reset)
         for (int k = 0; k < n; ++k) row[p.col_comm + k] = 0.0f;
     }
-    float o[20];
     if (EXT && p.col_tl >= 0) {   // clip([message, x', y'], 0, 1) in python float64 arithmetic, cast to fp32
         const int I = p.tl_interval;
         const double inc = (double)(counter % I) / (double)I * 0.1;
@@ -319,42 +335,99 @@ __device__ __forceinline__ void ego_navi_obs(const SimParams& p, EnvLds& L, int 
     }
     const int route = s.route & 0xffff, seg = s.route >> 16;
     const float* meta = L.rmeta + route * 4;
-    const float total = meta[0], latl = meta[1], latr = meta[2];
-    const int nseg = (int)meta[3];
+    const int nseg = (int)meta[1];
     const float* g = seg_ptr(L, route, seg);
-    float sl, lat, thr;
-    project_seg(g, s.x, s.y, sl, lat, thr);
-    const float psi = wrap_pi(s.th - thr);
-    const float W = latl + latr;
     const float cs = L.cs[lane], sn = L.sn[lane];
-    o[0] = clipf((latl - lat) / W, 0.0f, 1.0f);
-    o[1] = clipf((lat + latr) / W, 0.0f, 1.0f);
-    o[2] = clipf(0.5f + psi / kPi, 0.0f, 1.0f);
-    o[3] = clipf(s.v / p.max_speed, 0.0f, 1.0f);
-    o[4] = clipf(0.5f + 0.5f * s.steer, 0.0f, 1.0f);
-    o[5] = clipf(0.5f + 0.5f * s.steer, 0.0f, 1.0f);
-    o[6] = clipf(0.5f + 0.5f * s.throttle, 0.0f, 1.0f);
-    o[7] = clipf(0.5f + 0.5f * s.yawrate, 0.0f, 1.0f);
-    o[8] = clipf(0.5f + 0.5f * lat / p.lane_width, 0.0f, 1.0f);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        int kk = seg + j;
-        if (kk > nseg - 1) kk = nseg - 1;
-        const float* gk = seg_ptr(L, route, kk);
-        const float* gn = seg_ptr(L, route, kk + 1);
-        const float rx = gn[0] - s.x, ry = gn[1] - s.y;
-        const float fx = rx * cs + ry * sn, fy = ry * cs - rx * sn;
-        float* q = o + COPO_EGO_DIM + 5 * j;
-        q[0] = clipf(0.5f + fx * 0.01f, 0.0f, 1.0f);
-        q[1] = clipf(0.5f + fy * 0.01f, 0.0f, 1.0f);
-        q[2] = clipf(0.5f + gk[5] * 5.0f, 0.0f, 1.0f);
-        q[3] = clipf(gk[4] * 0.01f, 0.0f, 1.0f);
-        q[4] = (j == 0) ? clipf(s.prog / total, 0.0f, 1.0f) : ((kk == nseg - 1) ? 1.0f : 0.0f);
+    float sl, lat, sinpsi;
+    project_seg(g, s.x, s.y, cs, sn, sl, lat, sinpsi);
+    const float w = p.lane_width;
+    const float lanes = g[COPO_SEG_LANES];
+    float lif = floorf(0.5f - lat * p.inv_w);
+    lif = lif < 0.0f ? 0.0f : (lif > lanes - 1.0f ? lanes - 1.0f : lif);
+    const float left = 0.5f * w - lat;
+    const float right = lanes * w - left;
+    if (p.side_lasers == 0) {
+        const float tw = (lanes + 1.0f) * w;
+        row[0] = clipf(left / tw, 0.0f, 1.0f);
+        row[1] = clipf(right / tw, 0.0f, 1.0f);
     }
-    o[19] = (s.lcf + 1.0f) * 0.5f;
+    float* q = row + p.col_state;
+    q[0] = clipf(0.5f - 0.5f * sinpsi, 0.0f, 1.0f);
+    q[1] = clipf((s.v * 3.6f + 1.0f) * p.inv_vnorm, 0.0f, 1.0f);
+    q[2] = clipf(0.5f + s.steer * (1.0f / 120.0f), 0.0f, 1.0f);
+    q[3] = clipf(0.5f + 0.5f * s.psteer, 0.0f, 1.0f);
+    q[4] = clipf(0.5f + 0.5f * s.pthrottle, 0.0f, 1.0f);
+    q[5] = clipf(fabsf(s.yawrate), 0.0f, 1.0f);
+    if (p.lane_lasers == 0) {
+        const float latr = -(lat + lif * w);
+        row[p.col_lane] = clipf(0.5f + latr * (1.0f / 4.5f), 0.0f, 1.0f);
+    }
+    if (p.navi_dim) {
 #pragma unroll
-    for (int k = 0; k < 19; ++k) row[k] = o[k];
-    if (p.col_lcf >= 0) row[p.col_lcf] = o[19];
+        for (int j = 0; j < 2; ++j) {
+            int kk = seg + j;
+            if (kk > nseg - 1) kk = nseg - 1;
+            const float* gk = seg_ptr(L, route, kk);
+            float vx = gk[COPO_SEG_CKX] - s.x, vy = gk[COPO_SEG_CKX + 1] - s.y;
+            const float nrm = sqrtf(vx * vx + vy * vy);
+            if (nrm > 50.0f) {
+                const float sc = 50.0f / nrm;
+                vx = vx * sc;
+                vy = vy * sc;
+            }
+            const float fwd = vx * cs + vy * sn, rhs = vx * sn - vy * cs;
+            float* n5 = row + p.col_navi + 5 * j;
+            const float kap = gk[5];
+            n5[0] = clipf(0.5f + fwd * 0.01f, 0.0f, 1.0f);
+            n5[1] = clipf(0.5f + rhs * 0.01f, 0.0f, 1.0f);
+            n5[2] = gk[COPO_SEG_FEAT];
+            n5[3] = kap == 0.0f ? 0.5f : (kap < 0.0f ? 1.0f : 0.0f);
+            n5[4] = gk[COPO_SEG_FEAT + 2];
+        }
+    }
+    if (p.toll_dim) {
+        const uint32_t wait = (uint32_t)s.spawncnt >> 16;
+        row[p.col_toll] = (seg == (int)meta[2]) ? 1.0f : 0.0f;
+        row[p.col_toll + 1] = clipf((float)wait * p.inv_toll, 0.0f, 1.0f);
+    }
+    if (p.col_lcf >= 0) row[p.col_lcf] = (s.lcf + 1.0f) * 0.5f;
+}
+
+// One detector beam against the lane-line primitives (MetaDrive SideDetector / LaneLineDetector): see the oracle's
+// detector_ray for the arithmetic, which this repeats operation by operation.
+__device__ __forceinline__ float detector_ray(const SimParams& p, const float* __restrict__ lines, float x, float y, float dx,
+                                              float dy, float range, float min_kind) {
+    float best = range;
+    for (int l = 0; l < p.n_lines; ++l) {
+        const float* Ln = lines + (size_t)l * COPO_LINE_STRIDE;
+        if (Ln[0] < min_kind) continue;
+        if (Ln[6] == 0.0f) {
+            const float rx = Ln[1] - x, ry = Ln[2] - y;
+            const float den = dx * Ln[4] - dy * Ln[3];
+            if (den == 0.0f) continue;
+            const float sd = den > 0.0f ? 1.0f : -1.0f;
+            const float ad = den * sd;
+            const float tn = (rx * Ln[4] - ry * Ln[3]) * sd;
+            const float un = (rx * dy - ry * dx) * sd;
+            if (!(tn >= 0.0f && un >= 0.0f && un <= Ln[5] * ad && tn < best * ad)) continue;
+            best = tn / ad;
+        } else {
+            const float R = 1.0f / fabsf(Ln[6]);
+            const float mx = x - Ln[7], my = y - Ln[8];
+            const float b = mx * dx + my * dy;
+            const float cq = mx * mx + my * my - R * R;
+            const float disc = b * b - cq;
+            if (!(disc >= 0.0f)) continue;
+            const float sq = sqrtf(disc);
+            for (int r = 0; r < 2; ++r) {
+                const float tt = r == 0 ? -b - sq : -b + sq;
+                if (!(tt >= 0.0f && tt < best)) continue;
+                const float hx = mx + tt * dx, hy = my + tt * dy;
+                if (hx * Ln[9] + hy * Ln[10] >= R * Ln[11]) { best = tt; break; }
+            }
+        }
+    }
+    return best;
 }
 
 // Ray (origin (x, y), unit direction (dxr, dyr)) against the box of vehicle j: entering distance, or a negative
@@ -450,7 +523,7 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
     const int ncombo = np * ns;
     const float inv_ns = 1.0f / (float)(ns > 0 ? ns : 1);
     const float rays_per_rad = (float)NL * 0.159154943f;
-    for (int c0 = wave * 64; c0 < ((p.dbg_skip & 2) ? 0 : ncombo); c0 += nwaves * 64) {
+    for (int c0 = wave * 64; c0 < ncombo; c0 += nwaves * 64) {
         const int c = c0 + lane;
         const bool live = c < ncombo;
         const int ip = live ? (int)(((float)c + 0.5f) * inv_ns) : 0;
@@ -463,7 +536,7 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
                 cnt = NL;                         // origin inside the circumcircle: any ray may hit
             } else {
                 const float ci = L.cs[i], si = L.sn[i];
-                const float phi = atan2_window(ci * dy - si * dx, ci * dx + si * dy);
+                const float phi = p.ray_sign * atan2_window(ci * dy - si * dx, ci * dx + si * dy);   // in beam-index direction
                 const float x = circ * __builtin_amdgcn_rsqf(d2);
                 const float w = x + 0.5708f * x * x * x + 0.004f;     // >= asin(x) + margin
                 const int lo = (int)ceilf((phi - w) * rays_per_rad), hi = (int)floorf((phi + w) * rays_per_rad);
@@ -510,10 +583,29 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
     __syncthreads();
     const int nrays = N * NL;
     const float inv_nl = 1.0f / (float)NL;
-    for (int q = tid; q < ((p.dbg_skip & 4) ? 0 : nrays); q += nthreads) {
+    const float inv_range = p.inv_range;
+    const int col_lidar = p.col_lidar;
+    for (int q = tid; q < nrays; q += nthreads) {
         const int i = (int)(((float)q + 0.5f) * inv_nl), k = q - i * NL;
         const int rb = L.rowbase[i];
-        if (rb >= 0) eobs[i * O + (COPO_EGO_DIM + COPO_NAVI_DIM) + k] = __uint_as_float(best[rb + k]) / range;
+        if (rb >= 0) eobs[i * O + col_lidar + k] = __uint_as_float(best[rb + k]) * inv_range;
+    }
+    // optional side / lane-line detector beams (Bottleneck, Tollgate): one thread per (present agent, beam)
+    const int nb = p.side_lasers + p.lane_lasers;
+    if (nb > 0) {
+        const float inv_nb = 1.0f / (float)nb;
+        for (int q = tid; q < np * nb; q += nthreads) {
+            const int ip = (int)(((float)q + 0.5f) * inv_nb), b = q - ip * nb;
+            const int i = L.plist[ip];
+            const bool side = b < p.side_lasers;
+            const int k = side ? b : b - p.side_lasers;
+            const float* tab = side ? p.side_cs : p.lane_cs;
+            const float a0 = tab[2 * k], b0 = tab[2 * k + 1];
+            const float ci = L.cs[i], si = L.sn[i];
+            const float dx = ci * a0 - si * b0, dy = si * a0 + ci * b0;
+            const float t = detector_ray(p, p.lines, L.x[i], L.y[i], dx, dy, side ? p.side_range : p.lane_range, side ? 2.0f : 1.0f);
+            eobs[i * O + (side ? k : p.col_lane + k)] = t * (side ? p.inv_side_range : p.inv_lane_range);
+        }
     }
 }
 
@@ -621,7 +713,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
 
 #define COPO_STAMP(i) do { if (p.dbg && tid == 0) p.dbg[(size_t)e * 8 + (i)] = (long long)clock64(); } while (0)
     COPO_STAMP(0);
-    // ---- P0 (wave 0): timers + bicycle dynamics, poses -> LDS ------------------------------------
+    // ---- P0 (wave 0): timers + kinematic bicycle, poses -> LDS ----------------------------------------
     Slot s = Slot{};
     bool acted = false;
     float acc = 0.0f;
@@ -633,14 +725,14 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
         seed = p.seeds[e];
         if (lane < N) {
             load_slot(p, e, lane, s);
-            const int st = s.status & 0xff;
-            int tm = s.status >> 8;
+            const int st = st_status(s.status);
+            int tm = st_timer(s.status);
             acted = (st == ST_ALIVE);
             if (st == ST_WRECK) {
                 tm -= 1;
-                s.status = (tm <= 0) ? (ST_EMPTY | (p.respawn_cooldown << 8)) : (ST_WRECK | (tm << 8));
+                s.status = (tm <= 0) ? st_pack(ST_EMPTY, p.respawn_cooldown, 0) : st_pack(ST_WRECK, tm, 0);
             } else if (st == ST_EMPTY && tm > 0) {
-                s.status = ST_EMPTY | ((tm - 1) << 8);
+                s.status = st_pack(ST_EMPTY, tm - 1, 0);
             }
             if (acted) {
                 float a0, a1;
@@ -658,33 +750,39 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
                 const float delta = a0 * p.max_steer;
                 float sd, cd;
                 sincos_det(delta, sd, cd);
-                const float tan_over_L = (sd / cd) / p.wheelbase;
-                const float h = p.dt / (float)p.substeps;
+                const float tand = sd / cd;
+                const float tb = 0.5f * tand;
+                const float cb = 1.0f / sqrtf(1.0f + tb * tb), sb = tb * cb;
+                const float yawk = (tand / p.wheelbase) * cb;
+                float brake = -a1 * p.brake_gain;
+                if (brake > p.brake_max) brake = p.brake_max;
+                const float h = p.h_sub;
                 float x = s.x, y = s.y, th = s.th, v = s.v;
                 const float v0 = v, th0 = th;
                 for (int k = 0; k < p.substeps; ++k) {
-                    float a = a1 >= 0.0f ? a1 * p.acc_max * (1.0f - v / p.max_speed) : a1 * p.brake_max;
-                    a = a - p.drag * v;
+                    const float a = a1 >= 0.0f ? (v < p.max_speed ? a1 * p.acc_max : 0.0f) : -brake;
                     v = v + a * h;
                     if (v < 0.0f) v = 0.0f;
                     float sn, cs;
                     sincos_det(th, sn, cs);
-                    x = x + v * cs * h;
-                    y = y + v * sn * h;
-                    th = wrap_pi(th + v * tan_over_L * h);
+                    const float dxh = cs * cb - sn * sb, dyh = sn * cb + cs * sb;
+                    x = x + v * dxh * h;
+                    y = y + v * dyh * h;
+                    th = wrap_pi(th + v * yawk * h);
                 }
                 s.x = x; s.y = y; s.th = th; s.v = v;
+                s.psteer = s.steer; s.pthrottle = s.throttle;
                 s.steer = a0; s.throttle = a1;
-                s.yawrate = wrap_pi(th - th0) / p.dt;
-                acc = (v - v0) / p.dt;
-                s.age += 1;
+                s.yawrate = wrap_pi(th - th0) * p.inv_dt;
+                acc = (v - v0) * p.inv_dt;
+                s.status = st_pack(ST_ALIVE, 0, st_age(s.status) + 1);
             }
             stage_pose(L, lane, s);
         } else {
             L.x[lane] = 0.0f; L.y[lane] = 0.0f; L.cs[lane] = 1.0f; L.sn[lane] = 0.0f;
         }
         const unsigned long long ma = __ballot(acted);
-        const bool sol0 = lane < N && (s.status & 0xff) != ST_EMPTY;
+        const bool sol0 = lane < N && st_status(s.status) != ST_EMPTY;
         const unsigned long long ms = __ballot(sol0);
         const unsigned long long lt = (1ull << lane) - 1ull;
         if (acted) L.alist[__popcll(ma & lt)] = (uint8_t)lane;
@@ -700,7 +798,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
     COPO_STAMP(1);
 
     // ---- P1 (all waves): collision of every (acting agent, solid vehicle) pair, one lane per pair -----
-    for (int rep = 0; rep < ((p.dbg_skip & 16) ? 2 : 1); ++rep) {
+    {
         const int na = __popcll(L.m_acted), nc = __popcll(L.m_solid);
         const int npair = na * nc;
         const float inv_nc = 1.0f / (float)(nc > 0 ? nc : 1);
@@ -713,7 +811,15 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
             const float xi = L.x[i], yi = L.y[i], xj = L.x[j], yj = L.y[j];
             const float ddx = xj - xi, ddy = yj - yi;
             const bool near = live && (i != j) && (ddx * ddx + ddy * ddy <= near2);
-            if (near && obb_overlap(xi, yi, L.cs[i], L.sn[i], xj, yj, L.cs[j], L.sn[j], hl, hw)) L.crash[i] = 1;
+            if (near && obb_overlap2(xi, yi, L.cs[i], L.sn[i], hl, hw, xj, yj, L.cs[j], L.sn[j], hl, hw)) L.crash[i] = 1;
+        }
+        // the respawn places of the map: pose of place q (wave 1 if there is one; published by the barrier below)
+        if (wave == (nwaves > 1 ? 1 : 0) && lane < p.n_safe) {
+            const int sp = p.safe_ids[lane];
+            float sx, sy;
+            spawn_pose(p, L.rsegs, L.stab, L.sps, sp, sx, sy);
+            const float* g = seg_ptr(L, L.stab[sp * 4], 0);
+            L.spx[lane] = sx; L.spy[lane] = sy; L.spc[lane] = g[2]; L.spsn[lane] = g[3];
         }
     }
     __syncthreads();
@@ -731,35 +837,50 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
         aid_row = acted ? s.aid : -1;
         if (acted) {
             const int route = s.route & 0xffff;
-            int seg = s.route >> 16;
+            const int seg_before = s.route >> 16;
+            int seg = seg_before;
             const float* meta = L.rmeta + route * 4;
-            const float total = meta[0], latl = meta[1], latr = meta[2];
-            const int nseg = (int)meta[3];
+            const float total = meta[0];
+            const int nseg = (int)meta[1];
             const float* g = seg_ptr(L, route, seg);
-            float sl, lat, thr;
-            project_seg(g, s.x, s.y, sl, lat, thr);
+            const float ch = L.cs[lane], sh = L.sn[lane];
+            float sl, lat, sinpsi;
+            project_seg(g, s.x, s.y, ch, sh, sl, lat, sinpsi);
             for (int it = 0; it < 2; ++it) {
                 if (sl > g[4] && seg < nseg - 1) {
                     seg += 1;
                     g = seg_ptr(L, route, seg);
-                    project_seg(g, s.x, s.y, sl, lat, thr);
+                    project_seg(g, s.x, s.y, ch, sh, sl, lat, sinpsi);
                 }
             }
             if (sl < 0.0f && seg > 0) {
                 seg -= 1;
                 g = seg_ptr(L, route, seg);
-                project_seg(g, s.x, s.y, sl, lat, thr);
+                project_seg(g, s.x, s.y, ch, sh, sl, lat, sinpsi);
             }
             const float prog = g[6] + sl;
             const float prev = s.prog;
+            bool too_fast = false;
+            if (p.toll_dim) {
+                const int toll_seg = (int)meta[2];
+                const uint32_t sc = (uint32_t)s.spawncnt;
+                uint32_t wait = sc >> 16;
+                if (seg == toll_seg && wait < 0xffffu) wait += 1;
+                too_fast = toll_seg >= 0 && seg > toll_seg && seg_before <= toll_seg && wait < (uint32_t)p.toll_min_steps;
+                s.spawncnt = (int32_t)((sc & 0xffffu) | (wait << 16));
+            }
             s.route = route | (seg << 16);
             s.prog = prog;
-            s.lat = lat;
-            const bool arrive = (prog >= total - p.arrive_margin) && (lat <= latl) && (lat >= -latr);
-            const bool oor = (lat > latl) || (lat < -latr) || (prog < -5.0f);
-            const bool crash = L.crash[lane] != 0;
-            const float lf = clipf(1.0f - 2.0f * fabsf(lat) / p.lane_width, 0.0f, 1.0f);
-            float r = p.driving_reward * (prog - prev) * lf + p.speed_reward * (s.v / p.max_speed);
+            const float w = p.lane_width;
+            const float lanes = g[COPO_SEG_LANES];
+            float lif = floorf(0.5f - lat * p.inv_w);
+            lif = lif < 0.0f ? 0.0f : (lif > lanes - 1.0f ? lanes - 1.0f : lif);
+            const float left = 0.5f * w - lat, right = lanes * w - left;
+            const bool on_road = (left >= 0.0f) && (right >= 0.0f);
+            const bool arrive = (seg == nseg - 1) && (sl > g[4] - p.arrive_margin) && (sl < g[4] + p.arrive_margin) && on_road;
+            const bool oor = !on_road;
+            const bool crash = (L.crash[lane] != 0) || too_fast;
+            float r = p.driving_reward * ((prog - prev) * (1.0f + g[5] * (lif * w))) + p.speed_reward * (s.v / p.max_speed);
             fl = COPO_F_ACTED;
             if (arrive) { r = p.success_reward; fl |= COPO_F_ARRIVE; }
             else if (oor) { r = -p.out_penalty; }
@@ -779,63 +900,57 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
                 q[COPO_I_STEERING] = s.steer;
                 q[COPO_I_ACCELERATION] = acc;
                 q[COPO_I_STEP_REWARD] = r;
-                q[COPO_I_COST] = (crash || oor) ? 1.0f : 0.0f;
-                q[COPO_I_EPISODE_LENGTH] = (float)s.age;
+                q[COPO_I_COST] = crash ? 1.0f : 0.0f;
+                q[COPO_I_EPISODE_LENGTH] = (float)st_age(s.status);
                 q[COPO_I_EPISODE_REWARD] = s.eprew;
                 q[COPO_I_ROUTE_COMPLETION] = clipf(prog / total, 0.0f, 1.0f);
             }
             if (term) {
-                if ((fl & COPO_F_CRASH) && !(fl & (COPO_F_ARRIVE | COPO_F_OUT)) && p.delay_done > 0)
-                    s.status = ST_WRECK | (p.delay_done << 8);
+                if (!(fl & COPO_F_ARRIVE) && (fl & (COPO_F_CRASH | COPO_F_OUT)) && p.delay_done > 0)
+                    s.status = st_pack(ST_WRECK, p.delay_done, 0);
                 else
-                    s.status = ST_EMPTY | (p.respawn_cooldown << 8);
+                    s.status = st_pack(ST_EMPTY, p.respawn_cooldown, 0);
             }
         } else if (lane < N && out.info) {
             float* q = out.info + ((size_t)e * N + lane) * COPO_INFO_DIM;
             for (int k = 0; k < COPO_INFO_DIM; ++k) q[k] = 0.0f;
         }
         present = acted;
-        // respawn, serial over eligible slots in slot order; every lane tests its own vehicle
+        // respawn: a random one of the respawn places whose region is clear of the vehicles standing now, each place at
+        // most once per step; serial over the eligible slots in slot order, every lane tests its own vehicle
         if (!ending) {
-            const bool mine = lane < capacity_of(p) && !acted && s.status == ST_EMPTY;
+            const bool mine = lane < capacity_of(p) && !acted && s.status == st_pack(ST_EMPTY, 0, 0);
             unsigned long long elig = __ballot(mine);
-            // the three hashed spawn points of every eligible slot depend on (seed, slot, spawn count, t) only: all
-            // lanes draw theirs at once, the serial part below only tests them against the vehicles on the road
-            int spc[3] = {0, 0, 0};
-            float sxc[3] = {0.0f, 0.0f, 0.0f}, syc[3] = {0.0f, 0.0f, 0.0f};
-            if (mine) {
-#pragma unroll
-                for (uint32_t a = 0; a < 3; ++a) {
-                    const uint32_t hh = hash_rng(seed, (uint32_t)lane, (uint32_t)s.spawncnt, (uint32_t)t_env, RNG_SPAWN + a);
-                    const int sp = (int)(hh % (uint32_t)p.n_spawns);
-                    const float* g = seg_ptr(L, L.stab[sp * 4], 0);
-                    const float s0 = L.sps[sp];
-                    spc[a] = sp;
-                    sxc[a] = g[0] + g[2] * s0;
-                    syc[a] = g[1] + g[3] * s0;
+            if (elig) {
+                const bool solid_now = lane < N && st_status(s.status) != ST_EMPTY;
+                const float cj = L.cs[lane], sj = L.sn[lane];      // poses of terminated vehicles did not change since P0
+                uint32_t clear = 0;
+                for (int q = 0; q < p.n_safe; ++q) {
+                    const bool blk = solid_now && obb_overlap2(L.spx[q], L.spy[q], L.spc[q], L.spsn[q], p.region_hl, p.region_hw,
+                                                               s.x, s.y, cj, sj, hl, hw);
+                    if (__ballot(blk) == 0ull) clear |= 1u << q;
                 }
-            }
-            const float clear2 = p.spawn_clearance * p.spawn_clearance;
-            while (elig) {
-                const int n = __ffsll((long long)elig) - 1;
-                elig &= elig - 1;
-#pragma unroll
-                for (uint32_t a = 0; a < 3; ++a) {
-                    const float sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sxc[a]), n));
-                    const float sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(syc[a]), n));
-                    const int sp = spc[a];
-                    const float dx = s.x - sx, dy = s.y - sy;
-                    const bool blk = (lane < N) && ((s.status & 0xff) != ST_EMPTY) && (dx * dx + dy * dy < clear2);
-                    if (__ballot(blk) == 0ull) {
-                        if (lane == n) {
-                            spawn_slot(p, L.rsegs, L.stab, L.sps, seed, (uint32_t)episode, n, sp, next_aid, s);
-                            present = true;
-                            fl = COPO_F_SPAWNED;
-                            lcf_row = s.lcf;
-                        }
-                        next_aid += 1;
-                        break;
+                uint32_t used = 0;
+                while (elig) {
+                    const int n = __ffsll((long long)elig) - 1;
+                    elig &= elig - 1;
+                    const uint32_t freem = clear & ~used;
+                    if (!freem) break;
+                    const int nfree = __popc(freem);
+                    const uint32_t cnt_n = (uint32_t)__builtin_amdgcn_readlane(s.spawncnt, n) & 0xffffu;
+                    const uint32_t hh = hash_rng(seed, (uint32_t)n, cnt_n, (uint32_t)t_env, RNG_SPAWN);
+                    int pick = (int)(hh % (uint32_t)nfree);
+                    uint32_t m = freem;
+                    while (pick > 0) { m &= m - 1; --pick; }
+                    const int q = __ffs((int)m) - 1;
+                    used |= 1u << q;
+                    if (lane == n) {
+                        spawn_slot(p, L.rsegs, L.stab, L.sps, seed, (uint32_t)episode, n, p.safe_ids[q], next_aid, s);
+                        present = true;
+                        fl = COPO_F_SPAWNED;
+                        lcf_row = s.lcf;
                     }
+                    next_aid += 1;
                 }
             }
         }
@@ -846,7 +961,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
             L.rew[lane] = 0.0f;
         }
         const unsigned long long mp = __ballot(present);
-        const unsigned long long ms = __ballot(lane < N && (s.status & 0xff) != ST_EMPTY);
+        const unsigned long long ms = __ballot(lane < N && st_status(s.status) != ST_EMPTY);
         if (lane == 0) {
             L.m_present = mp;
             L.m_solid = ms;
@@ -856,8 +971,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
 
     COPO_STAMP(3);
     // ---- P3 (all waves): neighbour lists + reward reductions on the post-step (pre-reset) scene ---
-    if (!(p.dbg_skip & 1)) neighbours_phase<EXT>(p, L, e, wave, nwaves, lane, out, act, L.m_acted, ending);
-    else __syncthreads();
+    neighbours_phase<EXT>(p, L, e, wave, nwaves, lane, out, act, L.m_acted, ending);
     COPO_STAMP(4);
     // (neighbours_phase ends with a workgroup barrier: the reset below may overwrite the poses it read)
 
@@ -895,7 +1009,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
             env[1] = episode;
             env[2] = next_aid;
         }
-        if (!(p.dbg_skip & 8)) ego_navi_obs<EXT>(p, L, lane, s, present, (out.obs && lane < N) ? out.obs + ((size_t)e * N + lane) * p.O : nullptr, ending ? 0 : t_env + 1, ending);
+        ego_navi_obs<EXT>(p, L, lane, s, present, (out.obs && lane < N) ? out.obs + ((size_t)e * N + lane) * p.O : nullptr, ending ? 0 : t_env + 1, ending);
     }
     __syncthreads();
 

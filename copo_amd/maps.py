@@ -43,7 +43,7 @@ ENTRANCE_LENGTH = 10.0           # FirstPGBlock: the first 10 m of the first blo
 class MapTables:
     name: str
     route_segs: np.ndarray   # [R][MAX_SEGS+1][SEG_STRIDE] f32
-    route_meta: np.ndarray   # [R][4] f32: total_len (lane-0 line), nseg, lanes of the final road, 0
+    route_meta: np.ndarray   # [R][4] f32: total_len (lane-0 line), nseg, index of the toll-booth road (-1: none), 0
     spawn_tab: np.ndarray    # [P][4] i32: first_route, n_destinations, lane, safe (1 = a respawn place)
     spawn_s: np.ndarray      # [P] f32 longitudinal position of the slot on the spawn road
     default_num_agents: int
@@ -97,12 +97,15 @@ class Net:
         self.roads = OrderedDict()
         self.adj = OrderedDict()
         self.lines = []          # [x0, y0, theta0, length, kappa, kind, 0, 0]
+        self.toll_roads = set()  # roads that are toll booths (Tollgate)
 
     def add(self, a, b, pose, length, kappa, lanes, left_line=LINE_CONTINUOUS, right_line=LINE_CONTINUOUS,
-            inner_line=LINE_BROKEN):
+            inner_line=LINE_BROKEN, toll=False):
         """`pose` is the start of lane 0's centre line.  Line kinds: 0 = none (inside junctions)."""
         assert (a, b) not in self.roads, (a, b)
         self.roads[(a, b)] = (tuple(float(v) for v in pose), float(length), float(kappa), int(lanes))
+        if toll:
+            self.toll_roads.add((a, b))
         self.adj.setdefault(a, []).append(b)
         self.adj.setdefault(b, [])
         w = self.w
@@ -184,9 +187,11 @@ class _Builder:
         if len(nodes) - 1 > MAX_SEGS:
             raise ValueError("route needs %d roads > MAX_SEGS" % (len(nodes) - 1))
         rec = np.zeros((MAX_SEGS + 1, SEG_STRIDE), np.float64)
-        s, lanes = 0.0, 1
+        s, lanes, toll = 0.0, 1, -1
         for k in range(len(nodes) - 1):
             pose, ln, kap, lanes = net.roads[(nodes[k], nodes[k + 1])]
+            if (nodes[k], nodes[k + 1]) in net.toll_roads:
+                toll = k
             rec[k] = road_record(pose, ln, kap, lanes, s, w)
             s += ln
         end = net.end_pose(nodes[-2], nodes[-1])
@@ -194,7 +199,7 @@ class _Builder:
         for k in range(nseg, MAX_SEGS + 1):     # terminal record(s): end pose, zero length
             rec[k] = road_record(end, 0.0, 0.0, lanes, s, w)
         self.routes.append(rec)
-        self.meta.append([s, nseg, lanes, 0.0])
+        self.meta.append([s, nseg, toll, 0.0])
 
     def add_spawn_road(self, road, destinations, slot_longs, safe_only_first=True, lanes=None):
         """Routes from `road` (a, b) to every destination node; slots on each of its lanes at `slot_longs`."""
@@ -295,38 +300,21 @@ def roundabout(exit_length=60.0, exit_radius=10.0, inner_radius=30.0, angle_deg=
     return b.finish()
 
 
-def _wave(net, a, mid, b, pose, shift_left, length, lanes, **kw):
-    """Two opposite arcs that move a road `shift_left` metres sideways over `length` metres (MetaDrive's
-    create_wave_lanes); a straight if there is nothing to move."""
-    if abs(shift_left) < 1e-9:
-        p = net.add(a, mid, pose, length / 2, 0.0, lanes, **kw)
-        return net.add(mid, b, p, length / 2, 0.0, lanes, **kw)
-    # two arcs of angle phi and radius r: lateral = 2 r (1 - cos phi), longitudinal = 2 r sin phi
-    phi = 2.0 * math.atan2(abs(shift_left), length)
-    r = length / (2.0 * math.sin(phi))
-    k = math.copysign(1.0 / r, shift_left)
-    p = net.add(a, mid, pose, r * phi, k, lanes, **kw)
-    return net.add(mid, b, p, r * phi, -k, lanes, **kw)
-
-
 def bottleneck(exit_length=60.0, bottle_lanes=4, neck_lanes=1, neck_length=20.0, taper=20.0, lane_width=LANE_WIDTH):
     """MABottleneckMap: a two-way road that narrows from `bottle_lanes` to `neck_lanes` lanes per direction and widens
-    again (20 agents, eval/evaluate_population.py:118-124).  The leftmost `neck_lanes` lanes run straight into the neck;
-    every other entry lane has its own one-lane S-curve into the neck's last lane, and out again on the far side."""
+    again (20 agents, eval/evaluate_population.py:118-124; `bottle_lane_num=4, neck_lane_num=1, neck_length=20`).  The
+    merge zone is one `bottle_lanes`-wide road of length `taper`: a vehicle may merge anywhere inside it and is out of
+    its route if it reaches the neck outside the neck's lanes (the leftmost ones)."""
     w = lane_width
     net = Net(w)
     total = 2 * (exit_length + taper) + neck_length
     for d in range(2):
         o = (0.0, 0.0, 0.0) if d == 0 else reverse(shift((total, 0.0, 0.0), w))
-        e = net.add("in%d" % d, "w%d" % d, shift(o, 0.0), exit_length, 0.0, bottle_lanes)
-        net.add("w%d" % d, "n%d" % d, e, taper, 0.0, neck_lanes, LINE_CONTINUOUS, 0)
-        for lane in range(neck_lanes, bottle_lanes):
-            start = shift(e, -lane * w)
-            _wave(net, "w%d" % d, "w%d_%d" % (d, lane), "n%d" % d, start, (lane - (neck_lanes - 1)) * w, taper, 1,
-                  left_line=0, right_line=LINE_CONTINUOUS if lane == bottle_lanes - 1 else 0)
-        e2 = net.add("n%d" % d, "m%d" % d, advance(e, taper, 0.0), neck_length, 0.0, neck_lanes)
-        e3 = net.add("m%d" % d, "x%d" % d, e2, taper, 0.0, neck_lanes, LINE_CONTINUOUS, 0)
-        net.add("x%d" % d, "end%d" % d, e3, exit_length, 0.0, bottle_lanes)
+        e = net.add("in%d" % d, "w%d" % d, o, exit_length, 0.0, bottle_lanes)
+        e = net.add("w%d" % d, "n%d" % d, e, taper, 0.0, bottle_lanes)
+        e = net.add("n%d" % d, "m%d" % d, e, neck_length, 0.0, neck_lanes)
+        e = net.add("m%d" % d, "x%d" % d, e, taper, 0.0, bottle_lanes)
+        net.add("x%d" % d, "end%d" % d, e, exit_length, 0.0, bottle_lanes)
     b = _Builder("bottleneck", net, 20, total / 2)
     slots = spawn_slots(exit_length + ENTRANCE_LENGTH)
     for d in range(2):
@@ -345,7 +333,8 @@ def tollgate(exit_length=70.0, lanes=3, toll_lanes=8, toll_length=10.0, taper=30
         o = (0.0, 0.0, 0.0) if d == 0 else reverse(shift((total, 0.0, 0.0), w))
         e = net.add("in%d" % d, "f%d" % d, o, exit_length, 0.0, lanes)
         e = net.add("f%d" % d, "t%d" % d, e, taper, 0.0, toll_lanes, LINE_CONTINUOUS, LINE_CONTINUOUS, 0)
-        e = net.add("t%d" % d, "g%d" % d, e, toll_length, 0.0, toll_lanes, LINE_CONTINUOUS, LINE_CONTINUOUS, LINE_CONTINUOUS)
+        e = net.add("t%d" % d, "g%d" % d, e, toll_length, 0.0, toll_lanes, LINE_CONTINUOUS, LINE_CONTINUOUS, LINE_CONTINUOUS,
+                    toll=True)
         e = net.add("g%d" % d, "x%d" % d, e, taper, 0.0, toll_lanes, LINE_CONTINUOUS, LINE_CONTINUOUS, 0)
         net.add("x%d" % d, "end%d" % d, e, exit_length, 0.0, lanes)
     b = _Builder("tollgate", net, 40, total / 2)

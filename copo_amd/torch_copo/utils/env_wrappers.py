@@ -21,7 +21,7 @@ import numpy as np
 from copo_amd import _capi
 from copo_amd.engine import Box, DictSpace
 from copo_amd.maps import MAP_BUILDERS
-from copo_amd.sim import SimConfig, VecSim
+from copo_amd.sim import MAP_OBS_DEFAULTS, SimConfig, VecSim
 
 _ENV_REGISTRY = {}
 
@@ -112,7 +112,11 @@ class MultiAgentMetaDrive:
         lcf = bool(cls.ENABLE_LCF and cfg.get("enable_copo", True))
         ext = cls._extension_kwargs(cfg)
         cdim = ext["comm_size"] + (3 if ext["add_pos_in_comm"] else 0)
-        odim = 9 + 10 + int(cfg.get("num_lasers", 72)) + (1 if lcf else 0)
+        # MetaDrive's per-map observation: [side block | 6 state | lane block | navigation | lasers | toll] (sim.SimConfig)
+        probe = SimConfig(map=cfg["map"] if cfg["map"] in MAP_OBS_DEFAULTS else "intersection", enable_lcf=False,
+                          num_lasers=int(cfg.get("num_lasers", 72)),
+                          **{k: cfg[k] for k in ("side_lasers", "lane_line_lasers", "navi_dim", "toll_dim") if cfg.get(k) is not None})
+        odim = probe.obs_dim + (1 if lcf else 0)
         if lcf:    # LCFObs.observation_space (env_wrappers.py:225-247): the extra columns are declared with enable_copo only
             odim += (3 if ext["add_traffic_light"] else 0) + (ext["comm_neighbours"] * cdim if ext["comm_size"] else 0)
         # LCFEnv widens the space to [-1, 1] (env_wrappers.py:241-244); MetaDrive's own obs are in [0, 1]

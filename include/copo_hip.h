@@ -121,7 +121,7 @@ typedef struct copo_sim_cfg {
     int32_t n_routes;
     int32_t n_spawns;
     const float* route_segs;   /* [n_routes][COPO_MAX_SEGS + 1][COPO_SEG_STRIDE] */
-    const float* route_meta;   /* [n_routes][4] = {total_len, nseg, 0, 0} */
+    const float* route_meta;   /* [n_routes][4] = {total_len, nseg, index of the toll-booth road or -1, 0} */
     const int32_t* spawn_tab;  /* [n_spawns][4] = {first_route, n_destinations, lane, safe} */
     const float* spawn_s;      /* [n_spawns] longitudinal position of the slot on its spawn road */
     const float* ray_cs;       /* [num_lasers][2] = beam directions in the vehicle frame (forward, left) */

@@ -147,7 +147,7 @@ typedef struct oracle_sim {
     double lcf_mean, lcf_std, force_lcf;
     int capacity;              /* active agent slots (curriculum); num_agents by default */
     /* constants derived once, in float, exactly as the kernel derives them */
-    float inv_w, inv_range, inv_vnorm, inv_dt, inv_side_range, inv_lane_range;
+    float inv_w, inv_range, inv_vnorm, inv_dt, inv_side_range, inv_lane_range, inv_toll;
     int safe_ids[COPO_MAX_SAFE];
     int n_safe;
 } oracle_sim;
@@ -198,6 +198,7 @@ int oracle_sim_create(const copo_sim_cfg* cfg, oracle_sim** out) {
     s->inv_dt = 1.0f / cfg->dt;
     s->inv_side_range = cfg->side_lasers ? 1.0f / cfg->side_range : 0.0f;
     s->inv_lane_range = cfg->lane_line_lasers ? 1.0f / cfg->lane_line_range : 0.0f;
+    s->inv_toll = cfg->toll_dim ? 1.0f / (float)(cfg->toll_min_steps > 0 ? cfg->toll_min_steps : 1) : 0.0f;
     for (int p = 0; p < cfg->n_spawns; ++p)
         if (s->spawn_tab[p * 4 + 3]) {
             if (s->n_safe >= COPO_MAX_SAFE) { oracle_sim_destroy(s); return COPO_ERR_CONFIG; }
@@ -282,7 +283,7 @@ static void spawn_agent(oracle_sim* s, int e, int n, int sp) {
         lcf = o_clip(mean + (float)s->lcf_std * z, -1.0f, 1.0f);
     }
     FP(s, S_LCF, e)[n] = lcf;
-    IP(s, S_SPAWNCNT, e)[n] = (int32_t)((cnt + 1) & 0xffffu);
+    IP(s, S_SPAWNCNT, e)[n] = (int32_t)((cnt + 1) & 0xffffu);      /* toll wait (high half) starts at 0 */
 }
 
 static int oracle_capacity(const oracle_sim* s) {
@@ -554,6 +555,11 @@ static void write_obs(oracle_sim* s, int e, const copo_step_out* out, const uint
             lid[k] = best * s->inv_range;
         }
         col += L;
+        if (c->toll_dim) {              /* Tollgate: in-booth mark and the waited fraction of `toll_min_steps` */
+            uint32_t wait = (uint32_t)IP(s, S_SPAWNCNT, e)[i] >> 16;
+            o[col++] = (seg == (int)meta[2]) ? 1.0f : 0.0f;
+            o[col++] = o_clip((float)wait * s->inv_toll, 0.0f, 1.0f);
+        }
         if (c->add_traffic_light) {     /* counter = steps since the last reset (env word 0 is already advanced) */
             traffic_light_cols(c, s->env[e * 4], x, y, o + col);
             col += 3;
@@ -805,6 +811,15 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
             }
             float prog = g[6] + sl;
             float prev = FP(s, S_PROG, e)[n];
+            int too_fast = 0;
+            if (c->toll_dim) {          /* booth road meta[2]: count the steps spent on it; leaving it early is a failure */
+                int toll_seg = (int)meta[2], seg_before = rw >> 16;
+                uint32_t sc = (uint32_t)IP(s, S_SPAWNCNT, e)[n];
+                uint32_t wait = sc >> 16;
+                if (seg == toll_seg && wait < 0xffffu) wait += 1;
+                too_fast = toll_seg >= 0 && seg > toll_seg && seg_before <= toll_seg && wait < (uint32_t)c->toll_min_steps;
+                IP(s, S_SPAWNCNT, e)[n] = (int32_t)((sc & 0xffffu) | (wait << 16));
+            }
             IP(s, S_ROUTE, e)[n] = route | (seg << 16);
             FP(s, S_PROG, e)[n] = prog;
             float lanes = g[COPO_SEG_LANES];
@@ -815,7 +830,7 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
             /* _is_arrive_destination: within +-5 m of the end of the final road, anywhere across it */
             int arrive = (seg == nseg - 1) && (sl > g[4] - c->arrive_margin) && (sl < g[4] + c->arrive_margin) && on_road;
             int out_of_road = !on_road;         /* vehicle.out_of_route (out_of_route_done) */
-            int crash = crash_any[n];
+            int crash = crash_any[n] || too_fast;
             /* reward_function: longitudinal movement on the vehicle's lane (lane i of an arc is 1 + kappa * i * w longer
              * than lane 0) + speed term; use_lateral is off in 0.2.5 */
             float r = c->driving_reward * ((prog - prev) * (1.0f + g[5] * (lif * w))) + c->speed_reward * (V[n] / c->max_speed);
@@ -862,29 +877,32 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
         /* 7. respawn (serial in slot order): a random one of the SAFE places whose 8 x 3 m region holds no vehicle
          *    (SpawnManager.get_available_respawn_places), each place at most once per step */
         if (!ending) {
-            uint32_t used = 0;
+            /* places whose region is clear of the vehicles standing when the respawns begin; `used`: taken this step */
+            uint32_t clear = 0, used = 0;
+            for (int q = 0; q < s->n_safe; ++q) {
+                int sp = s->safe_ids[q];
+                const float* g = SEG(s, s->spawn_tab[sp * 4], 0);
+                float sx, sy;
+                spawn_pose(s, sp, &sx, &sy);
+                int blocked = 0;
+                for (int j = 0; j < N; ++j) {
+                    if (ST_STATUS(STA[j]) == ST_EMPTY) continue;
+                    if (obb_overlap2(sx, sy, g[2], g[3], 0.5f * c->spawn_region_len, 0.5f * c->spawn_region_wid,
+                                     X[j], Y[j], t.cs[j], t.sn[j], hl, hw)) blocked = 1;
+                }
+                if (!blocked) clear |= 1u << q;
+            }
             for (int n = 0; n < N; ++n) {
                 if (n >= oracle_capacity(s)) break;
                 if (t.acted[n] || STA[n] != ST_PACK(ST_EMPTY, 0, 0)) continue;
-                int freep[COPO_MAX_SAFE], nfree = 0;
-                for (int q = 0; q < s->n_safe; ++q) {
-                    if (used & (1u << q)) continue;
-                    int sp = s->safe_ids[q];
-                    const float* g = SEG(s, s->spawn_tab[sp * 4], 0);
-                    float sx, sy;
-                    spawn_pose(s, sp, &sx, &sy);
-                    int blocked = 0;
-                    for (int j = 0; j < N; ++j) {
-                        if (ST_STATUS(STA[j]) == ST_EMPTY) continue;
-                        if (obb_overlap2(sx, sy, g[2], g[3], 0.5f * c->spawn_region_len, 0.5f * c->spawn_region_wid,
-                                         X[j], Y[j], t.cs[j], t.sn[j], hl, hw)) blocked = 1;
-                    }
-                    if (!blocked) freep[nfree++] = q;
-                }
-                if (nfree == 0) break;          /* nowhere to go this step: everybody still waiting keeps waiting */
+                uint32_t freem = clear & ~used;
+                if (!freem) break;              /* nowhere to go this step: everybody still waiting keeps waiting */
+                int nfree = __builtin_popcount(freem);
                 uint32_t cnt = (uint32_t)IP(s, S_SPAWNCNT, e)[n] & 0xffffu;
                 uint32_t hh = o_hash(s->seeds[e], (uint32_t)n, cnt, (uint32_t)env[0], RNG_SPAWN);
-                int q = freep[hh % (uint32_t)nfree];
+                int pick = (int)(hh % (uint32_t)nfree), q = 0;
+                for (;; ++q)                    /* the pick-th clear place in table order */
+                    if ((freem >> q) & 1u) { if (pick == 0) break; --pick; }
                 used |= 1u << q;
                 spawn_agent(s, e, n, s->safe_ids[q]);
                 o_sincosf(TH[n], &t.sn[n], &t.cs[n]);

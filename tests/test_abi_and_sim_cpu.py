@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libcopo_hip.so does not export %s" % name
     assert set(_capi.EXPORTED_SYMBOLS) == declared, set(_capi.EXPORTED_SYMBOLS) ^ declared
-    assert _capi.lib.copo_version() == _capi.ABI_VERSION == 1
+    assert _capi.lib.copo_version() == _capi.ABI_VERSION == 2
     assert C.sizeof(_capi.SimCfg) == C.sizeof(ol.SimCfg)
 
 
@@ -49,22 +49,58 @@ def test_create_rejects_bad_arguments_without_a_gpu():
 def test_map_tables(name):
     t = maps.MAP_BUILDERS[name]()
     assert t.route_segs.shape[1:] == (maps.MAX_SEGS + 1, maps.SEG_STRIDE) and t.n_spawns >= t.default_num_agents
+    assert 1 <= int(t.spawn_tab[:, 3].sum()) <= 32                        # respawn places (COPO_MAX_SAFE)
     for r in range(t.n_routes):
-        nseg = int(t.route_meta[r, 3])
+        nseg = int(t.route_meta[r, 1])
         seg = t.route_segs[r].astype(np.float64)
-        assert 1 <= nseg <= maps.MAX_SEGS and seg[0, 5] == 0.0            # first piece straight (spawn piece)
-        assert abs(seg[:nseg, 4].sum() - t.route_meta[r, 0]) < 1e-3       # lengths add up
-        assert np.all(np.abs(seg[:nseg, 5] * seg[:nseg, 4]) <= np.radians(100) + 1e-6)   # arcs never wrap atan2
-        pts = maps.route_points(t, r, 0.5)
-        assert np.linalg.norm(np.diff(pts, axis=0), axis=1).max() < 0.6   # G0 continuity across pieces
-    # spawn poses of one map keep the clearance the simulator asks for
+        assert 1 <= nseg <= maps.MAX_SEGS and seg[0, maps.SEG_KAPPA] == 0.0   # spawn road: straight
+        assert abs(seg[:nseg, maps.SEG_LEN].sum() - t.route_meta[r, 0]) < 1e-3       # lengths add up
+        assert np.all(np.abs(seg[:nseg, maps.SEG_KAPPA] * seg[:nseg, maps.SEG_LEN]) <= np.pi + 1e-6)   # arcs of at most a half turn
+        arcs = seg[:nseg, maps.SEG_KAPPA] != 0
+        np.testing.assert_allclose(seg[:nseg, maps.SEG_RADIUS][arcs], 1.0 / np.abs(seg[:nseg, maps.SEG_KAPPA][arcs]), rtol=1e-6)
+        # G1 continuity of the lane-0 line wherever the lane count does not change: position and heading of consecutive roads
+        for k in range(nseg):
+            end = maps.advance((seg[k, 0], seg[k, 1], seg[k, maps.SEG_TH0]), seg[k, maps.SEG_LEN], seg[k, maps.SEG_KAPPA])
+            nxt = seg[k + 1]
+            assert np.hypot(end[0] - nxt[0], end[1] - nxt[1]) < 2e-3, (name, r, k)
+            assert abs(maps._wrap(end[2] - nxt[maps.SEG_TH0])) < 1e-4 or k == nseg - 1
+        # navigation check point: the end of the road, at its lateral middle
+        for k in range(nseg):
+            nxt, lanes = seg[k + 1], seg[k, maps.SEG_LANES]
+            mid = maps.shift((nxt[0], nxt[1], nxt[maps.SEG_TH0]) if k < nseg - 1 else
+                             maps.advance((seg[k, 0], seg[k, 1], seg[k, maps.SEG_TH0]), seg[k, maps.SEG_LEN], seg[k, maps.SEG_KAPPA]),
+                             -(lanes / 2 - 0.5) * t.lane_width)
+            if k == nseg - 1 or seg[k + 1, maps.SEG_LANES] == lanes:
+                assert np.hypot(mid[0] - seg[k, maps.SEG_CKX], mid[1] - seg[k, maps.SEG_CKY]) < 2e-3
+    # spawn slots keep clear of each other: lanes 3.5 m apart, slots >= 8 m along a lane
     sp = []
     for s in range(t.n_spawns):
-        g = t.route_segs[t.spawn_tab[s, 0], 0]
-        sp.append((g[0] + g[2] * t.spawn_s[s], g[1] + g[3] * t.spawn_s[s]))
+        g = t.route_segs[t.spawn_tab[s, 0], 0].astype(np.float64)
+        off = t.spawn_tab[s, 2] * t.lane_width
+        sp.append((g[0] + g[2] * t.spawn_s[s] + g[3] * off, g[1] + g[3] * t.spawn_s[s] - g[2] * off))
     sp = np.array(sp)
     d = np.linalg.norm(sp[:, None] - sp[None], axis=-1) + np.eye(len(sp)) * 1e9
     assert d.min() > 3.0
+
+
+def test_intersection_and_roundabout_follow_the_block_formulas():
+    """The two maps the reference's headline numbers are quoted on.  Intersection (radius 10, 2 lanes): right turns of
+    radius 10 / 13.5, left turns 17 / 20.5, crossing 30.5 m, U-turn 1.75, every entry reaches all four exits.
+    Roundabout (exit radius 10, inner radius 30, angle 70): every arm is built from its OWN entry road, so the ring only
+    closes -- the G1 check of test_map_tables over routes that run through several arms -- for the connecting radius
+    `beneath / cos(angle) - exit_radius`; a full turn of the ring is 11 roads."""
+    t = maps.intersection()
+    assert t.n_routes == 16 and t.n_spawns == 4 * 2 * 6 and t.default_num_agents == 30
+    kinds = {}
+    for r in range(4):          # the four routes of arm 0
+        g = t.route_segs[r, 1].astype(np.float64)
+        kinds[round(float(g[maps.SEG_LEN]), 3)] = (float(g[maps.SEG_KAPPA]), float(g[maps.SEG_LANES]))
+    assert set(kinds) == {round(1.75 * np.pi, 3), round(13.5 * np.pi / 2, 3), 30.5, round(17 * np.pi / 2, 3)}
+    assert abs(kinds[round(13.5 * np.pi / 2, 3)][0] + 1 / 13.5) < 1e-6 and abs(kinds[round(17 * np.pi / 2, 3)][0] - 1 / 17) < 1e-6
+    r = maps.roundabout()
+    assert r.n_routes == 16 and r.default_num_agents == 40 and int(r.route_meta[:, 1].max()) == 11
+    ring = r.route_segs[0, 2:4, maps.SEG_RADIUS].astype(np.float64)      # first ring arc + connecting arc of arm 0's U-turn route
+    np.testing.assert_allclose(sorted(ring), [15.25 / np.cos(np.radians(70)) - 10 - 3.5, 37.0], rtol=1e-6)
 
 
 def test_generated_roads_are_seeded_and_drivable():
@@ -72,15 +108,15 @@ def test_generated_roads_are_seeded_and_drivable():
     lane width apart through every block, and lane-keeping agents reach the far end in the oracle simulator."""
     a, b, c = maps.pgmap("SCSC", 3), maps.pgmap("SCSC", 3), maps.pgmap("SCSC", 4)
     assert np.array_equal(a.route_segs, b.route_segs) and not np.array_equal(a.route_segs, c.route_segs)
-    assert maps.pgmap(4, 9).n_routes == 4 and maps.pgmap(4, 9, lanes=3).n_routes == 6
+    assert maps.pgmap(4, 9).n_routes == 2 and maps.pgmap(4, 9, lanes=3).n_spawns == 2 * 3 * 6
     with pytest.raises(ValueError):
         maps.pgmap("SXS", 0)
     with pytest.raises(ValueError):
-        maps.pgmap(7, 0)                      # 7 blocks + 2 leads > MAX_SEGS
+        maps.pgmap(11, 0)                     # 11 blocks + 2 leads > MAX_SEGS
     for seq, seed in [("CCC", 1), ("SCSCSC", 3), (6, 7)]:
         t = maps.pgmap(seq, seed)
         fwd = maps.route_points(t, 0, 0.5)[:, :2]
-        rev = maps.route_points(t, 2, 0.5)[:, :2]
+        rev = maps.route_points(t, 1, 0.5)[:, :2]
         d = np.linalg.norm(fwd[:, None] - rev[None], axis=-1).min(1)
         assert 3.49 < d.min() and d.max() < 3.52          # inner lanes of the two directions: one lane width apart
     cfg = SimConfig(map="pgmap", map_kwargs=dict(sequence="SCS", seed=5), num_envs=2, num_agents=12, horizon=400)
@@ -98,8 +134,8 @@ def _rollout(cfg, steps, seed=0, policy="cruise"):
     hist = []
     for t in range(steps):
         if policy == "cruise":      # lane-keeping controller on the ego block of the observation
-            psi = (o["obs"][..., 2] - 0.5) * np.pi
-            lat = (o["obs"][..., 8] - 0.5) * 2 * cfg.lane_width
+            psi = np.arcsin(np.clip((0.5 - o["obs"][..., 2]) * 2, -1, 1))     # column 2: 0.5 - 0.5 sin(heading error)
+            lat = -(o["obs"][..., 8] - 0.5) * 4.5                             # column 8: offset in the lane, right +
             steer = np.clip(-1.5 * psi - 0.25 * lat + rng.normal(0, 0.02, psi.shape), -1, 1)
             act = np.stack([steer, np.full((s.E, s.N), 0.5)], -1)
         else:
@@ -178,7 +214,10 @@ def test_observation_extension_spaces_and_oracle_rollout():
     """f-4 host surface: CCEnv's `communication` / `add_traffic_light` keys size the spaces like LCFObs /
     CCEnv.action_space (env_wrappers.py:71-87, 225-247); the oracle simulator runs with the blocks on."""
     from copo_amd.torch_copo.utils import env_wrappers as W
-    lcf_env = W.get_lcf_env(W.MultiAgentBottleneckEnv)
+    assert W.get_lcf_env(W.MultiAgentBottleneckEnv).spaces_for({})[0].shape == (97,)      # first-layer shapes of the
+    assert W.get_lcf_env(W.MultiAgentTollgateEnv).spaces_for({})[0].shape == (157,)       # reference's best_checkpoints
+    assert W.get_ccenv(W.MultiAgentTollgateEnv).spaces_for({})[0].shape == (156,)
+    lcf_env = W.get_lcf_env(W.MultiAgentRoundaboutEnv)
     comm = dict(comm_method="broadcast", comm_size=4, comm_neighbours=4, add_pos_in_comm=True)
     o, a = lcf_env.spaces_for({})
     assert o.shape == (92,) and a.shape == (2,)
@@ -192,7 +231,7 @@ def test_observation_extension_spaces_and_oracle_rollout():
     assert lat.spaces_for(dict(enable_latent=True, latent_dim=6))[0].shape == (98,) and lat.spaces_for({})[0].shape == (92,)
     assert lat.default_config()["latent_dim"] == -1 and not lat.default_config()["enable_latent"]
 
-    cfg = SimConfig(map="bottleneck", num_envs=2, num_agents=20, horizon=60, add_traffic_light=True, traffic_light_interval=6,
+    cfg = SimConfig(map="roundabout", num_envs=2, num_agents=20, horizon=60, add_traffic_light=True, traffic_light_interval=6,
                     comm_size=3, comm_neighbours=2, add_pos_in_comm=True)
     assert cfg.obs_dim == 91 + 3 + 1 + 2 * 6 and cfg.act_dim == 5
     s = ol.OracleSim(cfg)

@@ -8,7 +8,7 @@ import oracle_lib as ol
 
 
 def test_oracle_builds_and_versions():
-    assert ol.lib().oracle_version() == 1
+    assert ol.lib().oracle_version() == 2
 
 
 def test_neighbours_and_rewards_vs_reference(golden_dir):
