@@ -255,8 +255,8 @@ def test_maximum_population_bit_exact():
     import oracle_lib as ol
     from copo_amd.sim import SimConfig, VecSim
     E, N = 3, 64
-    cfg = SimConfig(map="intersection", map_kwargs=dict(spawns_per_lane=8, spawn_gap=7.0), num_envs=E, num_agents=N, horizon=60,
-                    nbr_k=16, delay_done=4, spawn_clearance=5.0)
+    cfg = SimConfig(map="intersection", map_kwargs=dict(exit_length=100.0), num_envs=E, num_agents=N, horizon=60,
+                    nbr_k=16, delay_done=4)
     g, o = VecSim(cfg), ol.OracleSim(cfg)
     seeds = np.arange(E, dtype=np.uint64) + np.uint64(31)
     _compare("reset", g.reset(seeds), o.reset(seeds))

@@ -103,14 +103,15 @@ def test_dict_env_api_matches_reference_surface():
     """reset()/step(dict) of `get_lcf_env(MultiAgentIntersectionEnv)` as the reference's scripts use it
     (env_wrappers.py:600-617): agent-id keyed dicts, `__all__`, the info keys of CCEnv / LCFEnv."""
     from copo_amd.torch_copo.utils.env_wrappers import MultiAgentIntersectionEnv, get_lcf_env
-    env = get_lcf_env(MultiAgentIntersectionEnv)(dict(num_agents=10, horizon=50))
+    env = get_lcf_env(MultiAgentIntersectionEnv)(dict(num_agents=10, horizon=50, delay_done=5))
     o = env.reset(force_seed=0)
     assert len(o) == 10 and all(v.shape == (92,) and v.dtype == np.float32 for v in o.values())
     assert set(o) == set(env.vehicles) and env.observation_space["agent0"].contains(o["agent0"])
     seen_done, seen_spawn = False, False
     for t in range(50):
         before = set(env.vehicles)
-        o, r, d, i = env.step({k: [0.0, 1.0] for k in env.vehicles})
+        # every other vehicle steers off its road: terminations, wrecks that linger `delay_done` steps, respawns
+        o, r, d, i = env.step({k: [0.6 if int(k[5:]) % 2 else 0.0, 1.0] for k in env.vehicles})
         assert set(r) == set(d) - {"__all__"} == set(i) and before <= set(i)
         for k in before:
             inf = i[k]
@@ -172,7 +173,8 @@ def test_baseline_parity_configs_run(name, algo, map_cls, cfg):
     a = cls(config=cfg)
     if name.startswith("C4"):
         assert a.policy.fused is None and a.policy.autocast_dtype == torch.bfloat16
-        assert a.policy.model.get_centralized_critic_obs_dim() == 2 * 91 + 2
+        # Tollgate: O = 156 (72 side beams + 6 + 4 lane-line beams + 72 LiDAR + 2 toll columns), mean-field cc-obs 2 * 156 + 2
+        assert a.env.sim.O == 156 and a.policy.model.get_centralized_critic_obs_dim() == 2 * 156 + 2 == 314
     if name == "C1":
         assert a.env.sim.O == 91 and a.env.sim.N == 4 and a.sampler.T == 200 and a.policy.fused is not None
     if name.startswith("C5"):
@@ -367,11 +369,11 @@ def test_extension_wrappers_through_the_dict_api():
     conf = dict(num_agents=12, horizon=40, add_traffic_light=True, traffic_light_interval=5, communication=comm,
                 enable_latent=True, latent_dim=4)
     env = cls(conf)
-    O = 4 + 91 + 3 + 1 + 2 * 6
+    O = 4 + 96 + 3 + 1 + 2 * 6       # Bottleneck: 4 side + 6 + 4 lane-line beams + 10 navigation + 72 LiDAR = 96
     assert env.observation_space["agent0"].shape == (O,) and env.action_space["agent0"].shape == (5,)
     o = env.reset(force_seed=3)
     assert all(v.shape == (O,) and not v[:4].any() for v in o.values())           # no latent registered: zeros
-    assert all(v[4 + 91] == 1.0 and not v[4 + 95:].any() for v in o.values())     # message(0) = 1; no comm after reset
+    assert all(v[4 + 96] == 1.0 and not v[4 + 100:].any() for v in o.values())     # message(0) = 1; no comm after reset
     rng = np.random.RandomState(0)
     heard = 0
     for t in range(1, 40):
@@ -379,11 +381,11 @@ def test_extension_wrappers_through_the_dict_api():
         o, r, d, i = env.step(acts)
         msg = (t % 5) / 5 * 0.1 if (t // 5) % 2 == 1 else 1 - (t % 5) / 5 * 0.1
         for k in acts:
-            assert o[k].shape == (O,) and o[k][4 + 91] == np.float32(msg)
+            assert o[k].shape == (O,) and o[k][4 + 96] == np.float32(msg)
             inf = i[k]
             assert len(inf["comm_current_obs"]) == 2 and len(inf["nei_obs"]) == 3 and inf["nei_obs"][-1] is None
             for q, n in enumerate(inf["neighbours"][:2]):
-                blk = o[k][4 + 95 + 6 * q: 4 + 95 + 6 * (q + 1)]
+                blk = o[k][4 + 100 + 6 * q: 4 + 100 + 6 * (q + 1)]
                 np.testing.assert_array_equal(blk, inf["comm_current_obs"][q])
                 if n in acts:                      # the neighbour was given an action this step: its message arrives
                     np.testing.assert_array_equal(blk[:3], acts[n][2:])
@@ -392,7 +394,7 @@ def test_extension_wrappers_through_the_dict_api():
                 else:
                     assert not blk.any()
             for q in range(len(inf["neighbours"]), 2):
-                assert not o[k][4 + 95 + 6 * q: 4 + 95 + 6 * (q + 1)].any()
+                assert not o[k][4 + 100 + 6 * q: 4 + 100 + 6 * (q + 1)].any()
     assert heard > 20
     env.register_latent({3: {"agent%d" % a: np.full(4, a, np.float32) for a in range(200)}})
     o, r, d, i = env.step({k: np.zeros(5, np.float32) for k in env.vehicles})
