@@ -36,6 +36,11 @@ def load_policy_weights(model, weights, **kw):
     with torch.no_grad():
         for k, v in sd.items():
             own[k].copy_(v.to(own[k].device))
+    # a fused learner that reads these parameters through its transposed mirror must rebuild it: the owner of `model`
+    # (PPOPolicyBase._weights_changed / FusedLearner.invalidate_mirror) is told through this hook when it registered one
+    hook = getattr(model, "_on_external_write", None)
+    if hook is not None:
+        hook()
     return sorted(sd)
 
 
@@ -60,8 +65,11 @@ def get_policy_function_from_checkpoint(algo, ckpt, deterministic=False, policy_
         blob = pickle.loads(f.read())
     weights = pickle.loads(blob.pop("worker"))["state"][policy_name]
     weights = {k: v for k, v in weights.items() if k != "_optimizer_variables" and "value" not in k}
-    sfx = "_1" if "copo" in algo else ""
-    fn = _compute_actions_for_torch_policy2 if "ccppo" in algo else _compute_actions_for_tf_policy
+    # the key layout decides the reader (this build's own checkpoints are torch-layout for every algorithm); the `_1`
+    # suffix is the TF-era CoPO convention only (get_policy_function_from_checkpoint.py:15-29)
+    layout = detect_layout(weights)
+    sfx = "_1" if ("copo" in algo and layout == "tf") else ""
+    fn = _compute_actions_for_torch_policy2 if layout == "torch" else _compute_actions_for_tf_policy
 
     def policy(obs):
         return fn(weights, obs, policy_name=policy_name, layer_name_suffix=sfx, deterministic=deterministic)

@@ -116,14 +116,20 @@ class FusedLearner:
         self.target_flat = FlatParams(target_model, self.policy.device)
         assert self.target_flat.numel == self.flat.numel
 
+    def invalidate_mirror(self):
+        """Torch code wrote the parameters (load_state_dict, set_weights, a population loaded for evaluation ...): the
+        transposed mirror is stale until the next sync_mirror.  Writes through the nn.Parameter views do not bump the
+        flat buffer's version counter, so every such writer calls this explicitly."""
+        self._mirror_version = -1
+
     def sync_mirror(self):
-        """Re-derive the transposed mirror if torch code touched the parameters since the kernels last wrote it
-        (optimiser-free weight loads, checkpoints, tests).  Call outside captured graphs, before replaying them."""
+        """Re-derive the transposed mirror if it was invalidated (or never built) since the kernels last wrote it.
+        Call outside captured graphs, before replaying them."""
         v = self.flat.flat._version
-        if v != self._mirror_version:
+        if self._mirror_version < 0 or v != self._mirror_version:
             _capi.check(_capi.lib.copo_transpose_weights_f32(C.byref(self.cfg), self.flat.flat.data_ptr(),
                                                              self.flat_t.data_ptr(), _capi.current_stream()))
-            self._mirror_version = v
+            self._mirror_version = max(v, 0)
 
     @property
     def can_forward(self):

@@ -480,6 +480,8 @@ class CoPOPolicy(CCPPOPolicy):
                 self.target_model.lcf_parameters.data.copy_(self.model.lcf_parameters.data)
         else:
             self.target_model.load_state_dict(self.model.state_dict())
+            if fz is not None:
+                fz.invalidate_mirror()
 
     def assign_lcf(self, lcf_parameters, lcf_mean, lcf_std=None, my_name=None):
         """Copy LCF parameters into this policy and check the derived mean/std (algo_copo.py:446-471)."""
@@ -526,9 +528,20 @@ def _single_traj_gae(rollout, last_r, gamma, lambda_, rk, vk, ak, tk):
     v = torch.as_tensor(rollout[vk], dtype=torch.float32).cuda().reshape(1, -1, 1)
     T = r.shape[1]
     flags = torch.ones(T, 1, dtype=torch.uint8, device=r.device)
-    if float(last_r) == 0.0:    # the reference passes 0.0 for finished trajectories, V(last obs) otherwise
+    last = float(last_r)
+    own = float(v[0, -1, 0])
+    # the scan bootstraps a truncated trajectory from the value of its LAST row (what the reference's caller passes,
+    # algo_copo.py:492-496) and a finished one from 0; any other `last_r` is honoured through the linearity of GAE in the
+    # bootstrap value: A_t += (gamma * lambda)^(T-1-t) * gamma * last_r on top of the finished-trajectory result
+    general = last != 0.0 and last != own
+    if last == 0.0 or general:
         flags[-1, 0] |= 2
     adv, tgt = ops.gae3(r.contiguous(), v.contiguous(), flags, [gamma], lambda_)
+    if general:
+        k = torch.arange(T - 1, -1, -1, dtype=torch.float64, device=r.device)
+        corr = (torch.pow(torch.tensor(float(gamma) * float(lambda_), dtype=torch.float64, device=r.device), k)
+                * float(gamma) * last).to(torch.float32).reshape(adv.shape)
+        adv, tgt = adv + corr, tgt + corr
     rollout[ak] = adv.reshape(-1).cpu().numpy()
     rollout[tk] = tgt.reshape(-1).cpu().numpy()
     return rollout

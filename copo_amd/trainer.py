@@ -189,6 +189,8 @@ class PPOPolicyBase:
             from .fused import FusedLearner
             adv_key, meta_key = self.fused_adv_keys()
             self.fused = FusedLearner(self, self.train_columns(), int(config["sgd_minibatch_size"]), adv_key, meta_key)
+            # writers that only hold the nn.Module (checkpoint_io.load_policy_weights) reach the mirror through this hook
+            object.__setattr__(self.model, "_on_external_write", self._weights_changed)
 
     # ---- construction / inference --------------------------------------------------------------------
     def make_model(self, name):
@@ -224,13 +226,23 @@ class PPOPolicyBase:
     def get_weights(self):
         return {k: v.detach().cpu().numpy() for k, v in self.model.state_dict().items()}
 
+    def _weights_changed(self):
+        """Parameters were written from outside the kernels: refresh the fused learner's transposed mirror lazily and
+        drop captured graphs that baked anything derived from the old weights."""
+        if self.fused is not None:
+            self.fused.invalidate_mirror()
+
     def set_weights(self, weights):
         sd = {k: torch.as_tensor(v) for k, v in weights.items()}
         self.model.load_state_dict(sd)
+        self._weights_changed()
 
     def get_state(self):
-        return dict(model=self.model.state_dict(), optimizer=self.optimizer.state_dict(), kl_coeff=self._kl_value,
-                    num_grad_updates=self.num_grad_updates)
+        st = dict(model=self.model.state_dict(), optimizer=self.optimizer.state_dict(), kl_coeff=self._kl_value,
+                  num_grad_updates=self.num_grad_updates)
+        if self.fused is not None:       # the fused learner owns the Adam moments / step (the torch optimizer is never stepped)
+            st["fused"] = self.fused.state()
+        return st
 
     def set_state(self, state):
         self.model.load_state_dict(state["model"])
@@ -238,6 +250,9 @@ class PPOPolicyBase:
         self._kl_value = float(state["kl_coeff"])
         self.kl_coeff.fill_(self._kl_value)
         self.num_grad_updates = int(state.get("num_grad_updates", 0))
+        if self.fused is not None and state.get("fused") is not None:
+            self.fused.load_state(state["fused"])
+        self._weights_changed()
         if self._sgd is not None:
             self._sgd.reset()
 

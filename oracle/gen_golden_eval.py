@@ -64,7 +64,36 @@ def main():
     print("wrote eval_policy_function.npz", os.path.getsize(os.path.join(OUT, "eval_policy_function.npz")))
 
 
+def populations():
+    """More of the populations the reference ships as data (six arrays each), for the cross-simulator pin
+    (tests/test_gpu_reference_populations.py), and what the reference measured for its Intersection populations in
+    MetaDrive: the per-episode CSVs under eval/demo_results/evaluate_results, reduced to column means."""
+    import glob
+    import json
+    import pandas as pd
+    save = {}
+    for name in ("ippo_round", "copo_round", "ippo_parking"):
+        w = dict(np.load(os.path.join(CKPT, name + ".npz")))
+        for k, v in w.items():
+            save["%s/w/%s" % (name, k)] = v
+        if name in G.meta_svo_lookup_table:
+            save[name + "/lcf"] = np.array(G.meta_svo_lookup_table[name])
+    np.savez_compressed(os.path.join(OUT, "reference_populations.npz"), **save)
+    res_dir = os.path.join(os.path.dirname(os.path.abspath(G.__file__)), "demo_results", "evaluate_results")
+    cols = ["success_rate", "crash_rate", "out_rate", "episode_length_mean", "success_episode_length_mean",
+            "velocity_step_mean_episode_mean", "episode_reward_mean", "num_agents_total"]
+    stats = {}
+    for algo in ("ippo", "copo"):
+        files = sorted(glob.glob(os.path.join(res_dir, "%s_inter_*.csv" % algo)))
+        d = pd.concat([pd.read_csv(f) for f in files])
+        stats[algo + "_inter"] = dict(populations=len(files), episodes=int(len(d)), **{c: float(d[c].mean()) for c in cols})
+    with open(os.path.join(OUT, "reference_eval_stats.json"), "w") as f:
+        json.dump(stats, f, indent=1, sort_keys=True)
+    print("wrote reference_populations.npz", os.path.getsize(os.path.join(OUT, "reference_populations.npz")), stats)
+
+
 if __name__ == "__main__":
     if not os.path.isdir(ref_stubs.REFERENCE_ROOT):
         sys.exit("reference tree not present; fixtures are committed under tests/golden/")
     main()
+    populations()

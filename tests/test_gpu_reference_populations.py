@@ -1,0 +1,68 @@
+"""Cross-simulator pin of the simulator half (SURVEY.md section 8 rows a-1 / c): MetaDrive's source is not in the
+reference tree, but the reference ships what MetaDrive taught its agents -- the trained populations under
+copo/best_checkpoints (held here as data: tests/golden/eval_policy_function.npz, reference_populations.npz) -- and what
+those populations scored in MetaDrive (eval/demo_results/evaluate_results/*.csv -> tests/golden/reference_eval_stats.json).
+A policy is a function of the observation alone, so it only drives a simulator whose observation semantics (column
+meaning and scale, LiDAR beam order, navigation encoding, steering sign, road geometry) are MetaDrive's.  These tests
+roll the populations in the HIP simulator, 30 agents on the Intersection / 40 on the Roundabout as the reference's
+evaluation does (eval/evaluate_population.py:102-132), and fail if they fall back towards an untrained policy.
+
+Success is counted over terminated episodes that were not cut by the 1000-step horizon (the reference's recorder lets an
+episode drain after the horizon instead; `max_step` is ~0 in its tables)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _roll(algo, env, weights, lcf, n):
+    """One whole scene episode (1000 env steps, the reference's evaluation unit) of 64 scenes."""
+    from copo_amd.eval.evaluate import evaluate_population
+    r = evaluate_population(algo, env, weights, lcf, num_envs=64, num_agents=n, scene_episodes=1, seed=0)
+    cut = float(r["max_step_rate_mean"])
+    return dict(success=float(r["success_rate_mean"]) / max(1e-9, 1.0 - cut), crash=float(r["crash_rate_mean"]) / max(1e-9, 1.0 - cut),
+                out=float(r["out_of_road_rate_mean"]) / max(1e-9, 1.0 - cut), length=float(r["episode_length_mean"]),
+                velocity=float(r["velocity_mean"]), raw=r)
+
+
+def _weights(gold, name):
+    pre = name + "/w/"
+    return {k[len(pre):]: gold[k] for k in gold.files if k.startswith(pre)}
+
+
+def test_reference_intersection_populations_drive_the_hip_simulator(golden_dir):
+    gold = np.load(os.path.join(golden_dir, "eval_policy_function.npz"))
+    with open(os.path.join(golden_dir, "reference_eval_stats.json")) as f:
+        ref = json.load(f)
+    from copo_amd.eval.get_policy_function import meta_svo_lookup_table
+    untrained = _roll("ippo", "inter", None, None, 30)
+    assert untrained["success"] < 0.05, untrained
+    ippo = _roll("ippo", "inter", _weights(gold, "ippo_inter"), None, 30)
+    copo = _roll("copo", "inter", _weights(gold, "copo_inter"), meta_svo_lookup_table["copo_inter"], 30)
+    ccppo = _roll("ccppo", "inter", _weights(gold, "ccppo_inter"), None, 30)
+    print("ippo", ippo, "\ncopo", copo, "\nccppo", ccppo, "\nreference (MetaDrive)", ref)
+    # MetaDrive: IPPO populations 0.48 success / 0.42 crash / 27 km/h, CoPO 0.78 / 0.15 / 14 km/h.  The bands below are
+    # wide enough for the physics difference (kinematic bicycle vs Bullet) and far from the ~0 of wrong semantics.
+    assert abs(ippo["success"] - ref["ippo_inter"]["success_rate"]) < 0.15, ippo
+    assert abs(copo["success"] - ref["copo_inter"]["success_rate"]) < 0.15, copo
+    assert copo["success"] > ippo["success"] + 0.1                    # the ranking of the reference's table
+    assert ccppo["success"] > 0.45
+    assert copo["crash"] < 0.3 and ippo["out"] < 0.15 and copo["out"] < 0.15
+    assert abs(ippo["velocity"] - ref["ippo_inter"]["velocity_step_mean_episode_mean"]) < 8.0
+    assert abs(copo["velocity"] - ref["copo_inter"]["velocity_step_mean_episode_mean"]) < 8.0
+    assert copo["length"] > 1.5 * ippo["length"]                      # CoPO's populations are the patient ones (308 vs 132 steps)
+
+
+def test_reference_roundabout_populations_drive_the_hip_simulator(golden_dir):
+    """The roundabout's ring is eleven roads long for a full turn: populations that were trained on MetaDrive's block
+    geometry only get round it if the rebuilt geometry and navigation columns match."""
+    gold = np.load(os.path.join(golden_dir, "reference_populations.npz"))
+    ippo = _roll("ippo", "round", _weights(gold, "ippo_round"), None, 40)
+    copo = _roll("copo", "round", _weights(gold, "copo_round"), tuple(gold["copo_round/lcf"]), 40)
+    print("ippo_round", ippo, "\ncopo_round", copo)
+    # training-time success in MetaDrive (benchmarks/MetaDrive-0.2.5/README.md:19-31): IPPO 66 %, CoPO 73 %
+    assert ippo["success"] > 0.45 and copo["success"] > 0.45, (ippo, copo)
+    assert ippo["out"] < 0.1 and copo["out"] < 0.1

@@ -93,9 +93,23 @@ def test_trainers_run_and_report(algo, extra):
         assert all(torch.equal(tgt[k], cur[k]) for k in cur)          # update_old_policy
     path = a.save_checkpoint("/tmp/copo_ckpt_test")
     w0 = {k: v.clone() for k, v in a.policy.model.state_dict().items()}
+    fz = a.policy.fused
+    adam0 = None if fz is None else (fz.adam_m.clone(), fz.adam_v.clone(), fz.step_count.clone())
     a.train()
     a.load_checkpoint(path)
     assert all(torch.equal(v, a.policy.model.state_dict()[k]) for k, v in w0.items())
+    if fz is not None:
+        # the fused learner's own Adam moments / step travel with the checkpoint (the torch optimizer is never stepped) ...
+        assert int(adam0[2]) > 0 and torch.equal(fz.adam_m, adam0[0]) and torch.equal(fz.adam_v, adam0[1]) and torch.equal(fz.step_count, adam0[2])
+        # ... and the forward kernels see the restored weights: their transposed mirror was invalidated by the load
+        obs = torch.rand(64, a.env.sim.O, device="cuda")
+        eps = torch.zeros(64, 2, device="cuda")
+        act, logp, dist = torch.empty(64, 2, device="cuda"), torch.empty(64, device="cuda"), torch.empty(64, 4, device="cuda")
+        fz.sync_mirror()
+        fz.act(obs, eps, act, logp, dist)
+        with torch.no_grad():
+            _, _, ref = a.policy.compute_actions(obs, eps)
+        torch.testing.assert_close(dist, ref, rtol=1e-4, atol=1e-4)
     a.stop()
 
 
