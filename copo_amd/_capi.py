@@ -10,6 +10,15 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcopo_hip.so")
+# Profiling scripts (scripts/sim_valu_split.py) load a differently compiled copy -- phases of the step kernel compiled out,
+# `make prof SKIP=<mask>` -- by setting `copo_amd._libsel.PATH` BEFORE importing this module.  There is no environment
+# variable and no runtime knob: the shipped library always does all the work.
+try:
+    from . import _libsel as _sel
+    if getattr(_sel, "PATH", None):
+        LIB_PATH = _sel.PATH
+except ImportError:
+    pass
 
 from ._abi import (ABI_VERSION, INFO_DIM, LINE_STRIDE, MAX_AGENTS, MAX_LASERS, MAX_LINES, MAX_ROUTES, MAX_SAFE,  # noqa: F401
                    MAX_SEGS, MAX_SPAWNS, NAVI_DIM, SEG_STRIDE, STATE_DIM, STATE_FIELDS, SimCfg, StepOut)

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <algorithm>
 #include <vector>
 
 #include "sim_common.h"
@@ -28,6 +29,7 @@ static int fail(int code, const char* fmt, ...) {
 
 struct copo_sim {
     SimParams p;
+    SimParams* p_dev;          // device copy of p (the kernels' parameter block)
     int device;
     int block;
     bool started;
@@ -182,8 +184,16 @@ extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** o
     if (rc == COPO_OK && (rc = dev_alloc((size_t)p.E * 16, &d)) == COPO_OK) p.env = (int32_t*)d;
     if (rc == COPO_OK && (rc = dev_alloc((size_t)p.E * 8, &d)) == COPO_OK) p.seeds = (const uint64_t*)d;
     if (rc == COPO_OK && (rc = dev_alloc(16, &d)) == COPO_OK) p.lcf_dist = (const float*)d;
-    if (rc == COPO_OK)
-        rc = upload(s, cfg->route_segs, (size_t)cfg->n_routes * (COPO_MAX_SEGS + 1) * COPO_SEG_STRIDE, &p.route_segs);
+    if (rc == COPO_OK) {      // device table: only as many road records per route as the longest route needs (+ its terminal record)
+        int rows = 2;
+        for (int r = 0; r < cfg->n_routes; ++r) rows = std::max(rows, (int)cfg->route_meta[r * 4 + 1] + 1);
+        p.seg_rows = rows;
+        std::vector<float> compact((size_t)cfg->n_routes * rows * COPO_SEG_STRIDE);
+        for (int r = 0; r < cfg->n_routes; ++r)
+            memcpy(compact.data() + (size_t)r * rows * COPO_SEG_STRIDE,
+                   cfg->route_segs + (size_t)r * (COPO_MAX_SEGS + 1) * COPO_SEG_STRIDE, sizeof(float) * rows * COPO_SEG_STRIDE);
+        rc = upload(s, compact.data(), compact.size(), &p.route_segs);
+    }
     if (rc == COPO_OK) rc = upload(s, cfg->route_meta, (size_t)cfg->n_routes * 4, &p.route_meta);
     if (rc == COPO_OK) rc = upload(s, cfg->spawn_tab, (size_t)cfg->n_spawns * 4, &p.spawn_tab);
     if (rc == COPO_OK) rc = upload(s, cfg->spawn_s, (size_t)cfg->n_spawns, &p.spawn_s);
@@ -192,6 +202,11 @@ extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** o
     if (rc == COPO_OK && p.n_lines) rc = upload(s, cfg->lines, (size_t)cfg->n_lines * COPO_LINE_STRIDE, &p.lines);
     if (rc == COPO_OK && cfg->side_lasers) rc = upload(s, cfg->side_cs, (size_t)cfg->side_lasers * 2, &p.side_cs);
     if (rc == COPO_OK && cfg->lane_line_lasers) rc = upload(s, cfg->lane_line_cs, (size_t)cfg->lane_line_lasers * 2, &p.lane_cs);
+    if (rc == COPO_OK) {
+        const SimParams* pd = nullptr;
+        rc = upload(s, &s->p, 1, &pd);
+        s->p_dev = const_cast<SimParams*>(pd);
+    }
     if (rc != COPO_OK) {
         for (void* a : s->allocs) (void)hipFree(a);
         delete s;
@@ -258,6 +273,9 @@ extern "C" int copo_sim_set_force_lcf(copo_sim* s, double v) {
 extern "C" int copo_sim_set_debug(copo_sim* s, int64_t* stamps) {
     if (!s) return fail(COPO_ERR_NULL, "copo_sim_set_debug: NULL handle");
     s->p.dbg = reinterpret_cast<long long*>(stamps);
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());         // profiling aid: launches in flight keep the block they started with
+    HIP_TRY(hipMemcpy(s->p_dev, &s->p, sizeof(SimParams), hipMemcpyHostToDevice));
     return COPO_OK;
 }
 
@@ -278,7 +296,7 @@ extern "C" int copo_sim_reset(copo_sim* s, const uint64_t* seeds, const copo_ste
     HIP_TRY(hipMemsetAsync(s->p.state, 0, COPO_STATE_FIELDS * (size_t)s->p.E * s->p.N * 4, st));
     int rc = flush_lcf(s, st);
     if (rc != COPO_OK) return rc;
-    HIP_TRY(launch_sim_reset(s->p, *out, s->block, st));
+    HIP_TRY(launch_sim_reset(s->p, s->p_dev, *out, s->block, st));
     s->started = true;
     return COPO_OK;
 }
@@ -288,7 +306,7 @@ extern "C" int copo_sim_step(copo_sim* s, const float* act, const copo_step_out*
     if (!s->started) return fail(COPO_ERR_STATE, "copo_sim_step before copo_sim_reset");
     int rc = flush_lcf(s, static_cast<hipStream_t>(stream));
     if (rc != COPO_OK) return rc;
-    HIP_TRY(launch_sim_step(s->p, act, *out, s->block, static_cast<hipStream_t>(stream)));
+    HIP_TRY(launch_sim_step(s->p, s->p_dev, act, *out, s->block, static_cast<hipStream_t>(stream)));
     return COPO_OK;
 }
 
@@ -323,6 +341,7 @@ extern "C" int copo_neighbours_f32(const float* pos, const uint8_t* present, con
     SimParams p;
     memset(&p, 0, sizeof(p));
     p.E = E; p.N = N; p.K = K;
+    p.lists_for_absent = 1;
     p.neighbours_distance = radius;
     p.mf_distance = mf_distance;
     StepOut out;

@@ -17,7 +17,9 @@ enum : uint32_t { RNG_ROUTE = 1, RNG_LCF1 = 2, RNG_LCF2 = 3, RNG_SPAWN = 4, RNG_
 struct SimParams {
     int32_t E, N, O, K, num_lasers, enable_lcf, horizon, delay_done, respawn_cooldown, substeps;
     int32_t n_routes, n_spawns, n_safe, n_lines;
+    int32_t seg_rows;              // road records per route in the DEVICE copy of route_segs: longest route + 1 (compacted at create)
     int32_t side_lasers, lane_lasers, navi_dim, toll_dim, toll_min_steps;
+    int32_t lists_for_absent;      // 1: nbr_idx / nbr_dist rows of absent slots are filled with -1 / 0 (the stateless op); 0: left alone
     float lidar_range, neighbours_distance, mf_distance, dt, hl, hw, wheelbase, max_steer, max_speed;
     float acc_max, brake_gain, brake_max, region_hl, region_hw;
     float driving_reward, speed_reward, success_reward, crash_penalty, out_penalty, arrive_margin, lane_width;
@@ -33,7 +35,7 @@ struct SimParams {
     float* state;                  // [COPO_STATE_FIELDS][E][N] 32-bit words
     int32_t* env;                  // [E][4] = {t_env, episode, next_aid, started}
     const uint64_t* seeds;         // [E]
-    const float* route_segs;       // [R][COPO_MAX_SEGS+1][COPO_SEG_STRIDE]
+    const float* route_segs;       // [R][seg_rows][COPO_SEG_STRIDE]
     const float* route_meta;       // [R][4]
     const int32_t* spawn_tab;      // [P][4]
     const float* spawn_s;          // [P]
@@ -48,8 +50,9 @@ struct SimParams {
 
 using StepOut = copo_step_out;
 
-hipError_t launch_sim_reset(const SimParams& p, const StepOut& out, int block, hipStream_t stream);
-hipError_t launch_sim_step(const SimParams& p, const float* act, const StepOut& out, int block, hipStream_t stream);
+// p: host copy (launch shape), p_dev: the same block in device memory (what the kernels read)
+hipError_t launch_sim_reset(const SimParams& p, const SimParams* p_dev, const StepOut& out, int block, hipStream_t stream);
+hipError_t launch_sim_step(const SimParams& p, const SimParams* p_dev, const float* act, const StepOut& out, int block, hipStream_t stream);
 // stateless neighbour op: no communication block
 hipError_t launch_neighbours(const float* pos, const uint8_t* present, const float* rew, const SimParams& p,
                              const StepOut& out, hipStream_t stream);

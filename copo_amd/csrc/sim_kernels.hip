@@ -12,6 +12,13 @@
 // row outputs ~50 B; everything else stays in LDS / registers.
 #include "sim_common.h"
 
+// Profiling builds only (`make prof SKIP=<mask>`, a separate .so that the package never loads): phases compiled out to
+// split the instruction count -- 1 neighbour lists, 2 LiDAR windows + box tests, 4 LiDAR write-out, 8 state / navigation
+// block, 16 collision pairs, 32 respawn, 64 projection / termination.  The shipped library is built without it.
+#ifndef COPO_PROFILE_SKIP
+#define COPO_PROFILE_SKIP 0
+#endif
+
 namespace copo {
 
 // ------------------------------------------------------------------------------------------------
@@ -60,6 +67,7 @@ __device__ __forceinline__ bool obb_overlap2(float xi, float yi, float ci, float
 struct Slot {
     float x, y, th, v, steer, throttle, psteer, pthrottle, yawrate, prog, lcf, eprew;
     int32_t route, status, aid, spawncnt;
+    float hc, hs;      // heading unit vector of the step (registers only): sincos(th) / rotated through the sub-steps / the spawn road's
 };
 __device__ __forceinline__ int st_status(int32_t w) { return w & 0xff; }
 __device__ __forceinline__ int st_timer(int32_t w) { return (w >> 8) & 0xff; }
@@ -91,7 +99,7 @@ __device__ __forceinline__ void store_slot(const SimParams& p, int e, int n, con
 // pose of spawn slot sp: lane `stab[sp][2]` of the spawn road (road 0 of its routes), `sps[sp]` metres in
 __device__ __forceinline__ void spawn_pose(const SimParams& p, const float* rsegs, const int32_t* stab, const float* sps,
                                            int sp, float& x, float& y) {
-    const float* g = rsegs + (size_t)stab[sp * 4 + 0] * (COPO_MAX_SEGS + 1) * COPO_SEG_STRIDE;
+    const float* g = rsegs + (size_t)stab[sp * 4 + 0] * p.seg_rows * COPO_SEG_STRIDE;
     const float s0 = sps[sp];
     const float off = (float)stab[sp * 4 + 2] * p.lane_width;
     x = g[0] + g[2] * s0 + g[3] * off;
@@ -104,9 +112,10 @@ __device__ __forceinline__ void spawn_slot(const SimParams& p, const float* rseg
     const uint32_t cnt = (uint32_t)s.spawncnt & 0xffffu;
     const uint32_t h = hash_rng(seed, (uint32_t)n, cnt, episode, RNG_ROUTE);
     const int route = stab[sp * 4 + 0] + (int)(h % (uint32_t)stab[sp * 4 + 1]);
-    const float* g = rsegs + (size_t)route * (COPO_MAX_SEGS + 1) * COPO_SEG_STRIDE;
+    const float* g = rsegs + (size_t)route * p.seg_rows * COPO_SEG_STRIDE;
     spawn_pose(p, rsegs, stab, sps, sp, s.x, s.y);
     s.th = g[7];
+    s.hc = g[2]; s.hs = g[3];          // a fresh vehicle stands along its spawn road
     s.v = 0.0f; s.steer = 0.0f; s.throttle = 0.0f; s.psteer = 0.0f; s.pthrottle = 0.0f; s.yawrate = 0.0f;
     s.prog = sps[sp]; s.eprew = 0.0f;
     s.route = route;
@@ -128,9 +137,9 @@ __device__ __forceinline__ void spawn_slot(const SimParams& p, const float* rseg
 struct __align__(16) EnvLds {
     float x[64], y[64], cs[64], sn[64], rew[64];
     uint8_t plist[64], slist[64];   // slots of the present agents / solid vehicles, ascending (LiDAR pair list)
-    uint8_t ncnt[64];          // neighbour-list lengths (neighbour phase)
+    uint32_t ncnt[64], mfc[64];     // neighbour-list lengths / mean-field counts (neighbour phase, LDS atomics)
+    uint32_t n_entries;             // total list entries of the scene
     uint8_t alist[64], clist[64];   // acting agents / solid vehicles before the step's terminations (collision pairs)
-    int32_t rowbase[64];       // first LiDAR minimum of a present slot's fan, -1 for an absent slot
     unsigned long long m_acted, m_present, m_solid;
     uint8_t crash[64];
     float spx[COPO_MAX_SAFE], spy[COPO_MAX_SAFE], spc[COPO_MAX_SAFE], spsn[COPO_MAX_SAFE];   // respawn places: pose
@@ -139,18 +148,22 @@ struct __align__(16) EnvLds {
     const int32_t* stab;       // spawn table, same
     const float* sps;          // spawn offsets, same
     int32_t ending;
+    int32_t seg_rows;          // road records per route in the device tables (longest route + its terminal record)
 };
 
 // segment record k of a route (COPO_SEG_STRIDE floats), through whichever copy of the tables this workgroup uses
 __device__ __forceinline__ const float* seg_ptr(const EnvLds& L, int route, int k) {
-    return L.rsegs + ((size_t)route * (COPO_MAX_SEGS + 1) + k) * COPO_SEG_STRIDE;
+    return L.rsegs + ((size_t)route * L.seg_rows + k) * COPO_SEG_STRIDE;
 }
 constexpr int ROUTE_LDS_MAX_BYTES = 16 * 1024;
 // dynamic LDS: [slots][rays] LiDAR minima, then the route-table copy
 // (the neighbour phase borrows it for its [slots][slots] list-order rewards and a reset for its spawn permutation);
 // then the ray direction table, then the route-table copy
+// neighbour phase: list distances (fp64) [N][N] -- later reused for the rewards in list order --, list slots (u8) [N][N],
+// ranks (u8) [N][N], entry directory (u16) [N*N]
+__device__ __host__ inline int nbr_lds_words(int n_agents) { return 3 * n_agents * n_agents + 4; }
 __device__ __host__ inline int lidar_lds_words(int n_agents, int n_lasers) {
-    const int a = n_agents * n_lasers, b = n_agents * n_agents + COPO_MAX_SPAWNS / 2;
+    const int a = n_agents * n_lasers, b = nbr_lds_words(n_agents) > n_agents * n_agents + COPO_MAX_SPAWNS / 2 ? nbr_lds_words(n_agents) : n_agents * n_agents + COPO_MAX_SPAWNS / 2;
     return ((a > b ? a : b) + 3) & ~3;
 }
 __device__ __host__ inline int ray_lds_words(int n_lasers) { return (2 * n_lasers + 3) & ~3; }
@@ -162,8 +175,8 @@ __device__ __forceinline__ int16_t* lds_perm(const SimParams& p) {
     extern __shared__ unsigned int dyn[];
     return reinterpret_cast<int16_t*>(dyn + p.N * p.N);
 }
-__device__ __host__ inline int route_table_floats(int n_routes) {
-    return n_routes * ((COPO_MAX_SEGS + 1) * COPO_SEG_STRIDE + 4);
+__device__ __host__ inline int route_table_floats(int n_routes, int seg_rows) {
+    return n_routes * (seg_rows * COPO_SEG_STRIDE + 4);
 }
 
 // active agent slots: device memory next to the LCF distribution, so that captured graphs see updates
@@ -196,119 +209,167 @@ __device__ __forceinline__ void reset_env_wave0(const SimParams& p, EnvLds& L, u
     else if (lane < p.N) s.status = st_pack(ST_EMPTY, 0, 0);
 }
 
-// neighbour lists + reward reductions (CCEnv / LCFEnv) for agents i = wave, wave+nw, ...; lane = other agent j
+// Slot lists of the present agents / solid vehicles (ascending), by wave 0, from the masks of the scene.
+__device__ __forceinline__ void build_lists(EnvLds& L, int lane, unsigned long long present, unsigned long long solid,
+                                            bool for_neighbours = true) {
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    if ((present >> lane) & 1ull) L.plist[__popcll(present & lt)] = (uint8_t)lane;
+    if ((solid >> lane) & 1ull) L.slist[__popcll(solid & lt)] = (uint8_t)lane;
+    if (for_neighbours) {        // (not after a horizon reset: the tail of the neighbour phase may still be reading them)
+        L.ncnt[lane] = 0;
+        L.mfc[lane] = 0;
+        if (lane == 0) L.n_entries = 0;
+    }
+}
+
+// neighbour lists + reward reductions (CCEnv / LCFEnv).  Precondition: build_lists ran and is visible.
 //
 // The reference orders by d = sqrt_rn(dx^2 + dy^2) in float64 (np.linalg.norm) with ties in slot order and tests
-// `d < radius` (env_wrappers.py:125-158); the same fp64 operations are evaluated here, one sqrt per (i, j) pair.
+// `d < radius` (env_wrappers.py:125-158).  Pair-parallel in three steps:
+//   1. one lane per ORDERED pair (i, j) of present agents: an fp32 distance decides which pairs can be in range, those
+//      evaluate the reference's fp64 expression and append (d, j) to i's list in LDS (list order = arrival order);
+//   2. one lane per list entry: rank = number of entries of the same list that sort before it by (d, slot) -- the stable
+//      `sorted` of the reference -- then the first K ranks go to nbr_idx / nbr_dist;
+//   3. rewards scattered to list order, one lane per agent adds them up in that order in fp64 (:321-325).
+// Rows of absent slots: nbr_cnt / mf_cnt / nei_rew = 0; their nbr_idx / nbr_dist rows are NOT written (like obs rows).
 //
 // Communication (CCEnv.step :102-118, LCFEnv.step :362-371): the message columns of agent i hold the comm actions of
 // its `comm_nb` nearest neighbours (zeros for a neighbour that was not given an action this step, for a missing
 // neighbour, and everywhere after a reset: `fresh`), optionally followed by the neighbour's relative position.
 template <bool EXT>
-__device__ __forceinline__ void neighbours_phase(const SimParams& p, EnvLds& L, int e, int wave, int nwaves,
-                                                 int lane, const StepOut& out, const float* __restrict__ act = nullptr,
+__device__ __forceinline__ void neighbours_phase(const SimParams& p, EnvLds& L, int e, int tid, int nthreads,
+                                                 const StepOut& out, const float* __restrict__ act = nullptr,
                                                  unsigned long long acted_mask = 0ull, bool fresh = true) {
+    extern __shared__ unsigned int dyn[];
     const int N = p.N, K = p.K;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nwaves = nthreads >> 6;
     const bool comm = EXT && p.col_comm >= 0 && out.obs != nullptr;
     const int CS = p.comm_size, CD = p.comm_size + 3 * p.comm_pos;
     const unsigned long long present = L.m_present;
-    const bool pj = (lane < N) && ((present >> lane) & 1ull);
-    const double xj = (double)L.x[lane & 63], yj = (double)L.y[lane & 63];
+    const int np = __popcll(present);
     const size_t base = (size_t)e * N;
     const double R = (double)p.neighbours_distance, M = (double)p.mf_distance;
-    if (wave == 0 && out.glob_rew) {  // LCFEnv.step: sum(r.values()) / len(r.values()) in slot order, fp64
-        double gs = 0.0;
-        int gc = 0;
-        unsigned long long m = present;
-        while (m) {
-            const int j = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            gs += (double)L.rew[j];
-            gc++;
-        }
-        if (lane == 0) out.glob_rew[e] = gc ? (float)(gs / (double)gc) : 0.0f;
-    }
-    extern __shared__ unsigned int dyn[];
-    float* srt = reinterpret_cast<float*>(dyn);   // [N][N] rewards in list order (aliases the LiDAR minima of P5)
-    for (int i = wave; i < N; i += nwaves) {
-        const bool pi = (present >> i) & 1ull;
-        if (!pi) {   // absent slot: empty list (uniform branch)
-            if (lane == 0) {
-                if (out.nbr_cnt) out.nbr_cnt[base + i] = 0;
-                if (out.mf_cnt) out.mf_cnt[base + i] = 0;
-                L.ncnt[i] = 0;
+    double* nb_d = reinterpret_cast<double*>(dyn);                       // [N][N]
+    float* srt = reinterpret_cast<float*>(dyn);                          // [N][N], after the ranks are known
+    uint8_t* nb_j = reinterpret_cast<uint8_t*>(dyn + 2 * N * N);          // [N][N]
+    uint8_t* nb_rk = nb_j + N * N;                                        // [N][N]
+    uint16_t* ent = reinterpret_cast<uint16_t*>(dyn + 2 * N * N + (N * N) / 2 + 2);   // [N*N]: ia << 8 | pos
+    // ---- 1. candidate pairs -------------------------------------------------------------------------------------
+    {
+        const int npair = np * np;
+        const float inv_np = 1.0f / (float)(np > 0 ? np : 1);
+        const float r2hi = p.neighbours_distance * p.neighbours_distance * 1.00001f;   // fp32 d^2 errs by < 2e-7 relative
+        for (int c0 = wave * 64; c0 < npair; c0 += nwaves * 64) {
+            const int c = c0 + lane;
+            const bool live = c < npair;
+            const int ib = live ? (int)(((float)c + 0.5f) * inv_np) : 0;
+            const int ia = live ? c - ib * np : 0;                        // consecutive lanes: consecutive LISTS (no counter clash)
+            const int i = L.plist[ia], j = L.plist[ib];
+            const float xi = L.x[i], yi = L.y[i], xj = L.x[j], yj = L.y[j];
+            const float fx = xi - xj, fy = yi - yj;
+            bool inr = false;
+            double d = 0.0;
+            if (live && i != j && fx * fx + fy * fy < r2hi) {
+                const double dx = (double)xi - (double)xj, dy = (double)yi - (double)yj;
+                d = sqrt(dx * dx + dy * dy);
+                inr = d < R;
             }
-            if (lane < K) {
-                if (out.nbr_idx) out.nbr_idx[(base + i) * K + lane] = -1;
-                if (out.nbr_dist) out.nbr_dist[(base + i) * K + lane] = 0.0f;
-            }
-            continue;
-        }
-        const double dx = (double)L.x[i] - xj, dy = (double)L.y[i] - yj;
-        const double d = sqrt(dx * dx + dy * dy);
-        const bool in_m = d <= M;
-        const bool inr = pj && (lane != i) && (d < R);
-        const unsigned long long mask = __ballot(inr);
-        const int cnt = __popcll(mask);
-        const int mfc = __popcll(__ballot(inr && in_m));
-        // rank of j in i's list: stable order by (d, slot) == python sorted() on an insertion-ordered dict
-        int rank = 0;
-        unsigned long long m = mask;
-        while (m) {
-            const int k = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const double dk = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(d), k),
-                                               __builtin_amdgcn_readlane(__double2loint(d), k));   // k is wave-uniform
-            rank += (dk < d || (dk == d && k < lane)) ? 1 : 0;
-        }
-        if (out.nei_rew && inr) srt[i * N + rank] = L.rew[lane];
-        if (comm) {
-            float* row = out.obs + (base + i) * p.O + p.col_comm;
-            if (inr && rank < p.comm_nb) {
-                float* q = row + rank * CD;
-                const bool spoke = !fresh && ((acted_mask >> lane) & 1ull) && act != nullptr;
-                for (int k = 0; k < CS; ++k) q[k] = spoke ? act[(base + lane) * p.act_dim + 2 + k] : 0.0f;
-                if (p.comm_pos) {
-                    float ex[3] = {0.0f, 0.0f, 0.0f};
-                    if (spoke) {   // neighbour relative to ego in the ego frame, float64 like the reference's numpy
-                        const double ci = (double)L.cs[i], si = (double)L.sn[i];
-                        const double lon = (-dx) * ci + (-dy) * si, lat = (-dy) * ci - (-dx) * si;
-                        const double dis = sqrt(lon * lon + lat * lat);
-                        const double v[3] = {dis / 20.0, (lon / dis + 1.0) / 2.0, (lat / dis + 1.0) / 2.0};   // 0/0 = NaN for d == 0, as numpy
-#pragma unroll
-                        for (int k = 0; k < 3; ++k)
-                            ex[k] = v[k] != v[k] ? __uint_as_float(0x7fc00000u) : (float)(v[k] < 0.0 ? 0.0 : (v[k] > 1.0 ? 1.0 : v[k]));
-                    }
-                    q[CS] = ex[0]; q[CS + 1] = ex[1]; q[CS + 2] = ex[2];
+            const unsigned long long m = __ballot(inr);
+            if (m) {
+                unsigned int e0 = 0;
+                if (lane == 0) e0 = atomicAdd(&L.n_entries, (unsigned int)__popcll(m));
+                e0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)e0);
+                if (inr) {
+                    const unsigned int pos = atomicAdd(&L.ncnt[i], 1u);
+                    if (d <= M) atomicAdd(&L.mfc[i], 1u);
+                    nb_d[i * N + pos] = d;
+                    nb_j[i * N + pos] = (uint8_t)j;
+                    ent[e0 + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((ia << 8) | pos);
                 }
             }
-            if (lane >= cnt && lane < p.comm_nb) {
-                float* q = row + lane * CD;
-                for (int k = 0; k < CD; ++k) q[k] = 0.0f;
+        }
+        if (wave == nwaves - 1 && out.glob_rew) {  // LCFEnv.step: sum(r.values()) / len(r.values()) in slot order, fp64
+            double gs = 0.0;
+            unsigned long long m = present;
+            while (m) {
+                const int j = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                gs += (double)L.rew[j];
             }
-        }
-        if (lane == 0) {
-            if (out.nbr_cnt) out.nbr_cnt[base + i] = cnt;
-            if (out.mf_cnt) out.mf_cnt[base + i] = mfc;
-            L.ncnt[i] = (uint8_t)cnt;
-        }
-        if (inr && rank < K) {
-            if (out.nbr_idx) out.nbr_idx[(base + i) * K + rank] = lane;
-            if (out.nbr_dist) out.nbr_dist[(base + i) * K + rank] = (float)d;
-        }
-        if (lane >= cnt && lane < K) {
-            if (out.nbr_idx) out.nbr_idx[(base + i) * K + lane] = -1;
-            if (out.nbr_dist) out.nbr_dist[(base + i) * K + lane] = 0.0f;
+            if (lane == 0) out.glob_rew[e] = np ? (float)(gs / (double)np) : 0.0f;
         }
     }
     __syncthreads();
-    // mean of neighbour rewards, summed in list order in fp64 (env_wrappers.py:321-325): one lane per agent, on a
-    // wave that the caller's next (wave 0) phase does not need
-    if (out.nei_rew && wave == (nwaves > 1 ? 1 : 0) && lane < N) {
-        const int cnt = L.ncnt[lane];
-        double nsum = 0.0;
-        for (int r = 0; r < cnt; ++r) nsum += (double)srt[lane * N + r];
-        out.nei_rew[base + lane] = cnt ? (float)(nsum / (double)cnt) : 0.0f;
+    // ---- 2. ranks, first K entries of every list ------------------------------------------------------------------
+    const int T = (int)L.n_entries;
+    for (int q = tid; q < T; q += nthreads) {
+        const unsigned int pk = ent[q];
+        const int i = L.plist[pk >> 8], pos = (int)(pk & 255u);
+        const int cnt = (int)L.ncnt[i];
+        const double d = nb_d[i * N + pos];
+        const int j = nb_j[i * N + pos];
+        int rank = 0;
+        for (int k = 0; k < cnt; ++k) {
+            const double dk = nb_d[i * N + k];
+            const int jk = nb_j[i * N + k];
+            rank += (dk < d || (dk == d && jk < j)) ? 1 : 0;
+        }
+        nb_rk[i * N + pos] = (uint8_t)rank;
+        if (rank < K) {
+            if (out.nbr_idx) out.nbr_idx[(base + i) * K + rank] = j;
+            if (out.nbr_dist) out.nbr_dist[(base + i) * K + rank] = (float)d;
+        }
+        if (comm && rank < p.comm_nb) {
+            float* qm = out.obs + (base + i) * p.O + p.col_comm + rank * CD;
+            const bool spoke = !fresh && ((acted_mask >> j) & 1ull) && act != nullptr;
+            for (int k = 0; k < CS; ++k) qm[k] = spoke ? act[(base + j) * p.act_dim + 2 + k] : 0.0f;
+            if (p.comm_pos) {
+                float ex[3] = {0.0f, 0.0f, 0.0f};
+                if (spoke) {   // neighbour relative to ego in the ego frame, float64 like the reference's numpy
+                    const double ci = (double)L.cs[i], si = (double)L.sn[i];
+                    const double dx = (double)L.x[j] - (double)L.x[i], dy = (double)L.y[j] - (double)L.y[i];
+                    const double lon = dx * ci + dy * si, lat = dy * ci - dx * si;
+                    const double dis = sqrt(lon * lon + lat * lat);
+                    const double v[3] = {dis / 20.0, (lon / dis + 1.0) / 2.0, (lat / dis + 1.0) / 2.0};   // 0/0 = NaN for d == 0, as numpy
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        ex[k] = v[k] != v[k] ? __uint_as_float(0x7fc00000u) : (float)(v[k] < 0.0 ? 0.0 : (v[k] > 1.0 ? 1.0 : v[k]));
+                }
+                qm[CS] = ex[0]; qm[CS + 1] = ex[1]; qm[CS + 2] = ex[2];
+            }
+        }
+    }
+    __syncthreads();       // every read of the fp64 distances is done: their storage now takes the rewards in list order
+    // ---- 3. rewards in list order, per-agent tails ----------------------------------------------------------------
+    if (out.nei_rew)
+        for (int q = tid; q < T; q += nthreads) {
+            const unsigned int pk = ent[q];
+            const int i = L.plist[pk >> 8], pos = (int)(pk & 255u);
+            srt[i * N + nb_rk[i * N + pos]] = L.rew[nb_j[i * N + pos]];
+        }
+    __syncthreads();
+    // one lane per slot, on a wave that the caller's next (wave 0) phase does not need
+    if (wave == (nwaves > 1 ? 1 : 0) && lane < N) {
+        const bool pi = (present >> lane) & 1ull;
+        const int cnt = pi ? (int)L.ncnt[lane] : 0;
+        if (out.nbr_cnt) out.nbr_cnt[base + lane] = cnt;
+        if (out.mf_cnt) out.mf_cnt[base + lane] = pi ? (int)L.mfc[lane] : 0;
+        if (out.nei_rew) {
+            double nsum = 0.0;
+            for (int r = 0; r < cnt; ++r) nsum += (double)srt[lane * N + r];
+            out.nei_rew[base + lane] = cnt ? (float)(nsum / (double)cnt) : 0.0f;
+        }
+        if (pi || p.lists_for_absent) {    // (the stateless op fills the rows of absent slots too)
+            for (int k = cnt; k < K; ++k) {
+                if (out.nbr_idx) out.nbr_idx[(base + lane) * K + k] = -1;
+                if (out.nbr_dist) out.nbr_dist[(base + lane) * K + k] = 0.0f;
+            }
+            if (comm && pi)
+                for (int r = cnt; r < p.comm_nb; ++r) {
+                    float* qm = out.obs + (base + lane) * p.O + p.col_comm + r * CD;
+                    for (int k = 0; k < CD; ++k) qm[k] = 0.0f;
+                }
+        }
     }
 }
 
@@ -483,8 +544,8 @@ __device__ __forceinline__ float atan2_window(float v, float u) {
     return v < 0.0f ? -q : q;
 }
 
-// LiDAR + observation write-out, all threads of the workgroup.  Precondition: L.x/y/cs/sn, m_present,
-// m_solid, ego tile are final and visible (caller synchronised).
+// LiDAR + observation write-out, all threads of the workgroup.  Precondition: L.x/y/cs/sn, m_present, m_solid and the
+// slot lists (build_lists) are final and visible (caller synchronised).
 //
 // Pair-driven: a ray of agent i can only touch vehicle j inside the angular window bearing(j) +- asin(circumradius /
 // distance) of i's ray fan, so the work list is (present agent, solid vehicle) pairs expanded to the few rays of their
@@ -508,13 +569,6 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
     const int np = __popcll(present), ns = __popcll(solid);
     unsigned int* best = dyn;                     // [np][NL] nearest entry distance (float bits) per ray
     const unsigned int range_bits = __float_as_uint(range);
-    if (wave == 0) {                              // slot lists of the present agents / the solid vehicles
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        const int ip = __popcll(present & lt);
-        if ((present >> lane) & 1ull) L.plist[ip] = (uint8_t)lane;
-        if ((solid >> lane) & 1ull) L.slist[__popcll(solid & lt)] = (uint8_t)lane;
-        L.rowbase[lane] = ((present >> lane) & 1ull) ? ip * NL : -1;
-    }
     for (int q = tid; q < np * NL; q += nthreads) best[q] = range_bits;
     float* eobs = obs + (size_t)e * N * O;
     const float* __restrict__ rays = lds_rays(p);
@@ -523,7 +577,7 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
     const int ncombo = np * ns;
     const float inv_ns = 1.0f / (float)(ns > 0 ? ns : 1);
     const float rays_per_rad = (float)NL * 0.159154943f;
-    for (int c0 = wave * 64; c0 < ncombo; c0 += nwaves * 64) {
+    for (int c0 = wave * 64; c0 < ((COPO_PROFILE_SKIP & 2) ? 0 : ncombo); c0 += nwaves * 64) {
         const int c = c0 + lane;
         const bool live = c < ncombo;
         const int ip = live ? (int)(((float)c + 0.5f) * inv_ns) : 0;
@@ -581,14 +635,13 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
         }
     }
     __syncthreads();
-    const int nrays = N * NL;
+    const int nrays = np * NL;                    // rows of present slots only
     const float inv_nl = 1.0f / (float)NL;
     const float inv_range = p.inv_range;
     const int col_lidar = p.col_lidar;
-    for (int q = tid; q < nrays; q += nthreads) {
-        const int i = (int)(((float)q + 0.5f) * inv_nl), k = q - i * NL;
-        const int rb = L.rowbase[i];
-        if (rb >= 0) eobs[i * O + col_lidar + k] = __uint_as_float(best[rb + k]) * inv_range;
+    for (int q = tid; q < ((COPO_PROFILE_SKIP & 4) ? 0 : nrays); q += nthreads) {
+        const int ip = (int)(((float)q + 0.5f) * inv_nl), k = q - ip * NL;
+        eobs[(int)L.plist[ip] * O + col_lidar + k] = __uint_as_float(best[q]) * inv_range;
     }
     // optional side / lane-line detector beams (Bottleneck, Tollgate): one thread per (present agent, beam)
     const int nb = p.side_lasers + p.lane_lasers;
@@ -610,12 +663,10 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
 }
 
 __device__ __forceinline__ void stage_pose(EnvLds& L, int lane, const Slot& s) {
-    float sn, cs;
-    sincos_det(s.th, sn, cs);
     L.x[lane] = s.x;
     L.y[lane] = s.y;
-    L.cs[lane] = cs;
-    L.sn[lane] = sn;
+    L.cs[lane] = s.hc;
+    L.sn[lane] = s.hs;
 }
 
 __device__ __forceinline__ void load_rays(const SimParams& p, EnvLds& L, int tid, int nthreads) {
@@ -627,13 +678,17 @@ __device__ __forceinline__ void load_rays(const SimParams& p, EnvLds& L, int tid
 // reset kernel
 // ------------------------------------------------------------------------------------------------
 template <bool EXT>   // EXT: the traffic-light / communication observation blocks are compiled in (copo_sim_cfg extensions)
-__global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_reset_kernel(SimParams p, StepOut out) {
+__global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_reset_kernel(const SimParams* __restrict__ pp, StepOut out) {
+    // the parameter block lives in device memory: ~90 scalars as by-value kernel arguments are all loaded up front and
+    // kept live, and the resulting SGPR spills (v_writelane / v_readlane) were a quarter of the kernel's VALU instructions
+    const SimParams& p = *pp;
     __shared__ EnvLds L;
     const int e = blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nwaves = nthreads >> 6;
     const int N = p.N;
     load_rays(p, L, tid, nthreads);
     if (tid == 0) {
+        L.seg_rows = p.seg_rows;
         L.rsegs = p.route_segs;
         L.rmeta = p.route_meta;
         L.stab = p.spawn_tab;
@@ -661,6 +716,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_reset_kernel(SimParams
             L.x[lane] = 0.0f; L.y[lane] = 0.0f; L.cs[lane] = 1.0f; L.sn[lane] = 0.0f; L.rew[lane] = 0.0f;
         }
         const unsigned long long all = __ballot(lane < cap);
+        build_lists(L, lane, all, all);
         if (lane == 0) {
             L.m_present = all;
             L.m_solid = all;
@@ -671,7 +727,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_reset_kernel(SimParams
         ego_navi_obs<EXT>(p, L, lane, s, lane < cap, (out.obs && lane < N) ? out.obs + ((size_t)e * N + lane) * p.O : nullptr, 0, true);
     }
     __syncthreads();
-    neighbours_phase<EXT>(p, L, e, wave, nwaves, lane, out);
+    neighbours_phase<EXT>(p, L, e, tid, nthreads, out);
     __syncthreads();   // the list-order sums read the LDS words that the LiDAR minima reuse
     if (out.obs) obs_phase(p, L, e, tid, nthreads, out.obs);
 }
@@ -680,8 +736,9 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_reset_kernel(SimParams
 // step kernel
 // ------------------------------------------------------------------------------------------------
 template <bool EXT>
-__global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams p, const float* __restrict__ act,
-                                                                      StepOut out) {
+__global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(const SimParams* __restrict__ pp,
+                                                                      const float* __restrict__ act, StepOut out) {
+    const SimParams& p = *pp;       // device-memory parameter block (see sim_reset_kernel)
     __shared__ EnvLds L;
     const int e = blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nwaves = nthreads >> 6;
@@ -691,7 +748,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
     {   // route tables: a few KB read on every step by the projection / navigation code -> LDS copy when they fit
         // (the waves that idle during P0 do the copy; the barrier after P0 publishes it)
         extern __shared__ unsigned int dyn[];
-        const int nseg_f = p.n_routes * (COPO_MAX_SEGS + 1) * COPO_SEG_STRIDE, nmeta_f = p.n_routes * 4;
+        const int nseg_f = p.n_routes * p.seg_rows * COPO_SEG_STRIDE, nmeta_f = p.n_routes * 4;
         const int ntab = p.n_spawns * 4, nsp = p.n_spawns;
         const bool stage = (nseg_f + nmeta_f) * (int)sizeof(float) <= ROUTE_LDS_MAX_BYTES;
         float* rl = reinterpret_cast<float*>(dyn + lidar_lds_words(p.N, p.num_lasers) + ray_lds_words(p.num_lasers) + (nthreads >> 6) * 64);
@@ -704,6 +761,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
             for (int q = tid; q < nsp; q += nthreads) sl[q] = p.spawn_s[q];
         }
         if (tid == 0) {
+            L.seg_rows = p.seg_rows;
             L.rsegs = stage ? rl : p.route_segs;
             L.rmeta = stage ? rl + nseg_f : p.route_meta;
             L.stab = stage ? tl : p.spawn_tab;
@@ -734,6 +792,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
             } else if (st == ST_EMPTY && tm > 0) {
                 s.status = st_pack(ST_EMPTY, tm - 1, 0);
             }
+            sincos_det(s.th, s.hs, s.hc);     // the one sincos of the step: start heading of acting slots, pose heading of wrecks
             if (acted) {
                 float a0, a1;
                 if (EXT) {
@@ -758,19 +817,27 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
                 if (brake > p.brake_max) brake = p.brake_max;
                 const float h = p.h_sub;
                 float x = s.x, y = s.y, th = s.th, v = s.v;
+                float cs = s.hc, sn = s.hs;
                 const float v0 = v, th0 = th;
                 for (int k = 0; k < p.substeps; ++k) {
                     const float a = a1 >= 0.0f ? (v < p.max_speed ? a1 * p.acc_max : 0.0f) : -brake;
                     v = v + a * h;
                     if (v < 0.0f) v = 0.0f;
-                    float sn, cs;
-                    sincos_det(th, sn, cs);
                     const float dxh = cs * cb - sn * sb, dyh = sn * cb + cs * sb;
                     x = x + v * dxh * h;
                     y = y + v * dyh * h;
-                    th = wrap_pi(th + v * yawk * h);
+                    // turn the heading vector by the sub-step's small angle: 3-term sine / cosine, no range reduction
+                    const float dth = v * yawk * h;
+                    const float q = dth * dth;
+                    const float sd2 = dth - dth * q * (0.166666667f - q * 0.00833333333f);
+                    const float cd2 = 1.0f - q * (0.5f - q * 0.0416666667f);
+                    const float cn = cs * cd2 - sn * sd2, sm = sn * cd2 + cs * sd2;
+                    cs = cn;
+                    sn = sm;
+                    th = wrap_pi(th + dth);
                 }
                 s.x = x; s.y = y; s.th = th; s.v = v;
+                s.hc = cs; s.hs = sn;
                 s.psteer = s.steer; s.pthrottle = s.throttle;
                 s.steer = a0; s.throttle = a1;
                 s.yawrate = wrap_pi(th - th0) * p.inv_dt;
@@ -803,7 +870,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
         const int npair = na * nc;
         const float inv_nc = 1.0f / (float)(nc > 0 ? nc : 1);
         const float near2 = 4.0f * (hl * hl + hw * hw) * 1.001f;   // farther apart than two circumradii: no overlap
-        for (int c0 = wave * 64; c0 < npair; c0 += nwaves * 64) {
+        for (int c0 = wave * 64; c0 < ((COPO_PROFILE_SKIP & 16) ? 0 : npair); c0 += nwaves * 64) {
             const int c = c0 + lane;
             const bool live = c < npair;
             const int ia = live ? (int)(((float)c + 0.5f) * inv_nc) : 0;
@@ -835,7 +902,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
         bool term = false;
         lcf_row = s.lcf;
         aid_row = acted ? s.aid : -1;
-        if (acted) {
+        if (acted && !(COPO_PROFILE_SKIP & 64)) {
             const int route = s.route & 0xffff;
             const int seg_before = s.route >> 16;
             int seg = seg_before;
@@ -918,7 +985,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
         present = acted;
         // respawn: a random one of the respawn places whose region is clear of the vehicles standing now, each place at
         // most once per step; serial over the eligible slots in slot order, every lane tests its own vehicle
-        if (!ending) {
+        if (!ending && !(COPO_PROFILE_SKIP & 32)) {
             const bool mine = lane < capacity_of(p) && !acted && s.status == st_pack(ST_EMPTY, 0, 0);
             unsigned long long elig = __ballot(mine);
             if (elig) {
@@ -930,7 +997,11 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
                                                                s.x, s.y, cj, sj, hl, hw);
                     if (__ballot(blk) == 0ull) clear |= 1u << q;
                 }
+                // the serial part only hands out places (a few scalar operations per waiting slot); the spawns themselves
+                // -- three hash chains, the LCF draw -- run afterwards for all chosen lanes at once
                 uint32_t used = 0;
+                int my_q = -1;
+                int32_t my_aid = 0;
                 while (elig) {
                     const int n = __ffsll((long long)elig) - 1;
                     elig &= elig - 1;
@@ -944,13 +1015,14 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
                     while (pick > 0) { m &= m - 1; --pick; }
                     const int q = __ffs((int)m) - 1;
                     used |= 1u << q;
-                    if (lane == n) {
-                        spawn_slot(p, L.rsegs, L.stab, L.sps, seed, (uint32_t)episode, n, p.safe_ids[q], next_aid, s);
-                        present = true;
-                        fl = COPO_F_SPAWNED;
-                        lcf_row = s.lcf;
-                    }
+                    if (lane == n) { my_q = q; my_aid = next_aid; }
                     next_aid += 1;
+                }
+                if (my_q >= 0) {
+                    spawn_slot(p, L.rsegs, L.stab, L.sps, seed, (uint32_t)episode, lane, p.safe_ids[my_q], my_aid, s);
+                    present = true;
+                    fl = COPO_F_SPAWNED;
+                    lcf_row = s.lcf;
                 }
             }
         }
@@ -962,6 +1034,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
         }
         const unsigned long long mp = __ballot(present);
         const unsigned long long ms = __ballot(lane < N && st_status(s.status) != ST_EMPTY);
+        build_lists(L, lane, mp, ms);
         if (lane == 0) {
             L.m_present = mp;
             L.m_solid = ms;
@@ -971,7 +1044,8 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
 
     COPO_STAMP(3);
     // ---- P3 (all waves): neighbour lists + reward reductions on the post-step (pre-reset) scene ---
-    neighbours_phase<EXT>(p, L, e, wave, nwaves, lane, out, act, L.m_acted, ending);
+    if (!(COPO_PROFILE_SKIP & 1)) neighbours_phase<EXT>(p, L, e, tid, nthreads, out, act, L.m_acted, ending);
+    else __syncthreads();
     COPO_STAMP(4);
     // (neighbours_phase ends with a workgroup barrier: the reset below may overwrite the poses it read)
 
@@ -990,6 +1064,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
             if (!acted && lane < cap) lcf_out = s.lcf;
             if (lane < N) stage_pose(L, lane, s);
             const unsigned long long all = __ballot(lane < cap);
+            build_lists(L, lane, all, all, false);
             if (lane == 0) {
                 L.m_present = all;
                 L.m_solid = all;
@@ -1009,7 +1084,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(SimParams 
             env[1] = episode;
             env[2] = next_aid;
         }
-        ego_navi_obs<EXT>(p, L, lane, s, present, (out.obs && lane < N) ? out.obs + ((size_t)e * N + lane) * p.O : nullptr, ending ? 0 : t_env + 1, ending);
+        if (!(COPO_PROFILE_SKIP & 8)) ego_navi_obs<EXT>(p, L, lane, s, present, (out.obs && lane < N) ? out.obs + ((size_t)e * N + lane) * p.O : nullptr, ending ? 0 : t_env + 1, ending);
     }
     __syncthreads();
 
@@ -1043,10 +1118,11 @@ __global__ void __launch_bounds__(256) neighbours_kernel(const float* __restrict
             L.x[lane] = 0.0f; L.y[lane] = 0.0f; L.rew[lane] = 0.0f;
         }
         const unsigned long long m = __ballot(pr);
+        build_lists(L, lane, m, 0ull);
         if (lane == 0) L.m_present = m;
     }
     __syncthreads();
-    neighbours_phase<false>(p, L, e, wave, nwaves, lane, out);
+    neighbours_phase<false>(p, L, e, tid, (int)blockDim.x, out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1070,27 +1146,27 @@ static hipError_t sim_lds_attrs() {              // 64 slots x 256 rays + route 
     return once;
 }
 static size_t route_lds_bytes(const SimParams& p) {      // LDS copy of the route tables when they are small
-    const size_t b = (size_t)route_table_floats(p.n_routes) * sizeof(float);
+    const size_t b = (size_t)route_table_floats(p.n_routes, p.seg_rows) * sizeof(float);
     return b <= (size_t)ROUTE_LDS_MAX_BYTES ? b + (size_t)p.n_spawns * 5 * sizeof(float) : 0;      // + spawn table and offsets
 }
 
-hipError_t launch_sim_reset(const SimParams& p, const StepOut& out, int block, hipStream_t stream) {
+hipError_t launch_sim_reset(const SimParams& p, const SimParams* p_dev, const StepOut& out, int block, hipStream_t stream) {
     if (hipError_t a = sim_lds_attrs(); a != hipSuccess) return a;
-    if (sim_has_ext(p)) hipLaunchKernelGGL(sim_reset_kernel<true>, dim3(p.E), dim3(block), lidar_lds_bytes(p, block), stream, p, out);
-    else hipLaunchKernelGGL(sim_reset_kernel<false>, dim3(p.E), dim3(block), lidar_lds_bytes(p, block), stream, p, out);
+    if (sim_has_ext(p)) hipLaunchKernelGGL(sim_reset_kernel<true>, dim3(p.E), dim3(block), lidar_lds_bytes(p, block), stream, p_dev, out);
+    else hipLaunchKernelGGL(sim_reset_kernel<false>, dim3(p.E), dim3(block), lidar_lds_bytes(p, block), stream, p_dev, out);
     return hipGetLastError();
 }
 
-hipError_t launch_sim_step(const SimParams& p, const float* act, const StepOut& out, int block, hipStream_t stream) {
+hipError_t launch_sim_step(const SimParams& p, const SimParams* p_dev, const float* act, const StepOut& out, int block, hipStream_t stream) {
     if (hipError_t a = sim_lds_attrs(); a != hipSuccess) return a;
-    if (sim_has_ext(p)) hipLaunchKernelGGL(sim_step_kernel<true>, dim3(p.E), dim3(block), lidar_lds_bytes(p, block) + route_lds_bytes(p), stream, p, act, out);
-    else hipLaunchKernelGGL(sim_step_kernel<false>, dim3(p.E), dim3(block), lidar_lds_bytes(p, block) + route_lds_bytes(p), stream, p, act, out);
+    if (sim_has_ext(p)) hipLaunchKernelGGL(sim_step_kernel<true>, dim3(p.E), dim3(block), lidar_lds_bytes(p, block) + route_lds_bytes(p), stream, p_dev, act, out);
+    else hipLaunchKernelGGL(sim_step_kernel<false>, dim3(p.E), dim3(block), lidar_lds_bytes(p, block) + route_lds_bytes(p), stream, p_dev, act, out);
     return hipGetLastError();
 }
 
 hipError_t launch_neighbours(const float* pos, const uint8_t* present, const float* rew, const SimParams& p,
                              const StepOut& out, hipStream_t stream) {
-    hipLaunchKernelGGL(neighbours_kernel, dim3(p.E), dim3(256), (size_t)p.N * p.N * sizeof(float), stream, pos, present, rew, p, out);
+    hipLaunchKernelGGL(neighbours_kernel, dim3(p.E), dim3(256), (size_t)nbr_lds_words(p.N) * sizeof(unsigned int), stream, pos, present, rew, p, out);
     return hipGetLastError();
 }
 

@@ -36,12 +36,10 @@ __device__ __forceinline__ float atan2_det(float y, float x) {
     const float ax = fabsf(x), ay = fabsf(y);
     const float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
     if (mx == 0.0f) return 0.0f;
-    const float a = mn / mx;
-    float off = 0.0f, t = a;
-    if (a > 0.414213562f) {
-        t = (a - 1.0f) / (a + 1.0f);
-        off = 0.785398163f;
-    }
+    // one division: tan(a - pi/4) = (mn - mx) / (mn + mx) above tan(pi/8), mn / mx below
+    const bool hi = mn > 0.414213562f * mx;
+    const float t = (hi ? mn - mx : mn) / (hi ? mn + mx : mx);
+    const float off = hi ? 0.785398163f : 0.0f;
     const float z = t * t;
     const float p =
         (((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * t + t;

@@ -171,7 +171,9 @@ typedef struct copo_step_out {
     float* nei_rew;      /* [E][N]      env_wrappers.py:321-325                                           */
     float* glob_rew;     /* [E]         env_wrappers.py:313                                               */
     uint8_t* flags;      /* [E][N]      COPO_F_* bitfield                                                 */
-    int32_t* nbr_idx;    /* [E][N][K]   slot ids sorted by (distance, slot), -1 padded  (:125-139)        */
+    int32_t* nbr_idx;    /* [E][N][K]   slot ids sorted by (distance, slot), -1 padded  (:125-139); like obs, rows of
+                                         slots that held no agent when the lists were made (the scene BEFORE a horizon
+                                         reset) are not written -- nbr_cnt / mf_cnt / nei_rew are 0 there            */
     int32_t* nbr_cnt;    /* [E][N]      neighbours within neighbours_distance (may exceed K)              */
     int32_t* mf_cnt;     /* [E][N]      length of the list prefix with distance <= mf_distance            */
     float* nbr_dist;     /* [E][N][K]   distances (float64 compare, stored fp32)                          */

@@ -57,12 +57,10 @@ static float o_atan2f(float y, float x) {
     float ax = fabsf(x), ay = fabsf(y);
     float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
     if (mx == 0.0f) return 0.0f;
-    float a = mn / mx;
-    float off = 0.0f, t = a;
-    if (a > 0.414213562f) {
-        t = (a - 1.0f) / (a + 1.0f);
-        off = 0.785398163f;
-    }
+    /* one division: tan(a - pi/4) = (mn - mx) / (mn + mx) above tan(pi/8), mn / mx below */
+    int hi = mn > 0.414213562f * mx;
+    float t = (hi ? mn - mx : mn) / (hi ? mn + mx : mx);
+    float off = hi ? 0.785398163f : 0.0f;
     float z = t * t;
     float p = (((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * t + t;
     float r = off + p;
@@ -286,6 +284,13 @@ static void spawn_agent(oracle_sim* s, int e, int n, int sp) {
     IP(s, S_SPAWNCNT, e)[n] = (int32_t)((cnt + 1) & 0xffffu);      /* toll wait (high half) starts at 0 */
 }
 
+/* a freshly spawned vehicle stands along its spawn road: heading vector = the road record's (cos0, sin0) */
+static void road_heading(oracle_sim* s, int e, int n, float* cs, float* sn) {
+    const float* g0 = SEG(s, IP(s, S_ROUTE, e)[n] & 0xffff, 0);
+    *cs = g0[2];
+    *sn = g0[3];
+}
+
 static int oracle_capacity(const oracle_sim* s) {
     int c = s->capacity, N = s->cfg.num_agents;
     return c < 1 ? 1 : (c > N ? N : c);
@@ -448,12 +453,11 @@ static void write_obs(oracle_sim* s, int e, const copo_step_out* out, const uint
     float hl = c->veh_half_len, hw = c->veh_half_wid;
     float circ = sqrtf(hl * hl + hw * hw);
     float w = c->lane_width;
-    float cs[COPO_MAX_AGENTS], sn[COPO_MAX_AGENTS];
+    const float *cs = t->cs, *sn = t->sn;   /* heading unit vectors of the step (oracle_sim_step / reset keep them current) */
     uint8_t solid[COPO_MAX_AGENTS];
     for (int j = 0; j < N; ++j) {
         int st = ST_STATUS(IP(s, S_STATUS, e)[j]);
         solid[j] = (st == ST_ALIVE || st == ST_WRECK);
-        o_sincosf(FP(s, S_TH, e)[j], &sn[j], &cs[j]);
     }
     for (int i = 0; i < N; ++i) {
         float* o = out->obs + ((size_t)e * N + i) * O;
@@ -574,7 +578,7 @@ static void write_obs(oracle_sim* s, int e, const copo_step_out* out, const uint
 /* neighbour lists + reward reductions for one env on an explicit present set (fp64 distances) */
 static void neighbours_env(const float* px, const float* py, const uint8_t* present, const float* rew, int N, int K,
                            float radius, float mf, int32_t* nbr_idx, int32_t* nbr_cnt, int32_t* mf_cnt, float* nbr_dist,
-                           float* nei_rew, float* glob_rew, int (*full_ids)[COPO_MAX_AGENTS], int* full_cnt) {
+                           float* nei_rew, float* glob_rew, int (*full_ids)[COPO_MAX_AGENTS], int* full_cnt, int skip_absent) {
     double gsum = 0.0;
     int gcnt = 0;
     for (int i = 0; i < N; ++i)
@@ -606,7 +610,7 @@ static void neighbours_env(const float* px, const float* py, const uint8_t* pres
         for (int k = 0; k < cnt; ++k)
             if (ds[k] <= (double)mf) m++; else break;
         if (mf_cnt) mf_cnt[i] = m;
-        for (int k = 0; k < K; ++k) {
+        for (int k = 0; k < K && (present[i] || !skip_absent); ++k) {    /* simulator: rows of absent slots are left alone */
             if (nbr_idx) nbr_idx[i * K + k] = k < cnt ? ids[k] : -1;
             if (nbr_dist) nbr_dist[i * K + k] = k < cnt ? (float)ds[k] : 0.0f;
         }
@@ -628,7 +632,7 @@ int oracle_neighbours(const float* pos, const uint8_t* present, const float* rew
         neighbours_env(px, py, present + (size_t)e * N, rew ? rew + (size_t)e * N : NULL, N, K, radius, mf_distance,
                        nbr_idx ? nbr_idx + (size_t)e * N * K : NULL, nbr_cnt ? nbr_cnt + (size_t)e * N : NULL,
                        mf_cnt ? mf_cnt + (size_t)e * N : NULL, nbr_dist ? nbr_dist + (size_t)e * N * K : NULL,
-                       (rew && nei_rew) ? nei_rew + (size_t)e * N : NULL, (rew && glob_rew) ? glob_rew + e : NULL, NULL, NULL);
+                       (rew && nei_rew) ? nei_rew + (size_t)e * N : NULL, (rew && glob_rew) ? glob_rew + e : NULL, NULL, NULL, 0);
     }
     return COPO_OK;
 }
@@ -644,7 +648,7 @@ int oracle_obs_extensions(const float* pos, const float* cs_sn, const uint8_t* p
     static int ids[COPO_MAX_AGENTS][COPO_MAX_AGENTS];
     int cnt[COPO_MAX_AGENTS];
     for (int i = 0; i < N; ++i) { px[i] = pos[2 * i]; py[i] = pos[2 * i + 1]; }
-    neighbours_env(px, py, present, NULL, N, 1, radius, 10.0f, NULL, NULL, NULL, NULL, NULL, NULL, ids, cnt);
+    neighbours_env(px, py, present, NULL, N, 1, radius, 10.0f, NULL, NULL, NULL, NULL, NULL, NULL, ids, cnt, 0);
     copo_sim_cfg c;
     memset(&c, 0, sizeof(c));
     c.traffic_light_interval = interval;
@@ -668,7 +672,7 @@ static void emit_outputs(oracle_sim* s, int e, const copo_step_out* out, step_tm
     neighbours_env(FP(s, S_X, e), FP(s, S_Y, e), present, t->rew, N, K, c->neighbours_distance, c->mf_distance,
                    out->nbr_idx ? out->nbr_idx + b * K : NULL, out->nbr_cnt ? out->nbr_cnt + b : NULL,
                    out->mf_cnt ? out->mf_cnt + b : NULL, out->nbr_dist ? out->nbr_dist + b * K : NULL,
-                   out->nei_rew ? out->nei_rew + b : NULL, out->glob_rew ? out->glob_rew + e : NULL, t->nb_ids, t->nb_cnt);
+                   out->nei_rew ? out->nei_rew + b : NULL, out->glob_rew ? out->glob_rew + e : NULL, t->nb_ids, t->nb_cnt, 1);
     for (int n = 0; n < N; ++n) {
         if (out->rew) out->rew[b + n] = t->rew[n];
         if (out->flags) out->flags[b + n] = t->fl[n];
@@ -692,6 +696,7 @@ int oracle_sim_reset(oracle_sim* s, const uint64_t* seeds, const copo_step_out* 
         uint8_t present[COPO_MAX_AGENTS];
         for (int n = 0; n < N; ++n) {
             present[n] = n < oracle_capacity(s);
+            if (present[n]) road_heading(s, e, n, &t.cs[n], &t.sn[n]);
             t.fl[n] = present[n] ? COPO_F_SPAWNED : 0;
             t.lcf_row[n] = FP(s, S_LCF, e)[n];
             t.aid_row[n] = IP(s, S_AID, e)[n];
@@ -751,17 +756,29 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
             if (brake > c->brake_max) brake = c->brake_max;
             float x = X[n], y = Y[n], th = TH[n], v = V[n];
             float v0 = v, th0 = th;
+            /* heading unit vector: one sincos per step, then turned by every sub-step's small angle with a 3-term sine /
+             * 3-term cosine (|dth| <= 0.05 rad: error < 1e-11); the vector after the last sub-step is the pose's heading
+             * vector for the rest of the step (collision, LiDAR, observation) */
+            float sn, cs;
+            o_sincosf(th, &sn, &cs);
             for (int k = 0; k < c->substeps; ++k) {
                 float a = a1 >= 0.0f ? (v < c->max_speed ? a1 * c->acc_max : 0.0f) : -brake;
                 v = v + a * h;
                 if (v < 0.0f) v = 0.0f;
-                float sn, cs;
-                o_sincosf(th, &sn, &cs);
                 float dxh = cs * cb - sn * sb, dyh = sn * cb + cs * sb;
                 x = x + v * dxh * h;
                 y = y + v * dyh * h;
-                th = o_wrap_pi(th + v * yawk * h);
+                float dth = v * yawk * h;
+                float q = dth * dth;
+                float sd2 = dth - dth * q * (0.166666667f - q * 0.00833333333f);
+                float cd2 = 1.0f - q * (0.5f - q * 0.0416666667f);
+                float cn = cs * cd2 - sn * sd2, sm = sn * cd2 + cs * sd2;
+                cs = cn;
+                sn = sm;
+                th = o_wrap_pi(th + dth);
             }
+            t.cs[n] = cs;
+            t.sn[n] = sn;
             X[n] = x; Y[n] = y; TH[n] = th; V[n] = v;
             FP(s, S_PSTEER, e)[n] = FP(s, S_STEER, e)[n];
             FP(s, S_PTHROTTLE, e)[n] = FP(s, S_THROTTLE, e)[n];
@@ -771,8 +788,9 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
             t.acc[n] = (v - v0) * s->inv_dt;
             STA[n] = ST_PACK(ST_ALIVE, 0, ST_AGE(STA[n]) + 1);
         }
-        /* 2. heading unit vectors of all slots */
-        for (int n = 0; n < N; ++n) o_sincosf(TH[n], &t.sn[n], &t.cs[n]);
+        /* 2. heading unit vectors of the slots that did not act (wrecks; empty slots are never read) */
+        for (int n = 0; n < N; ++n)
+            if (!t.acted[n]) o_sincosf(TH[n], &t.sn[n], &t.cs[n]);
         int ending = (env[0] + 1 >= c->horizon);
         /* 3-5. collision, route projection, termination, reward */
         uint8_t term[COPO_MAX_AGENTS];
@@ -905,7 +923,7 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
                     if ((freem >> q) & 1u) { if (pick == 0) break; --pick; }
                 used |= 1u << q;
                 spawn_agent(s, e, n, s->safe_ids[q]);
-                o_sincosf(TH[n], &t.sn[n], &t.cs[n]);
+                road_heading(s, e, n, &t.cs[n], &t.sn[n]);
                 present[n] = 1;
                 t.newly[n] = 1;
                 t.fl[n] = COPO_F_SPAWNED;
@@ -921,6 +939,7 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
             reset_env(s, e);
             for (int n = 0; n < N; ++n) {
                 present[n] = n < oracle_capacity(s);
+                if (present[n]) road_heading(s, e, n, &t.cs[n], &t.sn[n]);
                 if (out->flags) out->flags[(size_t)e * N + n] |= (present[n] ? COPO_F_SPAWNED : 0) | COPO_F_ENV_RESET;
                 if (out->lcf && !t.acted[n] && present[n]) out->lcf[(size_t)e * N + n] = FP(s, S_LCF, e)[n];
             }

@@ -108,8 +108,11 @@ def test_state_roundtrip_and_determinism():
         out = g.step(a)
         present = (out["flags"] & 0x41) != 0          # rows of slots without an agent are not written (copo_step_out.obs)
         for k, v in r.items():
-            if k == "obs":
+            if k == "obs":                     # rows of absent slots are not written (copo_step_out)
                 assert torch.equal(out[k][present], v[present]), k
+            elif k == "nbr_idx":               # ... and the lists are those of the scene BEFORE a horizon reset
+                before = ((out["flags"] & 0x01) != 0) | (((out["flags"] & 0x40) != 0) & ((out["flags"] & 0x80) == 0))
+                assert torch.equal(out[k][before], v[before]), k
             else:
                 assert torch.equal(out[k], v), k
 
@@ -307,6 +310,9 @@ def test_full_size_configs_on_sampled_scenes(name, map_name, N, E, lasers, steps
             x, y = go[k], go2[k]
             if k == "obs":                     # rows of absent slots are not written (copo_hip.h)
                 x, y = x[present], y[present]
+            elif k in ("nbr_idx", "nbr_dist"):  # ... the neighbour lists are those of the scene before a horizon reset
+                before = ((go["flags"] & 0x01) != 0) | (((go["flags"] & 0x40) != 0) & ((go["flags"] & 0x80) == 0))
+                x, y = x[before], y[before]
             assert torch.equal(x.view(torch.uint8) if x.dtype != torch.float32 else x.view(torch.int32),
                                y.view(torch.uint8) if y.dtype != torch.float32 else y.view(torch.int32)), (name, t, k)
     for s in (g, g2, o):
