@@ -53,8 +53,9 @@ static int upload(copo_sim* s, const T* host, size_t count, const T** dev) {
     return COPO_OK;
 }
 
-// measured (scripts/bench_sim.py, 40 slots): one scene per CU or fewer -> 16 waves per scene; two per CU -> 8; beyond -> 4
-static int pick_block(int E) { return E <= 256 ? 1024 : (E <= 512 ? 512 : 256); }
+// measured (scripts/bench_sim.py, 40 slots): up to one scene per CU -> 16 waves per scene; two per CU -> 8; then 4; from
+// ~32 scenes per CU on, ONE wave per scene with the small LDS footprint (sim_shape_params): ~20 scenes resident per CU
+static int pick_block(int E) { return E <= 256 ? 1024 : (E <= 512 ? 512 : (E < 8192 ? 256 : 64)); }
 
 extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** out) {
     if (!cfg || !out) return fail(COPO_ERR_NULL, "copo_sim_create: cfg/out is NULL");
@@ -202,6 +203,7 @@ extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** o
     if (rc == COPO_OK && p.n_lines) rc = upload(s, cfg->lines, (size_t)cfg->n_lines * COPO_LINE_STRIDE, &p.lines);
     if (rc == COPO_OK && cfg->side_lasers) rc = upload(s, cfg->side_cs, (size_t)cfg->side_lasers * 2, &p.side_cs);
     if (rc == COPO_OK && cfg->lane_line_lasers) rc = upload(s, cfg->lane_line_cs, (size_t)cfg->lane_line_lasers * 2, &p.lane_cs);
+    sim_shape_params(p, s->block);
     if (rc == COPO_OK) {
         const SimParams* pd = nullptr;
         rc = upload(s, &s->p, 1, &pd);
@@ -284,7 +286,13 @@ extern "C" int copo_sim_set_block(copo_sim* s, int32_t threads) {
     if (threads == 0) threads = pick_block(s->p.E);
     if (threads != 64 && threads != 128 && threads != 256 && threads != 512 && threads != 1024)
         return fail(COPO_ERR_DIM, "block=%d must be 64/128/256/512/1024", threads);
-    s->block = threads;
+    if (threads != s->block) {
+        s->block = threads;
+        sim_shape_params(s->p, threads);
+        HIP_TRY(hipSetDevice(s->device));
+        HIP_TRY(hipDeviceSynchronize());         // launches in flight keep the shape they started with
+        HIP_TRY(hipMemcpy(s->p_dev, &s->p, sizeof(SimParams), hipMemcpyHostToDevice));
+    }
     return COPO_OK;
 }
 

@@ -17,6 +17,8 @@ enum : uint32_t { RNG_ROUTE = 1, RNG_LCF1 = 2, RNG_LCF2 = 3, RNG_SPAWN = 4, RNG_
 struct SimParams {
     int32_t E, N, O, K, num_lasers, enable_lcf, horizon, delay_done, respawn_cooldown, substeps;
     int32_t n_routes, n_spawns, n_safe, n_lines;
+    int32_t chunk;                 // present agents whose neighbour lists / LiDAR fans are in LDS at a time (launch shape: sim_shape_params)
+    int32_t stage_tables;          // 1: the step kernel copies the route / spawn tables to LDS (launch shape)
     int32_t seg_rows;              // road records per route in the DEVICE copy of route_segs: longest route + 1 (compacted at create)
     int32_t side_lasers, lane_lasers, navi_dim, toll_dim, toll_min_steps;
     int32_t lists_for_absent;      // 1: nbr_idx / nbr_dist rows of absent slots are filled with -1 / 0 (the stateless op); 0: left alone
@@ -50,6 +52,7 @@ struct SimParams {
 
 using StepOut = copo_step_out;
 
+void sim_shape_params(SimParams& p, int block);
 // p: host copy (launch shape), p_dev: the same block in device memory (what the kernels read)
 hipError_t launch_sim_reset(const SimParams& p, const SimParams* p_dev, const StepOut& out, int block, hipStream_t stream);
 hipError_t launch_sim_step(const SimParams& p, const SimParams* p_dev, const float* act, const StepOut& out, int block, hipStream_t stream);

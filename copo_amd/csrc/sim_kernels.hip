@@ -159,21 +159,23 @@ constexpr int ROUTE_LDS_MAX_BYTES = 16 * 1024;
 // dynamic LDS: [slots][rays] LiDAR minima, then the route-table copy
 // (the neighbour phase borrows it for its [slots][slots] list-order rewards and a reset for its spawn permutation);
 // then the ray direction table, then the route-table copy
-// neighbour phase: list distances (fp64) [N][N] -- later reused for the rewards in list order --, list slots (u8) [N][N],
-// ranks (u8) [N][N], entry directory (u16) [N*N]
-__device__ __host__ inline int nbr_lds_words(int n_agents) { return 3 * n_agents * n_agents + 4; }
-__device__ __host__ inline int lidar_lds_words(int n_agents, int n_lasers) {
-    const int a = n_agents * n_lasers, b = nbr_lds_words(n_agents) > n_agents * n_agents + COPO_MAX_SPAWNS / 2 ? nbr_lds_words(n_agents) : n_agents * n_agents + COPO_MAX_SPAWNS / 2;
+// Work areas in dynamic LDS are sized for a CHUNK of `ch` present agents (p.chunk: all N slots when several waves share a
+// scene, 8 when one wave owns it -- the per-scene footprint decides how many scenes a compute unit holds):
+// neighbour phase: list distances (fp64) [ch][N] -- later reused for the rewards in list order --, list slots (u8) [ch][N],
+// ranks (u8) [ch][N], entry directory (u16) [ch*N]; then the spawn permutation of a reset (int16 [COPO_MAX_SPAWNS])
+__device__ __host__ inline int nbr_lds_words(int ch, int n_agents) { return 3 * ch * n_agents + 4; }
+__device__ __host__ inline int lidar_lds_words(int ch, int n_agents, int n_lasers) {
+    const int a = ch * n_lasers, b = nbr_lds_words(ch, n_agents) + COPO_MAX_SPAWNS / 2;
     return ((a > b ? a : b) + 3) & ~3;
 }
 __device__ __host__ inline int ray_lds_words(int n_lasers) { return (2 * n_lasers + 3) & ~3; }
 __device__ __forceinline__ float* lds_rays(const SimParams& p) {
     extern __shared__ unsigned int dyn[];
-    return reinterpret_cast<float*>(dyn + lidar_lds_words(p.N, p.num_lasers));
+    return reinterpret_cast<float*>(dyn + lidar_lds_words(p.chunk, p.N, p.num_lasers));
 }
 __device__ __forceinline__ int16_t* lds_perm(const SimParams& p) {
     extern __shared__ unsigned int dyn[];
-    return reinterpret_cast<int16_t*>(dyn + p.N * p.N);
+    return reinterpret_cast<int16_t*>(dyn + nbr_lds_words(p.chunk, p.N));
 }
 __device__ __host__ inline int route_table_floats(int n_routes, int seg_rows) {
     return n_routes * (seg_rows * COPO_SEG_STRIDE + 4);
@@ -249,127 +251,145 @@ __device__ __forceinline__ void neighbours_phase(const SimParams& p, EnvLds& L, 
     const int np = __popcll(present);
     const size_t base = (size_t)e * N;
     const double R = (double)p.neighbours_distance, M = (double)p.mf_distance;
-    double* nb_d = reinterpret_cast<double*>(dyn);                       // [N][N]
-    float* srt = reinterpret_cast<float*>(dyn);                          // [N][N], after the ranks are known
-    uint8_t* nb_j = reinterpret_cast<uint8_t*>(dyn + 2 * N * N);          // [N][N]
-    uint8_t* nb_rk = nb_j + N * N;                                        // [N][N]
-    uint16_t* ent = reinterpret_cast<uint16_t*>(dyn + 2 * N * N + (N * N) / 2 + 2);   // [N*N]: ia << 8 | pos
-    // ---- 1. candidate pairs -------------------------------------------------------------------------------------
-    {
-        const int npair = np * np;
-        const float inv_np = 1.0f / (float)(np > 0 ? np : 1);
-        const float r2hi = p.neighbours_distance * p.neighbours_distance * 1.00001f;   // fp32 d^2 errs by < 2e-7 relative
-        for (int c0 = wave * 64; c0 < npair; c0 += nwaves * 64) {
-            const int c = c0 + lane;
-            const bool live = c < npair;
-            const int ib = live ? (int)(((float)c + 0.5f) * inv_np) : 0;
-            const int ia = live ? c - ib * np : 0;                        // consecutive lanes: consecutive LISTS (no counter clash)
-            const int i = L.plist[ia], j = L.plist[ib];
-            const float xi = L.x[i], yi = L.y[i], xj = L.x[j], yj = L.y[j];
-            const float fx = xi - xj, fy = yi - yj;
-            bool inr = false;
-            double d = 0.0;
-            if (live && i != j && fx * fx + fy * fy < r2hi) {
-                const double dx = (double)xi - (double)xj, dy = (double)yi - (double)yj;
-                d = sqrt(dx * dx + dy * dy);
-                inr = d < R;
-            }
-            const unsigned long long m = __ballot(inr);
-            if (m) {
-                unsigned int e0 = 0;
-                if (lane == 0) e0 = atomicAdd(&L.n_entries, (unsigned int)__popcll(m));
-                e0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)e0);
-                if (inr) {
-                    const unsigned int pos = atomicAdd(&L.ncnt[i], 1u);
-                    if (d <= M) atomicAdd(&L.mfc[i], 1u);
-                    nb_d[i * N + pos] = d;
-                    nb_j[i * N + pos] = (uint8_t)j;
-                    ent[e0 + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((ia << 8) | pos);
-                }
-            }
-        }
-        if (wave == nwaves - 1 && out.glob_rew) {  // LCFEnv.step: sum(r.values()) / len(r.values()) in slot order, fp64
-            double gs = 0.0;
-            unsigned long long m = present;
-            while (m) {
-                const int j = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                gs += (double)L.rew[j];
-            }
-            if (lane == 0) out.glob_rew[e] = np ? (float)(gs / (double)np) : 0.0f;
-        }
-    }
-    __syncthreads();
-    // ---- 2. ranks, first K entries of every list ------------------------------------------------------------------
-    const int T = (int)L.n_entries;
-    for (int q = tid; q < T; q += nthreads) {
-        const unsigned int pk = ent[q];
-        const int i = L.plist[pk >> 8], pos = (int)(pk & 255u);
-        const int cnt = (int)L.ncnt[i];
-        const double d = nb_d[i * N + pos];
-        const int j = nb_j[i * N + pos];
-        int rank = 0;
-        for (int k = 0; k < cnt; ++k) {
-            const double dk = nb_d[i * N + k];
-            const int jk = nb_j[i * N + k];
-            rank += (dk < d || (dk == d && jk < j)) ? 1 : 0;
-        }
-        nb_rk[i * N + pos] = (uint8_t)rank;
-        if (rank < K) {
-            if (out.nbr_idx) out.nbr_idx[(base + i) * K + rank] = j;
-            if (out.nbr_dist) out.nbr_dist[(base + i) * K + rank] = (float)d;
-        }
-        if (comm && rank < p.comm_nb) {
-            float* qm = out.obs + (base + i) * p.O + p.col_comm + rank * CD;
-            const bool spoke = !fresh && ((acted_mask >> j) & 1ull) && act != nullptr;
-            for (int k = 0; k < CS; ++k) qm[k] = spoke ? act[(base + j) * p.act_dim + 2 + k] : 0.0f;
-            if (p.comm_pos) {
-                float ex[3] = {0.0f, 0.0f, 0.0f};
-                if (spoke) {   // neighbour relative to ego in the ego frame, float64 like the reference's numpy
-                    const double ci = (double)L.cs[i], si = (double)L.sn[i];
-                    const double dx = (double)L.x[j] - (double)L.x[i], dy = (double)L.y[j] - (double)L.y[i];
-                    const double lon = dx * ci + dy * si, lat = dy * ci - dx * si;
-                    const double dis = sqrt(lon * lon + lat * lat);
-                    const double v[3] = {dis / 20.0, (lon / dis + 1.0) / 2.0, (lat / dis + 1.0) / 2.0};   // 0/0 = NaN for d == 0, as numpy
-#pragma unroll
-                    for (int k = 0; k < 3; ++k)
-                        ex[k] = v[k] != v[k] ? __uint_as_float(0x7fc00000u) : (float)(v[k] < 0.0 ? 0.0 : (v[k] > 1.0 ? 1.0 : v[k]));
-                }
-                qm[CS] = ex[0]; qm[CS + 1] = ex[1]; qm[CS + 2] = ex[2];
-            }
-        }
-    }
-    __syncthreads();       // every read of the fp64 distances is done: their storage now takes the rewards in list order
-    // ---- 3. rewards in list order, per-agent tails ----------------------------------------------------------------
-    if (out.nei_rew)
-        for (int q = tid; q < T; q += nthreads) {
-            const unsigned int pk = ent[q];
-            const int i = L.plist[pk >> 8], pos = (int)(pk & 255u);
-            srt[i * N + nb_rk[i * N + pos]] = L.rew[nb_j[i * N + pos]];
-        }
-    __syncthreads();
-    // one lane per slot, on a wave that the caller's next (wave 0) phase does not need
-    if (wave == (nwaves > 1 ? 1 : 0) && lane < N) {
-        const bool pi = (present >> lane) & 1ull;
-        const int cnt = pi ? (int)L.ncnt[lane] : 0;
-        if (out.nbr_cnt) out.nbr_cnt[base + lane] = cnt;
-        if (out.mf_cnt) out.mf_cnt[base + lane] = pi ? (int)L.mfc[lane] : 0;
-        if (out.nei_rew) {
-            double nsum = 0.0;
-            for (int r = 0; r < cnt; ++r) nsum += (double)srt[lane * N + r];
-            out.nei_rew[base + lane] = cnt ? (float)(nsum / (double)cnt) : 0.0f;
-        }
-        if (pi || p.lists_for_absent) {    // (the stateless op fills the rows of absent slots too)
-            for (int k = cnt; k < K; ++k) {
+    const int CH = p.chunk > 0 ? p.chunk : N;                            // present agents whose lists are in LDS at a time
+    double* nb_d = reinterpret_cast<double*>(dyn);                       // [CH][N]
+    float* srt = reinterpret_cast<float*>(dyn);                          // [CH][N], after the ranks are known
+    uint8_t* nb_j = reinterpret_cast<uint8_t*>(dyn + 2 * CH * N);         // [CH][N]
+    uint8_t* nb_rk = nb_j + CH * N;                                       // [CH][N]
+    uint16_t* ent = reinterpret_cast<uint16_t*>(dyn + 2 * CH * N + (CH * N) / 2 + 2);   // [CH*N]: local list << 8 | pos
+    const int tail_wave = nwaves > 1 ? 1 : 0;       // per-slot tails run on a wave that the caller's next (wave 0) phase does not need
+    // slots without an agent: empty lists (counts and reward only; their nbr_idx / nbr_dist rows are not written)
+    if (wave == tail_wave && lane < N && !((present >> lane) & 1ull)) {
+        if (out.nbr_cnt) out.nbr_cnt[base + lane] = 0;
+        if (out.mf_cnt) out.mf_cnt[base + lane] = 0;
+        if (out.nei_rew) out.nei_rew[base + lane] = 0.0f;
+        if (p.lists_for_absent)      // (the stateless op fills these rows too)
+            for (int k = 0; k < K; ++k) {
                 if (out.nbr_idx) out.nbr_idx[(base + lane) * K + k] = -1;
                 if (out.nbr_dist) out.nbr_dist[(base + lane) * K + k] = 0.0f;
             }
-            if (comm && pi)
-                for (int r = cnt; r < p.comm_nb; ++r) {
-                    float* qm = out.obs + (base + lane) * p.O + p.col_comm + r * CD;
-                    for (int k = 0; k < CD; ++k) qm[k] = 0.0f;
-                }
+    }
+    if (wave == nwaves - 1 && out.glob_rew) {  // LCFEnv.step: sum(r.values()) / len(r.values()) in slot order, fp64
+        double gs = 0.0;
+        unsigned long long m = present;
+        while (m) {
+            const int j = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            gs += (double)L.rew[j];
         }
+        if (lane == 0) out.glob_rew[e] = np ? (float)(gs / (double)np) : 0.0f;
+    }
+    const float r2hi = p.neighbours_distance * p.neighbours_distance * 1.00001f;   // fp32 d^2 errs by < 2e-7 relative
+    for (int ia0 = 0; ia0 < np; ia0 += CH) {
+        const int cha = np - ia0 < CH ? np - ia0 : CH;                   // lists of this pass: present agents ia0 .. ia0 + cha - 1
+        // ---- 1. candidate pairs -------------------------------------------------------------------------------------
+        {
+            const int npair = cha * np;
+            const float inv_cha = 1.0f / (float)cha;
+            for (int c0 = wave * 64; c0 < npair; c0 += nwaves * 64) {
+                const int c = c0 + lane;
+                const bool live = c < npair;
+                const int ib = live ? (int)(((float)c + 0.5f) * inv_cha) : 0;
+                const int la = live ? c - ib * cha : 0;                   // consecutive lanes: consecutive LISTS (no counter clash)
+                const int i = L.plist[ia0 + la], j = L.plist[ib];
+                const float xi = L.x[i], yi = L.y[i], xj = L.x[j], yj = L.y[j];
+                const float fx = xi - xj, fy = yi - yj;
+                bool inr = false;
+                double d = 0.0;
+                if (live && i != j && fx * fx + fy * fy < r2hi) {
+                    const double dx = (double)xi - (double)xj, dy = (double)yi - (double)yj;
+                    d = sqrt(dx * dx + dy * dy);
+                    inr = d < R;
+                }
+                const unsigned long long m = __ballot(inr);
+                if (m) {
+                    unsigned int e0 = 0;
+                    if (lane == 0) e0 = atomicAdd(&L.n_entries, (unsigned int)__popcll(m));
+                    e0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)e0);
+                    if (inr) {
+                        const unsigned int pos = atomicAdd(&L.ncnt[i], 1u);
+                        if (d <= M) atomicAdd(&L.mfc[i], 1u);
+                        nb_d[la * N + pos] = d;
+                        nb_j[la * N + pos] = (uint8_t)j;
+                        ent[e0 + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((la << 8) | pos);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- 2. ranks, first K entries of every list ------------------------------------------------------------------
+        const int T = (int)L.n_entries;
+        for (int q = tid; q < T; q += nthreads) {
+            const unsigned int pk = ent[q];
+            const int la = (int)(pk >> 8), pos = (int)(pk & 255u);
+            const int i = L.plist[ia0 + la];
+            const int cnt = (int)L.ncnt[i];
+            const double d = nb_d[la * N + pos];
+            const int j = nb_j[la * N + pos];
+            int rank = 0;
+            for (int k = 0; k < cnt; ++k) {
+                const double dk = nb_d[la * N + k];
+                const int jk = nb_j[la * N + k];
+                rank += (dk < d || (dk == d && jk < j)) ? 1 : 0;
+            }
+            nb_rk[la * N + pos] = (uint8_t)rank;
+            if (rank < K) {
+                if (out.nbr_idx) out.nbr_idx[(base + i) * K + rank] = j;
+                if (out.nbr_dist) out.nbr_dist[(base + i) * K + rank] = (float)d;
+            }
+            if (comm && rank < p.comm_nb) {
+                float* qm = out.obs + (base + i) * p.O + p.col_comm + rank * CD;
+                const bool spoke = !fresh && ((acted_mask >> j) & 1ull) && act != nullptr;
+                for (int k = 0; k < CS; ++k) qm[k] = spoke ? act[(base + j) * p.act_dim + 2 + k] : 0.0f;
+                if (p.comm_pos) {
+                    float ex[3] = {0.0f, 0.0f, 0.0f};
+                    if (spoke) {   // neighbour relative to ego in the ego frame, float64 like the reference's numpy
+                        const double ci = (double)L.cs[i], si = (double)L.sn[i];
+                        const double dx = (double)L.x[j] - (double)L.x[i], dy = (double)L.y[j] - (double)L.y[i];
+                        const double lon = dx * ci + dy * si, lat = dy * ci - dx * si;
+                        const double dis = sqrt(lon * lon + lat * lat);
+                        const double v[3] = {dis / 20.0, (lon / dis + 1.0) / 2.0, (lat / dis + 1.0) / 2.0};   // 0/0 = NaN for d == 0, as numpy
+#pragma unroll
+                        for (int k = 0; k < 3; ++k)
+                            ex[k] = v[k] != v[k] ? __uint_as_float(0x7fc00000u) : (float)(v[k] < 0.0 ? 0.0 : (v[k] > 1.0 ? 1.0 : v[k]));
+                    }
+                    qm[CS] = ex[0]; qm[CS + 1] = ex[1]; qm[CS + 2] = ex[2];
+                }
+            }
+        }
+        __syncthreads();       // every read of the fp64 distances is done: their storage now takes the rewards in list order
+        // ---- 3. rewards in list order, per-agent tails ----------------------------------------------------------------
+        if (out.nei_rew)
+            for (int q = tid; q < T; q += nthreads) {
+                const unsigned int pk = ent[q];
+                const int la = (int)(pk >> 8), pos = (int)(pk & 255u);
+                srt[la * N + nb_rk[la * N + pos]] = L.rew[nb_j[la * N + pos]];
+            }
+        __syncthreads();
+        if (wave == tail_wave) {       // one lane per list of this pass
+            if (lane < cha) {
+                const int i = L.plist[ia0 + lane];
+                const int cnt = (int)L.ncnt[i];
+                if (out.nbr_cnt) out.nbr_cnt[base + i] = cnt;
+                if (out.mf_cnt) out.mf_cnt[base + i] = (int)L.mfc[i];
+                if (out.nei_rew) {
+                    double nsum = 0.0;
+                    for (int r = 0; r < cnt; ++r) nsum += (double)srt[lane * N + r];
+                    out.nei_rew[base + i] = cnt ? (float)(nsum / (double)cnt) : 0.0f;
+                }
+                for (int k = cnt; k < K; ++k) {
+                    if (out.nbr_idx) out.nbr_idx[(base + i) * K + k] = -1;
+                    if (out.nbr_dist) out.nbr_dist[(base + i) * K + k] = 0.0f;
+                }
+                if (comm)
+                    for (int r = cnt; r < p.comm_nb; ++r) {
+                        float* qm = out.obs + (base + i) * p.O + p.col_comm + r * CD;
+                        for (int k = 0; k < CD; ++k) qm[k] = 0.0f;
+                    }
+            }
+            if (lane == 0) L.n_entries = 0;
+        }
+        if (ia0 + CH < np) __syncthreads();     // the next pass reuses the list storage (and the entry counter)
     }
 }
 
@@ -567,21 +587,27 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
     const float lim = range + circ;
     const unsigned long long solid = L.m_solid, present = L.m_present;
     const int np = __popcll(present), ns = __popcll(solid);
-    unsigned int* best = dyn;                     // [np][NL] nearest entry distance (float bits) per ray
+    unsigned int* best = dyn;                     // [chunk][NL] nearest entry distance (float bits) per ray
     const unsigned int range_bits = __float_as_uint(range);
-    for (int q = tid; q < np * NL; q += nthreads) best[q] = range_bits;
     float* eobs = obs + (size_t)e * N * O;
     const float* __restrict__ rays = lds_rays(p);
-    int* wtag = reinterpret_cast<int*>(dyn + lidar_lds_words(p.N, p.num_lasers) + ray_lds_words(p.num_lasers)) + wave * 64;
-    __syncthreads();
-    const int ncombo = np * ns;
+    int* wtag = reinterpret_cast<int*>(dyn + lidar_lds_words(p.chunk, p.N, p.num_lasers) + ray_lds_words(p.num_lasers)) + wave * 64;
+    const int CH = p.chunk > 0 ? p.chunk : N;     // present agents whose ray fans are in LDS at a time
     const float inv_ns = 1.0f / (float)(ns > 0 ? ns : 1);
     const float rays_per_rad = (float)NL * 0.159154943f;
+    const float inv_nl = 1.0f / (float)NL;
+    const float inv_range = p.inv_range;
+    const int col_lidar = p.col_lidar;
+    for (int ip0 = 0; ip0 < np; ip0 += CH) {
+    const int cha = np - ip0 < CH ? np - ip0 : CH;
+    for (int q = tid; q < cha * NL; q += nthreads) best[q] = range_bits;
+    __syncthreads();
+    const int ncombo = cha * ns;
     for (int c0 = wave * 64; c0 < ((COPO_PROFILE_SKIP & 2) ? 0 : ncombo); c0 += nwaves * 64) {
         const int c = c0 + lane;
         const bool live = c < ncombo;
-        const int ip = live ? (int)(((float)c + 0.5f) * inv_ns) : 0;
-        const int i = L.plist[ip], j = L.slist[live ? c - ip * ns : 0];
+        const int lp = live ? (int)(((float)c + 0.5f) * inv_ns) : 0;      // fan of this pass
+        const int i = L.plist[ip0 + lp], j = L.slist[live ? c - lp * ns : 0];
         const float dx = L.x[j] - L.x[i], dy = L.y[j] - L.y[i];
         const float d2 = dx * dx + dy * dy;
         int klo = 0, cnt = 0;
@@ -591,16 +617,25 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
             } else {
                 const float ci = L.cs[i], si = L.sn[i];
                 const float phi = p.ray_sign * atan2_window(ci * dy - si * dx, ci * dx + si * dy);   // in beam-index direction
-                const float x = circ * __builtin_amdgcn_rsqf(d2);
-                const float w = x + 0.5708f * x * x * x + 0.004f;     // >= asin(x) + margin
+                const float rd = __builtin_amdgcn_rsqf(d2);
+                const float x = circ * rd;
+                float w = x + 0.5708f * x * x * x;                    // >= asin(circumradius / distance)
+                // tighter for a box seen from outside its own length: every point of it lies at least d - h_par along the
+                // line of sight and at most h_perp beside it (extents of the box along / across that line), so the
+                // half-angle is below h_perp / (d - h_par) -- a vehicle seen end-on is 0.93 m wide, not 2.44
+                const float ux = dx * rd, uy = dy * rd, cj = L.cs[j], sj = L.sn[j];
+                const float ca = fabsf(cj * ux + sj * uy), sa = fabsf(cj * uy - sj * ux);
+                const float h_perp = hl * sa + hw * ca, along = d2 * rd - (hl * ca + hw * sa);
+                if (along > 0.5f) w = fminf(w, h_perp * __builtin_amdgcn_rcpf(along) * 1.0001f);
+                w += 0.004f;                                          // margin over the approximations above (< 1e-4 rad)
                 const int lo = (int)ceilf((phi - w) * rays_per_rad), hi = (int)floorf((phi + w) * rays_per_rad);
                 cnt = hi - lo + 1;
                 cnt = cnt < 0 ? 0 : (cnt > NL ? NL : cnt);
                 klo = lo < 0 ? lo + NL : lo;
             }
         }
-        // j: 6 bits, klo: 8 (< 256 rays), cnt: 9 (up to 256), ip: 6
-        const unsigned int pk = (unsigned int)j | ((unsigned int)klo << 6) | ((unsigned int)cnt << 14) | ((unsigned int)ip << 23);
+        // j: 6 bits, klo: 8 (< 256 rays), cnt: 9 (up to 256), local fan: 6
+        const unsigned int pk = (unsigned int)j | ((unsigned int)klo << 6) | ((unsigned int)cnt << 14) | ((unsigned int)lp << 23);
         const int incl = wave_scan_incl<false>(cnt);      // inclusive scan of the window sizes
         const int total = __builtin_amdgcn_readlane(incl, 63);
         const int excl = incl - cnt;                      // index of this pair's first box test
@@ -623,25 +658,24 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
             const unsigned int spk = (unsigned int)__shfl((int)pk, sl);
             const int sincl = __shfl(incl, sl);
             if (t < total) {
-                const int sj = (int)(spk & 63u), scnt = (int)((spk >> 14) & 511u), sip = (int)(spk >> 23);
+                const int sj = (int)(spk & 63u), scnt = (int)((spk >> 14) & 511u), slp = (int)(spk >> 23);
                 int k = (int)((spk >> 6) & 255u) + (t - (sincl - scnt));
                 if (k >= NL) k -= NL;
-                const int si_ = L.plist[sip];
+                const int si_ = L.plist[ip0 + slp];
                 const float ci = L.cs[si_], si = L.sn[si_];
                 const float rc = rays[2 * k], rs = rays[2 * k + 1];
                 const float tt = ray_box(L.x[sj] - L.x[si_], L.y[sj] - L.y[si_], ci * rc - si * rs, si * rc + ci * rs, L.cs[sj], L.sn[sj], hl, hw);
-                if (tt >= 0.0f) atomicMin(&best[sip * NL + k], __float_as_uint(tt));
+                if (tt >= 0.0f) atomicMin(&best[slp * NL + k], __float_as_uint(tt));
             }
         }
     }
     __syncthreads();
-    const int nrays = np * NL;                    // rows of present slots only
-    const float inv_nl = 1.0f / (float)NL;
-    const float inv_range = p.inv_range;
-    const int col_lidar = p.col_lidar;
+    const int nrays = cha * NL;                   // rows of present slots only
     for (int q = tid; q < ((COPO_PROFILE_SKIP & 4) ? 0 : nrays); q += nthreads) {
-        const int ip = (int)(((float)q + 0.5f) * inv_nl), k = q - ip * NL;
-        eobs[(int)L.plist[ip] * O + col_lidar + k] = __uint_as_float(best[q]) * inv_range;
+        const int lp = (int)(((float)q + 0.5f) * inv_nl), k = q - lp * NL;
+        eobs[(int)L.plist[ip0 + lp] * O + col_lidar + k] = __uint_as_float(best[q]) * inv_range;
+    }
+    if (ip0 + CH < np) __syncthreads();           // the next pass reuses the minima
     }
     // optional side / lane-line detector beams (Bottleneck, Tollgate): one thread per (present agent, beam)
     const int nb = p.side_lasers + p.lane_lasers;
@@ -684,7 +718,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_reset_kernel(const Sim
     const SimParams& p = *pp;
     __shared__ EnvLds L;
     const int e = blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nwaves = nthreads >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int N = p.N;
     load_rays(p, L, tid, nthreads);
     if (tid == 0) {
@@ -750,8 +784,8 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(const SimP
         extern __shared__ unsigned int dyn[];
         const int nseg_f = p.n_routes * p.seg_rows * COPO_SEG_STRIDE, nmeta_f = p.n_routes * 4;
         const int ntab = p.n_spawns * 4, nsp = p.n_spawns;
-        const bool stage = (nseg_f + nmeta_f) * (int)sizeof(float) <= ROUTE_LDS_MAX_BYTES;
-        float* rl = reinterpret_cast<float*>(dyn + lidar_lds_words(p.N, p.num_lasers) + ray_lds_words(p.num_lasers) + (nthreads >> 6) * 64);
+        const bool stage = p.stage_tables != 0;     // (host: several waves per scene and the tables are small)
+        float* rl = reinterpret_cast<float*>(dyn + lidar_lds_words(p.chunk, p.N, p.num_lasers) + ray_lds_words(p.num_lasers) + (nthreads >> 6) * 64);
         int32_t* tl = reinterpret_cast<int32_t*>(rl + nseg_f + nmeta_f);
         float* sl = reinterpret_cast<float*>(tl + ntab);
         if (stage) {
@@ -1104,7 +1138,7 @@ __global__ void __launch_bounds__(256) neighbours_kernel(const float* __restrict
                                                          const float* __restrict__ rew, SimParams p, StepOut out) {
     __shared__ EnvLds L;
     const int e = blockIdx.x, tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nwaves = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int N = p.N;
     if (wave == 0) {
         bool pr = false;
@@ -1130,7 +1164,7 @@ __global__ void __launch_bounds__(256) neighbours_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 // [slots][rays] minima, ray table, one 64-entry strip per wave (box-test owners)
 static size_t lidar_lds_bytes(const SimParams& p, int block) {
-    return (size_t)(lidar_lds_words(p.N, p.num_lasers) + ray_lds_words(p.num_lasers) + (block / 64) * 64) * sizeof(unsigned int);
+    return (size_t)(lidar_lds_words(p.chunk, p.N, p.num_lasers) + ray_lds_words(p.num_lasers) + (block / 64) * 64) * sizeof(unsigned int);
 }
 static bool sim_has_ext(const SimParams& p) { return p.col_tl >= 0 || p.col_comm >= 0; }
 static hipError_t sim_lds_attrs() {              // 64 slots x 256 rays + route tables exceed the default 64 KB
@@ -1145,9 +1179,15 @@ static hipError_t sim_lds_attrs() {              // 64 slots x 256 rays + route 
     }();
     return once;
 }
-static size_t route_lds_bytes(const SimParams& p) {      // LDS copy of the route tables when they are small
-    const size_t b = (size_t)route_table_floats(p.n_routes, p.seg_rows) * sizeof(float);
-    return b <= (size_t)ROUTE_LDS_MAX_BYTES ? b + (size_t)p.n_spawns * 5 * sizeof(float) : 0;      // + spawn table and offsets
+static size_t route_lds_bytes(const SimParams& p) {      // LDS copy of the route tables (+ spawn table and offsets)
+    return p.stage_tables ? (size_t)route_table_floats(p.n_routes, p.seg_rows) * sizeof(float) + (size_t)p.n_spawns * 5 * sizeof(float) : 0;
+}
+// Launch shape -> the two fields of the parameter block that depend on it.  Several waves per scene: everything of a scene
+// at once, route tables in LDS when small.  One wave per scene (large scene counts): work areas for 8 agents at a time and
+// tables from L2, so that a scene needs ~8 KB of LDS and a compute unit holds ~20 of them.
+void sim_shape_params(SimParams& p, int block) {
+    p.chunk = block > 64 ? p.N : (p.N < 8 ? p.N : 8);
+    p.stage_tables = (block > 64 && (size_t)route_table_floats(p.n_routes, p.seg_rows) * sizeof(float) <= (size_t)ROUTE_LDS_MAX_BYTES) ? 1 : 0;
 }
 
 hipError_t launch_sim_reset(const SimParams& p, const SimParams* p_dev, const StepOut& out, int block, hipStream_t stream) {
@@ -1166,7 +1206,7 @@ hipError_t launch_sim_step(const SimParams& p, const SimParams* p_dev, const flo
 
 hipError_t launch_neighbours(const float* pos, const uint8_t* present, const float* rew, const SimParams& p,
                              const StepOut& out, hipStream_t stream) {
-    hipLaunchKernelGGL(neighbours_kernel, dim3(p.E), dim3(256), (size_t)nbr_lds_words(p.N) * sizeof(unsigned int), stream, pos, present, rew, p, out);
+    hipLaunchKernelGGL(neighbours_kernel, dim3(p.E), dim3(256), (size_t)nbr_lds_words(p.N, p.N) * sizeof(unsigned int), stream, pos, present, rew, p, out);
     return hipGetLastError();
 }
 
