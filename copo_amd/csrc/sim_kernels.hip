@@ -169,6 +169,7 @@ __device__ __host__ inline int lidar_lds_words(int ch, int n_agents, int n_laser
     return ((a > b ? a : b) + 3) & ~3;
 }
 __device__ __host__ inline int ray_lds_words(int n_lasers) { return (2 * n_lasers + 3) & ~3; }
+constexpr int LIDAR_WAVE_WORDS = 64;   // per wave: head flags of the box-test batches
 __device__ __forceinline__ float* lds_rays(const SimParams& p) {
     extern __shared__ unsigned int dyn[];
     return reinterpret_cast<float*>(dyn + lidar_lds_words(p.chunk, p.N, p.num_lasers));
@@ -511,12 +512,10 @@ __device__ __forceinline__ float detector_ray(const SimParams& p, const float* _
     return best;
 }
 
-// Ray (origin (x, y), unit direction (dxr, dyr)) against the box of vehicle j: entering distance, or a negative
-// value for a miss.  Box frame mirrored so that the direction is non-negative on both axes; entering / exiting
+// Ray against the box of vehicle j, in j's box frame: entering distance, or a negative value for a miss.  Box frame mirrored so that the direction is non-negative on both axes; entering / exiting
 // times are fractions n/a compared by cross-multiplication, one IEEE division only for an actual hit (spec 3.4-9).
-__device__ __forceinline__ float ray_box(float rx, float ry, float dxr, float dyr, float cj, float sj, float hl, float hw) {
-    const float ox = -(rx * cj + ry * sj), oy = -(ry * cj - rx * sj);
-    const float ddx = dxr * cj + dyr * sj, ddy = dyr * cj - dxr * sj;
+__device__ __forceinline__ float ray_box(float ox, float oy, float ddx, float ddy, float hl, float hw) {
+    // (ox, oy): ray origin, (ddx, ddy): unit direction, both in the box frame of vehicle j
     const float ax = fabsf(ddx), ay = fabsf(ddy);
     const float oxs = ddx < 0.0f ? -ox : ox, oys = ddy < 0.0f ? -oy : oy;
     const float nxe = -(hl + oxs), nxx = hl - oxs, nye = -(hw + oys), nyx = hw - oys;
@@ -591,7 +590,7 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
     const unsigned int range_bits = __float_as_uint(range);
     float* eobs = obs + (size_t)e * N * O;
     const float* __restrict__ rays = lds_rays(p);
-    int* wtag = reinterpret_cast<int*>(dyn + lidar_lds_words(p.chunk, p.N, p.num_lasers) + ray_lds_words(p.num_lasers)) + wave * 64;
+    int* wtag = reinterpret_cast<int*>(dyn + lidar_lds_words(p.chunk, p.N, p.num_lasers) + ray_lds_words(p.num_lasers)) + wave * LIDAR_WAVE_WORDS;   // head flags
     const int CH = p.chunk > 0 ? p.chunk : N;     // present agents whose ray fans are in LDS at a time
     const float inv_ns = 1.0f / (float)(ns > 0 ? ns : 1);
     const float rays_per_rad = (float)NL * 0.159154943f;
@@ -634,11 +633,16 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
                 klo = lo < 0 ? lo + NL : lo;
             }
         }
-        // j: 6 bits, klo: 8 (< 256 rays), cnt: 9 (up to 256), local fan: 6
-        const unsigned int pk = (unsigned int)j | ((unsigned int)klo << 6) | ((unsigned int)cnt << 14) | ((unsigned int)lp << 23);
         const int incl = wave_scan_incl<false>(cnt);      // inclusive scan of the window sizes
         const int total = __builtin_amdgcn_readlane(incl, 63);
         const int excl = incl - cnt;                      // index of this pair's first box test
+        // the pair's record for its box tests (registers of this lane, fetched by the test lanes with ds_bpermute -- no LDS
+        // storage: a strip of records per wave cost more in resident scenes than it saved in instructions): ray origin in
+        // j's box frame, rotation from i's frame into it, first ray / first test (klo - excl: 24 bits signed, local fan: 6)
+        const float ci = L.cs[i], si = L.sn[i], cj = L.cs[j], sj = L.sn[j];
+        const float rec_ox = -(dx * cj + dy * sj), rec_oy = -(dy * cj - dx * sj);
+        const float rec_cr = ci * cj + si * sj, rec_sr = ci * sj - si * cj;
+        const int rec_ix = ((klo - excl) & 0xffffff) | (lp << 24);      // ray of test t = (klo - excl + t) mod NL
         int carry = 0;                                    // (lane + 1) of the pair that owns the last test of the previous batch
         for (int t0 = 0; t0 < total; t0 += 64) {
             const int t = t0 + lane;
@@ -655,16 +659,14 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
             carry = __builtin_amdgcn_readlane(own, 63);
             __builtin_amdgcn_wave_barrier();
             const int sl = own > 0 ? own - 1 : 0;
-            const unsigned int spk = (unsigned int)__shfl((int)pk, sl);
-            const int sincl = __shfl(incl, sl);
+            const float ox = __shfl(rec_ox, sl), oy = __shfl(rec_oy, sl), cr = __shfl(rec_cr, sl), sr = __shfl(rec_sr, sl);
+            const int pw = __shfl(rec_ix, sl);
             if (t < total) {
-                const int sj = (int)(spk & 63u), scnt = (int)((spk >> 14) & 511u), slp = (int)(spk >> 23);
-                int k = (int)((spk >> 6) & 255u) + (t - (sincl - scnt));
+                const int slp = pw >> 24;
+                int k = ((pw << 8) >> 8) + t;              // (klo - excl) is a signed 24-bit field
                 if (k >= NL) k -= NL;
-                const int si_ = L.plist[ip0 + slp];
-                const float ci = L.cs[si_], si = L.sn[si_];
-                const float rc = rays[2 * k], rs = rays[2 * k + 1];
-                const float tt = ray_box(L.x[sj] - L.x[si_], L.y[sj] - L.y[si_], ci * rc - si * rs, si * rc + ci * rs, L.cs[sj], L.sn[sj], hl, hw);
+                const float2 r = reinterpret_cast<const float2*>(rays)[k];
+                const float tt = ray_box(ox, oy, r.x * cr + r.y * sr, r.y * cr - r.x * sr, hl, hw);
                 if (tt >= 0.0f) atomicMin(&best[slp * NL + k], __float_as_uint(tt));
             }
         }
@@ -785,7 +787,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(const SimP
         const int nseg_f = p.n_routes * p.seg_rows * COPO_SEG_STRIDE, nmeta_f = p.n_routes * 4;
         const int ntab = p.n_spawns * 4, nsp = p.n_spawns;
         const bool stage = p.stage_tables != 0;     // (host: several waves per scene and the tables are small)
-        float* rl = reinterpret_cast<float*>(dyn + lidar_lds_words(p.chunk, p.N, p.num_lasers) + ray_lds_words(p.num_lasers) + (nthreads >> 6) * 64);
+        float* rl = reinterpret_cast<float*>(dyn + lidar_lds_words(p.chunk, p.N, p.num_lasers) + ray_lds_words(p.num_lasers) + (nthreads >> 6) * LIDAR_WAVE_WORDS);
         int32_t* tl = reinterpret_cast<int32_t*>(rl + nseg_f + nmeta_f);
         float* sl = reinterpret_cast<float*>(tl + ntab);
         if (stage) {
@@ -1164,7 +1166,7 @@ __global__ void __launch_bounds__(256) neighbours_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 // [slots][rays] minima, ray table, one 64-entry strip per wave (box-test owners)
 static size_t lidar_lds_bytes(const SimParams& p, int block) {
-    return (size_t)(lidar_lds_words(p.chunk, p.N, p.num_lasers) + ray_lds_words(p.num_lasers) + (block / 64) * 64) * sizeof(unsigned int);
+    return (size_t)(lidar_lds_words(p.chunk, p.N, p.num_lasers) + ray_lds_words(p.num_lasers) + (block / 64) * LIDAR_WAVE_WORDS) * sizeof(unsigned int);
 }
 static bool sim_has_ext(const SimParams& p) { return p.col_tl >= 0 || p.col_comm >= 0; }
 static hipError_t sim_lds_attrs() {              // 64 slots x 256 rays + route tables exceed the default 64 KB

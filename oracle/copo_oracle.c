@@ -529,22 +529,31 @@ static void write_obs(oracle_sim* s, int e, const copo_step_out* out, const uint
         /* LiDAR */
         float* lid = o + col;
         float range = c->lidar_range;
+        /* Every (ray, vehicle) decision is made in the box frame of vehicle j.  Per pair (i, j): the ray origin in that
+         * frame (ox, oy) and the rotation from i's frame into it (cr, sr); per ray only the direction (ddx, ddy). */
+        float pox[COPO_MAX_AGENTS], poy[COPO_MAX_AGENTS], pcr[COPO_MAX_AGENTS], psr[COPO_MAX_AGENTS];
+        uint8_t near[COPO_MAX_AGENTS];
+        for (int j = 0; j < N; ++j) {
+            near[j] = 0;
+            if (j == i || !solid[j]) continue;
+            float rx = FP(s, S_X, e)[j] - x, ry = FP(s, S_Y, e)[j] - y;
+            float lim = range + circ;
+            if (rx * rx + ry * ry > lim * lim) continue;
+            near[j] = 1;
+            pox[j] = -(rx * cs[j] + ry * sn[j]);
+            poy[j] = -(ry * cs[j] - rx * sn[j]);
+            pcr[j] = cs[i] * cs[j] + sn[i] * sn[j];
+            psr[j] = cs[i] * sn[j] - sn[i] * cs[j];
+        }
         for (int k = 0; k < L; ++k) {
-            float dxr = cs[i] * s->ray_cs[2 * k] - sn[i] * s->ray_cs[2 * k + 1];
-            float dyr = sn[i] * s->ray_cs[2 * k] + cs[i] * s->ray_cs[2 * k + 1];
+            float rc = s->ray_cs[2 * k], rs = s->ray_cs[2 * k + 1];
             float best = range;
             for (int j = 0; j < N; ++j) {
-                if (j == i || !solid[j]) continue;
-                float rx = FP(s, S_X, e)[j] - x, ry = FP(s, S_Y, e)[j] - y;
-                float lim = range + circ;
-                if (rx * rx + ry * ry > lim * lim) continue;
-                float along = dxr * rx + dyr * ry;
-                float perp = dxr * ry - dyr * rx;
-                if (along < -circ || fabsf(perp) > circ) continue;
+                if (!near[j]) continue;
                 /* ray vs box j in j's frame, mirrored so that the direction is non-negative on both axes; entering and
                  * exiting times are fractions n/a compared by cross-multiplication (no division until a hit is known) */
-                float ox = -(rx * cs[j] + ry * sn[j]), oy = -(ry * cs[j] - rx * sn[j]);
-                float ddx = dxr * cs[j] + dyr * sn[j], ddy = dyr * cs[j] - dxr * sn[j];
+                float ox = pox[j], oy = poy[j];
+                float ddx = rc * pcr[j] + rs * psr[j], ddy = rs * pcr[j] - rc * psr[j];
                 float ax = fabsf(ddx), ay = fabsf(ddy);
                 float oxs = ddx < 0.0f ? -ox : ox, oys = ddy < 0.0f ? -oy : oy;
                 float nxe = -(hl + oxs), nxx = hl - oxs, nye = -(hw + oys), nyx = hw - oys;
