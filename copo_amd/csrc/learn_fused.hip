@@ -83,19 +83,20 @@ static hipError_t gemm_lds_attrs() {
 // gather from the row store + fold (a meta pass over precomputed rows)
 struct MetaBatch { int nb; float* g_out; double* dot_out; float* stats_out; int part; };
 
-// COPO_FUSED_ROWPASS=0 keeps the four-kernel activation path (A/B measurements, tests of both paths)
-static const int g_wgrad_ot = [] {          // COPO_WGRAD_OT=2: two 32-row output tiles per wave (measured equal at H = 256)
-    const char* e = getenv("COPO_WGRAD_OT");
-    return (e && e[0] == '2') ? 2 : 1;
-}();
-static const bool g_use_wgrad = [] {
-    const char* e = getenv("COPO_FUSED_WGRAD");
-    return !(e && e[0] == '0');
-}();
-static const bool g_use_rowpass = [] {
-    const char* e = getenv("COPO_FUSED_ROWPASS");
-    return !(e && e[0] == '0');
-}();
+// The shipped library takes no environment variables: one code path, all of the work, every time.  Profiling builds
+// (`make prof`, -DCOPO_PROFILE_SKIP=<mask>, a separate .so that the package never loads) read COPO_RP_DBG for the
+// phase-stamp / phase-skip bits of the row pass and can fall back to the older kernel chains for A/B measurements.
+#ifdef COPO_PROFILE_SKIP
+static const int g_wgrad_ot = [] { const char* e = getenv("COPO_WGRAD_OT"); return (e && e[0] == '2') ? 2 : 1; }();
+static const bool g_use_wgrad = [] { const char* e = getenv("COPO_FUSED_WGRAD"); return !(e && e[0] == '0'); }();
+static const bool g_use_rowpass = [] { const char* e = getenv("COPO_FUSED_ROWPASS"); return !(e && e[0] == '0'); }();
+static int profile_dbg_bits() { static const int dbg = [] { const char* e = getenv("COPO_RP_DBG"); return e ? atoi(e) : 0; }(); return dbg; }
+#else
+static constexpr int g_wgrad_ot = 1;
+static constexpr bool g_use_wgrad = true;
+static constexpr bool g_use_rowpass = true;
+static constexpr int profile_dbg_bits() { return 0; }
+#endif
 
 // [lo, lo + n): the span of the flat parameter buffer that the first `nets` networks of the layout occupy
 static void fold_range(const copo_ppo_cfg& c, int nets_n, int64_t* lo_out, int* n_out) {
@@ -119,7 +120,7 @@ hipError_t launch_fused_step(FusedArgs a, hipStream_t s, const MetaTail* mt_ = n
     const copo_ppo_cfg& c = a.c;
     if (hipError_t e = gemm_lds_attrs(); e != hipSuccess) return e;
     a.ksplit = mbatch ? 1 : pick_ksplit(c.mb);
-    { static const int dbg = [] { const char* e = getenv("COPO_RP_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }     // a batched pass fills the chip without splitting rows
+    a.dbg = profile_dbg_bits();
     const int G = a.groups, mt = (c.mb + TM - 1) / TM, ht = (c.hidden + TN - 1) / TN;
     int kmax1 = c.pol.in_dim;
     if (a.head_mode == COPO_HEAD_PPO)

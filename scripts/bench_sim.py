@@ -9,33 +9,56 @@ import torch
 from copo_amd.sim import SimConfig, VecSim
 
 
-def run(E, N, lasers, block, map_name, steps=200, warm=30):
+def cruise_actions(obs, gen, speed=0.25):
+    """Lane-keeping controller on the observation (columns 2 / 8: heading error / offset in the lane; 3: speed; 10: check
+    point to the right): keeps vehicles on their routes, so scenes stay populated like those of a trained policy."""
+    psi = torch.asin(((0.5 - obs[..., 2]) * 2).clamp(-1, 1))
+    lat = -(obs[..., 8] - 0.5) * 4.5
+    aim = (obs[..., 10] - 0.5) * 2            # navigation: check point to the right (+) / left (-)
+    steer = (-1.5 * psi - 0.25 * lat - 0.8 * aim + 0.02 * torch.randn(psi.shape, device=obs.device, generator=gen)).clamp(-1, 1)
+    thr = ((speed - obs[..., 3]) * 8.0).clamp(-1, 1)
+    return torch.stack([steer, thr], -1).contiguous()
+
+
+def run(E, N, lasers, block, map_name, steps=200, warm=30, policy="random"):
     cfg = SimConfig(map=map_name, num_envs=E, num_agents=N, num_lasers=lasers)
     sim = VecSim(cfg, with_info=False)
     sim.set_block(block)
-    sim.reset()
-    act = torch.empty(E, sim.N, 2, device="cuda")
+    out = sim.reset()
     gen = torch.Generator(device="cuda").manual_seed(0)
-    acts = [torch.stack([torch.randn(E, sim.N, device="cuda", generator=gen) * 0.1,
-                         torch.rand(E, sim.N, device="cuda", generator=gen)], -1).contiguous() for _ in range(16)]
-    for i in range(warm):
-        sim.step(acts[i % 16])
+    if policy == "random":
+        acts = [torch.stack([torch.randn(E, sim.N, device="cuda", generator=gen) * 0.1,
+                             torch.rand(E, sim.N, device="cuda", generator=gen)], -1).contiguous() for _ in range(16)]
+        for i in range(warm):
+            sim.step(acts[i % 16])
+    else:
+        # closed-loop warm-up, then record the controller's actions over the timed stretch and replay them from the saved
+        # state (the simulator is deterministic), so that the timed loop holds nothing but simulator launches
+        for i in range(warm + 120):
+            out = sim.step(cruise_actions(out["obs"], gen))
+        st, env = sim.get_state()
+        acts = []
+        for i in range(steps):
+            a = cruise_actions(out["obs"], gen)
+            acts.append(a)
+            out = sim.step(a)
+        sim.set_state(st, env)
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    alive = 0
     ev0.record()
     for i in range(steps):
-        sim.step(acts[i % 16])
+        sim.step(acts[i % len(acts)])
     ev1.record()
     torch.cuda.synchronize()
     us = ev0.elapsed_time(ev1) * 1e3 / steps
-    acted = float((sim.out["flags"] & 1).float().mean())
+    present = float(((sim.out["flags"] & 0x41) != 0).float().mean())
     bytes_per = 202 + 4 * sim.O
     agents = E * sim.N
     sim.close()
-    return dict(E=E, N=sim.N, O=sim.O, block=block, us_per_step=round(us, 2), slots_per_s=round(agents / us * 1e6),
-                acted_frac=round(acted, 3), algo_GBps=round(agents * bytes_per / us * 1e-3, 1),
-                hbm_frac=round(agents * bytes_per / us * 1e-3 / 8000, 4))
+    return dict(E=E, N=sim.N, O=sim.O, block=block, policy=policy, us_per_step=round(us, 2), slots_per_s=round(agents / us * 1e6),
+                present_frac=round(present, 3), present_GBps=round(agents * present * bytes_per / us * 1e-3, 1),
+                hbm_frac_present=round(agents * present * bytes_per / us * 1e-3 / 8000, 4),
+                hbm_frac_all_slots=round(agents * bytes_per / us * 1e-3 / 8000, 4))
 
 
 if __name__ == "__main__":
@@ -45,7 +68,8 @@ if __name__ == "__main__":
     ap.add_argument("--lasers", type=int, default=72)
     ap.add_argument("--E", type=int, nargs="+", default=[256, 1024, 4096, 16384])
     ap.add_argument("--blocks", type=int, nargs="+", default=[256, 512, 1024])
+    ap.add_argument("--policy", default="random", choices=["random", "cruise"])
     a = ap.parse_args()
     for E in a.E:
         for b in a.blocks:
-            print(json.dumps(run(E, a.N, a.lasers, b, a.map)), flush=True)
+            print(json.dumps(run(E, a.N, a.lasers, b, a.map, policy=a.policy)), flush=True)
