@@ -104,7 +104,7 @@ def measure_sim_kernel_saturated(trainer, scenes=16384, launches=60, policy="cru
     out = sim.reset()
     gen = torch.Generator(device=sim.device).manual_seed(1)
     if policy == "cruise":
-        for i in range(100):
+        for i in range(250):         # past the first trips: junction traffic in steady state
             out = sim.step(cruise_actions(out["obs"], gen))
         st, env = sim.get_state()
         acts = []

@@ -55,7 +55,7 @@ static int upload(copo_sim* s, const T* host, size_t count, const T** dev) {
 
 // measured (scripts/bench_sim.py, 40 slots): up to one scene per CU -> 16 waves per scene; two per CU -> 8; then 4; from
 // ~32 scenes per CU on, ONE wave per scene with the small LDS footprint (sim_shape_params): ~20 scenes resident per CU
-static int pick_block(int E) { return E <= 256 ? 1024 : (E <= 512 ? 512 : (E < 8192 ? 256 : 64)); }
+static int pick_block(int E) { return E <= 256 ? 1024 : (E <= 512 ? 512 : (E <= 8192 ? 256 : 64)); }
 
 extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** out) {
     if (!cfg || !out) return fail(COPO_ERR_NULL, "copo_sim_create: cfg/out is NULL");

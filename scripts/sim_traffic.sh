@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/sim_traffic_E$E
 rm -rf $OUT; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-BLK=$(python -c "print(1024 if $E <= 256 else (512 if $E <= 512 else (256 if $E < 8192 else 64)))")
+BLK=$(python -c "print(1024 if $E <= 256 else (512 if $E <= 512 else (256 if $E <= 8192 else 64)))")
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -- python scripts/bench_sim.py --E $E --blocks $BLK --policy cruise > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -- python scripts/bench_sim.py --E $E --blocks $BLK --policy cruise > $OUT/write.log 2>&1
 python - <<PY
