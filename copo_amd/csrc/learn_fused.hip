@@ -239,6 +239,10 @@ extern "C" int copo_debug_rowpass_stamps(unsigned long long* out16) {
     return hipMemcpyFromSymbol(out16, HIP_SYMBOL(copo::g_rp_stamps), 16 * sizeof(unsigned long long)) == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
 }
 
+extern "C" int copo_debug_wg_times(unsigned long long* out4096) {
+    return hipMemcpyFromSymbol(out4096, HIP_SYMBOL(copo::g_wg_times), 4096 * sizeof(unsigned long long)) == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
+}
+
 extern "C" int64_t copo_ppo_workspace_floats(const copo_ppo_cfg* cfg) { return cfg ? (int64_t)fused_ws_floats(*cfg) : -1; }
 
 static int check_cfg(const copo_ppo_cfg* c) {

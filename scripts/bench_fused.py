@@ -1,6 +1,9 @@
 """Micro-benchmark of the fused learner step (eager launches, HIP events)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("COPO_RP_DBG"):          # phase stamps live in the profiling build only (make -C copo_amd/csrc prof SKIP=0)
+    import copo_amd._libsel as _S
+    _S.PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "copo_amd", "lib", "libcopo_hip_prof_0.so")
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from test_gpu_fused_learner import _make, _dense_batch
@@ -52,3 +55,22 @@ if int(os.environ.get("COPO_RP_DBG", "0")) & 512:
     for i, nme in enumerate(names):
         print("  %-30s %6.2f us" % (nme, (t[i + 1] - t[i]) / 100.0))
     print("  total                          %6.2f us" % ((t[5] - t[0]) / 100.0))
+
+if int(os.environ.get("COPO_RP_DBG", "0")) & 2048:
+    import ctypes as C
+    import numpy as np
+    from copo_amd import _capi
+    buf = (C.c_ulonglong * 4096)()
+    _capi.lib.copo_debug_wg_times.argtypes = [C.c_void_p]
+    _capi.lib.copo_debug_wg_times(buf)
+    t = np.array(list(buf), dtype=np.float64).reshape(2, 1024, 2) / 100.0      # us
+    for k, name in enumerate(("rowpass", "wgrad+adam")):
+        m = t[k, :, 0] > 0
+        st, en = t[k, m, 0], t[k, m, 1]
+        t0 = st.min()
+        print("%-11s %4d workgroups: first start 0.0, last start %.2f, first end %.2f, last end %.2f us; lifetime mean %.2f max %.2f" % (
+            name, int(m.sum()), st.max() - t0, en.min() - t0, en.max() - t0, (en - st).mean(), (en - st).max()))
+        order = np.argsort(en)[::-1][:5]
+        print("   slowest:", [(int(np.nonzero(m)[0][i]), round(float(st[i] - t0), 2), round(float(en[i] - t0), 2)) for i in order])
+    print("rowpass start -> wgrad start %.2f us; rowpass last end -> wgrad first start %.2f us; wgrad last end -> (next) " % (
+        t[1][t[1, :, 0] > 0, 0].min() - t[0][t[0, :, 0] > 0, 0].min(), t[1][t[1, :, 0] > 0, 0].min() - t[0][t[0, :, 0] > 0, 1].max()))
