@@ -4,7 +4,7 @@ import ctypes as C
 
 ABI_VERSION = 2
 MAX_AGENTS = 64
-MAX_SEGS = 12
+MAX_SEGS = 16
 SEG_STRIDE = 16
 MAX_LASERS = 256
 MAX_SPAWNS = 256

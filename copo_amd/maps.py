@@ -25,7 +25,7 @@ from typing import List, Tuple
 
 import numpy as np
 
-MAX_SEGS = 12         # COPO_MAX_SEGS: roads per route (a full turn of the roundabout is 11)
+MAX_SEGS = 16         # COPO_MAX_SEGS: roads per route (a full turn of the roundabout is 11)
 SEG_STRIDE = 16       # COPO_SEG_STRIDE
 LANE_WIDTH = 3.5
 # columns of a segment (road) record
@@ -396,47 +396,121 @@ def parkinglot(spaces=8, exit_length=20.0, lane_width=LANE_WIDTH, turn_radius=4.
     return b.finish()
 
 
-def pgmap(sequence="SCS", seed=0, lanes=2, lane_width=LANE_WIDTH, lead=50.0):
+PG_BLOCK_WEIGHTS = (("C", 0.3), ("S", 0.3), ("X", 0.15), ("T", 0.15), ("O", 0.1))   # a draw per block of an int `sequence`
+
+
+def _pgmap(sequence="SCS", seed=0, lanes=2, lane_width=LANE_WIDTH, lead=50.0):
     """Two-way road assembled from a block sequence, in the manner of MetaDrive's procedurally generated maps (the
-    `MultiAgentMetaDrive` env of train_all_copo_dist.py:10,30): `S` = straight of 40-80 m, `C` = curve of radius 30-60 m
-    through 30-90 degrees to a random side; an int `sequence` draws that many blocks.  Everything random comes from
-    `seed`, so a (sequence, seed) pair names one map.  `lead` metres of straight road at both ends hold the spawn slots;
-    vehicles enter at one end and leave at the other.  Junction blocks are not generated."""
+    `MultiAgentMetaDrive` env of train_all_copo_dist.py:10,30; MetaDrive's `map` key = a block count or a block string):
+      S  straight of 40-80 m (also stands in for the ramp blocks)
+      C  curve of radius 30-60 m through 30-90 degrees to a random side
+      X  standard intersection (radius 10): the road continues through a random arm -- right, straight or left
+      T  T-intersection: as X with the straight arm missing
+      O  roundabout (exit radius 10, inner radius 30, angle 70): the road continues through a random arm; the two driving
+         directions take the two sides of the ring
+    An int `sequence` draws that many blocks with MetaDrive's block weights.  Everything random comes from `seed`, so a
+    (sequence, seed) pair names one map.  `lead` metres of straight road at both ends hold the spawn slots; vehicles enter at
+    one end and leave at the other (the side arms of a junction block carry no traffic, so only the roads of the two routes
+    are built).  Junction blocks are geometry along the routes: lane lines end inside them (the detectors see none)."""
     rng = np.random.RandomState(int(seed))
     if isinstance(sequence, (int, np.integer)):
-        sequence = "".join("SC"[int(rng.randint(2))] for _ in range(int(sequence)))
-    centre, heading = [], 0.0
+        names, probs = zip(*PG_BLOCK_WEIGHTS)
+        sequence = "".join(names[int(rng.choice(len(names), p=probs))] for _ in range(int(sequence)))
+    w, n = lane_width, lanes
+    net = Net(w)
+    half = 10.0 + (2 * n - 1) * w / 2.0                     # intersection: stop line to junction centre (radius 10)
+    ang = math.radians(70.0)                                # roundabout
+    r_big = (2 * n - 1) * w + 30.0
+    r_join = ((2 * n - 1) * w / 2.0 + 10.0) / math.cos(ang) - 10.0
+    lane0 = lambda r_rightmost, left_turn: (r_rightmost - (n - 1) * w) if left_turn else (r_rightmost + (n - 1) * w)
+    r_e0, r_b0, r_j0 = lane0(10.0, False), lane0(r_big, True), lane0(r_join, True)
+    state = dict(pose=(0.0, 0.0, 0.0), heading=0.0, k=0)     # centre line (the yellow line) pose at the open end
+    fwd_nodes, bwd_roads = ["f0"], []
+
+    def centre_piece(ln, kap, lines=True):
+        """One road per direction following a centre-line piece: forward lane 0 is w/2 to its right."""
+        k, pose = state["k"], state["pose"]
+        kw = {} if lines else dict(left_line=0, right_line=0, inner_line=0)
+        a_off = -w / 2.0
+        p0 = shift(pose, a_off)
+        k0 = kap / (1.0 - kap * a_off) if kap else 0.0
+        l0 = ln * (1.0 - kap * a_off) if kap else ln
+        net.add("f%d" % k, "f%d" % (k + 1), p0, l0, k0, n, **kw)
+        bwd_roads.append(("f%d" % k, "f%d" % (k + 1), "b%d" % (k + 1), "b%d" % k, kw))
+        state["pose"], state["k"] = advance(pose, ln, kap), k + 1
+        state["heading"] += kap * ln
+
+    def ring_side(pose0, quarters):
+        """Lane-0 pieces of one passage of the roundabout from an arm's entry (lane-0 pose `pose0` at the stop line)
+        through `quarters` quarter turns to the exit arm's lane-0 pose."""
+        pieces = [(r_e0 * ang, -1.0 / r_e0)]
+        for q in range(quarters):
+            pieces.append((r_b0 * (2 * ang - math.pi / 2), 1.0 / r_b0))
+            if q < quarters - 1:
+                pieces.append((r_j0 * (math.pi - 2 * ang), 1.0 / r_j0))
+        pieces.append((r_e0 * ang, -1.0 / r_e0))
+        return pieces
+
+    centre_piece(lead, 0.0)
     for ch in str(sequence):
         if ch == "S":
-            centre.append((float(rng.uniform(40.0, 80.0)), 0.0))
+            centre_piece(float(rng.uniform(40.0, 80.0)), 0.0)
         elif ch == "C":
-            radius, ang = float(rng.uniform(30.0, 60.0)), math.radians(float(rng.uniform(30.0, 90.0)))
+            radius, a = float(rng.uniform(30.0, 60.0)), math.radians(float(rng.uniform(30.0, 90.0)))
             side = 1.0 if rng.rand() < 0.5 else -1.0
-            if abs(heading + side * ang) > math.radians(120.0):     # keep the chain from folding back over itself
+            if abs(state["heading"] + side * a) > math.radians(120.0):     # keep the chain from folding back over itself
                 side = -side
-            heading += side * ang
-            centre.append((radius * ang, side / radius))
+            centre_piece(radius * a, side / radius)
+        elif ch in "XT":
+            arm = int(rng.choice([1, 2, 3] if ch == "X" else [1, 3]))       # 1 right, 2 straight, 3 left
+            if arm != 2 and abs(state["heading"] + (math.pi / 2 if arm == 3 else -math.pi / 2)) > math.radians(120.0):
+                arm = 4 - arm
+            if arm == 2:
+                centre_piece(2 * half, 0.0, lines=False)
+            else:               # the lane arcs of a turn share the corner of the junction square as their centre: radius `half`
+                centre_piece(half * math.pi / 2, (1.0 if arm == 3 else -1.0) / half, lines=False)
+        elif ch == "O":
+            arm = int(rng.choice([1, 2, 3]))
+            turn = {1: -math.pi / 2, 2: 0.0, 3: math.pi / 2}[arm]
+            if abs(state["heading"] + turn) > math.radians(120.0):
+                arm, turn = 4 - arm, -turn
+            k, pose = state["k"], state["pose"]
+            # forward side: `arm` quarter turns; lane 0 of the forward road is w/2 right of the centre line
+            p = shift(pose, -w / 2.0)
+            fnodes = ["f%d" % k]
+            for q, (ln, kap) in enumerate(ring_side(p, arm)):
+                nxt = "f%d_%d" % (k, q)
+                p_next = net.add(fnodes[-1], nxt, p, ln, kap, n, LINE_BROKEN if kap < 0 else LINE_CONTINUOUS, LINE_CONTINUOUS if kap < 0 else LINE_BROKEN)
+                fnodes.append(nxt)
+                p = p_next
+            new_pose = shift(p, w / 2.0)                     # centre line at the exit arm
+            # rename the last forward node to the chain's next node
+            last = fnodes[-1]
+            rd = net.roads.pop((fnodes[-2], last))
+            net.roads[(fnodes[-2], "f%d" % (k + 1))] = rd
+            net.adj[fnodes[-2]] = ["f%d" % (k + 1) if v == last else v for v in net.adj[fnodes[-2]]]
+            net.adj.pop(last, None)
+            net.adj.setdefault("f%d" % (k + 1), [])
+            # backward side: from the exit arm back to the entry arm the other way round: 4 - arm quarter turns
+            pb = reverse(shift(new_pose, w / 2.0))           # lane 0 of the backward carriageway at the exit arm, heading back
+            bnodes = ["b%d" % (k + 1)]
+            side = ring_side(pb, 4 - arm)
+            for q, (ln, kap) in enumerate(side):
+                nxt = ("b%d_%d" % (k, q)) if q < len(side) - 1 else "b%d" % k
+                pb = net.add(bnodes[-1], nxt, pb, ln, kap, n, LINE_BROKEN if kap < 0 else LINE_CONTINUOUS, LINE_CONTINUOUS if kap < 0 else LINE_BROKEN)
+                bnodes.append(nxt)
+            want = reverse(shift(pose, w / 2.0))
+            if math.hypot(pb[0] - want[0], pb[1] - want[1]) > 1e-6:
+                raise AssertionError("roundabout block does not close: %r vs %r" % (pb, want))
+            state["pose"], state["k"] = new_pose, k + 1
+            state["heading"] += turn
         else:
-            raise ValueError("pgmap block %r: only S (straight) and C (curve) are generated" % ch)
-    chain = [(lead, 0.0)] + centre + [(lead, 0.0)]
-    if len(chain) > MAX_SEGS:
-        raise ValueError("pgmap: %d blocks + 2 lead pieces > %d route segments" % (len(centre), MAX_SEGS))
-    w = lane_width
-    net = Net(w)
-    # centre line (the yellow line) from the origin; forward lane 0 is w/2 to its right
-    pose = (0.0, 0.0, 0.0)
-    fwd = []
-    for k, (ln, kap) in enumerate(chain):
-        a = -w / 2.0
-        p0 = shift(pose, a)
-        k0 = kap / (1.0 - kap * a) if kap else 0.0
-        l0 = ln * (1.0 - kap * a) if kap else ln
-        net.add("f%d" % k, "f%d" % (k + 1), p0, l0, k0, lanes)
-        fwd.append((k, ln, kap, pose))
-        pose = advance(pose, ln, kap)
-    for k, ln, kap, p in reversed(fwd):
-        net.adverse("f%d" % k, "f%d" % (k + 1), "b%d" % (k + 1), "b%d" % k)
-    xe, ye = pose[0], pose[1]
+            raise ValueError("pgmap block %r: S, C, X, T or O" % ch)
+    centre_piece(lead, 0.0)
+    for fa, fb, ba, bb, kw in reversed(bwd_roads):
+        net.adverse(fa, fb, ba, bb, **kw)
+    nb = state["k"]
+    xe, ye = state["pose"][0], state["pose"][1]
     # centre the scene like the other maps: shift every road by minus the midpoint of the two ends
     ox, oy = -0.5 * xe, -0.5 * ye
     for key, (pp, ln, kap, nl) in list(net.roads.items()):
@@ -444,13 +518,29 @@ def pgmap(sequence="SCS", seed=0, lanes=2, lane_width=LANE_WIDTH, lead=50.0):
     for ln_ in net.lines:
         ln_[0] += ox
         ln_[1] += oy
-    total = sum(ln for ln, _ in chain)
-    b = _Builder("pgmap", net, 20, 0.5 * total)
+    b = _Builder("pgmap", net, 20, 0.5 * math.hypot(xe, ye) + lead)
     slots = spawn_slots(lead + ENTRANCE_LENGTH)
-    nb = len(chain)
     b.add_spawn_road(("f0", "f1"), ["f%d" % nb], slots)
     b.add_spawn_road(("b%d" % nb, "b%d" % (nb - 1)), ["b0"], slots)
     return b.finish()
+
+
+def pgmap(sequence="SCS", seed=0, **kw):
+    """`_pgmap`; a DRAWN sequence (int) whose routes need more than MAX_SEGS roads -- several roundabouts -- is redrawn with
+    its last roundabout replaced by a straight (still a function of (sequence, seed) alone)."""
+    if not isinstance(sequence, (int, np.integer)):
+        return _pgmap(sequence, seed, **kw)
+    rng = np.random.RandomState(int(seed))
+    names, probs = zip(*PG_BLOCK_WEIGHTS)
+    seq = "".join(names[int(rng.choice(len(names), p=probs))] for _ in range(int(sequence)))
+    while True:
+        try:
+            return _pgmap(seq, seed, **kw)
+        except ValueError:
+            if "O" not in seq:
+                raise
+            i = seq.rindex("O")
+            seq = seq[:i] + "S" + seq[i + 1:]
 
 
 MAP_BUILDERS = dict(intersection=intersection, roundabout=roundabout, tollgate=tollgate, parkinglot=parkinglot,

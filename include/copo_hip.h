@@ -35,7 +35,7 @@ extern "C" {
 #define COPO_ERR_CONFIG (-5)    /* inconsistent configuration / map tables */
 
 #define COPO_MAX_AGENTS 64      /* slots per env (one wave64 owns an env's agents) */
-#define COPO_MAX_SEGS 12        /* roads per route (a full turn of the roundabout is 11) */
+#define COPO_MAX_SEGS 16        /* roads per route (a full turn of the roundabout is 11) */
 #define COPO_SEG_STRIDE 16      /* floats per road record */
 #define COPO_MAX_LASERS 256
 #define COPO_MAX_SPAWNS 256     /* spawn slots per map */

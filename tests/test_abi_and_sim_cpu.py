@@ -110,16 +110,27 @@ def test_generated_roads_are_seeded_and_drivable():
     assert np.array_equal(a.route_segs, b.route_segs) and not np.array_equal(a.route_segs, c.route_segs)
     assert maps.pgmap(4, 9).n_routes == 2 and maps.pgmap(4, 9, lanes=3).n_spawns == 2 * 3 * 6
     with pytest.raises(ValueError):
-        maps.pgmap("SXS", 0)
+        maps.pgmap("SZS", 0)
     with pytest.raises(ValueError):
-        maps.pgmap(11, 0)                     # 11 blocks + 2 leads > MAX_SEGS
-    for seq, seed in [("CCC", 1), ("SCSCSC", 3), (6, 7)]:
+        maps.pgmap("C" * 15, 0)               # 15 blocks + 2 leads > MAX_SEGS
+    for seq, seed in [("CCC", 1), ("SCSCSC", 3), ("SXTCS", 7)]:      # (a roundabout block takes the two directions apart)
         t = maps.pgmap(seq, seed)
         fwd = maps.route_points(t, 0, 0.5)[:, :2]
         rev = maps.route_points(t, 1, 0.5)[:, :2]
         d = np.linalg.norm(fwd[:, None] - rev[None], axis=-1).min(1)
         assert 3.49 < d.min() and d.max() < 3.52          # inner lanes of the two directions: one lane width apart
-    cfg = SimConfig(map="pgmap", map_kwargs=dict(sequence="SCS", seed=5), num_envs=2, num_agents=12, horizon=400)
+    # junction blocks: the intersection's turn lanes share the corner of the junction square as their centre (lane-0 radii
+    # 13.5 right / 17 left for two lanes), a roundabout block closes for every exit arm (pgmap asserts it) and takes the two
+    # driving directions round the two sides of the ring: 2 + 2 * quarters roads one way, 2 + 2 * (4 - quarters) the other
+    x = maps.pgmap("X", 1)
+    radii = sorted(set(np.round(x.route_segs[:, 1, maps.SEG_RADIUS].astype(np.float64), 3)) - {0.0})
+    assert radii in ([13.5, 17.0], [13.5], [17.0], []) and x.route_segs[0, 1, maps.SEG_LEN] in (np.float32(30.5), np.float32(13.5 * np.pi / 2), np.float32(17 * np.pi / 2))
+    for seed in range(6):
+        o = maps.pgmap("O", seed)
+        nseg = sorted(int(v) for v in o.route_meta[:, 1])
+        assert nseg in ([5, 9], [7, 7]) and len(o.lines) > 0, nseg
+    assert any(c in "XTO" for c in "".join(maps.PG_BLOCK_WEIGHTS[i][0] for i in range(5)))
+    cfg = SimConfig(map="pgmap", map_kwargs=dict(sequence="SXS", seed=5), num_envs=2, num_agents=12, horizon=400)
     s, hist = _rollout(cfg, 380)
     flags = np.stack([h["flags"] for h in hist])
     assert ((flags & 4) > 0).sum() > 0, "lane keeping must bring some vehicles to the end of a generated road"

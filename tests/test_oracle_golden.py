@@ -175,3 +175,48 @@ def test_observation_extensions_vs_reference(golden_dir):
                     assert not got.any()
         nan_seen = nan_seen or bool(np.isnan(ext).any())
     assert nan_seen       # the coincident pair (d == 0 -> 0/0) went through the reference at least once
+
+
+def _roll_population_in_the_oracle(weights, odim, steps=350, E=3, seed=0):
+    """The oracle simulator (CPU) driven by a numpy policy in the reference's key layout; returns the counts of terminated
+    agents by outcome.  Deterministic: counter-based simulator RNG + a seeded numpy generator for the action noise."""
+    from copo_amd.eval.get_policy_function import detect_layout, layer_arrays
+    from copo_amd.sim import SimConfig
+    layers = layer_arrays(weights, detect_layout(weights), "default", "")
+    sim = ol.OracleSim(SimConfig(map="intersection", num_envs=E, num_agents=30, enable_lcf=False))
+    assert sim.O == odim == layers[0][0].shape[0]
+    out = sim.reset(np.arange(E, dtype=np.uint64) + np.uint64(5000 + 1000 * seed))
+    rng = np.random.RandomState(seed)
+    n = dict(arrive=0, crash=0, out=0)
+    for _ in range(steps):
+        x = out["obs"].reshape(E * sim.N, odim).astype(np.float64)
+        for depth, (w, b) in enumerate(layers):
+            x = x @ w + b
+            if depth < 2:
+                x = np.tanh(x)
+        act = x[:, :2] + np.exp(x[:, 2:]) * rng.normal(size=(E * sim.N, 2))
+        out = sim.step(act.astype(np.float32).reshape(E, sim.N, 2))
+        f = out["flags"]
+        n["arrive"] += int(((f & 4) != 0).sum())
+        n["crash"] += int((((f & 8) != 0) & ((f & 4) == 0)).sum())
+        n["out"] += int((((f & 16) != 0) & ((f & 4) == 0)).sum())
+    sim.close()
+    return n
+
+
+def test_oracle_simulator_is_pinned_by_the_reference_populations(golden_dir):
+    """Simulator half of the oracle (MetaDrive's source is absent): the populations the reference trained
+    in MetaDrive -- functions of the observation alone -- must DRIVE the oracle's scenes.  With build-defined observation
+    semantics (round 1) they scored 0 %; with the wrong LiDAR beam order they crash within 20 steps.  350 steps x 3 scenes
+    keep this in the CPU suite (seconds); the GPU suite repeats it on whole 1000-step episodes of 64 scenes with the
+    reference's MetaDrive scores next to it (tests/test_gpu_reference_populations.py)."""
+    gold = np.load(os.path.join(golden_dir, "eval_policy_function.npz"))
+    pre = "ippo_inter/w/"
+    w = {k[len(pre):]: gold[k] for k in gold.files if k.startswith(pre)}
+    n = _roll_population_in_the_oracle(w, 91)
+    done = n["arrive"] + n["crash"] + n["out"]
+    assert done > 150 and n["arrive"] / done > 0.3 and n["out"] / done < 0.15, n
+    rng = np.random.RandomState(1)
+    untrained = {k: (rng.normal(0, 0.05, v.shape) if v.ndim == 2 else np.zeros_like(v)) for k, v in w.items()}
+    n0 = _roll_population_in_the_oracle(untrained, 91)
+    assert n0["arrive"] == 0, n0
