@@ -1,0 +1,22 @@
+#!/bin/bash
+# Round-end evidence: rocprofv3 --kernel-trace --stats of the default bench command, the plain bench line next to it, and the
+# PMC traffic pass of the simulator kernel.   usage (on the GPU box): scripts/round_profile.sh r02   -> gpurun_out/<tag>_*
+TAG=${1:-rXX}
+cd /tmp && export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out
+mkdir -p $OUT; rm -rf /tmp/prof_bench
+cd $GRAFT_REPO_ROOT
+scripts/sim_traffic.sh 256 > /tmp/traffic.log 2>&1
+cp $OUT/sim_traffic_E256.json profiles/sim_traffic.json 2>/dev/null     # bench.py reads it (source hash checked)
+python bench.py --steps 10 --warmup 5 > /tmp/bench_plain.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/prof_bench -- python bench.py --steps 10 --warmup 5 --no-cpu-baseline > /tmp/bench_traced.log 2>&1
+DB=$(find /tmp/prof_bench -name "*_results.db" | head -1)
+{
+  echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 5 --no-cpu-baseline     ($TAG, one MI355X)"
+  echo "# bench line (traced run):"; tail -1 /tmp/bench_traced.log
+  echo "# bench line (plain run, with cpu_baseline):"; tail -1 /tmp/bench_plain.log
+  python scripts/top_kernels.py $DB 24
+} > $OUT/${TAG}_bench_kernel_stats.txt
+cp $OUT/sim_traffic_E256.json $OUT/${TAG}_sim_traffic.json 2>/dev/null
+rm -rf $OUT/sim_traffic_E256 $OUT/sim_traffic_E256.json
+tail -30 $OUT/${TAG}_bench_kernel_stats.txt | cut -c1-200
