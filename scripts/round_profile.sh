@@ -13,8 +13,8 @@ rocprofv3 --kernel-trace --stats -d /tmp/prof_bench -- python bench.py --steps 1
 DB=$(find /tmp/prof_bench -name "*_results.db" | head -1)
 {
   echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 5 --no-cpu-baseline     ($TAG, one MI355X)"
-  echo "# bench line (traced run):"; tail -1 /tmp/bench_traced.log
-  echo "# bench line (plain run, with cpu_baseline):"; tail -1 /tmp/bench_plain.log
+  echo "# bench line (traced run):"; grep '^{"metric"' /tmp/bench_traced.log | tail -1
+  echo "# bench line (plain run, with cpu_baseline):"; grep '^{"metric"' /tmp/bench_plain.log | tail -1
   python scripts/top_kernels.py $DB 24
 } > $OUT/${TAG}_bench_kernel_stats.txt
 cp $OUT/sim_traffic_E256.json $OUT/${TAG}_sim_traffic.json 2>/dev/null
