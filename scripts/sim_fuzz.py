@@ -1,0 +1,69 @@
+"""Randomised parity hunt: HIP simulator vs the CPU oracle, raw bits of every output, over random maps / populations /
+beam counts / launch shapes / action sources.  usage: python scripts/sim_fuzz.py [n_cases] [steps]"""
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+import oracle_lib as ol
+from copo_amd.sim import SimConfig, VecSim
+
+KEYS = ("obs", "rew", "nei_rew", "glob_rew", "flags", "nbr_cnt", "mf_cnt", "lcf", "info", "agent_id")
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 250
+rng = np.random.RandomState(2026)
+bad = 0
+for case in range(n_cases):
+    name = ["intersection", "roundabout", "parkinglot", "tollgate", "bottleneck", "pgmap"][rng.randint(6)]
+    kw = dict(sequence=int(rng.randint(1, 5)), seed=int(rng.randint(1000))) if name == "pgmap" else {}
+    tabs = __import__("copo_amd.maps", fromlist=["x"]).MAP_BUILDERS[name](**kw)
+    N = int(rng.randint(2, min(64, tabs.n_spawns) + 1))
+    E = int(rng.randint(1, 7))
+    lasers = int(rng.choice([30, 72, 72, 72, 120, 240]))
+    block = int(rng.choice([64, 64, 128, 256, 512, 1024]))
+    cfg = SimConfig(map=name, map_kwargs=kw, num_envs=E, num_agents=N, num_lasers=lasers, horizon=int(rng.randint(40, 200)),
+                    nbr_k=int(rng.randint(1, max(2, min(N, 12)))), delay_done=int(rng.randint(0, 30)), enable_lcf=bool(rng.randint(2)),
+                    neighbours_distance=float(rng.choice([10.0, 20.0, 40.0])))
+    g, o = VecSim(cfg), ol.OracleSim(cfg)
+    g.set_block(block)
+    seeds = rng.randint(0, 2 ** 31, E).astype(np.uint64)
+    go, oo = g.reset(seeds), o.reset(seeds)
+    mode = rng.randint(3)
+    fail = None
+    for t in range(steps):
+        if mode == 0:
+            a = np.stack([rng.normal(0, 0.15, (E, N)), rng.uniform(-0.3, 1.0, (E, N))], -1)
+        elif mode == 1:          # lane keeping on the oracle's observation (side_lasers = 0 layouts only; else random)
+            ob = oo["obs"]
+            c2 = cfg.ego_dim - 7 if cfg.lane_line_lasers == 0 else None
+            hd = ob[..., (cfg.side_lasers or 2)]
+            psi = np.arcsin(np.clip((0.5 - hd) * 2, -1, 1))
+            a = np.stack([np.clip(-1.5 * psi + rng.normal(0, 0.05, psi.shape), -1, 1), np.full((E, N), 0.6)], -1)
+        else:
+            a = rng.uniform(-1.2, 1.2, (E, N, 2))
+        a = a.astype(np.float32)
+        go, oo = g.step(torch.from_numpy(a).cuda()), o.step(a)
+        pres = (oo["flags"] & 0x41) != 0
+        before = ((oo["flags"] & 1) != 0) | (((oo["flags"] & 0x40) != 0) & ((oo["flags"] & 0x80) == 0))
+        for k in KEYS + ("nbr_idx", "nbr_dist"):
+            x, y = go[k].cpu().numpy(), oo[k]
+            if k == "obs":
+                x, y = x[pres], y[pres]
+            elif k in ("nbr_idx", "nbr_dist"):
+                x, y = x[before], y[before]
+            xb = x.view(np.uint32) if x.dtype == np.float32 else x
+            yb = y.view(np.uint32) if y.dtype == np.float32 else y
+            if not np.array_equal(xb, yb):
+                fail = (t, k, int((xb != yb).sum()))
+                break
+        if fail:
+            break
+    print("case %3d %-12s N=%2d E=%d lasers=%3d block=%4d O=%3d mode=%d: %s" % (case, name, N, E, lasers, block, cfg.obs_dim, mode,
+          "ok" if not fail else "MISMATCH step %d %s (%d words)" % fail), flush=True)
+    bad += 1 if fail else 0
+    g.close()
+    o.close()
+print("mismatching cases:", bad)
+sys.exit(1 if bad else 0)
