@@ -357,6 +357,27 @@ def main():
     agent_steps = trainer._counters["num_agent_steps_sampled"] - a0      # already summed over ranks
     value = agent_steps / dt
 
+    coll = None
+    if world > 1:
+        # what the data-parallel step adds: one all-reduce of the flat gradient bucket per SGD minibatch (every rank takes
+        # part; HIP events on this rank's stream, barrier-separated from the timed region above)
+        import torch.distributed as td
+        fz = trainer.policy.fused
+        n = int(fz.flat.numel) if fz is not None else sum(p.numel() for p in trainer.policy.model.parameters())
+        buf = torch.zeros(n, device="cuda")
+        for _ in range(5):
+            td.all_reduce(buf)
+        torch.cuda.synchronize()
+        D.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            td.all_reduce(buf)
+        e1.record()
+        torch.cuda.synchronize()
+        coll = {"allreduce_grad_us": round(e0.elapsed_time(e1) * 1e3 / 50, 2), "bucket_bytes": 4 * n,
+                "backend": td.get_backend(), "per": "SGD minibatch (one per optimizer step)"}
+
     line = None
     if rank == 0:
         sim = trainer.env.sim
@@ -411,6 +432,8 @@ def main():
                 "achieved": round(l_flops / l_s * 1e-12, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(l_flops / l_s * 1e-12 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
                 "us_per_step": round(l_s * 1e6, 2), "flops_per_step": int(l_flops)}
+        if coll is not None:
+            line["config"]["collective"] = coll
         if world == 1:
             line["phases"] = measure_phases(trainer)
         if world == 1 and not args.no_cpu_baseline:

@@ -491,3 +491,5 @@ def test_bench_harness_with_two_ranks_on_one_gpu():
     per_rank_iter = r["config"]["agent_steps_per_iter"]
     assert abs(r["value"] * r["ms_per_step"] * 1e-3 - 2 * per_rank_iter) <= 1e-3 * 2 * per_rank_iter    # both shards counted
     assert outs[0][0].strip().splitlines()[-1] == lines0[0]        # the JSON is the last line of stdout
+    coll = r["config"]["collective"]                            # the data-parallel step's own cost is on the line
+    assert coll["allreduce_grad_us"] > 0 and coll["bucket_bytes"] >= 4 * 360201 and coll["backend"] == "gloo"
