@@ -894,7 +894,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(const SimP
         if (lane == 0) {
             L.m_acted = ma;
             L.m_solid = ms;
-            L.ending = (t_env + 1 >= p.horizon) ? 1 : 0;
+            L.ending = 0;
         }
     }
     __syncthreads();
@@ -927,7 +927,9 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(const SimP
     }
     __syncthreads();
 
-    const bool ending = L.ending != 0;
+    // MultiAgentMetaDrive.step: after `horizon` env steps the scene stops respawning and drains; it is reset when nobody
+    // is left driving (P2 decides).  Every agent has its own limit of `horizon` steps (max_step).
+    const bool no_respawn = t_env + 1 >= p.horizon, force_end = t_env + 1 >= 5 * p.horizon;
     uint8_t fl = 0;
     float rew = 0.0f, lcf_row = 0.0f;
     int32_t aid_row = -1;
@@ -991,9 +993,8 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(const SimP
             if (oor) fl |= COPO_F_OUT;
             if (crash) fl |= COPO_F_CRASH;
             bool done = arrive || oor || crash;
-            if (!done && ending) { fl |= COPO_F_MAXSTEP; done = true; }
+            if (!done && (st_age(s.status) >= p.horizon || force_end)) { fl |= COPO_F_MAXSTEP; done = true; }
             if (done) fl |= COPO_F_DONE;
-            if (ending) fl |= COPO_F_ENV_RESET;
             term = done;
             rew = r;
             s.eprew += r;
@@ -1009,7 +1010,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(const SimP
                 q[COPO_I_ROUTE_COMPLETION] = clipf(prog / total, 0.0f, 1.0f);
             }
             if (term) {
-                if (!(fl & COPO_F_ARRIVE) && (fl & (COPO_F_CRASH | COPO_F_OUT)) && p.delay_done > 0)
+                if (!(fl & COPO_F_ARRIVE) && p.delay_done > 0)
                     s.status = st_pack(ST_WRECK, p.delay_done, 0);
                 else
                     s.status = st_pack(ST_EMPTY, p.respawn_cooldown, 0);
@@ -1021,7 +1022,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(const SimP
         present = acted;
         // respawn: a random one of the respawn places whose region is clear of the vehicles standing now, each place at
         // most once per step; serial over the eligible slots in slot order, every lane tests its own vehicle
-        if (!ending && !(COPO_PROFILE_SKIP & 32)) {
+        if (!no_respawn && !(COPO_PROFILE_SKIP & 32)) {
             const bool mine = lane < capacity_of(p) && !acted && s.status == st_pack(ST_EMPTY, 0, 0);
             unsigned long long elig = __ballot(mine);
             if (elig) {
@@ -1070,13 +1071,16 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(const SimP
         }
         const unsigned long long mp = __ballot(present);
         const unsigned long long ms = __ballot(lane < N && st_status(s.status) != ST_EMPTY);
+        const unsigned long long alive = __ballot(lane < N && st_status(s.status) == ST_ALIVE);
         build_lists(L, lane, mp, ms);
         if (lane == 0) {
             L.m_present = mp;
             L.m_solid = ms;
+            L.ending = alive == 0ull ? 1 : 0;   // nobody left driving: the episode is over
         }
     }
     __syncthreads();
+    const bool ending = L.ending != 0;
 
     COPO_STAMP(3);
     // ---- P3 (all waves): neighbour lists + reward reductions on the post-step (pre-reset) scene ---
@@ -1085,7 +1089,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(const SimP
     COPO_STAMP(4);
     // (neighbours_phase ends with a workgroup barrier: the reset below may overwrite the poses it read)
 
-    // ---- P4 (wave 0): horizon reset, row outputs, state write-back, ego/navi obs ------------------
+    // ---- P4 (wave 0): end-of-episode reset, row outputs, state write-back, ego/navi obs ------------------
     if (wave == 0) {
         uint8_t fl_out = fl;
         float lcf_out = lcf_row;

@@ -75,10 +75,10 @@ def make_eval_trainer(algo, env, num_envs=64, num_agents=40, seed=0, lcf=None, *
 
 def evaluate_population(algo, env, weights=None, lcf=None, num_envs=64, num_agents=40, episodes=2000, seed=0,
                         scene_episodes=None, **extra):
-    """Roll a population in `num_envs` scenes.  `scene_episodes` = whole scene episodes (`horizon` env steps each, the unit
-    of the reference's evaluation, eval/evaluate_population.py:57-76) -- every agent that terminates inside them counts,
-    agents still driving at the horizon are reported as `max_step`; otherwise stop after `episodes` terminated agents
-    (quick, but the first agents to terminate are the ones that fail early)."""
+    """Roll a population in `num_envs` scenes.  `scene_episodes` = whole scene episodes (until done["__all__"]: `horizon`
+    env steps of respawning, then the scene drains -- the unit of the reference's evaluation,
+    eval/evaluate_population.py:57-76) -- every agent that terminates inside them counts; otherwise stop after `episodes`
+    terminated agents (quick, but the first agents to terminate are the ones that fail early)."""
     from .checkpoint_io import load_policy_weights
     t = make_eval_trainer(algo, env, num_envs, num_agents, seed, lcf, **extra)
     if weights is not None:
@@ -86,8 +86,7 @@ def evaluate_population(algo, env, weights=None, lcf=None, num_envs=64, num_agen
         if t.policy.fused is not None:
             t.policy.fused.sync_mirror()
     if scene_episodes:
-        horizon = int(t.env.sim.cfg.horizon)
-        res = t.evaluate(num_fragments=int(scene_episodes) * -(-horizon // t.sampler.T), min_episodes=0)
+        res = t.evaluate(scene_episodes=int(scene_episodes))
     else:
         res = t.evaluate(num_fragments=1, min_episodes=episodes)
     t.stop()

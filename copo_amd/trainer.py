@@ -731,13 +731,34 @@ class VecTrainer:
         cm["num_acting_rows"] = na
         return cm
 
-    def evaluate(self, num_fragments=50, min_episodes=0):
+    def evaluate(self, num_fragments=50, min_episodes=0, scene_episodes=None):
         """Roll the CURRENT policy without learning and aggregate what `RecorderEnv` reports per population
         (copo/eval/recoder.py:139-152 success / crash / out / max_step rates, episode reward / length, velocity, ...)
-        over the agents that terminate: `num_fragments` sampler fragments, more until `min_episodes` agents finished."""
+        over the agents that terminate: `num_fragments` sampler fragments, more until `min_episodes` agents finished.
+        `scene_episodes` = k: the next k WHOLE episodes of every scene instead (until done["__all__"], the unit of
+        eval/evaluate_population.py:57-76) -- rows of a scene's partial first episode and of episodes after its k-th are
+        left out, so slow agents and the drain phase of an episode weigh what they weigh in the reference's evaluation."""
         tot, n_frag = {}, 0
-        while n_frag < num_fragments or tot.get("num_terminated_agents", 0) < min_episodes:
-            cm = self.episode_metrics(self.sampler.sample())
+        # [E] episodes completed per scene; -1: still inside the partial episode the call started in
+        ep = torch.full((self.sampler.E,), -1 if self.sampler._started else 0, dtype=torch.int64, device=self.sampler.device)
+        while True:
+            if scene_episodes is None:
+                if not (n_frag < num_fragments or tot.get("num_terminated_agents", 0) < min_episodes):
+                    break
+                if n_frag > 100 * max(1, num_fragments):
+                    break
+            elif bool((ep >= int(scene_episodes)).all()):
+                break
+            batch = self.sampler.sample()
+            if scene_episodes is not None:
+                fl = batch[SampleBatch.FLAGS]                                   # [T, E, N]
+                ended = ((fl & F_ENV_RESET) > 0).any(-1).to(torch.int64)        # [T, E]
+                before = ep[None] + torch.cumsum(ended, 0) - ended              # episodes completed before step t
+                keep = (before >= 0) & (before < int(scene_episodes))
+                ep = ep + ended.sum(0)
+                batch = SampleBatch(batch)
+                batch[SampleBatch.FLAGS] = fl * keep[..., None].to(fl.dtype)
+            cm = self.episode_metrics(batch)
             nd, na = cm.get("num_terminated_agents", 0.0), cm.get("num_acting_rows", 0.0)
             for k, v in cm.items():
                 if k in ("num_terminated_agents", "num_acting_rows"):
@@ -746,8 +767,8 @@ class VecTrainer:
                     w = nd if k in self._EPISODE_KEYS else na
                     tot[k] = tot.get(k, 0.0) + v * w
             n_frag += 1
-            if n_frag > 100 * max(1, num_fragments):
-                break
+            if scene_episodes is not None and n_frag * self.sampler.T > 6 * int(scene_episodes + 1) * int(self.env.sim.cfg.horizon):
+                break       # (an episode is at most 5 x horizon env steps)
         out = {}
         for k, v in tot.items():
             if k in ("num_terminated_agents", "num_acting_rows"):

@@ -56,9 +56,9 @@ extern "C" {
 #define COPO_F_ARRIVE 0x04u
 #define COPO_F_CRASH 0x08u
 #define COPO_F_OUT 0x10u
-#define COPO_F_MAXSTEP 0x20u
+#define COPO_F_MAXSTEP 0x20u    /* the AGENT drove `horizon` steps without terminating (episode_lengths[id] >= horizon) */
 #define COPO_F_SPAWNED 0x40u    /* a new agent occupies the slot after this step (obs valid, reward 0, no row) */
-#define COPO_F_ENV_RESET 0x80u  /* the env hit its horizon this step and was reset (done["__all__"]) */
+#define COPO_F_ENV_RESET 0x80u  /* the episode of this scene ended this step and the scene was reset (done["__all__"]) */
 
 /* columns of the optional per-slot info output [E][N][COPO_INFO_DIM] (utils/callbacks.py:35-46) */
 #define COPO_I_VELOCITY 0       /* km/h */
@@ -95,8 +95,10 @@ typedef struct copo_sim_cfg {
     int32_t obs_dim;           /* COPO_OBS_DIM() */
     int32_t nbr_k;             /* neighbour ids stored per slot (<= N-1) */
     int32_t enable_lcf;        /* 1: LCFEnv (append (lcf+1)/2 to obs, sample LCF at spawn); 0: CCEnv only */
-    int32_t horizon;           /* env steps per episode (MetaDrive `horizon`, 1000) */
-    int32_t delay_done;        /* steps a crashed / out-of-road vehicle lingers as an obstacle (MetaDrive `delay_done`) */
+    int32_t horizon;           /* MetaDrive `horizon` (1000), MultiAgentMetaDrive.step: (i) an agent that acted `horizon` steps is
+                                  done with max_step; (ii) once `horizon` env steps have run the scene stops respawning and
+                                  drains; (iii) the scene is reset when no agent is left driving (or after 5 x horizon steps) */
+    int32_t delay_done;        /* steps a vehicle that terminated without arriving lingers as an obstacle (MetaDrive `delay_done`) */
     int32_t respawn_cooldown;  /* steps a slot stays empty before re-use (0: MetaDrive respawns in the same step) */
     int32_t substeps;          /* physics sub-steps per env step (5) */
     /* radii */
@@ -172,8 +174,8 @@ typedef struct copo_step_out {
     float* glob_rew;     /* [E]         env_wrappers.py:313                                               */
     uint8_t* flags;      /* [E][N]      COPO_F_* bitfield                                                 */
     int32_t* nbr_idx;    /* [E][N][K]   slot ids sorted by (distance, slot), -1 padded  (:125-139); like obs, rows of
-                                         slots that held no agent when the lists were made (the scene BEFORE a horizon
-                                         reset) are not written -- nbr_cnt / mf_cnt / nei_rew are 0 there            */
+                                         slots that held no agent when the lists were made (the scene BEFORE an
+                                         end-of-episode reset) are not written -- nbr_cnt / mf_cnt / nei_rew are 0 there            */
     int32_t* nbr_cnt;    /* [E][N]      neighbours within neighbours_distance (may exceed K)              */
     int32_t* mf_cnt;     /* [E][N]      length of the list prefix with distance <= mf_distance            */
     float* nbr_dist;     /* [E][N][K]   distances (float64 compare, stored fp32)                          */

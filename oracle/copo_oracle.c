@@ -800,7 +800,11 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
         /* 2. heading unit vectors of the slots that did not act (wrecks; empty slots are never read) */
         for (int n = 0; n < N; ++n)
             if (!t.acted[n]) o_sincosf(TH[n], &t.sn[n], &t.cs[n]);
-        int ending = (env[0] + 1 >= c->horizon);
+        /* MultiAgentMetaDrive.step: once `horizon` env steps have run the scene stops respawning and drains; it is reset
+         * when no agent is left (done["__all__"] = episode_steps >= horizon and all(d.values()), or no vehicle at all, or
+         * 5 x horizon steps).  Every agent has its own step limit: episode_lengths[id] >= horizon -> max_step. */
+        int no_respawn = (env[0] + 1 >= c->horizon);
+        int force_end = (env[0] + 1 >= 5 * c->horizon);
         /* 3-5. collision, route projection, termination, reward */
         uint8_t term[COPO_MAX_AGENTS];
         uint8_t crash_any[COPO_MAX_AGENTS];
@@ -868,9 +872,8 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
             if (out_of_road) fl |= COPO_F_OUT;
             if (crash) fl |= COPO_F_CRASH;
             int done = arrive || out_of_road || crash;
-            if (!done && ending) { fl |= COPO_F_MAXSTEP; done = 1; }
+            if (!done && (ST_AGE(STA[n]) >= c->horizon || force_end)) { fl |= COPO_F_MAXSTEP; done = 1; }
             if (done) fl |= COPO_F_DONE;
-            if (ending) fl |= COPO_F_ENV_RESET;
             term[n] = (uint8_t)done;
             t.rew[n] = r;
             t.fl[n] = fl;
@@ -894,7 +897,7 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
          *    obstacle for `delay_done` steps (AgentManager.finish(ignore_delay_done = success)) */
         for (int n = 0; n < N; ++n) {
             if (!term[n]) continue;
-            if (!(t.fl[n] & COPO_F_ARRIVE) && (t.fl[n] & (COPO_F_CRASH | COPO_F_OUT)) && c->delay_done > 0)
+            if (!(t.fl[n] & COPO_F_ARRIVE) && c->delay_done > 0)
                 STA[n] = ST_PACK(ST_WRECK, c->delay_done, 0);
             else
                 STA[n] = ST_PACK(ST_EMPTY, c->respawn_cooldown, 0);
@@ -903,7 +906,7 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
         for (int n = 0; n < N; ++n) present[n] = t.acted[n];
         /* 7. respawn (serial in slot order): a random one of the SAFE places whose 8 x 3 m region holds no vehicle
          *    (SpawnManager.get_available_respawn_places), each place at most once per step */
-        if (!ending) {
+        if (!no_respawn) {
             /* places whose region is clear of the vehicles standing when the respawns begin; `used`: taken this step */
             uint32_t clear = 0, used = 0;
             for (int q = 0; q < s->n_safe; ++q) {
@@ -939,10 +942,13 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
                 t.lcf_row[n] = FP(s, S_LCF, e)[n];
             }
         }
+        int ending = 1;                     /* nobody left driving: the episode is over */
+        for (int n = 0; n < N; ++n)
+            if (ST_STATUS(STA[n]) == ST_ALIVE) ending = 0;
         /* 8. neighbour lists, reward reductions, row outputs (on the pre-reset scene) */
         emit_outputs(s, e, out, &t, present);
         env[0] += 1;
-        /* 9-10. horizon: reset the env, then observations of whoever occupies the slots now */
+        /* 9-10. end of the episode: reset the env, then observations of whoever occupies the slots now */
         if (ending) {
             env[1] += 1;
             reset_env(s, e);

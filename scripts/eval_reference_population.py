@@ -15,7 +15,7 @@ G1 = np.load(os.path.join(ROOT, "tests", "golden", "eval_policy_function.npz"))
 G2 = np.load(os.path.join(ROOT, "tests", "golden", "reference_populations.npz"))
 with open(os.path.join(ROOT, "tests", "golden", "reference_eval_stats.json")) as f:
     print("# reference, MetaDrive (eval/demo_results):", json.dumps({k: {c: round(v, 3) for c, v in d.items()} for k, d in json.load(f).items()}))
-scene_episodes = int(sys.argv[1]) if len(sys.argv) > 1 else 2      # whole 1000-step scene episodes of 64 scenes each
+scene_episodes = int(sys.argv[1]) if len(sys.argv) > 1 else 2      # whole scene episodes (until done["__all__"]) of 64 scenes each
 KEEP = ("success_rate_mean", "crash_rate_mean", "out_of_road_rate_mean", "max_step_rate_mean", "episode_reward_mean",
         "episode_length_mean", "route_completion_mean", "velocity_mean", "num_terminated_agents")
 for gold, name, algo, env, n in ((G1, "copo_inter", "copo", "inter", 30), (G1, "ippo_inter", "ippo", "inter", 30),
@@ -27,5 +27,4 @@ for gold, name, algo, env, n in ((G1, "copo_inter", "copo", "inter", 30), (G1, "
     for label, weights in (("reference-trained", w), ("untrained", None)):
         r = evaluate_population(algo, env, weights, lcf, num_envs=64, num_agents=n, scene_episodes=scene_episodes, seed=0)
         d = {k: round(float(r[k]), 4) for k in KEEP if k in r}
-        d["success_of_uncut"] = round(d["success_rate_mean"] / max(1e-9, 1 - d["max_step_rate_mean"]), 4)
         print("%-12s %2d agents %-18s %s" % (name, n, label, json.dumps(d)), flush=True)

@@ -158,10 +158,12 @@ def _rollout(cfg, steps, seed=0, policy="cruise"):
 
 def test_sim_invariants_on_the_oracle():
     cfg = SimConfig(map="intersection", num_envs=3, num_agents=30, horizon=200, delay_done=5)
-    s, hist = _rollout(cfg, 420)
-    spawned_total = 0
+    s, hist = _rollout(cfg, 520)
+    spawned_total, resets, max_steps = 0, 0, 0
+    t_scene = np.zeros(s.E, np.int64)          # env steps of every scene's current episode (MetaDrive episode_steps)
     for t, o in enumerate(hist):
         f = o["flags"]
+        t_scene += 1
         acted, done, spawned = (f & 1) > 0, (f & 2) > 0, (f & 64) > 0
         assert np.all(o["obs"] >= 0) and np.all(o["obs"] <= 1) and np.isfinite(o["rew"]).all()
         assert not np.any(done & ~acted)                                    # only acting agents terminate
@@ -181,9 +183,21 @@ def test_sim_invariants_on_the_oracle():
                 assert np.all(np.diff(d) >= 0) and np.all(d < cfg.neighbours_distance)
                 assert o["mf_cnt"][e, n] == np.sum(o["nbr_dist"][e, n, :c] <= cfg.mf_distance) or o["nbr_cnt"][e, n] > s.K
         spawned_total += int(spawned.sum())
-        if (f & 128).any():                                                 # horizon: the whole scene resets
-            assert (t + 1) % cfg.horizon == 0 and np.all((f[(f & 128) > 0] & 64) > 0)
-    assert spawned_total > 0
+        # MultiAgentMetaDrive.step: max_step belongs to the agent (its own `horizon` steps); from `horizon` env steps on the
+        # scene only drains; it is reset -- every slot spawned anew -- when nobody is left driving
+        ms = (f & 32) > 0
+        assert np.all(o["info"][..., 5][ms] == cfg.horizon) and np.all(o["info"][..., 5][acted] <= cfg.horizon)
+        max_steps += int(ms.sum())
+        for e in range(s.E):
+            ended = bool((f[e] & 128).any())
+            if ended:
+                assert t_scene[e] >= cfg.horizon and np.all(done[e] == acted[e]) and np.all((f[e] & (64 | 128)) == (64 | 128))
+                t_scene[e] = 0
+                resets += 1
+            else:
+                assert (acted[e] & ~done[e]).any() or spawned[e].any()      # somebody is still driving
+                assert t_scene[e] < cfg.horizon or not spawned[e].any()     # a draining scene does not respawn
+    assert spawned_total > 0 and resets >= 3
     flags = np.stack([h["flags"] for h in hist])
     assert ((flags & 4) > 0).sum() > 0, "cruising straight must reach some destinations"
     s.close()
@@ -249,29 +263,33 @@ def test_observation_extension_spaces_and_oracle_rollout():
     out = s.reset()
     assert np.all(out["obs"][..., 91] == 1.0) and not out["obs"][..., 95:].any()      # message(0) = 1, no comm after a reset
     rng = np.random.RandomState(0)
-    spoke = 0
-    for t in range(1, 130):
+    spoke, resets = 0, 0
+    clock = np.zeros(2, np.int64)            # env steps since the scene's last reset
+    for t in range(1, 260):
         a = np.concatenate([rng.normal(0, 0.05, (2, 20, 1)), rng.uniform(0.3, 1, (2, 20, 1)), rng.uniform(-1, 1, (2, 20, 3))], -1)
         out = s.step(a.astype(np.float32))
         f = out["flags"]
         present = (f & 0x41) > 0
-        c = t % 60            # steps since the last horizon reset
-        msg = (c % 6) / 6 * 0.1 if (c // 6) % 2 == 1 else 1 - (c % 6) / 6 * 0.1
-        np.testing.assert_array_equal(out["obs"][..., 91][present], np.float32(msg))
-        tlpos = out["obs"][..., 92:94][present]
-        assert np.all((tlpos > 0) & (tlpos < 1))
-        comm_block = out["obs"][..., 95:]
-        assert np.all(np.abs(comm_block[present]) <= 1)
-        if c == 0:
-            assert not comm_block[present].any()
-        # first message block == the comm action of the nearest neighbour if it acted this step
+        clock = np.where((f & 128).any(1), 0, clock + 1)
+        resets += int((f & 128).any(1).sum())
         for e in range(2):
+            c = int(clock[e])
+            msg = (c % 6) / 6 * 0.1 if (c // 6) % 2 == 1 else 1 - (c % 6) / 6 * 0.1
+            np.testing.assert_array_equal(out["obs"][e, :, 91][present[e]], np.float32(msg))
+            tlpos = out["obs"][e, :, 92:94][present[e]]
+            assert np.all((tlpos > 0) & (tlpos < 1))
+            comm_block = out["obs"][e, :, 95:]
+            assert np.all(np.abs(comm_block[present[e]]) <= 1)
+            if c == 0:
+                assert not comm_block[present[e]].any()
+            # first message block == the comm action of the nearest neighbour if it acted this step
             for n in np.nonzero(present[e])[0]:
                 if out["nbr_cnt"][e, n] > 0 and c != 0:
                     j = out["nbr_idx"][e, n, 0]
                     want = a[e, j, 2:].astype(np.float32) if (f[e, j] & 1) else np.zeros(3, np.float32)
-                    np.testing.assert_array_equal(comm_block[e, n, :3], want)
+                    np.testing.assert_array_equal(comm_block[n, :3], want)
                     spoke += int(f[e, j] & 1)
+    assert resets >= 2
     assert spoke > 100
     s.close()
     bad = SimConfig(map="intersection", num_envs=1, num_agents=4, add_traffic_light=True, traffic_light_interval=0)

@@ -7,8 +7,8 @@ meaning and scale, LiDAR beam order, navigation encoding, steering sign, road ge
 roll the populations in the HIP simulator, 30 agents on the Intersection / 40 on the Roundabout as the reference's
 evaluation does (eval/evaluate_population.py:102-132), and fail if they fall back towards an untrained policy.
 
-Success is counted over terminated episodes that were not cut by the 1000-step horizon (the reference's recorder lets an
-episode drain after the horizon instead; `max_step` is ~0 in its tables)."""
+Rates are over every agent that terminates inside whole scene episodes (1000 env steps of respawning, then the scene
+drains until its last agent ends -- MultiAgentMetaDrive.step's done["__all__"]), as the reference's recorder counts them."""
 import json
 import os
 
@@ -19,12 +19,11 @@ pytestmark = pytest.mark.gpu
 
 
 def _roll(algo, env, weights, lcf, n):
-    """One whole scene episode (1000 env steps, the reference's evaluation unit) of 64 scenes."""
+    """One whole scene episode (the reference's evaluation unit) of 64 scenes."""
     from copo_amd.eval.evaluate import evaluate_population
     r = evaluate_population(algo, env, weights, lcf, num_envs=64, num_agents=n, scene_episodes=1, seed=0)
-    cut = float(r["max_step_rate_mean"])
-    return dict(success=float(r["success_rate_mean"]) / max(1e-9, 1.0 - cut), crash=float(r["crash_rate_mean"]) / max(1e-9, 1.0 - cut),
-                out=float(r["out_of_road_rate_mean"]) / max(1e-9, 1.0 - cut), length=float(r["episode_length_mean"]),
+    return dict(success=float(r["success_rate_mean"]), crash=float(r["crash_rate_mean"]), out=float(r["out_of_road_rate_mean"]),
+                max_step=float(r["max_step_rate_mean"]), length=float(r["episode_length_mean"]),
                 velocity=float(r["velocity_mean"]), raw=r)
 
 

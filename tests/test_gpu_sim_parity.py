@@ -57,6 +57,7 @@ def test_rollout_bit_exact(map_name, N, E, lasers, steps, block):
     seeds = np.arange(E, dtype=np.uint64) * np.uint64(7919) + np.uint64(5000)
     _compare("reset", g.reset(seeds), o.reset(seeds))
     rng = np.random.RandomState(3)
+    resets = 0
     for t in range(steps):
         if t == 40:
             g.set_lcf_dist(0.4, 0.3)
@@ -65,11 +66,47 @@ def test_rollout_bit_exact(map_name, N, E, lasers, steps, block):
         go = g.step(torch.from_numpy(a).cuda())
         oo = o.step(a)
         _compare("%s step %d" % (map_name, t), go, oo)
+        resets += int(((oo["flags"] & 128) > 0).any(1).sum())
+    assert resets > 0 or steps < 150, "the rollout must run through the drain phase and a reset of some scene"
     gs, ge = g.get_state()
     os_, oe = o.get_state()
     assert np.array_equal(gs.cpu().numpy().view(np.uint32), os_.view(np.uint32))
     assert np.array_equal(ge.cpu().numpy()[:, :3], oe[:, :3])
     f = oo["flags"]
+    g.close()
+    o.close()
+
+
+def test_episode_structure_bit_exact():
+    """MultiAgentMetaDrive.step's episode: agents that drove `horizon` steps of their own end with max_step and linger
+    as obstacles, a scene past `horizon` env steps stops respawning, and it is reset with its last agent.  Half of the
+    agents stand still (-> max_step at their 25th step), the others drive."""
+    import torch
+    import oracle_lib as ol
+    from copo_amd.sim import SimConfig, VecSim
+    E, N, H = 4, 24, 25
+    cfg = SimConfig(map="intersection", num_envs=E, num_agents=N, horizon=H, delay_done=4, nbr_k=8)
+    g, o = VecSim(cfg), ol.OracleSim(cfg)
+    _compare("reset", g.reset(), o.reset())
+    rng = np.random.RandomState(11)
+    clock = np.zeros(E, np.int64)
+    n_max, n_reset, n_spawn_late = 0, 0, 0
+    for t in range(160):
+        a = _actions(rng, E, N, t)
+        a[:, ::2] = 0.0                                 # even slots: no steering, no throttle
+        go, oo = g.step(torch.from_numpy(a).cuda()), o.step(a)
+        _compare("step %d" % t, go, oo)
+        f = oo["flags"]
+        clock += 1
+        ended = ((f & 128) > 0).any(1)
+        ms = (f & 32) > 0
+        assert np.all(oo["info"][..., 5][ms] == H)
+        n_max += int(ms.sum())
+        n_reset += int(ended.sum())
+        n_spawn_late += int((((f & 64) > 0).any(1) & (clock >= H) & ~ended).sum())
+        assert np.all(clock[ended] >= H)
+        clock[ended] = 0
+    assert n_max > 20 and n_reset >= 8 and n_spawn_late == 0
     g.close()
     o.close()
 

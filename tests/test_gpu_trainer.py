@@ -121,8 +121,8 @@ def test_dict_env_api_matches_reference_surface():
     o = env.reset(force_seed=0)
     assert len(o) == 10 and all(v.shape == (92,) and v.dtype == np.float32 for v in o.values())
     assert set(o) == set(env.vehicles) and env.observation_space["agent0"].contains(o["agent0"])
-    seen_done, seen_spawn = False, False
-    for t in range(50):
+    seen_done, seen_spawn, seen_max_step = False, False, False
+    for t in range(250):
         before = set(env.vehicles)
         # every other vehicle steers off its road: terminations, wrecks that linger `delay_done` steps, respawns
         o, r, d, i = env.step({k: [0.6 if int(k[5:]) % 2 else 0.0, 1.0] for k in env.vehicles})
@@ -140,10 +140,14 @@ def test_dict_env_api_matches_reference_surface():
                 assert abs(inf["nei_rewards"] - np.mean([r[n] for n in inf["neighbours"] if n in r])) < 1e-5 or \
                     any(n not in r for n in inf["neighbours"])
             seen_done |= d[k]
-        seen_spawn |= len(set(o) - before) > 0
-        if d["__all__"]:
-            assert t == 49
+            # MultiAgentMetaDrive.done_function: an agent that drove `horizon` steps of its own is done with max_step
+            assert inf["max_step"] == (d[k] and inf["episode_length"] >= 50 and not (inf["arrive_dest"] or inf["crash"] or inf["out_of_road"]))
+            seen_max_step |= inf["max_step"]
+        if d["__all__"]:        # after `horizon` env steps the scene drains; the episode ends with its last agent
+            assert t >= 49 and all(d.values())
             break
+        assert t < 49 or set(o) <= before, "a scene past its horizon must not respawn"
+        seen_spawn |= len(set(o) - before) > 0
     assert seen_done and seen_spawn and d["__all__"]
     env.set_lcf_dist(0.5, 0.2)
     env.close()
