@@ -74,8 +74,13 @@ class VecSampler:
     """Time-major rollout buffers + the rollout loop.  Row (t, e, n) holds obs_t, the action sampled for it, and
     the reward / flags / neighbour lists / LCF produced by the step that executed that action."""
 
-    def __init__(self, vec_env, policy, T, use_graph=True):
+    def __init__(self, vec_env, policy, T, use_graph=True, stagger_episodes=False):
         self.env, self.sim, self.policy, self.T = vec_env, vec_env.sim, policy, int(T)
+        # E scenes stepped in lockstep all sit in the same phase of their episodes (`horizon` steps of dense traffic, then
+        # the drain): with stagger_episodes the FIRST episode of scene e starts at env step (e * horizon) // E instead of 0,
+        # so every fragment sees every phase (RLlib's 200-step fragments of 8 envs cycle through the phases every ~7
+        # iterations; 8-step fragments of 256 scenes take ~160)
+        self.stagger_episodes = bool(stagger_episodes)
         sim = self.sim
         E, N, O, K, dev = sim.E, sim.N, sim.O, sim.K, sim.device
         self.E, self.N, self.O, self.K, self.device = E, N, O, K, dev
@@ -110,6 +115,10 @@ class VecSampler:
             seeds = np.arange(sim.E, dtype=np.uint64) + np.uint64(sim.cfg.start_seed + 1000003 * D.rank())
         seeds = np.ascontiguousarray(seeds, np.uint64)
         sim._capi.check(sim._capi.lib.copo_sim_reset(sim._h, seeds.ctypes.data, C.byref(self._reset_out), sim._stream()))
+        if self.stagger_episodes and sim.E > 1:
+            st, env = sim.get_state()
+            env[:, 0] = (torch.arange(sim.E, device=env.device, dtype=torch.int64) * int(sim.cfg.horizon) // sim.E).to(torch.int32)
+            sim.set_state(st, env)
         torch.cuda.current_stream(self.device).synchronize()
         self._started = True
 
@@ -629,7 +638,8 @@ class VecTrainer:
         self.policy = pol_cls(cfg.observation_space, cfg.action_space, cfg)
         E = self.env.sim.E
         T = max(1, math.ceil(int(cfg["train_batch_size"]) / E))
-        self.sampler = VecSampler(self.env, self.policy, T, use_graph=cfg.get("use_hip_graphs", True))
+        self.sampler = VecSampler(self.env, self.policy, T, use_graph=cfg.get("use_hip_graphs", True),
+                                  stagger_episodes=cfg.get("stagger_episodes", False))
         self.workers = _LocalWorkerSet(self)
         self._episode_stats = defaultdict(float)
         if self.callbacks is not None and hasattr(self.callbacks, "on_algorithm_init"):
