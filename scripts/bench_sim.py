@@ -6,6 +6,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import torch
 
+if "--lib" in sys.argv:        # a profiling / comparison build of the library (never the default)
+    import copo_amd._libsel as _S
+    _S.PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 from copo_amd.sim import SimConfig, VecSim
 
 
@@ -69,6 +72,7 @@ if __name__ == "__main__":
     ap.add_argument("--E", type=int, nargs="+", default=[256, 1024, 4096, 16384])
     ap.add_argument("--blocks", type=int, nargs="+", default=[256, 512, 1024])
     ap.add_argument("--policy", default="random", choices=["random", "cruise"])
+    ap.add_argument("--lib", default=None)
     a = ap.parse_args()
     for E in a.E:
         for b in a.blocks:

@@ -29,15 +29,25 @@ def child(mask, E, block, path):
     acts = [torch.stack([torch.randn(E, 40, device="cuda", generator=gen) * 0.1, torch.rand(E, 40, device="cuda", generator=gen)], -1).contiguous() for _ in range(8)]
     if not os.path.exists(path):
         assert mask == 0
-        for i in range(60):
-            sim.step(acts[i % 8])
+        act = acts[0]
+        if os.environ.get("VALU_POLICY") == "cruise":     # populated scenes: lane-keeping controller, 250 closed-loop steps
+            sys.path.insert(0, ROOT)
+            from bench import cruise_actions
+            out = sim.step(act)
+            for i in range(250):
+                act = cruise_actions(out["obs"], gen)
+                if i < 249:
+                    out = sim.step(act)
+        else:
+            for i in range(60):
+                sim.step(acts[i % 8])
         st, env = sim.get_state()
-        torch.save(dict(st=st.cpu(), env=env.cpu()), path)
+        torch.save(dict(st=st.cpu(), env=env.cpu(), act=act.cpu()), path)
     d = torch.load(path)
-    st, env = d["st"].cuda(), d["env"].cuda()
+    st, env, act = d["st"].cuda(), d["env"].cuda(), d["act"].cuda()
     for i in range(12):
         sim.set_state(st, env)
-        out = sim.step(acts[0])
+        out = sim.step(act)
     torch.cuda.synchronize()
     print(json.dumps(dict(present=float(((out["flags"] & 0x41) != 0).sum()) / E)))
 
@@ -64,7 +74,7 @@ if __name__ == "__main__":
         sys.exit(0)
     E = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     block = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-    tmp = os.path.join("/tmp", "valu_split_E%d" % E)
+    tmp = os.path.join("/tmp", "valu_split_E%d_%s" % (E, os.environ.get("VALU_POLICY", "random")))
     os.makedirs(tmp, exist_ok=True)
     state = os.path.join(tmp, "state.pt")
     env = dict(os.environ, TMPDIR="/tmp")
