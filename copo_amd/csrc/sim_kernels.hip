@@ -469,8 +469,9 @@ __device__ __forceinline__ void ego_navi_obs(const SimParams& p, EnvLds& L, int 
     }
     if (p.toll_dim) {
         const uint32_t wait = (uint32_t)s.spawncnt >> 16;
-        row[p.col_toll] = (seg == (int)meta[2]) ? 1.0f : 0.0f;
-        row[p.col_toll + 1] = clipf((float)wait * p.inv_toll, 0.0f, 1.0f);
+        const bool in_booth = seg == (int)meta[2];      // [on the booth road, stayed longer than toll_min_steps], zeros off it
+        row[p.col_toll] = in_booth ? 1.0f : 0.0f;
+        row[p.col_toll + 1] = (in_booth && wait > (uint32_t)p.toll_min_steps) ? 1.0f : 0.0f;
     }
     if (p.col_lcf >= 0) row[p.col_lcf] = (s.lcf + 1.0f) * 0.5f;
 }

@@ -65,7 +65,9 @@ def make_eval_trainer(algo, env, num_envs=64, num_agents=40, seed=0, lcf=None, *
         cls, e = algo_ccppo.CCPPOTrainer, algo_ccppo.get_ccppo_env(base)
     else:
         cls, e = algo_ippo.IPPOTrainer, W.get_rllib_compatible_env(base)
-    cfg = dict(env=e, env_config=dict(num_agents=num_agents), num_envs=num_envs, train_batch_size=num_envs * 25, seed=seed)
+    extra = dict(extra)
+    cfg = dict(env=e, env_config=dict(extra.pop("env_config", None) or {}, num_agents=num_agents), num_envs=num_envs,
+               train_batch_size=num_envs * 25, seed=seed)
     cfg.update(extra)
     t = cls(config=cfg)
     if algo == "copo" and lcf is not None:

@@ -17,7 +17,7 @@ STATE_DIM, NAVI_DIM = 6, 10
 # per-map observation options of MetaDrive 0.2.5's multi-agent environments (first-layer shapes of the reference's
 # best_checkpoints: Intersection / Roundabout / ParkingLot 91, Bottleneck 96, Tollgate 156; +1 LCF column for CoPO)
 MAP_OBS_DEFAULTS = dict(
-    bottleneck=dict(side_lasers=4, side_range=20.0, lane_line_lasers=4, lane_line_range=20.0),
+    bottleneck=dict(side_lasers=4, side_range=50.0, lane_line_lasers=4, lane_line_range=20.0),
     tollgate=dict(side_lasers=72, side_range=20.0, lane_line_lasers=4, lane_line_range=20.0, navi_dim=0, toll_dim=2),
 )
 

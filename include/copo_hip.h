@@ -141,7 +141,7 @@ typedef struct copo_sim_cfg {
     int32_t lane_line_lasers;       /* lane-line detector beams (all lines) */
     float side_range, lane_line_range;
     int32_t navi_dim;               /* 10, or 0 (Tollgate) */
-    int32_t toll_dim;               /* 0, or 2 (Tollgate: in-booth mark, waited fraction) */
+    int32_t toll_dim;               /* 0, or 2 (Tollgate: on the booth road; stayed there longer than toll_min_steps -- zeros off it) */
     int32_t toll_min_steps;         /* steps a vehicle has to spend in a booth (30) */
     int32_t n_lines;
     const float* lines;             /* [n_lines][COPO_LINE_STRIDE] (HOST) */

@@ -568,10 +568,11 @@ static void write_obs(oracle_sim* s, int e, const copo_step_out* out, const uint
             lid[k] = best * s->inv_range;
         }
         col += L;
-        if (c->toll_dim) {              /* Tollgate: in-booth mark and the waited fraction of `toll_min_steps` */
+        if (c->toll_dim) {              /* Tollgate: [on the booth road, stayed longer than `toll_min_steps`], zeros off it */
             uint32_t wait = (uint32_t)IP(s, S_SPAWNCNT, e)[i] >> 16;
-            o[col++] = (seg == (int)meta[2]) ? 1.0f : 0.0f;
-            o[col++] = o_clip((float)wait * s->inv_toll, 0.0f, 1.0f);
+            int in_booth = (seg == (int)meta[2]);
+            o[col++] = in_booth ? 1.0f : 0.0f;
+            o[col++] = (in_booth && wait > (uint32_t)c->toll_min_steps) ? 1.0f : 0.0f;
         }
         if (c->add_traffic_light) {     /* counter = steps since the last reset (env word 0 is already advanced) */
             traffic_light_cols(c, s->env[e * 4], x, y, o + col);

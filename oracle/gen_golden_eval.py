@@ -79,6 +79,14 @@ def populations():
         if name in G.meta_svo_lookup_table:
             save[name + "/lcf"] = np.array(G.meta_svo_lookup_table[name])
     np.savez_compressed(os.path.join(OUT, "reference_populations.npz"), **save)
+    save = {}       # the Tollgate / Bottleneck populations (f-4 scenes: 156- / 96-wide first layers)
+    for name in ("ippo_tollgate", "copo_tollgate", "ippo_bottle", "copo_bottle"):
+        w = dict(np.load(os.path.join(CKPT, name + ".npz")))
+        for k, v in w.items():
+            save["%s/w/%s" % (name, k)] = v
+        if name in G.meta_svo_lookup_table:
+            save[name + "/lcf"] = np.array(G.meta_svo_lookup_table[name])
+    np.savez_compressed(os.path.join(OUT, "reference_populations_f4.npz"), **save)
     res_dir = os.path.join(os.path.dirname(os.path.abspath(G.__file__)), "demo_results", "evaluate_results")
     cols = ["success_rate", "crash_rate", "out_rate", "episode_length_mean", "success_episode_length_mean",
             "velocity_step_mean_episode_mean", "episode_reward_mean", "num_agents_total"]

@@ -65,3 +65,24 @@ def test_reference_roundabout_populations_drive_the_hip_simulator(golden_dir):
     # training-time success in MetaDrive (benchmarks/MetaDrive-0.2.5/README.md:19-31): IPPO 66 %, CoPO 73 %
     assert ippo["success"] > 0.45 and copo["success"] > 0.45, (ippo, copo)
     assert ippo["out"] < 0.1 and copo["out"] < 0.1
+
+
+def test_reference_tollgate_and_bottleneck_populations(golden_dir):
+    """f-4 scenes.  MetaDrive's source would settle the detector ranges and the booth rule; the populations the reference
+    trained there (156- / 96-wide first layers) settle them here: the side detector of the Bottleneck reaches 50 m (with
+    20 m CoPO's population crashes in the merge: 28 % success, 35 % crashes; with 50 m 51 % / 6 %), the second toll column is
+    the binary "stayed longer than min_pass_steps" mark (with a waited fraction the populations leave the booth early: 10 %).
+    Bands around the reference's own training table (benchmarks/MetaDrive-0.2.5/README.md:19-25: Bottleneck IPPO 24 +- 19,
+    CoPO 47 +- 19; Tollgate IPPO 4 +- 3, CoPO 27 +- 26)."""
+    gold = np.load(os.path.join(golden_dir, "reference_populations_f4.npz"))
+    from copo_amd.eval.get_policy_function import meta_svo_lookup_table
+    copo_b = _roll("copo", "bottle", _weights(gold, "copo_bottle"), meta_svo_lookup_table["copo_bottle"], 20)
+    ippo_b = _roll("ippo", "bottle", _weights(gold, "ippo_bottle"), None, 20)
+    copo_t = _roll("copo", "tollgate", _weights(gold, "copo_tollgate"), meta_svo_lookup_table["copo_tollgate"], 40)
+    ippo_t = _roll("ippo", "tollgate", _weights(gold, "ippo_tollgate"), None, 40)
+    print("copo_bottle", copo_b, "\nippo_bottle", ippo_b, "\ncopo_tollgate", copo_t, "\nippo_tollgate", ippo_t)
+    assert 0.35 < copo_b["success"] < 0.75 and copo_b["crash"] < 0.2, copo_b
+    assert 0.15 < ippo_b["success"] < 0.6, ippo_b
+    assert 0.15 < copo_t["success"] < 0.6, copo_t
+    assert ippo_t["success"] < 0.15, ippo_t          # IPPO does not learn the booth rule in the reference either
+    assert copo_t["success"] > ippo_t["success"] + 0.1
