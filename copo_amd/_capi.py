@@ -51,7 +51,7 @@ class PpoCfg(C.Structure):
         ("mb", C.c_int32), ("hidden", C.c_int32), ("act_dim", C.c_int32), ("n_value_heads", C.c_int32),
         ("pack_width", C.c_int32), ("col_actions", C.c_int32), ("col_logp", C.c_int32), ("col_dist", C.c_int32),
         ("col_adv", C.c_int32), ("col_meta_adv", C.c_int32), ("col_vpred", C.c_int32 * 3), ("col_vtarget", C.c_int32 * 3),
-        ("use_kl", C.c_int32), ("old_value_loss", C.c_int32),
+        ("use_kl", C.c_int32), ("old_value_loss", C.c_int32), ("operand_dtype", C.c_int32), ("reserved0", C.c_int32),
         ("clip_param", C.c_float), ("vf_clip_param", C.c_float), ("vf_loss_coeff", C.c_float), ("entropy_coeff", C.c_float),
         ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
         ("pol", NetLayout), ("val", NetLayout * 3), ("n_params", C.c_int64),
@@ -59,6 +59,7 @@ class PpoCfg(C.Structure):
 
 
 HEAD_PPO, HEAD_META_NEW, HEAD_META_OLD = 0, 1, 2
+OPERAND_F32, OPERAND_BF16 = 0, 1
 PPO_STATS = 8
 META_DOT_PARTIALS = 8192
 

@@ -68,10 +68,14 @@ static hipError_t gemm_lds_attrs() {
         for (const void* f : {reinterpret_cast<const void*>(rowpass_kernel<1, 4, false>), reinterpret_cast<const void*>(rowpass_kernel<2, 4, false>),
                               reinterpret_cast<const void*>(rowpass_kernel<2, 8, false>), reinterpret_cast<const void*>(rowpass_kernel<4, 8, false>),
                               reinterpret_cast<const void*>(rowpass_kernel<1, 4, true>), reinterpret_cast<const void*>(rowpass_kernel<2, 4, true>),
-                              reinterpret_cast<const void*>(rowpass_kernel<2, 8, true>), reinterpret_cast<const void*>(rowpass_kernel<4, 8, true>)})
+                              reinterpret_cast<const void*>(rowpass_kernel<2, 8, true>), reinterpret_cast<const void*>(rowpass_kernel<4, 8, true>),
+                              reinterpret_cast<const void*>(rowpass_kernel<1, 4, true, true>), reinterpret_cast<const void*>(rowpass_kernel<2, 4, true, true>),
+                              reinterpret_cast<const void*>(rowpass_kernel<2, 8, true, true>), reinterpret_cast<const void*>(rowpass_kernel<4, 8, true, true>)})
             if ((r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) != hipSuccess) e = r;
         for (const void* f : {reinterpret_cast<const void*>(mlp_fwd_kernel<1, 4>), reinterpret_cast<const void*>(mlp_fwd_kernel<2, 4>),
-                              reinterpret_cast<const void*>(mlp_fwd_kernel<2, 8>), reinterpret_cast<const void*>(mlp_fwd_kernel<4, 8>)})
+                              reinterpret_cast<const void*>(mlp_fwd_kernel<2, 8>), reinterpret_cast<const void*>(mlp_fwd_kernel<4, 8>),
+                              reinterpret_cast<const void*>(mlp_fwd_kernel<1, 4, true>), reinterpret_cast<const void*>(mlp_fwd_kernel<2, 4, true>),
+                              reinterpret_cast<const void*>(mlp_fwd_kernel<2, 8, true>), reinterpret_cast<const void*>(mlp_fwd_kernel<4, 8, true>)})
             if ((r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) != hipSuccess) e = r;
         if ((r = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_adam_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)) != hipSuccess) e = r;
         return e;
@@ -152,11 +156,15 @@ hipError_t launch_fused_step(FusedArgs a, hipStream_t s, const MetaTail* mt_ = n
     if (part == 2) vec = vec && ((reinterpret_cast<uintptr_t>(a.ws0) & 15) == 0);
     const bool rowpass = (vec || tw_ok) && !mbatch && g_use_rowpass && (rp_h == 64 || rp_h == 128 || rp_h == 256 || rp_h == 512) &&
                          rp_lds <= 150 * 1024;
+    // bfloat16 operands: only the row pass + fused weight-gradient kernels round where torch.autocast rounds
+    const bool bf = c.operand_dtype == COPO_OPERAND_BF16;
+    if (bf && !(rowpass && tw && tw_ok && a.head_mode == COPO_HEAD_PPO && g_use_wgrad)) return hipErrorInvalidValue;
     if (rowpass) {
         const dim3 grid(head_tiles(c), G);
 #define COPO_RP(NT_, W_)                                                                                       \
         do {                                                                                                   \
-            if (tw) hipLaunchKernelGGL((rowpass_kernel<NT_, W_, true>), grid, dim3(64 * W_), rp_lds, s, a);      \
+            if (bf) hipLaunchKernelGGL((rowpass_kernel<NT_, W_, true, true>), grid, dim3(64 * W_), rp_lds, s, a); \
+            else if (tw) hipLaunchKernelGGL((rowpass_kernel<NT_, W_, true>), grid, dim3(64 * W_), rp_lds, s, a); \
             else hipLaunchKernelGGL((rowpass_kernel<NT_, W_, false>), grid, dim3(64 * W_), rp_lds, s, a);        \
         } while (0)
         switch (rp_h) {
@@ -181,7 +189,8 @@ hipError_t launch_fused_step(FusedArgs a, hipStream_t s, const MetaTail* mt_ = n
         const int nty = (c.hidden + 32 * ot - 1) / (32 * ot), wx2 = (c.hidden + 1 + 31) / 32, wx1 = (kmax1 + 1 + 31) / 32;
         const dim3 grid((wx2 + wx1) * nty + wx2, G);
         const size_t lds = (size_t)WG_WAVES * 32 * ot * 33 * sizeof(float);
-        if (ot == 2) hipLaunchKernelGGL((wgrad_adam_kernel<2>), grid, dim3(64 * WG_WAVES), lds, s, a, nty, wx2, wx1);
+        if (bf) hipLaunchKernelGGL((wgrad_adam_kernel<1, true>), grid, dim3(64 * WG_WAVES), (size_t)WG_WAVES * 32 * 33 * sizeof(float), s, a, nty, (c.hidden + 1 + 31) / 32, wx1);
+        else if (ot == 2) hipLaunchKernelGGL((wgrad_adam_kernel<2>), grid, dim3(64 * WG_WAVES), lds, s, a, nty, wx2, wx1);
         else hipLaunchKernelGGL((wgrad_adam_kernel<1>), grid, dim3(64 * WG_WAVES), lds, s, a, nty, wx2, wx1);
         return hipGetLastError();
     }
@@ -251,6 +260,7 @@ static int check_cfg(const copo_ppo_cfg* c) {
         c->n_value_heads < 0 || c->n_value_heads > 3 || c->n_params < 1)
         return COPO_ERR_DIM;
     if (c->pol.out_dim != 4) return COPO_ERR_DIM;
+    if (c->operand_dtype != COPO_OPERAND_F32 && c->operand_dtype != COPO_OPERAND_BF16) return COPO_ERR_DIM;
     for (int g = 0; g < c->n_value_heads; ++g)
         if (c->val[g].out_dim != 1) return COPO_ERR_DIM;
     return COPO_OK;
@@ -316,12 +326,18 @@ static int mlp_forward(const copo_ppo_cfg* cfg, const float* theta, const float*
               action, logp, clipped, rows, rows ? n_out : n_rows};
     const dim3 grid((unsigned)((n_rows + HT - 1) / HT), n_nets);
     hipStream_t st = static_cast<hipStream_t>(stream);
+#define COPO_FWD(NT_, W_)                                                                                       \
+        do {                                                                                                   \
+            if (cfg->operand_dtype == COPO_OPERAND_BF16) hipLaunchKernelGGL((mlp_fwd_kernel<NT_, W_, true>), grid, dim3(64 * W_), lds, st, a); \
+            else hipLaunchKernelGGL((mlp_fwd_kernel<NT_, W_>), grid, dim3(64 * W_), lds, st, a);                 \
+        } while (0)
     switch (H) {
-        case 64: hipLaunchKernelGGL((mlp_fwd_kernel<1, 4>), grid, dim3(256), lds, st, a); break;
-        case 128: hipLaunchKernelGGL((mlp_fwd_kernel<2, 4>), grid, dim3(256), lds, st, a); break;
-        case 256: hipLaunchKernelGGL((mlp_fwd_kernel<2, 8>), grid, dim3(512), lds, st, a); break;
-        default: hipLaunchKernelGGL((mlp_fwd_kernel<4, 8>), grid, dim3(512), lds, st, a); break;
+        case 64: COPO_FWD(1, 4); break;
+        case 128: COPO_FWD(2, 4); break;
+        case 256: COPO_FWD(2, 8); break;
+        default: COPO_FWD(4, 8); break;
     }
+#undef COPO_FWD
     return hipGetLastError() == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
 }
 

@@ -89,6 +89,7 @@ class FusedLearner:
         c.pol = pol
         c.use_kl = 1 if cfg["kl_coeff"] > 0.0 else 0
         c.old_value_loss = 1 if cfg["old_value_loss"] else 0
+        c.operand_dtype = _capi.OPERAND_BF16 if getattr(policy, "autocast_dtype", None) is torch.bfloat16 else _capi.OPERAND_F32
         c.clip_param, c.vf_clip_param = float(cfg["clip_param"]), float(cfg["vf_clip_param"])
         c.vf_loss_coeff, c.entropy_coeff = float(cfg["vf_loss_coeff"]), float(policy.entropy_coeff)
         c.lr, c.beta1, c.beta2, c.eps = float(cfg["lr"]), 0.9, 0.999, 1e-8

@@ -192,14 +192,17 @@ class PPOPolicyBase:
         self._flat_grad = None
         self._sgd = None
         self._row_sources = None
-        # fused HIP learner (7 launches per minibatch step instead of ~250 autograd kernels); fp32 only
+        # fused HIP learner (2 launches per minibatch step instead of ~250 autograd kernels).  A bfloat16 policy
+        # (`policy_dtype`, BASELINE configs[3]) runs the same kernels in their bfloat16-operand mode (fp32 parameters, Adam and
+        # losses, as torch.autocast keeps them); the LCF meta pass has no such mode, so bfloat16 CoPO stays on autocast
         self.fused = None
-        if bool(config.get("use_fused_learner", True)) and cuda and self.autocast_dtype is None and not config.get("grad_clip"):
+        if bool(config.get("use_fused_learner", True)) and cuda and not config.get("grad_clip"):
             from .fused import FusedLearner
             adv_key, meta_key = self.fused_adv_keys()
-            self.fused = FusedLearner(self, self.train_columns(), int(config["sgd_minibatch_size"]), adv_key, meta_key)
-            # writers that only hold the nn.Module (checkpoint_io.load_policy_weights) reach the mirror through this hook
-            object.__setattr__(self.model, "_on_external_write", self._weights_changed)
+            if self.autocast_dtype is None or meta_key is None:
+                self.fused = FusedLearner(self, self.train_columns(), int(config["sgd_minibatch_size"]), adv_key, meta_key)
+                # writers that only hold the nn.Module (checkpoint_io.load_policy_weights) reach the mirror through this hook
+                object.__setattr__(self.model, "_on_external_write", self._weights_changed)
 
     # ---- construction / inference --------------------------------------------------------------------
     def make_model(self, name):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define COPO_ABI_VERSION 2
+#define COPO_ABI_VERSION 3
 
 #define COPO_OK 0
 #define COPO_ERR_NULL (-1)      /* required pointer is NULL */
@@ -290,6 +290,8 @@ typedef struct copo_net_layout {
 #define COPO_META_BATCH_MAX 256        /* minibatches per copo_meta_batch_grads_f32 call */
 #define COPO_META_DOT_PARTIALS 8192 /* doubles in the `dot_partials` workspace of the meta update */
 #define COPO_PPO_MAX_KSPLIT 4  /* row splits of the weight-gradient GEMMs (fixed order -> deterministic sums) */
+#define COPO_OPERAND_F32 0
+#define COPO_OPERAND_BF16 1
 #define COPO_PPO_STATS 8       /* sums of: total, policy, vf_ego, kl, entropy, vf_nei, vf_glob, advantage  */
 
 typedef struct copo_ppo_cfg {
@@ -301,6 +303,11 @@ typedef struct copo_ppo_cfg {
     int32_t col_actions, col_logp, col_dist, col_adv, col_meta_adv;  /* pack columns */
     int32_t col_vpred[3], col_vtarget[3];
     int32_t use_kl, old_value_loss;
+    int32_t operand_dtype;     /* COPO_OPERAND_F32, or COPO_OPERAND_BF16: the `policy_dtype = bfloat16` configuration -- inputs,
+                                  weights, activations and activation gradients are rounded to bfloat16 wherever torch.autocast
+                                  rounds them, products accumulate in fp32 (the arithmetic of v_mfma_f32_*_bf16); parameters,
+                                  Adam and the losses stay fp32.  Row-pass shapes, PPO head mode and copo_mlp_forward_f32 only. */
+    int32_t reserved0;
     float clip_param, vf_clip_param, vf_loss_coeff, entropy_coeff;
     float lr, beta1, beta2, eps;   /* Adam (torch.optim.Adam semantics, no weight decay) */
     copo_net_layout pol, val[3];

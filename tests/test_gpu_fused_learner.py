@@ -126,6 +126,80 @@ def test_fused_sgd_matches_torch(name, fuse, odim, over):
         assert float(diff.max()) <= 3 * 2 * 3e-4 + 1e-6, (n1, float(diff.max()))
 
 
+@pytest.mark.parametrize("name,fuse,odim", [("ccppo", "mf", 156), ("ippo", "none", 91)])
+def test_fused_bf16_operand_mode_matches_autocast(name, fuse, odim):
+    """`policy_dtype = bfloat16` (BASELINE configs[3]: CCPPO mean-field, Tollgate's 156-wide observation): the fused kernels
+    round inputs, weights, activations and activation gradients where torch.autocast rounds them and accumulate in fp32 --
+    forward outputs, loss statistics and every parameter gradient against the autocast step of the same policy, to bfloat16
+    accuracy (2^-8 per rounding); then real steps against torch.optim.Adam."""
+    R, mb = 1500, 512
+    ref = _make(name, fuse, odim, fused=False, policy_dtype="bfloat16")
+    fz = _make(name, fuse, odim, fused=True, policy_dtype="bfloat16")
+    assert fz.fused is not None and ref.fused is None and fz.fused.cfg.operand_dtype == 1
+    with torch.no_grad():
+        for p in ref.model.parameters():
+            if p.dtype == torch.float32:
+                p.add_(torch.randn_like(p) * 0.05)
+    _copy_weights(fz, ref)
+    fz.fused.invalidate_mirror()
+    batch = _dense_batch(ref, R, odim)
+    # forward: sampled actions / distribution inputs of the rollout kernel against the autocast model
+    obs = batch[SampleBatch.OBS].contiguous()
+    eps = torch.randn(R, 2, device="cuda")
+    act_r, logp_r, di_r = ref.compute_actions(obs, eps)
+    fz.fused.sync_mirror()
+    act_f, logp_f, di_f = (torch.empty(R, 2, device="cuda"), torch.empty(R, device="cuda"), torch.empty(R, 4, device="cuda"))
+    fz.fused.act(obs, eps, act_f, logp_f, di_f)
+    torch.cuda.synchronize()
+    assert float((di_r - di_f).abs().max()) < 0.03 * max(1.0, float(di_r.abs().max())), float((di_r - di_f).abs().max())
+    assert float((act_r - act_f).abs().max()) < 0.05
+    idx = torch.arange(R, device="cuda")[torch.randperm(R, device="cuda")][:1337].contiguous()
+    B = int(idx.numel())
+    for pol in (ref, fz):
+        pol.prepare_sgd(batch, R, mb)
+        torch.manual_seed(11)
+        pol.plan_epoch(idx, B, [B], mb)
+    ref._ensure_flat_grads()
+    ref._forward_backward()
+    fz.fused.stats.zero_()
+    fz.fused.step(fz._row_sources, apply_adam=False, stats=fz.fused.stats, bump_index=False)
+    g_ref = ref._flat_grad
+    off = fz.fused.flat.offset
+    g_fz = torch.cat([fz.fused.grad[off[id(p)]:off[id(p)] + p.numel()] for p in fz.model.parameters()
+                      if p.dtype == torch.float32])
+    assert float((g_fz - bf16_round(g_fz)).abs().max()) == 0.0          # weight gradients are bfloat16 tensors
+    rel = float((g_ref - g_fz).norm() / g_ref.norm())
+    assert rel < 0.02, rel
+    # against the fp32 kernels the difference must be of bfloat16 size, not zero: the mode really rounds
+    f32 = _make(name, fuse, odim, fused=True)
+    _copy_weights(f32, ref)
+    f32.fused.invalidate_mirror()
+    f32.prepare_sgd(batch, R, mb)
+    torch.manual_seed(11)
+    f32.plan_epoch(idx, B, [B], mb)
+    f32.fused.step(f32._row_sources, apply_adam=False, stats=f32.fused.stats, bump_index=False)
+    g32 = torch.cat([f32.fused.grad[off[id(p)]:off[id(p)] + p.numel()] for p in fz.model.parameters() if p.dtype == torch.float32])
+    r32 = float((g32 - g_fz).norm() / g32.norm())
+    assert 1e-4 < r32 < 0.02, r32
+    st = ref._row_sources["stats"].tolist()
+    fs = fz.fused.stats.tolist()
+    np.testing.assert_allclose(fs[:5], st[:5], rtol=2e-2, atol=2e-3)
+    ref._row_sources["k"].zero_()
+    for _ in range(2):
+        ref._forward_backward()
+        ref._apply()
+        fz.fused.step(fz._row_sources, stats=fz.fused.stats)
+    for (n1, p1), (n2, p2) in zip(ref.model.named_parameters(), fz.model.named_parameters()):
+        if p1.dtype == torch.float32:
+            diff = (p1 - p2).abs()       # Adam's first steps are ~lr * sign(g): only gradients at the rounding floor may flip
+            assert float((diff > 3e-5).float().mean()) < 0.05, (n1, float((diff > 3e-5).float().mean()))
+            assert float(diff.max()) <= 2 * 2 * 3e-4 + 1e-6, (n1, float(diff.max()))
+
+
+def bf16_round(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
 def test_fused_meta_update_matches_autograd():
     """Grouped META pass + fp64 LCF kernels == CoPOPolicy.meta_update's autograd path (algo_copo.py:228-309):
     both policy gradients, the LCF loss terms, grad_value, and the LCF parameters after real Adam steps."""

@@ -190,7 +190,8 @@ def test_baseline_parity_configs_run(name, algo, map_cls, cfg):
     cfg.setdefault("train_batch_size", cfg["num_envs"] * 4)
     a = cls(config=cfg)
     if name.startswith("C4"):
-        assert a.policy.fused is None and a.policy.autocast_dtype == torch.bfloat16
+        # the bfloat16 policy runs the fused HIP learner in its bfloat16-operand mode (no torch.autocast fallback)
+        assert a.policy.fused is not None and a.policy.fused.cfg.operand_dtype == 1 and a.policy.autocast_dtype == torch.bfloat16
         # Tollgate: O = 156 (72 side beams + 6 + 4 lane-line beams + 72 LiDAR + 2 toll columns), mean-field cc-obs 2 * 156 + 2
         assert a.env.sim.O == 156 and a.policy.model.get_centralized_critic_obs_dim() == 2 * 156 + 2 == 314
     if name == "C1":
