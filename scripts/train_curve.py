@@ -10,7 +10,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--algo", default="copo")
 ap.add_argument("--map", default="MultiAgentIntersectionEnv")
 ap.add_argument("--num-envs", type=int, default=256)
-ap.add_argument("--num-agents", type=int, default=40)
+ap.add_argument("--num-agents", type=int, default=0, help="0: the map's own population (Inter 30, Round 40, Bottle 20, Toll 40, Parking 10)")
 ap.add_argument("--stop", type=int, default=1_000_000)
 ap.add_argument("--every", type=int, default=25)
 ap.add_argument("--seed", type=int, default=0)
@@ -24,10 +24,10 @@ else:
     cls, env = IPPOTrainer, W.get_rllib_compatible_env(base)
 T = max(1, -(-2000 // a.num_envs))
 import json
-algo = cls(config=dict(env=env, env_config=dict(json.loads(a.env_config), num_agents=a.num_agents), num_envs=a.num_envs, train_batch_size=T * a.num_envs,
+algo = cls(config=dict(env=env, env_config=dict(json.loads(a.env_config), **(dict(num_agents=a.num_agents) if a.num_agents > 0 else {})), num_envs=a.num_envs, train_batch_size=T * a.num_envs,
                        seed=a.seed, callbacks=MultiAgentDrivingCallbacks, stagger_episodes=bool(a.stagger)))
 t0 = time.time()
-print("# %s %s E=%d N=%d seed=%d: iter env_steps agent_steps wall_s success crash out max_step ep_reward lcf kl agents_finished velocity_m_s episode_len (rates over the agents that finished since the previous line)" % (a.algo, a.map, a.num_envs, a.num_agents, a.seed))
+print("# %s %s E=%d N=%d seed=%d: iter env_steps agent_steps wall_s success crash out max_step ep_reward lcf kl agents_finished velocity_m_s episode_len (rates over the agents that finished since the previous line)" % (a.algo, a.map, a.num_envs, algo.env.sim.N, a.seed))
 KEYS = ("success_rate_mean", "crash_rate_mean", "out_of_road_rate_mean", "max_step_rate_mean", "episode_reward_mean")
 win = dict.fromkeys(KEYS, 0.0)      # rates over ALL agents that terminated since the last printed line
 win_n = 0.0
