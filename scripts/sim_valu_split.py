@@ -13,7 +13,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NAMES = {0: "everything (nothing skipped)", 1: "neighbour lists", 2: "LiDAR windows + box tests", 4: "LiDAR write-out",
-         8: "state / navigation block", 16: "collision pairs", 32: "respawn", 64: "projection / termination", 127: "all of the above"}
+         8: "state / navigation block", 16: "collision pairs", 32: "respawn", 64: "projection / termination", 127: "all of the above",
+         3: "neighbours + LiDAR tests", 6: "LiDAR tests + write-out", 7: "neighbours + all LiDAR"}
 
 
 def child(mask, E, block, path):
@@ -96,7 +97,7 @@ if __name__ == "__main__":
         per = {k: c[k] / E for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS")}
         if mask == 0:
             base = per
-        msg = "skip %3d  %-36s VALU %7.0f  SALU %6.0f  LDS %6.0f per scene" % (mask, name, per["SQ_INSTS_VALU"], per["SQ_INSTS_SALU"], per["SQ_INSTS_LDS"])
+        msg = "skip %3d  %-36s VALU %7.0f  SALU %6.0f  LDS %6.0f per scene  %7.1f us" % (mask, name, per["SQ_INSTS_VALU"], per["SQ_INSTS_SALU"], per["SQ_INSTS_LDS"], c.get("avg_us", float("nan")))
         if base is not None and mask:
             msg += "   -> phase: VALU %6.0f (%4.1f %%)  SALU %6.0f  LDS %5.0f" % (
                 base["SQ_INSTS_VALU"] - per["SQ_INSTS_VALU"], 100 * (base["SQ_INSTS_VALU"] - per["SQ_INSTS_VALU"]) / base["SQ_INSTS_VALU"],
