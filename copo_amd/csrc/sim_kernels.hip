@@ -284,6 +284,11 @@ __device__ __forceinline__ void neighbours_phase(const SimParams& p, EnvLds& L, 
     for (int ia0 = 0; ia0 < np; ia0 += CH) {
         const int cha = np - ia0 < CH ? np - ia0 : CH;                   // lists of this pass: present agents ia0 .. ia0 + cha - 1
         // ---- 1. candidate pairs -------------------------------------------------------------------------------------
+        // (a) one lane per ordered pair: an fp32 distance decides which pairs CAN be in range; those are appended to the
+        //     list of i.  (b) one lane per appended entry evaluates the reference's fp64 expression -- a batch of 64 pairs
+        //     almost always holds a candidate, so evaluating in (a) ran the fp64 block for every batch; the entries are
+        //     ~30 % of the pairs.  A candidate that turns out to be outside (the fp32 test errs by < 1e-5 relative: a 0.2 mm
+        //     shell) keeps its place with distance +inf: it sorts behind every neighbour and is counted out (ncnt >> 16).
         {
             const int npair = cha * np;
             const float inv_cha = 1.0f / (float)cha;
@@ -293,24 +298,15 @@ __device__ __forceinline__ void neighbours_phase(const SimParams& p, EnvLds& L, 
                 const int ib = live ? (int)(((float)c + 0.5f) * inv_cha) : 0;
                 const int la = live ? c - ib * cha : 0;                   // consecutive lanes: consecutive LISTS (no counter clash)
                 const int i = L.plist[ia0 + la], j = L.plist[ib];
-                const float xi = L.x[i], yi = L.y[i], xj = L.x[j], yj = L.y[j];
-                const float fx = xi - xj, fy = yi - yj;
-                bool inr = false;
-                double d = 0.0;
-                if (live && i != j && fx * fx + fy * fy < r2hi) {
-                    const double dx = (double)xi - (double)xj, dy = (double)yi - (double)yj;
-                    d = sqrt(dx * dx + dy * dy);
-                    inr = d < R;
-                }
-                const unsigned long long m = __ballot(inr);
+                const float fx = L.x[i] - L.x[j], fy = L.y[i] - L.y[j];
+                const bool cand = live && i != j && fx * fx + fy * fy < r2hi;
+                const unsigned long long m = __ballot(cand);
                 if (m) {
                     unsigned int e0 = 0;
                     if (lane == 0) e0 = atomicAdd(&L.n_entries, (unsigned int)__popcll(m));
                     e0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)e0);
-                    if (inr) {
-                        const unsigned int pos = atomicAdd(&L.ncnt[i], 1u);
-                        if (d <= M) atomicAdd(&L.mfc[i], 1u);
-                        nb_d[la * N + pos] = d;
+                    if (cand) {
+                        const unsigned int pos = atomicAdd(&L.ncnt[i], 1u) & 0xffffu;
                         nb_j[la * N + pos] = (uint8_t)j;
                         ent[e0 + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((la << 8) | pos);
                     }
@@ -318,27 +314,51 @@ __device__ __forceinline__ void neighbours_phase(const SimParams& p, EnvLds& L, 
             }
         }
         __syncthreads();
-        // ---- 2. ranks, first K entries of every list ------------------------------------------------------------------
         const int T = (int)L.n_entries;
         for (int q = tid; q < T; q += nthreads) {
             const unsigned int pk = ent[q];
             const int la = (int)(pk >> 8), pos = (int)(pk & 255u);
+            const int i = L.plist[ia0 + la], j = nb_j[la * N + pos];
+            const double dx = (double)L.x[i] - (double)L.x[j], dy = (double)L.y[i] - (double)L.y[j];
+            double d = sqrt(dx * dx + dy * dy);
+            if (d < R) {
+                if (d <= M) atomicAdd(&L.mfc[i], 1u);
+            } else {
+                d = __longlong_as_double(0x7ff0000000000000ll);
+                atomicAdd(&L.ncnt[i], 0x10000u);
+            }
+            nb_d[la * N + pos] = d;
+        }
+        __syncthreads();
+        // ---- 2. ranks, first K entries of every list ------------------------------------------------------------------
+        for (int q = tid; q < T; q += nthreads) {
+            const unsigned int pk = ent[q];
+            const int la = (int)(pk >> 8), pos = (int)(pk & 255u);
             const int i = L.plist[ia0 + la];
-            const int cnt = (int)L.ncnt[i];
+            const int cnt = (int)(L.ncnt[i] & 0xffffu);       // candidates (the +inf ones rank last)
             const double d = nb_d[la * N + pos];
             const int j = nb_j[la * N + pos];
+            // rank = entries of the list that sort before this one by (d, slot).  Distances are >= 0, so the upper word of
+            // the fp64 pattern orders them except when two upper words agree (distances within 1e-6 of each other: rare) --
+            // only then are the full values and the slots compared
+            const unsigned int* nb_hi = reinterpret_cast<const unsigned int*>(nb_d) + 1;
+            const unsigned int dh = nb_hi[2 * (la * N + pos)];
             int rank = 0;
             for (int k = 0; k < cnt; ++k) {
-                const double dk = nb_d[la * N + k];
-                const int jk = nb_j[la * N + k];
-                rank += (dk < d || (dk == d && jk < j)) ? 1 : 0;
+                const unsigned int dkh = nb_hi[2 * (la * N + k)];
+                rank += dkh < dh ? 1 : 0;
+                if (__ballot(dkh == dh && k != pos) != 0ull) {
+                    const double dk = nb_d[la * N + k];
+                    const int jk = nb_j[la * N + k];
+                    rank += (dkh == dh && (dk < d || (dk == d && jk < j))) ? 1 : 0;
+                }
             }
             nb_rk[la * N + pos] = (uint8_t)rank;
-            if (rank < K) {
+            if (rank < K && dh != 0x7ff00000u) {
                 if (out.nbr_idx) out.nbr_idx[(base + i) * K + rank] = j;
                 if (out.nbr_dist) out.nbr_dist[(base + i) * K + rank] = (float)d;
             }
-            if (comm && rank < p.comm_nb) {
+            if (comm && rank < p.comm_nb && dh != 0x7ff00000u) {
                 float* qm = out.obs + (base + i) * p.O + p.col_comm + rank * CD;
                 const bool spoke = !fresh && ((acted_mask >> j) & 1ull) && act != nullptr;
                 for (int k = 0; k < CS; ++k) qm[k] = spoke ? act[(base + j) * p.act_dim + 2 + k] : 0.0f;
@@ -370,7 +390,7 @@ __device__ __forceinline__ void neighbours_phase(const SimParams& p, EnvLds& L, 
         if (wave == tail_wave) {       // one lane per list of this pass
             if (lane < cha) {
                 const int i = L.plist[ia0 + lane];
-                const int cnt = (int)L.ncnt[i];
+                const int cnt = (int)(L.ncnt[i] & 0xffffu) - (int)(L.ncnt[i] >> 16);       // candidates - those outside
                 if (out.nbr_cnt) out.nbr_cnt[base + i] = cnt;
                 if (out.mf_cnt) out.mf_cnt[base + i] = (int)L.mfc[i];
                 if (out.nei_rew) {

@@ -61,6 +61,29 @@ def test_neighbours_vs_oracle(E, N, K):
                               b[k].view(np.uint32) if b[k].dtype == np.float32 else b[k]), k
 
 
+def test_neighbours_on_the_radius():
+    """Pairs exactly ON the neighbourhood radius (outside: the test is d < R) and on the mean-field radius (inside: d <= M),
+    pairs one fp32 ulp either side, exact duplicates of a distance with different slots: the fp32 pre-test of the kernel
+    admits all of them as candidates, the fp64 pass must sort them out as the oracle does."""
+    import oracle_lib as ol
+    eps = np.float32(40.0) - np.nextafter(np.float32(40.0), np.float32(0.0))
+    pts = [(0, 0), (40, 0), (24, 32), (-32, 24), (0, -40), (40 - eps, 0), (40 + eps, 0), (0, 10), (6, 8), (-10, 0),
+           (0, np.nextafter(np.float32(10.0), np.float32(20.0))), (39.75, 0), (0, 39.75), (28, 28), (28.25, 28.25)]
+    pos = np.zeros((2, 16, 2))
+    pos[0, :15] = pts
+    pos[1, :15] = np.array(pts)[::-1] + 3.0
+    pos[:, 15] = (500.0, 500.0)
+    present = np.ones((2, 16), bool)
+    rew = np.random.RandomState(0).normal(0, 1, (2, 16)).astype(np.float32)
+    a = hip_neighbours(pos, present, rew, 15, 40.0, 10.0)
+    b = ol.neighbours(pos, present, rew, 15, 40.0, 10.0)
+    for k in a:
+        assert np.array_equal(a[k].view(np.uint32) if a[k].dtype == np.float32 else a[k],
+                              b[k].view(np.uint32) if b[k].dtype == np.float32 else b[k]), k
+    # of slot 0: (40-eps,0) (0,10) (6,8) (-10,0) (0,10+ulp) (39.75,0) (0,39.75) (28,28) (28.25,28.25); mean field: (0,10) (6,8) (-10,0)
+    assert a["nbr_cnt"][0, 0] == 9 and a["mf_cnt"][0, 0] == 3
+
+
 def hip_gae3(rew, val, flags, gamma, lam):
     import torch
     from copo_amd import _capi
