@@ -18,14 +18,19 @@ ap.add_argument("--stagger", type=int, default=0, help="1: the scenes start thei
 ap.add_argument("--env-config", default="{}", help="JSON merged into env_config (e.g. map_kwargs, respawn_cooldown)")
 a = ap.parse_args()
 base = getattr(W, a.map)
+extra = {}
 if a.algo == "copo":
     cls, env = CoPOTrainer, W.get_rllib_compatible_env(W.get_lcf_env(base))
+elif a.algo.startswith("ccppo"):          # ccppo-mf / ccppo-concat (train_all_ccppo_{mf,concat}.py)
+    from copo_amd.torch_copo import algo_ccppo
+    cls, env = algo_ccppo.CCPPOTrainer, algo_ccppo.get_ccppo_env(base)
+    extra["fuse_mode"] = a.algo.split("-")[1] if "-" in a.algo else "mf"
 else:
     cls, env = IPPOTrainer, W.get_rllib_compatible_env(base)
 T = max(1, -(-2000 // a.num_envs))
 import json
 algo = cls(config=dict(env=env, env_config=dict(json.loads(a.env_config), **(dict(num_agents=a.num_agents) if a.num_agents > 0 else {})), num_envs=a.num_envs, train_batch_size=T * a.num_envs,
-                       seed=a.seed, callbacks=MultiAgentDrivingCallbacks, stagger_episodes=bool(a.stagger)))
+                       seed=a.seed, callbacks=MultiAgentDrivingCallbacks, stagger_episodes=bool(a.stagger), **extra))
 t0 = time.time()
 print("# %s %s E=%d N=%d seed=%d: iter env_steps agent_steps wall_s success crash out max_step ep_reward lcf kl agents_finished velocity_m_s episode_len (rates over the agents that finished since the previous line)" % (a.algo, a.map, a.num_envs, algo.env.sim.N, a.seed))
 KEYS = ("success_rate_mean", "crash_rate_mean", "out_of_road_rate_mean", "max_step_rate_mean", "episode_reward_mean")
