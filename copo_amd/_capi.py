@@ -116,6 +116,15 @@ _SIGS = {
     "copo_cc_fuse_concat_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 7 + [C.c_void_p, C.c_void_p]),
     "copo_lcf_mix_partial_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "copo_lcf_mix_apply_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "copo_peer_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32]),
+    "copo_peer_alloc": (C.c_int, [C.c_int64, C.POINTER(C.c_void_p)]),
+    "copo_peer_free": (C.c_int, [C.c_void_p]),
+    "copo_ipc_export": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "copo_ipc_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "copo_ipc_close": (C.c_int, [C.c_void_p]),
+    "copo_peer_allreduce_sum_f32": (C.c_int, [C.POINTER(C.c_void_p), C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    "copo_peer_status": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    "copo_debug_peer_allreduce_all_ranks": (C.c_int, [C.POINTER(C.c_void_p), C.c_int64, C.c_int32, C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS)

@@ -1,0 +1,72 @@
+"""Peer all-reduce of the data-parallel learner (C ABI `copo_peer_*` / `copo_ipc_*`): a two-shot sum over
+device memory that every rank of the node has mapped, instead of RCCL's ring, for the one message that sits on the critical
+path of every optimizer step (the 1.44 MB gradient sum of a 512-row minibatch).  Opt-in: COPO_PEER_ALLREDUCE=1 -- it has run
+with two processes sharing one GPU (tests/test_gpu_trainer.py), never on a multi-GPU node, so RCCL stays the default."""
+import ctypes as C
+import os
+
+import torch
+import torch.distributed as td
+
+from . import _capi
+
+
+def enabled():
+    return os.environ.get("COPO_PEER_ALLREDUCE", "0") == "1"
+
+
+class _Raw:
+    """Raw device memory as a `__cuda_array_interface__` provider (torch.as_tensor aliases it)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = dict(shape=(int(n),), typestr="<f4", data=(int(ptr), False), version=2)
+
+
+class PeerAllReduce:
+    """`data` [n] float32 lives in this rank's workspace; `all_reduce_()` replaces it with the sum over all ranks."""
+
+    def __init__(self, n, device):
+        assert td.is_initialized() and device.type == "cuda"
+        self.n, self.rank, self.world = int(n), td.get_rank(), td.get_world_size()
+        self.device = device
+        nbytes = _capi.lib.copo_peer_workspace_bytes(self.n, self.world)
+        if nbytes < 0:
+            raise ValueError("peer all-reduce: world size %d not supported" % self.world)
+        with torch.cuda.device(device):
+            own = C.c_void_p()
+            _capi.check(_capi.lib.copo_peer_alloc(nbytes, C.byref(own)))
+            self._own = own
+            handle = C.create_string_buffer(64)
+            _capi.check(_capi.lib.copo_ipc_export(own, handle))
+            handles = [None] * self.world
+            td.all_gather_object(handles, (os.getpid(), handle.raw))
+            self._mapped = []
+            ptrs = (C.c_void_p * self.world)()
+            for r, (pid, raw) in enumerate(handles):
+                if r == self.rank:
+                    ptrs[r] = own.value
+                else:
+                    p = C.c_void_p()
+                    _capi.check(_capi.lib.copo_ipc_open(raw, C.byref(p)))
+                    self._mapped.append(p)
+                    ptrs[r] = p.value
+            self._ptrs = ptrs
+        self.data = torch.as_tensor(_Raw(own.value, self.n), device=device)
+        td.barrier()          # nobody reduces before everybody has mapped everybody
+
+    def all_reduce_(self):
+        _capi.check(_capi.lib.copo_peer_allreduce_sum_f32(self._ptrs, self.n, self.rank, self.world, _capi.current_stream()))
+        return self.data
+
+    def status(self):
+        """Raises if a wait inside any call so far timed out (a rank that never arrived).  Synchronises the stream."""
+        _capi.check(_capi.lib.copo_peer_status(self._own, self.n, self.world, _capi.current_stream()))
+
+    def close(self):
+        if getattr(self, "_own", None) is not None:
+            torch.cuda.synchronize(self.device)
+            self.data = None
+            for p in self._mapped:
+                _capi.lib.copo_ipc_close(p)
+            _capi.lib.copo_peer_free(self._own)
+            self._own, self._mapped = None, []

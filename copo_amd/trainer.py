@@ -431,10 +431,29 @@ class PPOPolicyBase:
     DIST_CHAIN = int(os.environ.get("COPO_DIST_CHAIN", "0"))
 
     def _fused_dist_chain(self):
-        for _ in range(self.DIST_CHAIN):
+        for _ in range(self._dist_chain_len):
             self.fused.step(self._row_sources, apply_adam=False, stats=self.fused.stats, bump_index=False)
-            D.all_reduce_sum_(self.fused.grad)
+            self._grad_all_reduce()
             self.fused.adam(self._row_sources)
+
+    # COPO_PEER_ALLREDUCE=1: the gradient sums travel through the two-shot peer all-reduce (copo_amd/peer.py) instead of
+    # torch.distributed -- one kernel per step, so [gradient pass, all-reduce, Adam] chains are captured like the local ones.
+    # The gradient buffer of the fused learner then lives in the peer workspace (reduced in place).
+    _peer = None
+    _dist_chain_len = DIST_CHAIN
+
+    def _setup_peer_allreduce(self):
+        from . import peer
+        if self._peer is None and peer.enabled() and D.is_dist() and self.device.type == "cuda":
+            self._peer = peer.PeerAllReduce(self.fused.flat.numel, self.device)
+            self.fused.grad = self._peer.data
+            self._dist_chain_len = self.DIST_CHAIN or 16
+
+    def _grad_all_reduce(self):
+        if self._peer is not None:
+            self._peer.all_reduce_()
+        else:
+            D.all_reduce_sum_(self.fused.grad)
 
     def _fused_grads(self):
         self.fused.step(self._row_sources, apply_adam=False, stats=self.fused.stats, bump_index=False)
@@ -452,10 +471,11 @@ class PPOPolicyBase:
         assert mb == fz.cfg.mb, "fused learner was built for minibatch %d" % fz.cfg.mb
         if self._sgd is None:
             if D.is_dist():
+                self._setup_peer_allreduce()
                 self._sgd = (GraphedCallable(self._fused_grads, self.use_graphs),
                              GraphedCallable(self._fused_apply, self.use_graphs),
                              GraphedCallable(self._fused_apply_then_grads, self.use_graphs))
-                self._sgd_dist_chain = GraphedCallable(self._fused_dist_chain, self.use_graphs) if self.DIST_CHAIN > 0 else None
+                self._sgd_dist_chain = GraphedCallable(self._fused_dist_chain, self.use_graphs) if self._dist_chain_len > 0 else None
             else:
                 self._sgd = GraphedCallable(self._fused_local, self.use_graphs)
                 self._sgd_chain = GraphedCallable(self._fused_local_chain, self.use_graphs)
@@ -473,22 +493,24 @@ class PPOPolicyBase:
                     _k0 += self.SGD_CHAIN
                     steps += self.SGD_CHAIN
             if D.is_dist() and self.use_graphs and getattr(self, "_sgd_dist_chain", None) is not None:
-                while _k0 + self.DIST_CHAIN <= n_mb:
+                while _k0 + self._dist_chain_len <= n_mb:
                     self._sgd_dist_chain()
-                    _k0 += self.DIST_CHAIN
-                    steps += self.DIST_CHAIN
+                    _k0 += self._dist_chain_len
+                    steps += self._dist_chain_len
             for _k in range(_k0, n_mb):
                 if D.is_dist():
                     # two host calls per minibatch: [Adam of the previous one + this gradient pass], all-reduce; the
                     # last Adam of the epoch is flushed before the next plan resets the minibatch index
                     self._sgd[0 if _k == _k0 else 2]()
-                    D.all_reduce_sum_(fz.grad)
+                    self._grad_all_reduce()
                     if _k == n_mb - 1:
                         self._sgd[1]()
                 else:
                     self._sgd()
                 steps += 1
         self.num_grad_updates += steps
+        if self._peer is not None:
+            self._peer.status()       # a rank that never arrived in some call: raise here instead of training on partial sums
         tot, pol, vf, kl, ent, vfn, vfg, adv = (fz.stats / max(1, steps)).tolist()
         return dict(total_loss=tot, policy_loss=pol, vf_loss=vf, kl=kl, entropy=ent, cur_kl_coeff=self._kl_value,
                     cur_lr=float(self.config["lr"]), num_sgd_steps=steps, mean_nei_vf_loss=vfn, mean_global_vf_loss=vfg,
@@ -844,6 +866,10 @@ class VecTrainer:
             self.env.close()
         except Exception:
             pass
+        peer = getattr(self.policy, "_peer", None)
+        if peer is not None:
+            peer.close()
+            self.policy._peer = None
 
 
 class _LocalWorker:

@@ -433,6 +433,31 @@ int copo_meta_batch_lcf_f64(const float* pack_src, int32_t pack_width, int32_t c
                             double* lcf_param, const double* raw_mean_std, double* adam_state, double lr, double* stats,
                             void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Peer all-reduce (replaces the in-process tower averaging of RLlib's multi-GPU learner,
+ * algo_copo.py:519-577, for one process per GPU): a two-shot sum over device memory that every rank of the node has mapped.
+ *   workspace = copo_peer_alloc(copo_peer_workspace_bytes(n, world))      uncached device memory, zeroed; its first n floats are
+ *               the buffer that is reduced in place (the caller writes its gradient sums there)
+ *   copo_ipc_export / copo_ipc_open     64-byte handles, exchanged by the host side (torch.distributed all_gather_object)
+ *   copo_peer_allreduce_sum_f32(workspaces[world] as mapped in THIS process, n, rank, world, stream)
+ *               one kernel: shards scattered to their owners' inboxes, added up in rank order (bit-identical on every rank),
+ *               results stored to every rank's buffer; flags in the workspaces order the two hops.  Every rank must call it the
+ *               same number of times.  A peer that does not answer within ~2 s raises an error word instead of hanging the GPU:
+ *   copo_peer_status(workspace, n, world, stream)    COPO_OK, or COPO_ERR_DEVICE after a timed-out wait
+ */
+#define COPO_PEER_MAX_WORLD 16
+#define COPO_IPC_HANDLE_BYTES 64
+int64_t copo_peer_workspace_bytes(int64_t n, int32_t world);
+int copo_peer_alloc(int64_t bytes, void** out);
+int copo_peer_free(void* workspace);
+int copo_ipc_export(void* dev_ptr, unsigned char* handle64);
+int copo_ipc_open(const unsigned char* handle64, void** out);
+int copo_ipc_close(void* mapped);
+int copo_peer_allreduce_sum_f32(void* const* workspaces, int64_t n, int32_t rank, int32_t world, void* stream);
+int copo_peer_status(void* workspace, int64_t n, int32_t world, void* stream);
+/* test entry: all `world` ranks in one launch (the workspaces all belong to the calling process) */
+int copo_debug_peer_allreduce_all_ranks(void* const* workspaces, int64_t n, int32_t world, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -314,8 +314,11 @@ def test_episode_metrics_kernel_equals_tensor_code():
     a.stop()
 
 
-def test_two_ranks_fused_data_parallel_on_one_gpu():
-    """Two real ranks (gloo over CUDA tensors, both on cuda:0 -- RCCL would refuse to share a device) through the fused
+@pytest.mark.parametrize("peer", ["0", "1"])
+def test_two_ranks_fused_data_parallel_on_one_gpu(peer):
+    """peer = "1": the gradient sums go through the peer all-reduce (COPO_PEER_ALLREDUCE, hipIpc-mapped workspaces, captured
+    [gradient pass, all-reduce, Adam] chains) instead of torch.distributed.
+    Two real ranks (gloo over CUDA tensors, both on cuda:0 -- RCCL would refuse to share a device) through the fused
     data-parallel path: gradient all-reduce + flat Adam per minibatch, batched meta pass with exported gradient pairs,
     gathered LCF rows.  Ranks own different scenes, must take the same number of steps and end with identical parameters."""
     import subprocess
@@ -335,6 +338,7 @@ a = CoPOTrainer(config=dict(env=env, env_config=dict(num_agents=12), num_envs=8 
 assert a.policy.fused is not None and D.is_dist() and world == 2
 for _ in range(3):
     res = a.train()
+assert (a.policy._peer is not None) == (os.environ.get("COPO_PEER_ALLREDUCE") == "1")
 flat = a.policy.fused.flat.flat
 sig = torch.stack([flat.double().sum(), flat.double().abs().sum(), a.policy.model.lcf_parameters[0].double(),
                    a.policy.model.lcf_parameters[1].double(), torch.tensor(float(a.policy.num_grad_updates), dtype=torch.float64, device="cuda")])
@@ -349,10 +353,10 @@ td.destroy_process_group()
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29561",
-                   COPO_DIST_BACKEND="gloo", COPO_FORCE_DIST="0")
+                   COPO_DIST_BACKEND="gloo", COPO_FORCE_DIST="0", COPO_PEER_ALLREDUCE=peer)
         procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-    outs = [p.communicate(timeout=600) for p in procs]
+    outs = [p.communicate(timeout=300) for p in procs]
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, se[-3000:]
     line = [ln for ln in outs[0][0].splitlines() if ln.startswith("RESULT ")][-1]
