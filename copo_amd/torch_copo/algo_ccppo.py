@@ -109,6 +109,14 @@ class CCPPOPolicy(IPPOPolicy):
         self.centralized_critic_obs_dim = self.model.get_centralized_critic_obs_dim()
         self._cc_buf = None
 
+    # algo_ccppo.py:362-365 / algo_copo.py:492-496 bootstrap a cut trajectory with VF_PREDS[-1], the value of its last ROW:
+    # the centralised critic observation of the next step does not exist yet.  Critics that read nothing but the agent's own
+    # observation (fuse_mode "none": CoPO's three heads by default) use the exact bootstrap instead -- the shortcut touches a
+    # trajectory once or twice with the reference's 200-step fragments, but every row with the 8-step fragments of 256
+    # lockstep scenes (trainer.PPOPolicyBase.bootstrap_next_obs; `bootstrap_next_obs: False` restores the shortcut).
+    def bootstrap_next_obs(self):
+        return super().bootstrap_next_obs() and int(self.model.value_input_dim()) == int(self.observation_space.shape[0])
+
     def critic_obs_dense(self, batch):
         mode = self.config["fuse_mode"]
         if mode == "none":

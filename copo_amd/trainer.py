@@ -159,6 +159,7 @@ class VecSampler:
             "nei_rewards": self.rew3[1], "global_rewards": self.rew3[2], "rew3": self.rew3,
             SampleBatch.FLAGS: self.flags, "nbr_idx": self.nbr_idx, "nbr_cnt": self.nbr_cnt, "mf_cnt": self.mf_cnt,
             "step_lcf": self.lcf, "infos": self.info, "agent_id": self.agent_id,
+            "_next_obs_last": self.obs[self.T],      # observation after the fragment's last step (bootstrap of truncated trajectories)
         })
 
 
@@ -609,10 +610,51 @@ class PPOPolicyBase:
                 a, g = ops.gae3(rew[:, lo:hi].contiguous(), vals[:, lo:hi].contiguous(), flags[lo:hi].contiguous(),
                                 self.gae_gammas(), lam)
                 adv[:, lo:hi], tgt[:, lo:hi] = a, g
+        if self.bootstrap_next_obs() and frag >= T and b.get("_next_obs_last") is not None:
+            self._bootstrap_from_next_obs(b, vals, adv, tgt, flags, lam)
         b[SampleBatch.VF_PREDS], b[Postprocessing.ADVANTAGES], b[Postprocessing.VALUE_TARGETS] = \
             vals[0].view(T, E, N), adv[0].view(T, E, N), tgt[0].view(T, E, N)
         b["_vals"], b["_adv"], b["_tgt"] = vals, adv, tgt
         return b
+
+    def bootstrap_next_obs(self):
+        """How a trajectory that is cut by the end of the fragment is bootstrapped.  RLlib's PPO (the reference's IPPO,
+        algo_ippo.py: `compute_gae_for_sample_batch`) evaluates the critic on the observation AFTER the last step; the
+        reference's CCPPO / CoPO pass the value of the last ROW instead (algo_ccppo.py:362-365, algo_copo.py:492-496: the
+        centralised critic observation of the next step does not exist yet) -- the scan of `copo_gae3_f32`.  With 200-step
+        fragments that shortcut touches a trajectory once or twice; with the 8-step fragments of 256 lockstep scenes it
+        touches every row, so critics that only read the agent's own observation may opt into the exact bootstrap
+        (`bootstrap_next_obs`, default True; a centralised critic -- CCPPO's mean-field / concat modes -- cannot and keeps
+        the reference's shortcut).  Batches that carry no next observation (the reference's own postprocess inputs in the
+        golden tests) are scanned exactly as the reference does."""
+        v = self.config.get("bootstrap_next_obs")
+        return True if v is None else bool(v)
+
+    def _bootstrap_from_next_obs(self, b, vals, adv, tgt, flags, lam):
+        """GAE is linear in the bootstrap value: replacing V(last row) by V(next obs) adds (gamma lambda)^(T-1-t) gamma
+        (V(next obs) - V(last row)) to every row t of the trajectory that runs into the end of the fragment."""
+        H, T, M = vals.shape
+        nxt = b["_next_obs_last"].reshape(M, -1)
+        fl = flags.to(torch.int32)
+        cont = ((fl & F_ACTED) > 0) & ((fl & F_DONE) == 0)                          # [T, M] the agent drives on after row t
+        run = torch.flip(torch.cumprod(torch.flip(cont, [0]).to(torch.float32), 0), [0])      # rows of the trajectory alive at the end
+        alive = cont[T - 1]
+        idx = alive.nonzero(as_tuple=False).view(-1)
+        if idx.numel() == 0:
+            return
+        fz = self.fused
+        if fz is not None and fz.can_forward and self.config.get("use_fused_inference", True) and int(fz.cfg.n_value_heads) == H:
+            v_next = fz.values(nxt.contiguous(), None, rows=idx)
+        else:
+            v_next = torch.zeros(H, M, device=vals.device)
+            v_next[:, idx] = self.value_heads_dense(nxt[idx])
+        gam = torch.tensor(self.gae_gammas(), dtype=torch.float32, device=vals.device).view(H, 1)
+        delta = gam * (v_next - vals[:, T - 1]) * alive.to(torch.float32)              # [H, M]
+        k = torch.arange(T - 1, -1, -1, device=vals.device, dtype=torch.float32).view(1, T, 1)
+        w = torch.pow(gam.view(H, 1, 1) * lam, k) * run.unsqueeze(0)                      # [H, T, M]
+        corr = w * delta.unsqueeze(1)
+        adv += corr
+        tgt += corr
 
 
 # ----------------------------------------------------------------------------------------------------

@@ -15,6 +15,7 @@ ap.add_argument("--stop", type=int, default=1_000_000)
 ap.add_argument("--every", type=int, default=25)
 ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--stagger", type=int, default=0, help="1: the scenes start their first episodes at staggered env steps")
+ap.add_argument("--config", default="{}", help="JSON merged into the trainer config (e.g. bootstrap_next_obs)")
 ap.add_argument("--env-config", default="{}", help="JSON merged into env_config (e.g. map_kwargs, respawn_cooldown)")
 a = ap.parse_args()
 base = getattr(W, a.map)
@@ -30,7 +31,7 @@ else:
 T = max(1, -(-2000 // a.num_envs))
 import json
 algo = cls(config=dict(env=env, env_config=dict(json.loads(a.env_config), **(dict(num_agents=a.num_agents) if a.num_agents > 0 else {})), num_envs=a.num_envs, train_batch_size=T * a.num_envs,
-                       seed=a.seed, callbacks=MultiAgentDrivingCallbacks, stagger_episodes=bool(a.stagger), **extra))
+                       seed=a.seed, callbacks=MultiAgentDrivingCallbacks, stagger_episodes=bool(a.stagger), **extra, **json.loads(a.config)))
 t0 = time.time()
 print("# %s %s E=%d N=%d seed=%d: iter env_steps agent_steps wall_s success crash out max_step ep_reward lcf kl agents_finished velocity_m_s episode_len (rates over the agents that finished since the previous line)" % (a.algo, a.map, a.num_envs, algo.env.sim.N, a.seed))
 KEYS = ("success_rate_mean", "crash_rate_mean", "out_of_road_rate_mean", "max_step_rate_mean", "episode_reward_mean")

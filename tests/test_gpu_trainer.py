@@ -314,6 +314,71 @@ def test_episode_metrics_kernel_equals_tensor_code():
     a.stop()
 
 
+@pytest.mark.parametrize("algo", ["ippo", "copo"])
+def test_truncated_trajectories_bootstrap_from_the_next_observation(algo):
+    """RLlib's PPO postprocessing (the reference's IPPO) bootstraps a trajectory that is cut by the end of the fragment with
+    the critic's value of the observation AFTER the last step; the dense path adds that to the last-row scan of
+    `copo_gae3_f32` through the linearity of GAE.  Checked against a per-trajectory numpy GAE, for IPPO and for CoPO's three
+    observation-only heads."""
+    from copo_amd.torch_copo import algo_copo, algo_ippo
+    from copo_amd.torch_copo.utils import env_wrappers as W
+    if algo == "ippo":
+        cls, env, over = algo_ippo.IPPOTrainer, W.get_rllib_compatible_env(W.MultiAgentIntersectionEnv), {}
+    else:
+        cls, env, over = algo_copo.CoPOTrainer, W.get_rllib_compatible_env(W.get_lcf_env(W.MultiAgentIntersectionEnv)), {}
+    a = cls(config=dict(env=env, env_config=dict(num_agents=12, horizon=60), num_envs=4, train_batch_size=4 * 10, seed=1, **over))
+    pol = a.policy
+    assert pol.bootstrap_next_obs()
+    if algo == "copo":       # a centralised critic has no next critic observation: the reference's last-row shortcut stays
+        from copo_amd.torch_copo import algo_ccppo
+        cc = algo_ccppo.CCPPOTrainer(config=dict(env=algo_ccppo.get_ccppo_env(W.MultiAgentIntersectionEnv), env_config=dict(num_agents=4),
+                                                 num_envs=1, train_batch_size=10, fuse_mode="mf"))
+        assert not cc.policy.bootstrap_next_obs()
+        cc.stop()
+    for _ in range(3):          # a few fragments in: trajectories start, end and run through the boundaries
+        batch = a.sampler.sample()
+    b = pol.postprocess_trajectory(batch)
+    T, E, N = b[SampleBatch.FLAGS].shape
+    M = E * N
+    H = pol.gae_heads()
+    vals, adv, tgt = (b[k].reshape(H, T, M).cpu().numpy().astype(np.float64) for k in ("_vals", "_adv", "_tgt"))
+    rew = b["rew3"][:H].reshape(H, T, M).cpu().numpy().astype(np.float64)
+    fl = b[SampleBatch.FLAGS].reshape(T, M).cpu().numpy()
+    nxt = b["_next_obs_last"].reshape(M, -1)
+    v_next = pol.value_heads_dense(nxt).cpu().numpy().astype(np.float64)          # torch model, [H, M]
+    lam, gammas = float(pol.config["lambda"]), pol.gae_gammas()
+    checked, cut = 0, 0
+    for m in range(M):
+        t = 0
+        while t < T:
+            if not fl[t, m] & 1:
+                t += 1
+                continue
+            t0 = t
+            while t < T and (fl[t, m] & 1) and not (fl[t, m] & 2):
+                t += 1
+            done = t < T and bool(fl[t, m] & 2)
+            t1 = t if done else t - 1                     # last row of this trajectory
+            t = t1 + 1
+            for h in range(H):
+                g = gammas[h]
+                last = 0.0 if done else v_next[h, m]
+                assert done or t1 == T - 1
+                v = np.concatenate([vals[h, t0:t1 + 1, m], [last]])
+                delta = rew[h, t0:t1 + 1, m] + g * v[1:] - v[:-1]
+                want = np.zeros_like(delta)
+                acc = 0.0
+                for k in range(len(delta) - 1, -1, -1):
+                    acc = delta[k] + g * lam * acc
+                    want[k] = acc
+                np.testing.assert_allclose(adv[h, t0:t1 + 1, m], want, rtol=2e-4, atol=2e-4)
+                np.testing.assert_allclose(tgt[h, t0:t1 + 1, m], want + vals[h, t0:t1 + 1, m], rtol=2e-4, atol=2e-4)
+            checked += 1
+            cut += int(not done)
+    assert checked > 40 and cut > 20
+    a.stop()
+
+
 @pytest.mark.parametrize("peer", ["0", "1"])
 def test_two_ranks_fused_data_parallel_on_one_gpu(peer):
     """peer = "1": the gradient sums go through the peer all-reduce (COPO_PEER_ALLREDUCE, hipIpc-mapped workspaces, captured
