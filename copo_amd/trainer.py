@@ -580,6 +580,9 @@ class PPOPolicyBase:
         obs = b[SampleBatch.OBS]
         T, E, N = obs.shape[0], obs.shape[1], obs.shape[2]
         M = E * N
+        # look-ahead batches (VecTrainer._lookahead_batch, centralised critics): the last row only supplies the bootstrap value
+        look = bool(b.get("_lookahead", False))
+        Tt = T - 1 if look else T
         cc = self.critic_obs_dense(b)
         b["centralized_critic_obs"] = cc
         H = self.gae_heads()
@@ -592,25 +595,39 @@ class PPOPolicyBase:
             # is the one `valid_rows` needs anyway (the iteration's single host sync), kept on the batch for it
             valid = (b[SampleBatch.FLAGS].reshape(-1) & F_ACTED).bool()
             idx = valid.nonzero(as_tuple=False).view(-1)
-            b["_valid"], b["_valid_idx"] = valid, idx
+            if not look:
+                b["_valid"], b["_valid_idx"] = valid, idx
             vals = fz.values(obs.reshape(T * M, -1), None if cc_flat.data_ptr() == obs.data_ptr() else cc_flat,
                              rows=idx).view(H, T, M)
         else:
             vals = self.value_heads_dense(cc.reshape(T * M, -1)).reshape(H, T, M).contiguous()
         rew = b["rew3"][:H].reshape(H, T, M)
         flags = b[SampleBatch.FLAGS].reshape(T, M)
-        adv, tgt = torch.empty_like(vals), torch.empty_like(vals)
-        frag = int(self.config.get("rollout_fragment_length", T) or T)
+        frag = int(self.config.get("rollout_fragment_length", Tt) or Tt)
         lam = float(self.config["lambda"])
-        for lo in range(0, T, frag):
-            hi = min(T, lo + frag)
-            if lo == 0 and hi == T:
+        if look:
+            v_next = vals[:, Tt].contiguous()
+            vals, rew, flags = vals[:, :Tt].contiguous(), rew[:, :Tt].contiguous(), flags[:Tt]
+        adv, tgt = torch.empty_like(vals), torch.empty_like(vals)
+        for lo in range(0, Tt, frag):
+            hi = min(Tt, lo + frag)
+            if lo == 0 and hi == Tt:
                 ops.gae3(rew.contiguous(), vals, flags, self.gae_gammas(), lam, adv, tgt)
             else:
                 a, g = ops.gae3(rew[:, lo:hi].contiguous(), vals[:, lo:hi].contiguous(), flags[lo:hi].contiguous(),
                                 self.gae_gammas(), lam)
                 adv[:, lo:hi], tgt[:, lo:hi] = a, g
-        if self.bootstrap_next_obs() and frag >= T and b.get("_next_obs_last") is not None:
+        if look:
+            # the value of the NEXT ROW (its centralised critic observation exists now) instead of the last-row shortcut
+            self._apply_bootstrap(vals, adv, tgt, flags, lam, v_next)
+            b["_v_next"] = v_next
+            for k in list(b.keys()):          # what the trainer sees: the Tt training rows (views of the persistent buffers)
+                v = b[k]
+                if not torch.is_tensor(v) or k.startswith("_"):
+                    continue
+                b[k] = v[:, :Tt] if k == "rew3" else (v[:Tt] if v.shape[0] == T else v)
+            T = Tt
+        elif self.bootstrap_next_obs() and frag >= T and b.get("_next_obs_last") is not None:
             self._bootstrap_from_next_obs(b, vals, adv, tgt, flags, lam)
         b[SampleBatch.VF_PREDS], b[Postprocessing.ADVANTAGES], b[Postprocessing.VALUE_TARGETS] = \
             vals[0].view(T, E, N), adv[0].view(T, E, N), tgt[0].view(T, E, N)
@@ -631,14 +648,11 @@ class PPOPolicyBase:
         return True if v is None else bool(v)
 
     def _bootstrap_from_next_obs(self, b, vals, adv, tgt, flags, lam):
-        """GAE is linear in the bootstrap value: replacing V(last row) by V(next obs) adds (gamma lambda)^(T-1-t) gamma
-        (V(next obs) - V(last row)) to every row t of the trajectory that runs into the end of the fragment."""
+        """V(observation after the last step) for the trajectories that run into the end of the fragment."""
         H, T, M = vals.shape
         nxt = b["_next_obs_last"].reshape(M, -1)
-        fl = flags.to(torch.int32)
-        cont = ((fl & F_ACTED) > 0) & ((fl & F_DONE) == 0)                          # [T, M] the agent drives on after row t
-        run = torch.flip(torch.cumprod(torch.flip(cont, [0]).to(torch.float32), 0), [0])      # rows of the trajectory alive at the end
-        alive = cont[T - 1]
+        fl = flags[T - 1].to(torch.int32)
+        alive = ((fl & F_ACTED) > 0) & ((fl & F_DONE) == 0)
         idx = alive.nonzero(as_tuple=False).view(-1)
         if idx.numel() == 0:
             return
@@ -648,13 +662,28 @@ class PPOPolicyBase:
         else:
             v_next = torch.zeros(H, M, device=vals.device)
             v_next[:, idx] = self.value_heads_dense(nxt[idx])
+        self._apply_bootstrap(vals, adv, tgt, flags, lam, v_next)
+
+    def _apply_bootstrap(self, vals, adv, tgt, flags, lam, v_next):
+        """GAE is linear in the bootstrap value: replacing V(last row) by `v_next` [H, M] adds (gamma lambda)^(T-1-t) gamma
+        (v_next - V(last row)) to every row t of the trajectory that runs into the end of the fragment."""
+        H, T, M = vals.shape
+        fl = flags.to(torch.int32)
+        cont = ((fl & F_ACTED) > 0) & ((fl & F_DONE) == 0)                          # [T, M] the agent drives on after row t
+        run = torch.flip(torch.cumprod(torch.flip(cont, [0]).to(torch.float32), 0), [0])      # rows of the trajectory alive at the end
         gam = torch.tensor(self.gae_gammas(), dtype=torch.float32, device=vals.device).view(H, 1)
-        delta = gam * (v_next - vals[:, T - 1]) * alive.to(torch.float32)              # [H, M]
+        delta = gam * (v_next - vals[:, T - 1]) * cont[T - 1].to(torch.float32)       # [H, M]
         k = torch.arange(T - 1, -1, -1, device=vals.device, dtype=torch.float32).view(1, T, 1)
         w = torch.pow(gam.view(H, 1, 1) * lam, k) * run.unsqueeze(0)                      # [H, T, M]
         corr = w * delta.unsqueeze(1)
         adv += corr
         tgt += corr
+
+    def wants_lookahead(self):
+        """A centralised critic has no critic observation for the step after the fragment (the neighbours' next actions are
+        not taken yet); `lookahead` (default on) trains every row one step late instead, so that its successor row exists."""
+        return (not self.bootstrap_next_obs()) and bool(self.config.get("lookahead", True)) and \
+            int(self.model.value_input_dim()) != int(self.observation_space.shape[0])
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -720,9 +749,42 @@ class VecTrainer:
     def collect(self):
         t0 = time.perf_counter()
         batch = self.sampler.sample()
+        self._metrics_batch = batch            # the rows of THIS rollout (episode metrics, counters)
+        if self.policy.wants_lookahead():
+            batch = self._lookahead_batch(batch)
         self.policy.postprocess_trajectory(batch)
         self._timers["sample_time_ms"] = (time.perf_counter() - t0) * 1e3
         return batch
+
+    _look = None
+
+    def _lookahead_batch(self, cur):
+        """Centralised critics (CCPPO mean-field / concat): T + 1 rows = [last row of the previous rollout | the T new rows] in
+        persistent buffers.  The first T are trained on now; the last one is only evaluated by the critic -- the exact
+        bootstrap of the trajectories that run through the fragment boundary, which the reference replaces by the value of
+        the last row itself (algo_ccppo.py:362-365: negligible with its 200-step fragments, not with T = 8) -- and is
+        trained on in the next iteration.  Every row is used exactly once, one iteration late."""
+        T = self.sampler.T
+        skip = (SampleBatch.REWARDS, "nei_rewards", "global_rewards")          # views of rew3
+        if self._look is None:
+            self._look = {}
+            for k, v in cur.items():
+                if k.startswith("_") or k in skip or not torch.is_tensor(v):
+                    continue
+                shape = (3, T + 1) + tuple(v.shape[2:]) if k == "rew3" else (T + 1,) + tuple(v.shape[1:])
+                self._look[k] = torch.zeros(shape, dtype=v.dtype, device=v.device)
+        for k, buf in self._look.items():
+            if k == "rew3":
+                buf[:, 0].copy_(buf[:, T])
+                buf[:, 1:].copy_(cur[k])
+            else:
+                buf[0].copy_(buf[T])
+                buf[1:].copy_(cur[k])
+        out = SampleBatch(self._look)
+        r3 = self._look["rew3"]
+        out[SampleBatch.REWARDS], out["nei_rewards"], out["global_rewards"] = r3[0], r3[1], r3[2]
+        out["_lookahead"] = True
+        return out
 
     def valid_rows(self, batch):
         if "_valid_idx" in batch:                          # already listed by the dense postprocess
@@ -864,7 +926,7 @@ class VecTrainer:
         train_results = self.training_step()
         dt = time.perf_counter() - t0
         self.iteration += 1
-        cm = self.episode_metrics(self._last_batch)
+        cm = self.episode_metrics(getattr(self, "_metrics_batch", None) or self._last_batch)
         agent_steps = self._counters[NUM_AGENT_STEPS_SAMPLED]
         result = dict(
             training_iteration=self.iteration, timesteps_total=self._counters[NUM_ENV_STEPS_SAMPLED],

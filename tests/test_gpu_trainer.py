@@ -314,7 +314,7 @@ def test_episode_metrics_kernel_equals_tensor_code():
     a.stop()
 
 
-@pytest.mark.parametrize("algo", ["ippo", "copo"])
+@pytest.mark.parametrize("algo", ["ippo", "copo", "ccppo"])
 def test_truncated_trajectories_bootstrap_from_the_next_observation(algo):
     """RLlib's PPO postprocessing (the reference's IPPO) bootstraps a trajectory that is cut by the end of the fragment with
     the critic's value of the observation AFTER the last step; the dense path adds that to the last-row scan of
@@ -324,11 +324,14 @@ def test_truncated_trajectories_bootstrap_from_the_next_observation(algo):
     from copo_amd.torch_copo.utils import env_wrappers as W
     if algo == "ippo":
         cls, env, over = algo_ippo.IPPOTrainer, W.get_rllib_compatible_env(W.MultiAgentIntersectionEnv), {}
+    elif algo == "ccppo":       # centralised critic: every row is trained one step late, bootstrapped from its successor ROW
+        from copo_amd.torch_copo import algo_ccppo
+        cls, env, over = algo_ccppo.CCPPOTrainer, algo_ccppo.get_ccppo_env(W.MultiAgentIntersectionEnv), dict(fuse_mode="concat")
     else:
         cls, env, over = algo_copo.CoPOTrainer, W.get_rllib_compatible_env(W.get_lcf_env(W.MultiAgentIntersectionEnv)), {}
     a = cls(config=dict(env=env, env_config=dict(num_agents=12, horizon=60), num_envs=4, train_batch_size=4 * 10, seed=1, **over))
     pol = a.policy
-    assert pol.bootstrap_next_obs()
+    assert pol.bootstrap_next_obs() != (algo == "ccppo") and pol.wants_lookahead() == (algo == "ccppo")
     if algo == "copo":       # a centralised critic has no next critic observation: the reference's last-row shortcut stays
         from copo_amd.torch_copo import algo_ccppo
         cc = algo_ccppo.CCPPOTrainer(config=dict(env=algo_ccppo.get_ccppo_env(W.MultiAgentIntersectionEnv), env_config=dict(num_agents=4),
@@ -337,15 +340,27 @@ def test_truncated_trajectories_bootstrap_from_the_next_observation(algo):
         cc.stop()
     for _ in range(3):          # a few fragments in: trajectories start, end and run through the boundaries
         batch = a.sampler.sample()
+        if algo == "ccppo":
+            prev_last_flags = None if a._look is None else a._look[SampleBatch.FLAGS][a.sampler.T].clone()
+            batch = a._lookahead_batch(batch)
     b = pol.postprocess_trajectory(batch)
+    if algo == "ccppo":         # rows = [last row of the previous rollout | the first T - 1 new rows]
+        assert torch.equal(b[SampleBatch.FLAGS][0], prev_last_flags) and torch.equal(b[SampleBatch.FLAGS][1:], a.sampler.flags[:a.sampler.T - 1])
+        assert b["centralized_critic_obs"].shape[0] == a.sampler.T
     T, E, N = b[SampleBatch.FLAGS].shape
     M = E * N
     H = pol.gae_heads()
     vals, adv, tgt = (b[k].reshape(H, T, M).cpu().numpy().astype(np.float64) for k in ("_vals", "_adv", "_tgt"))
     rew = b["rew3"][:H].reshape(H, T, M).cpu().numpy().astype(np.float64)
     fl = b[SampleBatch.FLAGS].reshape(T, M).cpu().numpy()
-    nxt = b["_next_obs_last"].reshape(M, -1)
-    v_next = pol.value_heads_dense(nxt).cpu().numpy().astype(np.float64)          # torch model, [H, M]
+    if algo == "ccppo":
+        v_next = b["_v_next"].cpu().numpy().astype(np.float64)                      # critic values of the successor rows
+        cc_last = a._look["centralized_critic_obs"][a.sampler.T] if "centralized_critic_obs" in a._look else pol._cc_buf[a.sampler.T]
+        np.testing.assert_allclose(v_next[0], pol.value_heads_dense(cc_last.reshape(M, -1)).cpu().numpy()[0] *
+                                   ((a._look[SampleBatch.FLAGS][a.sampler.T].reshape(M) & 1) > 0).cpu().numpy(), rtol=1e-4, atol=1e-4)
+    else:
+        nxt = b["_next_obs_last"].reshape(M, -1)
+        v_next = pol.value_heads_dense(nxt).cpu().numpy().astype(np.float64)          # torch model, [H, M]
     lam, gammas = float(pol.config["lambda"]), pol.gae_gammas()
     checked, cut = 0, 0
     for m in range(M):
