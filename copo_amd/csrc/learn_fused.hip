@@ -70,7 +70,8 @@ static hipError_t gemm_lds_attrs() {
                               reinterpret_cast<const void*>(rowpass_kernel<1, 4, true>), reinterpret_cast<const void*>(rowpass_kernel<2, 4, true>),
                               reinterpret_cast<const void*>(rowpass_kernel<2, 8, true>), reinterpret_cast<const void*>(rowpass_kernel<4, 8, true>),
                               reinterpret_cast<const void*>(rowpass_kernel<1, 4, true, true>), reinterpret_cast<const void*>(rowpass_kernel<2, 4, true, true>),
-                              reinterpret_cast<const void*>(rowpass_kernel<2, 8, true, true>), reinterpret_cast<const void*>(rowpass_kernel<4, 8, true, true>)})
+                              reinterpret_cast<const void*>(rowpass_kernel<2, 8, true, true>), reinterpret_cast<const void*>(rowpass_kernel<4, 8, true, true>),
+                              reinterpret_cast<const void*>(rowpass_kernel<2, 8, true, false, true>)})
             if ((r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) != hipSuccess) e = r;
         for (const void* f : {reinterpret_cast<const void*>(mlp_fwd_kernel<1, 4>), reinterpret_cast<const void*>(mlp_fwd_kernel<2, 4>),
                               reinterpret_cast<const void*>(mlp_fwd_kernel<2, 8>), reinterpret_cast<const void*>(mlp_fwd_kernel<4, 8>),
@@ -161,17 +162,18 @@ hipError_t launch_fused_step(FusedArgs a, hipStream_t s, const MetaTail* mt_ = n
     if (bf && !(rowpass && tw && tw_ok && a.head_mode == COPO_HEAD_PPO && g_use_wgrad)) return hipErrorInvalidValue;
     if (rowpass) {
         const dim3 grid(head_tiles(c), G);
-#define COPO_RP(NT_, W_)                                                                                       \
+#define COPO_RP(NT_, W_, HO_)                                                                                     \
         do {                                                                                                   \
             if (bf) hipLaunchKernelGGL((rowpass_kernel<NT_, W_, true, true>), grid, dim3(64 * W_), rp_lds, s, a); \
+            else if (tw && HO_ && kmax1 <= 128) hipLaunchKernelGGL((rowpass_kernel<NT_, W_, true, false, HO_>), grid, dim3(64 * W_), rp_lds, s, a); \
             else if (tw) hipLaunchKernelGGL((rowpass_kernel<NT_, W_, true>), grid, dim3(64 * W_), rp_lds, s, a); \
             else hipLaunchKernelGGL((rowpass_kernel<NT_, W_, false>), grid, dim3(64 * W_), rp_lds, s, a);        \
         } while (0)
         switch (rp_h) {
-            case 64: COPO_RP(1, 4); break;
-            case 128: COPO_RP(2, 4); break;
-            case 256: COPO_RP(2, 8); break;
-            default: COPO_RP(4, 8); break;
+            case 64: COPO_RP(1, 4, false); break;
+            case 128: COPO_RP(2, 4, false); break;
+            case 256: COPO_RP(2, 8, true); break;       // hidden 256: layer 2 is two ring turns -> hand-over variant for narrow inputs
+            default: COPO_RP(4, 8, false); break;
         }
 #undef COPO_RP
     } else if (part != 2) {
