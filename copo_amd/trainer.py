@@ -473,6 +473,10 @@ class PPOPolicyBase:
         if self._sgd is None:
             if D.is_dist():
                 self._setup_peer_allreduce()
+                if self._peer is None and self._dist_chain_len == 0 and "COPO_DIST_CHAIN" not in os.environ and self.use_graphs:
+                    # RCCL inside a hipGraph: take it when a child process per rank shows that it captures and replays here
+                    if D.probe_graphed_allreduce():
+                        self._dist_chain_len = 16
                 self._sgd = (GraphedCallable(self._fused_grads, self.use_graphs),
                              GraphedCallable(self._fused_apply, self.use_graphs),
                              GraphedCallable(self._fused_apply_then_grads, self.use_graphs))
