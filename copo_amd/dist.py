@@ -100,7 +100,7 @@ def barrier():
         td.barrier()
 
 
-def probe_graphed_allreduce(timeout=120.0):
+def probe_graphed_allreduce(timeout=90.0):
     """True if EVERY rank could capture and replay a hipGraph that holds an RCCL all-reduce -- checked in a child process per
     rank (copo_amd/dist_probe.py, its own process group on MASTER_PORT + 17), so that a hang costs `timeout` seconds and a
     killed child instead of the job.  The trainer then captures [gradient pass, all-reduce, Adam] chains like the local ones
@@ -113,6 +113,7 @@ def probe_graphed_allreduce(timeout=120.0):
         return False
     env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 17))
     env.pop("COPO_FORCE_DIST", None)
+    env.pop("TORCHELASTIC_USE_AGENT_STORE", None)      # under torchrun: the child's rank 0 must open its OWN store on the new port
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     rc = -1
     try:
