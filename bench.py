@@ -376,7 +376,9 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         coll = {"allreduce_grad_us": round(e0.elapsed_time(e1) * 1e3 / 50, 2), "bucket_bytes": 4 * n,
-                "backend": td.get_backend(), "per": "SGD minibatch (one per optimizer step)"}
+                "backend": td.get_backend(), "per": "SGD minibatch (one per optimizer step)",
+                "steps_per_graph": int(getattr(trainer.policy, "_dist_chain_len", 0)),      # 16: [gradient pass, all-reduce, Adam] chains captured (start-up probe passed)
+                "peer_allreduce": getattr(trainer.policy, "_peer", None) is not None}
 
     line = None
     if rank == 0:
