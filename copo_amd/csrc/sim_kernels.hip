@@ -164,8 +164,11 @@ constexpr int ROUTE_LDS_MAX_BYTES = 16 * 1024;
 // neighbour phase: list distances (fp64) [ch][N] -- later reused for the rewards in list order --, list slots (u8) [ch][N],
 // ranks (u8) [ch][N], entry directory (u16) [ch*N]; then the spawn permutation of a reset (int16 [COPO_MAX_SPAWNS])
 __device__ __host__ inline int nbr_lds_words(int ch, int n_agents) { return 3 * ch * n_agents + 4; }
+// LiDAR phase: ray minima [ch][n_lasers]; when one wave owns the scene (ch < n_agents) also the queue of (fan, vehicle) pairs
+// in range, uint16 [ch * n_agents], behind them (mostly inside what the neighbour phase needs anyway)
+__device__ __host__ inline int lidar_queue_words(int ch, int n_agents) { return ch < n_agents ? (ch * n_agents + 1) / 2 : 0; }
 __device__ __host__ inline int lidar_lds_words(int ch, int n_agents, int n_lasers) {
-    const int a = ch * n_lasers, b = nbr_lds_words(ch, n_agents) + COPO_MAX_SPAWNS / 2;
+    const int a = ch * n_lasers + lidar_queue_words(ch, n_agents), b = nbr_lds_words(ch, n_agents) + COPO_MAX_SPAWNS / 2;
     return ((a > b ? a : b) + 3) & ~3;
 }
 __device__ __host__ inline int ray_lds_words(int n_lasers) { return (2 * n_lasers + 3) & ~3; }
@@ -623,11 +626,8 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
     for (int q = tid; q < cha * NL; q += nthreads) best[q] = range_bits;
     __syncthreads();
     const int ncombo = cha * ns;
-    for (int c0 = wave * 64; c0 < ((COPO_PROFILE_SKIP & 2) ? 0 : ncombo); c0 += nwaves * 64) {
-        const int c = c0 + lane;
-        const bool live = c < ncombo;
-        const int lp = live ? (int)(((float)c + 0.5f) * inv_ns) : 0;      // fan of this pass
-        const int i = L.plist[ip0 + lp], j = L.slist[live ? c - lp * ns : 0];
+    // everything per batch of 64 (fan, vehicle) pairs: window, numbering of the box tests, the tests themselves
+    auto pair_batch = [&](const bool live, const int lp, const int i, const int j) {
         const float dx = L.x[j] - L.x[i], dy = L.y[j] - L.y[i];
         const float d2 = dx * dx + dy * dy;
         int klo = 0, cnt = 0;
@@ -690,6 +690,40 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
                 const float tt = ray_box(ox, oy, r.x * cr + r.y * sr, r.y * cr - r.x * sr, hl, hw);
                 if (tt >= 0.0f) atomicMin(&best[slp * NL + k], __float_as_uint(tt));
             }
+        }
+    };
+    if (nwaves == 1 && lidar_queue_words(p.chunk, N) > 0 && !(COPO_PROFILE_SKIP & 2)) {
+        // one wave owns the scene: a cheap pass keeps the pairs within LiDAR reach (about half of them at a junction) in a
+        // queue, the window / test pass then runs on full batches of those -- the window arithmetic executes for a whole
+        // batch as soon as one of its pairs is in reach
+        uint16_t* cq = reinterpret_cast<uint16_t*>(dyn + cha * NL);
+        int nq = 0;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        for (int c0 = 0; c0 < ncombo; c0 += 64) {
+            const int c = c0 + lane;
+            const bool live = c < ncombo;
+            const int lp = live ? (int)(((float)c + 0.5f) * inv_ns) : 0;
+            const int i = L.plist[ip0 + lp], j = L.slist[live ? c - lp * ns : 0];
+            const float dx = L.x[j] - L.x[i], dy = L.y[j] - L.y[i];
+            const bool reach = live && j != i && !(dx * dx + dy * dy > lim * lim);
+            const unsigned long long m = __ballot(reach);
+            if (reach) cq[nq + __popcll(m & lt)] = (uint16_t)c;
+            nq += __popcll(m);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int q0 = 0; q0 < nq; q0 += 64) {
+            const bool live = q0 + lane < nq;
+            const int c = live ? (int)cq[q0 + lane] : 0;
+            const int lp = (int)(((float)c + 0.5f) * inv_ns);
+            pair_batch(live, lp, L.plist[ip0 + lp], L.slist[c - lp * ns]);
+        }
+    } else {
+        for (int c0 = wave * 64; c0 < ((COPO_PROFILE_SKIP & 2) ? 0 : ncombo); c0 += nwaves * 64) {
+            const int c = c0 + lane;
+            const bool live = c < ncombo;
+            const int lp = live ? (int)(((float)c + 0.5f) * inv_ns) : 0;      // fan of this pass
+            pair_batch(live, lp, L.plist[ip0 + lp], L.slist[live ? c - lp * ns : 0]);
         }
     }
     __syncthreads();
