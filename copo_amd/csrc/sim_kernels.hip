@@ -961,6 +961,34 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(const SimP
         const int npair = na * nc;
         const float inv_nc = 1.0f / (float)(nc > 0 ? nc : 1);
         const float near2 = 4.0f * (hl * hl + hw * hw) * 1.001f;   // farther apart than two circumradii: no overlap
+        extern __shared__ unsigned int dyn[];
+        const int qcap = 2 * nbr_lds_words(p.chunk > 0 ? p.chunk : N, N);          // the neighbour work area is free here
+        if (nwaves == 1 && npair <= qcap && !(COPO_PROFILE_SKIP & 16)) {
+            // one wave owns the scene: the pairs closer than two circumradii (a few per vehicle in a queue of cars) are
+            // queued by a cheap pass and box-tested in full batches; the separating-axis test otherwise runs for a whole
+            // batch of 64 pairs as soon as one of them is close
+            uint16_t* nq = reinterpret_cast<uint16_t*>(dyn);
+            int nn = 0;
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            for (int c0 = 0; c0 < npair; c0 += 64) {
+                const int c = c0 + lane;
+                const bool live = c < npair;
+                const int ia = live ? (int)(((float)c + 0.5f) * inv_nc) : 0;
+                const int i = L.alist[ia], j = L.clist[live ? c - ia * nc : 0];
+                const float ddx = L.x[j] - L.x[i], ddy = L.y[j] - L.y[i];
+                const bool near = live && (i != j) && (ddx * ddx + ddy * ddy <= near2);
+                const unsigned long long m = __ballot(near);
+                if (near) nq[nn + __popcll(m & lt)] = (uint16_t)((i << 8) | j);
+                nn += __popcll(m);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int q0 = 0; q0 < nn; q0 += 64) {
+                const bool live = q0 + lane < nn;
+                const int pk = live ? (int)nq[q0 + lane] : 0, i = pk >> 8, j = pk & 255;
+                if (live && obb_overlap2(L.x[i], L.y[i], L.cs[i], L.sn[i], hl, hw, L.x[j], L.y[j], L.cs[j], L.sn[j], hl, hw)) L.crash[i] = 1;
+            }
+        } else
         for (int c0 = wave * 64; c0 < ((COPO_PROFILE_SKIP & 16) ? 0 : npair); c0 += nwaves * 64) {
             const int c = c0 + lane;
             const bool live = c < npair;
