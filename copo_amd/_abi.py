@@ -26,7 +26,7 @@ SIM_CFG_FIELDS = [
     ("max_steer", C.c_float), ("max_speed", C.c_float), ("acc_max", C.c_float), ("brake_gain", C.c_float),
     ("brake_max", C.c_float), ("spawn_region_len", C.c_float), ("spawn_region_wid", C.c_float),
     ("driving_reward", C.c_float), ("speed_reward", C.c_float), ("success_reward", C.c_float),
-    ("crash_penalty", C.c_float), ("out_penalty", C.c_float), ("arrive_margin", C.c_float),
+    ("crash_penalty", C.c_float), ("out_penalty", C.c_float), ("arrive_margin", C.c_float), ("body_margin", C.c_float),
     ("lane_width", C.c_float),
     ("lcf_mean", C.c_double), ("lcf_std", C.c_double),
     ("n_routes", C.c_int32), ("n_spawns", C.c_int32),

@@ -100,7 +100,7 @@ extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** o
         if (r0 < 0 || nc < 1 || r0 + nc > cfg->n_routes) return fail(COPO_ERR_CONFIG, "spawn %d: bad route range", s);
         for (int r = r0; r < r0 + nc; ++r) {
             const float* g = cfg->route_segs + (size_t)r * (COPO_MAX_SEGS + 1) * COPO_SEG_STRIDE;
-            if (g[5] != 0.0f || !(cfg->spawn_s[s] < g[4]) || cfg->spawn_tab[s * 4 + 2] < 0 || (float)cfg->spawn_tab[s * 4 + 2] >= g[COPO_SEG_LANES])
+            if (g[5] != 0.0f || !(cfg->spawn_s[s] < g[4]) || cfg->spawn_tab[s * 4 + 2] < 0 || (float)cfg->spawn_tab[s * 4 + 2] >= floorf(g[COPO_SEG_LANES]))
                 return fail(COPO_ERR_CONFIG, "spawn %d must lie on a lane of the straight first road of route %d", s, r);
         }
         if (cfg->spawn_tab[s * 4 + 3]) safe.push_back(s);
@@ -155,7 +155,7 @@ extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** o
     p.brake_max = cfg->brake_max;
     p.region_hl = 0.5f * cfg->spawn_region_len; p.region_hw = 0.5f * cfg->spawn_region_wid;
     p.driving_reward = cfg->driving_reward; p.speed_reward = cfg->speed_reward; p.success_reward = cfg->success_reward;
-    p.crash_penalty = cfg->crash_penalty; p.out_penalty = cfg->out_penalty; p.arrive_margin = cfg->arrive_margin;
+    p.crash_penalty = cfg->crash_penalty; p.out_penalty = cfg->out_penalty; p.arrive_margin = cfg->arrive_margin; p.body_margin = cfg->body_margin;
     p.lane_width = cfg->lane_width;
     p.side_range = cfg->side_range; p.lane_range = cfg->lane_line_range;
     // derived constants: single float operations (this file is compiled with -ffp-contract=off), as in the oracle

@@ -446,7 +446,7 @@ __device__ __forceinline__ void ego_navi_obs(const SimParams& p, EnvLds& L, int 
     float sl, lat, sinpsi;
     project_seg(g, s.x, s.y, cs, sn, sl, lat, sinpsi);
     const float w = p.lane_width;
-    const float lanes = g[COPO_SEG_LANES];
+    const float lanes = floorf(g[COPO_SEG_LANES]);
     float lif = floorf(0.5f - lat * p.inv_w);
     lif = lif < 0.0f ? 0.0f : (lif > lanes - 1.0f ? lanes - 1.0f : lif);
     const float left = 0.5f * w - lat;
@@ -1060,11 +1060,14 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(const SimP
             s.route = route | (seg << 16);
             s.prog = prog;
             const float w = p.lane_width;
-            const float lanes = g[COPO_SEG_LANES];
+            const float lanes_f = g[COPO_SEG_LANES], lanes = floorf(lanes_f), lfr = lanes_f - lanes;      // fraction: edge-line flags
+            const bool left_solid = (lfr == 0.25f) || (lfr == 0.75f), right_solid = lfr >= 0.5f;
             float lif = floorf(0.5f - lat * p.inv_w);
             lif = lif < 0.0f ? 0.0f : (lif > lanes - 1.0f ? lanes - 1.0f : lif);
             const float left = 0.5f * w - lat, right = lanes * w - left;
-            const bool on_road = (left >= 0.0f) && (right >= 0.0f);
+            const float cos2 = 1.0f - sinpsi * sinpsi;
+            const float edge = p.body_margin * (hw * sqrtf(cos2 > 0.0f ? cos2 : 0.0f) + hl * fabsf(sinpsi));      // body extent across the road
+            const bool on_road = (left >= (left_solid ? edge : 0.0f)) && (right >= (right_solid ? edge : 0.0f));
             const bool arrive = (seg == nseg - 1) && (sl > g[4] - p.arrive_margin) && (sl < g[4] + p.arrive_margin) && on_road;
             const bool oor = !on_road;
             const bool crash = (L.crash[lane] != 0) || too_fast;

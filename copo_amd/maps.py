@@ -98,12 +98,15 @@ class Net:
         self.adj = OrderedDict()
         self.lines = []          # [x0, y0, theta0, length, kappa, kind, 0, 0]
         self.toll_roads = set()  # roads that are toll booths (Tollgate)
+        self.solid = {}          # road -> (left edge continuous, right edge continuous)
 
     def add(self, a, b, pose, length, kappa, lanes, left_line=LINE_CONTINUOUS, right_line=LINE_CONTINUOUS,
             inner_line=LINE_BROKEN, toll=False):
         """`pose` is the start of lane 0's centre line.  Line kinds: 0 = none (inside junctions)."""
         assert (a, b) not in self.roads, (a, b)
         self.roads[(a, b)] = (tuple(float(v) for v in pose), float(length), float(kappa), int(lanes))
+        # edge lines that a vehicle's body must not touch (MetaDrive: on_yellow / on_white_continuous_line): continuous ones
+        self.solid[(a, b)] = (left_line == LINE_CONTINUOUS, right_line == LINE_CONTINUOUS)
         if toll:
             self.toll_roads.add((a, b))
         self.adj.setdefault(a, []).append(b)
@@ -152,15 +155,16 @@ class Net:
         return path[::-1]
 
 
-def road_record(pose, length, kappa, lanes, s_start, w):
-    """One SEG_STRIDE record (float64) for a road whose lane-0 line starts at `pose`."""
+def road_record(pose, length, kappa, lanes, s_start, w, solid=(False, False)):
+    """One SEG_STRIDE record (float64) for a road whose lane-0 line starts at `pose`.  The lanes field carries the edge-line
+    flags in its fraction: lanes + 0.25 (left edge continuous) + 0.5 (right edge continuous)."""
     x, y, th = pose
     rec = np.zeros(SEG_STRIDE, np.float64)
     rec[[SEG_X0, SEG_Y0, SEG_COS, SEG_SIN, SEG_LEN, SEG_KAPPA, SEG_S0, SEG_TH0]] = [
         x, y, math.cos(th), math.sin(th), length, kappa, s_start, _wrap(th)]
     end = advance(pose, length, kappa)
     ck = shift(end, -(lanes / 2.0 - 0.5) * w)          # end of the road, lateral middle (Navigation check point)
-    rec[SEG_CKX], rec[SEG_CKY], rec[SEG_LANES] = ck[0], ck[1], lanes
+    rec[SEG_CKX], rec[SEG_CKY], rec[SEG_LANES] = ck[0], ck[1], lanes + 0.25 * bool(solid[0]) + 0.5 * bool(solid[1])
     if kappa == 0:
         rec[SEG_F_RADIUS], rec[SEG_RADIUS], rec[SEG_F_ANGLE] = 0.0, 0.0, 0.5
         rec[SEG_UMX], rec[SEG_UMY] = 1.0, 0.0
@@ -187,17 +191,18 @@ class _Builder:
         if len(nodes) - 1 > MAX_SEGS:
             raise ValueError("route needs %d roads > MAX_SEGS" % (len(nodes) - 1))
         rec = np.zeros((MAX_SEGS + 1, SEG_STRIDE), np.float64)
-        s, lanes, toll = 0.0, 1, -1
+        s, lanes, toll, solid = 0.0, 1, -1, (False, False)
         for k in range(len(nodes) - 1):
             pose, ln, kap, lanes = net.roads[(nodes[k], nodes[k + 1])]
+            solid = net.solid[(nodes[k], nodes[k + 1])]
             if (nodes[k], nodes[k + 1]) in net.toll_roads:
                 toll = k
-            rec[k] = road_record(pose, ln, kap, lanes, s, w)
+            rec[k] = road_record(pose, ln, kap, lanes, s, w, solid)
             s += ln
         end = net.end_pose(nodes[-2], nodes[-1])
         nseg = len(nodes) - 1
         for k in range(nseg, MAX_SEGS + 1):     # terminal record(s): end pose, zero length
-            rec[k] = road_record(end, 0.0, 0.0, lanes, s, w)
+            rec[k] = road_record(end, 0.0, 0.0, lanes, s, w, solid)
         self.routes.append(rec)
         self.meta.append([s, nseg, toll, 0.0])
 
@@ -488,6 +493,7 @@ def _pgmap(sequence="SCS", seed=0, lanes=2, lane_width=LANE_WIDTH, lead=50.0):
             last = fnodes[-1]
             rd = net.roads.pop((fnodes[-2], last))
             net.roads[(fnodes[-2], "f%d" % (k + 1))] = rd
+            net.solid[(fnodes[-2], "f%d" % (k + 1))] = net.solid.pop((fnodes[-2], last))
             net.adj[fnodes[-2]] = ["f%d" % (k + 1) if v == last else v for v in net.adj[fnodes[-2]]]
             net.adj.pop(last, None)
             net.adj.setdefault("f%d" % (k + 1), [])
@@ -553,7 +559,7 @@ def bounding_box(tables: MapTables, step=2.0):
     lo, hi = np.array([np.inf, np.inf]), np.array([-np.inf, -np.inf])
     for r in range(tables.n_routes):
         pts = route_points(tables, r, step)
-        pad = float(tables.route_segs[r, :, SEG_LANES].max()) * tables.lane_width
+        pad = float(np.floor(tables.route_segs[r, :, SEG_LANES]).max()) * tables.lane_width
         lo, hi = np.minimum(lo, pts.min(0) - pad), np.maximum(hi, pts.max(0) + pad)
     return float(lo[0]), float(hi[0]), float(lo[1]), float(hi[1])
 

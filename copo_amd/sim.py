@@ -56,6 +56,7 @@ class SimConfig:
     crash_penalty: float = 10.0
     out_penalty: float = 10.0
     arrive_margin: float = 5.0
+    body_margin: float = 0.75         # pinned by the reference populations: 0 = centre rule, 1 = whole body
     lane_width: float = 3.5
     lcf_mean: float = 0.0
     lcf_std: float = 0.1               # env_wrappers.py:176
@@ -142,7 +143,7 @@ def fill_cfg_struct(cfg: SimConfig, struct_cls):
     c.horizon, c.delay_done, c.respawn_cooldown, c.substeps = cfg.horizon, cfg.delay_done, cfg.respawn_cooldown, cfg.substeps
     for k in ("lidar_range", "neighbours_distance", "mf_distance", "dt", "veh_half_len", "veh_half_wid", "wheelbase",
               "max_steer", "max_speed", "acc_max", "brake_gain", "brake_max", "spawn_region_len", "spawn_region_wid",
-              "driving_reward", "speed_reward", "success_reward", "crash_penalty", "out_penalty", "arrive_margin",
+              "driving_reward", "speed_reward", "success_reward", "crash_penalty", "out_penalty", "arrive_margin", "body_margin",
               "lane_width", "side_range", "lane_line_range"):
         setattr(c, k, float(getattr(cfg, k)))
     c.lcf_mean, c.lcf_std = float(cfg.lcf_mean), float(cfg.lcf_std)

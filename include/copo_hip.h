@@ -75,7 +75,8 @@ extern "C" {
  *   0 x0, 1 y0, 2 cos0, 3 sin0   start pose            4 length      5 kappa (signed: + = counter-clockwise)
  *   6 s_start (route arc length at the start)           7 theta0
  *   8 ckx, 9 cky   navigation check point: the end of the road at its lateral middle
- *  10 lanes       11 radius feature of the navigation block, 12 radius (0 for a straight), 13 angle feature
+ *  10 lanes + 0.25 (left edge line continuous) + 0.5 (right edge line continuous): the edges a body must not touch (body_margin)
+ *                  11 radius feature of the navigation block, 12 radius (0 for a straight), 13 angle feature
  *  14 umx, 15 umy unit vector from an arc's centre to its mid point (projection without a wrap inside the arc)
  * A route has nseg roads followed by one terminal record (length 0) holding the end pose. */
 #define COPO_SEG_CKX 8
@@ -116,6 +117,9 @@ typedef struct copo_sim_cfg {
     /* reward (MetaDrive multi-agent scheme) */
     float driving_reward, speed_reward, success_reward, crash_penalty, out_penalty;
     float arrive_margin;       /* arrival: within +- this of the end of the final road */
+    float body_margin;         /* out of road when the BODY touches the road's edge lines (MetaDrive: on_yellow / on_white_continuous_line,
+                                  crash_sidewalk): the centre must keep body_margin x (half_wid |cos| + half_len |sin| of the heading
+                                  error) from both edges.  0: the centre rule (vehicle.out_of_route alone) */
     float lane_width;
     /* LCF distribution at creation (LCFEnv.current_lcf_mean/std, env_wrappers.py:200-201) */
     double lcf_mean, lcf_std;

@@ -470,7 +470,7 @@ static void write_obs(oracle_sim* s, int e, const copo_step_out* out, const uint
         const float* g = SEG(s, route, seg);
         float sl, lat, sinpsi;
         project_seg(g, x, y, cs[i], sn[i], &sl, &lat, &sinpsi);
-        float lanes = g[COPO_SEG_LANES];
+        float lanes = floorf(g[COPO_SEG_LANES]);
         float lif = floorf(0.5f - lat * s->inv_w);
         lif = lif < 0.0f ? 0.0f : (lif > lanes - 1.0f ? lanes - 1.0f : lif);
         float left = 0.5f * w - lat;            /* distance to the left edge of the road (of the current route) */
@@ -854,11 +854,15 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
             }
             IP(s, S_ROUTE, e)[n] = route | (seg << 16);
             FP(s, S_PROG, e)[n] = prog;
-            float lanes = g[COPO_SEG_LANES];
+            float lanes_f = g[COPO_SEG_LANES], lanes = floorf(lanes_f), lfr = lanes_f - lanes;      /* fraction: edge-line flags */
+            int left_solid = (lfr == 0.25f) || (lfr == 0.75f), right_solid = lfr >= 0.5f;
             float lif = floorf(0.5f - lat * s->inv_w);
             lif = lif < 0.0f ? 0.0f : (lif > lanes - 1.0f ? lanes - 1.0f : lif);
             float left = 0.5f * w - lat, right = lanes * w - left;
-            int on_road = (left >= 0.0f) && (right >= 0.0f);
+            /* the body's half extent across the road (heading error psi): the edge lines must not be touched */
+            float cos2 = 1.0f - sinpsi * sinpsi;
+            float edge = c->body_margin * (hw * sqrtf(cos2 > 0.0f ? cos2 : 0.0f) + hl * fabsf(sinpsi));
+            int on_road = (left >= (left_solid ? edge : 0.0f)) && (right >= (right_solid ? edge : 0.0f));
             /* _is_arrive_destination: within +-5 m of the end of the final road, anywhere across it */
             int arrive = (seg == nseg - 1) && (sl > g[4] - c->arrive_margin) && (sl < g[4] + c->arrive_margin) && on_road;
             int out_of_road = !on_road;         /* vehicle.out_of_route (out_of_route_done) */

@@ -66,11 +66,11 @@ def test_map_tables(name):
             assert abs(maps._wrap(end[2] - nxt[maps.SEG_TH0])) < 1e-4 or k == nseg - 1
         # navigation check point: the end of the road, at its lateral middle
         for k in range(nseg):
-            nxt, lanes = seg[k + 1], seg[k, maps.SEG_LANES]
+            nxt, lanes = seg[k + 1], np.floor(seg[k, maps.SEG_LANES])
             mid = maps.shift((nxt[0], nxt[1], nxt[maps.SEG_TH0]) if k < nseg - 1 else
                              maps.advance((seg[k, 0], seg[k, 1], seg[k, maps.SEG_TH0]), seg[k, maps.SEG_LEN], seg[k, maps.SEG_KAPPA]),
                              -(lanes / 2 - 0.5) * t.lane_width)
-            if k == nseg - 1 or seg[k + 1, maps.SEG_LANES] == lanes:
+            if k == nseg - 1 or np.floor(seg[k + 1, maps.SEG_LANES]) == lanes:
                 assert np.hypot(mid[0] - seg[k, maps.SEG_CKX], mid[1] - seg[k, maps.SEG_CKY]) < 2e-3
     # spawn slots keep clear of each other: lanes 3.5 m apart, slots >= 8 m along a lane
     sp = []
@@ -94,7 +94,7 @@ def test_intersection_and_roundabout_follow_the_block_formulas():
     kinds = {}
     for r in range(4):          # the four routes of arm 0
         g = t.route_segs[r, 1].astype(np.float64)
-        kinds[round(float(g[maps.SEG_LEN]), 3)] = (float(g[maps.SEG_KAPPA]), float(g[maps.SEG_LANES]))
+        kinds[round(float(g[maps.SEG_LEN]), 3)] = (float(g[maps.SEG_KAPPA]), float(np.floor(g[maps.SEG_LANES])))
     assert set(kinds) == {round(1.75 * np.pi, 3), round(13.5 * np.pi / 2, 3), 30.5, round(17 * np.pi / 2, 3)}
     assert abs(kinds[round(13.5 * np.pi / 2, 3)][0] + 1 / 13.5) < 1e-6 and abs(kinds[round(17 * np.pi / 2, 3)][0] - 1 / 17) < 1e-6
     r = maps.roundabout()

@@ -8,7 +8,8 @@ import oracle_lib as ol
 
 
 def test_oracle_builds_and_versions():
-    assert ol.lib().oracle_version() == 2
+    from copo_amd._abi import ABI_VERSION
+    assert ol.lib().oracle_version() == ABI_VERSION == 3
 
 
 def test_neighbours_and_rewards_vs_reference(golden_dir):
