@@ -45,11 +45,12 @@ def test_reference_intersection_populations_drive_the_hip_simulator(golden_dir):
     print("ippo", ippo, "\ncopo", copo, "\nccppo", ccppo, "\nreference (MetaDrive)", ref)
     # MetaDrive: IPPO populations 0.48 success / 0.42 crash / 27 km/h, CoPO 0.78 / 0.15 / 14 km/h.  The bands below are
     # wide enough for the physics difference (kinematic bicycle vs Bullet) and far from the ~0 of wrong semantics.
-    assert abs(ippo["success"] - ref["ippo_inter"]["success_rate"]) < 0.15, ippo
-    assert abs(copo["success"] - ref["copo_inter"]["success_rate"]) < 0.15, copo
+    assert abs(ippo["success"] - ref["ippo_inter"]["success_rate"]) < 0.08, ippo        # 0.475 vs 0.480
+    assert abs(copo["success"] - ref["copo_inter"]["success_rate"]) < 0.08, copo        # 0.781 vs 0.783
+    assert 0.02 < ippo["out"] < 0.15 and 0.02 < copo["out"] < 0.18                      # MetaDrive 0.10 / 0.06: the body-touches-edge-line rule
     assert copo["success"] > ippo["success"] + 0.1                    # the ranking of the reference's table
     assert ccppo["success"] > 0.45
-    assert copo["crash"] < 0.3 and ippo["out"] < 0.15 and copo["out"] < 0.15
+    assert copo["crash"] < 0.3
     assert abs(ippo["velocity"] - ref["ippo_inter"]["velocity_step_mean_episode_mean"]) < 8.0
     assert abs(copo["velocity"] - ref["copo_inter"]["velocity_step_mean_episode_mean"]) < 8.0
     assert copo["length"] > 1.5 * ippo["length"]                      # CoPO's populations are the patient ones (308 vs 132 steps)
