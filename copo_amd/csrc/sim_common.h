@@ -23,7 +23,7 @@ struct SimParams {
     int32_t side_lasers, lane_lasers, navi_dim, toll_dim, toll_min_steps;
     int32_t lists_for_absent;      // 1: nbr_idx / nbr_dist rows of absent slots are filled with -1 / 0 (the stateless op); 0: left alone
     float lidar_range, neighbours_distance, mf_distance, dt, hl, hw, wheelbase, max_steer, max_speed;
-    float acc_max, brake_gain, brake_max, region_hl, region_hw;
+    float acc_max, brake_gain, brake_max, lat_acc_max, region_hl, region_hw;
     float driving_reward, speed_reward, success_reward, crash_penalty, out_penalty, arrive_margin, body_margin, lane_width;
     float side_range, lane_range;
     float ray_sign;                // +1: beam k is turned k steps counter-clockwise of the heading, -1: clockwise (MetaDrive)

@@ -918,7 +918,11 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(const SimP
                     x = x + v * dxh * h;
                     y = y + v * dyh * h;
                     // turn the heading vector by the sub-step's small angle: 3-term sine / cosine, no range reduction
-                    const float dth = v * yawk * h;
+                    float dth = v * yawk * h;
+                    if (p.lat_acc_max > 0.0f && v * fabsf(dth) > p.lat_acc_max * h) {      // tyres slide: v x yaw rate is friction-limited
+                        const float lim = (p.lat_acc_max * h) / v;
+                        dth = dth < 0.0f ? -lim : lim;
+                    }
                     const float q = dth * dth;
                     const float sd2 = dth - dth * q * (0.166666667f - q * 0.00833333333f);
                     const float cd2 = 1.0f - q * (0.5f - q * 0.0416666667f);

@@ -113,6 +113,7 @@ typedef struct copo_sim_cfg {
     float max_speed;           /* m/s */
     float acc_max;             /* m/s^2 at full throttle (engine force cut above max_speed) */
     float brake_gain, brake_max; /* deceleration = min(brake_gain * |a1|, brake_max) for a1 < 0 */
+    float lat_acc_max;         /* tyre friction limit on the lateral acceleration v x yaw rate (m/s^2); 0 = none (the bicycle turns on rails) */
     float spawn_region_len, spawn_region_wid; /* the box that must hold no vehicle for a respawn (8 x 3 m) */
     /* reward (MetaDrive multi-agent scheme) */
     float driving_reward, speed_reward, success_reward, crash_penalty, out_penalty;

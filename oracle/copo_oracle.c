@@ -779,6 +779,10 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
                 x = x + v * dxh * h;
                 y = y + v * dyh * h;
                 float dth = v * yawk * h;
+                if (c->lat_acc_max > 0.0f && v * fabsf(dth) > c->lat_acc_max * h) {      /* tyres slide: v x yaw rate is friction-limited */
+                    float lim = (c->lat_acc_max * h) / v;
+                    dth = dth < 0.0f ? -lim : lim;
+                }
                 float q = dth * dth;
                 float sd2 = dth - dth * q * (0.166666667f - q * 0.00833333333f);
                 float cd2 = 1.0f - q * (0.5f - q * 0.0416666667f);
