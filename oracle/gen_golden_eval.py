@@ -95,6 +95,8 @@ def populations():
         files = sorted(glob.glob(os.path.join(res_dir, "%s_inter_*.csv" % algo)))
         d = pd.concat([pd.read_csv(f) for f in files])
         stats[algo + "_inter"] = dict(populations=len(files), episodes=int(len(d)), **{c: float(d[c].mean()) for c in cols})
+        # per population (the shipped `copo_inter.npz` is population 0: get_policy_function.py:30-31 "Best")
+        stats[algo + "_inter_per_population"] = [{c: float(pd.read_csv(f)[c].mean()) for c in cols} for f in files]
     with open(os.path.join(OUT, "reference_eval_stats.json"), "w") as f:
         json.dump(stats, f, indent=1, sort_keys=True)
     print("wrote reference_populations.npz", os.path.getsize(os.path.join(OUT, "reference_populations.npz")), stats)
