@@ -14,7 +14,7 @@ from copo_amd.eval.get_policy_function import meta_svo_lookup_table  # noqa: E40
 G1 = np.load(os.path.join(ROOT, "tests", "golden", "eval_policy_function.npz"))
 G2 = np.load(os.path.join(ROOT, "tests", "golden", "reference_populations.npz"))
 with open(os.path.join(ROOT, "tests", "golden", "reference_eval_stats.json")) as f:
-    print("# reference, MetaDrive (eval/demo_results):", json.dumps({k: {c: round(v, 3) for c, v in d.items()} for k, d in json.load(f).items()}))
+    print("# reference, MetaDrive (eval/demo_results):", json.dumps({k: {c: round(v, 3) for c, v in d.items()} for k, d in json.load(f).items() if isinstance(d, dict)}))
 scene_episodes = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 ENV_OVER = json.loads(sys.argv[2]) if len(sys.argv) > 2 else {}      # e.g. '{"body_margin": 0.5}'      # whole scene episodes (until done["__all__"]) of 64 scenes each
 KEEP = ("success_rate_mean", "crash_rate_mean", "out_of_road_rate_mean", "max_step_rate_mean", "episode_reward_mean",
