@@ -279,3 +279,58 @@ def test_module_surface_of_the_reference():
     with pytest.raises(Exception):
         deep_update(dict(x=1), dict(z=2))
     assert deep_update(dict(m=dict(type="a", p=1)), dict(m=dict(type="b")), False, None, ["m"]) == dict(m=dict(type="b"))
+
+
+def test_bootstrap_correction_is_gae_with_the_next_value():
+    """trainer.PPOPolicyBase._apply_bootstrap (CPU): the last-row scan of the GAE op plus the linear correction == GAE with an
+    explicit bootstrap value for every trajectory that runs into the end of the fragment (RLlib's `last_r = V(next obs)`),
+    for trajectories that start, end and restart inside the fragment, three heads with their own gammas."""
+    import oracle_lib as ol
+    from copo_amd.trainer import PPOPolicyBase
+    rng = np.random.RandomState(4)
+    H, T, M, lam, gammas = 3, 9, 40, 0.95, [0.99, 0.99, 1.0]
+    acted = rng.uniform(size=(T, M)) > 0.15
+    done = acted & (rng.uniform(size=(T, M)) < 0.12)
+    flags = (acted * 1 + done * 2).astype(np.uint8)
+    rew = rng.normal(0, 1, (H, T, M)).astype(np.float32)
+    val = rng.normal(0, 5, (H, T, M)).astype(np.float32)
+    v_next = rng.normal(0, 5, (H, M)).astype(np.float32)
+    adv, tgt = ol.gae3(rew, val, flags, gammas, lam)          # bootstraps a cut trajectory from its last row
+
+    class P:
+        def gae_gammas(self):
+            return gammas
+
+    a, g = torch.from_numpy(adv.copy()), torch.from_numpy(tgt.copy())
+    PPOPolicyBase._apply_bootstrap(P(), torch.from_numpy(val), a, g, torch.from_numpy(flags), lam, torch.from_numpy(v_next))
+    a, g = a.numpy().astype(np.float64), g.numpy().astype(np.float64)
+    checked = 0
+    for m in range(M):
+        t = 0
+        while t < T:
+            if not acted[t, m]:
+                t += 1
+                continue
+            t0 = t
+            while t < T and acted[t, m] and not done[t, m]:
+                t += 1
+            ended = t < T and done[t, m]
+            t1 = t if ended else t - 1
+            t = t1 + 1
+            for h in range(H):
+                if ended:
+                    last = 0.0
+                elif t1 == T - 1:
+                    last = float(v_next[h, m])
+                else:
+                    last = float(val[h, t1, m])      # cut by an empty slot inside the fragment: the op's own shortcut stays
+                v = np.concatenate([val[h, t0:t1 + 1, m].astype(np.float64), [last]])
+                delta = rew[h, t0:t1 + 1, m] + gammas[h] * v[1:] - v[:-1]
+                acc, want = 0.0, np.zeros_like(delta)
+                for k in range(len(delta) - 1, -1, -1):
+                    acc = delta[k] + gammas[h] * lam * acc
+                    want[k] = acc
+                np.testing.assert_allclose(a[h, t0:t1 + 1, m], want, rtol=1e-4, atol=1e-4)
+                np.testing.assert_allclose(g[h, t0:t1 + 1, m], want + val[h, t0:t1 + 1, m], rtol=1e-4, atol=1e-4)
+            checked += 1
+    assert checked > 60
