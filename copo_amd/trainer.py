@@ -652,34 +652,33 @@ class PPOPolicyBase:
         return True if v is None else bool(v)
 
     def _bootstrap_from_next_obs(self, b, vals, adv, tgt, flags, lam):
-        """V(observation after the last step) for the trajectories that run into the end of the fragment."""
+        """V(observation after the last step) for the trajectories that run into the end of the fragment (evaluated for every
+        slot: a dense forward pass costs less than listing the live slots would -- that needs a host round trip)."""
         H, T, M = vals.shape
         nxt = b["_next_obs_last"].reshape(M, -1)
-        fl = flags[T - 1].to(torch.int32)
-        alive = ((fl & F_ACTED) > 0) & ((fl & F_DONE) == 0)
-        idx = alive.nonzero(as_tuple=False).view(-1)
-        if idx.numel() == 0:
-            return
         fz = self.fused
         if fz is not None and fz.can_forward and self.config.get("use_fused_inference", True) and int(fz.cfg.n_value_heads) == H:
-            v_next = fz.values(nxt.contiguous(), None, rows=idx)
+            v_next = fz.values(nxt.contiguous(), None)
         else:
-            v_next = torch.zeros(H, M, device=vals.device)
-            v_next[:, idx] = self.value_heads_dense(nxt[idx])
+            v_next = self.value_heads_dense(nxt)
         self._apply_bootstrap(vals, adv, tgt, flags, lam, v_next)
+
+    _boot_w = None
 
     def _apply_bootstrap(self, vals, adv, tgt, flags, lam, v_next):
         """GAE is linear in the bootstrap value: replacing V(last row) by `v_next` [H, M] adds (gamma lambda)^(T-1-t) gamma
         (v_next - V(last row)) to every row t of the trajectory that runs into the end of the fragment."""
         H, T, M = vals.shape
-        fl = flags.to(torch.int32)
-        cont = ((fl & F_ACTED) > 0) & ((fl & F_DONE) == 0)                          # [T, M] the agent drives on after row t
+        key = (H, T, float(lam), tuple(self.gae_gammas()), str(vals.device))
+        if self._boot_w is None or self._boot_w[0] != key:
+            gam = torch.tensor(self.gae_gammas(), dtype=torch.float32, device=vals.device).view(H, 1, 1)
+            k = torch.arange(T - 1, -1, -1, device=vals.device, dtype=torch.float32).view(1, T, 1)
+            self._boot_w = (key, gam.view(H, 1), torch.pow(gam * lam, k))              # gamma [H, 1], (gamma lambda)^(T-1-t) [H, T, 1]
+        gam, w = self._boot_w[1], self._boot_w[2]
+        cont = (flags & (F_ACTED | F_DONE)) == F_ACTED                                # [T, M] the agent drives on after row t
         run = torch.flip(torch.cumprod(torch.flip(cont, [0]).to(torch.float32), 0), [0])      # rows of the trajectory alive at the end
-        gam = torch.tensor(self.gae_gammas(), dtype=torch.float32, device=vals.device).view(H, 1)
-        delta = gam * (v_next - vals[:, T - 1]) * cont[T - 1].to(torch.float32)       # [H, M]
-        k = torch.arange(T - 1, -1, -1, device=vals.device, dtype=torch.float32).view(1, T, 1)
-        w = torch.pow(gam.view(H, 1, 1) * lam, k) * run.unsqueeze(0)                      # [H, T, M]
-        corr = w * delta.unsqueeze(1)
+        delta = gam * (v_next - vals[:, T - 1]) * run[T - 1]                             # [H, M]
+        corr = w * run.unsqueeze(0) * delta.unsqueeze(1)
         adv += corr
         tgt += corr
 

@@ -298,6 +298,8 @@ def test_bootstrap_correction_is_gae_with_the_next_value():
     adv, tgt = ol.gae3(rew, val, flags, gammas, lam)          # bootstraps a cut trajectory from its last row
 
     class P:
+        _boot_w = None
+
         def gae_gammas(self):
             return gammas
 
