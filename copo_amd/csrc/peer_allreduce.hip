@@ -65,9 +65,12 @@ __device__ __forceinline__ bool peer_wait(const uint32_t* flag, uint32_t want, u
 // the last of the grid's workgroups to arrive returns true (and re-arms the counter)
 __device__ __forceinline__ bool grid_arrive(uint32_t* counter) {
     __shared__ uint32_t last;
+    // EVERY thread releases its own peer stores at system scope before the barrier: the workgroup barrier alone does not
+    // wait for other waves' outstanding vector stores (vmcnt), so a fence by thread 0 only could publish the arrival
+    // ahead of their scatter / reduce stores into xGMI memory
+    __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence_system();       // this workgroup's stores before its arrival
         const uint32_t v = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         last = (v == gridDim.x - 1) ? 1u : 0u;
         if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

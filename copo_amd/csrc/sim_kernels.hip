@@ -4,7 +4,8 @@
 // are spread over every thread of the workgroup.  Per-scene poses / masks are staged in LDS.
 //
 // Replaces, behind the C ABI of include/copo_hip.h:
-//   MultiAgent*Env.step / reset          (MetaDrive; call site utils/env_wrappers.py:95)  -- build-defined spec
+//   MultiAgent*Env.step / reset          (MetaDrive 0.2.5; call site utils/env_wrappers.py:95) -- MetaDrive's published
+//                                        semantics restated, pinned through the reference's populations
 //   CCEnv._update_distance_map/_find_in_range/step   (utils/env_wrappers.py:89-158)
 //   LCFEnv.step reward block + _add_lcf  (utils/env_wrappers.py:307-418)
 //

@@ -243,7 +243,12 @@ class VecSim:
         self._capi.check(self._capi.lib.copo_sim_flush(self._h, self._stream()))
 
     def set_block(self, threads):
+        """Launch shape of the step / reset kernels.  The shape parameters live in the device parameter block, so a hipGraph
+        captured before this call would replay its OLD block size against the NEW chunking: every holder of a captured
+        rollout registers a callback in `on_shape_change` (VecSampler does) and is reset here."""
         self._capi.check(self._capi.lib.copo_sim_set_block(self._h, int(threads)))
+        for cb in list(getattr(self, "on_shape_change", ())):
+            cb()
 
     def get_state(self):
         torch = self._torch

@@ -106,6 +106,9 @@ class VecSampler:
         self._reset_out = sim.make_step_out(dict(obs=self.obs[0]))
         self._started = False
         self._loop = GraphedCallable(self._rollout, use_graph and dev.type == "cuda")
+        if not hasattr(sim, "on_shape_change"):
+            sim.on_shape_change = []
+        sim.on_shape_change.append(self._loop.reset)      # VecSim.set_block invalidates the captured rollout
         self.env_steps_total = 0
 
     def reset(self, seeds=None):
@@ -200,7 +203,11 @@ class PPOPolicyBase:
         if bool(config.get("use_fused_learner", True)) and cuda and not config.get("grad_clip"):
             from .fused import FusedLearner
             adv_key, meta_key = self.fused_adv_keys()
-            if self.autocast_dtype is None or meta_key is None:
+            hid = [int(h) for h in (config["model"].get("fcnet_hiddens") or [256, 256])]
+            # the bfloat16-operand mode exists only in the row-pass kernels (hidden 64 / 128 / 256 / 512, two equal layers):
+            # other widths keep the torch.autocast step instead of failing at the first SGD step
+            bf16_ok = self.autocast_dtype is None or (len(hid) == 2 and hid[0] == hid[1] and hid[0] in (64, 128, 256, 512))
+            if (self.autocast_dtype is None or meta_key is None) and bf16_ok:
                 self.fused = FusedLearner(self, self.train_columns(), int(config["sgd_minibatch_size"]), adv_key, meta_key)
                 # writers that only hold the nn.Module (checkpoint_io.load_policy_weights) reach the mirror through this hook
                 object.__setattr__(self.model, "_on_external_write", self._weights_changed)
@@ -623,7 +630,10 @@ class PPOPolicyBase:
                 adv[:, lo:hi], tgt[:, lo:hi] = a, g
         if look:
             # the value of the NEXT ROW (its centralised critic observation exists now) instead of the last-row shortcut
-            self._apply_bootstrap(vals, adv, tgt, flags, lam, v_next)
+            # (only the LAST fragment runs into row Tt; earlier fragments were cut -- and bootstrapped from their own last
+            # row, the reference's shortcut -- by the scan above, so the correction must not reach back into them)
+            lo_last = ((Tt - 1) // frag) * frag if frag < Tt else 0
+            self._apply_bootstrap(vals[:, lo_last:], adv[:, lo_last:], tgt[:, lo_last:], flags[lo_last:], lam, v_next)
             b["_v_next"] = v_next
             for k in list(b.keys()):          # what the trainer sees: the Tt training rows (views of the persistent buffers)
                 v = b[k]
@@ -889,8 +899,15 @@ class VecTrainer:
                     break
                 if n_frag > 100 * max(1, num_fragments):
                     break
-            elif bool((ep >= int(scene_episodes)).all()):
-                break
+            else:
+                # the loop body holds collectives (episode_metrics all-reduces), so the stop decision has to be the same on
+                # every rank: scenes are seeded per rank and finish their k episodes after different fragment counts --
+                # a rank that is done keeps sampling (its rows are masked out) until the slowest rank is done too
+                pending = (ep < int(scene_episodes)).any().to(torch.float32).view(1)
+                if D.is_dist():
+                    D.all_reduce_max_(pending)
+                if not bool(pending.item() > 0):
+                    break
             batch = self.sampler.sample()
             if scene_episodes is not None:
                 fl = batch[SampleBatch.FLAGS]                                   # [T, E, N]

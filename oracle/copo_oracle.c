@@ -13,9 +13,15 @@
  *        oracle_cc_fuse_concat  <- algo_ccppo.py:225-263
  *        oracle_lcf_mix         <- algo_copo.py:539-551
  *  (2) the simulator step.  MetaDrive 0.2.5 (the reference's simulator, README.md:42) is a pip
- *      dependency whose source is NOT in the reference tree, so this half restates the BUILD-DEFINED
- *      spec of DESIGN.md section 3 ("parity unpinned" against MetaDrive; pinned only on obs dims, info keys and
- *      the wrapper semantics above).  It is the canonical definition the HIP kernel is checked
+ *      dependency whose source is NOT in the reference tree, so this half restates MetaDrive's published
+ *      multi-agent semantics as written down in DESIGN.md section 3 (observation columns, navigation,
+ *      spawn / respawn, reward, termination, episode structure; a kinematic bicycle stands in for
+ *      Bullet's raycast vehicle).  Parity status: pinned BEHAVIOURALLY -- the populations the reference
+ *      trained in MetaDrive (weights held as data under tests/golden/) must drive these scenes at the
+ *      levels the reference's own evaluation CSVs / training table / progress.csv record
+ *      (tests/test_oracle_golden.py, tests/test_gpu_reference_populations.py) -- not function by
+ *      function: no MetaDrive function output exists in the reference tree to compare with.
+ *      It is the canonical definition the HIP kernel is checked
  *      against, bit for bit: all float math is +,-,*,/,sqrt on IEEE fp32/fp64 with contraction off
  *      and hand-written polynomials for sin/cos/atan2/log, so CPU and GPU agree exactly.
  *
