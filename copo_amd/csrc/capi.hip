@@ -150,6 +150,20 @@ extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** o
         for (int k = 0; k < 4; ++k) p.bbox[k] = cfg->map_bbox[k];
     }
     p.lidar_range = cfg->lidar_range; p.neighbours_distance = cfg->neighbours_distance; p.mf_distance = cfg->mf_distance;
+    {   // neighbours_fast (sim_kernels.hip): conservative fp32 thresholds around the exact fp64 decisions
+        const double R2 = (double)cfg->neighbours_distance * (double)cfg->neighbours_distance;
+        const double M2 = (double)cfg->mf_distance * (double)cfg->mf_distance;
+        p.nbr_r2lo = (float)(R2 * (1.0 - 1e-6));
+        p.nbr_r2hi = (float)(R2 * (1.0 + 1e-6));
+        const float mlo = (float)(M2 * (1.0 - 1e-5)), mhi = (float)(M2 * (1.0 + 1e-6));
+        uint32_t blo, bhi;
+        memcpy(&blo, &mlo, 4);
+        memcpy(&bhi, &mhi, 4);
+        p.mf_key_lo = blo & ~63u;                    // key < lo: inside for certain (keys drop 6 mantissa bits of d^2)
+        p.mf_key_hi = (bhi + 63u) & ~63u;            // key >= hi: outside for certain
+        p.nbr_fast = (cfg->nbr_k <= 8 && cfg->neighbours_distance > 0.0f && cfg->mf_distance >= 0.0f &&
+                      cfg->mf_distance < 0.99f * cfg->neighbours_distance) ? 1 : 0;
+    }
     p.dt = cfg->dt; p.hl = cfg->veh_half_len; p.hw = cfg->veh_half_wid; p.wheelbase = cfg->wheelbase;
     p.max_steer = cfg->max_steer; p.max_speed = cfg->max_speed; p.acc_max = cfg->acc_max; p.brake_gain = cfg->brake_gain;
     p.brake_max = cfg->brake_max; p.lat_acc_max = cfg->lat_acc_max;

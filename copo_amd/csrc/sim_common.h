@@ -26,6 +26,11 @@ struct SimParams {
     float acc_max, brake_gain, brake_max, lat_acc_max, region_hl, region_hw;
     float driving_reward, speed_reward, success_reward, crash_penalty, out_penalty, arrive_margin, body_margin, lane_width;
     float side_range, lane_range;
+    // register formulation of the neighbour lists (neighbours_fast): fp32 d^2 thresholds 1e-6 inside / outside the exact radius,
+    // key thresholds of the mean-field range, and whether the configuration qualifies (K <= 8, mean-field range inside the radius)
+    float nbr_r2lo, nbr_r2hi;
+    uint32_t mf_key_lo, mf_key_hi;
+    int32_t nbr_fast;
     float ray_sign;                // +1: beam k is turned k steps counter-clockwise of the heading, -1: clockwise (MetaDrive)
     // constants derived once on the host, in float, exactly as the oracle derives them
     float inv_w, inv_range, inv_vnorm, inv_dt, inv_side_range, inv_lane_range, inv_toll, h_sub;

@@ -170,7 +170,8 @@ __device__ __host__ inline int nbr_lds_words(int ch, int n_agents) { return 3 * 
 __device__ __host__ inline int lidar_queue_words(int ch, int n_agents) { return ch < n_agents ? (ch * n_agents + 1) / 2 : 0; }
 __device__ __host__ inline int lidar_lds_words(int ch, int n_agents, int n_lasers) {
     const int a = ch * n_lasers + lidar_queue_words(ch, n_agents), b = nbr_lds_words(ch, n_agents) + COPO_MAX_SPAWNS / 2;
-    return ((a > b ? a : b) + 3) & ~3;
+    const int c = a > b ? a : b;
+    return ((c > 256 ? c : 256) + 3) & ~3;     // (>= the 64 float4 records of neighbours_fast)
 }
 __device__ __host__ inline int ray_lds_words(int n_lasers) { return (2 * n_lasers + 3) & ~3; }
 constexpr int LIDAR_WAVE_WORDS = 64;   // per wave: head flags of the box-test batches
@@ -416,6 +417,147 @@ __device__ __forceinline__ void neighbours_phase(const SimParams& p, EnvLds& L, 
         }
         if (ia0 + CH < np) __syncthreads();     // the next pass reuses the list storage (and the entry counter)
     }
+}
+
+// median of three unsigned values (compiles to v_med3_u32)
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+    const uint32_t mn = a < b ? a : b, mx = a < b ? b : a;
+    const uint32_t t = mn > c ? mn : c;
+    return t < mx ? t : mx;
+}
+
+// Neighbour lists + reward reductions of one scene by ONE wave, lane = slot: the same results as neighbours_phase, bit for
+// bit, or `false` (nothing written) when that cannot be guaranteed -- the caller then runs neighbours_phase.
+//
+// Every lane walks the present agents j in slot order (the record {x, y, (double) reward} of j is one broadcast LDS read)
+// and keeps, in registers: the count and the fp64 reward sum of the agents within `neighbours_distance`, and the 9 smallest
+// keys `fp32 d^2 bits (low 6 mantissa bits dropped) | j` in ascending order (one v_med3_u32 per position).  Exactness:
+//  * in range / mean-field range: decided on the fp32 d^2 against thresholds 1e-6 (1e-5 for the truncated keys) inside and
+//    outside the exact ones; a distance inside such a band -> false (fp32 d^2 errs by < 2.4e-7 relative).
+//  * order by (d, slot): adjacent keys of the nine must differ by >= 3 units of the truncated d^2 (2.3e-5 relative >> the fp32
+//    error), then the exact fp64 distances are ordered the same way and no tie exists; otherwise -> false.  Exact ties (the
+//    crafted cases of the tests, symmetric scenes) therefore always take neighbours_phase.
+//  * neighbourhood reward: the reference adds the fp64 rewards in list order.  If every reward of the scene is 0 or has
+//    2^-20 <= |r| <= 16, every partial sum of <= 64 of them is a multiple of 2^-43 below 2^10, i.e. exactly representable:
+//    no addition rounds and the order does not matter.  Otherwise -> false.
+//  * global reward: added in slot order, which IS the reference's order.
+// K > 8, the communication block and the stateless op's filled rows take neighbours_phase as well.
+constexpr uint32_t NBR_SENT = 0xffffffffu;
+__device__ __forceinline__ bool neighbours_fast(const SimParams& p, EnvLds& L, int e, int lane, const StepOut& out) {
+    extern __shared__ unsigned int dyn[];
+    const int N = p.N, K = p.K;
+    const unsigned long long present = L.m_present;
+    const bool me = (present >> lane) & 1ull;
+    const int np = __popcll(present);
+    const float xi = L.x[lane], yi = L.y[lane], rw = L.rew[lane];
+    const float arw = fabsf(rw);
+    const bool bad = me && !(rw == 0.0f || (arw >= 9.5367431640625e-07f && arw <= 16.0f));
+    if (__ballot(bad) != 0ull) return false;
+    float4* rec = reinterpret_cast<float4*>(dyn);          // [64] {x, y, (double) reward}: the neighbour work area is free here
+    {
+        const double rd = (double)rw;
+        rec[lane] = make_float4(xi, yi, __int_as_float(__double2loint(rd)), __int_as_float(__double2hiint(rd)));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const float r2lo = p.nbr_r2lo, r2hi = p.nbr_r2hi;
+    uint32_t a0 = NBR_SENT, a1 = NBR_SENT, a2 = NBR_SENT, a3 = NBR_SENT, a4 = NBR_SENT, a5 = NBR_SENT, a6 = NBR_SENT,
+             a7 = NBR_SENT, a8 = NBR_SENT;
+    double sum = 0.0, gs = 0.0;
+    int cnt = 0;
+    bool unc = false;
+    unsigned long long m = present;
+    int j = m ? __ffsll((long long)m) - 1 : 0;              // wave-uniform
+    float4 r = rec[j];
+    while (m) {
+        m &= m - 1ull;
+        const int jn = m ? __ffsll((long long)m) - 1 : j;
+        const float4 rn = rec[jn];                          // the next record is requested before this one is worked on
+        const double rj = __hiloint2double(__float_as_int(r.w), __float_as_int(r.z));
+        gs += rj;
+        const float dx = xi - r.x, dy = yi - r.y;
+        const float d2 = __builtin_fmaf(dy, dy, dx * dx);
+        const bool other = j != lane;
+        const bool in = other && d2 < r2lo, inhi = other && d2 < r2hi;
+        unc |= in != inhi;
+        if (in) {
+            sum += rj;
+            cnt += 1;
+        }
+        const uint32_t key = in ? ((__float_as_uint(d2) & ~63u) | (uint32_t)j) : NBR_SENT;
+        a8 = umed3(a7, a8, key); a7 = umed3(a6, a7, key); a6 = umed3(a5, a6, key); a5 = umed3(a4, a5, key);
+        a4 = umed3(a3, a4, key); a3 = umed3(a2, a3, key); a2 = umed3(a1, a2, key); a1 = umed3(a0, a1, key);
+        a0 = a0 < key ? a0 : key;
+        j = jn;
+        r = rn;
+    }
+    // mean-field count from the keys (the 9 nearest), order check of adjacent keys
+    const uint32_t ak[9] = {a0, a1, a2, a3, a4, a5, a6, a7, a8};
+    const uint32_t tlo = p.mf_key_lo, thi = p.mf_key_hi;
+    int mf = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        mf += ak[k] < tlo ? 1 : 0;
+        unc |= ak[k] >= tlo && ak[k] < thi;
+    }
+    unc |= a8 < thi;                                        // nine or more within the mean-field range: not countable here
+#pragma unroll
+    for (int k = 0; k < 8; ++k) unc |= (ak[k + 1] != NBR_SENT) && (ak[k + 1] - ak[k] < 192u);
+    if (__ballot(me && unc) != 0ull) return false;
+    // ---- write-out ------------------------------------------------------------------------------------------------------
+    const size_t base = (size_t)e * N;
+    if (lane == 0 && out.glob_rew) out.glob_rew[e] = np ? (float)(gs / (double)np) : 0.0f;
+    if (lane < N) {
+        if (out.nbr_cnt) out.nbr_cnt[base + lane] = me ? cnt : 0;
+        if (out.mf_cnt) out.mf_cnt[base + lane] = me ? mf : 0;
+        if (out.nei_rew) out.nei_rew[base + lane] = (me && cnt) ? (float)(sum / (double)cnt) : 0.0f;
+    }
+    if (me) {
+        if (out.nbr_idx) {
+            int32_t* row = out.nbr_idx + (base + lane) * K;
+            if (K == 8) {
+                int4 lo4, hi4;
+                lo4.x = 0 < cnt ? (int)(a0 & 63u) : -1; lo4.y = 1 < cnt ? (int)(a1 & 63u) : -1;
+                lo4.z = 2 < cnt ? (int)(a2 & 63u) : -1; lo4.w = 3 < cnt ? (int)(a3 & 63u) : -1;
+                hi4.x = 4 < cnt ? (int)(a4 & 63u) : -1; hi4.y = 5 < cnt ? (int)(a5 & 63u) : -1;
+                hi4.z = 6 < cnt ? (int)(a6 & 63u) : -1; hi4.w = 7 < cnt ? (int)(a7 & 63u) : -1;
+                reinterpret_cast<int4*>(row)[0] = lo4;
+                reinterpret_cast<int4*>(row)[1] = hi4;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (k < K) row[k] = k < cnt ? (int)(ak[k] & 63u) : -1;
+            }
+        }
+        if (out.nbr_dist) {                                 // the reference's fp64 distance, for the <= K entries that are written
+            float* row = out.nbr_dist + (base + lane) * K;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k < K) {
+                    float dv = 0.0f;
+                    if (k < cnt) {
+                        const int j = (int)(ak[k] & 63u);
+                        const double dx = (double)xi - (double)L.x[j], dy = (double)yi - (double)L.y[j];
+                        dv = (float)sqrt(dx * dx + dy * dy);
+                    }
+                    row[k] = dv;
+                }
+        }
+    }
+    return true;
+}
+
+template <bool EXT>
+__device__ __forceinline__ void neighbours_any(const SimParams& p, EnvLds& L, int e, int tid, int nthreads, const StepOut& out,
+                                               const float* __restrict__ act = nullptr, unsigned long long acted_mask = 0ull,
+                                               bool fresh = true) {
+    // one wave owns the scene: the register formulation above, unless it declines (ties, band cases, odd rewards, K > 8, comm)
+    const bool comm = EXT && p.col_comm >= 0 && out.obs != nullptr;
+    if (nthreads == 64 && p.nbr_fast && !comm && !(COPO_PROFILE_SKIP & 128)) {
+        if (neighbours_fast(p, L, e, tid, out)) return;
+    }
+    neighbours_phase<EXT>(p, L, e, tid, nthreads, out, act, acted_mask, fresh);
 }
 
 // State + navigation blocks of the observation of this lane's slot (MetaDrive 0.2.5 StateObservation.vehicle_state +
@@ -819,7 +961,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_reset_kernel(const Sim
         ego_navi_obs<EXT>(p, L, lane, s, lane < cap, (out.obs && lane < N) ? out.obs + ((size_t)e * N + lane) * p.O : nullptr, 0, true);
     }
     __syncthreads();
-    neighbours_phase<EXT>(p, L, e, tid, nthreads, out);
+    neighbours_any<EXT>(p, L, e, tid, nthreads, out);
     __syncthreads();   // the list-order sums read the LDS words that the LiDAR minima reuse
     if (out.obs) obs_phase(p, L, e, tid, nthreads, out.obs);
 }
@@ -1175,7 +1317,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(const SimP
 
     COPO_STAMP(3);
     // ---- P3 (all waves): neighbour lists + reward reductions on the post-step (pre-reset) scene ---
-    if (!(COPO_PROFILE_SKIP & 1)) neighbours_phase<EXT>(p, L, e, tid, nthreads, out, act, L.m_acted, ending);
+    if (!(COPO_PROFILE_SKIP & 1)) neighbours_any<EXT>(p, L, e, tid, nthreads, out, act, L.m_acted, ending);
     else __syncthreads();
     COPO_STAMP(4);
     // (neighbours_phase ends with a workgroup barrier: the reset below may overwrite the poses it read)
