@@ -43,7 +43,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f3
 CPU_BASELINE_THREADS = 8
 
 
-def make_trainer(num_envs, num_agents, device=None, graphs=True, seed=0):
+def make_trainer(num_envs, num_agents, device=None, graphs=True, seed=0, pretrained=True):
     from copo_amd.torch_copo.algo_copo import CoPOTrainer
     from copo_amd.torch_copo.utils.env_wrappers import MultiAgentIntersectionEnv, get_lcf_env, get_rllib_compatible_env
     env = get_rllib_compatible_env(get_lcf_env(MultiAgentIntersectionEnv))
@@ -52,32 +52,68 @@ def make_trainer(num_envs, num_agents, device=None, graphs=True, seed=0):
                train_batch_size=T * num_envs, seed=seed, use_hip_graphs=graphs)
     if device is not None:
         cfg["device"] = device
-    return CoPOTrainer(config=cfg)
+    tr = CoPOTrainer(config=cfg)
+    if pretrained:
+        load_population(tr.policy)
+    return tr
+
+
+POPULATION = os.path.join(ROOT, "tests", "golden", "eval_policy_function.npz")
+
+
+def population_weights(name="copo_inter"):
+    """The reference's published CoPO Intersection population (copo/best_checkpoints, held as DATA under tests/golden/ by
+    oracle/gen_golden_eval.py): policy-net weights only."""
+    with np.load(POPULATION) as g:
+        pre = name + "/w/"
+        return {k[len(pre):]: g[k] for k in g.files if k.startswith(pre)}
+
+
+def load_population(policy):
+    """Initialise the POLICY net from that population (value nets and the LCF parameters keep their random / default
+    initialisation): an untrained policy crashes or leaves the road within seconds and the scenes empty DURING the run
+    (round 2: 56 k acting rows per iteration in the timed region, 27 k a few iterations later), so `value`, `phases` and the
+    roofline's units would each refer to a different population.  A trained driver keeps ~90 % of the slots occupied."""
+    from copo_amd.eval.checkpoint_io import load_policy_weights
+    load_policy_weights(policy.model, population_weights())
+    if getattr(policy, "fused", None) is not None:
+        policy.fused.sync_mirror()
+    if hasattr(policy, "update_old_policy"):
+        policy.update_old_policy()
 
 
 def measure_sim_kernel(trainer, launches=200):
-    """Mean duration of `copo_sim_step` launches (HIP events on the launch stream) and the mean number of present
-    agent slots per launch, on the live scenes of the trainer."""
-    sim = trainer.env.sim
-    act = torch.zeros(sim.E, sim.N, 2, device=sim.device)
-    gen = torch.Generator(device=sim.device).manual_seed(1)
-    acts = [torch.stack([torch.randn(sim.E, sim.N, device=sim.device, generator=gen) * 0.1,
-                         torch.rand(sim.E, sim.N, device=sim.device, generator=gen)], -1).contiguous() for _ in range(8)]
-    for i in range(20):
-        sim.step(acts[i % 8])
+    """Mean duration of `copo_sim_step` launches (HIP events on the launch stream) and the mean number of present agent
+    slots per launch, ON THE STATE THE TIMED REGION RAN ON: the trainer's sampler rolls its own policy for `launches` env
+    steps from the trainer's live scenes (actions recorded), the scenes are put back, and the recorded actions are replayed
+    -- the simulator is deterministic -- so that the timed loop holds nothing but simulator launches."""
+    sim, smp = trainer.env.sim, trainer.sampler
+    st, env = sim.get_state()
+    acts = []
+    while len(acts) * smp.T < launches:
+        smp.sample()
+        acts.append(smp.clipped.clone())
+    acts = torch.cat(acts, 0)[:launches].contiguous()
+    st_end, env_end = sim.get_state()
+    sim.set_state(st, env)
+    for i in range(min(20, launches)):         # warm (caches, clocks); the state is put back once more below
+        sim.step(acts[i])
+    sim.set_state(st, env)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    present = 0.0
     e0.record()
     for i in range(launches):
-        sim.step(acts[i % 8])
+        sim.step(acts[i])
     e1.record()
     torch.cuda.synchronize()
-    for i in range(16):
-        out = sim.step(acts[i % 8])
+    k_s = e0.elapsed_time(e1) * 1e-3 / launches
+    sim.set_state(st, env)
+    present = 0.0
+    for i in range(launches):                  # the same launches once more, counting the rows they produce
+        out = sim.step(acts[i])
         present += float(((out["flags"] & 0x41) != 0).sum())
-    del act
-    return e0.elapsed_time(e1) * 1e-3 / launches, present / 16.0
+    sim.set_state(st_end, env_end)             # (the sampler's buffers belong to this state)
+    return k_s, present / launches
 
 
 def cruise_actions(obs, gen, speed=0.25):
@@ -332,16 +368,30 @@ def main():
     ap.add_argument("--num-agents", type=int, default=40)
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--untrained", action="store_true",
+                    help="random-init policy net instead of the reference's published population (the scenes then empty during the run)")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="warm-up iterations, then ONLY the live simulator-kernel measurement (recorded replay on the trainer's scenes) "
+                         "and one small JSON line: the command scripts/sim_traffic.sh runs under rocprofv3 --pmc")
     args = ap.parse_args()
 
     from copo_amd import dist as D
     rank, local_rank, world = D.init_from_env()
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     torch.cuda.set_device(local_rank)
-    trainer = make_trainer(args.num_envs, args.num_agents, graphs=not args.no_graphs)
+    trainer = make_trainer(args.num_envs, args.num_agents, graphs=not args.no_graphs, pretrained=not args.untrained)
     warm = max(args.warmup, 4 if not args.no_graphs else 0)   # eager warm-ups + graph capture happen untimed
     for _ in range(warm):
         trainer.train()
+    if args.roofline_only:
+        k_s, present = measure_sim_kernel(trainer)
+        sim = trainer.env.sim
+        print(json.dumps({"kernel": "copo::sim_step_kernel", "scenes": sim.E, "slots": sim.N, "launches": 200,
+                          "us_per_launch": round(k_s * 1e6, 2), "units_per_launch": round(present, 1),
+                          "bytes_per_unit": 202 + 4 * sim.O, "kernel_source_sha1": kernel_source_hash()}), flush=True)
+        trainer.stop()
+        D.shutdown()
+        return
     D.barrier()
     torch.cuda.synchronize()
     a0 = trainer._counters["num_agent_steps_sampled"]
@@ -388,13 +438,13 @@ def main():
         achieved = present * bytes_per_unit / k_s * 1e-9
         # HBM bytes per launch from the PMC counters are taken in a separate rocprofv3 pass (scripts/sim_traffic.sh writes
         # profiles/sim_traffic.json); quoted only if that pass ran on exactly this kernel source
-        traffic = None
+        traffic, traffic_units = None, None
         tfile = os.path.join(ROOT, "profiles", "sim_traffic.json")
         if os.path.exists(tfile):
             tj = json.load(open(tfile))
             if tj.get("kernel_source_sha1") == kernel_source_hash():
                 traffic = tj.get("bytes_per_launch")
-        timers = res["timers"]
+                traffic_units = tj.get("units_per_launch")        # present slots of the launches the counters saw
         learner = measure_learner_step(trainer)
         sat_s, sat_present, sat_slots = measure_sim_kernel_saturated(trainer, policy="cruise")
         rnd_s, rnd_present, _ = measure_sim_kernel_saturated(trainer, policy="random")
@@ -402,19 +452,29 @@ def main():
             "metric": "agent-env-steps/sec (sim+learn), Intersection 40-agent", "value": round(value, 1),
             "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" if args.untrained else "synthetic (seeded HIP scenes; policy net initialised from the reference's published "
+                    "CoPO Intersection population so that the scenes stay populated; value nets / LCF random-init)",
             "config": {"workload": "CoPO Intersection, %d agent slots x %d scenes per GPU, fp32 (BASELINE configs[1])"
                                    % (sim.N, sim.E), "rollout_steps": trainer.sampler.T,
                        "sgd_minibatch_size_per_rank": 512, "num_sgd_iter": 5, "lcf_num_iters": 5,
                        "parallelism": "dp%d" % world, "hip_graphs": not args.no_graphs,
                        "agent_steps_per_iter": round(agent_steps / args.steps / world, 1),
-                       "sample_ms": round(timers.get("sample_time_ms", 0), 2),
-                       "learn_ms": round(timers.get("learn_time_ms", 0), 2),
-                       "meta_ms": round(timers.get("meta_time_ms", 0), 2)},
+                       "policy_init": "random" if args.untrained else "reference population copo_inter (tests/golden, weights as data)",
+                       # tuning knobs the product path reads from the environment (they skip no work): recorded, not hidden
+                       "knobs": {"COPO_SGD_CHAIN": int(getattr(trainer.policy, "SGD_CHAIN", 0)),
+                                 "COPO_DIST_CHAIN": int(getattr(trainer.policy, "_dist_chain_len", 0) or 0),
+                                 "COPO_FORCE_DIST": os.environ.get("COPO_FORCE_DIST", "0"),
+                                 "COPO_PEER_ALLREDUCE": os.environ.get("COPO_PEER_ALLREDUCE", "0")}},
             "roofline": {"bound": "hbm", "kernel": "copo::sim_step_kernel", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                         "traffic": traffic, "us_per_launch": round(k_s * 1e6, 2),
+                         "traffic": traffic, "traffic_units_per_launch": traffic_units,
+                         "us_per_launch": round(k_s * 1e6, 2),
                          "units_per_launch": round(present, 1), "bytes_per_unit": bytes_per_unit,
+                         "state": "the trainer's own scenes and policy: actions of 200 env steps recorded closed-loop, scenes put "
+                                  "back, actions replayed (timed loop = simulator launches only); `traffic` = PMC FETCH_SIZE + "
+                                  "WRITE_SIZE per launch from rocprofv3 passes over `bench.py --roofline-only` (the same replay), "
+                                  "with the present slots those launches had",
                          "saturated": {"scenes": sat_slots // sim.N, "actions": "lane-keeping controller (recorded, replayed)",
                                        "us_per_launch": round(sat_s * 1e6, 1),
                                        "present_slots": round(sat_present), "slots_stepped": sat_slots,

@@ -102,6 +102,7 @@ _SIGS = {
     "copo_sim_set_force_lcf": (C.c_int, [C.c_void_p, C.c_double]),
     "copo_sim_set_capacity": (C.c_int, [C.c_void_p, C.c_int32]),
     "copo_sim_set_block": (C.c_int, [C.c_void_p, C.c_int32]),
+    "copo_sim_set_chunk": (C.c_int, [C.c_void_p, C.c_int32]),
     "copo_sim_flush": (C.c_int, [C.c_void_p, C.c_void_p]),
     "copo_sim_set_debug": (C.c_int, [C.c_void_p, C.c_void_p]),
     "copo_sim_step": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(StepOut), C.c_void_p]),

@@ -53,9 +53,11 @@ static int upload(copo_sim* s, const T* host, size_t count, const T** dev) {
     return COPO_OK;
 }
 
-// measured (scripts/bench_sim.py, 40 slots): up to one scene per CU -> 16 waves per scene; two per CU -> 8; then 4; from
-// ~32 scenes per CU on, ONE wave per scene with the small LDS footprint (sim_shape_params): ~20 scenes resident per CU
-static int pick_block(int E) { return E <= 256 ? 1024 : (E <= 512 ? 512 : (E <= 8192 ? 256 : 64)); }
+// measured (scripts/bench_sim.py, 40 slots, populated scenes): up to one scene per CU -> 16 waves per scene; two per CU -> 8;
+// then 4; from ~12 scenes per CU on, ONE wave per scene with the small LDS footprint (sim_shape_params, ~20 scenes resident
+// per CU) and the register formulation of the neighbour lists (round 3: 4096 scenes 124 -> 110 us, 8192 222 -> 173 us; at
+// 2048 four waves per scene still win, 72 vs 96 us)
+static int pick_block(int E) { return E <= 256 ? 1024 : (E <= 512 ? 512 : (E <= 3072 ? 256 : 64)); }
 
 extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** out) {
     if (!cfg || !out) return fail(COPO_ERR_NULL, "copo_sim_create: cfg/out is NULL");
@@ -214,6 +216,20 @@ extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** o
     if (rc == COPO_OK) rc = upload(s, cfg->spawn_s, (size_t)cfg->n_spawns, &p.spawn_s);
     if (rc == COPO_OK) rc = upload(s, cfg->ray_cs, (size_t)cfg->num_lasers * 2, &p.ray_cs);
     if (rc == COPO_OK) rc = upload(s, safe.data(), safe.size(), &p.safe_ids);
+    if (rc == COPO_OK) {      // pose of every respawn place (sim_kernels.hip spawn_pose, the same float operations in the same order)
+        std::vector<float> sp4(4 * std::max<size_t>(safe.size(), 1), 0.0f);
+        for (size_t q = 0; q < safe.size(); ++q) {
+            const int sp = safe[q];
+            const float* g = cfg->route_segs + (size_t)cfg->spawn_tab[sp * 4 + 0] * (COPO_MAX_SEGS + 1) * COPO_SEG_STRIDE;
+            const float s0 = cfg->spawn_s[sp];
+            const float off = (float)cfg->spawn_tab[sp * 4 + 2] * cfg->lane_width;
+            sp4[4 * q + 0] = g[0] + g[2] * s0 + g[3] * off;
+            sp4[4 * q + 1] = g[1] + g[3] * s0 - g[2] * off;
+            sp4[4 * q + 2] = g[2];
+            sp4[4 * q + 3] = g[3];
+        }
+        rc = upload(s, sp4.data(), sp4.size(), &p.safe_pose);
+    }
     if (rc == COPO_OK && p.n_lines) rc = upload(s, cfg->lines, (size_t)cfg->n_lines * COPO_LINE_STRIDE, &p.lines);
     if (rc == COPO_OK && cfg->side_lasers) rc = upload(s, cfg->side_cs, (size_t)cfg->side_lasers * 2, &p.side_cs);
     if (rc == COPO_OK && cfg->lane_line_lasers) rc = upload(s, cfg->lane_line_cs, (size_t)cfg->lane_line_lasers * 2, &p.lane_cs);
@@ -303,6 +319,19 @@ extern "C" int copo_sim_set_block(copo_sim* s, int32_t threads) {
     if (threads != s->block) {
         s->block = threads;
         sim_shape_params(s->p, threads);
+        HIP_TRY(hipSetDevice(s->device));
+        HIP_TRY(hipDeviceSynchronize());         // launches in flight keep the shape they started with
+        HIP_TRY(hipMemcpy(s->p_dev, &s->p, sizeof(SimParams), hipMemcpyHostToDevice));
+    }
+    return COPO_OK;
+}
+
+extern "C" int copo_sim_set_chunk(copo_sim* s, int32_t fans) {
+    if (!s) return fail(COPO_ERR_NULL, "copo_sim_set_chunk: NULL handle");
+    if (fans < 0 || fans > COPO_MAX_AGENTS) return fail(COPO_ERR_DIM, "fans=%d must be 0..%d", fans, COPO_MAX_AGENTS);
+    if (fans != s->p.chunk_one_wave) {
+        s->p.chunk_one_wave = fans;
+        sim_shape_params(s->p, s->block);
         HIP_TRY(hipSetDevice(s->device));
         HIP_TRY(hipDeviceSynchronize());         // launches in flight keep the shape they started with
         HIP_TRY(hipMemcpy(s->p_dev, &s->p, sizeof(SimParams), hipMemcpyHostToDevice));

@@ -17,7 +17,9 @@ enum : uint32_t { RNG_ROUTE = 1, RNG_LCF1 = 2, RNG_LCF2 = 3, RNG_SPAWN = 4, RNG_
 struct SimParams {
     int32_t E, N, O, K, num_lasers, enable_lcf, horizon, delay_done, respawn_cooldown, substeps;
     int32_t n_routes, n_spawns, n_safe, n_lines;
-    int32_t chunk;                 // present agents whose neighbour lists / LiDAR fans are in LDS at a time (launch shape: sim_shape_params)
+    int32_t chunk;                 // present agents whose LiDAR fans are in LDS at a time (launch shape: sim_shape_params)
+    int32_t nbr_chunk;             // present agents whose pair-parallel neighbour lists are in LDS at a time (same)
+    int32_t chunk_one_wave;        // `chunk` of the one-wave-per-scene shape (copo_sim_set_chunk; 0 = default)
     int32_t stage_tables;          // 1: the step kernel copies the route / spawn tables to LDS (launch shape)
     int32_t seg_rows;              // road records per route in the DEVICE copy of route_segs: longest route + 1 (compacted at create)
     int32_t side_lasers, lane_lasers, navi_dim, toll_dim, toll_min_steps;
@@ -47,6 +49,7 @@ struct SimParams {
     const int32_t* spawn_tab;      // [P][4]
     const float* spawn_s;          // [P]
     const int32_t* safe_ids;       // [n_safe] spawn slots that are respawn places
+    const float* safe_pose;        // [n_safe][4] pose of respawn place q: x, y, cos, sin of its lane (derived on the host at create)
     const float* ray_cs;           // [num_lasers][2]
     const float* side_cs;          // [side_lasers][2]
     const float* lane_cs;          // [lane_lasers][2]

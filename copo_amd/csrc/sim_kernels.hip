@@ -15,10 +15,14 @@
 
 // Profiling builds only (`make prof SKIP=<mask>`, a separate .so that the package never loads): phases compiled out to
 // split the instruction count -- 1 neighbour lists, 2 LiDAR windows + box tests, 4 LiDAR write-out, 8 state / navigation
-// block, 16 collision pairs, 32 respawn, 64 projection / termination.  The shipped library is built without it.
+// block, 16 collision pairs, 32 respawn, 64 projection / termination, 128 register formulation of the neighbour lists off;
+// 256: nothing compiled out, the LiDAR phase COUNTS its work into the debug rows instead ([E][16] then: 8 queued pairs,
+// 9 pair batches, 10 box tests, 11 test batches, 12 hits).  The shipped library is built without it.
 #ifndef COPO_PROFILE_SKIP
 #define COPO_PROFILE_SKIP 0
 #endif
+#define COPO_DBG_STRIDE ((COPO_PROFILE_SKIP & 256) ? 16 : 8)
+#define COPO_COUNT(slot, v) do { if ((COPO_PROFILE_SKIP & 256) && p.dbg && lane == 0) p.dbg[(size_t)e * 16 + (slot)] += (long long)(v); } while (0)
 
 namespace copo {
 
@@ -138,12 +142,11 @@ __device__ __forceinline__ void spawn_slot(const SimParams& p, const float* rseg
 struct __align__(16) EnvLds {
     float x[64], y[64], cs[64], sn[64], rew[64];
     uint8_t plist[64], slist[64];   // slots of the present agents / solid vehicles, ascending (LiDAR pair list)
-    uint32_t ncnt[64], mfc[64];     // neighbour-list lengths / mean-field counts (neighbour phase, LDS atomics)
-    uint32_t n_entries;             // total list entries of the scene
+    uint32_t n_entries;             // total list entries of the scene (pair-parallel neighbour lists; their per-list counters
+                                    // live behind the list storage in dynamic LDS)
     uint8_t alist[64], clist[64];   // acting agents / solid vehicles before the step's terminations (collision pairs)
     unsigned long long m_acted, m_present, m_solid;
     uint8_t crash[64];
-    float spx[COPO_MAX_SAFE], spy[COPO_MAX_SAFE], spc[COPO_MAX_SAFE], spsn[COPO_MAX_SAFE];   // respawn places: pose
     const float* rsegs;        // route segment records: the LDS copy of the step kernel (small maps) or global memory
     const float* rmeta;        // route meta records, same
     const int32_t* stab;       // spawn table, same
@@ -164,12 +167,15 @@ constexpr int ROUTE_LDS_MAX_BYTES = 16 * 1024;
 // scene, 8 when one wave owns it -- the per-scene footprint decides how many scenes a compute unit holds):
 // neighbour phase: list distances (fp64) [ch][N] -- later reused for the rewards in list order --, list slots (u8) [ch][N],
 // ranks (u8) [ch][N], entry directory (u16) [ch*N]; then the spawn permutation of a reset (int16 [COPO_MAX_SPAWNS])
-__device__ __host__ inline int nbr_lds_words(int ch, int n_agents) { return 3 * ch * n_agents + 4; }
+// then the list lengths / mean-field counts [64] + [64] (LDS atomics)
+__device__ __host__ inline int nbr_lds_words(int ch, int n_agents) { return 3 * ch * n_agents + 4 + 128; }
 // LiDAR phase: ray minima [ch][n_lasers]; when one wave owns the scene (ch < n_agents) also the queue of (fan, vehicle) pairs
 // in range, uint16 [ch * n_agents], behind them (mostly inside what the neighbour phase needs anyway)
 __device__ __host__ inline int lidar_queue_words(int ch, int n_agents) { return ch < n_agents ? (ch * n_agents + 1) / 2 : 0; }
-__device__ __host__ inline int lidar_lds_words(int ch, int n_agents, int n_lasers) {
-    const int a = ch * n_lasers + lidar_queue_words(ch, n_agents), b = nbr_lds_words(ch, n_agents) + COPO_MAX_SPAWNS / 2;
+// (`nch`: the chunk of the pair-parallel neighbour lists -- smaller than the LiDAR chunk when one wave owns the scene: that path
+// only runs for the scenes the register formulation declines)
+__device__ __host__ inline int lidar_lds_words(int ch, int nch, int n_agents, int n_lasers) {
+    const int a = ch * n_lasers + lidar_queue_words(ch, n_agents), b = nbr_lds_words(nch, n_agents) + COPO_MAX_SPAWNS / 2;
     const int c = a > b ? a : b;
     return ((c > 256 ? c : 256) + 3) & ~3;     // (>= the 64 float4 records of neighbours_fast)
 }
@@ -177,11 +183,11 @@ __device__ __host__ inline int ray_lds_words(int n_lasers) { return (2 * n_laser
 constexpr int LIDAR_WAVE_WORDS = 64;   // per wave: head flags of the box-test batches
 __device__ __forceinline__ float* lds_rays(const SimParams& p) {
     extern __shared__ unsigned int dyn[];
-    return reinterpret_cast<float*>(dyn + lidar_lds_words(p.chunk, p.N, p.num_lasers));
+    return reinterpret_cast<float*>(dyn + lidar_lds_words(p.chunk, p.nbr_chunk, p.N, p.num_lasers));
 }
 __device__ __forceinline__ int16_t* lds_perm(const SimParams& p) {
     extern __shared__ unsigned int dyn[];
-    return reinterpret_cast<int16_t*>(dyn + nbr_lds_words(p.chunk, p.N));
+    return reinterpret_cast<int16_t*>(dyn + nbr_lds_words(p.nbr_chunk, p.N));
 }
 __device__ __host__ inline int route_table_floats(int n_routes, int seg_rows) {
     return n_routes * (seg_rows * COPO_SEG_STRIDE + 4);
@@ -223,11 +229,7 @@ __device__ __forceinline__ void build_lists(EnvLds& L, int lane, unsigned long l
     const unsigned long long lt = (1ull << lane) - 1ull;
     if ((present >> lane) & 1ull) L.plist[__popcll(present & lt)] = (uint8_t)lane;
     if ((solid >> lane) & 1ull) L.slist[__popcll(solid & lt)] = (uint8_t)lane;
-    if (for_neighbours) {        // (not after a horizon reset: the tail of the neighbour phase may still be reading them)
-        L.ncnt[lane] = 0;
-        L.mfc[lane] = 0;
-        if (lane == 0) L.n_entries = 0;
-    }
+    (void)for_neighbours;        // (the pair-parallel neighbour phase clears its own counters)
 }
 
 // neighbour lists + reward reductions (CCEnv / LCFEnv).  Precondition: build_lists ran and is visible.
@@ -257,12 +259,20 @@ __device__ __forceinline__ void neighbours_phase(const SimParams& p, EnvLds& L, 
     const int np = __popcll(present);
     const size_t base = (size_t)e * N;
     const double R = (double)p.neighbours_distance, M = (double)p.mf_distance;
-    const int CH = p.chunk > 0 ? p.chunk : N;                            // present agents whose lists are in LDS at a time
+    const int CH = p.nbr_chunk > 0 ? p.nbr_chunk : N;                    // present agents whose lists are in LDS at a time
     double* nb_d = reinterpret_cast<double*>(dyn);                       // [CH][N]
     float* srt = reinterpret_cast<float*>(dyn);                          // [CH][N], after the ranks are known
     uint8_t* nb_j = reinterpret_cast<uint8_t*>(dyn + 2 * CH * N);         // [CH][N]
     uint8_t* nb_rk = nb_j + CH * N;                                       // [CH][N]
     uint16_t* ent = reinterpret_cast<uint16_t*>(dyn + 2 * CH * N + (CH * N) / 2 + 2);   // [CH*N]: local list << 8 | pos
+    uint32_t* ncnt = dyn + 3 * CH * N + 4;                                // [64] list lengths (low half) | outside candidates (high half)
+    uint32_t* mfcn = ncnt + 64;                                           // [64] mean-field counts
+    if (tid < 64) {
+        ncnt[tid] = 0;
+        mfcn[tid] = 0;
+    }
+    if (tid == 0) L.n_entries = 0;
+    __syncthreads();
     const int tail_wave = nwaves > 1 ? 1 : 0;       // per-slot tails run on a wave that the caller's next (wave 0) phase does not need
     // slots without an agent: empty lists (counts and reward only; their nbr_idx / nbr_dist rows are not written)
     if (wave == tail_wave && lane < N && !((present >> lane) & 1ull)) {
@@ -311,7 +321,7 @@ __device__ __forceinline__ void neighbours_phase(const SimParams& p, EnvLds& L, 
                     if (lane == 0) e0 = atomicAdd(&L.n_entries, (unsigned int)__popcll(m));
                     e0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)e0);
                     if (cand) {
-                        const unsigned int pos = atomicAdd(&L.ncnt[i], 1u) & 0xffffu;
+                        const unsigned int pos = atomicAdd(&ncnt[i], 1u) & 0xffffu;
                         nb_j[la * N + pos] = (uint8_t)j;
                         ent[e0 + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((la << 8) | pos);
                     }
@@ -327,10 +337,10 @@ __device__ __forceinline__ void neighbours_phase(const SimParams& p, EnvLds& L, 
             const double dx = (double)L.x[i] - (double)L.x[j], dy = (double)L.y[i] - (double)L.y[j];
             double d = sqrt(dx * dx + dy * dy);
             if (d < R) {
-                if (d <= M) atomicAdd(&L.mfc[i], 1u);
+                if (d <= M) atomicAdd(&mfcn[i], 1u);
             } else {
                 d = __longlong_as_double(0x7ff0000000000000ll);
-                atomicAdd(&L.ncnt[i], 0x10000u);
+                atomicAdd(&ncnt[i], 0x10000u);
             }
             nb_d[la * N + pos] = d;
         }
@@ -340,7 +350,7 @@ __device__ __forceinline__ void neighbours_phase(const SimParams& p, EnvLds& L, 
             const unsigned int pk = ent[q];
             const int la = (int)(pk >> 8), pos = (int)(pk & 255u);
             const int i = L.plist[ia0 + la];
-            const int cnt = (int)(L.ncnt[i] & 0xffffu);       // candidates (the +inf ones rank last)
+            const int cnt = (int)(ncnt[i] & 0xffffu);       // candidates (the +inf ones rank last)
             const double d = nb_d[la * N + pos];
             const int j = nb_j[la * N + pos];
             // rank = entries of the list that sort before this one by (d, slot).  Distances are >= 0, so the upper word of
@@ -395,9 +405,9 @@ __device__ __forceinline__ void neighbours_phase(const SimParams& p, EnvLds& L, 
         if (wave == tail_wave) {       // one lane per list of this pass
             if (lane < cha) {
                 const int i = L.plist[ia0 + lane];
-                const int cnt = (int)(L.ncnt[i] & 0xffffu) - (int)(L.ncnt[i] >> 16);       // candidates - those outside
+                const int cnt = (int)(ncnt[i] & 0xffffu) - (int)(ncnt[i] >> 16);       // candidates - those outside
                 if (out.nbr_cnt) out.nbr_cnt[base + i] = cnt;
-                if (out.mf_cnt) out.mf_cnt[base + i] = (int)L.mfc[i];
+                if (out.mf_cnt) out.mf_cnt[base + i] = (int)mfcn[i];
                 if (out.nei_rew) {
                     double nsum = 0.0;
                     for (int r = 0; r < cnt; ++r) nsum += (double)srt[lane * N + r];
@@ -555,7 +565,9 @@ __device__ __forceinline__ void neighbours_any(const SimParams& p, EnvLds& L, in
     // one wave owns the scene: the register formulation above, unless it declines (ties, band cases, odd rewards, K > 8, comm)
     const bool comm = EXT && p.col_comm >= 0 && out.obs != nullptr;
     if (nthreads == 64 && p.nbr_fast && !comm && !(COPO_PROFILE_SKIP & 128)) {
-        if (neighbours_fast(p, L, e, tid, out)) return;
+        const bool ok = neighbours_fast(p, L, e, tid, out);
+        if (p.dbg && tid == 0) p.dbg[(size_t)e * COPO_DBG_STRIDE + 7] = ok ? 1 : 2;      // profiling aid: which formulation ran
+        if (ok) return;
     }
     neighbours_phase<EXT>(p, L, e, tid, nthreads, out, act, acted_mask, fresh);
 }
@@ -757,13 +769,17 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
     const unsigned int range_bits = __float_as_uint(range);
     float* eobs = obs + (size_t)e * N * O;
     const float* __restrict__ rays = lds_rays(p);
-    int* wtag = reinterpret_cast<int*>(dyn + lidar_lds_words(p.chunk, p.N, p.num_lasers) + ray_lds_words(p.num_lasers)) + wave * LIDAR_WAVE_WORDS;   // head flags
+    int* wtag = reinterpret_cast<int*>(dyn + lidar_lds_words(p.chunk, p.nbr_chunk, p.N, p.num_lasers) + ray_lds_words(p.num_lasers)) + wave * LIDAR_WAVE_WORDS;   // head flags
     const int CH = p.chunk > 0 ? p.chunk : N;     // present agents whose ray fans are in LDS at a time
     const float inv_ns = 1.0f / (float)(ns > 0 ? ns : 1);
     const float rays_per_rad = (float)NL * 0.159154943f;
     const float inv_nl = 1.0f / (float)NL;
     const float inv_range = p.inv_range;
     const int col_lidar = p.col_lidar;
+    const int head = (4 - (col_lidar & 3)) & 3;   // rays in front of the first 16-byte aligned column of a row
+    const int nvec = (NL - head) >> 2;
+    const bool vec_out = ((O & 3) == 0) && nvec > 0 && ((reinterpret_cast<uintptr_t>(obs) & 15) == 0);
+    const float inv_nvec = 1.0f / (float)(nvec > 0 ? nvec : 1), inv_nsc = 1.0f / (float)(NL - 4 * nvec > 0 ? NL - 4 * nvec : 1);
     for (int ip0 = 0; ip0 < np; ip0 += CH) {
     const int cha = np - ip0 < CH ? np - ip0 : CH;
     for (int q = tid; q < cha * NL; q += nthreads) best[q] = range_bits;
@@ -799,6 +815,7 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
         }
         const int incl = wave_scan_incl<false>(cnt);      // inclusive scan of the window sizes
         const int total = __builtin_amdgcn_readlane(incl, 63);
+        COPO_COUNT(9, 1); COPO_COUNT(10, total); COPO_COUNT(11, (total + 63) >> 6);
         const int excl = incl - cnt;                      // index of this pair's first box test
         // the pair's record for its box tests (registers of this lane, fetched by the test lanes with ds_bpermute -- no LDS
         // storage: a strip of records per wave cost more in resident scenes than it saved in instructions): ray origin in
@@ -832,6 +849,7 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
                 const float2 r = reinterpret_cast<const float2*>(rays)[k];
                 const float tt = ray_box(ox, oy, r.x * cr + r.y * sr, r.y * cr - r.x * sr, hl, hw);
                 if (tt >= 0.0f) atomicMin(&best[slp * NL + k], __float_as_uint(tt));
+                if (COPO_PROFILE_SKIP & 256) { const int nh = __popcll(__ballot(tt >= 0.0f)); COPO_COUNT(12, nh); }
             }
         }
     };
@@ -855,6 +873,7 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        COPO_COUNT(8, nq);
         for (int q0 = 0; q0 < nq; q0 += 64) {
             const bool live = q0 + lane < nq;
             const int c = live ? (int)cq[q0 + lane] : 0;
@@ -871,6 +890,23 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
     }
     __syncthreads();
     const int nrays = cha * NL;                   // rows of present slots only
+    if (vec_out && !(COPO_PROFILE_SKIP & 4)) {
+        // 16-byte stores: [head scalars | nvec aligned quads | tail scalars] of every fan (rows are 16-byte aligned: O % 4 == 0)
+        for (int q = tid; q < cha * nvec; q += nthreads) {
+            const int lp = (int)(((float)q + 0.5f) * inv_nvec), k = head + 4 * (q - lp * nvec);
+            const unsigned int* b = best + lp * NL + k;
+            float4 v;
+            v.x = __uint_as_float(b[0]) * inv_range; v.y = __uint_as_float(b[1]) * inv_range;
+            v.z = __uint_as_float(b[2]) * inv_range; v.w = __uint_as_float(b[3]) * inv_range;
+            *reinterpret_cast<float4*>(eobs + (int)L.plist[ip0 + lp] * O + col_lidar + k) = v;
+        }
+        const int nsc = NL - 4 * nvec;            // head + tail scalars per fan
+        for (int q = tid; q < cha * nsc; q += nthreads) {
+            const int lp = (int)(((float)q + 0.5f) * inv_nsc), r = q - lp * nsc;
+            const int k = r < head ? r : r + 4 * nvec;
+            eobs[(int)L.plist[ip0 + lp] * O + col_lidar + k] = __uint_as_float(best[lp * NL + k]) * inv_range;
+        }
+    } else
     for (int q = tid; q < ((COPO_PROFILE_SKIP & 4) ? 0 : nrays); q += nthreads) {
         const int lp = (int)(((float)q + 0.5f) * inv_nl), k = q - lp * NL;
         eobs[(int)L.plist[ip0 + lp] * O + col_lidar + k] = __uint_as_float(best[q]) * inv_range;
@@ -985,7 +1021,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(const SimP
         const int nseg_f = p.n_routes * p.seg_rows * COPO_SEG_STRIDE, nmeta_f = p.n_routes * 4;
         const int ntab = p.n_spawns * 4, nsp = p.n_spawns;
         const bool stage = p.stage_tables != 0;     // (host: several waves per scene and the tables are small)
-        float* rl = reinterpret_cast<float*>(dyn + lidar_lds_words(p.chunk, p.N, p.num_lasers) + ray_lds_words(p.num_lasers) + (nthreads >> 6) * LIDAR_WAVE_WORDS);
+        float* rl = reinterpret_cast<float*>(dyn + lidar_lds_words(p.chunk, p.nbr_chunk, p.N, p.num_lasers) + ray_lds_words(p.num_lasers) + (nthreads >> 6) * LIDAR_WAVE_WORDS);
         int32_t* tl = reinterpret_cast<int32_t*>(rl + nseg_f + nmeta_f);
         float* sl = reinterpret_cast<float*>(tl + ntab);
         if (stage) {
@@ -1003,7 +1039,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(const SimP
         }
     }
 
-#define COPO_STAMP(i) do { if (p.dbg && tid == 0) p.dbg[(size_t)e * 8 + (i)] = (long long)clock64(); } while (0)
+#define COPO_STAMP(i) do { if (p.dbg && tid == 0) p.dbg[(size_t)e * COPO_DBG_STRIDE + (i)] = (long long)clock64(); } while (0)
     COPO_STAMP(0);
     // ---- P0 (wave 0): timers + kinematic bicycle, poses -> LDS ----------------------------------------
     Slot s = Slot{};
@@ -1109,7 +1145,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(const SimP
         const float inv_nc = 1.0f / (float)(nc > 0 ? nc : 1);
         const float near2 = 4.0f * (hl * hl + hw * hw) * 1.001f;   // farther apart than two circumradii: no overlap
         extern __shared__ unsigned int dyn[];
-        const int qcap = 2 * nbr_lds_words(p.chunk > 0 ? p.chunk : N, N);          // the neighbour work area is free here
+        const int qcap = 2 * lidar_lds_words(p.chunk, p.nbr_chunk, N, p.num_lasers);      // the LiDAR / neighbour work area is free here
         if (nwaves == 1 && npair <= qcap && !(COPO_PROFILE_SKIP & 16)) {
             // one wave owns the scene: the pairs closer than two circumradii (a few per vehicle in a queue of cars) are
             // queued by a cheap pass and box-tested in full batches; the separating-axis test otherwise runs for a whole
@@ -1145,14 +1181,6 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(const SimP
             const float ddx = xj - xi, ddy = yj - yi;
             const bool near = live && (i != j) && (ddx * ddx + ddy * ddy <= near2);
             if (near && obb_overlap2(xi, yi, L.cs[i], L.sn[i], hl, hw, xj, yj, L.cs[j], L.sn[j], hl, hw)) L.crash[i] = 1;
-        }
-        // the respawn places of the map: pose of place q (wave 1 if there is one; published by the barrier below)
-        if (wave == (nwaves > 1 ? 1 : 0) && lane < p.n_safe) {
-            const int sp = p.safe_ids[lane];
-            float sx, sy;
-            spawn_pose(p, L.rsegs, L.stab, L.sps, sp, sx, sy);
-            const float* g = seg_ptr(L, L.stab[sp * 4], 0);
-            L.spx[lane] = sx; L.spy[lane] = sy; L.spc[lane] = g[2]; L.spsn[lane] = g[3];
         }
     }
     __syncthreads();
@@ -1263,7 +1291,8 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(const SimP
                 const float cj = L.cs[lane], sj = L.sn[lane];      // poses of terminated vehicles did not change since P0
                 uint32_t clear = 0;
                 for (int q = 0; q < p.n_safe; ++q) {
-                    const bool blk = solid_now && obb_overlap2(L.spx[q], L.spy[q], L.spc[q], L.spsn[q], p.region_hl, p.region_hw,
+                    const float4 sp4 = reinterpret_cast<const float4*>(p.safe_pose)[q];      // pose of respawn place q (host table)
+                    const bool blk = solid_now && obb_overlap2(sp4.x, sp4.y, sp4.z, sp4.w, p.region_hl, p.region_hw,
                                                                s.x, s.y, cj, sj, hl, hw);
                     if (__ballot(blk) == 0ull) clear |= 1u << q;
                 }
@@ -1403,7 +1432,7 @@ __global__ void __launch_bounds__(256) neighbours_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 // [slots][rays] minima, ray table, one 64-entry strip per wave (box-test owners)
 static size_t lidar_lds_bytes(const SimParams& p, int block) {
-    return (size_t)(lidar_lds_words(p.chunk, p.N, p.num_lasers) + ray_lds_words(p.num_lasers) + (block / 64) * LIDAR_WAVE_WORDS) * sizeof(unsigned int);
+    return (size_t)(lidar_lds_words(p.chunk, p.nbr_chunk, p.N, p.num_lasers) + ray_lds_words(p.num_lasers) + (block / 64) * LIDAR_WAVE_WORDS) * sizeof(unsigned int);
 }
 static bool sim_has_ext(const SimParams& p) { return p.col_tl >= 0 || p.col_comm >= 0; }
 static hipError_t sim_lds_attrs() {              // 64 slots x 256 rays + route tables exceed the default 64 KB
@@ -1425,7 +1454,11 @@ static size_t route_lds_bytes(const SimParams& p) {      // LDS copy of the rout
 // at once, route tables in LDS when small.  One wave per scene (large scene counts): work areas for 8 agents at a time and
 // tables from L2, so that a scene needs ~8 KB of LDS and a compute unit holds ~20 of them.
 void sim_shape_params(SimParams& p, int block) {
-    p.chunk = block > 64 ? p.N : (p.N < 8 ? p.N : 8);
+    // one wave per scene: 10 fans at a time (scripts/bench_sim.py --chunks, 16 384 populated scenes: 6 263 / 8 257 / 10 251 / 12 262 /
+    // 14 259 / 16 275 us -- fuller pair and box-test batches against resident scenes per compute unit, 26 at 6.2 KB of LDS)
+    const int lch = p.chunk_one_wave > 0 ? p.chunk_one_wave : 10;
+    p.chunk = block > 64 ? p.N : (p.N < lch ? p.N : lch);
+    p.nbr_chunk = block > 64 ? p.N : (p.N < 4 ? p.N : 4);
     p.stage_tables = (block > 64 && (size_t)route_table_floats(p.n_routes, p.seg_rows) * sizeof(float) <= (size_t)ROUTE_LDS_MAX_BYTES) ? 1 : 0;
 }
 

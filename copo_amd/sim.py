@@ -250,6 +250,12 @@ class VecSim:
         for cb in list(getattr(self, "on_shape_change", ())):
             cb()
 
+    def set_chunk(self, fans):
+        """LiDAR fans held in LDS at a time in the one-wave-per-scene shape (tuning knob; 0 = default)."""
+        self._capi.check(self._capi.lib.copo_sim_set_chunk(self._h, int(fans)))
+        for cb in list(getattr(self, "on_shape_change", ())):
+            cb()
+
     def get_state(self):
         torch = self._torch
         st = torch.empty(self._capi.STATE_FIELDS, self.E, self.N, dtype=torch.float32, device=self.device)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define COPO_ABI_VERSION 3
+#define COPO_ABI_VERSION 4
 
 #define COPO_OK 0
 #define COPO_ERR_NULL (-1)      /* required pointer is NULL */
@@ -220,8 +220,11 @@ int copo_sim_get_state(copo_sim* sim, float* slot_state, int32_t* env_state, voi
 int copo_sim_set_state(copo_sim* sim, const float* slot_state, const int32_t* env_state, void* stream);
 /* workgroup size of the step kernel: 256, 512 or 1024 (0 = pick from E); tuning knob, results do not depend on it */
 int copo_sim_set_block(copo_sim* sim, int32_t threads);
+/* LiDAR fans whose ray minima are held in LDS at a time when ONE wave owns a scene (workgroup size 64): 1..64, 0 = default;
+ * trades resident scenes per compute unit against fuller work batches; tuning knob, results do not depend on it */
+int copo_sim_set_chunk(copo_sim* sim, int32_t fans);
 /* profiling aid: device buffer [E][8] int64 receiving clock64() stamps at the phase boundaries of the step kernel
- * (NULL switches it off; results of the step do not depend on it) */
+ * (NULL switches it off; results of the step do not depend on it); row [7]: which formulation of the neighbour lists ran */
 int copo_sim_set_debug(copo_sim* sim, int64_t* stamps);
 
 /* ---- stateless ops ---- */

@@ -23,10 +23,11 @@ def cruise_actions(obs, gen, speed=0.25):
     return torch.stack([steer, thr], -1).contiguous()
 
 
-def run(E, N, lasers, block, map_name, steps=200, warm=30, policy="random"):
+def run(E, N, lasers, block, map_name, steps=200, warm=30, policy="random", chunk=0):
     cfg = SimConfig(map=map_name, num_envs=E, num_agents=N, num_lasers=lasers)
     sim = VecSim(cfg, with_info=False)
     sim.set_block(block)
+    sim.set_chunk(chunk)
     out = sim.reset()
     gen = torch.Generator(device="cuda").manual_seed(0)
     if policy == "random":
@@ -58,7 +59,7 @@ def run(E, N, lasers, block, map_name, steps=200, warm=30, policy="random"):
     bytes_per = 202 + 4 * sim.O
     agents = E * sim.N
     sim.close()
-    return dict(E=E, N=sim.N, O=sim.O, block=block, policy=policy, us_per_step=round(us, 2), slots_per_s=round(agents / us * 1e6),
+    return dict(E=E, N=sim.N, O=sim.O, block=block, chunk=chunk, policy=policy, us_per_step=round(us, 2), slots_per_s=round(agents / us * 1e6),
                 present_frac=round(present, 3), present_GBps=round(agents * present * bytes_per / us * 1e-3, 1),
                 hbm_frac_present=round(agents * present * bytes_per / us * 1e-3 / 8000, 4),
                 hbm_frac_all_slots=round(agents * bytes_per / us * 1e-3 / 8000, 4))
@@ -73,7 +74,9 @@ if __name__ == "__main__":
     ap.add_argument("--blocks", type=int, nargs="+", default=[256, 512, 1024])
     ap.add_argument("--policy", default="random", choices=["random", "cruise"])
     ap.add_argument("--lib", default=None)
+    ap.add_argument("--chunks", type=int, nargs="+", default=[0])
     a = ap.parse_args()
     for E in a.E:
         for b in a.blocks:
-            print(json.dumps(run(E, a.N, a.lasers, b, a.map, policy=a.policy)), flush=True)
+            for ch in a.chunks:
+                print(json.dumps(run(E, a.N, a.lasers, b, a.map, policy=a.policy, chunk=ch)), flush=True)

@@ -14,7 +14,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NAMES = {0: "everything (nothing skipped)", 1: "neighbour lists", 2: "LiDAR windows + box tests", 4: "LiDAR write-out",
          8: "state / navigation block", 16: "collision pairs", 32: "respawn", 64: "projection / termination", 127: "all of the above",
-         3: "neighbours + LiDAR tests", 6: "LiDAR tests + write-out", 7: "neighbours + all LiDAR"}
+         128: "neighbour lists pair-parallel (register formulation off: phase = NEGATIVE of its saving)", 3: "neighbours + LiDAR tests", 6: "LiDAR tests + write-out", 7: "neighbours + all LiDAR"}
 
 
 def child(mask, E, block, path):
