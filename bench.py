@@ -432,8 +432,18 @@ def main():
 
     line = None
     if rank == 0:
-        sim = trainer.env.sim
-        k_s, present = measure_sim_kernel(trainer)
+        # Side measurements refer to the state the timed region STARTED from: training moves the policy (the value nets start
+        # untrained, their advantages perturb the loaded driver) and with it the population, so with one process a second trainer
+        # is built with the same seed and brought to the same point (`warm` iterations); several ranks keep the trainer they
+        # have (building one on rank 0 alone would leave the other ranks' collectives without a partner)
+        side = trainer
+        if world == 1:
+            side = make_trainer(args.num_envs, args.num_agents, graphs=not args.no_graphs, pretrained=not args.untrained)
+            for _ in range(warm):
+                side.train()
+            torch.cuda.synchronize()
+        sim = side.env.sim
+        k_s, present = measure_sim_kernel(side)
         bytes_per_unit = 202 + 4 * sim.O
         achieved = present * bytes_per_unit / k_s * 1e-9
         # HBM bytes per launch from the PMC counters are taken in a separate rocprofv3 pass (scripts/sim_traffic.sh writes
@@ -445,9 +455,9 @@ def main():
             if tj.get("kernel_source_sha1") == kernel_source_hash():
                 traffic = tj.get("bytes_per_launch")
                 traffic_units = tj.get("units_per_launch")        # present slots of the launches the counters saw
-        learner = measure_learner_step(trainer)
-        sat_s, sat_present, sat_slots = measure_sim_kernel_saturated(trainer, policy="cruise")
-        rnd_s, rnd_present, _ = measure_sim_kernel_saturated(trainer, policy="random")
+        learner = None     # (after `phases`: it walks the trainer's SGD plan tables)
+        sat_s, sat_present, sat_slots = measure_sim_kernel_saturated(side, policy="cruise")
+        rnd_s, rnd_present, _ = measure_sim_kernel_saturated(side, policy="random")
         line = {
             "metric": "agent-env-steps/sec (sim+learn), Intersection 40-agent", "value": round(value, 1),
             "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -487,6 +497,9 @@ def main():
                                    "the previous launch's drain with their own ramp-up",
                          "library_build": "shipped libcopo_hip.so: no environment knobs, all phases compiled in"},
         }
+        if world == 1:
+            line["phases"] = measure_phases(side)
+        learner = measure_learner_step(side)
         if learner is not None:
             l_s, l_flops = learner
             line["learner_roofline"] = {
@@ -496,8 +509,8 @@ def main():
                 "us_per_step": round(l_s * 1e6, 2), "flops_per_step": int(l_flops)}
         if coll is not None:
             line["config"]["collective"] = coll
-        if world == 1:
-            line["phases"] = measure_phases(trainer)
+        if side is not trainer:
+            side.stop()
         if world == 1 and not args.no_cpu_baseline:
             v, cdt, n, used = cpu_baseline(args.num_envs, args.num_agents)
             host = os.cpu_count() or 1

@@ -1005,13 +1005,15 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_reset_kernel(const Sim
 // ------------------------------------------------------------------------------------------------
 // step kernel
 // ------------------------------------------------------------------------------------------------
-template <bool EXT>
-__global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_kernel(const SimParams* __restrict__ pp,
-                                                                      const float* __restrict__ act, StepOut out) {
+// ONE: the one-wave-per-scene launch shape as its own instantiation (workgroup = 64 threads known at compile time: the
+// wave-role branches fold away, workgroup barriers become wave-local, the register budget is that of a 64-thread kernel)
+template <bool EXT, bool ONE>
+__global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel(const SimParams* __restrict__ pp,
+                                                                                 const float* __restrict__ act, StepOut out) {
     const SimParams& p = *pp;       // device-memory parameter block (see sim_reset_kernel)
     __shared__ EnvLds L;
-    const int e = blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nwaves = nthreads >> 6;
+    const int e = blockIdx.x, tid = threadIdx.x, nthreads = ONE ? 64 : (int)blockDim.x;
+    const int wave = ONE ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nwaves = ONE ? 1 : nthreads >> 6;
     const int N = p.N;
     const float hl = p.hl, hw = p.hw;
     load_rays(p, L, tid, nthreads);
@@ -1439,7 +1441,8 @@ static hipError_t sim_lds_attrs() {              // 64 slots x 256 rays + route 
     static hipError_t once = [] {
         hipError_t r = hipSuccess;
         for (const void* f : {reinterpret_cast<const void*>(sim_reset_kernel<false>), reinterpret_cast<const void*>(sim_reset_kernel<true>),
-                              reinterpret_cast<const void*>(sim_step_kernel<false>), reinterpret_cast<const void*>(sim_step_kernel<true>)}) {
+                              reinterpret_cast<const void*>(sim_step_kernel<false, false>), reinterpret_cast<const void*>(sim_step_kernel<true, false>),
+                              reinterpret_cast<const void*>(sim_step_kernel<false, true>), reinterpret_cast<const void*>(sim_step_kernel<true, true>)}) {
             const hipError_t a = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             if (a != hipSuccess) r = a;
         }
@@ -1471,8 +1474,14 @@ hipError_t launch_sim_reset(const SimParams& p, const SimParams* p_dev, const St
 
 hipError_t launch_sim_step(const SimParams& p, const SimParams* p_dev, const float* act, const StepOut& out, int block, hipStream_t stream) {
     if (hipError_t a = sim_lds_attrs(); a != hipSuccess) return a;
-    if (sim_has_ext(p)) hipLaunchKernelGGL(sim_step_kernel<true>, dim3(p.E), dim3(block), lidar_lds_bytes(p, block) + route_lds_bytes(p), stream, p_dev, act, out);
-    else hipLaunchKernelGGL(sim_step_kernel<false>, dim3(p.E), dim3(block), lidar_lds_bytes(p, block) + route_lds_bytes(p), stream, p_dev, act, out);
+    const size_t lds = lidar_lds_bytes(p, block) + route_lds_bytes(p);
+    if (block == 64) {
+        if (sim_has_ext(p)) hipLaunchKernelGGL((sim_step_kernel<true, true>), dim3(p.E), dim3(64), lds, stream, p_dev, act, out);
+        else hipLaunchKernelGGL((sim_step_kernel<false, true>), dim3(p.E), dim3(64), lds, stream, p_dev, act, out);
+    } else {
+        if (sim_has_ext(p)) hipLaunchKernelGGL((sim_step_kernel<true, false>), dim3(p.E), dim3(block), lds, stream, p_dev, act, out);
+        else hipLaunchKernelGGL((sim_step_kernel<false, false>), dim3(p.E), dim3(block), lds, stream, p_dev, act, out);
+    }
     return hipGetLastError();
 }
 
