@@ -373,6 +373,9 @@ def main():
     ap.add_argument("--roofline-only", action="store_true",
                     help="warm-up iterations, then ONLY the live simulator-kernel measurement (recorded replay on the trainer's scenes) "
                          "and one small JSON line: the command scripts/sim_traffic.sh runs under rocprofv3 --pmc")
+    ap.add_argument("--saturated-only", action="store_true",
+                    help="ONLY the saturated simulator-kernel measurement (16 384 populated scenes, recorded replay) and one small "
+                         "JSON line: the command scripts/prof_sim_r03.sh profiles")
     args = ap.parse_args()
 
     from copo_amd import dist as D
@@ -380,6 +383,15 @@ def main():
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     torch.cuda.set_device(local_rank)
     trainer = make_trainer(args.num_envs, args.num_agents, graphs=not args.no_graphs, pretrained=not args.untrained)
+    if args.saturated_only:
+        sat_s, sat_present, sat_slots = measure_sim_kernel_saturated(trainer, policy="cruise")
+        b = 202 + 4 * trainer.env.sim.O
+        print(json.dumps({"kernel": "copo::sim_step_kernel", "scenes": sat_slots // trainer.env.sim.N, "launches": 60,
+                          "us_per_launch": round(sat_s * 1e6, 2), "present_slots": round(sat_present), "bytes_per_unit": b,
+                          "frac": round(sat_present * b / sat_s * 1e-9 / HBM_PEAK_GBPS, 4)}), flush=True)
+        trainer.stop()
+        D.shutdown()
+        return
     warm = max(args.warmup, 4 if not args.no_graphs else 0)   # eager warm-ups + graph capture happen untimed
     for _ in range(warm):
         trainer.train()

@@ -55,6 +55,24 @@ __device__ __forceinline__ void project_seg(const float* __restrict__ g, float x
     }
 }
 
+// Extra drivable width to the right of a straight road of a Merge / Split block at arc length sl (record fields 12 wave radius R,
+// 14 extra width D at the wide end: + narrowing / - widening, 15 hand-over point of the edge line's two arcs, measured from the
+// wide end): the outer edge of the outermost wave lane, two arcs of radius R + w / 2 and R - w / 2 (maps.Net.add_funnel).
+__device__ __forceinline__ float funnel_extra(const float* __restrict__ g, float sl, float w) {
+    const float R = g[12];
+    if (g[5] != 0.0f || R == 0.0f) return 0.0f;
+    const float L = g[4], Ds = g[14], u1 = g[15];
+    const float D = fabsf(Ds);
+    float u = Ds > 0.0f ? sl : L - sl;             // distance from the wide end
+    u = u < 0.0f ? 0.0f : (u > L ? L : u);
+    if (u <= u1) {
+        const float R1 = R + 0.5f * w;
+        return D - (R1 - sqrtf(R1 * R1 - u * u));
+    }
+    const float R2 = R - 0.5f * w, v = L - u;
+    return R2 - sqrtf(R2 * R2 - v * v);
+}
+
 // SAT overlap of two oriented boxes (centre, heading unit vector, half length, half width each)
 __device__ __forceinline__ bool obb_overlap2(float xi, float yi, float ci, float si, float ai, float bi, float xj, float yj,
                                              float cj, float sj, float aj, float bj) {
@@ -628,7 +646,17 @@ __device__ __forceinline__ void ego_navi_obs(const SimParams& p, EnvLds& L, int 
             int kk = seg + j;
             if (kk > nseg - 1) kk = nseg - 1;
             const float* gk = seg_ptr(L, route, kk);
-            float vx = gk[COPO_SEG_CKX] - s.x, vy = gk[COPO_SEG_CKX + 1] - s.y;
+            float ckx = gk[COPO_SEG_CKX], cky = gk[COPO_SEG_CKX + 1];
+            if (floorf(gk[COPO_SEG_LANES]) != lanes) {
+                // Navigation._get_info_for_checkpoint puts BOTH check points at the lateral middle of the CURRENT road's lane
+                // count ((get_current_lane_num() / 2 - 0.5) * width to the right of the checked road's lane 0): where the lane
+                // count changes (Merge / Split blocks) the next check point is not the middle of its own road
+                const float* gn = seg_ptr(L, route, kk + 1);          // start of the next record = end of road kk, lane 0
+                const float off = (lanes * 0.5f - 0.5f) * w;
+                ckx = gn[0] + gn[3] * off;
+                cky = gn[1] - gn[2] * off;
+            }
+            float vx = ckx - s.x, vy = cky - s.y;
             const float nrm = sqrtf(vx * vx + vy * vy);
             if (nrm > 50.0f) {
                 const float sc = 50.0f / nrm;
@@ -1241,7 +1269,7 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
             const bool left_solid = (lfr == 0.25f) || (lfr == 0.75f), right_solid = lfr >= 0.5f;
             float lif = floorf(0.5f - lat * p.inv_w);
             lif = lif < 0.0f ? 0.0f : (lif > lanes - 1.0f ? lanes - 1.0f : lif);
-            const float left = 0.5f * w - lat, right = lanes * w - left;
+            const float left = 0.5f * w - lat, right = (lanes * w + funnel_extra(g, sl, w)) - left;
             const float cos2 = 1.0f - sinpsi * sinpsi;
             const float edge = p.body_margin * (hw * sqrtf(cos2 > 0.0f ? cos2 : 0.0f) + hl * fabsf(sinpsi));      // body extent across the road
             const bool on_road = (left >= (left_solid ? edge : 0.0f)) && (right >= (right_solid ? edge : 0.0f));

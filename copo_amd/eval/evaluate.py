@@ -95,6 +95,39 @@ def evaluate_population(algo, env, weights=None, lcf=None, num_envs=64, num_agen
     return res
 
 
+def evaluate_population_rows(algo, env, weights=None, lcf=None, num_envs=64, num_agents=40, scene_episodes=1, seed=0,
+                             recorder_distance=20.0, **extra):
+    """The reference's per-episode evaluation table (`evaluate_once`, eval/evaluate_population.py:21-99: one row of
+    `RecorderEnv.get_episode_result` per whole scene episode) for `num_envs` scenes at once: a pandas DataFrame with the
+    reference's column names (`vec_recorder.COLUMNS`).  The recorder counts neighbours within its own radius (20 m,
+    recoder.py:76), so the scenes are built with that `neighbours_distance` -- the policies do not read it."""
+    import torch
+    from .checkpoint_io import load_policy_weights
+    from .vec_recorder import F_ENV_RESET, VecRecorder
+    extra = dict(extra)
+    env_config = dict(extra.pop("env_config", None) or {}, neighbours_distance=float(recorder_distance))
+    t = make_eval_trainer(algo, env, num_envs, num_agents, seed, lcf, env_config=env_config, **extra)
+    if weights is not None:
+        load_policy_weights(t.policy.model, weights)
+        if t.policy.fused is not None:
+            t.policy.fused.sync_mirror()
+    smp = t.sampler
+    rec = VecRecorder(smp.E, smp.device)
+    ep = torch.zeros(smp.E, dtype=torch.int64, device=smp.device)
+    horizon = int(t.env.sim.cfg.horizon)
+    n_frag = 0
+    while bool((ep < int(scene_episodes)).any()) and n_frag * smp.T <= 6 * (int(scene_episodes) + 1) * horizon:
+        b = smp.sample()
+        fl = b["flags"]
+        ended = ((fl & F_ENV_RESET) > 0).any(-1).to(torch.int64)            # [T, E]
+        before = ep[None] + torch.cumsum(ended, 0) - ended                   # whole episodes finished before step t
+        rec.add(dict(flags=fl, infos=b["infos"], nbr_cnt=b["nbr_cnt"]), keep=before < int(scene_episodes))
+        ep = ep + ended.sum(0)
+        n_frag += 1
+    t.stop()
+    return rec.frame()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--algo", default="copo", choices=["ippo", "ccppo", "copo", "cl"])

@@ -99,6 +99,7 @@ class Net:
         self.lines = []          # [x0, y0, theta0, length, kappa, kind, 0, 0]
         self.toll_roads = set()  # roads that are toll booths (Tollgate)
         self.solid = {}          # road -> (left edge continuous, right edge continuous)
+        self.funnel = {}         # road -> (wave radius, extra width at the wide end, +1 narrowing / -1 widening): Merge / Split blocks
 
     def add(self, a, b, pose, length, kappa, lanes, left_line=LINE_CONTINUOUS, right_line=LINE_CONTINUOUS,
             inner_line=LINE_BROKEN, toll=False):
@@ -121,6 +122,38 @@ class Net:
                 ln = length * (1.0 - kappa * a_off) if kappa else length
                 self.lines.append([p[0], p[1], p[2], ln, k, kind, 0.0, 0.0])
         return advance(pose, length, kappa)
+
+    def add_funnel(self, a, b, pose, length, lanes, extra_lanes, narrowing):
+        """MetaDrive's Merge ("y", `narrowing`) / Split ("Y") block: the route follows a straight `lanes`-lane road of
+        `length` (Bottleneck.BOTTLENECK_LEN = 20 m); `extra_lanes` more lanes to its right run into it / out of it on WAVE lanes
+        -- two arcs of opposite sense, `create_wave_lanes`: lane `index` is shifted by `index * lane_width` over the length, half
+        of it by each arc, angle = pi - 2 atan(length / (2 * lateral_dist)), radius = length / (2 sin(angle)) with lateral_dist
+        = index * lane_width / 2.  Those lanes are drivable but not part of the route: the road record keeps `lanes` (check
+        points, lane index) and carries the outermost wave lane as extra width on its right (R, D, direction); the only lines
+        are the centre line (continuous) and the outer edge of the outermost wave lane (continuous): two arcs."""
+        w = self.w
+        end = self.add(a, b, pose, length, 0.0, lanes, LINE_CONTINUOUS, 0, 0)
+        self.solid[(a, b)] = (True, True)
+        d = extra_lanes * w / 2.0                              # lateral_dist of the outermost wave lane, per arc
+        ang = math.pi - 2.0 * math.atan(length / (2.0 * d))
+        R = length / (2.0 * math.sin(ang))
+        # record fields of the funnel: wave radius, extra width at the wide end (+ narrowing / - widening), and how far from the
+        # wide end the edge line's first arc (radius R + w / 2: the edge runs outside that bend) hands over to the second (R - w / 2)
+        self.funnel[(a, b)] = (R, (2.0 * d) if narrowing else -(2.0 * d), (R + 0.5 * w) * math.sin(ang))
+        # outer edge line = the outermost wave lane's centre line shifted w / 2 to the right.  Narrowing: it starts (lanes +
+        # extra - 0.5) w to the right of lane 0 and bends LEFT first, then right; widening: it starts (lanes - 0.5) w to the
+        # right and bends RIGHT first, then left.
+        first = 1.0 if narrowing else -1.0                      # sense of the first arc (+ = left)
+        off0 = (lanes + (extra_lanes if narrowing else 0) - 1) * w      # outermost wave lane's centre at the start, to the right of lane 0
+        c = shift(pose, -off0)
+        for sense in (first, -first):
+            kap = sense / R
+            a_off = -0.5 * w                                    # the lane's right edge
+            p = shift(c, a_off)
+            k = kap / (1.0 - kap * a_off)
+            self.lines.append([p[0], p[1], p[2], R * ang * (1.0 - kap * a_off), k, LINE_CONTINUOUS, 0.0, 0.0])
+            c = advance(c, R * ang, kap)
+        return end
 
     def end_pose(self, a, b):
         pose, ln, k, _ = self.roads[(a, b)]
@@ -155,7 +188,7 @@ class Net:
         return path[::-1]
 
 
-def road_record(pose, length, kappa, lanes, s_start, w, solid=(False, False)):
+def road_record(pose, length, kappa, lanes, s_start, w, solid=(False, False), funnel=None):
     """One SEG_STRIDE record (float64) for a road whose lane-0 line starts at `pose`.  The lanes field carries the edge-line
     flags in its fraction: lanes + 0.25 (left edge continuous) + 0.5 (right edge continuous)."""
     x, y, th = pose
@@ -168,6 +201,8 @@ def road_record(pose, length, kappa, lanes, s_start, w, solid=(False, False)):
     if kappa == 0:
         rec[SEG_F_RADIUS], rec[SEG_RADIUS], rec[SEG_F_ANGLE] = 0.0, 0.0, 0.5
         rec[SEG_UMX], rec[SEG_UMY] = 1.0, 0.0
+        if funnel is not None:      # straight road of a Merge / Split block: wave radius, extra width at the wide end, direction
+            rec[SEG_RADIUS], rec[SEG_UMX], rec[SEG_UMY] = funnel
     else:
         radius, ang = 1.0 / abs(kappa), abs(kappa) * length
         rec[SEG_F_RADIUS] = min(1.0, radius / (NAVI_RADIUS_NORM + lanes * w))
@@ -197,7 +232,7 @@ class _Builder:
             solid = net.solid[(nodes[k], nodes[k + 1])]
             if (nodes[k], nodes[k + 1]) in net.toll_roads:
                 toll = k
-            rec[k] = road_record(pose, ln, kap, lanes, s, w, solid)
+            rec[k] = road_record(pose, ln, kap, lanes, s, w, solid, net.funnel.get((nodes[k], nodes[k + 1])))
             s += ln
         end = net.end_pose(nodes[-2], nodes[-1])
         nseg = len(nodes) - 1
@@ -306,44 +341,55 @@ def roundabout(exit_length=60.0, exit_radius=10.0, inner_radius=30.0, angle_deg=
 
 
 def bottleneck(exit_length=60.0, bottle_lanes=4, neck_lanes=1, neck_length=20.0, taper=20.0, lane_width=LANE_WIDTH):
-    """MABottleneckMap: a two-way road that narrows from `bottle_lanes` to `neck_lanes` lanes per direction and widens
-    again (20 agents, eval/evaluate_population.py:118-124; `bottle_lane_num=4, neck_lane_num=1, neck_length=20`).  The
-    merge zone is one `bottle_lanes`-wide road of length `taper`: a vehicle may merge anywhere inside it and is out of
-    its route if it reaches the neck outside the neck's lanes (the leftmost ones)."""
+    """MABottleneckMap (20 agents, eval/evaluate_population.py:118-124; `bottle_lane_num=4, neck_lane_num=1, neck_length=20`):
+    FirstPGBlock -> Merge -> Split.  The first block's spawn road is `exit_length - 10` long (NODE_2 -> NODE_3), the Split's socket
+    road `exit_length`; the Merge / Split blocks are funnels (`Net.add_funnel`): the route follows the `neck_lanes` leftmost lanes
+    straight through, the other lanes bend into / out of them on wave lanes over `taper` = BOTTLENECK_LEN = 20 m."""
     w = lane_width
     net = Net(w)
-    total = 2 * (exit_length + taper) + neck_length
+    first = exit_length - ENTRANCE_LENGTH
+    total = first + exit_length + 2 * taper + neck_length
+    extra = bottle_lanes - neck_lanes
     for d in range(2):
         o = (0.0, 0.0, 0.0) if d == 0 else reverse(shift((total, 0.0, 0.0), w))
-        e = net.add("in%d" % d, "w%d" % d, o, exit_length, 0.0, bottle_lanes)
-        e = net.add("w%d" % d, "n%d" % d, e, taper, 0.0, bottle_lanes)
+        l_in, l_out = (first, exit_length) if d == 0 else (exit_length, first)
+        e = net.add("in%d" % d, "w%d" % d, o, l_in, 0.0, bottle_lanes)
+        e = net.add_funnel("w%d" % d, "n%d" % d, e, taper, neck_lanes, extra, True)
         e = net.add("n%d" % d, "m%d" % d, e, neck_length, 0.0, neck_lanes)
-        e = net.add("m%d" % d, "x%d" % d, e, taper, 0.0, bottle_lanes)
-        net.add("x%d" % d, "end%d" % d, e, exit_length, 0.0, bottle_lanes)
+        e = net.add_funnel("m%d" % d, "x%d" % d, e, taper, neck_lanes, extra, False)
+        net.add("x%d" % d, "end%d" % d, e, l_out, 0.0, bottle_lanes)
     b = _Builder("bottleneck", net, 20, total / 2)
-    slots = spawn_slots(exit_length + ENTRANCE_LENGTH)
+    slots = spawn_slots(exit_length)
     for d in range(2):
         b.add_spawn_road(("in%d" % d, "w%d" % d), ["end%d" % d], slots)
     return b.finish()
 
 
-def tollgate(exit_length=70.0, lanes=3, toll_lanes=8, toll_length=10.0, taper=30.0, lane_width=LANE_WIDTH):
-    """MATollGateMap: a `lanes`-lane two-way road that fans out into `toll_lanes` booths and closes again (40 agents).
-    The fan is modelled as one road whose corridor is `toll_lanes` wide; the booth logic (a vehicle must spend
-    `min_pass_steps` inside a booth) is the simulator's `toll` option."""
+def tollgate(exit_length=70.0, lanes=3, toll_lanes=8, toll_length=10.0, taper=20.0, socket=2.0, lane_width=LANE_WIDTH):
+    """MATollGateMap (40 agents): FirstPGBlock (`lanes` lanes) -> Split (funnel to `toll_lanes` lanes over BOTTLENECK_LEN =
+    `taper` = 20 m, socket road of 2 m) -> TollGate block (`toll_length`) -> Merge (funnel back, socket road = `exit_length`).
+    The route follows the `lanes` leftmost lanes straight through both funnels (`Net.add_funnel`); the booth logic (a vehicle
+    must spend `min_pass_steps` inside a booth) is the simulator's `toll` option."""
     w = lane_width
     net = Net(w)
-    total = 2 * (exit_length + taper) + toll_length
+    first = exit_length - ENTRANCE_LENGTH
+    total = first + exit_length + 2 * taper + socket + toll_length
+    extra = toll_lanes - lanes
     for d in range(2):
         o = (0.0, 0.0, 0.0) if d == 0 else reverse(shift((total, 0.0, 0.0), w))
-        e = net.add("in%d" % d, "f%d" % d, o, exit_length, 0.0, lanes)
-        e = net.add("f%d" % d, "t%d" % d, e, taper, 0.0, toll_lanes, LINE_CONTINUOUS, LINE_CONTINUOUS, 0)
-        e = net.add("t%d" % d, "g%d" % d, e, toll_length, 0.0, toll_lanes, LINE_CONTINUOUS, LINE_CONTINUOUS, LINE_CONTINUOUS,
-                    toll=True)
-        e = net.add("g%d" % d, "x%d" % d, e, taper, 0.0, toll_lanes, LINE_CONTINUOUS, LINE_CONTINUOUS, 0)
-        net.add("x%d" % d, "end%d" % d, e, exit_length, 0.0, lanes)
+        l_in, l_out = (first, exit_length) if d == 0 else (exit_length, first)
+        e = net.add("in%d" % d, "f%d" % d, o, l_in, 0.0, lanes)
+        e = net.add_funnel("f%d" % d, "s%d" % d, e, taper, lanes, extra, False)
+        if d == 0:      # (the blocks are laid out along direction 0: its socket road precedes the booths, direction 1 meets it after them)
+            e = net.add("s%d" % d, "t%d" % d, e, socket, 0.0, toll_lanes, LINE_CONTINUOUS, LINE_CONTINUOUS, 0)
+            e = net.add("t%d" % d, "g%d" % d, e, toll_length, 0.0, toll_lanes, LINE_CONTINUOUS, LINE_CONTINUOUS, LINE_CONTINUOUS, toll=True)
+        else:
+            e = net.add("s%d" % d, "t%d" % d, e, toll_length, 0.0, toll_lanes, LINE_CONTINUOUS, LINE_CONTINUOUS, LINE_CONTINUOUS, toll=True)
+            e = net.add("t%d" % d, "g%d" % d, e, socket, 0.0, toll_lanes, LINE_CONTINUOUS, LINE_CONTINUOUS, 0)
+        e = net.add_funnel("g%d" % d, "x%d" % d, e, taper, lanes, extra, True)
+        net.add("x%d" % d, "end%d" % d, e, l_out, 0.0, lanes)
     b = _Builder("tollgate", net, 40, total / 2)
-    slots = spawn_slots(exit_length + ENTRANCE_LENGTH)
+    slots = spawn_slots(exit_length)
     for d in range(2):
         b.add_spawn_road(("in%d" % d, "f%d" % d), ["end%d" % d], slots)
     return b.finish()

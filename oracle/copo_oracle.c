@@ -352,6 +352,23 @@ static void project_seg(const float* g, float x, float y, float ch, float sh, fl
     }
 }
 
+/* Extra drivable width to the right of a straight road of a Merge / Split block (sim_kernels.hip funnel_extra, the same
+ * operations in the same order; maps.Net.add_funnel documents the geometry). */
+static float funnel_extra(const float* g, float sl, float w) {
+    float R = g[12];
+    if (g[5] != 0.0f || R == 0.0f) return 0.0f;
+    float L = g[4], Ds = g[14], u1 = g[15];
+    float D = fabsf(Ds);
+    float u = Ds > 0.0f ? sl : L - sl;
+    u = u < 0.0f ? 0.0f : (u > L ? L : u);
+    if (u <= u1) {
+        float R1 = R + 0.5f * w;
+        return D - (R1 - sqrtf(R1 * R1 - u * u));
+    }
+    float R2 = R - 0.5f * w, v = L - u;
+    return R2 - sqrtf(R2 * R2 - v * v);
+}
+
 typedef struct step_tmp {
     uint8_t acted[COPO_MAX_AGENTS], newly[COPO_MAX_AGENTS], fl[COPO_MAX_AGENTS];
     float rew[COPO_MAX_AGENTS], acc[COPO_MAX_AGENTS], lcf_row[COPO_MAX_AGENTS];
@@ -516,7 +533,16 @@ static void write_obs(oracle_sim* s, int e, const copo_step_out* out, const uint
                 int kk = seg + j;
                 if (kk > nseg - 1) kk = nseg - 1;
                 const float* gk = SEG(s, route, kk);
-                float vx = gk[COPO_SEG_CKX] - x, vy = gk[COPO_SEG_CKX + 1] - y;
+                float ckx = gk[COPO_SEG_CKX], cky = gk[COPO_SEG_CKX + 1];
+                if (floorf(gk[COPO_SEG_LANES]) != lanes) {
+                    /* both check points sit at the lateral middle of the CURRENT road's lane count (Navigation.
+                     * _get_info_for_checkpoint: later_middle from get_current_lane_num()), to the right of road kk's lane 0 */
+                    const float* gn = SEG(s, route, kk + 1);
+                    float off = (lanes * 0.5f - 0.5f) * w;
+                    ckx = gn[0] + gn[3] * off;
+                    cky = gn[1] - gn[2] * off;
+                }
+                float vx = ckx - x, vy = cky - y;
                 float nrm = sqrtf(vx * vx + vy * vy);
                 if (nrm > 50.0f) {
                     float sc = 50.0f / nrm;
@@ -868,7 +894,7 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
             int left_solid = (lfr == 0.25f) || (lfr == 0.75f), right_solid = lfr >= 0.5f;
             float lif = floorf(0.5f - lat * s->inv_w);
             lif = lif < 0.0f ? 0.0f : (lif > lanes - 1.0f ? lanes - 1.0f : lif);
-            float left = 0.5f * w - lat, right = lanes * w - left;
+            float left = 0.5f * w - lat, right = (lanes * w + funnel_extra(g, sl, w)) - left;
             /* the body's half extent across the road (heading error psi): the edge lines must not be touched */
             float cos2 = 1.0f - sinpsi * sinpsi;
             float edge = c->body_margin * (hw * sqrtf(cos2 > 0.0f ? cos2 : 0.0f) + hl * fabsf(sinpsi));

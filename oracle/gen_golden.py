@@ -552,18 +552,17 @@ def tensor_batch(b):
     return SampleBatch({k: torch.as_tensor(v) for k, v in b.items()})
 
 
-def gen_losses():
-    rng = np.random.RandomState(21)
-    for tag, pcls, mcls, fuse, over in [
-        ("ippo", I.IPPOPolicy, C.CCModel, "none", {}),
-        ("ccppo_mf", C.CCPPOPolicy, C.CCModel, "mf", {}),
-        ("ccppo_concat", C.CCPPOPolicy, C.CCModel, "concat", {}),
-        ("copo", A.CoPOPolicy, A.CoPOModel, "none", {}),
-        ("copo_newvf", A.CoPOPolicy, A.CoPOModel, "none", dict(old_value_loss=False, vf_clip_param=10.0)),
-        ("copo_nokl", A.CoPOPolicy, A.CoPOModel, "none", dict(kl_coeff=0.0)),
+def gen_losses(cases=None, seed=21):
+    rng = np.random.RandomState(seed)
+    for tag, pcls, mcls, fuse, over, O, B, hiddens in cases or [
+        ("ippo", I.IPPOPolicy, C.CCModel, "none", {}, 12, 96, [32, 32]),
+        ("ccppo_mf", C.CCPPOPolicy, C.CCModel, "mf", {}, 12, 96, [32, 32]),
+        ("ccppo_concat", C.CCPPOPolicy, C.CCModel, "concat", {}, 12, 96, [32, 32]),
+        ("copo", A.CoPOPolicy, A.CoPOModel, "none", {}, 12, 96, [32, 32]),
+        ("copo_newvf", A.CoPOPolicy, A.CoPOModel, "none", dict(old_value_loss=False, vf_clip_param=10.0), 12, 96, [32, 32]),
+        ("copo_nokl", A.CoPOPolicy, A.CoPOModel, "none", dict(kl_coeff=0.0), 12, 96, [32, 32]),
     ]:
-        O, B = 12, 96
-        model = make_model(mcls, O, fuse, [32, 32], 30)
+        model = make_model(mcls, O, fuse, hiddens, 30)
         # move weights away from the near-zero head init so that KL/ratio terms are exercised
         with torch.no_grad():
             for p_ in model.parameters():
@@ -597,6 +596,18 @@ def gen_losses():
                                      float(cfg["old_value_loss"]), pol.kl_coeff, pol.entropy_coeff])
         np.savez_compressed(os.path.join(OUT, "loss_%s.npz" % tag), **save)
         print("loss_%s.npz" % tag, float(loss))
+
+
+def gen_losses_config_shapes():
+    """The same reference functions at the observation widths of the BASELINE configurations (the rows above use 12-wide
+    toy observations and 32-wide layers, which the fused learner serves with its tile-GEMM kernels): 64-wide hidden layers take
+    the production row-pass kernels.  configs[1]: CoPO, O = 92, one 512-row minibatch; configs[3]: CCPPO mean-field on the
+    Tollgate, O = 156, centralised critic 2 * 156 + 2 = 314 wide; configs[4]: CoPO on the ParkingLot with 240 beams, O = 260."""
+    gen_losses([
+        ("copo_o92_b512", A.CoPOPolicy, A.CoPOModel, "none", {}, 92, 512, [64, 64]),
+        ("ccppo_mf_o156", C.CCPPOPolicy, C.CCModel, "mf", {}, 156, 128, [64, 64]),
+        ("copo_o260", A.CoPOPolicy, A.CoPOModel, "none", {}, 260, 128, [64, 64]),
+    ], seed=22)
 
 
 def gen_meta_update():
@@ -949,6 +960,7 @@ if __name__ == "__main__":
     gen_param_counts()
     gen_postprocess()
     gen_losses()
+    gen_losses_config_shapes()
     gen_meta_update()
     gen_training_step()
     gen_callbacks()

@@ -89,7 +89,9 @@ def populations():
     np.savez_compressed(os.path.join(OUT, "reference_populations_f4.npz"), **save)
     res_dir = os.path.join(os.path.dirname(os.path.abspath(G.__file__)), "demo_results", "evaluate_results")
     cols = ["success_rate", "crash_rate", "out_rate", "episode_length_mean", "success_episode_length_mean",
-            "velocity_step_mean_episode_mean", "episode_reward_mean", "num_agents_total"]
+            "velocity_step_mean_episode_mean", "velocity_step_mean_episode_max", "episode_reward_mean", "episode_reward_min",
+            "episode_reward_max", "num_agents_total", "num_agents_total_per_300_steps", "num_neighbours_mean_episode_mean",
+            "num_neighbours_mean_episode_max", "episode_cost_mean"]
     stats = {}
     for algo in ("ippo", "copo"):
         files = sorted(glob.glob(os.path.join(res_dir, "%s_inter_*.csv" % algo)))
@@ -97,6 +99,24 @@ def populations():
         stats[algo + "_inter"] = dict(populations=len(files), episodes=int(len(d)), **{c: float(d[c].mean()) for c in cols})
         # per population (the shipped `copo_inter.npz` is population 0: get_policy_function.py:30-31 "Best")
         stats[algo + "_inter_per_population"] = [{c: float(pd.read_csv(f)[c].mean()) for c in cols} for f in files]
+    for k in list(stats):      # env episode length in steps (recoder.py:246-247: agents per 300 steps = agents / steps * 300)
+        for d in (stats[k] if isinstance(stats[k], list) else [stats[k]]):
+            d["env_episode_steps"] = d["num_agents_total"] / d["num_agents_total_per_300_steps"] * 300.0
+    # the reference's own TRAINING run of CoPO on the Intersection (MetaDrive 0.2.5, torch stack; eval/demo_raw_checkpoints/copo/
+    # .../progress.csv): per-agent return, rates, env episode length and LCF along the run -- a second, independent record of
+    # what MetaDrive returns for a CoPO population (the evaluation CSVs above come from populations of the paper's release)
+    prog = glob.glob(os.path.join(os.path.dirname(os.path.abspath(G.__file__)), "demo_raw_checkpoints", "copo", "*", "progress.csv"))
+    if prog:
+        d = pd.read_csv(prog[0])
+        keep = ["timesteps_total", "episode_reward_mean", "success", "crash", "out", "max_step", "episode_len_mean",
+                "info/learner/svo", "info/learner/svo_std", "raw_episode_reward_mean"]
+        rows = d[keep].iloc[[99, 199, 299, 399, 499, 599, len(d) - 1]]
+        stats["copo_inter_training_progress"] = [
+            dict(timesteps_total=int(r["timesteps_total"]), episode_reward_mean=float(r["episode_reward_mean"]), success=float(r["success"]),
+                 crash=float(r["crash"]), out=float(r["out"]), max_step=float(r["max_step"]), env_episode_steps=float(r["episode_len_mean"]),
+                 lcf=float(r["info/learner/svo"]), lcf_std=float(r["info/learner/svo_std"]),
+                 agents_per_env_episode=float(r["raw_episode_reward_mean"] / r["episode_reward_mean"])) for _, r in rows.iterrows()]
+        stats["copo_inter_training_progress_max_success"] = float(d["success"].max())
     with open(os.path.join(OUT, "reference_eval_stats.json"), "w") as f:
         json.dump(stats, f, indent=1, sort_keys=True)
     print("wrote reference_populations.npz", os.path.getsize(os.path.join(OUT, "reference_populations.npz")), stats)

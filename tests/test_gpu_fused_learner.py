@@ -445,6 +445,12 @@ def test_forward_kernel_matches_torch_models(name, fuse, odim, over):
     ("copo", "copo", "none", {}),
     ("copo_newvf", "copo", "none", dict(old_value_loss=False, vf_clip_param=10.0)),
     ("copo_nokl", "copo", "none", dict(kl_coeff=0.0)),
+    # the observation widths of the BASELINE configurations, 64-wide layers = the production row-pass kernels (the rows above:
+    # 12-wide toy observations, 32-wide layers = the tile-GEMM kernels): configs[1] CoPO O = 92 with one 512-row minibatch,
+    # configs[3] CCPPO mean-field on the Tollgate (O = 156, critic 314 wide), configs[4] CoPO ParkingLot 240 beams (O = 260)
+    ("copo_o92_b512", "copo", "none", {}),
+    ("ccppo_mf_o156", "ccppo", "mf", {}),
+    ("copo_o260", "copo", "none", {}),
 ])
 def test_fused_gradients_vs_reference_golden(golden_dir, tag, name, fuse, over):
     """The HIP learner against the REFERENCE's own outputs (tests/golden/loss_*.npz, recorded from
@@ -452,7 +458,8 @@ def test_fused_gradients_vs_reference_golden(golden_dir, tag, name, fuse, over):
     algo_copo.py:311-424): total loss, tower statistics and every parameter gradient of one 96-row batch."""
     g = np.load(os.path.join(golden_dir, "loss_%s.npz" % tag))
     B, odim = g["in_obs"].shape
-    pol = _make(name, fuse, odim, fused=True, hiddens=(32, 32), mb=B, **over)
+    hid = int(g["w__hidden_layers.0._model.0.bias"].shape[0]) if "w__hidden_layers.0._model.0.bias" in g.files else 32
+    pol = _make(name, fuse, odim, fused=True, hiddens=(hid, hid), mb=B, **over)
     assert pol.fused is not None
     pol.model.load_state_dict({k[2:]: torch.as_tensor(g[k]) for k in g.files if k.startswith("w_")}, strict=True)
     b = SampleBatch({k[3:]: torch.as_tensor(g[k]).cuda() for k in g.files if k.startswith("in_") and g[k].ndim >= 1})

@@ -118,7 +118,9 @@ def test_gae3_golden(golden_dir):
             assert np.array_equal(adv[h, :T, k], g[ak][k, :T]), (h, k)   # in fact bit-exact
 
 
-@pytest.mark.parametrize("T,M", [(8, 10240), (200, 517), (1, 64), (33, 1)])
+# (1, 40960): BASELINE configs[4] (ParkingLot, 10 slots x 4096 scenes, T = 1); (2, 20480): configs[3] (Tollgate, 40 x 512, T = 2);
+# (16, 5120): one shard of configs[2] (Roundabout, 40 x 128, T = 16)
+@pytest.mark.parametrize("T,M", [(8, 10240), (200, 517), (1, 64), (33, 1), (1, 40960), (2, 20480), (16, 5120)])
 def test_gae3_vs_oracle(T, M):
     import oracle_lib as ol
     rng = np.random.RandomState(T + M)
@@ -206,6 +208,31 @@ def test_cc_fuse_at_the_bench_batch(mode, cf):
     a = hip_cc_fuse(mode, obs, act, flags, nbr_idx, cnt, cf)
     b = ol.cc_fuse(mode, obs, act, flags, nbr_idx, cnt, cf)
     assert a.shape[0] * a.shape[1] == 81920 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("name,R,N,O,mode", [
+    ("configs[3] CCPPO mean-field Tollgate: 2 steps x 512 scenes x 40 slots, O = 156, cc 314", 2 * 512, 40, 156, "mf"),
+    ("configs[3] shape with the concat critic", 64, 40, 156, "concat"),
+    ("configs[4] shape: ParkingLot 10 slots, 240 beams, O = 260 (4096 scenes x T = 1)", 4096, 10, 260, "mf"),
+    ("configs[2] shard: Roundabout 16 steps x 128 scenes x 40 slots, O = 92", 16 * 128, 40, 92, "mf")])
+def test_cc_fuse_at_the_other_baseline_shapes(name, R, N, O, mode):
+    """The neighbourhood fusion against the oracle, bit for bit, at the observation widths / row counts of the BASELINE
+    configurations other than the bench one (algo_ccppo.py:225-311; cc width 2 * O + 2 for mean-field)."""
+    import oracle_lib as ol
+    rng = np.random.RandomState(O + N)
+    A, K = 2, min(8, N - 1)
+    obs = rng.uniform(-1, 1, (R, N, O)).astype(np.float32)
+    act = rng.normal(0, 1, (R, N, A)).astype(np.float32)
+    flags = (rng.uniform(size=(R, N)) > 0.3).astype(np.uint8)
+    cnt = rng.randint(0, K + 3, (R, N))
+    others = np.argsort(rng.uniform(size=(R, N, N - 1)), axis=-1)[..., :K].astype(np.int32)
+    others += (others >= np.arange(N)[None, :, None])
+    nbr_idx = np.where(np.arange(K)[None, None, :] < np.minimum(cnt, K)[..., None], others, -1).astype(np.int32)
+    a = hip_cc_fuse(mode, obs, act, flags, nbr_idx, cnt, True)
+    b = ol.cc_fuse(mode, obs, act, flags, nbr_idx, cnt, True)
+    if mode == "mf":
+        assert a.shape[-1] == 2 * O + 2, a.shape
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), name
 
 
 def hip_lcf_mix(adv, nei, glob, lcf, valid=None):
