@@ -1144,3 +1144,6 @@ int oracle_lcf_mix_apply(const float* mixed, const float* glob_adv, const uint8_
 }
 
 int oracle_version(void) { return COPO_ABI_VERSION; }
+
+/* test hook: the funnel width function of Merge / Split roads at arc length sl of road record g */
+float oracle_funnel_extra(const float* g, float sl, float w) { return funnel_extra(g, sl, w); }

@@ -103,6 +103,57 @@ def test_intersection_and_roundabout_follow_the_block_formulas():
     np.testing.assert_allclose(sorted(ring), [15.25 / np.cos(np.radians(70)) - 10 - 3.5, 37.0], rtol=1e-6)
 
 
+def test_merge_and_split_blocks_follow_the_wave_lane_formulas():
+    """Bottleneck / Tollgate: MetaDrive's Merge / Split blocks.  `create_wave_lanes`: lane `index` is shifted by index * w
+    over BOTTLENECK_LEN = 20 m by two arcs of angle pi - 2 atan(L / (2 d)) and radius L / (2 sin(angle)), d = index * w / 2.
+    The road record keeps the route's lanes and carries the outermost wave lane as extra width; the edge line (two arcs) must
+    run G1 from the wide road's right edge to the narrow road's, and the oracle's width function must BE that line."""
+    import ctypes as C
+    lib = ol.lib()
+    lib.oracle_funnel_extra.restype = C.c_float
+    lib.oracle_funnel_extra.argtypes = [C.c_void_p, C.c_float, C.c_float]
+    for t, lanes, extra, spawn_lanes in ((maps.bottleneck(), 1, 3, 4), (maps.tollgate(), 3, 5, 3)):
+        w = t.lane_width
+        d = extra * w / 2
+        ang = np.pi - 2 * np.arctan(20.0 / (2 * d))
+        R = 20.0 / (2 * np.sin(ang))
+        seg = t.route_segs[0]
+        funnels = [k for k in range(int(t.route_meta[0, 1])) if seg[k, maps.SEG_KAPPA] == 0 and seg[k, maps.SEG_RADIUS] > 0]
+        assert len(funnels) == 2
+        assert int(t.spawn_tab[:, 2].max()) + 1 == spawn_lanes
+        for k in funnels:
+            g = seg[k].astype(np.float64)
+            np.testing.assert_allclose([g[maps.SEG_LEN], g[maps.SEG_RADIUS], abs(g[maps.SEG_UMX]), g[maps.SEG_UMY]],
+                                       [20.0, R, extra * w, (R + w / 2) * np.sin(ang)], rtol=1e-6)
+            assert np.floor(g[maps.SEG_LANES]) == lanes and g[maps.SEG_LANES] - lanes == 0.75       # both edges continuous
+            narrowing = g[maps.SEG_UMX] > 0
+            # the edge line's arcs: find the two continuous arc lines that start inside this road's extent
+            x0, x1 = g[0], g[0] + 20.0
+            arcs = [ln for ln in t.lines.astype(np.float64) if ln[4] != 0 and ln[5] == maps.LINE_CONTINUOUS and
+                    min(x0, x1) - 1e-3 <= ln[0] <= max(x0, x1) + 1e-3 and abs(ln[1]) > 1.0 and ln[1] < 0]
+            assert len(arcs) == 2, (k, len(arcs))
+            arcs.sort(key=lambda ln: ln[0])
+            # G1: wide edge -> arc -> arc -> narrow edge
+            y_wide, y_narrow = -(lanes + extra - 0.5) * w, -(lanes - 0.5) * w
+            a, b = arcs
+            ea = maps.advance((a[0], a[1], a[2]), a[3], a[4])
+            eb = maps.advance((b[0], b[1], b[2]), b[3], b[4])
+            np.testing.assert_allclose([a[0], a[1], a[2]], [x0, y_wide if narrowing else y_narrow, 0.0], atol=2e-3)
+            np.testing.assert_allclose([ea[0], ea[1]], [b[0], b[1]], atol=2e-3)
+            assert abs(maps._wrap(ea[2] - b[2])) < 1e-4
+            np.testing.assert_allclose([eb[0], eb[1], maps._wrap(eb[2])], [x1, y_narrow if narrowing else y_wide, 0.0], atol=2e-3)
+            # the width function of the simulator IS that line: sample the arcs, compare the lateral position
+            rec = np.ascontiguousarray(seg[k], np.float32)
+            for ln in arcs:
+                for u in np.linspace(0.0, ln[3], 9):
+                    px, py, _ = maps.advance((ln[0], ln[1], ln[2]), u, ln[4])
+                    got = lib.oracle_funnel_extra(rec.ctypes.data, np.float32(px - x0), np.float32(w))
+                    assert abs((lanes - 0.5) * w + got - (-py)) < 2e-3, (k, u, got, py)
+        # every other road: no extra width
+        plain = np.ascontiguousarray(seg[0], np.float32)
+        assert lib.oracle_funnel_extra(plain.ctypes.data, np.float32(5.0), np.float32(w)) == 0.0
+
+
 def test_generated_roads_are_seeded_and_drivable():
     """PG road (the `MultiAgentMetaDrive` base env): a (sequence, seed) pair names one map, opposite carriageways stay a
     lane width apart through every block, and lane-keeping agents reach the far end in the oracle simulator."""
