@@ -170,6 +170,7 @@ struct __align__(16) EnvLds {
     const int32_t* stab;       // spawn table, same
     const float* sps;          // spawn offsets, same
     int32_t ending;
+    int32_t nbr_ok;            // wave-role step: the register formulation of the neighbour lists went through
     int32_t seg_rows;          // road records per route in the device tables (longest route + its terminal record)
 };
 
@@ -471,8 +472,7 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
 //  * global reward: added in slot order, which IS the reference's order.
 // K > 8, the communication block and the stateless op's filled rows take neighbours_phase as well.
 constexpr uint32_t NBR_SENT = 0xffffffffu;
-__device__ __forceinline__ bool neighbours_fast(const SimParams& p, EnvLds& L, int e, int lane, const StepOut& out) {
-    extern __shared__ unsigned int dyn[];
+__device__ __forceinline__ bool neighbours_fast(const SimParams& p, EnvLds& L, int e, int lane, const StepOut& out, float4* rec) {
     const int N = p.N, K = p.K;
     const unsigned long long present = L.m_present;
     const bool me = (present >> lane) & 1ull;
@@ -481,8 +481,7 @@ __device__ __forceinline__ bool neighbours_fast(const SimParams& p, EnvLds& L, i
     const float arw = fabsf(rw);
     const bool bad = me && !(rw == 0.0f || (arw >= 9.5367431640625e-07f && arw <= 16.0f));
     if (__ballot(bad) != 0ull) return false;
-    float4* rec = reinterpret_cast<float4*>(dyn);          // [64] {x, y, (double) reward}: the neighbour work area is free here
-    {
+    {   // rec: [64] {x, y, (double) reward} in LDS (the caller's choice: the neighbour work area when one wave owns the scene)
         const double rd = (double)rw;
         rec[lane] = make_float4(xi, yi, __int_as_float(__double2loint(rd)), __int_as_float(__double2hiint(rd)));
     }
@@ -583,7 +582,8 @@ __device__ __forceinline__ void neighbours_any(const SimParams& p, EnvLds& L, in
     // one wave owns the scene: the register formulation above, unless it declines (ties, band cases, odd rewards, K > 8, comm)
     const bool comm = EXT && p.col_comm >= 0 && out.obs != nullptr;
     if (nthreads == 64 && p.nbr_fast && !comm && !(COPO_PROFILE_SKIP & 128)) {
-        const bool ok = neighbours_fast(p, L, e, tid, out);
+        extern __shared__ unsigned int dyn[];
+        const bool ok = neighbours_fast(p, L, e, tid, out, reinterpret_cast<float4*>(dyn));
         if (p.dbg && tid == 0) p.dbg[(size_t)e * COPO_DBG_STRIDE + 7] = ok ? 1 : 2;      // profiling aid: which formulation ran
         if (ok) return;
     }
@@ -782,8 +782,12 @@ __device__ __forceinline__ float atan2_window(float v, float u) {
 // the per-ray minimum with LDS atomicMin on the float bit pattern (distances are >= 0, so unsigned order == float
 // order and the result does not depend on the task order).  Rays outside every window keep `range`, exactly what
 // the exhaustive test of the oracle gives them.
+// `phases`: 1 = initialise the ray minima, 2 = window / box-test work, 4 = write-out (+ detector beams); all of them (7) is the
+// whole phase.  The step kernel of the many-waves-per-scene shape runs them apart (wave roles): 2 on waves >= `wave_lo` only
+// while waves 0 / 1 write the state back and build the neighbour lists; 4 starts with a workgroup barrier.
+template <int PHASES = 7>
 __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, int tid, int nthreads,
-                                          float* __restrict__ obs) {
+                                          float* __restrict__ obs, int wave_lo = 0) {
     extern __shared__ unsigned int dyn[];
     const int N = p.N, O = p.O, NL = p.num_lasers;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nwaves = nthreads >> 6;
@@ -810,8 +814,10 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
     const float inv_nvec = 1.0f / (float)(nvec > 0 ? nvec : 1), inv_nsc = 1.0f / (float)(NL - 4 * nvec > 0 ? NL - 4 * nvec : 1);
     for (int ip0 = 0; ip0 < np; ip0 += CH) {
     const int cha = np - ip0 < CH ? np - ip0 : CH;
-    for (int q = tid; q < cha * NL; q += nthreads) best[q] = range_bits;
-    __syncthreads();
+    if (PHASES & 1) {
+        for (int q = tid; q < cha * NL; q += nthreads) best[q] = range_bits;
+        __syncthreads();
+    }
     const int ncombo = cha * ns;
     // everything per batch of 64 (fan, vehicle) pairs: window, numbering of the box tests, the tests themselves
     auto pair_batch = [&](const bool live, const int lp, const int i, const int j) {
@@ -881,7 +887,8 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
             }
         }
     };
-    if (nwaves == 1 && lidar_queue_words(p.chunk, N) > 0 && !(COPO_PROFILE_SKIP & 2)) {
+    if (!(PHASES & 2)) {
+    } else if (nwaves == 1 && lidar_queue_words(p.chunk, N) > 0 && !(COPO_PROFILE_SKIP & 2)) {
         // one wave owns the scene: a cheap pass keeps the pairs within LiDAR reach (about half of them at a junction) in a
         // queue, the window / test pass then runs on full batches of those -- the window arithmetic executes for a whole
         // batch as soon as one of its pairs is in reach
@@ -909,13 +916,14 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
             pair_batch(live, lp, L.plist[ip0 + lp], L.slist[c - lp * ns]);
         }
     } else {
-        for (int c0 = wave * 64; c0 < ((COPO_PROFILE_SKIP & 2) ? 0 : ncombo); c0 += nwaves * 64) {
+        for (int c0 = (wave - wave_lo) * 64; c0 < ((COPO_PROFILE_SKIP & 2) || wave < wave_lo ? 0 : ncombo); c0 += (nwaves - wave_lo) * 64) {
             const int c = c0 + lane;
             const bool live = c < ncombo;
             const int lp = live ? (int)(((float)c + 0.5f) * inv_ns) : 0;      // fan of this pass
             pair_batch(live, lp, L.plist[ip0 + lp], L.slist[live ? c - lp * ns : 0]);
         }
     }
+    if (!(PHASES & 4)) continue;
     __syncthreads();
     const int nrays = cha * NL;                   // rows of present slots only
     if (vec_out && !(COPO_PROFILE_SKIP & 4)) {
@@ -943,7 +951,7 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
     }
     // optional side / lane-line detector beams (Bottleneck, Tollgate): one thread per (present agent, beam)
     const int nb = p.side_lasers + p.lane_lasers;
-    if (nb > 0) {
+    if ((PHASES & 4) && nb > 0) {
         const float inv_nb = 1.0f / (float)nb;
         for (int q = tid; q < np * nb; q += nthreads) {
             const int ip = (int)(((float)q + 0.5f) * inv_nb), b = q - ip * nb;
@@ -1045,6 +1053,7 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
     const int N = p.N;
     const float hl = p.hl, hw = p.hw;
     load_rays(p, L, tid, nthreads);
+    float4* rec_roles = nullptr;
     {   // route tables: a few KB read on every step by the projection / navigation code -> LDS copy when they fit
         // (the waves that idle during P0 do the copy; the barrier after P0 publishes it)
         extern __shared__ unsigned int dyn[];
@@ -1054,6 +1063,8 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
         float* rl = reinterpret_cast<float*>(dyn + lidar_lds_words(p.chunk, p.nbr_chunk, p.N, p.num_lasers) + ray_lds_words(p.num_lasers) + (nthreads >> 6) * LIDAR_WAVE_WORDS);
         int32_t* tl = reinterpret_cast<int32_t*>(rl + nseg_f + nmeta_f);
         float* sl = reinterpret_cast<float*>(tl + ntab);
+        // (several waves per scene: 64 float4 records for neighbours_fast behind everything else -- the LiDAR minima are live then)
+        rec_roles = reinterpret_cast<float4*>(stage ? reinterpret_cast<float*>(((reinterpret_cast<uintptr_t>(sl + nsp) + 15) & ~(uintptr_t)15)) : rl);
         if (stage) {
             for (int q = tid; q < nseg_f; q += nthreads) rl[q] = p.route_segs[q];
             for (int q = tid; q < nmeta_f; q += nthreads) rl[nseg_f + q] = p.route_meta[q];
@@ -1223,6 +1234,15 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
     int32_t aid_row = -1;
     bool present = false;
     COPO_STAMP(2);
+    // Wave roles after P2 (8 / 16 waves per scene, i.e. few scenes per launch, where a launch is latency-bound): wave 0 writes the
+    // state back (P4), wave 1 builds the neighbour lists in registers (neighbours_fast), waves 2.. run the LiDAR windows / box tests;
+    // then everybody writes the LiDAR columns.  The ray minima are initialised here, by the waves that idle during P2.
+    const bool roles_ok = !ONE && nwaves >= 8 && p.nbr_fast && out.obs != nullptr && !(EXT && p.col_comm >= 0) && !(COPO_PROFILE_SKIP & 0x187);
+    if (roles_ok && wave != 0) {
+        extern __shared__ unsigned int dyn[];
+        const unsigned int range_bits = __float_as_uint(p.lidar_range);
+        for (int q = tid - 64; q < N * p.num_lasers; q += nthreads - 64) dyn[q] = range_bits;
+    }
     // ---- P2 (wave 0): route projection, termination, reward, respawn ------------------------------
     if (wave == 0) {
         bool term = false;
@@ -1375,8 +1395,17 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
     const bool ending = L.ending != 0;
 
     COPO_STAMP(3);
+    const bool roles = roles_ok && !ending;      // (a scene that resets this step: the neighbour lists need the poses BEFORE the reset, the LiDAR the ones after)
     // ---- P3 (all waves): neighbour lists + reward reductions on the post-step (pre-reset) scene ---
-    if (!(COPO_PROFILE_SKIP & 1)) neighbours_any<EXT>(p, L, e, tid, nthreads, out, act, L.m_acted, ending);
+    if (roles) {
+        if (wave == 1) {
+            const bool ok = neighbours_fast(p, L, e, lane, out, rec_roles);
+            if (lane == 0) L.nbr_ok = ok ? 1 : 0;
+            if (p.dbg && lane == 0) p.dbg[(size_t)e * COPO_DBG_STRIDE + 7] = ok ? 1 : 2;
+        } else if (wave >= 2) {
+            obs_phase<2>(p, L, e, tid, nthreads, out.obs, 2);
+        }
+    } else if (!(COPO_PROFILE_SKIP & 1)) neighbours_any<EXT>(p, L, e, tid, nthreads, out, act, L.m_acted, ending);
     else __syncthreads();
     COPO_STAMP(4);
     // (neighbours_phase ends with a workgroup barrier: the reset below may overwrite the poses it read)
@@ -1422,7 +1451,13 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
 
     COPO_STAMP(5);
     // ---- P5 (all threads): LiDAR + observation write-out -------------------------------------------
-    if (out.obs) obs_phase(p, L, e, tid, nthreads, out.obs);
+    if (roles) {
+        obs_phase<4>(p, L, e, tid, nthreads, out.obs);
+        if (!L.nbr_ok) {            // the register formulation declined (ties, band cases, odd rewards): the pair-parallel lists, on the
+            __syncthreads();        // work area that the ray minima no longer need
+            neighbours_phase<EXT>(p, L, e, tid, nthreads, out, act, L.m_acted, ending);
+        }
+    } else if (out.obs) obs_phase(p, L, e, tid, nthreads, out.obs);
     __syncthreads();
     COPO_STAMP(6);
 #undef COPO_STAMP
@@ -1462,7 +1497,8 @@ __global__ void __launch_bounds__(256) neighbours_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 // [slots][rays] minima, ray table, one 64-entry strip per wave (box-test owners)
 static size_t lidar_lds_bytes(const SimParams& p, int block) {
-    return (size_t)(lidar_lds_words(p.chunk, p.nbr_chunk, p.N, p.num_lasers) + ray_lds_words(p.num_lasers) + (block / 64) * LIDAR_WAVE_WORDS) * sizeof(unsigned int);
+    return (size_t)(lidar_lds_words(p.chunk, p.nbr_chunk, p.N, p.num_lasers) + ray_lds_words(p.num_lasers) + (block / 64) * LIDAR_WAVE_WORDS) * sizeof(unsigned int) +
+           (block > 64 ? 64 * sizeof(float4) + 16 : 0);       // (step kernel, wave roles: the records of neighbours_fast)
 }
 static bool sim_has_ext(const SimParams& p) { return p.col_tl >= 0 || p.col_comm >= 0; }
 static hipError_t sim_lds_attrs() {              // 64 slots x 256 rays + route tables exceed the default 64 KB

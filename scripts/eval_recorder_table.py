@@ -17,6 +17,7 @@ with open(os.path.join(ROOT, "tests", "golden", "reference_eval_stats.json")) as
     REF = json.load(f)
 episodes = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 ENV_OVER = json.loads(sys.argv[2]) if len(sys.argv) > 2 else {}
+FIXED_LCF = len(sys.argv) > 3 and sys.argv[3] == "fixed-lcf"      # evaluate_population.py:33 passes use_distributional_svo=False for copo_*: every agent gets the MEAN
 COLS = ("success_rate", "crash_rate", "out_rate", "episode_reward_mean", "episode_reward_min", "episode_reward_max",
         "episode_length_mean", "success_episode_length_mean", "velocity_step_mean_episode_mean", "velocity_step_mean_episode_max",
         "num_neighbours_mean_episode_mean", "num_neighbours_mean_episode_max", "num_agents_total", "num_agents_total_per_300_steps",
@@ -24,7 +25,10 @@ COLS = ("success_rate", "crash_rate", "out_rate", "episode_reward_mean", "episod
 for name, algo in (("copo_inter", "copo"), ("ippo_inter", "ippo")):
     pre = name + "/w/"
     w = {k[len(pre):]: G1[k] for k in G1.files if k.startswith(pre)}
-    df = evaluate_population_rows(algo, "inter", w, meta_svo_lookup_table.get(name), num_envs=64, num_agents=30, scene_episodes=episodes,
+    lcf = meta_svo_lookup_table.get(name)
+    if lcf is not None and FIXED_LCF:
+        lcf = (lcf[0], 1e-6)
+    df = evaluate_population_rows(algo, "inter", w, lcf, num_envs=64, num_agents=30, scene_episodes=episodes,
                                   seed=0, env_config=dict(ENV_OVER))
     m = df.mean(numeric_only=True)
     ref, per = REF[name], REF[name + "_per_population"]
