@@ -6,8 +6,8 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT; rm -rf /tmp/prof_bench
 cd $GRAFT_REPO_ROOT
-scripts/sim_traffic.sh 256 > /tmp/traffic.log 2>&1
-cp $OUT/sim_traffic_E256.json profiles/sim_traffic.json 2>/dev/null     # bench.py reads it (source hash checked)
+scripts/sim_traffic.sh > /tmp/traffic.log 2>&1
+cp $OUT/sim_traffic.json profiles/sim_traffic.json 2>/dev/null     # bench.py reads it (source hash checked)
 python bench.py --steps 10 --warmup 5 > /tmp/bench_plain.log 2>&1
 rocprofv3 --kernel-trace --stats -d /tmp/prof_bench -- python bench.py --steps 10 --warmup 5 --no-cpu-baseline > /tmp/bench_traced.log 2>&1
 DB=$(find /tmp/prof_bench -name "*_results.db" | head -1)
@@ -17,6 +17,6 @@ DB=$(find /tmp/prof_bench -name "*_results.db" | head -1)
   echo "# bench line (plain run, with cpu_baseline):"; grep '^{"metric"' /tmp/bench_plain.log | tail -1
   python scripts/top_kernels.py $DB 24
 } > $OUT/${TAG}_bench_kernel_stats.txt
-cp $OUT/sim_traffic_E256.json $OUT/${TAG}_sim_traffic.json 2>/dev/null
-rm -rf $OUT/sim_traffic_E256 $OUT/sim_traffic_E256.json
+cp $OUT/sim_traffic.json $OUT/${TAG}_sim_traffic.json 2>/dev/null
+rm -rf /tmp/prof_bench
 tail -30 $OUT/${TAG}_bench_kernel_stats.txt | cut -c1-200
