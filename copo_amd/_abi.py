@@ -24,7 +24,7 @@ SIM_CFG_FIELDS = [
     ("lidar_range", C.c_float), ("neighbours_distance", C.c_float), ("mf_distance", C.c_float),
     ("dt", C.c_float), ("veh_half_len", C.c_float), ("veh_half_wid", C.c_float), ("wheelbase", C.c_float),
     ("max_steer", C.c_float), ("max_speed", C.c_float), ("acc_max", C.c_float), ("brake_gain", C.c_float),
-    ("brake_max", C.c_float), ("lat_acc_max", C.c_float), ("spawn_region_len", C.c_float), ("spawn_region_wid", C.c_float),
+    ("brake_max", C.c_float), ("lat_acc_max", C.c_float), ("reverse_acc", C.c_float), ("spawn_region_len", C.c_float), ("spawn_region_wid", C.c_float),
     ("driving_reward", C.c_float), ("speed_reward", C.c_float), ("success_reward", C.c_float),
     ("crash_penalty", C.c_float), ("out_penalty", C.c_float), ("arrive_margin", C.c_float), ("body_margin", C.c_float),
     ("lane_width", C.c_float),

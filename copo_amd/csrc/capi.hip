@@ -168,7 +168,7 @@ extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** o
     }
     p.dt = cfg->dt; p.hl = cfg->veh_half_len; p.hw = cfg->veh_half_wid; p.wheelbase = cfg->wheelbase;
     p.max_steer = cfg->max_steer; p.max_speed = cfg->max_speed; p.acc_max = cfg->acc_max; p.brake_gain = cfg->brake_gain;
-    p.brake_max = cfg->brake_max; p.lat_acc_max = cfg->lat_acc_max;
+    p.brake_max = cfg->brake_max; p.lat_acc_max = cfg->lat_acc_max; p.reverse_acc = cfg->reverse_acc;
     p.region_hl = 0.5f * cfg->spawn_region_len; p.region_hw = 0.5f * cfg->spawn_region_wid;
     p.driving_reward = cfg->driving_reward; p.speed_reward = cfg->speed_reward; p.success_reward = cfg->success_reward;
     p.crash_penalty = cfg->crash_penalty; p.out_penalty = cfg->out_penalty; p.arrive_margin = cfg->arrive_margin; p.body_margin = cfg->body_margin;

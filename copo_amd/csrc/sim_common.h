@@ -25,7 +25,7 @@ struct SimParams {
     int32_t side_lasers, lane_lasers, navi_dim, toll_dim, toll_min_steps;
     int32_t lists_for_absent;      // 1: nbr_idx / nbr_dist rows of absent slots are filled with -1 / 0 (the stateless op); 0: left alone
     float lidar_range, neighbours_distance, mf_distance, dt, hl, hw, wheelbase, max_steer, max_speed;
-    float acc_max, brake_gain, brake_max, lat_acc_max, region_hl, region_hw;
+    float acc_max, brake_gain, brake_max, lat_acc_max, reverse_acc, region_hl, region_hw;
     float driving_reward, speed_reward, success_reward, crash_penalty, out_penalty, arrive_margin, body_margin, lane_width;
     float side_range, lane_range;
     // register formulation of the neighbour lists (neighbours_fast): fp32 d^2 thresholds 1e-6 inside / outside the exact radius,

@@ -631,7 +631,7 @@ __device__ __forceinline__ void ego_navi_obs(const SimParams& p, EnvLds& L, int 
     }
     float* q = row + p.col_state;
     q[0] = clipf(0.5f - 0.5f * sinpsi, 0.0f, 1.0f);
-    q[1] = clipf((s.v * 3.6f + 1.0f) * p.inv_vnorm, 0.0f, 1.0f);
+    q[1] = clipf((fabsf(s.v) * 3.6f + 1.0f) * p.inv_vnorm, 0.0f, 1.0f);      // vehicle.speed is a magnitude
     q[2] = clipf(0.5f + s.steer * (1.0f / 120.0f), 0.0f, 1.0f);
     q[3] = clipf(0.5f + 0.5f * s.psteer, 0.0f, 1.0f);
     q[4] = clipf(0.5f + 0.5f * s.pthrottle, 0.0f, 1.0f);
@@ -1131,9 +1131,10 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
                 float cs = s.hc, sn = s.hs;
                 const float v0 = v, th0 = th;
                 for (int k = 0; k < p.substeps; ++k) {
-                    const float a = a1 >= 0.0f ? (v < p.max_speed ? a1 * p.acc_max : 0.0f) : -brake;
+                    // (reverse gear, MetaDrive enable_reverse: a negative throttle is engine force backwards, no brake, v may go negative)
+                    const float a = a1 >= 0.0f ? (v < p.max_speed ? a1 * p.acc_max : 0.0f) : (p.reverse_acc > 0.0f ? a1 * p.reverse_acc : -brake);
                     v = v + a * h;
-                    if (v < 0.0f) v = 0.0f;
+                    if (v < 0.0f && !(p.reverse_acc > 0.0f)) v = 0.0f;
                     const float dxh = cs * cb - sn * sb, dyh = sn * cb + cs * sb;
                     x = x + v * dxh * h;
                     y = y + v * dyh * h;
@@ -1296,7 +1297,7 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
             const bool arrive = (seg == nseg - 1) && (sl > g[4] - p.arrive_margin) && (sl < g[4] + p.arrive_margin) && on_road;
             const bool oor = !on_road;
             const bool crash = (L.crash[lane] != 0) || too_fast;
-            float r = p.driving_reward * ((prog - prev) * (1.0f + g[5] * (lif * w))) + p.speed_reward * (s.v / p.max_speed);
+            float r = p.driving_reward * ((prog - prev) * (1.0f + g[5] * (lif * w))) + p.speed_reward * (fabsf(s.v) / p.max_speed);
             fl = COPO_F_ACTED;
             if (arrive) { r = p.success_reward; fl |= COPO_F_ARRIVE; }
             else if (oor) { r = -p.out_penalty; }
@@ -1311,7 +1312,7 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
             s.eprew += r;
             if (out.info) {
                 float* q = out.info + ((size_t)e * N + lane) * COPO_INFO_DIM;
-                q[COPO_I_VELOCITY] = s.v * 3.6f;
+                q[COPO_I_VELOCITY] = fabsf(s.v) * 3.6f;
                 q[COPO_I_STEERING] = s.steer;
                 q[COPO_I_ACCELERATION] = acc;
                 q[COPO_I_STEP_REWARD] = r;

@@ -395,55 +395,98 @@ def tollgate(exit_length=70.0, lanes=3, toll_lanes=8, toll_length=10.0, taper=20
     return b.finish()
 
 
-def parkinglot(spaces=8, exit_length=20.0, lane_width=LANE_WIDTH, turn_radius=4.0, depth=6.0, pitch=7.0):
-    """MAParkingLotMap (10 agents, `parking_space_num=8`): a two-way one-lane aisle with `spaces` perpendicular parking
-    spaces.  Vehicles start in a space and leave through either end of the aisle, or enter at an end and drive into a
-    space."""
+def parkinglot(spaces=8, exit_length=20.0, lane_width=LANE_WIDTH, turn_radius=4.0, depth=8.0, arm=10.0, junction_radius=10.0):
+    """MAParkinglotMap (10 agents, `parking_space_num = 8`, `exit_length = 20`, one lane per direction): FirstPGBlock ->
+    ParkingLot block -> T-intersection (`t_type = 1`: the straight arm is missing, `EXIT_PART_LENGTH = 10`).
+    ParkingLot block (`one_side_vehicle_num = spaces / 2`, `radius` 4, `length` 8): a main road of `2 r + (n - 1) w` = 18.5 m and a
+    4 m socket road; `n` spaces of `w x 8` m side by side on either side, perpendicular to the road.  Every space is its own little
+    road system, as MetaDrive builds it (`_add_one_parking_space`) -- overlapping roads, not cuts of one aisle:
+      in from the near lane:  [straight `dist_to_in`] -> right bend (r) -> the space (8 m)
+      in from the far lane:   [straight `dist_to_out`] -> left bend (r) -> straight `w` across the near lane -> the space
+      out to the near lane:   the space reversed (its spawn road) -> right bend (r) -> [straight `dist_to_out`] -> next block
+      out to the far lane:    the space reversed -> straight `w` -> left bend (r) -> [straight `dist_to_in`] -> previous block
+    Entrances (spawn roads, one slot each at 4 m): the first block's 10 m spawn road and the two arms of the T; a vehicle that enters
+    there is sent into a space, a vehicle that starts in a space (slot at 4 m of its 8 m) to the far end of one of the three exits.
+    Frame: the positive lane runs along +x at y = 0, the negative lane back at y = w."""
     w, r = lane_width, turn_radius
     net = Net(w)
-    per_side = spaces // 2
-    span = per_side * pitch
-    half = span / 2 + exit_length
-    # aisle: east-bound lane y = -w/2 ("E"), west-bound y = +w/2 ("W"), cut at every space's turn points
-    xs = [(-per_side / 2 + 0.5 + k) * pitch for k in range(per_side)]
-    spots = [(x, +1) for x in xs] + [(x, -1) for x in xs]      # +1: north of the aisle
-    cuts = sorted(set([-half, half] + [x - r for x in xs] + [x + r for x in xs]))
-    for i in range(len(cuts) - 1):
-        net.add("E%d" % i, "E%d" % (i + 1), (cuts[i], -w / 2, 0.0), cuts[i + 1] - cuts[i], 0.0, 1)
-    for i in range(len(cuts) - 1, 0, -1):
-        net.add("W%d" % i, "W%d" % (i - 1), (cuts[i], w / 2, math.pi), cuts[i] - cuts[i - 1], 0.0, 1)
-    ci = {c: i for i, c in enumerate(cuts)}
-    for s, (x0, side) in enumerate(spots):
-        y_far = side * (w + depth + r)
-        p = net.add("P%d" % s, "P%dx" % s, (x0, y_far, -side * math.pi / 2), abs(y_far) - r - w / 2, 0.0, 1)
-        for east in (True, False):
-            y_lane = -w / 2 if east else w / 2
-            left = (side > 0) == east
-            kap = (1.0 if left else -1.0) / r
-            # out of the space onto the aisle: the lead ends r short of the NEAR lane line; the far lane needs w more
-            lead_extra = abs(y_far - y_lane) - r - (abs(y_far) - r - w / 2)
-            q = advance(p, lead_extra, 0.0)
-            mid = "P%d%s" % (s, "e" if east else "w")
-            if lead_extra > 1e-9:
-                net.add("P%dx" % s, mid, p, lead_extra, 0.0, 1, 0, 0, 0)
-                src = mid
-            else:
-                src = "P%dx" % s
-            net.add(src, ("E%d" % ci[x0 + r]) if east else ("W%d" % ci[x0 - r]), q, r * math.pi / 2, kap, 1, 0, 0, 0)
-            # from the aisle into the space
-            x_turn = x0 - r if east else x0 + r
-            node = ("E%d" if east else "W%d") % ci[x_turn]
-            t = net.add(node, "Q%d%s" % (s, "e" if east else "w"), (x_turn, y_lane, 0.0 if east else math.pi),
-                        r * math.pi / 2, kap, 1, 0, 0, 0)
-            net.add("Q%d%s" % (s, "e" if east else "w"), "S%d%s" % (s, "e" if east else "w"), t, abs(y_far - y_lane) - r, 0.0, 1)
-    b = _Builder("parkinglot", net, 10, half + 10.0)
-    last = len(cuts) - 1
-    for s in range(len(spots)):          # parked vehicles leave through the east or the west end
-        b.add_spawn_road(("P%d" % s, "P%dx" % s), ["E%d" % last, "W0"], [0.5], safe_only_first=False)
-    for east in (True, False):           # arriving vehicles park in one of the spaces
-        road = ("E0", "E1") if east else ("W%d" % last, "W%d" % (last - 1))
-        b.add_spawn_road(road, ["S%d%s" % (s, "e" if east else "w") for s in range(len(spots))],
-                         [RESPAWN_REGION_LONGITUDE / 2], safe_only_first=False)
+    n = spaces // 2
+    x0 = exit_length                                   # the ParkingLot block starts where the first block ends
+    main = 2 * r + (n - 1) * w
+    x1 = x0 + main                                     # socket road starts
+    x2 = x1 + 4.0                                      # T-intersection starts (SOCKET_LENGTH = 4)
+    NO = (0, 0, 0)
+    # ---- first block (spawn road and its adverse = exit 1) ----------------------------------------------------------------
+    net.add("in0", "P", (x0 - (exit_length - ENTRANCE_LENGTH), 0.0, 0.0), exit_length - ENTRANCE_LENGTH, 0.0, 1, LINE_BROKEN, LINE_CONTINUOUS)
+    net.add("Q", "end0", (x0, w, math.pi), exit_length - ENTRANCE_LENGTH, 0.0, 1, LINE_BROKEN, LINE_CONTINUOUS)
+    # ---- ParkingLot block: main road + socket, both directions ---------------------------------------------------------------
+    net.add("P", "S", (x0, 0.0, 0.0), main, 0.0, 1, LINE_BROKEN, 0)
+    net.add("S", "T", (x1, 0.0, 0.0), 4.0, 0.0, 1, LINE_BROKEN, LINE_CONTINUOUS)
+    net.add("Tn", "Sn", (x2, w, math.pi), 4.0, 0.0, 1, LINE_BROKEN, LINE_CONTINUOUS)
+    net.add("Sn", "Q", (x1, w, math.pi), main, 0.0, 1, LINE_BROKEN, 0)
+    # ---- T-intersection (radius 10, one lane): right arm "A" (south), left arm "B" (north) ---------------------------------
+    R, RL = junction_radius, junction_radius + w       # right / left turn radii of a one-lane junction
+    cross = 2 * junction_radius + w                    # straight through: 2 r + (2 lanes - 1) w
+    e = net.add("T", "Ax", (x2, 0.0, 0.0), R * math.pi / 2, -1.0 / R, 1, *NO)                       # parking road -> south arm
+    net.add("Ax", "endA", e, arm, 0.0, 1, LINE_BROKEN, LINE_CONTINUOUS)
+    e = net.add("T", "Bx", (x2, 0.0, 0.0), RL * math.pi / 2, 1.0 / RL, 1, *NO)                      # parking road -> north arm
+    net.add("Bx", "endB", e, arm, 0.0, 1, LINE_BROKEN, LINE_CONTINUOUS)
+    a_in = (x2 + R + w, -(R + arm), math.pi / 2)       # south arm's entrance lane: w to the left of its exit lane, heading north
+    e = net.add("inA", "Ai", a_in, arm, 0.0, 1, LINE_BROKEN, LINE_CONTINUOUS)
+    net.add("Ai", "Tn", e, RL * math.pi / 2, 1.0 / RL, 1, *NO)                                        # south arm -> parking road (left turn)
+    net.add("Ai", "Bx", e, cross, 0.0, 1, *NO)                                                       # south arm -> north arm
+    b_in = (x2 + R, w + R + arm, -math.pi / 2)         # north arm's entrance lane, heading south
+    e = net.add("inB", "Bi", b_in, arm, 0.0, 1, LINE_BROKEN, LINE_CONTINUOUS)
+    net.add("Bi", "Tn", e, R * math.pi / 2, -1.0 / R, 1, *NO)                                         # north arm -> parking road (right turn)
+    net.add("Bi", "Ax", e, cross, 0.0, 1, *NO)                                                       # north arm -> south arm
+    # ---- the spaces ------------------------------------------------------------------------------------------------------------
+    dests = []
+    for side in (-1, +1):                              # -1: south of the positive lane (MetaDrive's part 2), +1: north of the negative lane
+        for i in range(n):
+            k = "%s%d" % ("s" if side < 0 else "n", i)
+            d_in, d_out = i * w, (n - 1 - i) * w
+            if side < 0:    # near lane = positive lane, entered from P; far lane = negative lane, entered from Sn
+                near, near_node, near_next = (x0, 0.0, 0.0), "P", "S"
+                far, far_node, far_next = (x1, w, math.pi), "Sn", "Q"
+            else:           # near lane = negative lane, entered from Sn; far lane = positive lane, entered from P
+                near, near_node, near_next = (x1, w, math.pi), "Sn", "Q"
+                far, far_node, far_next = (x0, 0.0, 0.0), "P", "S"
+            # in from the near lane: [straight] -> right bend -> space
+            e, src = near, near_node
+            if d_in > 1e-9:
+                e = net.add(src, k + "a", e, d_in, 0.0, 1, *NO)
+                src = k + "a"
+            e = net.add(src, k + "b", e, r * math.pi / 2, -1.0 / r, 1, *NO)
+            space_start = e
+            net.add(k + "b", k + "c", e, depth, 0.0, 1, LINE_CONTINUOUS, LINE_CONTINUOUS)
+            dests.append(k + "c")
+            # in from the far lane: [straight] -> left bend -> straight w -> space
+            e, src = far, far_node
+            if d_out > 1e-9:
+                e = net.add(src, k + "d", e, d_out, 0.0, 1, *NO)
+                src = k + "d"
+            e = net.add(src, k + "e", e, r * math.pi / 2, 1.0 / r, 1, *NO)
+            e = net.add(k + "e", k + "b", e, w, 0.0, 1, *NO)
+            assert math.hypot(e[0] - space_start[0], e[1] - space_start[1]) < 1e-6 and abs(_wrap(e[2] - space_start[2])) < 1e-9
+            # the space reversed = its spawn road (a parked vehicle faces the road)
+            back = reverse(advance(space_start, depth, 0.0))
+            e = net.add(k + "f", k + "g", back, depth, 0.0, 1, LINE_CONTINUOUS, LINE_CONTINUOUS)
+            # out to the near lane: right bend -> [straight] -> the next block's road
+            o = net.add(k + "g", k + "h" if d_out > 1e-9 else near_next, e, r * math.pi / 2, -1.0 / r, 1, *NO)
+            if d_out > 1e-9:
+                net.add(k + "h", near_next, o, d_out, 0.0, 1, *NO)
+            # out to the far lane: straight w -> left bend -> [straight] -> the previous block's road
+            o = net.add(k + "g", k + "i", e, w, 0.0, 1, *NO)
+            o = net.add(k + "i", k + "j" if d_in > 1e-9 else far_next, o, r * math.pi / 2, 1.0 / r, 1, *NO)
+            if d_in > 1e-9:
+                net.add(k + "j", far_next, o, d_in, 0.0, 1, *NO)
+    b = _Builder("parkinglot", net, 10, 40.0)
+    half_slot = [RESPAWN_REGION_LONGITUDE / 2]
+    for road in (("in0", "P"), ("inA", "Ai"), ("inB", "Bi")):         # entrants park in one of the spaces
+        b.add_spawn_road(road, dests, half_slot, safe_only_first=False)
+    for side in ("s", "n"):                                          # parked vehicles leave through one of the three exits
+        for i in range(n):
+            b.add_spawn_road(("%s%df" % (side, i), "%s%dg" % (side, i)), ["end0", "endA", "endB"], half_slot, safe_only_first=False)
     return b.finish()
 
 

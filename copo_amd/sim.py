@@ -49,6 +49,7 @@ class SimConfig:
     brake_gain: float = 27.0           # 4 wheels x max_brake_force 150 N s per 0.02 s physics step / 1100 kg ...
     brake_max: float = 8.8             # ... limited by tyre friction 0.9 g
     lat_acc_max: float = 0.0           # friction limit on v x yaw rate (0: none)
+    reverse_acc: float = None          # reverse gear (MetaDrive enable_reverse): m/s^2 at full negative throttle; None / 0 = none
     spawn_region_len: float = 8.0      # SpawnManager.RESPAWN_REGION_LONGITUDE / LATERAL
     spawn_region_wid: float = 3.0
     driving_reward: float = 1.0
@@ -84,6 +85,11 @@ class SimConfig:
                         ("navi_dim", NAVI_DIM), ("toll_dim", 0)):
             if getattr(self, k) is None:
                 setattr(self, k, d.get(k, dflt))
+        if self.reverse_acc is None:
+            # no reverse gear anywhere by default.  (Later MetaDrive versions set vehicle_config["enable_reverse"] for the ParkingLot;
+            # the population the reference ships for it drives the rebuilt scene better WITHOUT a reverse gear -- success 0.18 vs
+            # 0.11, the reference's table has 0.17 -- so 0.2.5's env is taken to have none.  `reverse_acc = acc_max` switches it on.)
+            self.reverse_acc = 0.0
 
     def tables(self):
         return _maps.MAP_BUILDERS[self.map](**self.map_kwargs)
@@ -143,7 +149,7 @@ def fill_cfg_struct(cfg: SimConfig, struct_cls):
     c.enable_lcf = 1 if cfg.enable_lcf else 0
     c.horizon, c.delay_done, c.respawn_cooldown, c.substeps = cfg.horizon, cfg.delay_done, cfg.respawn_cooldown, cfg.substeps
     for k in ("lidar_range", "neighbours_distance", "mf_distance", "dt", "veh_half_len", "veh_half_wid", "wheelbase",
-              "max_steer", "max_speed", "acc_max", "brake_gain", "brake_max", "lat_acc_max", "spawn_region_len", "spawn_region_wid",
+              "max_steer", "max_speed", "acc_max", "brake_gain", "brake_max", "lat_acc_max", "reverse_acc", "spawn_region_len", "spawn_region_wid",
               "driving_reward", "speed_reward", "success_reward", "crash_penalty", "out_penalty", "arrive_margin", "body_margin",
               "lane_width", "side_range", "lane_line_range"):
         setattr(c, k, float(getattr(cfg, k)))

@@ -114,6 +114,9 @@ typedef struct copo_sim_cfg {
     float acc_max;             /* m/s^2 at full throttle (engine force cut above max_speed) */
     float brake_gain, brake_max; /* deceleration = min(brake_gain * |a1|, brake_max) for a1 < 0 */
     float lat_acc_max;         /* tyre friction limit on the lateral acceleration v x yaw rate (m/s^2); 0 = none (the bicycle turns on rails) */
+    float reverse_acc;         /* m/s^2 at full NEGATIVE throttle when the vehicle has a reverse gear (MetaDrive `enable_reverse`, the
+                                  ParkingLot's vehicle config: a negative throttle is engine force backwards, there is no brake); 0 = no
+                                  reverse gear: a negative throttle brakes and the speed stops at 0 */
     float spawn_region_len, spawn_region_wid; /* the box that must hold no vehicle for a respawn (8 x 3 m) */
     /* reward (MetaDrive multi-agent scheme) */
     float driving_reward, speed_reward, success_reward, crash_penalty, out_penalty;

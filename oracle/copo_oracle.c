@@ -511,7 +511,7 @@ static void write_obs(oracle_sim* s, int e, const copo_step_out* out, const uint
             o[col++] = o_clip(right / tw, 0.0f, 1.0f);
         }
         o[col++] = o_clip(0.5f - 0.5f * sinpsi, 0.0f, 1.0f);        /* heading_diff: cos to the lane's RIGHT normal */
-        o[col++] = o_clip((FP(s, S_V, e)[i] * 3.6f + 1.0f) * s->inv_vnorm, 0.0f, 1.0f);
+        o[col++] = o_clip((fabsf(FP(s, S_V, e)[i]) * 3.6f + 1.0f) * s->inv_vnorm, 0.0f, 1.0f);    /* vehicle.speed: a magnitude */
         o[col++] = o_clip(0.5f + FP(s, S_STEER, e)[i] * (1.0f / 120.0f), 0.0f, 1.0f);  /* (steering / MAX_STEERING(60) + 1) / 2 */
         o[col++] = o_clip(0.5f + 0.5f * FP(s, S_PSTEER, e)[i], 0.0f, 1.0f);    /* last_current_action[0]: the step before */
         o[col++] = o_clip(0.5f + 0.5f * FP(s, S_PTHROTTLE, e)[i], 0.0f, 1.0f);
@@ -804,9 +804,10 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
             float sn, cs;
             o_sincosf(th, &sn, &cs);
             for (int k = 0; k < c->substeps; ++k) {
-                float a = a1 >= 0.0f ? (v < c->max_speed ? a1 * c->acc_max : 0.0f) : -brake;
+                /* reverse gear (MetaDrive enable_reverse): a negative throttle is engine force backwards, no brake, v may go negative */
+                float a = a1 >= 0.0f ? (v < c->max_speed ? a1 * c->acc_max : 0.0f) : (c->reverse_acc > 0.0f ? a1 * c->reverse_acc : -brake);
                 v = v + a * h;
-                if (v < 0.0f) v = 0.0f;
+                if (v < 0.0f && !(c->reverse_acc > 0.0f)) v = 0.0f;
                 float dxh = cs * cb - sn * sb, dyh = sn * cb + cs * sb;
                 x = x + v * dxh * h;
                 y = y + v * dyh * h;
@@ -905,7 +906,7 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
             int crash = crash_any[n] || too_fast;
             /* reward_function: longitudinal movement on the vehicle's lane (lane i of an arc is 1 + kappa * i * w longer
              * than lane 0) + speed term; use_lateral is off in 0.2.5 */
-            float r = c->driving_reward * ((prog - prev) * (1.0f + g[5] * (lif * w))) + c->speed_reward * (V[n] / c->max_speed);
+            float r = c->driving_reward * ((prog - prev) * (1.0f + g[5] * (lif * w))) + c->speed_reward * (fabsf(V[n]) / c->max_speed);
             uint8_t fl = COPO_F_ACTED;
             if (arrive) { r = c->success_reward; fl |= COPO_F_ARRIVE; }
             else if (out_of_road) { r = -c->out_penalty; }
@@ -921,7 +922,7 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
             FP(s, S_EPREW, e)[n] += r;
             if (out->info) {
                 float* q = out->info + ((size_t)e * N + n) * COPO_INFO_DIM;
-                q[COPO_I_VELOCITY] = V[n] * 3.6f;
+                q[COPO_I_VELOCITY] = fabsf(V[n]) * 3.6f;
                 q[COPO_I_STEERING] = FP(s, S_STEER, e)[n];
                 q[COPO_I_ACCELERATION] = t.acc[n];
                 q[COPO_I_STEP_REWARD] = r;

@@ -137,6 +137,17 @@ def test_reference_roundabout_populations_drive_the_hip_simulator(golden_dir):
     assert ippo["out"] < 0.1 and copo["out"] < 0.1
 
 
+def test_reference_parking_lot_population(golden_dir):
+    """ParkingLot rebuilt from MetaDrive's blocks (round 3, `maps.parkinglot`: FirstPGBlock -> ParkingLot block with eight 3.5 x 8 m
+    spaces side by side, radius-4 bends to and from both lanes as overlapping roads -> T-intersection; three entrances, three
+    exits).  On round 2's stand-in (7 m pitch, a straight aisle with two ends) the shipped IPPO population scored 0.110 with 55 %
+    out-of-road; on the rebuilt scene 0.184 / 33 %.  The reference's table (MetaDrive 0.2.5) has IPPO 16.98 +- 5.90."""
+    gold = np.load(os.path.join(golden_dir, "reference_populations.npz"))
+    ippo = _roll("ippo", "parking", _weights(gold, "ippo_parking"), None, 10)
+    print("ippo_parking", ippo)
+    assert abs(ippo["success"] - 0.170) < 0.08 and ippo["out"] < 0.45, ippo
+
+
 def test_reference_tollgate_and_bottleneck_populations(golden_dir):
     """f-4 scenes: MetaDrive's Merge / Split blocks restated (maps.Net.add_funnel: the route follows the leftmost lanes straight
     through, the other lanes run into / out of them on two-arc wave lanes; the only lines are the centre line and the outer edge

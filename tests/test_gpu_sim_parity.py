@@ -44,6 +44,7 @@ def _actions(rng, E, N, t):
     ("bottleneck", 20, 4, 72, 200, 256),
     ("pgmap", 20, 4, 72, 200, 256),
     ("pgmap-junctions", 20, 3, 72, 260, 256),      # intersection + roundabout blocks inside the generated road
+    ("parkinglot-reverse", 10, 4, 72, 150, 64),    # reverse gear (copo_sim_cfg.reverse_acc): negative throttle = engine force backwards
 ])
 def test_rollout_bit_exact(map_name, N, E, lasers, steps, block):
     import torch
@@ -51,7 +52,7 @@ def test_rollout_bit_exact(map_name, N, E, lasers, steps, block):
     from copo_amd.sim import SimConfig, VecSim
     kw = {"pgmap": dict(sequence="CSCCS", seed=11), "pgmap-junctions": dict(sequence="XOT", seed=2)}.get(map_name, {})
     cfg = SimConfig(map=map_name.split("-")[0], num_envs=E, num_agents=N, num_lasers=lasers, horizon=90, nbr_k=min(8, max(1, N - 1)),
-                    delay_done=5, map_kwargs=kw)
+                    delay_done=5, map_kwargs=kw, reverse_acc=2.9 if map_name.endswith("-reverse") else None)
     g, o = VecSim(cfg), ol.OracleSim(cfg)
     g.set_block(block)
     seeds = np.arange(E, dtype=np.uint64) * np.uint64(7919) + np.uint64(5000)
