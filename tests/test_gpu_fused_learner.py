@@ -200,6 +200,57 @@ def bf16_round(x):
     return x.to(torch.bfloat16).to(torch.float32)
 
 
+@pytest.mark.parametrize("name,fuse,odim", [("ccppo", "mf", 156), ("ippo", "none", 91)])
+def test_fused_bf16_forward_equals_a_bfloat16_rounded_fp32_oracle(name, fuse, odim):
+    """The bfloat16-operand mode against an ORACLE instead of torch.autocast: the same network evaluated in float64 on the host
+    with a round-to-nearest-even bfloat16 rounding at exactly the points the kernels round (learn_rowpass.inc:527-581: inputs,
+    weights and biases at use, the linear output, the tanh output, the head output).  Products of two bfloat16 values are exact in
+    fp32 and the fp32 / fp64 accumulation orders differ by ~1e-7, far below the bfloat16 spacing of 4e-3, so the kernel must return
+    the SAME bfloat16 values except where a sum lands within that 1e-7 of a rounding boundary (or the kernel's 1.8e-7 tanh does):
+    >= 99 % of the outputs bit-equal (measured: 99.9 %), the others within a rounding flip of one hidden unit or of the output.
+    Policy head (rollout kernel, distribution inputs) and critic head (value kernel)."""
+    R = 1500
+    pol = _make(name, fuse, odim, fused=True, policy_dtype="bfloat16")
+    assert pol.fused is not None and pol.fused.cfg.operand_dtype == 1
+    with torch.no_grad():
+        for p in pol.model.parameters():
+            if p.dtype == torch.float32:
+                p.add_(torch.randn_like(p) * 0.05)
+    pol.fused.invalidate_mirror()
+    pol.fused.sync_mirror()
+    batch = _dense_batch(pol, R, odim)
+    obs = batch[SampleBatch.OBS].contiguous()
+
+    def bf(x):
+        return x.to(torch.float32).to(torch.bfloat16).to(torch.float64)
+
+    def oracle(x, trunk, head):
+        h = bf(x.double().cpu())
+        for lin in [m for m in trunk.modules() if isinstance(m, torch.nn.Linear)]:
+            h = bf(torch.tanh(bf(h @ bf(lin.weight.detach().cpu()).T + bf(lin.bias.detach().cpu()))))
+        lin = [m for m in head.modules() if isinstance(m, torch.nn.Linear)][0]
+        return bf(h @ bf(lin.weight.detach().cpu()).T + bf(lin.bias.detach().cpu())).float()
+
+    def check(got, want, what):
+        got, want = got.float().cpu(), want.float()
+        same = float((got == want).float().mean())
+        # where they differ: one hidden unit rounded the other way (a bfloat16 step of a tanh output, <= 2^-8, times its weight) or
+        # the output itself did (|out| * 2^-7): a few 1e-3 at most
+        worst = float(((got - want).abs() / (4e-3 + want.abs() * 2.0 ** -7)).max())
+        assert same >= 0.99 and worst <= 2.0, (what, same, worst)
+
+    eps = torch.zeros(R, 2, device="cuda")
+    act, logp, di = torch.empty(R, 2, device="cuda"), torch.empty(R, device="cuda"), torch.empty(R, 4, device="cuda")
+    pol.fused.act(obs, eps, act, logp, di)
+    torch.cuda.synchronize()
+    check(di, oracle(obs, pol.model._hidden_layers, pol.model._logits), "policy head")
+    cdim = pol.model.value_input_dim()
+    cc = obs if cdim == odim else batch["centralized_critic_obs"].contiguous()
+    v = pol.fused.values(obs, None if cc is obs else cc)
+    torch.cuda.synchronize()
+    check(v.reshape(-1), oracle(cc, pol.model._value_branch_separate, pol.model._value_branch).reshape(-1), "critic head")
+
+
 def test_fused_meta_update_matches_autograd():
     """Grouped META pass + fp64 LCF kernels == CoPOPolicy.meta_update's autograd path (algo_copo.py:228-309):
     both policy gradients, the LCF loss terms, grad_value, and the LCF parameters after real Adam steps."""
