@@ -394,6 +394,64 @@ def test_truncated_trajectories_bootstrap_from_the_next_observation(algo):
     a.stop()
 
 
+def test_lookahead_bootstrap_with_several_fragments_per_rollout():
+    """A centralised critic with `rollout_fragment_length` < rollout length (the reference's CCPPO `_test` config: T = 25,
+    fragments of 20): the GAE scan is cut per fragment; a piece that runs into the end of an EARLIER fragment is bootstrapped
+    from the value of its own last row (the reference's shortcut, algo_ccppo.py:362-365), only the pieces that run into the end
+    of the LAST fragment get the look-ahead row's value (round-2 advisor finding: the correction reached back into the earlier
+    fragments)."""
+    from copo_amd.torch_copo import algo_ccppo
+    from copo_amd.torch_copo.utils import env_wrappers as W
+    a = algo_ccppo.CCPPOTrainer(config=dict(env=algo_ccppo.get_ccppo_env(W.MultiAgentIntersectionEnv), env_config=dict(num_agents=12, horizon=80),
+                                            num_envs=4, train_batch_size=4 * 25, rollout_fragment_length=20, fuse_mode="mf", seed=2))
+    pol = a.policy
+    assert pol.wants_lookahead() and a.sampler.T == 25
+    for _ in range(3):
+        batch = a._lookahead_batch(a.sampler.sample())
+    b = pol.postprocess_trajectory(batch)
+    T, E, N = b[SampleBatch.FLAGS].shape
+    assert T == 25
+    M, H, frag = E * N, pol.gae_heads(), 20
+    vals, adv, tgt = (b[k].reshape(H, T, M).cpu().numpy().astype(np.float64) for k in ("_vals", "_adv", "_tgt"))
+    rew = b["rew3"][:H].reshape(H, T, M).cpu().numpy().astype(np.float64)
+    fl = b[SampleBatch.FLAGS].reshape(T, M).cpu().numpy()
+    v_next = b["_v_next"].cpu().numpy().astype(np.float64)
+    lam, gammas = float(pol.config["lambda"]), pol.gae_gammas()
+    pieces = {"done": 0, "cut_inner": 0, "cut_last": 0}
+    for m in range(M):
+        for lo, hi in ((0, frag), (frag, T)):
+            t = lo
+            while t < hi:
+                if not fl[t, m] & 1:
+                    t += 1
+                    continue
+                t0 = t
+                while t < hi and (fl[t, m] & 1) and not (fl[t, m] & 2):
+                    t += 1
+                done = t < hi and bool(fl[t, m] & 2)
+                t1 = t if done else t - 1
+                t = t1 + 1
+                for h in range(H):
+                    g = gammas[h]
+                    if done:
+                        last, kind = 0.0, "done"
+                    elif hi == T:
+                        last, kind = v_next[h, m], "cut_last"
+                    else:
+                        last, kind = vals[h, t1, m], "cut_inner"          # V(last row of the piece): the reference's shortcut
+                    v = np.concatenate([vals[h, t0:t1 + 1, m], [last]])
+                    delta = rew[h, t0:t1 + 1, m] + g * v[1:] - v[:-1]
+                    want, acc = np.zeros_like(delta), 0.0
+                    for k in range(len(delta) - 1, -1, -1):
+                        acc = delta[k] + g * lam * acc
+                        want[k] = acc
+                    np.testing.assert_allclose(adv[h, t0:t1 + 1, m], want, rtol=2e-4, atol=2e-4, err_msg=kind)
+                    np.testing.assert_allclose(tgt[h, t0:t1 + 1, m], want + vals[h, t0:t1 + 1, m], rtol=2e-4, atol=2e-4, err_msg=kind)
+                pieces[kind] += 1
+    assert pieces["cut_inner"] > 10 and pieces["cut_last"] > 10, pieces
+    a.stop()
+
+
 @pytest.mark.parametrize("peer", ["0", "1"])
 def test_two_ranks_fused_data_parallel_on_one_gpu(peer):
     """peer = "1": the gradient sums go through the peer all-reduce (COPO_PEER_ALLREDUCE, hipIpc-mapped workspaces, captured
