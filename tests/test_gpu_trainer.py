@@ -470,13 +470,19 @@ import torch.distributed as td
 from copo_amd.torch_copo.algo_copo import CoPOTrainer
 from copo_amd.torch_copo.utils.env_wrappers import MultiAgentIntersectionEnv, get_lcf_env, get_rllib_compatible_env
 env = get_rllib_compatible_env(get_lcf_env(MultiAgentIntersectionEnv))
-a = CoPOTrainer(config=dict(env=env, env_config=dict(num_agents=12), num_envs=8 + 4 * rank, train_batch_size=(8 + 4 * rank) * 8,
+a = CoPOTrainer(config=dict(env=env, env_config=dict(num_agents=12, horizon=60), num_envs=8 + 4 * rank, train_batch_size=(8 + 4 * rank) * 8,
                             sgd_minibatch_size=128, num_sgd_iter=2, lcf_num_iters=2, seed=3, meta_batch_size=4,
                             model={"fcnet_hiddens": [64, 64]}))
 assert a.policy.fused is not None and D.is_dist() and world == 2
 for _ in range(3):
     res = a.train()
 assert (a.policy._peer is not None) == (os.environ.get("COPO_PEER_ALLREDUCE") == "1")
+# whole-episode evaluation: the ranks' scenes finish their episode after different fragment counts, the loop holds collectives --
+# the stop decision must be the same on both ranks (round-2 advisor finding: a rank-local stop rule hangs here)
+ev = a.evaluate(scene_episodes=1)
+evs = [None, None]
+td.all_gather_object(evs, (ev["num_terminated_agents"], ev["env_steps"] // a.sampler.E))
+assert evs[0][0] == evs[1][0] > 0 and evs[0][1] == evs[1][1], evs          # global totals, same number of fragments on both ranks
 flat = a.policy.fused.flat.flat
 sig = torch.stack([flat.double().sum(), flat.double().abs().sum(), a.policy.model.lcf_parameters[0].double(),
                    a.policy.model.lcf_parameters[1].double(), torch.tensor(float(a.policy.num_grad_updates), dtype=torch.float64, device="cuda")])
