@@ -137,12 +137,21 @@ def main():
     ap.add_argument("--num-envs", type=int, default=64)
     ap.add_argument("--num-agents", type=int, default=40)
     ap.add_argument("--episodes", type=int, default=2000)
+    ap.add_argument("--table", default=None, metavar="CSV",
+                    help="write the reference's per-episode evaluation table (RecorderEnv columns, one row per whole scene episode) "
+                         "instead of the headline rates")
+    ap.add_argument("--scene-episodes", type=int, default=1)
     a = ap.parse_args()
     w = None
     if a.npz:
         with np.load(a.npz) as f:
             w = {k: f[k] for k in f.files}
     algo = "ippo" if a.algo == "cl" else a.algo
+    if a.table:
+        df = evaluate_population_rows(algo, a.env, w, a.lcf, a.num_envs, a.num_agents, scene_episodes=a.scene_episodes)
+        df.to_csv(a.table)
+        print(df.mean(numeric_only=True).to_string())
+        return
     print(json.dumps(evaluate_population(algo, a.env, w, a.lcf, a.num_envs, a.num_agents, a.episodes), indent=1))
 
 

@@ -43,6 +43,7 @@ class VecRecorder:
                         cmax=inf(-1), lsum=z(), slsum=z())
         self._init = {k: v.clone() for k, v in self.acc.items()}
         self.rows = []
+        self.cost_acc = None      # [E, N] per-agent sum of info["cost"] over its steps (recoder.py:264-274), sized on first use
 
     def _flush(self, mask):
         """Finish the episode of the scenes in `mask` [E] bool: emit their rows, re-arm their accumulators."""
@@ -96,14 +97,16 @@ class VecRecorder:
             A["nsteps"] += has_n.to(f64)
             A["nsum"] += torch.where(has_n, nn_, torch.zeros_like(nn_))
             A["nmax"] = torch.where(has_n, torch.maximum(A["nmax"], nn_), A["nmax"])
+            if self.cost_acc is None:
+                self.cost_acc = torch.zeros(f.shape, dtype=f64, device=self.device)
+            self.cost_acc += info[t, :, :, I_COST].to(f64) * acted
             done = acted & ((f & F_DONE) > 0) & k[:, None]
+            all_done = acted & ((f & F_DONE) > 0)
             if bool(done.any()):
                 d64 = done.to(f64)
                 succ = done & ((f & F_ARRIVE) > 0)
                 er, el = info[t, :, :, I_EPISODE_REWARD].to(f64), info[t, :, :, I_EPISODE_LENGTH].to(f64)
-                # the reference's cost column: 1 per crash step; an agent terminates on its first crash, so its episode cost is
-                # its terminal crash flag (MetaDrive's multi-agent default out_of_road_cost = 0)
-                ec = ((f & F_CRASH) > 0).to(f64)
+                ec = self.cost_acc          # the agent's cost summed over its steps
                 big = torch.full_like(er, float("inf"))
                 A["agents"] += d64.sum(-1)
                 A["succ"] += succ.to(f64).sum(-1)
@@ -117,6 +120,7 @@ class VecRecorder:
                 A["cmax"] = torch.maximum(A["cmax"], torch.where(done, ec, -big).amax(-1))
                 A["lsum"] += (el * d64).sum(-1)
                 A["slsum"] += (el * succ.to(f64)).sum(-1)
+            self.cost_acc = torch.where(all_done, torch.zeros_like(self.cost_acc), self.cost_acc)
             ended = ((f & F_ENV_RESET) > 0).any(-1) & k
             if bool(ended.any()):
                 self._flush(ended)

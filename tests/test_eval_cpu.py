@@ -164,3 +164,43 @@ def test_recorder_env_vs_reference(golden_dir):
     assert dm.find_in_range("a0", 40) == ["a1", "a2"] and dm.find_in_range("a2", 40) == ["a1", "a0"] and dm.find_in_range("a3", 40) == []
     own, nei, cnt = dm.get_rewards(dict(a0=1.0, a1=2.0, a2=3.0, a3=4.0), 40)
     assert (nei["a0"], nei["a1"], nei["a2"], nei["a3"]) == (2.5, 2.0, 1.5, 4.0) and cnt["a3"] == 0
+
+
+def test_vectorised_recorder_equals_the_reference_recorder(golden_dir):
+    """`copo_amd.eval.vec_recorder.VecRecorder` (the evaluation table computed from the sampler's dense [T, E, N] tensors) against
+    what the REFERENCE's RecorderEnv returned for the scripted episodes of tests/golden/recorder.npz (eval/recoder.py:188-299):
+    every column the vectorised recorder reports.  The scripted stream is turned into the simulator's tensor format: flags (acted
+    / spawned / done / outcome), the info columns, and the neighbour counts within the recorder's radius."""
+    import torch
+    from copo_amd.eval.vec_recorder import (COLUMNS, F_ACTED, F_ARRIVE, F_CRASH, F_DONE, F_ENV_RESET, F_OUT, F_SPAWNED, VecRecorder)
+    g = np.load(os.path.join(golden_dir, "recorder.npz"))
+    for c in range(int(g["n_cases"])):
+        s = {k[len("c%d_in_" % c):]: g[k] for k in g.files if k.startswith("c%d_in_" % c)}
+        T, N = s["present"].shape
+        present, first, done = s["present"], s["first"] & s["present"], s["done"] & s["present"]
+        acted = present & ~first
+        fl = np.zeros((T, 1, N), np.uint8)
+        fl[:, 0][acted] |= F_ACTED
+        fl[:, 0][first] |= F_SPAWNED
+        fl[:, 0][done & acted] |= F_DONE
+        for kind, bit in ((0, F_ARRIVE), (1, F_CRASH), (2, F_OUT)):
+            fl[:, 0][done & acted & (s["kind"] == kind)] |= bit
+        fl[T - 1, 0, :] |= F_ENV_RESET
+        info = np.zeros((T, 1, N, 8), np.float32)
+        for col, key in ((0, "velocity"), (4, "cost"), (5, "episode_length"), (6, "episode_reward")):
+            info[:, 0, :, col] = np.where(acted, s[key], 0.0)
+        dist = float(s["distance"])
+        d = np.linalg.norm(s["pos"][:, :, None, :] - s["pos"][:, None, :, :], axis=-1)          # [T, N, N]
+        both = present[:, :, None] & present[:, None, :] & ~np.eye(N, dtype=bool)[None]
+        nbr = ((d < dist) & both).sum(-1).astype(np.int32)[:, None, :]
+        rec = VecRecorder(1, "cpu")
+        # float32 info columns: the reference's statistics in float64 on the same numbers rounded to float32
+        rec.add(dict(flags=torch.from_numpy(fl), infos=torch.from_numpy(info), nbr_cnt=torch.from_numpy(nbr)))
+        assert len(rec.rows) == 1
+        ref = dict(zip(list(g["c%d_keys" % c]), g["c%d_vals" % c]))
+        row = rec.rows[0]
+        for col in COLUMNS:
+            if col == "env_episode_steps":
+                assert row[col] == T
+                continue
+            np.testing.assert_allclose(row[col], float(ref[col]), rtol=2e-6, atol=2e-6, err_msg="case %d: %s" % (c, col))
