@@ -178,13 +178,26 @@ def test_observation_extensions_vs_reference(golden_dir):
     assert nan_seen       # the coincident pair (d == 0 -> 0/0) went through the reference at least once
 
 
-def _roll_population_in_the_oracle(weights, odim, steps=350, E=3, seed=0):
+def test_oracle_bottleneck_is_the_one_the_reference_population_was_trained_on(golden_dir):
+    """Merge / Split blocks of the oracle's Bottleneck (maps.Net.add_funnel + Navigation's check-point rule): the CoPO population
+    the reference ships for this scene (`eval/get_policy_function.py:29`: success 0.867 in MetaDrive) must get through the funnel.
+    On round 2's corridor model half of its agents left the road (success 0.42)."""
+    gold = np.load(os.path.join(golden_dir, "reference_populations_f4.npz"))
+    pre = "copo_bottle/w/"
+    w = {k[len(pre):]: gold[k] for k in gold.files if k.startswith(pre)}
+    n = _roll_population_in_the_oracle(w, 97, steps=700, E=3, map_name="bottleneck", agents=20, lcf=tuple(gold["copo_bottle/lcf"]))
+    done = n["arrive"] + n["crash"] + n["out"]
+    assert done > 120 and n["arrive"] / done > 0.6 and n["out"] / done < 0.08, n
+
+
+def _roll_population_in_the_oracle(weights, odim, steps=350, E=3, seed=0, map_name="intersection", agents=30, lcf=None):
     """The oracle simulator (CPU) driven by a numpy policy in the reference's key layout; returns the counts of terminated
     agents by outcome.  Deterministic: counter-based simulator RNG + a seeded numpy generator for the action noise."""
     from copo_amd.eval.get_policy_function import detect_layout, layer_arrays
     from copo_amd.sim import SimConfig
-    layers = layer_arrays(weights, detect_layout(weights), "default", "")
-    sim = ol.OracleSim(SimConfig(map="intersection", num_envs=E, num_agents=30, enable_lcf=False))
+    layers = layer_arrays(weights, detect_layout(weights), "default", "" if lcf is None else "_1")
+    sim = ol.OracleSim(SimConfig(map=map_name, num_envs=E, num_agents=agents, enable_lcf=lcf is not None,
+                                 lcf_mean=0.0 if lcf is None else float(lcf[0]), lcf_std=0.1 if lcf is None else float(lcf[1])))
     assert sim.O == odim == layers[0][0].shape[0]
     out = sim.reset(np.arange(E, dtype=np.uint64) + np.uint64(5000 + 1000 * seed))
     rng = np.random.RandomState(seed)
