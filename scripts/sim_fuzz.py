@@ -25,9 +25,12 @@ for case in range(n_cases):
     block = int(rng.choice([64, 64, 128, 256, 512, 1024]))
     cfg = SimConfig(map=name, map_kwargs=kw, num_envs=E, num_agents=N, num_lasers=lasers, horizon=int(rng.randint(40, 200)),
                     nbr_k=int(rng.randint(1, max(2, min(N, 12)))), delay_done=int(rng.randint(0, 30)), enable_lcf=bool(rng.randint(2)),
-                    neighbours_distance=float(rng.choice([10.0, 20.0, 40.0])))
+                    neighbours_distance=float(rng.choice([10.0, 20.0, 40.0])),
+                    reverse_acc=float(rng.choice([0.0, 0.0, 0.0, 2.9])))        # (round 3: optional reverse gear)
     g, o = VecSim(cfg), ol.OracleSim(cfg)
     g.set_block(block)
+    chunk = int(rng.choice([0, 0, 3, 8, 13, 20]))                               # (round 3: LiDAR fans per pass of the one-wave shape)
+    g.set_chunk(chunk)
     seeds = rng.randint(0, 2 ** 31, E).astype(np.uint64)
     go, oo = g.reset(seeds), o.reset(seeds)
     mode = rng.randint(3)
@@ -60,7 +63,7 @@ for case in range(n_cases):
                 break
         if fail:
             break
-    print("case %3d %-12s N=%2d E=%d lasers=%3d block=%4d O=%3d mode=%d: %s" % (case, name, N, E, lasers, block, cfg.obs_dim, mode,
+    print("case %3d %-12s N=%2d E=%d lasers=%3d block=%4d chunk=%2d rev=%.1f O=%3d mode=%d: %s" % (case, name, N, E, lasers, block, chunk, cfg.reverse_acc, cfg.obs_dim, mode,
           "ok" if not fail else "MISMATCH step %d %s (%d words)" % fail), flush=True)
     bad += 1 if fail else 0
     g.close()
