@@ -136,6 +136,8 @@ class Net:
         self.solid[(a, b)] = (True, True)
         d = extra_lanes * w / 2.0                              # lateral_dist of the outermost wave lane, per arc
         ang = math.pi - 2.0 * math.atan(length / (2.0 * d))
+        if not 0.0 < ang < math.pi / 2:      # (each arc turns by less than a quarter: the edge arcs R +- w / 2 stay real for the width function)
+            raise ValueError("funnel of %d extra lanes over %.1f m: the wave lanes would turn by %.0f degrees" % (extra_lanes, length, math.degrees(ang)))
         R = length / (2.0 * math.sin(ang))
         # record fields of the funnel: wave radius, extra width at the wide end (+ narrowing / - widening), and how far from the
         # wide end the edge line's first arc (radius R + w / 2: the edge runs outside that bend) hands over to the second (R - w / 2)
