@@ -154,6 +154,48 @@ def test_merge_and_split_blocks_follow_the_wave_lane_formulas():
         assert lib.oracle_funnel_extra(plain.ctypes.data, np.float32(5.0), np.float32(w)) == 0.0
 
 
+def test_parking_lot_follows_the_block_formulas():
+    """MAParkinglotMap: FirstPGBlock (spawn road 10 m) -> ParkingLot block (one_side_vehicle_num 4, radius 4, length 8: main road 2 r +
+    3 w = 18.5 m, socket 4 m, spaces 3.5 m apart, each entered by a right bend from its near lane and by a left bend + 3.5 m from the
+    far lane) -> T-intersection (radius 10: right turn 10, left turn 13.5, crossing 23.5 m, arms 10 m).  3 entrances x 8 spaces + 8
+    spaces x 3 exits = 48 routes, 3 + 8 spawn places."""
+    t = maps.parkinglot()
+    w = t.lane_width
+    assert t.n_routes == 48 and t.n_spawns == 11 and t.default_num_agents == 10
+    seg = t.route_segs.astype(np.float64)
+    meta = t.route_meta
+    # entrants of the first block (routes 0-7): south spaces 0-3 by [straight 3.5 i] + right bend, north spaces by [straight] + left bend + w
+    for i in range(4):
+        r = seg[i]
+        k = 1
+        if i:
+            assert abs(r[k, maps.SEG_LEN] - w * i) < 1e-6 and r[k, maps.SEG_KAPPA] == 0
+            k += 1
+        assert abs(r[k, maps.SEG_KAPPA] + 1 / 4.0) < 1e-9 and abs(r[k, maps.SEG_LEN] - 2 * np.pi) < 1e-6          # right bend, radius 4, 90 degrees
+        sp = r[k + 1]
+        np.testing.assert_allclose([sp[0], sp[1], sp[maps.SEG_LEN]], [20.0 + w * i + 4.0, -4.0, 8.0], atol=1e-5)      # the space: x = 24 + 3.5 i, y -4 .. -12
+        assert int(meta[i, 1]) == k + 2
+    for j in range(4):
+        r = seg[4 + j]
+        k = 1
+        d_out = w * (3 - j)
+        if d_out > 1e-9:
+            assert abs(r[k, maps.SEG_LEN] - d_out) < 1e-6
+            k += 1
+        assert abs(r[k, maps.SEG_KAPPA] - 1 / 4.0) < 1e-9                                                       # left bend across the far lane
+        assert abs(r[k + 1, maps.SEG_LEN] - w) < 1e-6 and r[k + 1, maps.SEG_KAPPA] == 0
+        sp = r[k + 2]
+        np.testing.assert_allclose([sp[0], sp[1], sp[maps.SEG_LEN]], [34.5 - w * j, w + 4.0, 8.0], atol=1e-5)       # north spaces, mirrored
+    # T-intersection: the turns from the parking road, and an arm's way into it
+    lens = {round(float(x), 3) for x in seg[:, :, maps.SEG_LEN].ravel() if x > 0}
+    assert {round(10 * np.pi / 2, 3), round(13.5 * np.pi / 2, 3), 4.0, 10.0} <= lens          # turns, socket, arms (no route uses the whole 18.5 m main road or the 23.5 m arm-to-arm crossing)
+    kinds = sorted({round(float(abs(k)), 4) for k in seg[:, :, maps.SEG_KAPPA].ravel() if k != 0})
+    assert kinds == [round(1 / 13.5, 4), 0.1, 0.25]
+    # parked vehicles face the road: their spawn road runs from the back wall to the mouth of the space
+    park = [s_ for s_ in range(t.n_spawns) if abs(seg[t.spawn_tab[s_, 0], 0, maps.SEG_LEN] - 8.0) < 1e-6]
+    assert len(park) == 8 and all(abs(t.spawn_s[s_] - 4.0) < 1e-6 for s_ in park)
+
+
 def test_generated_roads_are_seeded_and_drivable():
     """PG road (the `MultiAgentMetaDrive` base env): a (sequence, seed) pair names one map, opposite carriageways stay a
     lane width apart through every block, and lane-keeping agents reach the far end in the oracle simulator."""
