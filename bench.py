@@ -109,10 +109,28 @@ def measure_sim_kernel(trainer, launches=200):
     k_s = e0.elapsed_time(e1) * 1e-3 / launches
     sim.set_state(st, env)
     present = 0.0
-    for i in range(launches):                  # the same launches once more, counting the rows they produce
+    # the same launches once more, counting the rows they produce and which formulation built the neighbour lists (debug
+    # column 7 of copo_sim_set_debug: 1 register formulation, 16 + n with n agents evaluated exactly, 2 it declined and the
+    # pair-parallel one ran: a launch of one scene per compute unit lasts as long as its slowest scene)
+    from copo_amd import _capi
+    dbg = torch.zeros(sim.E, 8, dtype=torch.int64, device=sim.device)
+    _capi.check(_capi.lib.copo_sim_set_debug(sim._h, dbg.data_ptr()))
+    which = torch.zeros(3, dtype=torch.int64, device=sim.device)
+    exact_agents, launches_all_register = 0, 0
+    for i in range(launches):
         out = sim.step(acts[i])
         present += float(((out["flags"] & 0x41) != 0).sum())
+        code = dbg[:, 7]
+        c = torch.stack([(code == 1).sum(), (code >= 16).sum(), (code == 2).sum()])
+        which += c
+        exact_agents += int((code - 16).clamp(min=0).sum())
+        launches_all_register += int(c[2] == 0)
+    _capi.check(_capi.lib.copo_sim_set_debug(sim._h, None))
     sim.set_state(st_end, env_end)             # (the sampler's buffers belong to this state)
+    w = which.tolist()
+    measure_sim_kernel.lists = {"scene_steps": int(sum(w)), "register": w[0], "register_with_exactly_evaluated_agents": w[1],
+                                "agents_evaluated_exactly": exact_agents, "declined": w[2],
+                                "launches_without_a_declined_scene": launches_all_register, "launches": launches}
     return k_s, present / launches
 
 
@@ -400,7 +418,8 @@ def main():
         sim = trainer.env.sim
         print(json.dumps({"kernel": "copo::sim_step_kernel", "scenes": sim.E, "slots": sim.N, "launches": 200,
                           "us_per_launch": round(k_s * 1e6, 2), "units_per_launch": round(present, 1),
-                          "bytes_per_unit": 202 + 4 * sim.O, "kernel_source_sha1": kernel_source_hash()}), flush=True)
+                          "bytes_per_unit": 202 + 4 * sim.O, "neighbour_lists": measure_sim_kernel.lists,
+                          "kernel_source_sha1": kernel_source_hash()}), flush=True)
         trainer.stop()
         D.shutdown()
         return
@@ -493,6 +512,7 @@ def main():
                          "traffic": traffic, "traffic_units_per_launch": traffic_units,
                          "us_per_launch": round(k_s * 1e6, 2),
                          "units_per_launch": round(present, 1), "bytes_per_unit": bytes_per_unit,
+                         "neighbour_lists": measure_sim_kernel.lists,
                          "state": "the trainer's own scenes and policy: actions of 200 env steps recorded closed-loop, scenes put "
                                   "back, actions replayed (timed loop = simulator launches only); `traffic` = PMC FETCH_SIZE + "
                                   "WRITE_SIZE per launch from rocprofv3 passes over `bench.py --roofline-only` (the same replay), "

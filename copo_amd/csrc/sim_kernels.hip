@@ -21,7 +21,9 @@
 #ifndef COPO_PROFILE_SKIP
 #define COPO_PROFILE_SKIP 0
 #endif
-#define COPO_DBG_STRIDE ((COPO_PROFILE_SKIP & 256) ? 16 : 8)
+#define COPO_DBG_STRIDE ((COPO_PROFILE_SKIP & 0x300) ? 16 : 8)
+// (mask 512: the wave roles' own finishing times -- slot 8 wave 0, slot 9 wave 1, slot 10 the last LiDAR wave; scripts/phase_sim.py)
+#define COPO_ROLE_STAMP(slot) do { if ((COPO_PROFILE_SKIP & 512) && p.dbg && lane == 0) atomicMax(reinterpret_cast<unsigned long long*>(p.dbg) + (size_t)e * 16 + (slot), (unsigned long long)clock64()); } while (0)
 #define COPO_COUNT(slot, v) do { if ((COPO_PROFILE_SKIP & 256) && p.dbg && lane == 0) p.dbg[(size_t)e * 16 + (slot)] += (long long)(v); } while (0)
 
 namespace copo {
@@ -455,32 +457,88 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
     return t < mx ? t : mx;
 }
 
+__device__ __forceinline__ float readlane_f(float v, int lane_uniform) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_uniform));
+}
+
+// The lists of ONE agent i (wave-uniform) by one wave, lane = slot j, with the reference's own expressions: fp64 distance of
+// every present j, in range / mean-field range on it, rank by (d, slot), the rewards added in list order
+// (env_wrappers.py:321-325; neighbours_phase does the same for all agents at once).  `scratch`: 64 doubles of LDS.
+__device__ __forceinline__ void neighbours_exact_one(const SimParams& p, int e, int lane, int i, float xl, float yl, float rwl,
+                                                     unsigned long long present, const StepOut& out, double* scratch) {
+    const int N = p.N, K = p.K;
+    const double R = (double)p.neighbours_distance, M = (double)p.mf_distance;
+    const float xi = readlane_f(xl, i), yi = readlane_f(yl, i);
+    const double dx = (double)xi - (double)xl, dy = (double)yi - (double)yl;
+    const double d = sqrt(dx * dx + dy * dy);
+    const bool inr = ((present >> lane) & 1ull) && lane != i && d < R;
+    const unsigned long long mi = __ballot(inr);
+    const int cnt = __popcll(mi);
+    const int mf = __popcll(__ballot(inr && d <= M));
+    const int dlo = __double2loint(d), dhi = __double2hiint(d);
+    int rank = 0;
+    for (unsigned long long m = mi; m; m &= m - 1ull) {
+        const int k = __ffsll((long long)m) - 1;
+        const double dk = __hiloint2double(__builtin_amdgcn_readlane(dhi, k), __builtin_amdgcn_readlane(dlo, k));
+        rank += (dk < d || (dk == d && k < lane)) ? 1 : 0;
+    }
+    const size_t row = ((size_t)e * N + i) * K;
+    if (inr) {
+        scratch[rank] = (double)rwl;
+        if (rank < K) {
+            if (out.nbr_idx) out.nbr_idx[row + rank] = lane;
+            if (out.nbr_dist) out.nbr_dist[row + rank] = (float)d;
+        }
+    }
+    if (lane >= cnt && lane < K) {
+        if (out.nbr_idx) out.nbr_idx[row + lane] = -1;
+        if (out.nbr_dist) out.nbr_dist[row + lane] = 0.0f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double nsum = 0.0;
+    for (int r = 0; r < cnt; ++r) nsum += scratch[r];
+    if (lane == 0) {
+        if (out.nbr_cnt) out.nbr_cnt[(size_t)e * N + i] = cnt;
+        if (out.mf_cnt) out.mf_cnt[(size_t)e * N + i] = mf;
+        if (out.nei_rew) out.nei_rew[(size_t)e * N + i] = cnt ? (float)(nsum / (double)cnt) : 0.0f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();            // (the next agent's rewards go to the same words)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Neighbour lists + reward reductions of one scene by ONE wave, lane = slot: the same results as neighbours_phase, bit for
-// bit, or `false` (nothing written) when that cannot be guaranteed -- the caller then runs neighbours_phase.
+// bit.  Returns 0 when the scene is done -- `*n_exact` agents of it through neighbours_exact_one -- or 2 (nothing written)
+// when more than NBR_EXACT_MAX agents would need that: the caller then runs neighbours_phase.
 //
 // Every lane walks the present agents j in slot order (the record {x, y, (double) reward} of j is one broadcast LDS read)
 // and keeps, in registers: the count and the fp64 reward sum of the agents within `neighbours_distance`, and the 9 smallest
-// keys `fp32 d^2 bits (low 6 mantissa bits dropped) | j` in ascending order (one v_med3_u32 per position).  Exactness:
+// keys `fp32 d^2 bits (low 6 mantissa bits dropped) | j` in ascending order (one v_med3_u32 per position).  A lane's
+// registers ARE the reference's result unless one of these holds, and then the agent is evaluated by neighbours_exact_one:
 //  * in range / mean-field range: decided on the fp32 d^2 against thresholds 1e-6 (1e-5 for the truncated keys) inside and
-//    outside the exact ones; a distance inside such a band -> false (fp32 d^2 errs by < 2.4e-7 relative).
-//  * order by (d, slot): adjacent keys of the nine must differ by >= 3 units of the truncated d^2 (2.3e-5 relative >> the fp32
-//    error), then the exact fp64 distances are ordered the same way and no tie exists; otherwise -> false.  Exact ties (the
-//    crafted cases of the tests, symmetric scenes) therefore always take neighbours_phase.
-//  * neighbourhood reward: the reference adds the fp64 rewards in list order.  If every reward of the scene is 0 or has
+//    outside the exact ones; a distance inside such a band is not decided (fp32 d^2 errs by < 2.4e-7 relative).  Nine or
+//    more agents inside the mean-field range cannot be counted on nine keys.
+//  * order by (d, slot): adjacent keys of the nine must differ by >= 2 units of the truncated d^2 (the fp32 values then
+//    differ by > 64 ulp >> their error: the exact fp64 distances are ordered the same way and no tie exists).  Exact ties
+//    (the crafted cases of the tests, symmetric scenes) therefore always go to the exact evaluation.
+//  * neighbourhood reward: the reference adds the fp64 rewards in list order.  If every reward in range is 0 or has
 //    2^-20 <= |r| <= 16, every partial sum of <= 64 of them is a multiple of 2^-43 below 2^10, i.e. exactly representable:
-//    no addition rounds and the order does not matter.  Otherwise -> false.
+//    no addition rounds and the order does not matter.  An agent with another kind of reward in range is not decided.
 //  * global reward: added in slot order, which IS the reference's order.
 // K > 8, the communication block and the stateless op's filled rows take neighbours_phase as well.
 constexpr uint32_t NBR_SENT = 0xffffffffu;
-__device__ __forceinline__ bool neighbours_fast(const SimParams& p, EnvLds& L, int e, int lane, const StepOut& out, float4* rec) {
+constexpr int NBR_EXACT_MAX = 6;
+__device__ __forceinline__ int neighbours_fast(const SimParams& p, EnvLds& L, int e, int lane, const StepOut& out, float4* rec,
+                                               int* n_exact) {
     const int N = p.N, K = p.K;
     const unsigned long long present = L.m_present;
     const bool me = (present >> lane) & 1ull;
     const int np = __popcll(present);
     const float xi = L.x[lane], yi = L.y[lane], rw = L.rew[lane];
     const float arw = fabsf(rw);
-    const bool bad = me && !(rw == 0.0f || (arw >= 9.5367431640625e-07f && arw <= 16.0f));
-    if (__ballot(bad) != 0ull) return false;
+    const unsigned long long odd = __ballot(me && !(rw == 0.0f || (arw >= 9.5367431640625e-07f && arw <= 16.0f)));
     {   // rec: [64] {x, y, (double) reward} in LDS (the caller's choice: the neighbour work area when one wave owns the scene)
         const double rd = (double)rw;
         rec[lane] = make_float4(xi, yi, __int_as_float(__double2loint(rd)), __int_as_float(__double2hiint(rd)));
@@ -530,17 +588,25 @@ __device__ __forceinline__ bool neighbours_fast(const SimParams& p, EnvLds& L, i
     }
     unc |= a8 < thi;                                        // nine or more within the mean-field range: not countable here
 #pragma unroll
-    for (int k = 0; k < 8; ++k) unc |= (ak[k + 1] != NBR_SENT) && (ak[k + 1] - ak[k] < 192u);
-    if (__ballot(me && unc) != 0ull) return false;
+    for (int k = 0; k < 8; ++k) unc |= (ak[k + 1] != NBR_SENT) && (ak[k + 1] - ak[k] < 128u);
+    for (unsigned long long mo = odd; mo; mo &= mo - 1ull) {          // (rare) a reward outside the exact-sum range: who has it in range?
+        const int b = __ffsll((long long)mo) - 1;
+        const float dx = xi - readlane_f(xi, b), dy = yi - readlane_f(yi, b);
+        unc |= b != lane && __builtin_fmaf(dy, dy, dx * dx) < r2hi;
+    }
+    const unsigned long long exact = __ballot(me && unc);
+    *n_exact = __popcll(exact);
+    if (*n_exact > NBR_EXACT_MAX) return 2;
     // ---- write-out ------------------------------------------------------------------------------------------------------
     const size_t base = (size_t)e * N;
+    const bool mine = me && !unc;                           // this lane's registers are the result
     if (lane == 0 && out.glob_rew) out.glob_rew[e] = np ? (float)(gs / (double)np) : 0.0f;
-    if (lane < N) {
+    if (lane < N && !(me && unc)) {
         if (out.nbr_cnt) out.nbr_cnt[base + lane] = me ? cnt : 0;
         if (out.mf_cnt) out.mf_cnt[base + lane] = me ? mf : 0;
         if (out.nei_rew) out.nei_rew[base + lane] = (me && cnt) ? (float)(sum / (double)cnt) : 0.0f;
     }
-    if (me) {
+    if (mine) {
         if (out.nbr_idx) {
             int32_t* row = out.nbr_idx + (base + lane) * K;
             if (K == 8) {
@@ -572,7 +638,9 @@ __device__ __forceinline__ bool neighbours_fast(const SimParams& p, EnvLds& L, i
                 }
         }
     }
-    return true;
+    for (unsigned long long mx = exact; mx; mx &= mx - 1ull)        // (rare) the agents that the registers do not decide
+        neighbours_exact_one(p, e, lane, __ffsll((long long)mx) - 1, xi, yi, rw, present, out, reinterpret_cast<double*>(rec));
+    return 0;
 }
 
 template <bool EXT>
@@ -583,9 +651,11 @@ __device__ __forceinline__ void neighbours_any(const SimParams& p, EnvLds& L, in
     const bool comm = EXT && p.col_comm >= 0 && out.obs != nullptr;
     if (nthreads == 64 && p.nbr_fast && !comm && !(COPO_PROFILE_SKIP & 128)) {
         extern __shared__ unsigned int dyn[];
-        const bool ok = neighbours_fast(p, L, e, tid, out, reinterpret_cast<float4*>(dyn));
-        if (p.dbg && tid == 0) p.dbg[(size_t)e * COPO_DBG_STRIDE + 7] = ok ? 1 : 2;      // profiling aid: which formulation ran
-        if (ok) return;
+        int n_exact = 0;
+        const int why = neighbours_fast(p, L, e, tid, out, reinterpret_cast<float4*>(dyn), &n_exact);
+        // profiling aid, which formulation ran: 1 register, 16 + n register with n agents evaluated exactly, 2 declined (pair-parallel)
+        if (p.dbg && tid == 0) p.dbg[(size_t)e * COPO_DBG_STRIDE + 7] = why ? 2 : (n_exact ? 16 + n_exact : 1);
+        if (why == 0) return;
     }
     neighbours_phase<EXT>(p, L, e, tid, nthreads, out, act, acted_mask, fresh);
 }
@@ -1082,6 +1152,7 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
 
 #define COPO_STAMP(i) do { if (p.dbg && tid == 0) p.dbg[(size_t)e * COPO_DBG_STRIDE + (i)] = (long long)clock64(); } while (0)
     COPO_STAMP(0);
+    if ((COPO_PROFILE_SKIP & 512) && p.dbg && tid == 0) p.dbg[(size_t)e * 16 + 11] = (long long)wall_clock64();     // (100 MHz: the shader clock of the launch)
     // ---- P0 (wave 0): timers + kinematic bicycle, poses -> LDS ----------------------------------------
     Slot s = Slot{};
     bool acted = false;
@@ -1225,6 +1296,19 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
             if (near && obb_overlap2(xi, yi, L.cs[i], L.sn[i], hl, hw, xj, yj, L.cs[j], L.sn[j], hl, hw)) L.crash[i] = 1;
         }
     }
+    // several waves per scene: which vehicles stand in the region of respawn place q, as a slot mask per place, next to
+    // the collision pairs -- P2 (wave 0 alone, on the critical path of a launch with one scene per
+    // compute unit) then only ANDs the masks with the slots that are still solid
+    unsigned long long* spblk = reinterpret_cast<unsigned long long*>(rec_roles + 64);
+    if (!ONE && nwaves > 1 && !(COPO_PROFILE_SKIP & 32)) {     // (places dealt from the last wave down: those have the fewest pairs)
+        const float xj = L.x[lane], yj = L.y[lane], cj = L.cs[lane], sj = L.sn[lane];
+        for (int q = nwaves - 1 - wave; q < p.n_safe; q += nwaves) {
+            const float4 sp4 = reinterpret_cast<const float4*>(p.safe_pose)[q];
+            const bool blk = lane < N && obb_overlap2(sp4.x, sp4.y, sp4.z, sp4.w, p.region_hl, p.region_hw, xj, yj, cj, sj, hl, hw);
+            const unsigned long long mq = __ballot(blk);
+            if (lane == 0) spblk[q] = mq;
+        }
+    }
     __syncthreads();
 
     // MultiAgentMetaDrive.step: after `horizon` env steps the scene stops respawning and drains; it is reset when nobody
@@ -1341,6 +1425,11 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
                 const bool solid_now = lane < N && st_status(s.status) != ST_EMPTY;
                 const float cj = L.cs[lane], sj = L.sn[lane];      // poses of terminated vehicles did not change since P0
                 uint32_t clear = 0;
+                if (!ONE && nwaves > 1) {          // the box tests ran during P1 (above); the poses of standing vehicles did not change
+                    const unsigned long long solid_mask = __ballot(solid_now);
+                    for (int q = 0; q < p.n_safe; ++q)
+                        if ((spblk[q] & solid_mask) == 0ull) clear |= 1u << q;
+                } else
                 for (int q = 0; q < p.n_safe; ++q) {
                     const float4 sp4 = reinterpret_cast<const float4*>(p.safe_pose)[q];      // pose of respawn place q (host table)
                     const bool blk = solid_now && obb_overlap2(sp4.x, sp4.y, sp4.z, sp4.w, p.region_hl, p.region_hw,
@@ -1400,11 +1489,14 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
     // ---- P3 (all waves): neighbour lists + reward reductions on the post-step (pre-reset) scene ---
     if (roles) {
         if (wave == 1) {
-            const bool ok = neighbours_fast(p, L, e, lane, out, rec_roles);
-            if (lane == 0) L.nbr_ok = ok ? 1 : 0;
-            if (p.dbg && lane == 0) p.dbg[(size_t)e * COPO_DBG_STRIDE + 7] = ok ? 1 : 2;
+            int n_exact = 0;
+            const int why = neighbours_fast(p, L, e, lane, out, rec_roles, &n_exact);
+            if (lane == 0) L.nbr_ok = why == 0 ? 1 : 0;
+            if (p.dbg && lane == 0) p.dbg[(size_t)e * COPO_DBG_STRIDE + 7] = why ? 2 : (n_exact ? 16 + n_exact : 1);
+            COPO_ROLE_STAMP(9);
         } else if (wave >= 2) {
             obs_phase<2>(p, L, e, tid, nthreads, out.obs, 2);
+            COPO_ROLE_STAMP(10);
         }
     } else if (!(COPO_PROFILE_SKIP & 1)) neighbours_any<EXT>(p, L, e, tid, nthreads, out, act, L.m_acted, ending);
     else __syncthreads();
@@ -1447,6 +1539,7 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
             env[2] = next_aid;
         }
         if (!(COPO_PROFILE_SKIP & 8)) ego_navi_obs<EXT>(p, L, lane, s, present, (out.obs && lane < N) ? out.obs + ((size_t)e * N + lane) * p.O : nullptr, ending ? 0 : t_env + 1, ending);
+        COPO_ROLE_STAMP(8);
     }
     __syncthreads();
 
@@ -1461,6 +1554,7 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
     } else if (out.obs) obs_phase(p, L, e, tid, nthreads, out.obs);
     __syncthreads();
     COPO_STAMP(6);
+    if ((COPO_PROFILE_SKIP & 512) && p.dbg && tid == 0) p.dbg[(size_t)e * 16 + 12] = (long long)wall_clock64();
 #undef COPO_STAMP
 }
 
@@ -1499,7 +1593,8 @@ __global__ void __launch_bounds__(256) neighbours_kernel(const float* __restrict
 // [slots][rays] minima, ray table, one 64-entry strip per wave (box-test owners)
 static size_t lidar_lds_bytes(const SimParams& p, int block) {
     return (size_t)(lidar_lds_words(p.chunk, p.nbr_chunk, p.N, p.num_lasers) + ray_lds_words(p.num_lasers) + (block / 64) * LIDAR_WAVE_WORDS) * sizeof(unsigned int) +
-           (block > 64 ? 64 * sizeof(float4) + 16 : 0);       // (step kernel, wave roles: the records of neighbours_fast)
+           (block > 64 ? 64 * sizeof(float4) + 16 + COPO_MAX_SAFE * sizeof(unsigned long long) : 0);       // (step kernel, several waves per
+                                                                                                      //  scene: the records of neighbours_fast, the blocker masks of the respawn places)
 }
 static bool sim_has_ext(const SimParams& p) { return p.col_tl >= 0 || p.col_comm >= 0; }
 static hipError_t sim_lds_attrs() {              // 64 slots x 256 rays + route tables exceed the default 64 KB

@@ -79,59 +79,77 @@ def test_rollout_bit_exact(map_name, N, E, lasers, steps, block):
 
 
 def test_register_neighbour_lists_decline_on_ties_and_band_cases():
-    """The register formulation of the neighbour lists (neighbours_fast, the one-wave-per-scene shape) must hand a scene to the
-    pair-parallel formulation whenever it cannot prove the reference's result -- and the result must be the oracle's either way.
-    Crafted scenes through `copo_sim_set_state` (vehicles at rest, zero actions: the poses of the step are the crafted ones):
-      scene 0  generic positions                                     -> register formulation (debug column 7 == 1)
-      scene 1  two agents at exactly the same distance of a third    -> declined (== 2): tie, slot order decides
-      scene 2  an agent exactly ON the 40 m radius (strict <)        -> declined: inside the band of the in-range decision
-      scene 3  an agent exactly ON the 10 m mean-field radius (<=)   -> declined: inside the band of the mean-field decision
-      scene 4  the reset state itself (vehicles on the spawn grid)   -> declined: the grid is full of equal distances
-      scene 5  as scene 0, one vehicle on a road's axis far away      -> declined: its jump in route progress is a reward > 16
-    Outputs (counts, first K ids and distances, neighbourhood / global rewards, observations) are compared bit for bit."""
+    """The register formulation of the neighbour lists (neighbours_fast, one wave per scene) must hand every agent whose
+    result its registers do not PROVE to the exact evaluation (neighbours_exact_one, the reference's fp64 expressions for that
+    agent), and a scene with many such agents to the pair-parallel formulation -- the result must be the oracle's either way.
+    Crafted scenes through `copo_sim_set_state` (vehicles at rest, zero actions: the poses of the step are the crafted ones);
+    debug column 7: 1 = registers only, 16 + n = n agents evaluated exactly, 2 = declined (pair-parallel formulation):
+      scene 0  generic positions                                     -> 1
+      scene 1  two agents at exactly the same distance of a third    -> 16 + n: tie, slot order decides
+      scene 2  an agent exactly ON the 40 m radius (strict <)        -> 16 + n: inside the band of the in-range decision
+      scene 3  an agent exactly ON the 10 m mean-field radius (<=)   -> 16 + n: inside the band of the mean-field decision
+      scene 4  the reset state itself (vehicles on the spawn grid)   -> 16 + n: equal distances along the grid
+      scene 5  as scene 0, one vehicle on a road's axis far away      -> 1: its jump in route progress is a reward > 16, but
+                                                                        nobody has it in range
+      scene 6  three such vehicles within range of each other         -> 16 + n: a reward outside the range in which sums are exact
+      scene 7  nine vehicles on a cross (ties for every one of them)  -> 2: more agents than the exact evaluation takes
+    Outputs (counts, first K ids and distances, neighbourhood / global rewards, observations) are compared bit for bit, in
+    both launch shapes (one wave per scene; 16 waves per scene, where wave 1 builds the lists)."""
     import torch
     import oracle_lib as ol
     from copo_amd import _capi
     from copo_amd.sim import SimConfig, VecSim
-    E, N = 6, 12
+    E, N = 8, 12
     cfg = SimConfig(map="intersection", num_envs=E, num_agents=N, nbr_k=8, horizon=200)
-    g, o = VecSim(cfg), ol.OracleSim(cfg)
-    g.set_block(64)
-    seeds = np.arange(E, dtype=np.uint64) + np.uint64(5000)
-    _compare("reset", g.reset(seeds), o.reset(seeds))
-    st, env = o.get_state()
-    st0 = st.copy()
-    st = st.copy()
-    rng = np.random.RandomState(0)
-    xy = np.zeros((E, N, 2), np.float32)
-    xy[..., 0] = 1000.0 + 137.0 * np.arange(N)[None, :] + rng.uniform(-3, 3, (E, N))       # far apart: no neighbours by default
-    xy[..., 1] = 700.0 + rng.uniform(-3, 3, (E, N))     # (far from every road: out of road, reward -10 -- on a road's axis the jump
-    #                                                       in route progress would be a reward of +1000, which the formulation declines)
-    xy[0, :6] = rng.uniform(-25, 25, (6, 2))                                                  # scene 0: a generic cluster
-    xy[1, 0], xy[1, 1], xy[1, 2] = (0.0, 0.0), (30.0, 0.0), (-30.0, 0.0)                      # scene 1: tie at 30 m
-    xy[2, 0], xy[2, 1], xy[2, 2] = (0.0, 0.0), (0.0, 40.0), (12.5, 3.0)                       # scene 2: on the radius
-    xy[3, 0], xy[3, 1], xy[3, 2] = (0.0, 0.0), (6.0, 8.0), (-20.0, 7.0)                       # scene 3: on the mean-field radius (d = 10)
-    xy[5] = xy[0]
-    xy[5, 7] = (1500.0, 0.3)                                                                  # scene 5: on the axis of arm 0's road, 1.4 km out
-    st[0], st[1] = xy[..., 0], xy[..., 1]
-    st[:, 4] = st0[:, 4]                                                                      # scene 4: the reset state
-    o.set_state(st, env)
-    g.set_state(torch.from_numpy(st).cuda(), torch.from_numpy(env).cuda())
-    dbg = torch.zeros(E, 8, dtype=torch.int64, device="cuda")
-    _capi.check(_capi.lib.copo_sim_set_debug(g._h, dbg.data_ptr()))
-    a = np.zeros((E, N, 2), np.float32)
-    go, oo = g.step(torch.from_numpy(a).cuda()), o.step(a)
-    torch.cuda.synchronize()
-    _compare("crafted step", go, oo)
-    which = dbg[:, 7].cpu().numpy().tolist()
-    assert which == [1, 2, 2, 2, 2, 2], which
-    cnt = oo["nbr_cnt"]
-    assert cnt[1, 0] == 2 and list(oo["nbr_idx"][1, 0, :2]) == [1, 2]          # the tie: slot order
-    assert cnt[2, 0] == 1 and oo["nbr_idx"][2, 0, 0] == 2                        # d == 40 is not a neighbour
-    assert oo["mf_cnt"][3, 0] == 1                                               # d == 10 is inside the mean-field range
-    _capi.check(_capi.lib.copo_sim_set_debug(g._h, None))
-    g.close()
-    o.close()
+    for block in (64, 1024):
+        g, o = VecSim(cfg), ol.OracleSim(cfg)
+        g.set_block(block)
+        seeds = np.arange(E, dtype=np.uint64) + np.uint64(5000)
+        _compare("reset", g.reset(seeds), o.reset(seeds))
+        st, env = o.get_state()
+        st0 = st.copy()
+        st = st.copy()
+        rng = np.random.RandomState(0)
+        xy = np.zeros((E, N, 2), np.float32)
+        xy[..., 0] = 1000.0 + 137.0 * np.arange(N)[None, :] + rng.uniform(-3, 3, (E, N))       # far apart: no neighbours by default
+        xy[..., 1] = 700.0 + rng.uniform(-3, 3, (E, N))     # (far from every road: out of road, reward -10 -- on a road's axis the jump
+        #                                                       in route progress would be a reward of +1000)
+        xy[0, :6] = rng.uniform(-25, 25, (6, 2))                                                  # scene 0: a generic cluster
+        xy[1, 0], xy[1, 1], xy[1, 2] = (0.0, 0.0), (30.0, 0.0), (-30.0, 0.0)                      # scene 1: tie at 30 m
+        xy[2, 0], xy[2, 1], xy[2, 2] = (0.0, 0.0), (0.0, 40.0), (12.5, 3.0)                       # scene 2: on the radius
+        xy[3, 0], xy[3, 1], xy[3, 2] = (0.0, 0.0), (6.0, 8.0), (-20.0, 7.0)                       # scene 3: on the mean-field radius (d = 10)
+        xy[5] = xy[0]
+        xy[5, 7] = (1500.0, 0.3)                                                                  # scene 5: on the axis of arm 0's road, 1.4 km out
+        xy[6] = xy[0]
+        xy[6, 7], xy[6, 8], xy[6, 9] = (1500.0, 0.3), (1512.0, 0.4), (1529.0, 0.2)                # scene 6: three of them, in range of each other
+        xy[7, :9] = [(0, 0), (15, 0), (-15, 0), (0, 15), (0, -15), (30, 0), (-30, 0), (0, 30), (0, -30)]   # scene 7: a cross
+        st[0], st[1] = xy[..., 0], xy[..., 1]
+        st[:, 4] = st0[:, 4]                                                                      # scene 4: the reset state
+        o.set_state(st, env)
+        g.set_state(torch.from_numpy(st).cuda(), torch.from_numpy(env).cuda())
+        dbg = torch.zeros(E, 8, dtype=torch.int64, device="cuda")
+        _capi.check(_capi.lib.copo_sim_set_debug(g._h, dbg.data_ptr()))
+        a = np.zeros((E, N, 2), np.float32)
+        go, oo = g.step(torch.from_numpy(a).cuda()), o.step(a)
+        torch.cuda.synchronize()
+        _compare("crafted step (block %d)" % block, go, oo)
+        which = dbg[:, 7].cpu().numpy().tolist()
+        if block == 64:
+            assert which[0] == 1 and which[5] == 1, which
+            assert all(17 <= w <= 16 + 6 for w in which[1:4]), which
+            assert 17 <= which[4] <= 16 + 6, which
+            assert which[6] in (18, 19) and which[7] == 2, which
+        else:      # (a scene whose last agent terminates in this step -- most of these -- resets, and a resetting scene of the
+            #         many-wave shape builds its lists pair-parallel on the poses before the reset: column 7 stays 0)
+            assert all(w == 0 or w == 2 or w == 1 or 17 <= w <= 22 for w in which) and any(w >= 17 for w in which), which
+        assert float(np.abs(oo["rew"][6, 7:10]).max()) > 16.0              # (the premise of scene 6)
+        cnt = oo["nbr_cnt"]
+        assert cnt[1, 0] == 2 and list(oo["nbr_idx"][1, 0, :2]) == [1, 2]          # the tie: slot order
+        assert cnt[2, 0] == 1 and oo["nbr_idx"][2, 0, 0] == 2                        # d == 40 is not a neighbour
+        assert oo["mf_cnt"][3, 0] == 1                                               # d == 10 is inside the mean-field range
+        _capi.check(_capi.lib.copo_sim_set_debug(g._h, None))
+        g.close()
+        o.close()
 
 
 def test_episode_structure_bit_exact():
