@@ -173,6 +173,7 @@ struct __align__(16) EnvLds {
     const float* sps;          // spawn offsets, same
     int32_t ending;
     int32_t nbr_ok;            // wave-role step: the register formulation of the neighbour lists went through
+    unsigned long long nbr_exact, nbr_odd;   // ... except for these agents (evaluated exactly next to the LiDAR write-out) / slots with odd rewards
     int32_t seg_rows;          // road records per route in the device tables (longest route + its terminal record)
 };
 
@@ -463,9 +464,11 @@ __device__ __forceinline__ float readlane_f(float v, int lane_uniform) {
 
 // The lists of ONE agent i (wave-uniform) by one wave, lane = slot j, with the reference's own expressions: fp64 distance of
 // every present j, in range / mean-field range on it, rank by (d, slot), the rewards added in list order
-// (env_wrappers.py:321-325; neighbours_phase does the same for all agents at once).  `scratch`: 64 doubles of LDS.
+// (env_wrappers.py:321-325; neighbours_phase does the same for all agents at once).  `odd`: slots whose reward is outside
+// the range in which sums are exact in any order -- only with one of those in range are the rewards brought into list
+// order (a cross-lane push by rank) before they are added; otherwise slot order gives the same bits.
 __device__ __forceinline__ void neighbours_exact_one(const SimParams& p, int e, int lane, int i, float xl, float yl, float rwl,
-                                                     unsigned long long present, const StepOut& out, double* scratch) {
+                                                     unsigned long long present, unsigned long long odd, const StepOut& out) {
     const int N = p.N, K = p.K;
     const double R = (double)p.neighbours_distance, M = (double)p.mf_distance;
     const float xi = readlane_f(xl, i), yi = readlane_f(yl, i);
@@ -476,42 +479,47 @@ __device__ __forceinline__ void neighbours_exact_one(const SimParams& p, int e, 
     const int cnt = __popcll(mi);
     const int mf = __popcll(__ballot(inr && d <= M));
     const int dlo = __double2loint(d), dhi = __double2hiint(d);
+    // rank = in-range slots that sort before this one by (d, slot).  Distances are >= 0: the upper word of the fp64 pattern
+    // orders them except when two upper words agree (distances within 1e-6 of each other) -- only then the full compare
     int rank = 0;
     for (unsigned long long m = mi; m; m &= m - 1ull) {
         const int k = __ffsll((long long)m) - 1;
-        const double dk = __hiloint2double(__builtin_amdgcn_readlane(dhi, k), __builtin_amdgcn_readlane(dlo, k));
-        rank += (dk < d || (dk == d && k < lane)) ? 1 : 0;
+        const unsigned int kh = (unsigned int)__builtin_amdgcn_readlane(dhi, k);
+        rank += kh < (unsigned int)dhi ? 1 : 0;
+        if (__ballot(inr && kh == (unsigned int)dhi && k != lane) != 0ull) {
+            const double dk = __hiloint2double((int)kh, __builtin_amdgcn_readlane(dlo, k));
+            rank += (kh == (unsigned int)dhi && (dk < d || (dk == d && k < lane))) ? 1 : 0;
+        }
     }
     const size_t row = ((size_t)e * N + i) * K;
-    if (inr) {
-        scratch[rank] = (double)rwl;
-        if (rank < K) {
-            if (out.nbr_idx) out.nbr_idx[row + rank] = lane;
-            if (out.nbr_dist) out.nbr_dist[row + rank] = (float)d;
-        }
+    if (inr && rank < K) {
+        if (out.nbr_idx) out.nbr_idx[row + rank] = lane;
+        if (out.nbr_dist) out.nbr_dist[row + rank] = (float)d;
     }
     if (lane >= cnt && lane < K) {
         if (out.nbr_idx) out.nbr_idx[row + lane] = -1;
         if (out.nbr_dist) out.nbr_dist[row + lane] = 0.0f;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     double nsum = 0.0;
-    for (int r = 0; r < cnt; ++r) nsum += scratch[r];
+    if (out.nei_rew) {
+        if (mi & odd) {       // list order matters: lane `rank` receives the reward of this lane (lanes out of range push to lane 63)
+            const int byrank = __builtin_amdgcn_ds_permute((inr ? rank : 63) << 2, __float_as_int(rwl));
+            for (int r = 0; r < cnt; ++r) nsum += (double)__int_as_float(__builtin_amdgcn_readlane(byrank, r));
+        } else {
+            for (unsigned long long m = mi; m; m &= m - 1ull) nsum += (double)readlane_f(rwl, __ffsll((long long)m) - 1);
+        }
+    }
     if (lane == 0) {
         if (out.nbr_cnt) out.nbr_cnt[(size_t)e * N + i] = cnt;
         if (out.mf_cnt) out.mf_cnt[(size_t)e * N + i] = mf;
         if (out.nei_rew) out.nei_rew[(size_t)e * N + i] = cnt ? (float)(nsum / (double)cnt) : 0.0f;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();            // (the next agent's rewards go to the same words)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // Neighbour lists + reward reductions of one scene by ONE wave, lane = slot: the same results as neighbours_phase, bit for
 // bit.  Returns 0 when the scene is done -- `*n_exact` agents of it through neighbours_exact_one -- or 2 (nothing written)
-// when more than NBR_EXACT_MAX agents would need that: the caller then runs neighbours_phase.
+// when more than NBR_EXACT_MAX agents would need that: the caller then runs neighbours_phase.  With `defer_exact` those
+// agents are not evaluated but handed back (slot mask, with the mask of slots with odd rewards) for the caller to do it.
 //
 // Every lane walks the present agents j in slot order (the record {x, y, (double) reward} of j is one broadcast LDS read)
 // and keeps, in registers: the count and the fp64 reward sum of the agents within `neighbours_distance`, and the 9 smallest
@@ -531,7 +539,8 @@ __device__ __forceinline__ void neighbours_exact_one(const SimParams& p, int e, 
 constexpr uint32_t NBR_SENT = 0xffffffffu;
 constexpr int NBR_EXACT_MAX = 6;
 __device__ __forceinline__ int neighbours_fast(const SimParams& p, EnvLds& L, int e, int lane, const StepOut& out, float4* rec,
-                                               int* n_exact) {
+                                               int* n_exact, unsigned long long* defer_exact = nullptr,
+                                               unsigned long long* defer_odd = nullptr) {
     const int N = p.N, K = p.K;
     const unsigned long long present = L.m_present;
     const bool me = (present >> lane) & 1ull;
@@ -638,8 +647,13 @@ __device__ __forceinline__ int neighbours_fast(const SimParams& p, EnvLds& L, in
                 }
         }
     }
+    if (defer_exact) {                                          // (the caller spreads them over waves)
+        *defer_exact = exact;
+        *defer_odd = odd;
+        return 0;
+    }
     for (unsigned long long mx = exact; mx; mx &= mx - 1ull)        // (rare) the agents that the registers do not decide
-        neighbours_exact_one(p, e, lane, __ffsll((long long)mx) - 1, xi, yi, rw, present, out, reinterpret_cast<double*>(rec));
+        neighbours_exact_one(p, e, lane, __ffsll((long long)mx) - 1, xi, yi, rw, present, odd, out);
     return 0;
 }
 
@@ -857,10 +871,13 @@ __device__ __forceinline__ float atan2_window(float v, float u) {
 // while waves 0 / 1 write the state back and build the neighbour lists; 4 starts with a workgroup barrier.
 template <int PHASES = 7>
 __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, int tid, int nthreads,
-                                          float* __restrict__ obs, int wave_lo = 0) {
+                                          float* __restrict__ obs, int wave_lo = 0, int idle_n = 0) {
     extern __shared__ unsigned int dyn[];
     const int N = p.N, O = p.O, NL = p.num_lasers;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nwaves = nthreads >> 6;
+    // write-out (4): waves 1 .. idle_n take no part (they pass the barriers only; the step kernel gives them other work)
+    const int otid = (wave >= 1 && wave <= idle_n) ? 0x3fffffff : tid - (wave > idle_n ? idle_n * 64 : 0);
+    const int onth = nthreads - idle_n * 64;
     const float hl = p.hl, hw = p.hw;
     const float circ = sqrtf(hl * hl + hw * hw);
     const float range = p.lidar_range;
@@ -998,7 +1015,7 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
     const int nrays = cha * NL;                   // rows of present slots only
     if (vec_out && !(COPO_PROFILE_SKIP & 4)) {
         // 16-byte stores: [head scalars | nvec aligned quads | tail scalars] of every fan (rows are 16-byte aligned: O % 4 == 0)
-        for (int q = tid; q < cha * nvec; q += nthreads) {
+        for (int q = otid; q < cha * nvec; q += onth) {
             const int lp = (int)(((float)q + 0.5f) * inv_nvec), k = head + 4 * (q - lp * nvec);
             const unsigned int* b = best + lp * NL + k;
             float4 v;
@@ -1007,13 +1024,13 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
             *reinterpret_cast<float4*>(eobs + (int)L.plist[ip0 + lp] * O + col_lidar + k) = v;
         }
         const int nsc = NL - 4 * nvec;            // head + tail scalars per fan
-        for (int q = tid; q < cha * nsc; q += nthreads) {
+        for (int q = otid; q < cha * nsc; q += onth) {
             const int lp = (int)(((float)q + 0.5f) * inv_nsc), r = q - lp * nsc;
             const int k = r < head ? r : r + 4 * nvec;
             eobs[(int)L.plist[ip0 + lp] * O + col_lidar + k] = __uint_as_float(best[lp * NL + k]) * inv_range;
         }
     } else
-    for (int q = tid; q < ((COPO_PROFILE_SKIP & 4) ? 0 : nrays); q += nthreads) {
+    for (int q = otid; q < ((COPO_PROFILE_SKIP & 4) ? 0 : nrays); q += onth) {
         const int lp = (int)(((float)q + 0.5f) * inv_nl), k = q - lp * NL;
         eobs[(int)L.plist[ip0 + lp] * O + col_lidar + k] = __uint_as_float(best[q]) * inv_range;
     }
@@ -1023,7 +1040,7 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
     const int nb = p.side_lasers + p.lane_lasers;
     if ((PHASES & 4) && nb > 0) {
         const float inv_nb = 1.0f / (float)nb;
-        for (int q = tid; q < np * nb; q += nthreads) {
+        for (int q = otid; q < np * nb; q += onth) {
             const int ip = (int)(((float)q + 0.5f) * inv_nb), b = q - ip * nb;
             const int i = L.plist[ip];
             const bool side = b < p.side_lasers;
@@ -1490,8 +1507,13 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
     if (roles) {
         if (wave == 1) {
             int n_exact = 0;
-            const int why = neighbours_fast(p, L, e, lane, out, rec_roles, &n_exact);
-            if (lane == 0) L.nbr_ok = why == 0 ? 1 : 0;
+            unsigned long long ex = 0ull, odd = 0ull;
+            const int why = neighbours_fast(p, L, e, lane, out, rec_roles, &n_exact, &ex, &odd);
+            if (lane == 0) {
+                L.nbr_ok = why == 0 ? 1 : 0;
+                L.nbr_exact = ex;
+                L.nbr_odd = odd;
+            }
             if (p.dbg && lane == 0) p.dbg[(size_t)e * COPO_DBG_STRIDE + 7] = why ? 2 : (n_exact ? 16 + n_exact : 1);
             COPO_ROLE_STAMP(9);
         } else if (wave >= 2) {
@@ -1546,7 +1568,16 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
     COPO_STAMP(5);
     // ---- P5 (all threads): LiDAR + observation write-out -------------------------------------------
     if (roles) {
-        obs_phase<4>(p, L, e, tid, nthreads, out.obs);
+        // the agents whose neighbour lists the registers did not decide (<= NBR_EXACT_MAX, usually none): one each on waves
+        // 1 .. n, next to the write-out of the ray minima by the other waves
+        const unsigned long long ex = L.nbr_ok ? L.nbr_exact : 0ull;
+        const int n_ex = __popcll(ex);
+        obs_phase<4>(p, L, e, tid, nthreads, out.obs, 0, n_ex);
+        if (wave >= 1 && wave <= n_ex) {
+            unsigned long long m = ex;
+            for (int k = 1; k < wave; ++k) m &= m - 1ull;
+            neighbours_exact_one(p, e, lane, __ffsll((long long)m) - 1, L.x[lane], L.y[lane], L.rew[lane], L.m_present, L.nbr_odd, out);
+        }
         if (!L.nbr_ok) {            // the register formulation declined (ties, band cases, odd rewards): the pair-parallel lists, on the
             __syncthreads();        // work area that the ray minima no longer need
             neighbours_phase<EXT>(p, L, e, tid, nthreads, out, act, L.m_acted, ending);

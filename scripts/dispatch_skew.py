@@ -11,20 +11,35 @@ from copo_amd.sim import SimConfig, VecSim
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 from bench_sim import cruise_actions
 E, block = int(sys.argv[1]), int(sys.argv[2])
-sim = VecSim(SimConfig(map="intersection", num_envs=E, num_agents=40), with_info=False)
-sim.set_block(block)
-sim.out["nbr_dist"] = None
-sim._step_out = sim.make_step_out(sim.out)
-out = sim.reset()
-gen = torch.Generator(device="cuda").manual_seed(0)
-for i in range(250):
-    out = sim.step(cruise_actions(out["obs"], gen))
+LIVE = len(sys.argv) > 3 and sys.argv[3] == "live"          # the bench trainer's own scenes and policy instead of the lane-keeping controller
+if LIVE:
+    import bench
+    tr = bench.make_trainer(E, 40, graphs=False, pretrained=True)
+    for _ in range(3):
+        tr.train()
+    sim = tr.env.sim
+    sim.set_block(block)
+else:
+    sim = VecSim(SimConfig(map="intersection", num_envs=E, num_agents=40), with_info=False)
+    sim.set_block(block)
+    sim.out["nbr_dist"] = None
+    sim._step_out = sim.make_step_out(sim.out)
+    out = sim.reset()
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    for i in range(250):
+        out = sim.step(cruise_actions(out["obs"], gen))
 dbg = torch.zeros(E, 16, dtype=torch.int64, device="cuda")
 _capi.check(_capi.lib.copo_sim_set_debug(sim._h, dbg.data_ptr()))
-a = cruise_actions(out["obs"], gen)
-for rep in range(3):
+if not LIVE:
+    a = cruise_actions(out["obs"], gen)
+for rep in range(4):
     torch.cuda.synchronize()
-    sim.step(a); sim.step(a); sim.step(a)
+    if LIVE:
+        tr.sampler.sample()
+        out = {"flags": tr.sampler.flags[-1]}
+    else:
+        for _ in range(3):
+            out = sim.step(cruise_actions(out["obs"], gen))
     torch.cuda.synchronize()
     t0, t1 = dbg[:, 11].cpu().double() * 10e-3, dbg[:, 12].cpu().double() * 10e-3       # us
     base = t0.min()
@@ -41,7 +56,7 @@ for rep in range(3):
     for e in top:
         ph = [(d[e, k + 1] - d[e, k]).item() for k in range(6)]
         print("  scene %3d: %.2f us, phases (cycles) P0 %d P1 %d P2 %d P3 %d P4 %d P5 %d | lists %s | roles done w0 %d w1 %d lidar %d | present %d"
-              % (e, life[e], *ph, {1: "register", 2: "pair-parallel (order, band)", 3: "pair-parallel (rewards)"}.get(d[e, 7].item(), "?"), *[(d[e, k] - d[e, 4]).item() for k in (8, 9, 10)], pres[e]))
+              % (e, life[e], *ph, {1: "register", 2: "pair-parallel"}.get(d[e, 7].item(), "register + %d agents exactly" % (d[e, 7].item() - 16)), *[(d[e, k] - d[e, 4]).item() for k in (8, 9, 10)], pres[e]))
     dbg[:, 7:11] = 0
     import numpy as np
     dd = d.numpy()
