@@ -1170,6 +1170,8 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
 #define COPO_STAMP(i) do { if (p.dbg && tid == 0) p.dbg[(size_t)e * COPO_DBG_STRIDE + (i)] = (long long)clock64(); } while (0)
     COPO_STAMP(0);
     if ((COPO_PROFILE_SKIP & 512) && p.dbg && tid == 0) p.dbg[(size_t)e * 16 + 11] = (long long)wall_clock64();     // (100 MHz: the shader clock of the launch)
+    if ((COPO_PROFILE_SKIP & 512) && p.dbg && lane == 0 && !ONE)     // which SIMD runs which wave (HW_ID bits 5:4), 2 bits per wave
+        atomicOr(reinterpret_cast<unsigned long long*>(p.dbg) + (size_t)e * 16 + 13, (unsigned long long)__builtin_amdgcn_s_getreg(2308) << (2 * wave));
     // ---- P0 (wave 0): timers + kinematic bicycle, poses -> LDS ----------------------------------------
     Slot s = Slot{};
     bool acted = false;

@@ -58,8 +58,6 @@ for rep in range(4):
         print("  scene %3d: %.2f us, phases (cycles) P0 %d P1 %d P2 %d P3 %d P4 %d P5 %d | lists %s | roles done w0 %d w1 %d lidar %d | present %d"
               % (e, life[e], *ph, {1: "register", 2: "pair-parallel"}.get(d[e, 7].item(), "register + %d agents exactly" % (d[e, 7].item() - 16)), *[(d[e, k] - d[e, 4]).item() for k in (8, 9, 10)], pres[e]))
     dbg[:, 7:11] = 0
-    import numpy as np
-    dd = d.numpy()
-    for e in np.nonzero(dd[:, 13])[0][:6]:
-        print("  scene %d out-of-range rewards: largest |r| %g smallest %g" % (e, np.array([dd[e, 13]], np.uint32).view(np.float32)[0], np.array([0x7fffffff - dd[e, 14]], np.uint32).view(np.float32)[0]))
+    simd = d[:, 13]
+    print("  SIMD of waves 0..15 (scene 0, 1, 2):", [[(int(simd[k]) >> (2 * w)) & 3 for w in range(block // 64)] for k in range(3)])
     dbg[:, 11:16] = 0
