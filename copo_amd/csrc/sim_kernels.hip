@@ -132,10 +132,30 @@ __device__ __forceinline__ void spawn_pose(const SimParams& p, const float* rseg
 }
 
 // Spawn a fresh agent into this lane's slot at spawn slot sp.  `aid` is the env-wide id.
+// the random draws of the `cnt`-th spawn in slot n: route hash, LCF sample (LCFEnv._add_lcf: normal(mean, std) clipped to [-1, 1])
+__device__ __forceinline__ void spawn_draws(const SimParams& p, uint64_t seed, uint32_t episode, int n, uint32_t cnt,
+                                            uint32_t& h_route, float& lcf) {
+    h_route = hash_rng(seed, (uint32_t)n, cnt, episode, RNG_ROUTE);
+    lcf = 0.0f;
+    if (p.enable_lcf) {
+        const float u1 = uniform01(hash_rng(seed, (uint32_t)n, cnt, episode, RNG_LCF1));
+        const float u2 = uniform01(hash_rng(seed, (uint32_t)n, cnt, episode, RNG_LCF2));
+        float sn, cs;
+        sincos_det(kTwoPi * u2 - kPi, sn, cs);
+        const float z = sqrtf(-2.0f * log_det(u1)) * cs;
+        lcf = clipf(p.lcf_dist[0] + p.lcf_dist[1] * z, -1.0f, 1.0f);
+    }
+}
+
+// `pre`: the draws were made ahead of time (step kernel, several waves per scene: a wave that idles during P0 makes them for
+// every slot, so that a spawn costs wave 0 -- the critical path of the launch -- two LDS reads instead of ~200 instructions)
 __device__ __forceinline__ void spawn_slot(const SimParams& p, const float* rsegs, const int32_t* stab, const float* sps,
-                                           uint64_t seed, uint32_t episode, int n, int sp, int32_t aid, Slot& s) {
+                                           uint64_t seed, uint32_t episode, int n, int sp, int32_t aid, Slot& s,
+                                           bool pre = false, uint32_t pre_h = 0, float pre_lcf = 0.0f) {
     const uint32_t cnt = (uint32_t)s.spawncnt & 0xffffu;
-    const uint32_t h = hash_rng(seed, (uint32_t)n, cnt, episode, RNG_ROUTE);
+    uint32_t h = pre_h;
+    float lcf = pre_lcf;
+    if (!pre) spawn_draws(p, seed, episode, n, cnt, h, lcf);
     const int route = stab[sp * 4 + 0] + (int)(h % (uint32_t)stab[sp * 4 + 1]);
     const float* g = rsegs + (size_t)route * p.seg_rows * COPO_SEG_STRIDE;
     spawn_pose(p, rsegs, stab, sps, sp, s.x, s.y);
@@ -146,15 +166,6 @@ __device__ __forceinline__ void spawn_slot(const SimParams& p, const float* rseg
     s.route = route;
     s.status = st_pack(ST_ALIVE, 0, 0);
     s.aid = aid;
-    float lcf = 0.0f;
-    if (p.enable_lcf) {
-        const float u1 = uniform01(hash_rng(seed, (uint32_t)n, cnt, episode, RNG_LCF1));
-        const float u2 = uniform01(hash_rng(seed, (uint32_t)n, cnt, episode, RNG_LCF2));
-        float sn, cs;
-        sincos_det(kTwoPi * u2 - kPi, sn, cs);
-        const float z = sqrtf(-2.0f * log_det(u1)) * cs;
-        lcf = clipf(p.lcf_dist[0] + p.lcf_dist[1] * z, -1.0f, 1.0f);
-    }
     s.lcf = lcf;
     s.spawncnt = (int32_t)((cnt + 1) & 0xffffu);
 }
@@ -1147,6 +1158,9 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
     const int ctid = copy_apart ? tid - 64 : tid, cnth = copy_apart ? nthreads - 64 : nthreads;
     if (ctid >= 0) load_rays(p, L, ctid, cnth);
     float4* rec_roles = nullptr;
+    unsigned long long* spblk = nullptr;      // [COPO_MAX_SAFE] slot masks: who stands on respawn place q (filled during P1)
+    float* lcf_pre = nullptr;                 // [64] / [64]: the draws of each slot's NEXT spawn (filled by the last wave during P0)
+    uint32_t* hr_pre = nullptr;
     {   // route tables: a few KB read on every step by the projection / navigation code -> LDS copy when they fit
         // (the waves that idle during P0 do the copy; the barrier after P0 publishes it)
         extern __shared__ unsigned int dyn[];
@@ -1158,6 +1172,17 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
         float* sl = reinterpret_cast<float*>(tl + ntab);
         // (several waves per scene: 64 float4 records for neighbours_fast behind everything else -- the LiDAR minima are live then)
         rec_roles = reinterpret_cast<float4*>(stage ? reinterpret_cast<float*>(((reinterpret_cast<uintptr_t>(sl + nsp) + 15) & ~(uintptr_t)15)) : rl);
+        spblk = reinterpret_cast<unsigned long long*>(rec_roles + 64);
+        lcf_pre = reinterpret_cast<float*>(spblk + COPO_MAX_SAFE);
+        hr_pre = reinterpret_cast<uint32_t*>(lcf_pre + 64);
+        if (copy_apart && wave == nwaves - 1 && lane < N && !(COPO_PROFILE_SKIP & 32)) {
+            const uint32_t cnt = (uint32_t)reinterpret_cast<const int32_t*>(p.state)[(size_t)15 * p.E * N + (size_t)e * N + lane] & 0xffffu;
+            uint32_t h;
+            float lcf;
+            spawn_draws(p, p.seeds[e], (uint32_t)p.env[(size_t)e * 4 + 1], lane, cnt, h, lcf);
+            hr_pre[lane] = h;
+            lcf_pre[lane] = lcf;
+        }
         if (stage && ctid >= 0) {
             for (int q = ctid; q < nseg_f; q += cnth) rl[q] = p.route_segs[q];
             for (int q = ctid; q < nmeta_f; q += cnth) rl[nseg_f + q] = p.route_meta[q];
@@ -1324,7 +1349,6 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
     // several waves per scene: which vehicles stand in the region of respawn place q, as a slot mask per place, next to
     // the collision pairs -- P2 (wave 0 alone, on the critical path of a launch with one scene per
     // compute unit) then only ANDs the masks with the slots that are still solid
-    unsigned long long* spblk = reinterpret_cast<unsigned long long*>(rec_roles + 64);
     if (!ONE && nwaves > 1 && !(COPO_PROFILE_SKIP & 32)) {     // (places dealt from the last wave down: those have the fewest pairs)
         const float xj = L.x[lane], yj = L.y[lane], cj = L.cs[lane], sj = L.sn[lane];
         for (int q = nwaves - 1 - wave; q < p.n_safe; q += nwaves) {
@@ -1483,7 +1507,8 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
                     next_aid += 1;
                 }
                 if (my_q >= 0) {
-                    spawn_slot(p, L.rsegs, L.stab, L.sps, seed, (uint32_t)episode, lane, p.safe_ids[my_q], my_aid, s);
+                    if (copy_apart) spawn_slot(p, L.rsegs, L.stab, L.sps, seed, (uint32_t)episode, lane, p.safe_ids[my_q], my_aid, s, true, hr_pre[lane], lcf_pre[lane]);
+                    else spawn_slot(p, L.rsegs, L.stab, L.sps, seed, (uint32_t)episode, lane, p.safe_ids[my_q], my_aid, s);
                     present = true;
                     fl = COPO_F_SPAWNED;
                     lcf_row = s.lcf;
@@ -1632,8 +1657,8 @@ __global__ void __launch_bounds__(256) neighbours_kernel(const float* __restrict
 // [slots][rays] minima, ray table, one 64-entry strip per wave (box-test owners)
 static size_t lidar_lds_bytes(const SimParams& p, int block) {
     return (size_t)(lidar_lds_words(p.chunk, p.nbr_chunk, p.N, p.num_lasers) + ray_lds_words(p.num_lasers) + (block / 64) * LIDAR_WAVE_WORDS) * sizeof(unsigned int) +
-           (block > 64 ? 64 * sizeof(float4) + 16 + COPO_MAX_SAFE * sizeof(unsigned long long) : 0);       // (step kernel, several waves per
-                                                                                                      //  scene: the records of neighbours_fast, the blocker masks of the respawn places)
+           (block > 64 ? 64 * sizeof(float4) + 16 + COPO_MAX_SAFE * sizeof(unsigned long long) + 128 * sizeof(float) : 0);       // (step kernel, several waves per
+                                                                                                      //  scene: the records of neighbours_fast, the blocker masks of the respawn places, the spawn draws)
 }
 static bool sim_has_ext(const SimParams& p) { return p.col_tl >= 0 || p.col_comm >= 0; }
 static hipError_t sim_lds_attrs() {              // 64 slots x 256 rays + route tables exceed the default 64 KB
