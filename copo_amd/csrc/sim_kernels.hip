@@ -549,6 +549,7 @@ __device__ __forceinline__ void neighbours_exact_one(const SimParams& p, int e, 
 // K > 8, the communication block and the stateless op's filled rows take neighbours_phase as well.
 constexpr uint32_t NBR_SENT = 0xffffffffu;
 constexpr int NBR_EXACT_MAX = 6;
+template <bool PIPE = false>     // PIPE: the hand-pipelined walk (below) -- for the wave that has a SIMD to itself
 __device__ __forceinline__ int neighbours_fast(const SimParams& p, EnvLds& L, int e, int lane, const StepOut& out, float4* rec,
                                                int* n_exact, unsigned long long* defer_exact = nullptr,
                                                unsigned long long* defer_odd = nullptr) {
@@ -566,19 +567,25 @@ __device__ __forceinline__ int neighbours_fast(const SimParams& p, EnvLds& L, in
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const float r2lo = p.nbr_r2lo, r2hi = p.nbr_r2hi;
+    float r2lo = p.nbr_r2lo, r2hi = p.nbr_r2hi;
+    // (in vector registers before the walk starts: a scalar operand that came from memory makes the compiler wait for `lgkmcnt(0)`
+    //  inside the loop -- the counter the records' LDS reads use too)
+    if (PIPE) asm volatile("" : "+v"(r2lo), "+v"(r2hi));
     uint32_t a0 = NBR_SENT, a1 = NBR_SENT, a2 = NBR_SENT, a3 = NBR_SENT, a4 = NBR_SENT, a5 = NBR_SENT, a6 = NBR_SENT,
              a7 = NBR_SENT, a8 = NBR_SENT;
     double sum = 0.0, gs = 0.0;
     int cnt = 0;
     bool unc = false;
-    unsigned long long m = present;
-    int j = m ? __ffsll((long long)m) - 1 : 0;              // wave-uniform
-    float4 r = rec[j];
-    while (m) {
-        m &= m - 1ull;
-        const int jn = m ? __ffsll((long long)m) - 1 : j;
-        const float4 rn = rec[jn];                          // the next record is requested before this one is worked on
+    // The walk over the present agents.  PIPE: software-pipelined by hand -- the record of the NEXT agent is requested
+    // (ds_read_b128, inline: the optimiser otherwise sinks the load to where the record is used and every iteration waits out
+    // an LDS round trip) before the current one is worked on: 256 scenes 17.6 -> 17.3 us per launch.  With 26 scenes per compute
+    // unit other waves hide that latency and the two-copy loop only costs instructions (16 384 scenes: +1.3 %): plain loop there.
+    typedef float v4f32 __attribute__((ext_vector_type(4)));
+    const uint32_t rec_lds = (uint32_t)(uintptr_t)rec;        // byte offset of the records in LDS
+    auto request = [&](v4f32& dst, int jj) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(rec_lds + 16u * (uint32_t)jj)); };
+    // (the wait is tied to a0, the last value a walk step produces: it must not be scheduled ahead of the step it hides behind)
+    auto arrive = [&](v4f32& dst) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dst), "+v"(a0)); };
+    auto walk = [&](const v4f32& r, const int j) {            // j: wave-uniform
         const double rj = __hiloint2double(__float_as_int(r.w), __float_as_int(r.z));
         gs += rj;
         const float dx = xi - r.x, dy = yi - r.y;
@@ -586,16 +593,65 @@ __device__ __forceinline__ int neighbours_fast(const SimParams& p, EnvLds& L, in
         const bool other = j != lane;
         const bool in = other && d2 < r2lo, inhi = other && d2 < r2hi;
         unc |= in != inhi;
-        if (in) {
-            sum += rj;
-            cnt += 1;
-        }
+        sum = fma(in ? 1.0 : 0.0, rj, sum);                   // (exact: the product is rj or 0)
+        cnt += in ? 1 : 0;
         const uint32_t key = in ? ((__float_as_uint(d2) & ~63u) | (uint32_t)j) : NBR_SENT;
         a8 = umed3(a7, a8, key); a7 = umed3(a6, a7, key); a6 = umed3(a5, a6, key); a5 = umed3(a4, a5, key);
         a4 = umed3(a3, a4, key); a3 = umed3(a2, a3, key); a2 = umed3(a1, a2, key); a1 = umed3(a0, a1, key);
         a0 = a0 < key ? a0 : key;
-        j = jn;
-        r = rn;
+    };
+    unsigned long long m = present;
+    if (!PIPE) {
+        int j = m ? __ffsll((long long)m) - 1 : 0;              // wave-uniform
+        float4 r = rec[j];
+        while (m) {
+            m &= m - 1ull;
+            const int jn = m ? __ffsll((long long)m) - 1 : j;
+            const float4 rn = rec[jn];
+            const double rj = __hiloint2double(__float_as_int(r.w), __float_as_int(r.z));
+            gs += rj;
+            const float dx = xi - r.x, dy = yi - r.y;
+            const float d2 = __builtin_fmaf(dy, dy, dx * dx);
+            const bool other = j != lane;
+            const bool in = other && d2 < r2lo, inhi = other && d2 < r2hi;
+            unc |= in != inhi;
+            if (in) {
+                sum += rj;
+                cnt += 1;
+            }
+            const uint32_t key = in ? ((__float_as_uint(d2) & ~63u) | (uint32_t)j) : NBR_SENT;
+            a8 = umed3(a7, a8, key); a7 = umed3(a6, a7, key); a6 = umed3(a5, a6, key); a5 = umed3(a4, a5, key);
+            a4 = umed3(a3, a4, key); a3 = umed3(a2, a3, key); a2 = umed3(a1, a2, key); a1 = umed3(a0, a1, key);
+            a0 = a0 < key ? a0 : key;
+            j = jn;
+            r = rn;
+        }
+    } else if (m) {
+        v4f32 ra, rb;
+        int ja = __ffsll((long long)m) - 1, jb = 0;
+        m &= m - 1ull;
+        request(ra, ja);
+        arrive(ra);
+        for (;;) {
+            const bool more_b = m != 0ull;
+            if (more_b) {
+                jb = __ffsll((long long)m) - 1;
+                m &= m - 1ull;
+                request(rb, jb);
+            }
+            walk(ra, ja);
+            if (!more_b) break;
+            arrive(rb);
+            const bool more_a = m != 0ull;
+            if (more_a) {
+                ja = __ffsll((long long)m) - 1;
+                m &= m - 1ull;
+                request(ra, ja);
+            }
+            walk(rb, jb);
+            if (!more_a) break;
+            arrive(ra);
+        }
     }
     // mean-field count from the keys (the 9 nearest), order check of adjacent keys
     const uint32_t ak[9] = {a0, a1, a2, a3, a4, a5, a6, a7, a8};
@@ -1541,7 +1597,7 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
         if (wave == 1) {
             int n_exact = 0;
             unsigned long long ex = 0ull, odd = 0ull;
-            const int why = neighbours_fast(p, L, e, lane, out, rec_roles, &n_exact, &ex, &odd);
+            const int why = neighbours_fast<true>(p, L, e, lane, out, rec_roles, &n_exact, &ex, &odd);
             if (lane == 0) {
                 L.nbr_ok = why == 0 ? 1 : 0;
                 L.nbr_exact = ex;
