@@ -183,8 +183,8 @@ struct __align__(16) EnvLds {
     const int32_t* stab;       // spawn table, same
     const float* sps;          // spawn offsets, same
     int32_t ending;
-    int32_t nbr_ok;            // wave-role step: the register formulation of the neighbour lists went through
-    unsigned long long nbr_exact, nbr_odd;   // ... except for these agents (evaluated exactly next to the LiDAR write-out) / slots with odd rewards
+    unsigned long long nbr_exact, nbr_exact2, nbr_odd;   // wave roles: agents the two neighbour waves could not decide (evaluated exactly next
+                                                         // to the LiDAR write-out) / slots with odd rewards
     int32_t seg_rows;          // road records per route in the device tables (longest route + its terminal record)
 };
 
@@ -529,8 +529,7 @@ __device__ __forceinline__ void neighbours_exact_one(const SimParams& p, int e, 
 
 // Neighbour lists + reward reductions of one scene by ONE wave, lane = slot: the same results as neighbours_phase, bit for
 // bit.  Returns 0 when the scene is done -- `*n_exact` agents of it through neighbours_exact_one -- or 2 (nothing written)
-// when more than NBR_EXACT_MAX agents would need that: the caller then runs neighbours_phase.  With `defer_exact` those
-// agents are not evaluated but handed back (slot mask, with the mask of slots with odd rewards) for the caller to do it.
+// when more than NBR_EXACT_MAX agents would need that: the caller then runs neighbours_phase.
 //
 // Every lane walks the present agents j in slot order (the record {x, y, (double) reward} of j is one broadcast LDS read)
 // and keeps, in registers: the count and the fp64 reward sum of the agents within `neighbours_distance`, and the 9 smallest
@@ -549,10 +548,8 @@ __device__ __forceinline__ void neighbours_exact_one(const SimParams& p, int e, 
 // K > 8, the communication block and the stateless op's filled rows take neighbours_phase as well.
 constexpr uint32_t NBR_SENT = 0xffffffffu;
 constexpr int NBR_EXACT_MAX = 6;
-template <bool PIPE = false>     // PIPE: the hand-pipelined walk (below) -- for the wave that has a SIMD to itself
 __device__ __forceinline__ int neighbours_fast(const SimParams& p, EnvLds& L, int e, int lane, const StepOut& out, float4* rec,
-                                               int* n_exact, unsigned long long* defer_exact = nullptr,
-                                               unsigned long long* defer_odd = nullptr) {
+                                               int* n_exact) {
     const int N = p.N, K = p.K;
     const unsigned long long present = L.m_present;
     const bool me = (present >> lane) & 1ull;
@@ -567,25 +564,19 @@ __device__ __forceinline__ int neighbours_fast(const SimParams& p, EnvLds& L, in
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    float r2lo = p.nbr_r2lo, r2hi = p.nbr_r2hi;
-    // (in vector registers before the walk starts: a scalar operand that came from memory makes the compiler wait for `lgkmcnt(0)`
-    //  inside the loop -- the counter the records' LDS reads use too)
-    if (PIPE) asm volatile("" : "+v"(r2lo), "+v"(r2hi));
+    const float r2lo = p.nbr_r2lo, r2hi = p.nbr_r2hi;
     uint32_t a0 = NBR_SENT, a1 = NBR_SENT, a2 = NBR_SENT, a3 = NBR_SENT, a4 = NBR_SENT, a5 = NBR_SENT, a6 = NBR_SENT,
              a7 = NBR_SENT, a8 = NBR_SENT;
     double sum = 0.0, gs = 0.0;
     int cnt = 0;
     bool unc = false;
-    // The walk over the present agents.  PIPE: software-pipelined by hand -- the record of the NEXT agent is requested
-    // (ds_read_b128, inline: the optimiser otherwise sinks the load to where the record is used and every iteration waits out
-    // an LDS round trip) before the current one is worked on: 256 scenes 17.6 -> 17.3 us per launch.  With 26 scenes per compute
-    // unit other waves hide that latency and the two-copy loop only costs instructions (16 384 scenes: +1.3 %): plain loop there.
-    typedef float v4f32 __attribute__((ext_vector_type(4)));
-    const uint32_t rec_lds = (uint32_t)(uintptr_t)rec;        // byte offset of the records in LDS
-    auto request = [&](v4f32& dst, int jj) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(rec_lds + 16u * (uint32_t)jj)); };
-    // (the wait is tied to a0, the last value a walk step produces: it must not be scheduled ahead of the step it hides behind)
-    auto arrive = [&](v4f32& dst) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dst), "+v"(a0)); };
-    auto walk = [&](const v4f32& r, const int j) {            // j: wave-uniform
+    unsigned long long m = present;
+    int j = m ? __ffsll((long long)m) - 1 : 0;              // wave-uniform
+    float4 r = rec[j];
+    while (m) {
+        m &= m - 1ull;
+        const int jn = m ? __ffsll((long long)m) - 1 : j;
+        const float4 rn = rec[jn];
         const double rj = __hiloint2double(__float_as_int(r.w), __float_as_int(r.z));
         gs += rj;
         const float dx = xi - r.x, dy = yi - r.y;
@@ -593,65 +584,16 @@ __device__ __forceinline__ int neighbours_fast(const SimParams& p, EnvLds& L, in
         const bool other = j != lane;
         const bool in = other && d2 < r2lo, inhi = other && d2 < r2hi;
         unc |= in != inhi;
-        sum = fma(in ? 1.0 : 0.0, rj, sum);                   // (exact: the product is rj or 0)
-        cnt += in ? 1 : 0;
+        if (in) {
+            sum += rj;
+            cnt += 1;
+        }
         const uint32_t key = in ? ((__float_as_uint(d2) & ~63u) | (uint32_t)j) : NBR_SENT;
         a8 = umed3(a7, a8, key); a7 = umed3(a6, a7, key); a6 = umed3(a5, a6, key); a5 = umed3(a4, a5, key);
         a4 = umed3(a3, a4, key); a3 = umed3(a2, a3, key); a2 = umed3(a1, a2, key); a1 = umed3(a0, a1, key);
         a0 = a0 < key ? a0 : key;
-    };
-    unsigned long long m = present;
-    if (!PIPE) {
-        int j = m ? __ffsll((long long)m) - 1 : 0;              // wave-uniform
-        float4 r = rec[j];
-        while (m) {
-            m &= m - 1ull;
-            const int jn = m ? __ffsll((long long)m) - 1 : j;
-            const float4 rn = rec[jn];
-            const double rj = __hiloint2double(__float_as_int(r.w), __float_as_int(r.z));
-            gs += rj;
-            const float dx = xi - r.x, dy = yi - r.y;
-            const float d2 = __builtin_fmaf(dy, dy, dx * dx);
-            const bool other = j != lane;
-            const bool in = other && d2 < r2lo, inhi = other && d2 < r2hi;
-            unc |= in != inhi;
-            if (in) {
-                sum += rj;
-                cnt += 1;
-            }
-            const uint32_t key = in ? ((__float_as_uint(d2) & ~63u) | (uint32_t)j) : NBR_SENT;
-            a8 = umed3(a7, a8, key); a7 = umed3(a6, a7, key); a6 = umed3(a5, a6, key); a5 = umed3(a4, a5, key);
-            a4 = umed3(a3, a4, key); a3 = umed3(a2, a3, key); a2 = umed3(a1, a2, key); a1 = umed3(a0, a1, key);
-            a0 = a0 < key ? a0 : key;
-            j = jn;
-            r = rn;
-        }
-    } else if (m) {
-        v4f32 ra, rb;
-        int ja = __ffsll((long long)m) - 1, jb = 0;
-        m &= m - 1ull;
-        request(ra, ja);
-        arrive(ra);
-        for (;;) {
-            const bool more_b = m != 0ull;
-            if (more_b) {
-                jb = __ffsll((long long)m) - 1;
-                m &= m - 1ull;
-                request(rb, jb);
-            }
-            walk(ra, ja);
-            if (!more_b) break;
-            arrive(rb);
-            const bool more_a = m != 0ull;
-            if (more_a) {
-                ja = __ffsll((long long)m) - 1;
-                m &= m - 1ull;
-                request(ra, ja);
-            }
-            walk(rb, jb);
-            if (!more_a) break;
-            arrive(ra);
-        }
+        j = jn;
+        r = rn;
     }
     // mean-field count from the keys (the 9 nearest), order check of adjacent keys
     const uint32_t ak[9] = {a0, a1, a2, a3, a4, a5, a6, a7, a8};
@@ -714,14 +656,109 @@ __device__ __forceinline__ int neighbours_fast(const SimParams& p, EnvLds& L, in
                 }
         }
     }
-    if (defer_exact) {                                          // (the caller spreads them over waves)
-        *defer_exact = exact;
-        *defer_odd = odd;
-        return 0;
-    }
     for (unsigned long long mx = exact; mx; mx &= mx - 1ull)        // (rare) the agents that the registers do not decide
         neighbours_exact_one(p, e, lane, __ffsll((long long)mx) - 1, xi, yi, rw, present, odd, out);
     return 0;
+}
+
+// The register formulation for the step kernel's wave roles (several waves per scene), split over TWO waves.  Two things are
+// different from neighbours_fast, where 26 scenes per compute unit hide every latency: (i) the record of agent j comes out of
+// lane j's registers (v_readlane), not out of LDS -- next to 13 waves of LiDAR atomics and permutes an LDS round trip takes
+// ~300 cycles, and a walk step waited one out whatever it computed (neighbour wave done 9.2k -> 6.4k cycles after P3, 256-scene
+// launch 17.3 -> 16.1 us); (ii) the walk is the longest single-wave stretch of such a launch, so two waves share it:
+//   PART 1: range decisions, counts, fp64 reward sums, the global reward    -> nbr_cnt, nei_rew, glob_rew
+//   PART 2: the nine smallest keys                                           -> mf_cnt, nbr_idx, nbr_dist
+// Both walk all present agents and write the rows their registers prove; each hands back the agents it cannot decide, the caller
+// evaluates the union exactly (neighbours_exact_one rewrites every field of such an agent) or falls back for the scene.
+template <int PART>
+__device__ __forceinline__ unsigned long long neighbours_roles(const SimParams& p, EnvLds& L, int e, int lane, const StepOut& out,
+                                                               unsigned long long* odd_out) {
+    const int N = p.N, K = p.K;
+    const unsigned long long present = L.m_present;
+    const bool me = (present >> lane) & 1ull;
+    const int np = __popcll(present);
+    const float xi = L.x[lane], yi = L.y[lane], rw = L.rew[lane];
+    const float arw = fabsf(rw);
+    const unsigned long long odd = __ballot(me && !(rw == 0.0f || (arw >= 9.5367431640625e-07f && arw <= 16.0f)));
+    float r2lo = p.nbr_r2lo, r2hi = p.nbr_r2hi;
+    uint32_t a0 = NBR_SENT, a1 = NBR_SENT, a2 = NBR_SENT, a3 = NBR_SENT, a4 = NBR_SENT, a5 = NBR_SENT, a6 = NBR_SENT,
+             a7 = NBR_SENT, a8 = NBR_SENT;
+    double sum = 0.0, gs = 0.0;
+    int cnt = 0;
+    bool unc = false;
+    // the record of agent j comes out of lane j's registers (v_readlane into scalar operands), not out of LDS: next to 13 waves
+    // of LiDAR atomics and permutes an LDS round trip takes ~300 cycles, and a walk step waited one out whatever it computed
+    for (unsigned long long m = present; m; m &= m - 1ull) {
+        const int j = __ffsll((long long)m) - 1;
+        const float xj = readlane_f(xi, j), yj = readlane_f(yi, j);
+        const float dx = xi - xj, dy = yi - yj;
+        const float d2 = __builtin_fmaf(dy, dy, dx * dx);
+        const bool other = j != lane;
+        const bool in = other && d2 < r2lo;
+        if (PART == 1) {
+            const double rj = (double)readlane_f(rw, j);
+            gs += rj;
+            const bool inhi = other && d2 < r2hi;
+            unc |= in != inhi;
+            sum = fma(in ? 1.0 : 0.0, rj, sum);
+            cnt += in ? 1 : 0;
+        } else {
+            const uint32_t key = in ? ((__float_as_uint(d2) & ~63u) | (uint32_t)j) : NBR_SENT;
+            a8 = umed3(a7, a8, key); a7 = umed3(a6, a7, key); a6 = umed3(a5, a6, key); a5 = umed3(a4, a5, key);
+            a4 = umed3(a3, a4, key); a3 = umed3(a2, a3, key); a2 = umed3(a1, a2, key); a1 = umed3(a0, a1, key);
+            a0 = a0 < key ? a0 : key;
+        }
+    }
+    const size_t base = (size_t)e * N;
+    if (PART == 1) {
+        for (unsigned long long mo = odd; mo; mo &= mo - 1ull) {          // (rare) a reward outside the exact-sum range: who has it in range?
+            const int b = __ffsll((long long)mo) - 1;
+            const float dx = xi - readlane_f(xi, b), dy = yi - readlane_f(yi, b);
+            unc |= b != lane && __builtin_fmaf(dy, dy, dx * dx) < r2hi;
+        }
+        if (lane == 0 && out.glob_rew) out.glob_rew[e] = np ? (float)(gs / (double)np) : 0.0f;
+        if (lane < N && !(me && unc)) {
+            if (out.nbr_cnt) out.nbr_cnt[base + lane] = me ? cnt : 0;
+            if (out.nei_rew) out.nei_rew[base + lane] = (me && cnt) ? (float)(sum / (double)cnt) : 0.0f;
+        }
+        *odd_out = odd;
+        return __ballot(me && unc);
+    }
+    const uint32_t ak[9] = {a0, a1, a2, a3, a4, a5, a6, a7, a8};
+    const uint32_t tlo = p.mf_key_lo, thi = p.mf_key_hi;
+    int mf = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        mf += ak[k] < tlo ? 1 : 0;
+        unc |= ak[k] >= tlo && ak[k] < thi;
+    }
+    unc |= a8 < thi;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) unc |= (ak[k + 1] != NBR_SENT) && (ak[k + 1] - ak[k] < 128u);
+    if (lane < N && !(me && unc) && out.mf_cnt) out.mf_cnt[base + lane] = me ? mf : 0;
+    if (me && !unc) {
+        if (out.nbr_idx) {
+            int32_t* row = out.nbr_idx + (base + lane) * K;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k < K) row[k] = ak[k] != NBR_SENT ? (int)(ak[k] & 63u) : -1;
+        }
+        if (out.nbr_dist) {
+            float* row = out.nbr_dist + (base + lane) * K;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k < K) {
+                    float dv = 0.0f;
+                    if (ak[k] != NBR_SENT) {
+                        const int j = (int)(ak[k] & 63u);
+                        const double dx = (double)xi - (double)L.x[j], dy = (double)yi - (double)L.y[j];
+                        dv = (float)sqrt(dx * dx + dy * dy);
+                    }
+                    row[k] = dv;
+                }
+        }
+    }
+    return __ballot(me && unc);
 }
 
 template <bool EXT>
@@ -1595,18 +1632,20 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
     // ---- P3 (all waves): neighbour lists + reward reductions on the post-step (pre-reset) scene ---
     if (roles) {
         if (wave == 1) {
-            int n_exact = 0;
-            unsigned long long ex = 0ull, odd = 0ull;
-            const int why = neighbours_fast<true>(p, L, e, lane, out, rec_roles, &n_exact, &ex, &odd);
+            unsigned long long odd = 0ull;
+            const unsigned long long ex = neighbours_roles<1>(p, L, e, lane, out, &odd);
             if (lane == 0) {
-                L.nbr_ok = why == 0 ? 1 : 0;
                 L.nbr_exact = ex;
                 L.nbr_odd = odd;
             }
-            if (p.dbg && lane == 0) p.dbg[(size_t)e * COPO_DBG_STRIDE + 7] = why ? 2 : (n_exact ? 16 + n_exact : 1);
             COPO_ROLE_STAMP(9);
-        } else if (wave >= 2) {
-            obs_phase<2>(p, L, e, tid, nthreads, out.obs, 2);
+        } else if (wave == 2) {
+            unsigned long long odd = 0ull;
+            const unsigned long long ex = neighbours_roles<2>(p, L, e, lane, out, &odd);
+            if (lane == 0) L.nbr_exact2 = ex;
+            COPO_ROLE_STAMP(9);
+        } else if (wave >= 3) {
+            obs_phase<2>(p, L, e, tid, nthreads, out.obs, 3);
             COPO_ROLE_STAMP(10);
         }
     } else if (!(COPO_PROFILE_SKIP & 1)) neighbours_any<EXT>(p, L, e, tid, nthreads, out, act, L.m_acted, ending);
@@ -1659,15 +1698,18 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
     if (roles) {
         // the agents whose neighbour lists the registers did not decide (<= NBR_EXACT_MAX, usually none): one each on waves
         // 1 .. n, next to the write-out of the ray minima by the other waves
-        const unsigned long long ex = L.nbr_ok ? L.nbr_exact : 0ull;
+        const unsigned long long ex_all = L.nbr_exact | L.nbr_exact2;
+        const bool nbr_ok = __popcll(ex_all) <= NBR_EXACT_MAX;
+        const unsigned long long ex = nbr_ok ? ex_all : 0ull;
         const int n_ex = __popcll(ex);
+        if (p.dbg && tid == 0) p.dbg[(size_t)e * COPO_DBG_STRIDE + 7] = !nbr_ok ? 2 : (n_ex ? 16 + n_ex : 1);
         obs_phase<4>(p, L, e, tid, nthreads, out.obs, 0, n_ex);
         if (wave >= 1 && wave <= n_ex) {
             unsigned long long m = ex;
             for (int k = 1; k < wave; ++k) m &= m - 1ull;
             neighbours_exact_one(p, e, lane, __ffsll((long long)m) - 1, L.x[lane], L.y[lane], L.rew[lane], L.m_present, L.nbr_odd, out);
         }
-        if (!L.nbr_ok) {            // the register formulation declined (ties, band cases, odd rewards): the pair-parallel lists, on the
+        if (!nbr_ok) {              // the register formulation declined (ties, band cases, odd rewards): the pair-parallel lists, on the
             __syncthreads();        // work area that the ray minima no longer need
             neighbours_phase<EXT>(p, L, e, tid, nthreads, out, act, L.m_acted, ending);
         }
