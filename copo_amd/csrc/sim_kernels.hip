@@ -1012,6 +1012,7 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
     const int ncombo = cha * ns;
     // everything per batch of 64 (fan, vehicle) pairs: window, numbering of the box tests, the tests themselves
     auto pair_batch = [&](const bool live, const int lp, const int i, const int j) {
+        const float ci = L.cs[i], si = L.sn[i], cj = L.cs[j], sj = L.sn[j];      // (all eight pose reads in one LDS round trip)
         const float dx = L.x[j] - L.x[i], dy = L.y[j] - L.y[i];
         const float d2 = dx * dx + dy * dy;
         int klo = 0, cnt = 0;
@@ -1019,7 +1020,6 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
             if (d2 <= circ * circ * 1.002f) {
                 cnt = NL;                         // origin inside the circumcircle: any ray may hit
             } else {
-                const float ci = L.cs[i], si = L.sn[i];
                 const float phi = p.ray_sign * atan2_window(ci * dy - si * dx, ci * dx + si * dy);   // in beam-index direction
                 const float rd = __builtin_amdgcn_rsqf(d2);
                 const float x = circ * rd;
@@ -1027,7 +1027,7 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
                 // tighter for a box seen from outside its own length: every point of it lies at least d - h_par along the
                 // line of sight and at most h_perp beside it (extents of the box along / across that line), so the
                 // half-angle is below h_perp / (d - h_par) -- a vehicle seen end-on is 0.93 m wide, not 2.44
-                const float ux = dx * rd, uy = dy * rd, cj = L.cs[j], sj = L.sn[j];
+                const float ux = dx * rd, uy = dy * rd;
                 const float ca = fabsf(cj * ux + sj * uy), sa = fabsf(cj * uy - sj * ux);
                 const float h_perp = hl * sa + hw * ca, along = d2 * rd - (hl * ca + hw * sa);
                 if (along > 0.5f) w = fminf(w, h_perp * __builtin_amdgcn_rcpf(along) * 1.0001f);
@@ -1045,7 +1045,6 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
         // the pair's record for its box tests (registers of this lane, fetched by the test lanes with ds_bpermute -- no LDS
         // storage: a strip of records per wave cost more in resident scenes than it saved in instructions): ray origin in
         // j's box frame, rotation from i's frame into it, first ray / first test (klo - excl: 24 bits signed, local fan: 6)
-        const float ci = L.cs[i], si = L.sn[i], cj = L.cs[j], sj = L.sn[j];
         const float rec_ox = -(dx * cj + dy * sj), rec_oy = -(dy * cj - dx * sj);
         const float rec_cr = ci * cj + si * sj, rec_sr = ci * sj - si * cj;
         const int rec_ix = ((klo - excl) & 0xffffff) | (lp << 24);      // ray of test t = (klo - excl + t) mod NL
