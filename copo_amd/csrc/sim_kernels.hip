@@ -1105,6 +1105,47 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
             const int lp = (int)(((float)c + 0.5f) * inv_ns);
             pair_batch(live, lp, L.plist[ip0 + lp], L.slist[c - lp * ns]);
         }
+    } else if (wave_lo > 0) {
+        // wave roles: a wave takes its (fan, vehicle) pairs two batches of 64 at a time, keeps the ones within LiDAR reach (about a
+        // quarter at a junction) and, when they fit one batch, pushes them together across the lanes (ds_permute) -- the window
+        // arithmetic and its LDS round trips then run once instead of twice
+        const int nact = nwaves - wave_lo;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        for (int c0 = (wave - wave_lo) * 128; c0 < ((COPO_PROFILE_SKIP & 2) || wave < wave_lo ? 0 : ncombo); c0 += nact * 128) {
+            int cc[2], ii[2], jj[2];
+            bool rr[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = c0 + 64 * h + lane;
+                const bool valid = c < ncombo;
+                const int lp = valid ? (int)(((float)c + 0.5f) * inv_ns) : 0;
+                cc[h] = c;
+                ii[h] = L.plist[ip0 + lp];
+                jj[h] = L.slist[valid ? c - lp * ns : 0];
+                rr[h] = valid;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float dx = L.x[jj[h]] - L.x[ii[h]], dy = L.y[jj[h]] - L.y[ii[h]];
+                rr[h] = rr[h] && jj[h] != ii[h] && !(dx * dx + dy * dy > lim * lim);
+            }
+            const unsigned long long m0 = __ballot(rr[0]), m1 = __ballot(rr[1]);
+            const int n0 = __popcll(m0), n1 = __popcll(m1);
+            if (n0 + n1 <= 63) {            // one batch: lane r takes the r-th pair in reach (lanes out of reach push to lane 63, which is not used)
+                const int p0 = __builtin_amdgcn_ds_permute((rr[0] ? __popcll(m0 & lt) : 63) << 2, cc[0]);
+                const int p1 = __builtin_amdgcn_ds_permute((rr[1] ? n0 + __popcll(m1 & lt) : 63) << 2, cc[1]);
+                const bool live = lane < n0 + n1;
+                const int c = live ? (lane < n0 ? p0 : p1) : 0;
+                const int lp = (int)(((float)c + 0.5f) * inv_ns);
+                if (n0 + n1 > 0) pair_batch(live, lp, L.plist[ip0 + lp], L.slist[c - lp * ns]);
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int lp = (int)(((float)(rr[h] ? cc[h] : 0) + 0.5f) * inv_ns);
+                    if (h == 0 ? n0 > 0 : n1 > 0) pair_batch(rr[h], lp, ii[h], jj[h]);
+                }
+            }
+        }
     } else {
         for (int c0 = (wave - wave_lo) * 64; c0 < ((COPO_PROFILE_SKIP & 2) || wave < wave_lo ? 0 : ncombo); c0 += (nwaves - wave_lo) * 64) {
             const int c = c0 + lane;
