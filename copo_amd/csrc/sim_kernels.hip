@@ -1348,6 +1348,10 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
         seed = p.seeds[e];
         if (lane < N) {
             load_slot(p, e, lane, s);
+            if ((COPO_PROFILE_SKIP & 512) && p.dbg) {        // when have P0's loads arrived?  (slot 14: cycles after stamp 0)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) p.dbg[(size_t)e * 16 + 14] = (long long)clock64() - p.dbg[(size_t)e * 16 + 0];
+            }
             const int st = st_status(s.status);
             int tm = st_timer(s.status);
             acted = (st == ST_ALIVE);

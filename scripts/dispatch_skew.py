@@ -58,6 +58,7 @@ for rep in range(4):
         print("  scene %3d: %.2f us, phases (cycles) P0 %d P1 %d P2 %d P3 %d P4 %d P5 %d | lists %s | roles done w0 %d w1 %d lidar %d | present %d"
               % (e, life[e], *ph, {1: "register", 2: "pair-parallel"}.get(d[e, 7].item(), "register + %d agents exactly" % (d[e, 7].item() - 16)), *[(d[e, k] - d[e, 4]).item() for k in (8, 9, 10)], pres[e]))
     dbg[:, 7:11] = 0
+    print("  P0: state loads arrived %.0f cycles after the kernel's first stamp (mean over scenes)" % d[:, 14].double().mean().item())
     simd = d[:, 13]
     print("  SIMD of waves 0..15 (scene 0, 1, 2):", [[(int(simd[k]) >> (2 * w)) & 3 for w in range(block // 64)] for k in range(3)])
     dbg[:, 11:16] = 0
