@@ -972,7 +972,8 @@ __device__ __forceinline__ float atan2_window(float v, float u) {
 // the exhaustive test of the oracle gives them.
 // `phases`: 1 = initialise the ray minima, 2 = window / box-test work, 4 = write-out (+ detector beams); all of them (7) is the
 // whole phase.  The step kernel of the many-waves-per-scene shape runs them apart (wave roles): 2 on waves >= `wave_lo` only
-// while waves 0 / 1 write the state back and build the neighbour lists; 4 starts with a workgroup barrier.
+// while waves 0 / 1 / 2 write the state back and build the neighbour lists; 4 starts with a workgroup barrier (waves 1 .. idle_n
+// only pass it).
 template <int PHASES = 7>
 __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, int tid, int nthreads,
                                           float* __restrict__ obs, int wave_lo = 0, int idle_n = 0) {
@@ -1506,8 +1507,8 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
     bool present = false;
     COPO_STAMP(2);
     // Wave roles after P2 (8 / 16 waves per scene, i.e. few scenes per launch, where a launch is latency-bound): wave 0 writes the
-    // state back (P4), wave 1 builds the neighbour lists in registers (neighbours_fast), waves 2.. run the LiDAR windows / box tests;
-    // then everybody writes the LiDAR columns.  The ray minima are initialised here, by the waves that idle during P2.
+    // state back (P4), waves 1 and 2 build the neighbour lists in registers (neighbours_roles: counts + sums / keys), waves 3.. run the
+    // LiDAR windows / box tests; then everybody writes the LiDAR columns, except the waves that evaluate an undecided agent's lists.  The ray minima are initialised here, by the waves that idle during P2.
     const bool roles_ok = !ONE && nwaves >= 8 && p.nbr_fast && out.obs != nullptr && !(EXT && p.col_comm >= 0) && !(COPO_PROFILE_SKIP & 0x187);
     if (roles_ok && wave != 0) {
         extern __shared__ unsigned int dyn[];
