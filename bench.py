@@ -187,12 +187,15 @@ def measure_sim_kernel_saturated(trainer, scenes=16384, launches=60, policy="cru
 
 
 def kernel_source_hash():
-    """sha1 over the simulator kernel sources: a committed PMC traffic figure is only quoted for the code it was taken on."""
+    """sha1 over the simulator kernel sources: a committed PMC traffic figure is only quoted for the code it was taken on
+    (the CODE: `//` comments and white space are left out, so that a reworded comment does not orphan a measurement)."""
     import hashlib
+    import re
     h = hashlib.sha1()
     for f in ("sim_kernels.hip", "sim_common.h", "sim_math.h"):
-        with open(os.path.join(ROOT, "copo_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
+        with open(os.path.join(ROOT, "copo_amd", "csrc", f), "r") as fh:
+            text = re.sub(r"//[^\n]*", "", fh.read())
+        h.update("".join(text.split()).encode())
     return h.hexdigest()[:16]
 
 
