@@ -380,6 +380,76 @@ def cpu_sim_only(num_agents, threads, scenes_per_thread=16, steps=40):
     return sum(counts) / dt
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n, argv, cpu_only=False):
+    """`python bench.py --gpus N` as ONE command: start N copies of this script, one per GPU, with the env rendezvous the
+    driver's `torch.distributed.run` form uses (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT); their stdout
+    and stderr pass through (rank 0 prints the JSON line).  Fails -- never runs on fewer GPUs -- when the node has fewer
+    than N devices.  COPO_BENCH_SHARE_DEVICE=1 (tests on a one-GPU box): every rank uses device 0 and the collectives go
+    over gloo, which unlike RCCL accepts several ranks on one device.  Returns the exit code."""
+    import subprocess
+    share = os.environ.get("COPO_BENCH_SHARE_DEVICE", "0") == "1"
+    if not cpu_only:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < (1 if share else n):
+            print("bench.py --gpus %d: this node answers with %d GPU(s); refusing to run on fewer" % (n, have), file=sys.stderr)
+            return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0" if (share or cpu_only) else str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        if share or cpu_only:
+            env["COPO_DIST_BACKEND"] = "gloo"
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, cwd=ROOT))
+    rc = 0
+    try:
+        alive = list(procs)
+        while alive:
+            for p in list(alive):
+                try:
+                    r = p.wait(timeout=0.5)
+                except subprocess.TimeoutExpired:
+                    continue
+                alive.remove(p)
+                if r != 0 and rc == 0:
+                    rc = r
+                    for q in alive:      # a rank died: its partners would wait in a collective for ever -- stop exactly them
+                        q.terminate()
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def rendezvous_only(D, args):
+    """`--rendezvous-only`: the ranks of `--gpus N` meet over gloo on the host (no GPU touched), add up their rank numbers and
+    rank 0 prints the head of the result line -- the launcher and the env rendezvous checked where there is no GPU."""
+    import torch.distributed as td
+    os.environ["COPO_DIST_BACKEND"] = "gloo"
+    rank, local_rank, world = D.init_from_env("cpu")
+    if world != args.gpus:
+        sys.exit("bench.py --gpus %d was started with WORLD_SIZE=%d" % (args.gpus, world))
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    if world > 1:
+        td.all_reduce(t)
+        td.barrier()
+    assert float(t.item()) == world * (world + 1) / 2
+    if rank == 0:
+        print(json.dumps({"metric": "agent-env-steps/sec (sim+learn), Intersection 40-agent", "value": None, "n_gpus": world,
+                          "rendezvous": "ok", "config": {"parallelism": "dp%d" % world}}), flush=True)
+    D.shutdown()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -397,11 +467,26 @@ def main():
     ap.add_argument("--saturated-only", action="store_true",
                     help="ONLY the saturated simulator-kernel measurement (16 384 populated scenes, recorded replay) and one small "
                          "JSON line: the command scripts/prof_sim_r03.sh profiles")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="start the ranks of --gpus N, let them meet over gloo on the host and print the head of the line: "
+                         "checks the launcher where there is no GPU")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.rendezvous_only):
+        # one command, N ranks: this process only launches them (the driver's `torch.distributed.run` form arrives with
+        # WORLD_SIZE set and skips this)
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:], cpu_only=args.rendezvous_only))
     from copo_amd import dist as D
+    if args.rendezvous_only:
+        rendezvous_only(D, args)
+        return
     rank, local_rank, world = D.init_from_env()
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        sys.exit("bench.py --gpus %d was started with WORLD_SIZE=%d: launch it with torch.distributed.run --nproc-per-node %d "
+                 "(or without WORLD_SIZE in the environment: it then starts its own ranks)" % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available() or local_rank >= torch.cuda.device_count():
+        sys.exit("bench.py: rank %d wants GPU %d, this node answers with %d device(s) -- not falling back to fewer GPUs"
+                 % (rank, local_rank, torch.cuda.device_count() if torch.cuda.is_available() else 0))
     torch.cuda.set_device(local_rank)
     trainer = make_trainer(args.num_envs, args.num_agents, graphs=not args.no_graphs, pretrained=not args.untrained)
     if args.saturated_only:

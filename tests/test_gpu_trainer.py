@@ -646,3 +646,26 @@ def test_bench_harness_with_two_ranks_on_one_gpu():
     assert outs[0][0].strip().splitlines()[-1] == lines0[0]        # the JSON is the last line of stdout
     coll = r["config"]["collective"]                            # the data-parallel step's own cost is on the line
     assert coll["allreduce_grad_us"] > 0 and coll["bucket_bytes"] >= 4 * 360201 and coll["backend"] == "gloo"
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1200)
+def test_bench_gpus_2_as_one_command_on_a_shared_device():
+    """`python bench.py --gpus 2` as ONE command (no WORLD_SIZE in the environment): the script starts its own two ranks.  On a
+    one-GPU box they share cuda:0 over gloo (COPO_BENCH_SHARE_DEVICE=1); the line must say n_gpus 2 and count both shards."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(COPO_BENCH_SHARE_DEVICE="1", COPO_FORCE_DIST="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--num-envs", "32"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=1100)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
+    per_rank_iter = d["config"]["agent_steps_per_iter"]
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 2 * per_rank_iter) <= 1e-3 * 2 * per_rank_iter
+
