@@ -126,6 +126,8 @@ _SIGS = {
     "copo_peer_allreduce_sum_f32": (C.c_int, [C.POINTER(C.c_void_p), C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "copo_peer_status": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "copo_debug_peer_allreduce_all_ranks": (C.c_int, [C.POINTER(C.c_void_p), C.c_int64, C.c_int32, C.c_void_p]),
+    "copo_debug_rowpass_stamps": (C.c_int, [C.c_void_p]),
+    "copo_debug_wg_times": (C.c_int, [C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS)

@@ -57,7 +57,11 @@ static int upload(copo_sim* s, const T* host, size_t count, const T** dev) {
 // then 4; from ~12 scenes per CU on, ONE wave per scene with the small LDS footprint (sim_shape_params, ~20 scenes resident
 // per CU) and the register formulation of the neighbour lists (round 3: 4096 scenes 124 -> 110 us, 8192 222 -> 173 us; at
 // 2048 four waves per scene still win, 72 vs 96 us)
-static int pick_block(int E) { return E <= 256 ? 1024 : (E <= 512 ? 512 : (E <= 3072 ? 256 : 64)); }
+// (`nbr_fast` = the register formulation of the neighbour lists can run, SimParams::nbr_fast: without it -- K > 8, a mean-field
+// range of 0 or beyond the radius -- one wave per scene only pays above 8192 scenes, as before that formulation existed)
+static int pick_block(int E, bool nbr_fast = true) {
+    return E <= 256 ? 1024 : (E <= 512 ? 512 : (E <= (nbr_fast ? 3072 : 8192) ? 256 : 64));
+}
 
 extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** out) {
     if (!cfg || !out) return fail(COPO_ERR_NULL, "copo_sim_create: cfg/out is NULL");
@@ -118,7 +122,6 @@ extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** o
     s->force_lcf = -100.0;
     s->capacity = cfg->num_agents;
     s->lcf_dirty = true;
-    s->block = pick_block(cfg->num_envs);
     if (hipSetDevice(device) != hipSuccess) {
         delete s;
         return fail(COPO_ERR_DEVICE, "hipSetDevice(%d) failed", device);
@@ -163,8 +166,11 @@ extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** o
         memcpy(&bhi, &mhi, 4);
         p.mf_key_lo = blo & ~63u;                    // key < lo: inside for certain (keys drop 6 mantissa bits of d^2)
         p.mf_key_hi = (bhi + 63u) & ~63u;            // key >= hi: outside for certain
-        p.nbr_fast = (cfg->nbr_k <= 8 && cfg->neighbours_distance > 0.0f && cfg->mf_distance >= 0.0f &&
+        // (a mean-field range of exactly 0 stays with the exact formulation: a coincident pair has d = 0 <= 0 there, and the
+        // key thresholds of a zero range cannot express it)
+        p.nbr_fast = (cfg->nbr_k <= 8 && cfg->neighbours_distance > 0.0f && cfg->mf_distance > 0.0f &&
                       cfg->mf_distance < 0.99f * cfg->neighbours_distance) ? 1 : 0;
+        s->block = pick_block(cfg->num_envs, p.nbr_fast != 0);
     }
     p.dt = cfg->dt; p.hl = cfg->veh_half_len; p.hw = cfg->veh_half_wid; p.wheelbase = cfg->wheelbase;
     p.max_steer = cfg->max_steer; p.max_speed = cfg->max_speed; p.acc_max = cfg->acc_max; p.brake_gain = cfg->brake_gain;
@@ -313,7 +319,7 @@ extern "C" int copo_sim_set_debug(copo_sim* s, int64_t* stamps) {
 
 extern "C" int copo_sim_set_block(copo_sim* s, int32_t threads) {
     if (!s) return fail(COPO_ERR_NULL, "copo_sim_set_block: NULL handle");
-    if (threads == 0) threads = pick_block(s->p.E);
+    if (threads == 0) threads = pick_block(s->p.E, s->p.nbr_fast != 0);
     if (threads != 64 && threads != 128 && threads != 256 && threads != 512 && threads != 1024)
         return fail(COPO_ERR_DIM, "block=%d must be 64/128/256/512/1024", threads);
     if (threads != s->block) {

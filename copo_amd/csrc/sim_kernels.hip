@@ -1390,8 +1390,9 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
                 float cs = s.hc, sn = s.hs;
                 const float v0 = v, th0 = th;
                 for (int k = 0; k < p.substeps; ++k) {
-                    // (reverse gear, MetaDrive enable_reverse: a negative throttle is engine force backwards, no brake, v may go negative)
-                    const float a = a1 >= 0.0f ? (v < p.max_speed ? a1 * p.acc_max : 0.0f) : (p.reverse_acc > 0.0f ? a1 * p.reverse_acc : -brake);
+                    // (reverse gear, MetaDrive enable_reverse: a negative throttle is engine force backwards, no brake, v may go negative;
+                    //  the engine is cut at max_speed in either direction)
+                    const float a = a1 >= 0.0f ? (v < p.max_speed ? a1 * p.acc_max : 0.0f) : (p.reverse_acc > 0.0f ? (v > -p.max_speed ? a1 * p.reverse_acc : 0.0f) : -brake);
                     v = v + a * h;
                     if (v < 0.0f && !(p.reverse_acc > 0.0f)) v = 0.0f;
                     const float dxh = cs * cb - sn * sb, dyh = sn * cb + cs * sb;
@@ -1828,7 +1829,10 @@ void sim_shape_params(SimParams& p, int block) {
     // 14 259 / 16 275 us -- fuller pair and box-test batches against resident scenes per compute unit, 26 at 6.2 KB of LDS)
     const int lch = p.chunk_one_wave > 0 ? p.chunk_one_wave : 10;
     p.chunk = block > 64 ? p.N : (p.N < lch ? p.N : lch);
-    p.nbr_chunk = block > 64 ? p.N : (p.N < 4 ? p.N : 4);
+    // (pair-parallel neighbour lists, one wave per scene: 4 agents at a time when they only serve the scenes the register
+    //  formulation declines, 8 when they are the only formulation this configuration has)
+    const int nch = p.nbr_fast ? 4 : 8;
+    p.nbr_chunk = block > 64 ? p.N : (p.N < nch ? p.N : nch);
     p.stage_tables = (block > 64 && (size_t)route_table_floats(p.n_routes, p.seg_rows) * sizeof(float) <= (size_t)ROUTE_LDS_MAX_BYTES) ? 1 : 0;
 }
 

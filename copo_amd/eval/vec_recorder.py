@@ -83,7 +83,10 @@ class VecRecorder:
             f = fl[t]
             k = torch.ones(self.E, dtype=torch.bool, device=self.device) if keep is None else keep[t]
             acted = (f & F_ACTED) > 0
-            present = acted | ((f & F_SPAWNED) > 0)
+            # (the row that carries F_ENV_RESET flags the NEXT episode's slots as spawned; their neighbour counts belong to the
+            #  scene before the reset and the reference's RecorderEnv never sees a reset observation: not part of this episode)
+            resetting = ((f & F_ENV_RESET) > 0).any(-1, keepdim=True)
+            present = acted | (((f & F_SPAWNED) > 0) & ~resetting)
             na, npres = acted.sum(-1).to(f64), present.sum(-1).to(f64)
             vel = (info[t, :, :, I_VELOCITY].to(f64) * acted).sum(-1) / na.clamp(min=1.0)
             has_v = k & (na > 0)
@@ -99,7 +102,7 @@ class VecRecorder:
             A["nmax"] = torch.where(has_n, torch.maximum(A["nmax"], nn_), A["nmax"])
             if self.cost_acc is None:
                 self.cost_acc = torch.zeros(f.shape, dtype=f64, device=self.device)
-            self.cost_acc += info[t, :, :, I_COST].to(f64) * acted
+            self.cost_acc += info[t, :, :, I_COST].to(f64) * (acted & k[:, None])
             done = acted & ((f & F_DONE) > 0) & k[:, None]
             all_done = acted & ((f & F_DONE) > 0)
             if bool(done.any()):

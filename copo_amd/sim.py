@@ -194,6 +194,7 @@ class VecSim:
         h = C.c_void_p()
         _capi.check(_capi.lib.copo_sim_create(C.byref(struct), device, C.byref(h)))
         self._h = h
+        self.on_shape_change = []        # weak references to callables (VecSampler registers the reset of its captured rollout)
         E, N, O, K, dev = self.E, self.N, self.O, self.K, self.device
         f32, i32, u8 = torch.float32, torch.int32, torch.uint8
         self.out = dict(
@@ -253,14 +254,21 @@ class VecSim:
         captured before this call would replay its OLD block size against the NEW chunking: every holder of a captured
         rollout registers a callback in `on_shape_change` (VecSampler does) and is reset here."""
         self._capi.check(self._capi.lib.copo_sim_set_block(self._h, int(threads)))
-        for cb in list(getattr(self, "on_shape_change", ())):
-            cb()
+        self._shape_changed()
+
+    def _shape_changed(self):
+        live = []
+        for ref in self.on_shape_change:
+            cb = ref()
+            if cb is not None:        # (its owner is gone otherwise: drop the entry)
+                cb()
+                live.append(ref)
+        self.on_shape_change = live
 
     def set_chunk(self, fans):
         """LiDAR fans held in LDS at a time in the one-wave-per-scene shape (tuning knob; 0 = default)."""
         self._capi.check(self._capi.lib.copo_sim_set_chunk(self._h, int(fans)))
-        for cb in list(getattr(self, "on_shape_change", ())):
-            cb()
+        self._shape_changed()
 
     def get_state(self):
         torch = self._torch

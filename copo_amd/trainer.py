@@ -106,9 +106,10 @@ class VecSampler:
         self._reset_out = sim.make_step_out(dict(obs=self.obs[0]))
         self._started = False
         self._loop = GraphedCallable(self._rollout, use_graph and dev.type == "cuda")
-        if not hasattr(sim, "on_shape_change"):
-            sim.on_shape_change = []
-        sim.on_shape_change.append(self._loop.reset)      # VecSim.set_block invalidates the captured rollout
+        # VecSim.set_block / set_chunk invalidate the captured rollout.  Held weakly: a sampler that was dropped (trainers rebuilt
+        # on the same simulator) must not be kept alive -- with its graphs and buffers -- by the simulator's callback list
+        import weakref
+        sim.on_shape_change.append(weakref.WeakMethod(self._loop.reset))
         self.env_steps_total = 0
 
     def reset(self, seeds=None):

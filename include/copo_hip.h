@@ -76,8 +76,15 @@ extern "C" {
  *   6 s_start (route arc length at the start)           7 theta0
  *   8 ckx, 9 cky   navigation check point: the end of the road at its lateral middle
  *  10 lanes + 0.25 (left edge line continuous) + 0.5 (right edge line continuous): the edges a body must not touch (body_margin)
- *                  11 radius feature of the navigation block, 12 radius (0 for a straight), 13 angle feature
+ *                  11 radius feature of the navigation block, 12 radius (0 for a plain straight), 13 angle feature
  *  14 umx, 15 umy unit vector from an arc's centre to its mid point (projection without a wrap inside the arc)
+ * STRAIGHT records (kappa == 0) overload 12 / 14 / 15 for MetaDrive's Merge / Split blocks (maps.Net.add_funnel; read by
+ * funnel_extra in the step kernel and the oracle): extra drivable width to the RIGHT of the record's lanes, bounded by the
+ * outer edge of the outermost wave lane -- two arcs of opposite sense:
+ *   12 wave radius R (> 0 switches the funnel on; 0 = plain straight, 14 / 15 are then ignored)
+ *   14 extra width D at the wide end, signed: + the road narrows along its direction, - it widens
+ *   15 arc length u1 from the wide end at which the edge line's first arc (radius R + w/2) hands over to the second (R - w/2)
+ * A map builder that leaves field 12 of a straight non-zero therefore changes its out-of-road decisions.
  * A route has nseg roads followed by one terminal record (length 0) holding the end pose. */
 #define COPO_SEG_CKX 8
 #define COPO_SEG_LANES 10
@@ -468,6 +475,10 @@ int copo_peer_allreduce_sum_f32(void* const* workspaces, int64_t n, int32_t rank
 int copo_peer_status(void* workspace, int64_t n, int32_t world, void* stream);
 /* test entry: all `world` ranks in one launch (the workspaces all belong to the calling process) */
 int copo_debug_peer_allreduce_all_ranks(void* const* workspaces, int64_t n, int32_t world, void* stream);
+/* profiling entries (scripts/ only): device-side wall-clock stamps that profiling calls of the fused learner leave behind --
+ * 16 phase stamps of one row-pass workgroup / [2][1024][2] start-end stamps per workgroup of the two kernels of a step */
+int copo_debug_rowpass_stamps(unsigned long long* out16);
+int copo_debug_wg_times(unsigned long long* out4096);
 
 #ifdef __cplusplus
 }

@@ -805,7 +805,7 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
             o_sincosf(th, &sn, &cs);
             for (int k = 0; k < c->substeps; ++k) {
                 /* reverse gear (MetaDrive enable_reverse): a negative throttle is engine force backwards, no brake, v may go negative */
-                float a = a1 >= 0.0f ? (v < c->max_speed ? a1 * c->acc_max : 0.0f) : (c->reverse_acc > 0.0f ? a1 * c->reverse_acc : -brake);
+                float a = a1 >= 0.0f ? (v < c->max_speed ? a1 * c->acc_max : 0.0f) : (c->reverse_acc > 0.0f ? (v > -c->max_speed ? a1 * c->reverse_acc : 0.0f) : -brake);
                 v = v + a * h;
                 if (v < 0.0f && !(c->reverse_acc > 0.0f)) v = 0.0f;
                 float dxh = cs * cb - sn * sb, dyh = sn * cb + cs * sb;

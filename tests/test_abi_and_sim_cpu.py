@@ -296,6 +296,25 @@ def test_sim_invariants_on_the_oracle():
     s.close()
 
 
+def test_reverse_gear_is_cut_at_max_speed():
+    """Optional reverse gear (`reverse_acc` > 0, MetaDrive `enable_reverse`): full negative throttle on an open map accelerates
+    backwards only up to `max_speed` -- the engine cut works in both directions (round-3 advisor: |v| ran away, and with it the
+    speed reward and the speed column of the observation)."""
+    cfg = SimConfig(map="intersection", num_envs=1, num_agents=4, horizon=3000, reverse_acc=60.0)
+    s = ol.OracleSim(cfg)
+    s.reset()
+    act = np.zeros((1, 4, 2), np.float32)
+    act[..., 1] = -1.0
+    vmax = 0.0
+    for _ in range(120):
+        o = s.step(act)
+        vmax = max(vmax, float(o["info"][..., 0].max()))
+    s.close()
+    lim = cfg.max_speed * 3.6
+    assert vmax > 0.5 * lim, "the reverse gear never engaged: %r" % vmax
+    assert vmax <= lim + cfg.reverse_acc * cfg.dt * 3.6 / cfg.substeps + 1e-3, (vmax, lim)
+
+
 def test_sim_is_deterministic_and_seed_sensitive():
     cfg = SimConfig(map="roundabout", num_envs=2, num_agents=20, horizon=80)
     _, a = _rollout(cfg, 100, seed=1, policy="random")
