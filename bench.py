@@ -476,6 +476,9 @@ def main():
         # one command, N ranks: this process only launches them (the driver's `torch.distributed.run` form arrives with
         # WORLD_SIZE set and skips this)
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:], cpu_only=args.rendezvous_only))
+    if os.environ.get("COPO_BENCH_TRACE_S"):       # diagnostics: where is every thread after so many seconds (then exit)
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["COPO_BENCH_TRACE_S"]), exit=True)
     from copo_amd import dist as D
     if args.rendezvous_only:
         rendezvous_only(D, args)
@@ -594,7 +597,11 @@ def main():
                        "knobs": {"COPO_SGD_CHAIN": int(getattr(trainer.policy, "SGD_CHAIN", 0)),
                                  "COPO_DIST_CHAIN": int(getattr(trainer.policy, "_dist_chain_len", 0) or 0),
                                  "COPO_FORCE_DIST": os.environ.get("COPO_FORCE_DIST", "0"),
-                                 "COPO_PEER_ALLREDUCE": os.environ.get("COPO_PEER_ALLREDUCE", "0")}},
+                                 "COPO_PEER_ALLREDUCE": os.environ.get("COPO_PEER_ALLREDUCE", "0"),
+                                 "COPO_DP_EXCHANGE": os.environ.get("COPO_DP_EXCHANGE", "auto")},
+                       # how the data-parallel SGD step sums its gradients: "tile" = inside the weight-gradient kernel
+                       # (peer stores over xGMI), "rccl" = all-reduce + flat Adam; None = one process
+                       "dp_step": getattr(trainer.policy, "_dp_mode", None)},
             "roofline": {"bound": "hbm", "kernel": "copo::sim_step_kernel", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                          "traffic": traffic, "traffic_units_per_launch": traffic_units,

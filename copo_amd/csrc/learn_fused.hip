@@ -185,11 +185,12 @@ hipError_t launch_fused_step(FusedArgs a, hipStream_t s, const MetaTail* mt_ = n
     }
 #undef COPO_GEMM
     if (part == 1) return hipGetLastError();
+    if (a.dp_world > 1 && (mbatch || a.head_mode == MODE_META_BOTH || !g_use_wgrad || g_wgrad_ot != 1 || !a.apply_adam)) return hipErrorInvalidValue;
     if (!mbatch && a.head_mode != MODE_META_BOTH && g_use_wgrad) {
         // weight gradients, fold and Adam in one kernel: the SGD step ends here
         const int ot = g_wgrad_ot;
         const int nty = (c.hidden + 32 * ot - 1) / (32 * ot), wx2 = (c.hidden + 1 + 31) / 32, wx1 = (kmax1 + 1 + 31) / 32;
-        const dim3 grid((wx2 + wx1) * nty + wx2, G);
+        const dim3 grid((wx2 + wx1) * nty + wx2, G);      // (wgrad_tiles() below: the exchange workspace is sized by this grid)
         const size_t lds = (size_t)WG_WAVES * 32 * ot * 33 * sizeof(float);
         if (bf) hipLaunchKernelGGL((wgrad_adam_kernel<1, true>), grid, dim3(64 * WG_WAVES), (size_t)WG_WAVES * 32 * 33 * sizeof(float), s, a, nty, (c.hidden + 1 + 31) / 32, wx1);
         else if (ot == 2) hipLaunchKernelGGL((wgrad_adam_kernel<2>), grid, dim3(64 * WG_WAVES), lds, s, a, nty, wx2, wx1);
@@ -229,6 +230,15 @@ hipError_t launch_fused_step(FusedArgs a, hipStream_t s, const MetaTail* mt_ = n
     // the next row pass would read stale weights
     if (a.apply_adam && a.theta_t && a.head_mode == COPO_HEAD_PPO) return launch_refresh_transposed(c, a.theta, a.theta_t, s);
     return hipGetLastError();
+}
+
+// tiles of the weight-gradient kernel's grid for a PPO step over all nets of `c` (= workgroups; launch_fused_step)
+static int wgrad_tiles(const copo_ppo_cfg& c) {
+    const int G = 1 + c.n_value_heads;
+    int kmax1 = c.pol.in_dim;
+    for (int g = 1; g < G; ++g) kmax1 = c.val[g - 1].in_dim > kmax1 ? c.val[g - 1].in_dim : kmax1;
+    const int nty = (c.hidden + 31) / 32, wx2 = (c.hidden + 1 + 31) / 32, wx1 = (kmax1 + 1 + 31) / 32;
+    return ((wx2 + wx1) * nty + wx2) * G;
 }
 
 hipError_t launch_adam_flat(const FusedArgs& a, long long n, hipStream_t s) {
@@ -300,6 +310,48 @@ extern "C" int copo_ppo_fused_step_f32(const copo_ppo_cfg* cfg, float* theta, fl
     a.theta_t = theta_t;
     hipError_t e = launch_fused_step(a, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
+}
+
+extern "C" int64_t copo_dp_workspace_bytes(const copo_ppo_cfg* cfg, int32_t world) {
+    if (check_cfg(cfg) != COPO_OK || world < 1 || world > COPO_PEER_MAX_WORLD) return -1;
+    return (int64_t)(DpLay(wgrad_tiles(*cfg), world).words() * sizeof(float));
+}
+
+extern "C" int copo_ppo_fused_step_dp_f32(const copo_ppo_cfg* cfg, float* theta, float* adam_m, float* adam_v,
+                                          const float* obs_src, const float* cc_src, const float* pack_src,
+                                          const int64_t* rows, const float* w, const float* denom, const float* kl_coeff,
+                                          int64_t* step, float* workspace, float* stats, int64_t* mb_index, int32_t bump_index,
+                                          float* theta_t, void* const* dp_workspaces, int32_t rank, int32_t world, void* stream) {
+    int rc = check_cfg(cfg);
+    if (rc != COPO_OK) return rc;
+    if (!theta || !obs_src || !pack_src || !rows || !w || !denom || !workspace || !adam_m || !adam_v || !step) return COPO_ERR_NULL;
+    if (cfg->use_kl && !kl_coeff) return COPO_ERR_NULL;
+    if (world < 1 || world > COPO_PEER_MAX_WORLD || rank < 0 || rank >= world) return COPO_ERR_DIM;
+    if (world > 1 && !dp_workspaces) return COPO_ERR_NULL;
+    FusedArgs a;
+    fill_common(a, cfg, obs_src, cc_src, pack_src, rows, w, denom, workspace, mb_index);
+    a.theta = theta; a.adam_m = adam_m; a.adam_v = adam_v;
+    a.kl_coeff = kl_coeff; a.step = step; a.stats = stats; a.apply_adam = 1; a.head_mode = COPO_HEAD_PPO;
+    a.groups = 1 + cfg->n_value_heads;
+    a.bump_k = (mb_index && bump_index) ? 1 : 0;
+    a.theta_t = theta_t;
+    a.dp_rank = rank; a.dp_world = world;
+    for (int r = 0; r < world && world > 1; ++r) {
+        if (!dp_workspaces[r]) return COPO_ERR_NULL;
+        a.dp_ws[r] = static_cast<float*>(dp_workspaces[r]);
+    }
+    hipError_t e = launch_fused_step(a, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
+}
+
+// error word of this rank's exchange workspace (0 = every wait so far was answered); synchronises the stream first
+extern "C" int copo_dp_status(void* workspace, const copo_ppo_cfg* cfg, int32_t world, void* stream) {
+    if (!workspace || check_cfg(cfg) != COPO_OK || world < 1 || world > COPO_PEER_MAX_WORLD) return COPO_ERR_NULL;
+    uint32_t ctl[8];
+    if (hipStreamSynchronize(static_cast<hipStream_t>(stream)) != hipSuccess) return COPO_ERR_DEVICE;
+    if (hipMemcpy(ctl, static_cast<float*>(workspace) + DpLay(wgrad_tiles(*cfg), world).control(), sizeof(ctl), hipMemcpyDeviceToHost) != hipSuccess)
+        return COPO_ERR_DEVICE;
+    return ctl[0] ? COPO_ERR_DEVICE : COPO_OK;
 }
 
 static int mlp_forward(const copo_ppo_cfg* cfg, const float* theta, const float* theta_t, const float* obs_src,

@@ -131,6 +131,58 @@ def probe_graphed_allreduce(timeout=90.0):
     return bool(ok.item())
 
 
+def ranks_share_a_device(device):
+    """True if two ranks of the job use the same physical GPU (tests on a one-GPU box).  Kernels that wait for their peers
+    INSIDE the kernel (the tile exchange) then compete with those peers for the same compute units and may starve them."""
+    if not is_dist() or td.get_world_size() < 2 or device.type != "cuda":
+        return False
+    import socket
+    pr = torch.cuda.get_device_properties(device)
+    me = (socket.gethostname(), getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", device.index), getattr(pr, "pci_device_id", 0))
+    every = [None] * td.get_world_size()
+    td.all_gather_object(every, me)
+    return len(set(every)) < len(every)
+
+
+def _probe_child(module, port_shift, timeout, need_nccl, extra_env=None):
+    """Run `python -m <module>` once per rank as a CHILD process with its own process group (MASTER_PORT shifted); the ranks
+    agree on the outcome with a MIN all-reduce.  A child that hangs is killed by PID after `timeout` seconds."""
+    import subprocess
+    import sys
+    if not (td.is_available() and td.is_initialized() and torch.cuda.is_available()):
+        return False
+    if (need_nccl and td.get_backend() != "nccl") or os.environ.get("COPO_DIST_PROBE", "1") == "0":
+        return False
+    env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + port_shift))
+    env.pop("COPO_FORCE_DIST", None)
+    env.pop("TORCHELASTIC_USE_AGENT_STORE", None)      # under torchrun: the child's rank 0 must open its OWN store on the new port
+    env.update(extra_env or {})
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rc = -1
+    try:
+        p = subprocess.Popen([sys.executable, "-m", module], env=env, cwd=root, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        try:
+            rc = p.wait(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            p.kill()            # exactly the child we started
+            p.wait()
+    except OSError:
+        rc = -1
+    ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device="cuda")
+    td.all_reduce(ok, op=td.ReduceOp.MIN)
+    return bool(ok.item())
+
+
+def probe_tile_exchange(hidden=64, obs_dim=20, nets=2, timeout=150.0):
+    """True if the data-parallel tile exchange (`copo_ppo_fused_step_dp_f32`: hipIpc-mapped uncached workspaces, peer stores,
+    system-scope flags inside the weight-gradient kernel) works between the GPUs of THIS node: every rank runs
+    copo_amd/dp_probe.py in a child process (its own process group on MASTER_PORT + 19) -- a learner of the caller's shape takes captured chains
+    of data-parallel steps; all ranks must end with bit-identical parameters that agree with the RCCL-reduced step, and no wait
+    may have timed out.  A failure or a hang (child killed after `timeout` s) leaves the RCCL loop in place."""
+    return _probe_child("copo_amd.dp_probe", 19, timeout, need_nccl=False,
+                        extra_env=dict(COPO_DP_PROBE_HIDDEN=str(int(hidden)), COPO_DP_PROBE_OBS=str(int(obs_dim)), COPO_DP_PROBE_NETS=str(int(nets))))
+
+
 def shutdown():
     """Tear the process group down (quietens the exit-time warning of ProcessGroupNCCL); safe to call when not initialised."""
     import torch.distributed as td

@@ -180,6 +180,20 @@ class FusedLearner:
             int(head_mode), rs["k"].data_ptr(), 1 if bump_index else 0,
             self.flat_t.data_ptr() if theta is None else None, _capi.current_stream()))
 
+    def step_dp(self, rs, exchange, stats=None, bump_index=True):
+        """One data-parallel PPO minibatch step: the local step's two launches, the gradient tiles summed over the ranks
+        inside the weight-gradient kernel (`exchange`: peer.TileExchange; None = a world of one, i.e. the local step)."""
+        cc = rs["cc_obs"]
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync_mirror()
+        _capi.check(_capi.lib.copo_ppo_fused_step_dp_f32(
+            C.byref(self.cfg), self.flat.flat.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr(), rs["obs"].data_ptr(),
+            None if cc is None else cc.data_ptr(), rs["pack"].data_ptr(), rs["rows_all"].data_ptr(), rs["w_all"].data_ptr(),
+            rs["denom_all"].data_ptr(), self.policy.kl_coeff.data_ptr(), self.step_count.data_ptr(), self.workspace.data_ptr(),
+            None if stats is None else stats.data_ptr(), rs["k"].data_ptr(), 1 if bump_index else 0, self.flat_t.data_ptr(),
+            None if exchange is None else exchange.ptrs, 0 if exchange is None else exchange.rank,
+            1 if exchange is None else exchange.world, _capi.current_stream()))
+
     def adam(self, rs, grad=None):
         """Adam on the flat buffers after a gradient all-reduce; advances the minibatch index."""
         _capi.check(_capi.lib.copo_adam_step_f32(

@@ -70,3 +70,60 @@ class PeerAllReduce:
                 _capi.lib.copo_ipc_close(p)
             _capi.lib.copo_peer_free(self._own)
             self._own, self._mapped = None, []
+
+
+def _map_all(own, device):
+    """Exchange the hipIpc handle of `own` (this rank's device allocation) with every rank; returns (ctypes array of the
+    world pointers as mapped here, list of the mappings to close)."""
+    rank, world = td.get_rank(), td.get_world_size()
+    handle = C.create_string_buffer(64)
+    _capi.check(_capi.lib.copo_ipc_export(own, handle))
+    handles = [None] * world
+    td.all_gather_object(handles, (os.getpid(), handle.raw))
+    mapped = []
+    ptrs = (C.c_void_p * world)()
+    for r, (pid, raw) in enumerate(handles):
+        if r == rank:
+            ptrs[r] = own.value
+        else:
+            p = C.c_void_p()
+            _capi.check(_capi.lib.copo_ipc_open(raw, C.byref(p)))
+            mapped.append(p)
+            ptrs[r] = p.value
+    return ptrs, mapped
+
+
+class TileExchange:
+    """Workspaces of the data-parallel SGD step (`copo_ppo_fused_step_dp_f32`): every rank allocates
+    one (uncached device memory), all ranks map all of them.  The step kernels then exchange gradient tiles through them --
+    no gradient buffer, no all-reduce call, no separate Adam launch."""
+
+    def __init__(self, cfg, device):
+        assert td.is_initialized() and device.type == "cuda"
+        self.cfg, self.rank, self.world, self.device = cfg, td.get_rank(), td.get_world_size(), device
+        nbytes = _capi.lib.copo_dp_workspace_bytes(C.byref(cfg), self.world)
+        if nbytes < 0:
+            raise ValueError("tile exchange: world size %d not supported" % self.world)
+        with torch.cuda.device(device):
+            own = C.c_void_p()
+            _capi.check(_capi.lib.copo_peer_alloc(nbytes, C.byref(own)))
+            self._own = own
+            self.ptrs, self._mapped = _map_all(own, device)
+        td.barrier()          # nobody steps before everybody has mapped everybody
+
+    def status(self):
+        """Raises if a wait inside any step so far timed out (a rank that never arrived).  Synchronises the stream."""
+        rc = _capi.lib.copo_dp_status(self._own, C.byref(self.cfg), self.world, _capi.current_stream())
+        if rc != 0:
+            raise RuntimeError("data-parallel tile exchange: a wait for a peer rank timed out (rank %d of %d, code %d) -- the "
+                               "parameters of this run are not trustworthy; COPO_DP_EXCHANGE=rccl selects the RCCL loop"
+                               % (self.rank, self.world, rc))
+
+    def close(self):
+        if getattr(self, "_own", None) is not None:
+            torch.cuda.synchronize(self.device)
+            for p in self._mapped:
+                _capi.lib.copo_ipc_close(p)
+            _capi.lib.copo_peer_free(self._own)
+            self._own, self._mapped = None, []
+

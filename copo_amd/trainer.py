@@ -274,8 +274,9 @@ class PPOPolicyBase:
         if self.fused is not None and state.get("fused") is not None:
             self.fused.load_state(state["fused"])
         self._weights_changed()
-        if self._sgd is not None:
-            self._sgd.reset()
+        for g in (self._sgd if isinstance(self._sgd, tuple) else (self._sgd,)):
+            if g is not None:
+                g.reset()
 
     # ---- minibatch SGD --------------------------------------------------------------------------------
     def loss(self, model, dist_class, train_batch):
@@ -424,15 +425,40 @@ class PPOPolicyBase:
         """(pack column used as the PPO advantage, pack column used by the meta update or None)."""
         return Postprocessing.ADVANTAGES, None
 
+    # Data-parallel SGD step, default: the gradient tiles are summed over the ranks INSIDE the weight-gradient kernel
+    # (`copo_ppo_fused_step_dp_f32`, peer.TileExchange; DESIGN.md section 6) -- the data-parallel step is the local step's two
+    # launches, in the same captured chains.  COPO_DP_EXCHANGE = tile | rccl | auto (default): auto takes the tile exchange
+    # when a child process per rank shows that it works on this node (dist.probe_tile_exchange), else the RCCL loop below.
+    _tile = None            # peer.TileExchange
+    _dp_mode = None         # "tile" / "rccl", decided at the first SGD call of a distributed run
+
     def _fused_local(self):
-        self.fused.step(self._row_sources, stats=self.fused.stats)
+        if self._dp_mode == "tile":
+            self.fused.step_dp(self._row_sources, self._tile, stats=self.fused.stats)
+        else:
+            self.fused.step(self._row_sources, stats=self.fused.stats)
 
     # minibatch steps per captured graph (the device-side minibatch counter walks the plan by itself)
     SGD_CHAIN = int(os.environ.get("COPO_SGD_CHAIN", "16"))
 
     def _fused_local_chain(self):
         for _ in range(self.SGD_CHAIN):
-            self.fused.step(self._row_sources, stats=self.fused.stats)
+            self._fused_local()
+
+    def _pick_dp_mode(self):
+        from . import peer
+        want = os.environ.get("COPO_DP_EXCHANGE", "auto")
+        if self.device.type != "cuda" or peer.enabled() or want == "rccl":
+            return "rccl"
+        if D.world_size() == 1:
+            return "tile"                    # COPO_FORCE_DIST with one rank: nothing to exchange, the same kernels
+        if want != "tile" and D.ranks_share_a_device(self.device):
+            return "rccl"                    # (a one-GPU test box: a kernel that waits for its peers starves them of compute units)
+        c = self.fused.cfg
+        if want == "tile" or D.probe_tile_exchange(c.hidden, c.pol.in_dim, 1 + c.n_value_heads):
+            self._tile = peer.TileExchange(self.fused.cfg, self.device)
+            return "tile"
+        return "rccl"
 
     # data-parallel path, opt-in (COPO_DIST_CHAIN=K): K x [gradient pass, all-reduce, Adam] captured in one graph, the
     # collective included.  torch.distributed + RCCL capture and replay it on this stack (scripts/micro/nccl_graph_probe.py,
@@ -478,8 +504,11 @@ class PPOPolicyBase:
     def run_sgd_fused(self, valid_idx, B_local, B_all, mb, num_epochs):
         fz = self.fused
         assert mb == fz.cfg.mb, "fused learner was built for minibatch %d" % fz.cfg.mb
+        if self._sgd is None and D.is_dist() and self._dp_mode is None:
+            self._dp_mode = self._pick_dp_mode()
+        tile = self._dp_mode == "tile"
         if self._sgd is None:
-            if D.is_dist():
+            if D.is_dist() and not tile:
                 self._setup_peer_allreduce()
                 if self._peer is None and self._dist_chain_len == 0 and "COPO_DIST_CHAIN" not in os.environ and self.use_graphs:
                     # RCCL inside a hipGraph: take it when a child process per rank shows that it captures and replays here
@@ -499,19 +528,19 @@ class PPOPolicyBase:
         for ep in range(num_epochs):
             n_mb = self.plan_epoch(valid_idx, B_local, B_all, mb, perm=None if perms is None else perms[ep])
             _k0 = 0
-            if not D.is_dist() and self.use_graphs:
+            if (tile or not D.is_dist()) and self.use_graphs:
                 # most of an epoch in graphs of SGD_CHAIN steps: fewer graph launches, no gap between their kernels
                 while _k0 + self.SGD_CHAIN <= n_mb:
                     self._sgd_chain()
                     _k0 += self.SGD_CHAIN
                     steps += self.SGD_CHAIN
-            if D.is_dist() and self.use_graphs and getattr(self, "_sgd_dist_chain", None) is not None:
+            if D.is_dist() and not tile and self.use_graphs and getattr(self, "_sgd_dist_chain", None) is not None:
                 while _k0 + self._dist_chain_len <= n_mb:
                     self._sgd_dist_chain()
                     _k0 += self._dist_chain_len
                     steps += self._dist_chain_len
             for _k in range(_k0, n_mb):
-                if D.is_dist():
+                if D.is_dist() and not tile:
                     # two host calls per minibatch: [Adam of the previous one + this gradient pass], all-reduce; the
                     # last Adam of the epoch is flushed before the next plan resets the minibatch index
                     self._sgd[0 if _k == _k0 else 2]()
@@ -524,6 +553,8 @@ class PPOPolicyBase:
         self.num_grad_updates += steps
         if self._peer is not None:
             self._peer.status()       # a rank that never arrived in some call: raise here instead of training on partial sums
+        if self._tile is not None:
+            self._tile.status()
         tot, pol, vf, kl, ent, vfn, vfg, adv = (fz.stats / max(1, steps)).tolist()
         return dict(total_loss=tot, policy_loss=pol, vf_loss=vf, kl=kl, entropy=ent, cur_kl_coeff=self._kl_value,
                     cur_lr=float(self.config["lr"]), num_sgd_steps=steps, mean_nei_vf_loss=vfn, mean_global_vf_loss=vfg,
@@ -991,10 +1022,11 @@ class VecTrainer:
             self.env.close()
         except Exception:
             pass
-        peer = getattr(self.policy, "_peer", None)
-        if peer is not None:
-            peer.close()
-            self.policy._peer = None
+        for name in ("_peer", "_tile"):
+            peer = getattr(self.policy, name, None)
+            if peer is not None:
+                peer.close()
+                setattr(self.policy, name, None)
 
 
 class _LocalWorker:

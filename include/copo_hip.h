@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define COPO_ABI_VERSION 4
+#define COPO_ABI_VERSION 5
 
 #define COPO_OK 0
 #define COPO_ERR_NULL (-1)      /* required pointer is NULL */
@@ -371,6 +371,24 @@ int copo_mlp_forward_rows_f32(const copo_ppo_cfg* cfg, const float* theta, const
  * launch -- or NULL: *step + 1 is used and both counters are advanced by a separate 1-thread kernel. */
 int copo_adam_step_f32(const copo_ppo_cfg* cfg, float* theta, float* adam_m, float* adam_v, const float* grad,
                        int64_t n, int64_t* step, int64_t* mb_index, float* theta_t, float* workspace, void* stream);
+
+/* ---- data-parallel SGD step: the local step's two launches, gradients summed over the ranks INSIDE the weight-gradient
+ * kernel (replaces RLlib's multi_gpu_train_one_step + the weight broadcasts, algo_copo.py:555-558, 572-613).  One process per
+ * GPU; every rank owns an exchange workspace of copo_dp_workspace_bytes(cfg, world) bytes from copo_peer_alloc (uncached
+ * device memory), exported / opened with copo_ipc_* so that `dp_workspaces[r]` is rank r's workspace as mapped HERE.
+ * Every 32 x 32 gradient tile is sent to the rank that owns it (tile index mod world), added up there in rank order and
+ * sent back; then every rank applies the same Adam update, so parameters, moments and the transposed mirror stay
+ * bit-identical on all ranks without being communicated.  Arguments as copo_ppo_fused_step_f32 (PPO head mode, Adam
+ * applied, `w / denom` with the GLOBAL row count in denom); every rank must make the same calls in the same order.
+ * world == 1 is the local step.  A peer that does not answer within ~10 s raises an error word (copo_dp_status) instead of
+ * hanging the GPU; every later wait then returns at once. */
+int64_t copo_dp_workspace_bytes(const copo_ppo_cfg* cfg, int32_t world);
+int copo_ppo_fused_step_dp_f32(const copo_ppo_cfg* cfg, float* theta, float* adam_m, float* adam_v, const float* obs_src,
+                               const float* cc_src, const float* pack_src, const int64_t* rows, const float* w,
+                               const float* denom, const float* kl_coeff, int64_t* step, float* workspace, float* stats,
+                               int64_t* mb_index, int32_t bump_index, float* theta_t, void* const* dp_workspaces,
+                               int32_t rank, int32_t world, void* stream);
+int copo_dp_status(void* workspace, const copo_ppo_cfg* cfg, int32_t world, void* stream);
 
 /* ---- LCF meta update (CoPOPolicy.meta_update, algo_copo.py:228-309) in three calls ------------------------------
  * (1) both policy gradients in one grouped pass: g_new = d mean(-clip-surrogate(global adv)) / d theta on the

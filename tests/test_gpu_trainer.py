@@ -452,9 +452,13 @@ def test_lookahead_bootstrap_with_several_fragments_per_rollout():
     a.stop()
 
 
-@pytest.mark.parametrize("peer", ["0", "1"])
+@pytest.mark.parametrize("peer", ["0", "1", "tile", "auto"])
 def test_two_ranks_fused_data_parallel_on_one_gpu(peer):
-    """peer = "1": the gradient sums go through the peer all-reduce (COPO_PEER_ALLREDUCE, hipIpc-mapped workspaces, captured
+    """peer = "tile": the data-parallel step of DESIGN.md section 6 -- gradient tiles summed over the ranks inside the
+    weight-gradient kernel (copo_ppo_fused_step_dp_f32), captured chains like the local step; "auto": the default -- that path
+    where every rank has a GPU of its own and the start-up probe (copo_amd/dp_probe.py) passes; HERE both ranks share one GPU
+    (kernels that wait for their peers would compete with them for compute units), which the default notices: RCCL loop.
+    peer = "1": the gradient sums go through the peer all-reduce (COPO_PEER_ALLREDUCE, hipIpc-mapped workspaces, captured
     [gradient pass, all-reduce, Adam] chains) instead of torch.distributed.
     Two real ranks (gloo over CUDA tensors, both on cuda:0 -- RCCL would refuse to share a device) through the fused
     data-parallel path: gradient all-reduce + flat Adam per minibatch, batched meta pass with exported gradient pairs,
@@ -477,6 +481,8 @@ assert a.policy.fused is not None and D.is_dist() and world == 2
 for _ in range(3):
     res = a.train()
 assert (a.policy._peer is not None) == (os.environ.get("COPO_PEER_ALLREDUCE") == "1")
+want_tile = os.environ.get("COPO_DP_EXCHANGE") == "tile"
+assert (a.policy._tile is not None) == want_tile and (a.policy._dp_mode == "tile") == want_tile, a.policy._dp_mode
 # whole-episode evaluation: the ranks' scenes finish their episode after different fragment counts, the loop holds collectives --
 # the stop decision must be the same on both ranks (round-2 advisor finding: a rank-local stop rule hangs here)
 ev = a.evaluate(scene_episodes=1)
@@ -497,10 +503,11 @@ td.destroy_process_group()
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29561",
-                   COPO_DIST_BACKEND="gloo", COPO_FORCE_DIST="0", COPO_PEER_ALLREDUCE=peer)
+                   COPO_DIST_BACKEND="gloo", COPO_FORCE_DIST="0", COPO_PEER_ALLREDUCE=peer if peer in "01" else "0",
+                   COPO_DP_EXCHANGE=peer if peer in ("tile", "auto") else "rccl")
         procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-    outs = [p.communicate(timeout=300) for p in procs]
+    outs = [p.communicate(timeout=600) for p in procs]
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, se[-3000:]
     line = [ln for ln in outs[0][0].splitlines() if ln.startswith("RESULT ")][-1]
