@@ -345,6 +345,141 @@ def cpu_baseline(num_envs, num_agents, iters=1):
     return agent_steps / dt, dt, agent_steps, used
 
 
+def cpu_baseline_all_cores(num_envs, num_agents, iters=1):
+    """Best-effort host figure for the same iteration (round-3 review: the one-thread simulator + 8-thread learner above is
+    not what a 256-thread host can do): the scenes are dealt over one C oracle instance per host thread (ctypes releases the
+    GIL), policy inference is one batched torch call per env step, and the learner runs at the thread count that a short
+    calibration finds fastest for this minibatch size.  Test infrastructure used as the measured CPU port."""
+    from concurrent.futures import ThreadPoolExecutor
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    from copo_amd.engine import Postprocessing, SampleBatch
+    from copo_amd.sim import SimConfig
+    from copo_amd.torch_copo import algo_copo as A
+    from copo_amd.torch_copo.utils.env_wrappers import MultiAgentIntersectionEnv, get_lcf_env, get_rllib_compatible_env
+    host = os.cpu_count() or 1
+    prev_threads = torch.get_num_threads()
+    env = get_rllib_compatible_env(get_lcf_env(MultiAgentIntersectionEnv))
+    cfg = A.CoPOConfig()
+    cfg.update_from_dict(dict(env=env, device="cpu", use_hip_graphs=False, env_config=dict(num_agents=num_agents)))
+    cfg.validate()
+    pol = A.CoPOPolicy(cfg.observation_space, cfg.action_space, cfg)
+    E, N = num_envs, num_agents
+    T = max(1, -(-2000 // E))
+    W = max(1, min(host, E))                       # simulator workers
+    per = [E // W + (1 if k < E % W else 0) for k in range(W)]
+    offs = np.concatenate([[0], np.cumsum(per)])
+    sims = [ol.OracleSim(SimConfig(map="intersection", num_envs=per[k], num_agents=N, start_seed=5000 + 131 * k)) for k in range(W)]
+    O = sims[0].O
+    pool = ThreadPoolExecutor(W)
+    keys = ("obs", "rew", "nei_rew", "glob_rew", "flags", "lcf")
+
+    def step_all(act):          # act [E, N, 2] numpy or None (reset)
+        def one(k):
+            o = sims[k].reset() if act is None else sims[k].step(act[offs[k]:offs[k + 1]])
+            return {q: o[q].copy() for q in keys}
+        outs = list(pool.map(one, range(W)))
+        return {q: np.concatenate([o[q] for o in outs], 0) for q in keys}
+
+    torch.set_num_threads(min(host, 64))
+    out = step_all(None)
+    for _ in range(60):
+        a, _, _ = pol.compute_actions(torch.from_numpy(out["obs"]).view(E * N, O))
+        out = step_all(a.view(E, N, 2).clamp(-1, 1).numpy())
+    # learner thread count: time a few minibatch steps of the real loss at each candidate
+    best_t, best_s = 8, float("inf")
+    probe = SampleBatch({SampleBatch.OBS: torch.rand(512, O), SampleBatch.ACTIONS: torch.zeros(512, 2), SampleBatch.ACTION_LOGP: torch.zeros(512),
+                         SampleBatch.ACTION_DIST_INPUTS: torch.zeros(512, 4), Postprocessing.ADVANTAGES: torch.randn(512),
+                         SampleBatch.VF_PREDS: torch.zeros(512), Postprocessing.VALUE_TARGETS: torch.randn(512), A.NEI_VALUES: torch.zeros(512),
+                         A.NEI_ADVANTAGE: torch.randn(512), A.NEI_TARGET: torch.randn(512), A.GLOBAL_VALUES: torch.zeros(512),
+                         A.GLOBAL_TARGET: torch.randn(512), A.GLOBAL_ADVANTAGES: torch.randn(512), "normalized_advantages": torch.randn(512),
+                         SampleBatch.VALID: torch.ones(512), "valid_denominator": torch.tensor(512.0)})
+    probe["centralized_critic_obs"] = probe[SampleBatch.OBS]
+    for cand in (4, 8, 16, 32, 64):
+        if cand > host:
+            break
+        torch.set_num_threads(cand)
+        for rep in range(6):
+            if rep == 2:
+                t0 = time.perf_counter()
+            for p_ in pol.model.parameters():
+                p_.grad = None
+            pol.loss(pol.model, pol.dist_class, probe).backward()
+        dt = (time.perf_counter() - t0) / 4
+        if dt < best_s:
+            best_t, best_s = cand, dt
+    obs = torch.from_numpy(out["obs"])
+    agent_steps, t0 = 0, time.perf_counter()
+    for _ in range(iters):
+        torch.set_num_threads(min(host, 64))
+        buf = dict(obs=torch.zeros(T, E, N, O), act=torch.zeros(T, E, N, 2), logp=torch.zeros(T, E, N), di=torch.zeros(T, E, N, 4),
+                   rew3=np.zeros((3, T, E, N), np.float32), flags=np.zeros((T, E, N), np.uint8), lcf=np.zeros((T, E, N), np.float32))
+        for t in range(T):
+            a, lp, di = pol.compute_actions(obs.view(E * N, O))
+            buf["obs"][t], buf["act"][t], buf["logp"][t], buf["di"][t] = obs, a.view(E, N, 2), lp.view(E, N), di.view(E, N, 4)
+            out = step_all(a.view(E, N, 2).clamp(-1, 1).numpy())
+            buf["rew3"][0, t], buf["rew3"][1, t] = out["rew"], out["nei_rew"]
+            buf["rew3"][2, t] = out["glob_rew"][:, None]
+            buf["flags"][t], buf["lcf"][t] = out["flags"], out["lcf"]
+            obs = torch.from_numpy(out["obs"])
+        M = E * N
+        vals = pol.value_heads_dense(buf["obs"].view(T * M, O)).view(3, T, M).numpy()
+        adv, tgt = ol.gae3(buf["rew3"].reshape(3, T, M), vals, buf["flags"].reshape(T, M), pol.gae_gammas(), 0.95)
+        valid = (buf["flags"].reshape(-1) & 1) > 0
+        mixed, stats, norm, gstd = ol.lcf_mix(adv[0].ravel(), adv[1].ravel(), adv[2].ravel(), buf["lcf"].ravel(), valid)
+        mean = stats[1] / stats[0]
+        pol._raw_lcf_adv_mean.fill_(mean)
+        pol._raw_lcf_adv_std.fill_(max(1e-4, float(np.sqrt(max(stats[2] / stats[0] - mean * mean, 0)))))
+        f = lambda x: torch.from_numpy(np.ascontiguousarray(x)).view(T, E, N)  # noqa: E731
+        batch = SampleBatch({
+            SampleBatch.OBS: buf["obs"], SampleBatch.ACTIONS: buf["act"], SampleBatch.ACTION_LOGP: buf["logp"],
+            SampleBatch.ACTION_DIST_INPUTS: buf["di"], SampleBatch.FLAGS: torch.from_numpy(buf["flags"]),
+            Postprocessing.ADVANTAGES: f(adv[0]), SampleBatch.VF_PREDS: f(vals[0]), Postprocessing.VALUE_TARGETS: f(tgt[0]),
+            A.NEI_VALUES: f(vals[1]), A.NEI_ADVANTAGE: f(adv[1]), A.NEI_TARGET: f(tgt[1]), A.GLOBAL_VALUES: f(vals[2]),
+            A.GLOBAL_TARGET: f(tgt[2]), A.GLOBAL_ADVANTAGES: f(gstd), "normalized_advantages": f(norm)})
+        idx = torch.from_numpy(np.nonzero(valid)[0])
+        B = int(idx.numel())
+        torch.set_num_threads(best_t)
+        pol.prepare_sgd(batch, T * M, 512)
+        pol.run_sgd(idx, B, [B], 512, 5)
+        pol.run_meta(idx, B, [B], 512, 5)
+        pol.update_old_policy()
+        agent_steps += B
+    dt = time.perf_counter() - t0
+    pool.shutdown()
+    for sm in sims:
+        sm.close()
+    torch.set_num_threads(prev_threads)
+    return agent_steps / dt, dt, agent_steps, W, best_t
+
+
+def live_reference(seconds=20.0):
+    """if the reference's own stack is importable on this box (MetaDrive + Ray), time its CPU-runnable
+    configuration C1 (IPPO, Intersection, 4 agents, 1 env, local mode) for a bounded sample; else say so.  Nothing of
+    /root/reference is read: the packages would have to be installed in the image."""
+    try:
+        import metadrive  # noqa: F401
+        import ray  # noqa: F401
+    except Exception as e:      # noqa: BLE001
+        return {"live_reference": "unavailable", "why": "import metadrive, ray: %s" % type(e).__name__}
+    try:
+        from metadrive.envs.marl_envs import MultiAgentIntersectionEnv as RefEnv
+        env = RefEnv(dict(num_agents=4))
+        obs = env.reset()
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            obs, r, d, i = env.step({k: env.action_space[k].sample() for k in obs})
+            n += len(r)
+            if d.get("__all__"):
+                obs = env.reset()
+        dt = time.perf_counter() - t0
+        env.close()
+        return {"live_reference": "MetaDrive MultiAgentIntersectionEnv, 4 agents, random actions (simulator half of C1)",
+                "value": round(n / dt, 1), "unit": "agent-steps/s", "seconds": round(dt, 1)}
+    except Exception as e:      # noqa: BLE001
+        return {"live_reference": "unavailable", "why": "%s: %s" % (type(e).__name__, e)}
+
+
 def cpu_sim_only(num_agents, threads, scenes_per_thread=16, steps=40):
     """Simulator half alone on the host (SURVEY section 8d iii: single thread and all host threads): the scalar C oracle,
     one simulator instance per thread (ctypes releases the GIL), lane-keeping actions computed outside the timed calls."""
@@ -641,14 +776,20 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             v, cdt, n, used = cpu_baseline(args.num_envs, args.num_agents)
             host = os.cpu_count() or 1
+            va, adt, an, aw, at = cpu_baseline_all_cores(args.num_envs, args.num_agents)
             sim1 = cpu_sim_only(args.num_agents, 1)
             simn = cpu_sim_only(args.num_agents, host)
             line["cpu_baseline"] = {"value": round(v, 1), "unit": "agent-steps/s", "cores": used, "kind": "port",
                                     "sample": "1 iteration of the same workload on a steady-state population (%d agent-steps, "
                                               "%.1f s): scalar C oracle simulator on 1 thread + the build's torch learner on %d "
                                               "CPU threads (host has %d)" % (n, cdt, used, host),
+                                    "all_cores": {"value": round(va, 1), "unit": "agent-steps/s", "sim_threads": aw, "learner_threads": at,
+                                                  "sample": "the same iteration (%d agent-steps, %.1f s): one C oracle instance per host thread "
+                                                            "for the scenes, batched torch inference, torch learner at its fastest thread "
+                                                            "count for 512-row minibatches" % (an, adt)},
                                     "sim_only": {"threads_1": round(sim1, 1), "threads_%d" % host: round(simn, 1),
                                                  "unit": "agent-steps/s, simulator half alone (C oracle, one instance per thread)"},
+                                    "live_reference": live_reference(),
                                     "recorded_reference": {"value": 1500.0, "unit": "agent-steps/s",
                                                            "what": "the reference itself: MetaDrive + RLlib on 4 rollout workers, 60 env-steps/s "
                                                                    "(BASELINE.md; cited, not re-measured: MetaDrive and Ray are not installable here)"}}
