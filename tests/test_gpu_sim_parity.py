@@ -392,6 +392,8 @@ def test_maximum_population_bit_exact():
 @pytest.mark.parametrize("name,map_name,N,E,lasers,steps", [
     ("C2", "intersection", 40, 256, 72, 120),        # BASELINE configs[1], the bench workload
     ("C3", "roundabout", 40, 1024, 72, 60),          # configs[2], all 1024 scenes on one GPU
+    ("C4", "tollgate", 40, 512, 72, 60),             # configs[3]: O = 156 (72 side-detector beams, toll columns, no navigation)
+    ("bottleneck", "bottleneck", 20, 512, 72, 60),   # O = 96 (4 + 4 detector beams), Merge / Split funnels
     ("C5", "parkinglot", 10, 4096, 240, 60),         # configs[4], 240 beams
     ("saturated", "intersection", 40, 16384, 72, 30),   # the scene count of the saturated roofline figure
 ])
