@@ -462,12 +462,18 @@ int copo_meta_batch_wgrads_f32(const copo_ppo_cfg* cfg, const float* obs_src, co
 /* Phase B: n_mb sequential LCF Adam steps (minibatch order) in one kernel.  Row inputs either gathered from
  * pack_src via rows (ego_nei NULL, n_seg 1) or dense: ego_nei [n_seg][n_mb][mb][2] = {A_ego, A_nei} with w / eps
  * [n_seg][n_mb][mb] (data-parallel: the all-gathered rows of every rank).  gv [n_mb], stats_in [n_mb][2][8] from
- * phase A; lcf_param / adam_state / stats as in copo_meta_finish_f64. */
+ * phase A; lcf_param / adam_state / stats as in copo_meta_finish_f64.
+ * n_wg workgroups share the rows of every step (0 = automatic: 1 up to eight segments, where one workgroup is as fast, then
+ * one per four segments; <= 16): each adds up
+ * its rows, publishes three partial sums in `exchange` (COPO_META_SEQ_XCHG_DOUBLES doubles of device memory, zeroed ONCE by the
+ * caller and then left to the kernel) and applies the same Adam step to the sum of all partials -- with N ranks' rows a step
+ * then costs what it costs with one.  A workgroup that never arrives (2 s) turns lcf_param into NaN. */
+#define COPO_META_SEQ_XCHG_DOUBLES 256
 int copo_meta_batch_lcf_f64(const float* pack_src, int32_t pack_width, int32_t col_adv, int32_t col_nei_adv,
                             const int64_t* rows, const float* ego_nei, int32_t n_seg, const float* w, const double* eps,
                             const float* denom, int32_t mb, int32_t n_mb, const double* gv, const float* stats_in,
                             double* lcf_param, const double* raw_mean_std, double* adam_state, double lr, double* stats,
-                            void* stream);
+                            int32_t n_wg, double* exchange, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Peer all-reduce (replaces the in-process tower averaging of RLlib's multi-GPU learner,

@@ -588,3 +588,42 @@ def test_batched_meta_loop_vs_reference_golden(golden_dir, store):
     np.testing.assert_allclose(pol.model.lcf_parameters.detach().cpu().numpy(), g["out_lcf_parameters"], rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose([pol.model.lcf_mean.item(), pol.model.lcf_std.item()], g["out_env_lcf_dist"], rtol=1e-6, atol=1e-9)
     assert float(pol._lcf_adam[4]) == 15.0
+
+
+@pytest.mark.parametrize("n_seg,n_wg", [(1, 4), (1, 8), (3, 3), (8, 8), (16, 16), (12, 0)])
+def test_sequential_lcf_kernel_over_several_workgroups(n_seg, n_wg):
+    """Phase B of the batched meta pass (`copo_meta_batch_lcf_f64`) with the rows of every LCF step dealt over several workgroups
+    -- one per rank's rows in a data-parallel run -- that hand their partial sums over through device memory and all apply the
+    same Adam step: the parameters, Adam state and statistics after 90 sequential steps must equal the one-workgroup kernel's
+    (which the golden LCF trajectory pins) up to the reordering of three fp64 sums per step; repeated calls reuse the area."""
+    import ctypes as C
+    from copo_amd import _capi
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cuda").manual_seed(5 + n_seg)
+    mb, n_mb = 512, 90
+    en = torch.randn(n_seg, n_mb, mb, 2, device=dev, generator=g)
+    w = (torch.rand(n_seg, n_mb, mb, device=dev, generator=g) > 0.1).float()
+    eps = torch.randn(n_seg, n_mb, mb, device=dev, generator=g, dtype=torch.float64)
+    denom = w.sum((0, 2)).clamp(min=1).float().contiguous()
+    gv = torch.randn(n_mb, device=dev, generator=g, dtype=torch.float64) * 50
+    stats_in = torch.randn(n_mb, 2, 8, device=dev, generator=g)
+    raw = torch.tensor([0.1, 1.3], dtype=torch.float64, device=dev)
+    xchg = torch.zeros(256, dtype=torch.float64, device=dev)
+
+    def run(wgs, calls=1):
+        p = torch.tensor([0.05, -2.3], dtype=torch.float64, device=dev)
+        adam = torch.zeros(5, dtype=torch.float64, device=dev)
+        st = torch.zeros(7, dtype=torch.float64, device=dev)
+        for _ in range(calls):
+            _capi.check(_capi.lib.copo_meta_batch_lcf_f64(
+                None, 0, 0, 0, None, en.data_ptr(), n_seg, w.data_ptr(), eps.data_ptr(), denom.data_ptr(), mb, n_mb, gv.data_ptr(),
+                stats_in.data_ptr(), p.data_ptr(), raw.data_ptr(), adam.data_ptr(), 1e-3, st.data_ptr(), wgs, xchg.data_ptr(),
+                _capi.current_stream()))
+        torch.cuda.synchronize()
+        return p.cpu(), adam.cpu(), st.cpu()
+
+    one = run(1, calls=2)
+    many = run(n_wg, calls=2)          # the second call finds the flags of the first in the hand-over area
+    assert torch.isfinite(many[0]).all() and (one[0] - torch.tensor([0.05, -2.3], dtype=torch.float64)).abs().max() > 1e-3
+    for a, b, name in zip(one, many, ("lcf_param", "adam", "stats")):
+        torch.testing.assert_close(b, a, rtol=1e-10, atol=1e-12, msg=name)
