@@ -54,14 +54,27 @@ def rank():
     return td.get_rank() if is_dist() else 0
 
 
+def _several():
+    # (a forced data-parallel run with ONE rank takes every data-parallel code path; a sum or maximum over one rank is the
+    #  identity and is not sent through the collective library)
+    return is_dist() and td.get_world_size() > 1
+
+
 def all_reduce_sum_(t):
-    if is_dist():
+    if _several():
         td.all_reduce(t, op=td.ReduceOp.SUM)
     return t
 
 
+def all_reduce_sum_async(t):
+    """Start the sum; returns the work handle (None for a single process).  `.wait()` makes the CURRENT stream wait for it."""
+    if _several():
+        return td.all_reduce(t, op=td.ReduceOp.SUM, async_op=True)
+    return None
+
+
 def all_reduce_max_(t):
-    if is_dist():
+    if _several():
         td.all_reduce(t, op=td.ReduceOp.MAX)
     return t
 

@@ -354,15 +354,29 @@ class CoPOPolicy(CCPPOPolicy):
         # of a whole chunk BEFORE their dot products; the LCF row terms of every rank are gathered once per iteration
         # and every rank runs the (cheap, sequential) LCF steps on the full rows, so the parameters stay identical.
         nf, S, mb = fz.meta_fold_len(), D.world_size(), mb_["mb"]
-        if mb_.get("g_chunk") is None or mb_["g_chunk"].shape[0] < nb:
-            mb_["g_chunk"] = torch.zeros(nb, 2, nf, dtype=torch.float32, device=self.device)
-        for c0 in range(0, n_mb, nb):
-            n = min(nb, n_mb - c0)
-            grads(rs, c0, n, mb_["gv"], mb_["stats_k"], g_out=mb_["g_chunk"])
-            D.all_reduce_sum_(mb_["g_chunk"][:n])
-            fz.meta_batch_dot(mb_["g_chunk"], nf, n, mb_["gv"][c0:])
+        if mb_.get("g_chunk") is None or mb_["g_chunk"][0].shape[0] < nb:
+            mb_["g_chunk"] = [torch.zeros(nb, 2, nf, dtype=torch.float32, device=self.device) for _ in range(2)]
+        # two export buffers: the all-reduce of chunk c (23 MB of gradient pairs at the bench shape -- over xGMI about as long
+        # as a chunk's GEMMs) runs on the collective's own stream under the gradient GEMMs of chunk c + 1
+        pending = None
+
+        def finish(c0, n, buf, work):
+            if work is not None:
+                work.wait()               # (the compute stream waits; the host does not)
+            fz.meta_batch_dot(buf, nf, n, mb_["gv"][c0:])
             if self._meta_row_store:          # exported gradients carry unit row weights: both factors 1 / D_k
                 mb_["gv"][c0:c0 + n].div_(mb_["denom_all"][c0:c0 + n].double() ** 2)
+
+        for q, c0 in enumerate(range(0, n_mb, nb)):
+            n = min(nb, n_mb - c0)
+            buf = mb_["g_chunk"][q & 1]
+            grads(rs, c0, n, mb_["gv"], mb_["stats_k"], g_out=buf)
+            work = D.all_reduce_sum_async(buf[:n])
+            if pending is not None:
+                finish(*pending)
+            pending = (c0, n, buf, work)
+        if pending is not None:
+            finish(*pending)
         D.all_reduce_sum_(mb_["stats_k"][:n_mb])
         rows = mb_["rows_all"][:n_mb]
         en = torch.stack([pack[:, mb_["col_adv"]][rows], pack[:, mb_["col_nei_adv"]][rows]], dim=-1).contiguous()
