@@ -39,6 +39,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+VALU_PEAK_GINST = 1024 * 2.4 / 4   # 256 CUs x 4 SIMDs, 2.4 GHz, one wave64 VALU instruction per 4 cycles and SIMD: 614.4 G wave-instructions/s
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)
 CPU_BASELINE_THREADS = 8
 
@@ -712,6 +713,14 @@ def main():
             if tj.get("kernel_source_sha1") == kernel_source_hash():
                 traffic = tj.get("bytes_per_launch")
                 traffic_units = tj.get("units_per_launch")        # present slots of the launches the counters saw
+        # VALU roofline of the saturated launch (the kernel is bound by the vector ALUs' issue rate, not by HBM): wave-level VALU
+        # instructions per launch from the PMC pass of scripts/prof_sim_round.sh (profiles/sim_valu.json, same source-hash rule)
+        valu = None
+        vfile = os.path.join(ROOT, "profiles", "sim_valu.json")
+        if os.path.exists(vfile):
+            vj = json.load(open(vfile))
+            if vj.get("kernel_source_sha1") == kernel_source_hash() and vj.get("valu_wave_instructions_per_launch"):
+                valu = vj
         learner = None     # (after `phases`: it walks the trainer's SGD plan tables)
         sat_s, sat_present, sat_slots = measure_sim_kernel_saturated(side, policy="cruise")
         rnd_s, rnd_present, _ = measure_sim_kernel_saturated(side, policy="random")
@@ -759,6 +768,18 @@ def main():
                                    "the previous launch's drain with their own ramp-up",
                          "library_build": "shipped libcopo_hip.so: no environment knobs, all phases compiled in"},
         }
+        if valu is not None:
+            # peak: 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction (MI355X_MICROARCH.md); issued: this launch's
+            # instructions / its duration measured live above
+            issued = valu["valu_wave_instructions_per_launch"] / sat_s * 1e-9
+            line["roofline"]["valu"] = {
+                "bound": "valu-issue", "issued": round(issued, 1), "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
+                "frac": round(issued / VALU_PEAK_GINST, 4),
+                "instructions_per_launch": round(valu["valu_wave_instructions_per_launch"]),
+                "instructions_per_present_slot": round(valu["valu_wave_instructions_per_launch"] * 64 / max(sat_present, 1.0), 1),
+                "what": "copo::sim_step_kernel on %d populated scenes: SQ_INSTS_VALU per launch (profiles/sim_valu.json, rocprofv3 --pmc on "
+                        "`bench.py --saturated-only`) / the launch time measured here; `instructions_per_present_slot` counts lane-"
+                        "instructions (x 64).  The HBM fraction of this launch can only rise by deleting instructions" % valu["scenes"]}
         if world == 1:
             line["phases"] = measure_phases(side)
         learner = measure_learner_step(side)

@@ -72,7 +72,8 @@ static hipError_t gemm_lds_attrs() {
                               reinterpret_cast<const void*>(rowpass_kernel<1, 4, true, true>), reinterpret_cast<const void*>(rowpass_kernel<2, 4, true, true>),
                               reinterpret_cast<const void*>(rowpass_kernel<2, 8, true, true>), reinterpret_cast<const void*>(rowpass_kernel<4, 8, true, true>),
                               reinterpret_cast<const void*>(rowpass_kernel<2, 8, true, false, true>),
-                              reinterpret_cast<const void*>(rowpass_kernel<2, 8, true, false, true, 8>), reinterpret_cast<const void*>(rowpass_kernel<2, 8, true, false, false, 8>)})
+                              reinterpret_cast<const void*>(rowpass_kernel<2, 8, true, false, true, 8>), reinterpret_cast<const void*>(rowpass_kernel<2, 8, true, false, false, 8>),
+                              reinterpret_cast<const void*>(rowpass8_kernel<4>)})
             if ((r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) != hipSuccess) e = r;
         for (const void* f : {reinterpret_cast<const void*>(mlp_fwd_kernel<1, 4>), reinterpret_cast<const void*>(mlp_fwd_kernel<2, 4>),
                               reinterpret_cast<const void*>(mlp_fwd_kernel<2, 8>), reinterpret_cast<const void*>(mlp_fwd_kernel<4, 8>),
@@ -93,12 +94,14 @@ struct MetaBatch { int nb; float* g_out; double* dot_out; float* stats_out; int 
 // (`make prof`, -DCOPO_PROFILE_SKIP=<mask>, a separate .so that the package never loads) read COPO_RP_DBG for the
 // phase-stamp / phase-skip bits of the row pass and can fall back to the older kernel chains for A/B measurements.
 #ifdef COPO_PROFILE_SKIP
+static const bool g_rowpass_4x4 = [] { const char* e = getenv("COPO_ROWPASS_4X4"); return !(e && e[0] == '0'); }();
 static const bool g_rowpass_rt8 = [] { const char* e = getenv("COPO_ROWPASS_RT8"); return !(e && e[0] == '0'); }();
 static const int g_wgrad_ot = [] { const char* e = getenv("COPO_WGRAD_OT"); return (e && e[0] == '2') ? 2 : 1; }();
 static const bool g_use_wgrad = [] { const char* e = getenv("COPO_FUSED_WGRAD"); return !(e && e[0] == '0'); }();
 static const bool g_use_rowpass = [] { const char* e = getenv("COPO_FUSED_ROWPASS"); return !(e && e[0] == '0'); }();
 static int profile_dbg_bits() { static const int dbg = [] { const char* e = getenv("COPO_RP_DBG"); return e ? atoi(e) : 0; }(); return dbg; }
 #else
+static constexpr bool g_rowpass_4x4 = true;
 static constexpr bool g_rowpass_rt8 = true;
 static constexpr int g_wgrad_ot = 1;
 static constexpr bool g_use_wgrad = true;
@@ -173,6 +176,7 @@ hipError_t launch_fused_step(FusedArgs a, hipStream_t s, const MetaTail* mt_ = n
 #define COPO_RP(NT_, W_, HO_)                                                                                     \
         do {                                                                                                   \
             if (bf) hipLaunchKernelGGL((rowpass_kernel<NT_, W_, true, true>), grid, dim3(64 * W_), rp_lds, s, a); \
+            else if (rt8 && g_rowpass_4x4) hipLaunchKernelGGL((rowpass8_kernel<4>), grid, dim3(512), rowpass8_lds_floats(256, rowpass8_k1p(kmax1)) * sizeof(float), s, a); \
             else if (rt8 && HO_ && kmax1 <= 128) hipLaunchKernelGGL((rowpass_kernel<2, 8, true, false, true, 8>), grid, dim3(64 * W_), rp_lds, s, a); \
             else if (rt8) hipLaunchKernelGGL((rowpass_kernel<2, 8, true, false, false, 8>), grid, dim3(64 * W_), rp_lds, s, a); \
             else if (tw && HO_ && kmax1 <= 128) hipLaunchKernelGGL((rowpass_kernel<NT_, W_, true, false, HO_>), grid, dim3(64 * W_), rp_lds, s, a); \
