@@ -176,7 +176,7 @@ hipError_t launch_fused_step(FusedArgs a, hipStream_t s, const MetaTail* mt_ = n
 #define COPO_RP(NT_, W_, HO_)                                                                                     \
         do {                                                                                                   \
             if (bf) hipLaunchKernelGGL((rowpass_kernel<NT_, W_, true, true>), grid, dim3(64 * W_), rp_lds, s, a); \
-            else if (rt8 && g_rowpass_4x4) hipLaunchKernelGGL((rowpass8_kernel<4>), grid, dim3(512), rowpass8_lds_floats(256, rowpass8_k1p(kmax1)) * sizeof(float), s, a); \
+            else if (rt8 && g_rowpass_4x4) hipLaunchKernelGGL((rowpass8_kernel<4>), grid, dim3(64 * R8_KS * 4), rowpass8_lds_floats(256, rowpass8_k1p(kmax1)) * sizeof(float), s, a); \
             else if (rt8 && HO_ && kmax1 <= 128) hipLaunchKernelGGL((rowpass_kernel<2, 8, true, false, true, 8>), grid, dim3(64 * W_), rp_lds, s, a); \
             else if (rt8) hipLaunchKernelGGL((rowpass_kernel<2, 8, true, false, false, 8>), grid, dim3(64 * W_), rp_lds, s, a); \
             else if (tw && HO_ && kmax1 <= 128) hipLaunchKernelGGL((rowpass_kernel<NT_, W_, true, false, HO_>), grid, dim3(64 * W_), rp_lds, s, a); \
@@ -310,7 +310,8 @@ extern "C" int copo_ppo_fused_step_f32(const copo_ppo_cfg* cfg, float* theta, fl
                                        void* stream) {
     int rc = check_cfg(cfg);
     if (rc != COPO_OK) return rc;
-    if (!theta || !obs_src || !pack_src || !rows || !w || !denom || !workspace) return COPO_ERR_NULL;
+    if (!theta || !obs_src || !pack_src || !w || !denom || !workspace) return COPO_ERR_NULL;
+    if (!rows && head_mode != COPO_HEAD_PPO) return COPO_ERR_NULL;       // (sources in minibatch order: the PPO step only)
     if (apply_adam && (!adam_m || !adam_v || !step)) return COPO_ERR_NULL;
     if (!apply_adam && !grad) return COPO_ERR_NULL;
     if (head_mode < COPO_HEAD_PPO || head_mode > COPO_HEAD_META_OLD) return COPO_ERR_DIM;
@@ -338,7 +339,7 @@ extern "C" int copo_ppo_fused_step_dp_f32(const copo_ppo_cfg* cfg, float* theta,
                                           float* theta_t, void* const* dp_workspaces, int32_t rank, int32_t world, void* stream) {
     int rc = check_cfg(cfg);
     if (rc != COPO_OK) return rc;
-    if (!theta || !obs_src || !pack_src || !rows || !w || !denom || !workspace || !adam_m || !adam_v || !step) return COPO_ERR_NULL;
+    if (!theta || !obs_src || !pack_src || !w || !denom || !workspace || !adam_m || !adam_v || !step) return COPO_ERR_NULL;
     if (cfg->use_kl && !kl_coeff) return COPO_ERR_NULL;
     if (world < 1 || world > COPO_PEER_MAX_WORLD || rank < 0 || rank >= world) return COPO_ERR_DIM;
     if (world > 1 && !dp_workspaces) return COPO_ERR_NULL;

@@ -432,11 +432,14 @@ class PPOPolicyBase:
     _tile = None            # peer.TileExchange
     _dp_mode = None         # "tile" / "rccl", decided at the first SGD call of a distributed run
 
+    _rs_step = None         # what the step kernels read: the epoch's rows in minibatch order (FusedLearner.gather_epoch)
+
     def _fused_local(self):
+        rs = self._rs_step if self._rs_step is not None else self._row_sources
         if self._dp_mode == "tile":
-            self.fused.step_dp(self._row_sources, self._tile, stats=self.fused.stats)
+            self.fused.step_dp(rs, self._tile, stats=self.fused.stats)
         else:
-            self.fused.step(self._row_sources, stats=self.fused.stats)
+            self.fused.step(rs, stats=self.fused.stats)
 
     # minibatch steps per captured graph (the device-side minibatch counter walks the plan by itself)
     SGD_CHAIN = int(os.environ.get("COPO_SGD_CHAIN", "16"))
@@ -527,6 +530,9 @@ class PPOPolicyBase:
         perms = self.draw_perms(num_epochs, B_local)
         for ep in range(num_epochs):
             n_mb = self.plan_epoch(valid_idx, B_local, B_all, mb, perm=None if perms is None else perms[ep])
+            if (tile or not D.is_dist()) and self.config.get("gather_epoch_rows", True):
+                # (persistent buffers: the captured chains keep reading the same addresses)
+                self._rs_step = fz.gather_epoch(self._row_sources, n_mb)
             _k0 = 0
             if (tile or not D.is_dist()) and self.use_graphs:
                 # most of an epoch in graphs of SGD_CHAIN steps: fewer graph launches, no gap between their kernels
