@@ -14,9 +14,10 @@ batch = _dense_batch(pol, R, odim)
 idx = torch.arange(R, device="cuda")
 pol.prepare_sgd(batch, R, mb)
 pol.plan_epoch(idx, R, [R], mb)
+RS = pol._row_sources if os.environ.get("COPO_BENCH_TABLE") else pol.fused.gather_epoch(pol._row_sources, 160)      # the trainer's way: rows in minibatch order
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 for _ in range(10):
-    pol.fused.step(pol._row_sources, stats=pol.fused.stats)
+    pol.fused.step(RS, stats=pol.fused.stats)
 torch.cuda.synchronize()
 pol._row_sources["k"].zero_()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -25,7 +26,7 @@ e0.record()
 for i in range(n):
     if i % 128 == 0:
         pol._row_sources["k"].zero_()          # stay inside the epoch plan (161 minibatches)
-    pol.fused.step(pol._row_sources, stats=pol.fused.stats)
+    pol.fused.step(RS, stats=pol.fused.stats)
 e1.record()
 t1 = time.perf_counter()
 torch.cuda.synchronize()
