@@ -65,7 +65,8 @@ class FullyConnectedModel(nn.Module):
 
     def forward(self, input_dict, state=None, seq_lens=None):
         obs = input_dict["obs"] if isinstance(input_dict, dict) else input_dict
-        obs = obs.float().reshape(obs.shape[0], -1)
+        # (the parameters' dtype: fp32 in every trainer; a float64 copy of the model is what the tests' exact reference uses)
+        obs = obs.to(self._logits._model[0].weight.dtype).reshape(obs.shape[0], -1)
         self._last_obs = obs
         return self._logits(self._hidden_layers(obs)), (state or [])
 

@@ -102,7 +102,7 @@ def test_fused_sgd_matches_torch(name, fuse, odim, over):
                       if p.dtype == torch.float32])
     scale = float(g_ref.abs().max())
     err = float((g_ref - g_fz).abs().max())
-    assert err <= 2e-4 * scale + 1e-7, (err, scale)
+    assert err <= 1e-5 * scale + 1e-8, (err, scale)      # (both are fp32 evaluations ~1e-6 x scale from the exact gradient)
     st = ref._row_sources["stats"].tolist()          # total, policy, vf, kl, entropy, (nei, glob, adv)
     fs = fz.fused.stats.tolist()                     # total, policy, vf_ego, kl, entropy, vf_nei, vf_glob, adv
     np.testing.assert_allclose(fs[:5], st[:5], rtol=2e-4, atol=1e-5)
@@ -530,7 +530,10 @@ def test_fused_gradients_vs_reference_golden(golden_dir, tag, name, fuse, over):
         if p.dtype != torch.float32 or ref.size == 0:
             continue
         got = fz.grad[off[id(p)]:off[id(p)] + p.numel()].view_as(p).cpu().numpy()
-        np.testing.assert_allclose(got, ref, rtol=5e-4, atol=2e-6, err_msg=pname)
+        # 1e-5 of the tensor's largest element (SURVEY 8a's fp32 contract, read per tensor): two correct fp32 evaluations of a
+        # gradient agree to ~1e-6 of that (test_fused_gradients_against_a_float64_evaluation measures both against float64);
+        # relative to a SMALL element the difference is unbounded (cancellation in a 96- to 512-term sum), so no element-wise rtol
+        np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5 * float(np.abs(ref).max()) + 1e-9, err_msg=pname)
     st = fz.stats.tolist()               # total, policy, vf_ego, kl, entropy, vf_nei, vf_glob, adv
     np.testing.assert_allclose(st[0], float(g["out_total_loss"]), rtol=2e-5, atol=1e-6)
     for idx, key in ((1, "mean_policy_loss"), (2, "mean_vf_loss"), (3, "mean_kl_loss"), (4, "mean_entropy"),
@@ -585,8 +588,12 @@ def test_batched_meta_loop_vs_reference_golden(golden_dir, store):
         pol._run_meta_batched(n_mb, 2)                 # chunks of 2 + 1 minibatches
     torch.cuda.current_stream().wait_stream(pol._meta_side)
     pol._meta_keep.clear()
-    np.testing.assert_allclose(pol.model.lcf_parameters.detach().cpu().numpy(), g["out_lcf_parameters"], rtol=1e-6, atol=1e-9)
-    np.testing.assert_allclose([pol.model.lcf_mean.item(), pol.model.lcf_std.item()], g["out_env_lcf_dist"], rtol=1e-6, atol=1e-9)
+    _got = pol.model.lcf_parameters.detach().cpu().numpy()
+    print("LCF parameters after the golden loop: max relative difference %.3e" % float(np.max(np.abs(_got - g["out_lcf_parameters"]) / np.abs(g["out_lcf_parameters"]))))
+    # the tightest bound two correct fp32 evaluations allow: the fp64 LCF step takes <g_new, g_old> of two
+    # fp32 gradient vectors, each ~1e-6 of its norm from the exact one (kernels and the reference's torch alike); measured 1.4e-7
+    np.testing.assert_allclose(pol.model.lcf_parameters.detach().cpu().numpy(), g["out_lcf_parameters"], rtol=5e-7, atol=1e-10)
+    np.testing.assert_allclose([pol.model.lcf_mean.item(), pol.model.lcf_std.item()], g["out_env_lcf_dist"], rtol=5e-7, atol=1e-10)
     assert float(pol._lcf_adam[4]) == 15.0
 
 
@@ -627,3 +634,59 @@ def test_sequential_lcf_kernel_over_several_workgroups(n_seg, n_wg):
     assert torch.isfinite(many[0]).all() and (one[0] - torch.tensor([0.05, -2.3], dtype=torch.float64)).abs().max() > 1e-3
     for a, b, name in zip(one, many, ("lcf_param", "adam", "stats")):
         torch.testing.assert_close(b, a, rtol=1e-10, atol=1e-12, msg=name)
+
+
+@pytest.mark.parametrize("name,fuse,odim", [("copo", "none", 92), ("ccppo", "mf", 91)])
+def test_fused_gradients_against_a_float64_evaluation(name, fuse, odim):
+    """Where the tolerances of this file come from.  The same minibatch through (a) the HIP kernels, (b) torch
+    autograd in fp32, (c) torch autograd in FLOAT64 -- the exact gradient up to 1e-16.  Both fp32 evaluations add the same products in
+    different orders, so each differs from (c) by the forward error of a re-ordered fp32 sum: for a weight gradient a sum over 512
+    rows, relative to the tensor's largest element <= 512 u ~ 3e-5 plus the propagated activation error (u = 2^-24).  Asserted: the
+    kernels are as close to the exact gradient as torch's own fp32 step is (within a factor 3), and both stay under 1e-5 of the
+    tensor's largest element (measured: 8e-7 and 1e-6) -- the bound the golden-gradient comparisons of this file use."""
+    R, mb = 600, 512
+    ref = _make(name, fuse, odim, fused=False)
+    fz = _make(name, fuse, odim, fused=True)
+    with torch.no_grad():
+        for p in ref.model.parameters():
+            if p.dtype == torch.float32:
+                p.add_(torch.randn_like(p) * 0.05)
+    _copy_weights(fz, ref)
+    batch = _dense_batch(ref, R, odim)
+    idx = torch.arange(R, device="cuda")
+    for pol in (ref, fz):
+        pol.prepare_sgd(batch, R, mb)
+        torch.manual_seed(5)
+        pol.plan_epoch(idx, R, [R], mb)
+    ref._ensure_flat_grads()
+    ref._forward_backward()
+    g32 = {n: p.grad.detach().double().clone() for n, p in ref.model.named_parameters() if p.dtype == torch.float32 and p.grad is not None}
+    fz.fused.stats.zero_()
+    fz.fused.step(fz._row_sources, apply_adam=False, stats=fz.fused.stats, bump_index=False)
+    off = fz.fused.flat.offset
+    ghip = {n: fz.fused.grad[off[id(p)]:off[id(p)] + p.numel()].view_as(p).double().clone() for n, p in fz.model.named_parameters()
+            if p.dtype == torch.float32}
+    # (c): the same minibatch and loss in float64
+    tb = ref._gather_minibatch()
+    tb64 = SampleBatch({k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in tb.items()})
+    kl32 = ref.kl_coeff
+    ref.model.double()
+    ref.kl_coeff = kl32.double()
+    for p in ref.model.parameters():
+        p.grad = None
+    ref.loss(ref.model, ref.dist_class, tb64).backward()
+    worst_hip, worst_t32 = 0.0, 0.0
+    for n, p in ref.model.named_parameters():
+        if n not in g32 or p.grad is None:
+            continue
+        g64 = p.grad.detach()
+        scale = float(g64.abs().max())
+        if scale == 0.0:
+            continue
+        e_hip = float((ghip[n] - g64).abs().max()) / scale
+        e_t32 = float((g32[n] - g64).abs().max()) / scale
+        worst_hip, worst_t32 = max(worst_hip, e_hip), max(worst_t32, e_t32)
+        assert e_hip <= 1e-5 and e_t32 <= 1e-5, (n, e_hip, e_t32)          # measured: 8e-7 (HIP), 1e-6 (torch fp32)
+        assert e_hip <= 3.0 * e_t32 + 512 * 2.0 ** -24, (n, e_hip, e_t32)
+    assert worst_hip > 0.0 and worst_t32 > 0.0
+    print("max error / largest gradient element per tensor: HIP %.2e, torch fp32 %.2e" % (worst_hip, worst_t32))
