@@ -676,3 +676,27 @@ def test_bench_gpus_2_as_one_command_on_a_shared_device():
     per_rank_iter = d["config"]["agent_steps_per_iter"]
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 2 * per_rank_iter) <= 1e-3 * 2 * per_rank_iter
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,hidden,nets", [(4, 64, 4), (3, 128, 2), (8, 64, 2)])
+def test_tile_exchange_probe_with_several_ranks_on_one_gpu(world, hidden, nets):
+    """The data-parallel tile exchange beyond two ranks (owners dealt round-robin over 3 / 4 / 8 ranks, rank-order sums of up to
+    eight partial tiles): `copo_amd/dp_probe.py` -- a learner stepping in captured chains with the exchange and, from the same
+    start, with torch.distributed's all-reduce + flat Adam -- as `world` processes that share cuda:0 over gloo.  Every rank must
+    end with bit-identical parameters that agree with the all-reduced step to rounding, and no wait may have timed out."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for rank in range(world):
+        env = {k: v for k, v in os.environ.items() if k not in ("COPO_FORCE_DIST", "COPO_PEER_ALLREDUCE")}
+        env.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT="29651",
+                   COPO_DIST_BACKEND="gloo", COPO_DP_PROBE_HIDDEN=str(hidden), COPO_DP_PROBE_OBS="20", COPO_DP_PROBE_NETS=str(nets),
+                   COPO_DP_PROBE_VERBOSE="1")
+        procs.append(subprocess.Popen([sys.executable, "-m", "copo_amd.dp_probe"], env=env, cwd=root, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=400) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, (so[-1500:], se[-3000:])
+    assert all("identical on all ranks True" in so for so, _ in outs), outs[0][0]
