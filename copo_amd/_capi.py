@@ -67,6 +67,9 @@ _SIGS = {
     "copo_ppo_workspace_floats": (C.c_int64, [C.POINTER(PpoCfg)]),
     "copo_ppo_fused_step_f32": (C.c_int, [C.POINTER(PpoCfg)] + [C.c_void_p] * 14 + [C.c_int32, C.c_int32, C.c_void_p,
                                                                                    C.c_int32, C.c_void_p, C.c_void_p]),
+    "copo_gather_rows_f32": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int32, C.c_void_p,
+                                       C.c_int64, C.c_void_p]),
+    "copo_pack_columns_f32": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "copo_dp_workspace_bytes": (C.c_int64, [C.POINTER(PpoCfg), C.c_int32]),
     "copo_ppo_fused_step_dp_f32": (C.c_int, [C.POINTER(PpoCfg)] + [C.c_void_p] * 13 + [C.c_void_p, C.c_int32, C.c_void_p,
                                                                                       C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p]),

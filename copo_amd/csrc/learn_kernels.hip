@@ -3,6 +3,8 @@
 //   cc_fuse_mf      mean-field centralised-critic observation            (algo_ccppo.py:266-311)
 //   cc_fuse_concat  concat centralised-critic observation                (algo_ccppo.py:225-263)
 //   lcf_mix         coordinated advantage + batch standardisation        (algo_copo.py:539-551)
+#include <string.h>
+
 #include "sim_common.h"
 
 namespace copo {
@@ -433,7 +435,101 @@ hipError_t launch_plan_epoch(const PlanArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// row movers around the SGD loop (each replaces a handful of framework copy / index kernels per call)
+// ------------------------------------------------------------------------------------------------
+// dst_s[r][:] = src_s[rows[r]][:] for up to COPO_GATHER_MAX_SRC sources in one launch: one wave per output row, float4
+// along a row where the widths and bases allow (the epoch's planned rows into minibatch order: observation + pack
+// (+ centralised-critic observation) rows of ~75 k minibatch entries)
+struct GatherArgs {
+    const float* src[COPO_GATHER_MAX_SRC];
+    float* dst[COPO_GATHER_MAX_SRC];
+    int32_t width[COPO_GATHER_MAX_SRC];
+    int32_t n_src;
+    const int64_t* rows;
+    int64_t n_rows;
+};
+__global__ void __launch_bounds__(256) gather_rows_kernel(GatherArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= a.n_rows) return;
+    const int64_t sr = a.rows[r];
+#pragma unroll
+    for (int s = 0; s < COPO_GATHER_MAX_SRC; ++s) {
+        if (s >= a.n_src) continue;
+        const int w = a.width[s];
+        const float* in = a.src[s] + (size_t)sr * w;
+        float* out = a.dst[s] + (size_t)r * w;
+        if ((w & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.src[s]) | reinterpret_cast<uintptr_t>(a.dst[s])) & 15) == 0) {
+            for (int q = lane; q < (w >> 2); q += 64) reinterpret_cast<float4*>(out)[q] = reinterpret_cast<const float4*>(in)[q];
+        } else {
+            for (int q = lane; q < w; q += 64) out[q] = in[q];
+        }
+    }
+}
+
+// pack[r][off_c .. off_c + width_c) = col_c[r][:] for up to COPO_PACK_MAX_COLS per-row columns (the [rows][17] pack of
+// per-row scalars the step kernels read, from the iteration's separate [T][E][N](x w) tensors)
+struct PackArgs {
+    const float* col[COPO_PACK_MAX_COLS];
+    int32_t width[COPO_PACK_MAX_COLS];
+    int32_t n_cols, pack_width;
+    float* pack;
+    int64_t n_rows;
+};
+__global__ void __launch_bounds__(256) pack_columns_kernel(PackArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // one thread per pack element
+    const int64_t r = i / a.pack_width;
+    if (r >= a.n_rows) return;
+    int k = (int)(i - r * a.pack_width);
+    const int k0 = k;
+    for (int c = 0; c < a.n_cols; ++c) {          // (uniform trip count; the column table is read with scalar loads)
+        if (k < a.width[c]) {
+            a.pack[(size_t)r * a.pack_width + k0] = a.col[c][(size_t)r * a.width[c] + k];
+            return;
+        }
+        k -= a.width[c];
+    }
+}
+
 }  // namespace copo
+
+extern "C" int copo_gather_rows_f32(const float* const* srcs, float* const* dsts, const int32_t* widths, int32_t n_src,
+                                    const int64_t* rows, int64_t n_rows, void* stream) {
+    if (!srcs || !dsts || !widths || !rows) return COPO_ERR_NULL;
+    if (n_src < 1 || n_src > COPO_GATHER_MAX_SRC || n_rows < 0) return COPO_ERR_DIM;
+    if (n_rows == 0) return COPO_OK;
+    copo::GatherArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int s = 0; s < n_src; ++s) {
+        if (!srcs[s] || !dsts[s]) return COPO_ERR_NULL;
+        if (widths[s] < 1) return COPO_ERR_DIM;
+        a.src[s] = srcs[s]; a.dst[s] = dsts[s]; a.width[s] = widths[s];
+    }
+    a.n_src = n_src; a.rows = rows; a.n_rows = n_rows;
+    hipLaunchKernelGGL(copo::gather_rows_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
+}
+
+extern "C" int copo_pack_columns_f32(const float* const* cols, const int32_t* widths, int32_t n_cols, int64_t n_rows, float* pack,
+                                     void* stream) {
+    if (!cols || !widths || !pack) return COPO_ERR_NULL;
+    if (n_cols < 1 || n_cols > COPO_PACK_MAX_COLS || n_rows < 0) return COPO_ERR_DIM;
+    if (n_rows == 0) return COPO_OK;
+    copo::PackArgs a;
+    memset(&a, 0, sizeof(a));
+    int pw = 0;
+    for (int c = 0; c < n_cols; ++c) {
+        if (!cols[c]) return COPO_ERR_NULL;
+        if (widths[c] < 1) return COPO_ERR_DIM;
+        a.col[c] = cols[c]; a.width[c] = widths[c];
+        pw += widths[c];
+    }
+    a.n_cols = n_cols; a.pack_width = pw; a.pack = pack; a.n_rows = n_rows;
+    const int64_t total = n_rows * pw;
+    hipLaunchKernelGGL(copo::pack_columns_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
+}
 
 extern "C" int copo_episode_metrics(const uint8_t* flags, const float* info, const int32_t* nbr_cnt, int64_t n_rows,
                                     double* out15, void* stream) {

@@ -179,10 +179,12 @@ class FusedLearner:
                      cc_obs=None if rs["cc_obs"] is None else torch.zeros(cap, rs["cc_obs"].shape[1], device=dev))
             rs["_dense"] = d
         n = rows.numel()
-        torch.index_select(rs["obs"], 0, rows, out=d["obs"][:n])
-        torch.index_select(rs["pack"], 0, rows, out=d["pack"][:n])
-        if d["cc_obs"] is not None:
-            torch.index_select(rs["cc_obs"], 0, rows, out=d["cc_obs"][:n])
+        names = ["obs", "pack"] + (["cc_obs"] if d["cc_obs"] is not None else [])
+        srcs = (C.c_void_p * len(names))(*[rs[k].data_ptr() for k in names])
+        dsts = (C.c_void_p * len(names))(*[d[k].data_ptr() for k in names])
+        widths = (C.c_int32 * len(names))(*[int(rs[k].shape[1]) for k in names])
+        assert all(rs[k].is_contiguous() and rs[k].dtype == torch.float32 for k in names)
+        _capi.check(_capi.lib.copo_gather_rows_f32(srcs, dsts, widths, len(names), rows.data_ptr(), n, _capi.current_stream()))
         out = dict(rs)
         out.update(obs=d["obs"], pack=d["pack"], cc_obs=d["cc_obs"], rows_all=None)
         return out

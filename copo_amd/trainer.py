@@ -319,11 +319,18 @@ class PPOPolicyBase:
             )
             self._sgd = None
         rs = self._row_sources
-        off = 0
-        for name, w in cols:
-            src = dense[name].reshape(max_rows, w) if w > 1 else dense[name].reshape(max_rows, 1)
-            rs["pack"][:, off:off + w].copy_(src)
-            off += w
+        srcs = [dense[name].reshape(max_rows, w) for name, w in cols]
+        if dev.type == "cuda" and len(cols) <= 24 and all(t.is_contiguous() and t.dtype == torch.float32 for t in srcs):
+            import ctypes as C      # one kernel instead of one strided copy per column
+            from . import _capi
+            _capi.check(_capi.lib.copo_pack_columns_f32((C.c_void_p * len(srcs))(*[t.data_ptr() for t in srcs]),
+                                                        (C.c_int32 * len(srcs))(*[w for _, w in cols]), len(srcs), int(max_rows),
+                                                        rs["pack"].data_ptr(), _capi.current_stream()))
+        else:
+            off = 0
+            for (name, w), src in zip(cols, srcs):
+                rs["pack"][:, off:off + w].copy_(src)
+                off += w
         rs["obs"] = dense[SampleBatch.OBS].reshape(max_rows, -1)
         cc = dense.get("centralized_critic_obs")
         rs["cc_obs"] = None if cc is None else cc.reshape(max_rows, -1)

@@ -281,6 +281,18 @@ int copo_lcf_mix_apply_f32(const float* mixed, const float* glob_adv, const uint
 int copo_episode_metrics(const uint8_t* flags, const float* info, const int32_t* nbr_cnt, int64_t n_rows, double* out15,
                          void* stream);
 
+/* Row movers around the SGD loop.  copo_gather_rows_f32: dsts[s][r][:] = srcs[s][rows[r]][:] for n_src <= COPO_GATHER_MAX_SRC
+ * sources of widths[s] floats per row in ONE launch (host arrays of device pointers) -- the epoch's planned rows into minibatch
+ * order, after which copo_ppo_fused_step_f32 takes rows = NULL.  copo_pack_columns_f32: pack[r] = [cols[0][r] | cols[1][r] | ...]
+ * (widths[c] floats each, <= COPO_PACK_MAX_COLS columns): the per-row pack the step kernels read, from the iteration's separate
+ * column tensors.  (Replace RLlib's SampleBatch column handling inside `train_one_step`, algo_copo.py:555-558.) */
+#define COPO_GATHER_MAX_SRC 4
+#define COPO_PACK_MAX_COLS 24
+int copo_gather_rows_f32(const float* const* srcs, float* const* dsts, const int32_t* widths, int32_t n_src, const int64_t* rows,
+                         int64_t n_rows, void* stream);
+int copo_pack_columns_f32(const float* const* cols, const int32_t* widths, int32_t n_cols, int64_t n_rows, float* pack,
+                          void* stream);
+
 /* Minibatch plan of one SGD epoch (the static-shape replacement of RLlib's shuffled minibatch iterator used by
  * `train_one_step`, algo_copo.py:555-558): from a permutation `perm` of this rank's B_local valid rows `valid_idx`,
  * minibatch k takes q + (k < r) consecutive entries of the shuffled list (q, r = divmod(B_local, n_mb)); rows / w are

@@ -281,3 +281,26 @@ def test_lcf_mix_vs_oracle(B, masked):
     np.testing.assert_allclose(a[3], b[3], rtol=1e-6, atol=1e-6)
     a2 = hip_lcf_mix(adv, nei, glob, lcf, valid)
     assert all(np.array_equal(x, y) for x, y in zip(a, a2))                  # run-to-run deterministic
+
+
+def test_row_movers_equal_the_tensor_code():
+    """`copo_gather_rows_f32` (several sources, one launch; float4 and scalar rows) and `copo_pack_columns_f32` against
+    torch.index_select / column copies, bit for bit."""
+    import ctypes as C
+    import torch
+    from copo_amd import _capi
+    g = torch.Generator(device="cuda").manual_seed(3)
+    R, n = 5000, 7001
+    srcs = [torch.randn(R, w, device="cuda", generator=g) for w in (92, 17, 91)]
+    rows = torch.randint(0, R, (n,), device="cuda", generator=g)
+    dsts = [torch.zeros(n, s.shape[1], device="cuda") for s in srcs]
+    _capi.check(_capi.lib.copo_gather_rows_f32((C.c_void_p * 3)(*[s.data_ptr() for s in srcs]), (C.c_void_p * 3)(*[d.data_ptr() for d in dsts]),
+                                               (C.c_int32 * 3)(92, 17, 91), 3, rows.data_ptr(), n, _capi.current_stream()))
+    for s, d in zip(srcs, dsts):
+        assert torch.equal(d, s.index_select(0, rows))
+    widths = [2, 1, 4, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1]
+    cols = [torch.randn(R, w, device="cuda", generator=g) for w in widths]
+    pack = torch.zeros(R, sum(widths), device="cuda")
+    _capi.check(_capi.lib.copo_pack_columns_f32((C.c_void_p * len(cols))(*[c.data_ptr() for c in cols]), (C.c_int32 * len(cols))(*widths),
+                                                len(cols), R, pack.data_ptr(), _capi.current_stream()))
+    assert torch.equal(pack, torch.cat(cols, 1))
