@@ -348,9 +348,10 @@ def cpu_baseline(num_envs, num_agents, iters=1):
 
 def cpu_baseline_all_cores(num_envs, num_agents, iters=1):
     """Best-effort host figure for the same iteration (round-3 review: the one-thread simulator + 8-thread learner above is
-    not what a 256-thread host can do): the scenes are dealt over one C oracle instance per host thread (ctypes releases the
-    GIL), policy inference is one batched torch call per env step, and the learner runs at the thread count that a short
-    calibration finds fastest for this minibatch size.  Test infrastructure used as the measured CPU port."""
+    not what a 256-thread host can do): the scenes are dealt over C oracle instances on host threads (ctypes releases the GIL),
+    policy inference is one batched torch call per env step, and both the number of simulator workers and the learner's thread
+    count are CALIBRATED on the real thing first (a few env steps / a few real minibatch steps per candidate) -- more threads are
+    not faster for 512-row minibatches.  Test infrastructure used as the measured CPU port."""
     from concurrent.futures import ThreadPoolExecutor
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
@@ -367,58 +368,63 @@ def cpu_baseline_all_cores(num_envs, num_agents, iters=1):
     pol = A.CoPOPolicy(cfg.observation_space, cfg.action_space, cfg)
     E, N = num_envs, num_agents
     T = max(1, -(-2000 // E))
-    W = max(1, min(host, E))                       # simulator workers
-    per = [E // W + (1 if k < E % W else 0) for k in range(W)]
-    offs = np.concatenate([[0], np.cumsum(per)])
-    sims = [ol.OracleSim(SimConfig(map="intersection", num_envs=per[k], num_agents=N, start_seed=5000 + 131 * k)) for k in range(W)]
-    O = sims[0].O
-    pool = ThreadPoolExecutor(W)
     keys = ("obs", "rew", "nei_rew", "glob_rew", "flags", "lcf")
 
-    def step_all(act):          # act [E, N, 2] numpy or None (reset)
-        def one(k):
-            o = sims[k].reset() if act is None else sims[k].step(act[offs[k]:offs[k + 1]])
-            return {q: o[q].copy() for q in keys}
-        outs = list(pool.map(one, range(W)))
-        return {q: np.concatenate([o[q] for o in outs], 0) for q in keys}
+    class Workers:
+        def __init__(self, W):
+            self.W = W
+            per = [E // W + (1 if k < E % W else 0) for k in range(W)]
+            self.offs = np.concatenate([[0], np.cumsum(per)])
+            self.sims = [ol.OracleSim(SimConfig(map="intersection", num_envs=per[k], num_agents=N, start_seed=5000 + 131 * k)) for k in range(W)]
+            self.pool = ThreadPoolExecutor(W)
 
-    torch.set_num_threads(min(host, 64))
-    out = step_all(None)
+        def step(self, act):          # act [E, N, 2] numpy or None (reset)
+            def one(k):
+                o = self.sims[k].reset() if act is None else self.sims[k].step(act[self.offs[k]:self.offs[k + 1]])
+                return {q: o[q].copy() for q in keys}
+            outs = list(self.pool.map(one, range(self.W)))
+            return {q: np.concatenate([o[q] for o in outs], 0) for q in keys}
+
+        def close(self):
+            self.pool.shutdown()
+            for sm in self.sims:
+                sm.close()
+
+    # simulator workers: a few env steps per candidate
+    zero = np.zeros((E, N, 2), np.float32)
+    best_w, best_s = 1, float("inf")
+    for cand in (8, 16, 32, 64, 128, 256):
+        if cand > min(host, E):
+            break
+        wk = Workers(cand)
+        wk.step(None)
+        wk.step(zero)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            wk.step(zero)
+        dt = time.perf_counter() - t0
+        wk.close()
+        if dt < best_s:
+            best_w, best_s = cand, dt
+    wk = Workers(best_w)
+    O = wk.sims[0].O
+    torch.set_num_threads(min(host, 32))
+    out = wk.step(None)
     for _ in range(60):
         a, _, _ = pol.compute_actions(torch.from_numpy(out["obs"]).view(E * N, O))
-        out = step_all(a.view(E, N, 2).clamp(-1, 1).numpy())
-    # learner thread count: time a few minibatch steps of the real loss at each candidate
-    best_t, best_s = 8, float("inf")
-    probe = SampleBatch({SampleBatch.OBS: torch.rand(512, O), SampleBatch.ACTIONS: torch.zeros(512, 2), SampleBatch.ACTION_LOGP: torch.zeros(512),
-                         SampleBatch.ACTION_DIST_INPUTS: torch.zeros(512, 4), Postprocessing.ADVANTAGES: torch.randn(512),
-                         SampleBatch.VF_PREDS: torch.zeros(512), Postprocessing.VALUE_TARGETS: torch.randn(512), A.NEI_VALUES: torch.zeros(512),
-                         A.NEI_ADVANTAGE: torch.randn(512), A.NEI_TARGET: torch.randn(512), A.GLOBAL_VALUES: torch.zeros(512),
-                         A.GLOBAL_TARGET: torch.randn(512), A.GLOBAL_ADVANTAGES: torch.randn(512), "normalized_advantages": torch.randn(512),
-                         SampleBatch.VALID: torch.ones(512), "valid_denominator": torch.tensor(512.0)})
-    probe["centralized_critic_obs"] = probe[SampleBatch.OBS]
-    for cand in (4, 8, 16, 32, 64):
-        if cand > host:
-            break
-        torch.set_num_threads(cand)
-        for rep in range(6):
-            if rep == 2:
-                t0 = time.perf_counter()
-            for p_ in pol.model.parameters():
-                p_.grad = None
-            pol.loss(pol.model, pol.dist_class, probe).backward()
-        dt = (time.perf_counter() - t0) / 4
-        if dt < best_s:
-            best_t, best_s = cand, dt
+        out = wk.step(a.view(E, N, 2).clamp(-1, 1).numpy())
     obs = torch.from_numpy(out["obs"])
+    best_t = None
     agent_steps, t0 = 0, time.perf_counter()
+    t_cal = 0.0
     for _ in range(iters):
-        torch.set_num_threads(min(host, 64))
+        torch.set_num_threads(min(host, 32))
         buf = dict(obs=torch.zeros(T, E, N, O), act=torch.zeros(T, E, N, 2), logp=torch.zeros(T, E, N), di=torch.zeros(T, E, N, 4),
                    rew3=np.zeros((3, T, E, N), np.float32), flags=np.zeros((T, E, N), np.uint8), lcf=np.zeros((T, E, N), np.float32))
         for t in range(T):
             a, lp, di = pol.compute_actions(obs.view(E * N, O))
             buf["obs"][t], buf["act"][t], buf["logp"][t], buf["di"][t] = obs, a.view(E, N, 2), lp.view(E, N), di.view(E, N, 4)
-            out = step_all(a.view(E, N, 2).clamp(-1, 1).numpy())
+            out = wk.step(a.view(E, N, 2).clamp(-1, 1).numpy())
             buf["rew3"][0, t], buf["rew3"][1, t] = out["rew"], out["nei_rew"]
             buf["rew3"][2, t] = out["glob_rew"][:, None]
             buf["flags"][t], buf["lcf"][t] = out["flags"], out["lcf"]
@@ -440,18 +446,35 @@ def cpu_baseline_all_cores(num_envs, num_agents, iters=1):
             A.GLOBAL_TARGET: f(tgt[2]), A.GLOBAL_ADVANTAGES: f(gstd), "normalized_advantages": f(norm)})
         idx = torch.from_numpy(np.nonzero(valid)[0])
         B = int(idx.numel())
-        torch.set_num_threads(best_t)
         pol.prepare_sgd(batch, T * M, 512)
+        if best_t is None:
+            # learner threads: a few REAL minibatch steps per candidate (loss, backward, Adam, the row gathers), outside the clock
+            tc = time.perf_counter()
+            pol._ensure_flat_grads()
+            pol.plan_epoch(idx, B, [B], 512)
+            best_s = float("inf")
+            for cand in (2, 4, 8, 16, 32):
+                if cand > host:
+                    break
+                torch.set_num_threads(cand)
+                pol._row_sources["k"].zero_()
+                pol._sgd_step_local()
+                ts = time.perf_counter()
+                for _ in range(3):
+                    pol._sgd_step_local()
+                dts = (time.perf_counter() - ts) / 3
+                if dts < best_s:
+                    best_t, best_s = cand, dts
+            t_cal += time.perf_counter() - tc
+        torch.set_num_threads(best_t)
         pol.run_sgd(idx, B, [B], 512, 5)
         pol.run_meta(idx, B, [B], 512, 5)
         pol.update_old_policy()
         agent_steps += B
-    dt = time.perf_counter() - t0
-    pool.shutdown()
-    for sm in sims:
-        sm.close()
+    dt = time.perf_counter() - t0 - t_cal
+    wk.close()
     torch.set_num_threads(prev_threads)
-    return agent_steps / dt, dt, agent_steps, W, best_t
+    return agent_steps / dt, dt, agent_steps, best_w, best_t
 
 
 def live_reference(seconds=20.0):

@@ -111,6 +111,10 @@ class TileExchange:
             self.ptrs, self._mapped = _map_all(own, device)
         td.barrier()          # nobody steps before everybody has mapped everybody
 
+    def ok(self):
+        """False if a wait inside any step so far timed out.  Synchronises the stream."""
+        return _capi.lib.copo_dp_status(self._own, C.byref(self.cfg), self.world, _capi.current_stream()) == 0
+
     def status(self):
         """Raises if a wait inside any step so far timed out (a rank that never arrived).  Synchronises the stream."""
         rc = _capi.lib.copo_dp_status(self._own, C.byref(self.cfg), self.world, _capi.current_stream())

@@ -434,7 +434,7 @@ class PPOPolicyBase:
 
     # Data-parallel SGD step, default: the gradient tiles are summed over the ranks INSIDE the weight-gradient kernel
     # (`copo_ppo_fused_step_dp_f32`, peer.TileExchange) -- the data-parallel step is the local step's two
-    # launches, in the same captured chains.  COPO_DP_EXCHANGE = tile | rccl | auto (default): auto takes the tile exchange
+    # launches, in the same captured chains.  COPO_DP_EXCHANGE = tile | try | rccl | auto (default): auto takes the tile exchange
     # when a child process per rank shows that it works on this node (dist.probe_tile_exchange), else the RCCL loop below.
     _tile = None            # peer.TileExchange
     _dp_mode = None         # "tile" / "rccl", decided at the first SGD call of a distributed run
@@ -462,10 +462,12 @@ class PPOPolicyBase:
             return "rccl"
         if D.world_size() == 1:
             return "tile"                    # COPO_FORCE_DIST with one rank: nothing to exchange, the same kernels
-        if want != "tile" and D.ranks_share_a_device(self.device):
+        if want not in ("tile", "try") and D.ranks_share_a_device(self.device):
             return "rccl"                    # (a one-GPU test box: a kernel that waits for its peers starves them of compute units)
         c = self.fused.cfg
-        if want == "tile" or D.probe_tile_exchange(c.hidden, c.pol.in_dim, 1 + c.n_value_heads):
+        # "tile": by name, no probe, a timed-out wait raises; "try": no probe either, but a timed-out wait falls back to the RCCL loop
+        # (what `auto` does after its probe has passed; the tests use it to exercise that fall-back)
+        if want in ("tile", "try") or D.probe_tile_exchange(c.hidden, c.pol.in_dim, 1 + c.n_value_heads):
             self._tile = peer.TileExchange(self.fused.cfg, self.device)
             return "tile"
         return "rccl"
@@ -531,6 +533,11 @@ class PPOPolicyBase:
             else:
                 self._sgd = GraphedCallable(self._fused_local, self.use_graphs)
                 self._sgd_chain = GraphedCallable(self._fused_local_chain, self.use_graphs)
+        # the tile exchange has a bounded wait instead of a hang; should one ever time out on the job's links, every rank goes back
+        # to the state this call started from and repeats it through the RCCL loop (unless the exchange was asked for by name)
+        snap = None
+        if tile and self._tile is not None and os.environ.get("COPO_DP_EXCHANGE", "auto") != "tile":
+            snap = (fz.flat.flat.clone(), fz.adam_m.clone(), fz.adam_v.clone(), fz.step_count.clone(), self.num_grad_updates)
         fz.stats.zero_()
         fz.sync_mirror()          # graph replays below do not run python: refresh the transposed weights here if needed
         steps = 0
@@ -567,7 +574,22 @@ class PPOPolicyBase:
         if self._peer is not None:
             self._peer.status()       # a rank that never arrived in some call: raise here instead of training on partial sums
         if self._tile is not None:
-            self._tile.status()
+            if snap is None:
+                self._tile.status()
+            else:
+                good = torch.tensor([1 if self._tile.ok() else 0], dtype=torch.int32, device=self.device)
+                if D.world_size() > 1:
+                    import torch.distributed as td
+                    td.all_reduce(good, op=td.ReduceOp.MIN)
+                if not bool(good.item()):
+                    import warnings
+                    warnings.warn("data-parallel tile exchange: a wait for a peer timed out; back to the RCCL loop from the state before this call")
+                    fz.flat.flat.copy_(snap[0]); fz.adam_m.copy_(snap[1]); fz.adam_v.copy_(snap[2]); fz.step_count.copy_(snap[3])
+                    self.num_grad_updates = snap[4]
+                    fz.invalidate_mirror()
+                    self._tile.close()
+                    self._tile, self._dp_mode, self._sgd, self._rs_step = None, "rccl", None, None
+                    return self.run_sgd_fused(valid_idx, B_local, B_all, mb, num_epochs)
         tot, pol, vf, kl, ent, vfn, vfg, adv = (fz.stats / max(1, steps)).tolist()
         return dict(total_loss=tot, policy_loss=pol, vf_loss=vf, kl=kl, entropy=ent, cur_kl_coeff=self._kl_value,
                     cur_lr=float(self.config["lr"]), num_sgd_steps=steps, mean_nei_vf_loss=vfn, mean_global_vf_loss=vfg,

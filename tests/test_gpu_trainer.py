@@ -700,3 +700,52 @@ def test_tile_exchange_probe_with_several_ranks_on_one_gpu(world, hidden, nets):
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, (so[-1500:], se[-3000:])
     assert all("identical on all ranks True" in so for so, _ in outs), outs[0][0]
+
+
+@pytest.mark.gpu
+def test_tile_exchange_falls_back_to_the_collective_loop_when_a_wait_times_out():
+    """COPO_DP_EXCHANGE=try on a learner whose weight-gradient grid (hidden 256 x 4 nets = 420 workgroups per rank) cannot be
+    co-resident for two ranks on ONE GPU: the ranks starve each other, a wait times out (10 s), the error word is raised -- and
+    instead of training on partial sums both ranks restore the state the call started from, agree to leave the tile exchange and
+    repeat the epochs through the all-reduce loop.  Parameters must end bit-identical on both ranks and must have moved."""
+    import subprocess
+    import sys
+    code = r'''
+import json, os, sys, warnings, torch
+sys.path.insert(0, os.getcwd())
+from copo_amd import dist as D
+rank, _, world = D.init_from_env("cuda")
+import torch.distributed as td
+from copo_amd.dp_probe import _learner
+os.environ["COPO_DP_PROBE_HIDDEN"], os.environ["COPO_DP_PROBE_OBS"], os.environ["COPO_DP_PROBE_NETS"] = "256", "92", "4"
+pol, batch, R = _learner("try", rank)
+before = pol.fused.flat.flat.clone()
+pol.prepare_sgd(batch, R, 128)
+idx = torch.arange(R, device="cuda")
+B_all = D.all_gather_int(R, "cuda")
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    st = pol.run_sgd(idx, R, B_all, 128, 2)
+fell_back = any("back to the RCCL loop" in str(x.message) for x in w)
+flat = pol.fused.flat.flat
+every = [torch.empty_like(flat) for _ in range(world)]
+td.all_gather(every, flat)
+print("RESULT " + json.dumps(dict(same=all(bool(torch.equal(every[0], e)) for e in every), moved=float((flat - before).abs().max()),
+                                  mode=pol._dp_mode, fell_back=fell_back, steps=st["num_sgd_steps"], finite=bool(torch.isfinite(flat).all()))))
+td.barrier()
+td.destroy_process_group()
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29671",
+                   COPO_DIST_BACKEND="gloo", COPO_FORCE_DIST="0", COPO_PEER_ALLREDUCE="0", COPO_DIST_CHAIN="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=root))
+    outs = [p.communicate(timeout=400) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    for so, _ in outs:
+        r = __import__("json").loads([ln for ln in so.splitlines() if ln.startswith("RESULT ")][-1][7:])
+        assert r["same"] and r["finite"] and r["moved"] > 1e-4 and r["steps"] > 0, r
+        assert r["fell_back"] and r["mode"] == "rccl", r
+
