@@ -73,7 +73,7 @@ static hipError_t gemm_lds_attrs() {
                               reinterpret_cast<const void*>(rowpass_kernel<2, 8, true, true>), reinterpret_cast<const void*>(rowpass_kernel<4, 8, true, true>),
                               reinterpret_cast<const void*>(rowpass_kernel<2, 8, true, false, true>),
                               reinterpret_cast<const void*>(rowpass_kernel<2, 8, true, false, true, 8>), reinterpret_cast<const void*>(rowpass_kernel<2, 8, true, false, false, 8>),
-                              reinterpret_cast<const void*>(rowpass8_kernel<4>)})
+                              reinterpret_cast<const void*>(rowpass8_kernel<4>), reinterpret_cast<const void*>(rowpass8_kernel<4, true>)})
             if ((r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) != hipSuccess) e = r;
         for (const void* f : {reinterpret_cast<const void*>(mlp_fwd_kernel<1, 4>), reinterpret_cast<const void*>(mlp_fwd_kernel<2, 4>),
                               reinterpret_cast<const void*>(mlp_fwd_kernel<2, 8>), reinterpret_cast<const void*>(mlp_fwd_kernel<4, 8>),
@@ -170,12 +170,13 @@ hipError_t launch_fused_step(FusedArgs a, hipStream_t s, const MetaTail* mt_ = n
     if (rowpass) {
         // 8-row tiles where 16-row tiles would leave compute units without a workgroup (rowpass_kernel, RT): the production
         // shape only (hidden 256 through the transposed mirror)
-        const bool rt8 = tw && !bf && rp_h == 256 && head_tiles(c) * G <= 160 && g_rowpass_rt8;
+        const bool rt8 = tw && rp_h == 256 && head_tiles(c) * G <= 160 && g_rowpass_rt8 && (!bf || g_rowpass_4x4);
         if (rt8) a.stat_tiles = (c.mb + 7) / 8;
         const dim3 grid(a.stat_tiles, G);
 #define COPO_RP(NT_, W_, HO_)                                                                                     \
         do {                                                                                                   \
-            if (bf) hipLaunchKernelGGL((rowpass_kernel<NT_, W_, true, true>), grid, dim3(64 * W_), rp_lds, s, a); \
+            if (bf && rt8 && g_rowpass_4x4) hipLaunchKernelGGL((rowpass8_kernel<4, true>), grid, dim3(64 * R8_KS * 4), rowpass8_lds_floats(256, rowpass8_k1p(kmax1)) * sizeof(float), s, a); \
+            else if (bf) hipLaunchKernelGGL((rowpass_kernel<NT_, W_, true, true>), grid, dim3(64 * W_), rp_lds, s, a); \
             else if (rt8 && g_rowpass_4x4) hipLaunchKernelGGL((rowpass8_kernel<4>), grid, dim3(64 * R8_KS * 4), rowpass8_lds_floats(256, rowpass8_k1p(kmax1)) * sizeof(float), s, a); \
             else if (rt8 && HO_ && kmax1 <= 128) hipLaunchKernelGGL((rowpass_kernel<2, 8, true, false, true, 8>), grid, dim3(64 * W_), rp_lds, s, a); \
             else if (rt8) hipLaunchKernelGGL((rowpass_kernel<2, 8, true, false, false, 8>), grid, dim3(64 * W_), rp_lds, s, a); \
