@@ -308,12 +308,15 @@ class PPOPolicyBase:
             gmax = torch.tensor([max_rows], dtype=torch.int64, device=dev)
             D.all_reduce_max_(gmax)
             max_mb = max(1, math.ceil(int(gmax.item()) / mb))
+            # the tables hold the plans of ALL epochs of an iteration back to back (run_sgd_fused plans them up front and the
+            # device-side minibatch counter runs through them without a stop); max_mb = minibatches of ONE epoch
+            n_ep = max(1, int(self.config.get("num_sgd_iter", 1)))
             self._row_sources = dict(
                 max_rows=max_rows, mb=mb, max_mb=max_mb,
                 pack=torch.zeros(max_rows, width, dtype=torch.float32, device=dev),
-                rows_all=torch.zeros(max_mb, mb, dtype=torch.int64, device=dev),
-                w_all=torch.zeros(max_mb, mb, dtype=torch.float32, device=dev),
-                denom_all=torch.ones(max_mb, dtype=torch.float32, device=dev),
+                rows_all=torch.zeros(max_mb * n_ep, mb, dtype=torch.int64, device=dev),
+                w_all=torch.zeros(max_mb * n_ep, mb, dtype=torch.float32, device=dev),
+                denom_all=torch.ones(max_mb * n_ep, dtype=torch.float32, device=dev),
                 k=torch.zeros(1, dtype=torch.int64, device=dev),
                 stats=torch.zeros(len(self.STAT_KEYS), dtype=torch.float32, device=dev),
             )
@@ -455,6 +458,15 @@ class PPOPolicyBase:
         for _ in range(self.SGD_CHAIN):
             self._fused_local()
 
+    # optional longer chain for the bulk of an iteration's ~725 steps (COPO_SGD_CHAIN_LONG > COPO_SGD_CHAIN switches it on).  Measured
+    # on one box, same session: chains of 16 2.58 M agent-steps/s, 32 2.56 M, 64 2.45 M -- the synchronised SGD phase is the same
+    # 23.6 ms, but the host cannot run as far ahead of a 128-node graph launch; off by default
+    SGD_CHAIN_LONG = int(os.environ.get("COPO_SGD_CHAIN_LONG", "0"))
+
+    def _fused_local_chain_long(self):
+        for _ in range(self.SGD_CHAIN_LONG):
+            self._fused_local()
+
     def _pick_dp_mode(self):
         from . import peer
         want = os.environ.get("COPO_DP_EXCHANGE", "auto")
@@ -533,6 +545,7 @@ class PPOPolicyBase:
             else:
                 self._sgd = GraphedCallable(self._fused_local, self.use_graphs)
                 self._sgd_chain = GraphedCallable(self._fused_local_chain, self.use_graphs)
+                self._sgd_chain_long = GraphedCallable(self._fused_local_chain_long, self.use_graphs)
         # the tile exchange has a bounded wait instead of a hang; should one ever time out on the job's links, every rank goes back
         # to the state this call started from and repeats it through the RCCL loop (unless the exchange was asked for by name)
         snap = None
@@ -541,7 +554,32 @@ class PPOPolicyBase:
         fz.stats.zero_()
         fz.sync_mirror()          # graph replays below do not run python: refresh the transposed weights here if needed
         steps = 0
+        n_epochs_asked = num_epochs
         perms = self.draw_perms(num_epochs, B_local)
+        rs0 = self._row_sources
+        n_mb_ep = max(1, math.ceil(max(B_all) / mb))
+        if (tile or not D.is_dist()) and self.use_graphs and self.config.get("gather_epoch_rows", True) and self.config.get("plan_all_epochs", True) \
+                and num_epochs * n_mb_ep <= int(rs0["rows_all"].shape[0]):
+            # every epoch's plan up front, back to back in the tables, ONE gather of all planned rows into minibatch order; the
+            # device-side minibatch counter then walks all num_epochs x n_mb steps in captured chains without a host stop
+            # between the epochs (per epoch that was a plan kernel, a gather kernel and the launch gaps around them)
+            for ep in range(num_epochs):
+                o = ep * n_mb_ep
+                self.plan_epoch(valid_idx, B_local, B_all, mb, perm=None if perms is None else perms[ep],
+                                bufs=dict(rows_all=rs0["rows_all"][o:], w_all=rs0["w_all"][o:], denom_all=rs0["denom_all"][o:], k=rs0["k"]))
+            total = num_epochs * n_mb_ep
+            self._rs_step = fz.gather_epoch(rs0, total)
+            _k0 = 0
+            while self.SGD_CHAIN_LONG > self.SGD_CHAIN and _k0 + self.SGD_CHAIN_LONG <= total:
+                self._sgd_chain_long()
+                _k0 += self.SGD_CHAIN_LONG
+            while _k0 + self.SGD_CHAIN <= total:
+                self._sgd_chain()
+                _k0 += self.SGD_CHAIN
+            for _k in range(_k0, total):
+                self._sgd()
+            steps = total
+            num_epochs = 0          # (the per-epoch loop below has nothing left to do)
         for ep in range(num_epochs):
             n_mb = self.plan_epoch(valid_idx, B_local, B_all, mb, perm=None if perms is None else perms[ep])
             if (tile or not D.is_dist()) and self.config.get("gather_epoch_rows", True):
@@ -589,7 +627,7 @@ class PPOPolicyBase:
                     fz.invalidate_mirror()
                     self._tile.close()
                     self._tile, self._dp_mode, self._sgd, self._rs_step = None, "rccl", None, None
-                    return self.run_sgd_fused(valid_idx, B_local, B_all, mb, num_epochs)
+                    return self.run_sgd_fused(valid_idx, B_local, B_all, mb, n_epochs_asked)
         tot, pol, vf, kl, ent, vfn, vfg, adv = (fz.stats / max(1, steps)).tolist()
         return dict(total_loss=tot, policy_loss=pol, vf_loss=vf, kl=kl, entropy=ent, cur_kl_coeff=self._kl_value,
                     cur_lr=float(self.config["lr"]), num_sgd_steps=steps, mean_nei_vf_loss=vfn, mean_global_vf_loss=vfg,
