@@ -590,10 +590,16 @@ extern "C" int copo_meta_batch_wgrads_f32(const copo_ppo_cfg* cfg, const float* 
     return hipGetLastError() == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
 }
 
-extern "C" int copo_meta_batch_dot_f64(const float* g, int64_t n, int32_t nb, double* gv_out, void* stream) {
+extern "C" int copo_meta_batch_dot_f64(const float* g, int64_t n, int32_t nb, double* gv_out, const float* denom, void* stream) {
     if (!g || !gv_out) return COPO_ERR_NULL;
     if (n < 1 || nb < 1) return COPO_ERR_DIM;
-    hipLaunchKernelGGL(meta_batch_dot_kernel, dim3(nb), dim3(1024), 0, static_cast<hipStream_t>(stream), nullptr, g, n, gv_out);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (nb <= DOT_MAX_NB) {
+        hipLaunchKernelGGL(meta_batch_dot_part_kernel, dim3(nb, DOT_SPLIT), dim3(512), 0, st, g, n);
+        hipLaunchKernelGGL(meta_batch_dot_fin_kernel, dim3((nb + 63) / 64), dim3(64), 0, st, nb, gv_out, denom);
+    } else {
+        hipLaunchKernelGGL(meta_batch_dot_kernel, dim3(nb), dim3(1024), 0, st, nullptr, g, n, gv_out, denom);
+    }
     return hipGetLastError() == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
 }
 

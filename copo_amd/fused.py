@@ -305,8 +305,10 @@ class FusedLearner:
             None if g_out is None else g_out.data_ptr(), gv[first:].data_ptr(), stats_k[first:].data_ptr(),
             _capi.current_stream()))
 
-    def meta_batch_dot(self, g, n, nb, gv):
-        _capi.check(_capi.lib.copo_meta_batch_dot_f64(g.data_ptr(), int(n), int(nb), gv.data_ptr(), _capi.current_stream()))
+    def meta_batch_dot(self, g, n, nb, gv, denom=None):
+        """gv[:nb] = <g[b][0], g[b][1]>; denom [nb] float32: scaled by 1 / denom^2 (unit-weight gradients of the row store)."""
+        _capi.check(_capi.lib.copo_meta_batch_dot_f64(g.data_ptr(), int(n), int(nb), gv.data_ptr(),
+                                                      None if denom is None else denom.data_ptr(), _capi.current_stream()))
 
     _seq_xchg = None
 

@@ -363,9 +363,8 @@ class CoPOPolicy(CCPPOPolicy):
         def finish(c0, n, buf, work):
             if work is not None:
                 work.wait()               # (the compute stream waits; the host does not)
-            fz.meta_batch_dot(buf, nf, n, mb_["gv"][c0:])
-            if self._meta_row_store:          # exported gradients carry unit row weights: both factors 1 / D_k
-                mb_["gv"][c0:c0 + n].div_(mb_["denom_all"][c0:c0 + n].double() ** 2)
+            # (exported gradients of the row store carry unit row weights: both factors 1 / D_k, applied by the kernel)
+            fz.meta_batch_dot(buf, nf, n, mb_["gv"][c0:], denom=mb_["denom_all"][c0:] if self._meta_row_store else None)
 
         for q, c0 in enumerate(range(0, n_mb, nb)):
             n = min(nb, n_mb - c0)

@@ -455,7 +455,10 @@ int copo_meta_batch_grads_f32(const copo_ppo_cfg* cfg, float* theta, float* thet
                               const float* pack_src, const int64_t* rows, const float* w, const float* denom,
                               float* workspace, int32_t nb_cap, int64_t mb_first, int32_t nb, float* g_out,
                               double* gv_out, float* stats_out, void* stream);
-int copo_meta_batch_dot_f64(const float* g /* [nb][2][n] */, int64_t n, int32_t nb, double* gv_out, void* stream);
+/* gv_out[b] = <g[b][0], g[b][1]> (fp64 accumulation, fixed order) of exported -- all-reduced -- gradient pairs; denom (may be
+ * NULL): [nb] row counts D_b, the result is scaled by 1 / D_b^2 (exported gradients of the row-store path carry unit weights). */
+int copo_meta_batch_dot_f64(const float* g /* [nb][2][n] */, int64_t n, int32_t nb, double* gv_out, const float* denom,
+                            void* stream);
 /* Row store.  Everything of phase A that is local to a ROW (both forward passes, the loss gradients, the activation
  * gradients -- with unit row weight) does not depend on how a meta pass groups the rows into minibatches, and the
  * `lcf_num_iters` passes of one training iteration regroup the same rows.  copo_meta_rows_f32 computes it once for rows
