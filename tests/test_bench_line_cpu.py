@@ -1,4 +1,4 @@
-"""The bench line the repository last committed (profiles/r03_bench_kernel_stats.txt, printed by `python bench.py` on an MI355X)
+"""The bench line the repository last committed (profiles/r04_bench_kernel_stats.txt, printed by `python bench.py` on an MI355X)
 carries every field the driver's contract names, with consistent arithmetic -- a CPU-side guard for the line's shape."""
 import json
 import os
@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _committed_line():
-    path = os.path.join(ROOT, "profiles", "r03_bench_kernel_stats.txt")
+    path = os.path.join(ROOT, "profiles", "r04_bench_kernel_stats.txt")
     lines = [ln for ln in open(path) if ln.startswith('{"metric"')]
     assert lines, "no bench line in %s" % path
     return json.loads(lines[-1])        # the plain run (with cpu_baseline) is printed last
@@ -32,6 +32,10 @@ def test_committed_bench_line_has_the_contract_fields():
     want = r["units_per_launch"] * r["bytes_per_unit"] / (r["us_per_launch"] * 1e-6) * 1e-9
     assert abs(r["achieved"] - want) <= 5e-3 * want
     assert r["traffic"] is None or r["traffic"] >= 0.9 * r["units_per_launch"] * r["bytes_per_unit"]     # counters cannot undercut the useful bytes by much
+    # the kernel's actual bound next to the HBM figure: VALU issue rate of the saturated launch
+    v = r["valu"]
+    assert v["bound"] == "valu-issue" and abs(v["frac"] - v["issued"] / v["peak"]) < 1e-3 and 0.5 < v["frac"] <= 1.0
+    assert abs(v["issued"] - v["instructions_per_launch"] / (r["saturated"]["us_per_launch"] * 1e-6) * 1e-9) <= 5e-3 * v["issued"]
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
