@@ -73,24 +73,34 @@ class PeerAllReduce:
 
 
 def _map_all(own, device):
-    """Exchange the hipIpc handle of `own` (this rank's device allocation) with every rank; returns (ctypes array of the
-    world pointers as mapped here, list of the mappings to close)."""
+    """Exchange the hipIpc handle of `own` (this rank's device allocation, or None if the allocation failed) with every rank and
+    map the others'.  Every rank takes part in the SAME collectives whatever fails locally; returns (ctypes array of the world
+    pointers as mapped here, list of the mappings to close, ok) with `ok` agreed by all ranks (a failure anywhere = False
+    everywhere, so that nobody waits for a peer that gave up)."""
     rank, world = td.get_rank(), td.get_world_size()
-    handle = C.create_string_buffer(64)
-    _capi.check(_capi.lib.copo_ipc_export(own, handle))
+    raw = None
+    if own is not None:
+        handle = C.create_string_buffer(64)
+        if _capi.lib.copo_ipc_export(own, handle) == 0:
+            raw = handle.raw
     handles = [None] * world
-    td.all_gather_object(handles, (os.getpid(), handle.raw))
-    mapped = []
+    td.all_gather_object(handles, (os.getpid(), raw))
+    mapped, good = [], raw is not None and all(h[1] is not None for h in handles)
     ptrs = (C.c_void_p * world)()
-    for r, (pid, raw) in enumerate(handles):
-        if r == rank:
-            ptrs[r] = own.value
-        else:
-            p = C.c_void_p()
-            _capi.check(_capi.lib.copo_ipc_open(raw, C.byref(p)))
-            mapped.append(p)
-            ptrs[r] = p.value
-    return ptrs, mapped
+    if good:
+        for r, (pid, h) in enumerate(handles):
+            if r == rank:
+                ptrs[r] = own.value
+            else:
+                p = C.c_void_p()
+                if _capi.lib.copo_ipc_open(h, C.byref(p)) != 0:
+                    good = False
+                    break
+                mapped.append(p)
+                ptrs[r] = p.value
+    flag = torch.tensor([1 if good else 0], dtype=torch.int32, device=device)
+    td.all_reduce(flag, op=td.ReduceOp.MIN)
+    return ptrs, mapped, bool(flag.item())
 
 
 class TileExchange:
@@ -106,10 +116,12 @@ class TileExchange:
             raise ValueError("tile exchange: world size %d not supported" % self.world)
         with torch.cuda.device(device):
             own = C.c_void_p()
-            _capi.check(_capi.lib.copo_peer_alloc(nbytes, C.byref(own)))
+            if _capi.lib.copo_peer_alloc(nbytes, C.byref(own)) != 0:
+                own = None
             self._own = own
-            self.ptrs, self._mapped = _map_all(own, device)
-        td.barrier()          # nobody steps before everybody has mapped everybody
+            self.ptrs, self._mapped, self.usable = _map_all(own, device)      # (its all-reduce: nobody steps before everybody has mapped everybody)
+        if not self.usable:           # agreed by all ranks: hipIpc export / open failed somewhere -- the caller keeps the collective loop
+            self.close()
 
     def ok(self):
         """False if a wait inside any step so far timed out.  Synchronises the stream."""
@@ -124,10 +136,10 @@ class TileExchange:
                                % (self.rank, self.world, rc))
 
     def close(self):
+        torch.cuda.synchronize(self.device)
+        for p in getattr(self, "_mapped", []):
+            _capi.lib.copo_ipc_close(p)
         if getattr(self, "_own", None) is not None:
-            torch.cuda.synchronize(self.device)
-            for p in self._mapped:
-                _capi.lib.copo_ipc_close(p)
             _capi.lib.copo_peer_free(self._own)
-            self._own, self._mapped = None, []
+        self._own, self._mapped = None, []
 

@@ -480,8 +480,12 @@ class PPOPolicyBase:
         # "tile": by name, no probe, a timed-out wait raises; "try": no probe either, but a timed-out wait falls back to the RCCL loop
         # (what `auto` does after its probe has passed; the tests use it to exercise that fall-back)
         if want in ("tile", "try") or D.probe_tile_exchange(c.hidden, c.pol.in_dim, 1 + c.n_value_heads):
-            self._tile = peer.TileExchange(self.fused.cfg, self.device)
-            return "tile"
+            tile = peer.TileExchange(self.fused.cfg, self.device)
+            if tile.usable:               # (agreed by all ranks; False: a hipIpc export / open failed somewhere)
+                self._tile = tile
+                return "tile"
+            if want == "tile":
+                raise RuntimeError("COPO_DP_EXCHANGE=tile: the ranks could not map each other's exchange workspaces (hipIpc)")
         return "rccl"
 
     # data-parallel path, opt-in (COPO_DIST_CHAIN=K): K x [gradient pass, all-reduce, Adam] captured in one graph, the
