@@ -99,6 +99,8 @@ extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** o
     for (int r = 0; r < cfg->n_routes; ++r) {
         const int nseg = (int)cfg->route_meta[r * 4 + 1];
         if (nseg < 1 || nseg > COPO_MAX_SEGS) return fail(COPO_ERR_CONFIG, "route %d has %d roads", r, nseg);
+        const int space = (int)cfg->route_meta[r * 4 + 3];
+        if (space < 0 || space > 32) return fail(COPO_ERR_CONFIG, "route %d: exclusive destination id %d outside 0..32", r, space);
     }
     std::vector<int32_t> safe;
     for (int s = 0; s < cfg->n_spawns; ++s) {
@@ -191,6 +193,11 @@ extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** o
     p.h_sub = cfg->dt / (float)cfg->substeps;
     p.ray_sign = (cfg->num_lasers > 2 && cfg->ray_cs[3] < 0.0f) ? -1.0f : 1.0f;   // the beam table's sense of rotation
     p.n_safe = (int32_t)safe.size();
+    p.n_spaces = 0;
+    for (int r = 0; r < cfg->n_routes; ++r) {
+        const int d = (int)cfg->route_meta[r * 4 + 3];
+        p.n_spaces = std::max(p.n_spaces, (int32_t)d);
+    }
     p.n_lines = (cfg->side_lasers || cfg->lane_line_lasers) ? cfg->n_lines : 0;
     int rc = COPO_OK;
     const size_t EN = (size_t)p.E * p.N;

@@ -17,6 +17,7 @@ enum : uint32_t { RNG_ROUTE = 1, RNG_LCF1 = 2, RNG_LCF2 = 3, RNG_SPAWN = 4, RNG_
 struct SimParams {
     int32_t E, N, O, K, num_lasers, enable_lcf, horizon, delay_done, respawn_cooldown, substeps;
     int32_t n_routes, n_spawns, n_safe, n_lines;
+    int32_t n_spaces;              // exclusive destinations (route_meta[.][3] = id + 1, at most 32); 0 = none
     int32_t chunk;                 // present agents whose LiDAR fans are in LDS at a time (launch shape: sim_shape_params)
     int32_t nbr_chunk;             // present agents whose pair-parallel neighbour lists are in LDS at a time (same)
     int32_t chunk_one_wave;        // `chunk` of the one-wave-per-scene shape (copo_sim_set_chunk; 0 = default)

@@ -147,16 +147,52 @@ __device__ __forceinline__ void spawn_draws(const SimParams& p, uint64_t seed, u
     }
 }
 
+// Route of a spawn at place sp: the (h mod count)-th of the routes that start there.  With exclusive destinations
+// (route_meta[.][3] = id + 1; MetaDrive's ParkingSpaceManager: a parking space is the goal of one living vehicle at a time) it is
+// the (h mod free)-th of those whose space is not in `taken`, in table order; all of them when none is free.  The chosen space
+// joins `taken`.  Uniform over the wave (every lane evaluates it for the slot being served).
+__device__ __forceinline__ int pick_route_exclusive(const float* rmeta, const int32_t* stab, int sp, uint32_t h, uint32_t& taken) {
+    const int first = stab[sp * 4 + 0], count = stab[sp * 4 + 1];
+    int route = first + (int)(h % (uint32_t)count);
+    if (rmeta[first * 4 + 3] > 0.0f) {
+        int nfree = 0;
+        for (int k = 0; k < count; ++k) {
+            const int d = (int)rmeta[(first + k) * 4 + 3];
+            if (!(d > 0 && ((taken >> (d - 1)) & 1u))) nfree += 1;
+        }
+        if (nfree > 0) {
+            int pick = (int)(h % (uint32_t)nfree);
+            for (int k = 0; k < count; ++k) {
+                const int d = (int)rmeta[(first + k) * 4 + 3];
+                if (d > 0 && ((taken >> (d - 1)) & 1u)) continue;
+                if (pick == 0) { route = first + k; break; }
+                --pick;
+            }
+        }
+    }
+    const int d = (int)rmeta[route * 4 + 3];
+    if (d > 0) taken |= 1u << (d - 1);
+    return route;
+}
+// the spaces the living vehicles of the scene are heading for (one lane per slot)
+__device__ __forceinline__ uint32_t spaces_taken(const SimParams& p, const float* rmeta, bool alive, int route_word) {
+    const int d = alive ? (int)rmeta[(route_word & 0xffff) * 4 + 3] : 0;
+    uint32_t taken = 0;
+    for (int k = 1; k <= p.n_spaces; ++k)
+        if (__ballot(d == k) != 0ull) taken |= 1u << (k - 1);
+    return taken;
+}
+
 // `pre`: the draws were made ahead of time (step kernel, several waves per scene: a wave that idles during P0 makes them for
 // every slot, so that a spawn costs wave 0 -- the critical path of the launch -- two LDS reads instead of ~200 instructions)
 __device__ __forceinline__ void spawn_slot(const SimParams& p, const float* rsegs, const int32_t* stab, const float* sps,
                                            uint64_t seed, uint32_t episode, int n, int sp, int32_t aid, Slot& s,
-                                           bool pre = false, uint32_t pre_h = 0, float pre_lcf = 0.0f) {
+                                           bool pre = false, uint32_t pre_h = 0, float pre_lcf = 0.0f, int route_fixed = -1) {
     const uint32_t cnt = (uint32_t)s.spawncnt & 0xffffu;
     uint32_t h = pre_h;
     float lcf = pre_lcf;
     if (!pre) spawn_draws(p, seed, episode, n, cnt, h, lcf);
-    const int route = stab[sp * 4 + 0] + (int)(h % (uint32_t)stab[sp * 4 + 1]);
+    const int route = route_fixed >= 0 ? route_fixed : stab[sp * 4 + 0] + (int)(h % (uint32_t)stab[sp * 4 + 1]);
     const float* g = rsegs + (size_t)route * p.seg_rows * COPO_SEG_STRIDE;
     spawn_pose(p, rsegs, stab, sps, sp, s.x, s.y);
     s.th = g[7];
@@ -252,7 +288,17 @@ __device__ __forceinline__ void reset_env_wave0(const SimParams& p, EnvLds& L, u
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     // population capacity (curriculum): slots beyond it start empty and never respawn
     const int cap = capacity_of(p);
-    if (lane < cap) spawn_slot(p, L.rsegs, L.stab, L.sps, seed, episode, lane, (int)perm[lane], lane, s);
+    int route_fixed = -1;
+    if (p.n_spaces > 0) {          // exclusive destinations: handed out in slot order (nobody of the old episode holds one)
+        uint32_t taken = 0;
+        for (int n = 0; n < cap; ++n) {
+            const uint32_t cnt_n = (uint32_t)__builtin_amdgcn_readlane(s.spawncnt, n) & 0xffffu;
+            const uint32_t h = hash_rng(seed, (uint32_t)n, cnt_n, episode, RNG_ROUTE);
+            const int r = pick_route_exclusive(L.rmeta, L.stab, (int)perm[n], h, taken);
+            if (lane == n) route_fixed = r;
+        }
+    }
+    if (lane < cap) spawn_slot(p, L.rsegs, L.stab, L.sps, seed, episode, lane, (int)perm[lane], lane, s, false, 0u, 0.0f, route_fixed);
     else if (lane < p.N) s.status = st_pack(ST_EMPTY, 0, 0);
 }
 
@@ -1559,13 +1605,14 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
             s.prog = prog;
             const float w = p.lane_width;
             const float lanes_f = g[COPO_SEG_LANES], lanes = floorf(lanes_f), lfr = lanes_f - lanes;      // fraction: edge-line flags
-            const bool left_solid = (lfr == 0.25f) || (lfr == 0.75f), right_solid = lfr >= 0.5f;
+            const int lcode = (int)(lfr * 8.0f);      // edge-line flags in eighths: 1 = left edge open (broken centre line), 2 / 4 = left / right edge solid
+            const bool left_solid = (lcode & 2) != 0, right_solid = (lcode & 4) != 0, left_open = (lcode & 1) != 0;
             float lif = floorf(0.5f - lat * p.inv_w);
             lif = lif < 0.0f ? 0.0f : (lif > lanes - 1.0f ? lanes - 1.0f : lif);
             const float left = 0.5f * w - lat, right = (lanes * w + funnel_extra(g, sl, w)) - left;
             const float cos2 = 1.0f - sinpsi * sinpsi;
             const float edge = p.body_margin * (hw * sqrtf(cos2 > 0.0f ? cos2 : 0.0f) + hl * fabsf(sinpsi));      // body extent across the road
-            const bool on_road = (left >= (left_solid ? edge : 0.0f)) && (right >= (right_solid ? edge : 0.0f));
+            const bool on_road = (left >= (left_solid ? edge : (left_open ? -w : 0.0f))) && (right >= (right_solid ? edge : 0.0f));
             const bool arrive = (seg == nseg - 1) && (sl > g[4] - p.arrive_margin) && (sl < g[4] + p.arrive_margin) && on_road;
             const bool oor = !on_road;
             const bool crash = (L.crash[lane] != 0) || too_fast;
@@ -1627,8 +1674,10 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
                 // the serial part only hands out places (a few scalar operations per waiting slot); the spawns themselves
                 // -- three hash chains, the LCF draw -- run afterwards for all chosen lanes at once
                 uint32_t used = 0;
-                int my_q = -1;
+                int my_q = -1, my_route = -1;
                 int32_t my_aid = 0;
+                uint32_t taken = 0;
+                if (p.n_spaces > 0) taken = spaces_taken(p, L.rmeta, lane < N && st_status(s.status) == ST_ALIVE, s.route);
                 while (elig) {
                     const int n = __ffsll((long long)elig) - 1;
                     elig &= elig - 1;
@@ -1642,12 +1691,17 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
                     while (pick > 0) { m &= m - 1; --pick; }
                     const int q = __ffs((int)m) - 1;
                     used |= 1u << q;
+                    if (p.n_spaces > 0) {
+                        const uint32_t hr = copy_apart ? hr_pre[n] : hash_rng(seed, (uint32_t)n, cnt_n, (uint32_t)episode, RNG_ROUTE);
+                        const int r = pick_route_exclusive(L.rmeta, L.stab, p.safe_ids[q], hr, taken);
+                        if (lane == n) my_route = r;
+                    }
                     if (lane == n) { my_q = q; my_aid = next_aid; }
                     next_aid += 1;
                 }
                 if (my_q >= 0) {
-                    if (copy_apart) spawn_slot(p, L.rsegs, L.stab, L.sps, seed, (uint32_t)episode, lane, p.safe_ids[my_q], my_aid, s, true, hr_pre[lane], lcf_pre[lane]);
-                    else spawn_slot(p, L.rsegs, L.stab, L.sps, seed, (uint32_t)episode, lane, p.safe_ids[my_q], my_aid, s);
+                    if (copy_apart) spawn_slot(p, L.rsegs, L.stab, L.sps, seed, (uint32_t)episode, lane, p.safe_ids[my_q], my_aid, s, true, hr_pre[lane], lcf_pre[lane], my_route);
+                    else spawn_slot(p, L.rsegs, L.stab, L.sps, seed, (uint32_t)episode, lane, p.safe_ids[my_q], my_aid, s, false, 0u, 0.0f, my_route);
                     present = true;
                     fl = COPO_F_SPAWNED;
                     lcf_row = s.lcf;

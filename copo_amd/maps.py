@@ -43,7 +43,7 @@ ENTRANCE_LENGTH = 10.0           # FirstPGBlock: the first 10 m of the first blo
 class MapTables:
     name: str
     route_segs: np.ndarray   # [R][MAX_SEGS+1][SEG_STRIDE] f32
-    route_meta: np.ndarray   # [R][4] f32: total_len (lane-0 line), nseg, index of the toll-booth road (-1: none), 0
+    route_meta: np.ndarray   # [R][4] f32: total_len (lane-0 line), nseg, index of the toll-booth road (-1: none), exclusive destination id + 1 (0: none)
     spawn_tab: np.ndarray    # [P][4] i32: first_route, n_destinations, lane, safe (1 = a respawn place)
     spawn_s: np.ndarray      # [P] f32 longitudinal position of the slot on the spawn road
     default_num_agents: int
@@ -100,14 +100,20 @@ class Net:
         self.toll_roads = set()  # roads that are toll booths (Tollgate)
         self.solid = {}          # road -> (left edge continuous, right edge continuous)
         self.funnel = {}         # road -> (wave radius, extra width at the wide end, +1 narrowing / -1 widening): Merge / Split blocks
+        self.open_left = set()   # roads whose broken left edge line may be crossed (one lane width of the opposite direction)
+        self.open_left_if_broken = False
 
     def add(self, a, b, pose, length, kappa, lanes, left_line=LINE_CONTINUOUS, right_line=LINE_CONTINUOUS,
-            inner_line=LINE_BROKEN, toll=False):
+            inner_line=LINE_BROKEN, toll=False, open_left=False):
         """`pose` is the start of lane 0's centre line.  Line kinds: 0 = none (inside junctions)."""
         assert (a, b) not in self.roads, (a, b)
         self.roads[(a, b)] = (tuple(float(v) for v in pose), float(length), float(kappa), int(lanes))
         # edge lines that a vehicle's body must not touch (MetaDrive: on_yellow / on_white_continuous_line): continuous ones
         self.solid[(a, b)] = (left_line == LINE_CONTINUOUS, right_line == LINE_CONTINUOUS)
+        # a BROKEN left edge line with the opposite direction's lane behind it may be crossed (MetaDrive: the vehicle is still
+        # `on_lane`; only continuous lines and the sidewalk end an agent): maps that model it set `open_left_if_broken`
+        if getattr(self, "open_left_if_broken", False) and (left_line == LINE_BROKEN or open_left):
+            self.open_left.add((a, b))
         if toll:
             self.toll_roads.add((a, b))
         self.adj.setdefault(a, []).append(b)
@@ -190,16 +196,17 @@ class Net:
         return path[::-1]
 
 
-def road_record(pose, length, kappa, lanes, s_start, w, solid=(False, False), funnel=None):
+def road_record(pose, length, kappa, lanes, s_start, w, solid=(False, False), funnel=None, open_left=False):
     """One SEG_STRIDE record (float64) for a road whose lane-0 line starts at `pose`.  The lanes field carries the edge-line
-    flags in its fraction: lanes + 0.25 (left edge continuous) + 0.5 (right edge continuous)."""
+    flags in its fraction: lanes + 0.25 (left edge continuous) + 0.5 (right edge continuous) + 0.125 (left edge broken with a
+    drivable lane of the opposite direction behind it: the centre may go one lane width beyond the line)."""
     x, y, th = pose
     rec = np.zeros(SEG_STRIDE, np.float64)
     rec[[SEG_X0, SEG_Y0, SEG_COS, SEG_SIN, SEG_LEN, SEG_KAPPA, SEG_S0, SEG_TH0]] = [
         x, y, math.cos(th), math.sin(th), length, kappa, s_start, _wrap(th)]
     end = advance(pose, length, kappa)
     ck = shift(end, -(lanes / 2.0 - 0.5) * w)          # end of the road, lateral middle (Navigation check point)
-    rec[SEG_CKX], rec[SEG_CKY], rec[SEG_LANES] = ck[0], ck[1], lanes + 0.25 * bool(solid[0]) + 0.5 * bool(solid[1])
+    rec[SEG_CKX], rec[SEG_CKY], rec[SEG_LANES] = ck[0], ck[1], lanes + 0.25 * bool(solid[0]) + 0.5 * bool(solid[1]) + 0.125 * bool(open_left and not solid[0])
     if kappa == 0:
         rec[SEG_F_RADIUS], rec[SEG_RADIUS], rec[SEG_F_ANGLE] = 0.0, 0.0, 0.5
         rec[SEG_UMX], rec[SEG_UMY] = 1.0, 0.0
@@ -234,7 +241,8 @@ class _Builder:
             solid = net.solid[(nodes[k], nodes[k + 1])]
             if (nodes[k], nodes[k + 1]) in net.toll_roads:
                 toll = k
-            rec[k] = road_record(pose, ln, kap, lanes, s, w, solid, net.funnel.get((nodes[k], nodes[k + 1])))
+            rec[k] = road_record(pose, ln, kap, lanes, s, w, solid, net.funnel.get((nodes[k], nodes[k + 1])),
+                                 open_left=(nodes[k], nodes[k + 1]) in net.open_left)
             s += ln
         end = net.end_pose(nodes[-2], nodes[-1])
         nseg = len(nodes) - 1
@@ -243,13 +251,17 @@ class _Builder:
         self.routes.append(rec)
         self.meta.append([s, nseg, toll, 0.0])
 
-    def add_spawn_road(self, road, destinations, slot_longs, safe_only_first=True, lanes=None):
-        """Routes from `road` (a, b) to every destination node; slots on each of its lanes at `slot_longs`."""
+    def add_spawn_road(self, road, destinations, slot_longs, safe_only_first=True, lanes=None, exclusive=None):
+        """Routes from `road` (a, b) to every destination node; slots on each of its lanes at `slot_longs`.
+        `exclusive`: per destination an id >= 0 of a place that only ONE living agent may be heading for at a time (MetaDrive's
+        ParkingSpaceManager: a parking space is handed out once and comes back when its agent is done) -> route_meta[r][3] = id + 1."""
         net = self.net
         first = len(self.routes)
-        for d in destinations:
+        for k, d in enumerate(destinations):
             nodes = [road[0]] + net.bfs(road[1], d)
             self.add_route(nodes)
+            if exclusive is not None:
+                self.meta[-1][3] = float(exclusive[k] + 1)
         n_l = net.roads[road][3] if lanes is None else lanes
         if slot_longs and max(slot_longs) >= net.roads[road][1]:
             raise ValueError("spawn slot beyond the spawn road")
@@ -397,7 +409,8 @@ def tollgate(exit_length=70.0, lanes=3, toll_lanes=8, toll_length=10.0, taper=20
     return b.finish()
 
 
-def parkinglot(spaces=8, exit_length=20.0, lane_width=LANE_WIDTH, turn_radius=4.0, depth=8.0, arm=10.0, junction_radius=10.0):
+def parkinglot(spaces=8, exit_length=20.0, lane_width=LANE_WIDTH, turn_radius=4.0, depth=8.0, arm=10.0, junction_radius=10.0,
+               unique_spaces=True, centre_line_open=True):
     """MAParkinglotMap (10 agents, `parking_space_num = 8`, `exit_length = 20`, one lane per direction): FirstPGBlock ->
     ParkingLot block -> T-intersection (`t_type = 1`: the straight arm is missing, `EXIT_PART_LENGTH = 10`).
     ParkingLot block (`one_side_vehicle_num = spaces / 2`, `radius` 4, `length` 8): a main road of `2 r + (n - 1) w` = 18.5 m and a
@@ -409,9 +422,14 @@ def parkinglot(spaces=8, exit_length=20.0, lane_width=LANE_WIDTH, turn_radius=4.
       out to the far lane:    the space reversed -> straight `w` -> left bend (r) -> [straight `dist_to_in`] -> previous block
     Entrances (spawn roads, one slot each at 4 m): the first block's 10 m spawn road and the two arms of the T; a vehicle that enters
     there is sent into a space, a vehicle that starts in a space (slot at 4 m of its 8 m) to the far end of one of the three exits.
+    `unique_spaces` (MetaDrive's ParkingSpaceManager, envs/marl_envs/marl_parking_lot.py): an entrant is sent to a space that no
+    other living agent is heading for; the space comes back when that agent is done.  `centre_line_open`: the broken centre line
+    of the two-way roads may be crossed -- a vehicle in the opposite lane is still `on_lane` in MetaDrive; continuous lines and
+    the sidewalk end an agent.  (Both False: the round-3 scene.)
     Frame: the positive lane runs along +x at y = 0, the negative lane back at y = w."""
     w, r = lane_width, turn_radius
     net = Net(w)
+    net.open_left_if_broken = bool(centre_line_open)
     n = spaces // 2
     x0 = exit_length                                   # the ParkingLot block starts where the first block ends
     main = 2 * r + (n - 1) * w
@@ -455,8 +473,8 @@ def parkinglot(spaces=8, exit_length=20.0, lane_width=LANE_WIDTH, turn_radius=4.
                 far, far_node, far_next = (x0, 0.0, 0.0), "P", "S"
             # in from the near lane: [straight] -> right bend -> space
             e, src = near, near_node
-            if d_in > 1e-9:
-                e = net.add(src, k + "a", e, d_in, 0.0, 1, *NO)
+            if d_in > 1e-9:       # (the in-block straights run along the main road's lanes: the same broken centre line on their left)
+                e = net.add(src, k + "a", e, d_in, 0.0, 1, *NO, open_left=True)
                 src = k + "a"
             e = net.add(src, k + "b", e, r * math.pi / 2, -1.0 / r, 1, *NO)
             space_start = e
@@ -465,7 +483,7 @@ def parkinglot(spaces=8, exit_length=20.0, lane_width=LANE_WIDTH, turn_radius=4.
             # in from the far lane: [straight] -> left bend -> straight w -> space
             e, src = far, far_node
             if d_out > 1e-9:
-                e = net.add(src, k + "d", e, d_out, 0.0, 1, *NO)
+                e = net.add(src, k + "d", e, d_out, 0.0, 1, *NO, open_left=True)
                 src = k + "d"
             e = net.add(src, k + "e", e, r * math.pi / 2, 1.0 / r, 1, *NO)
             e = net.add(k + "e", k + "b", e, w, 0.0, 1, *NO)
@@ -476,16 +494,16 @@ def parkinglot(spaces=8, exit_length=20.0, lane_width=LANE_WIDTH, turn_radius=4.
             # out to the near lane: right bend -> [straight] -> the next block's road
             o = net.add(k + "g", k + "h" if d_out > 1e-9 else near_next, e, r * math.pi / 2, -1.0 / r, 1, *NO)
             if d_out > 1e-9:
-                net.add(k + "h", near_next, o, d_out, 0.0, 1, *NO)
+                net.add(k + "h", near_next, o, d_out, 0.0, 1, *NO, open_left=True)
             # out to the far lane: straight w -> left bend -> [straight] -> the previous block's road
             o = net.add(k + "g", k + "i", e, w, 0.0, 1, *NO)
             o = net.add(k + "i", k + "j" if d_in > 1e-9 else far_next, o, r * math.pi / 2, 1.0 / r, 1, *NO)
             if d_in > 1e-9:
-                net.add(k + "j", far_next, o, d_in, 0.0, 1, *NO)
+                net.add(k + "j", far_next, o, d_in, 0.0, 1, *NO, open_left=True)
     b = _Builder("parkinglot", net, 10, 40.0)
     half_slot = [RESPAWN_REGION_LONGITUDE / 2]
     for road in (("in0", "P"), ("inA", "Ai"), ("inB", "Bi")):         # entrants park in one of the spaces
-        b.add_spawn_road(road, dests, half_slot, safe_only_first=False)
+        b.add_spawn_road(road, dests, half_slot, safe_only_first=False, exclusive=list(range(len(dests))) if unique_spaces else None)
     for side in ("s", "n"):                                          # parked vehicles leave through one of the three exits
         for i in range(n):
             b.add_spawn_road(("%s%df" % (side, i), "%s%dg" % (side, i)), ["end0", "endA", "endB"], half_slot, safe_only_first=False)

@@ -76,6 +76,8 @@ extern "C" {
  *   6 s_start (route arc length at the start)           7 theta0
  *   8 ckx, 9 cky   navigation check point: the end of the road at its lateral middle
  *  10 lanes + 0.25 (left edge line continuous) + 0.5 (right edge line continuous): the edges a body must not touch (body_margin)
+ *            + 0.125 (left edge line BROKEN and crossable: the reference point may be up to one lane width left of lane 0 --
+ *                     MetaDrive's on_lane of the opposite road across a broken centre line, as in the parking-lot block)
  *                  11 radius feature of the navigation block, 12 radius (0 for a plain straight), 13 angle feature
  *  14 umx, 15 umy unit vector from an arc's centre to its mid point (projection without a wrap inside the arc)
  * STRAIGHT records (kappa == 0) overload 12 / 14 / 15 for MetaDrive's Merge / Split blocks (maps.Net.add_funnel; read by
@@ -138,7 +140,10 @@ typedef struct copo_sim_cfg {
     int32_t n_routes;
     int32_t n_spawns;
     const float* route_segs;   /* [n_routes][COPO_MAX_SEGS + 1][COPO_SEG_STRIDE] */
-    const float* route_meta;   /* [n_routes][4] = {total_len, nseg, index of the toll-booth road or -1, 0} */
+    const float* route_meta;   /* [n_routes][4] = {total_len, nseg, index of the toll-booth road or -1, exclusive destination id + 1 or 0}.
+                                * Exclusive destinations (at most 32 per map; MetaDrive's ParkingSpaceManager): a spawn draws its route among
+                                * those of its spawn place whose destination no LIVING agent of the scene is heading for (all of them if
+                                * none is free); the space is free again when that agent is done. */
     const int32_t* spawn_tab;  /* [n_spawns][4] = {first_route, n_destinations, lane, safe} */
     const float* spawn_s;      /* [n_spawns] longitudinal position of the slot on its spawn road */
     const float* ray_cs;       /* [num_lasers][2] = beam directions in the vehicle frame (forward, left) */

@@ -154,6 +154,7 @@ typedef struct oracle_sim {
     float inv_w, inv_range, inv_vnorm, inv_dt, inv_side_range, inv_lane_range, inv_toll;
     int safe_ids[COPO_MAX_SAFE];
     int n_safe;
+    int n_spaces;              /* exclusive destinations (route_meta[.][3] = id + 1), 0 = none; at most 32 */
 } oracle_sim;
 
 static float* FP(oracle_sim* s, int f, int e) { return s->st + ((size_t)f * s->cfg.num_envs + e) * s->cfg.num_agents; }
@@ -209,6 +210,11 @@ int oracle_sim_create(const copo_sim_cfg* cfg, oracle_sim** out) {
             s->safe_ids[s->n_safe++] = p;
         }
     if (s->n_safe < 1) { oracle_sim_destroy(s); return COPO_ERR_CONFIG; }
+    for (int r = 0; r < cfg->n_routes; ++r) {
+        int d = (int)s->route_meta[r * 4 + 3];
+        if (d < 0 || d > 32) { oracle_sim_destroy(s); return COPO_ERR_CONFIG; }
+        if (d > s->n_spaces) s->n_spaces = d;
+    }
     *out = s;
     return COPO_OK;
 }
@@ -260,7 +266,33 @@ static void spawn_agent(oracle_sim* s, int e, int n, int sp) {
     uint32_t cnt = (uint32_t)IP(s, S_SPAWNCNT, e)[n] & 0xffffu;
     uint32_t epi = (uint32_t)env[1];
     uint32_t h = o_hash(seed, (uint32_t)n, cnt, epi, RNG_ROUTE);
-    int route = s->spawn_tab[sp * 4 + 0] + (int)(h % (uint32_t)s->spawn_tab[sp * 4 + 1]);
+    int first = s->spawn_tab[sp * 4 + 0], count = s->spawn_tab[sp * 4 + 1];
+    int route = first + (int)(h % (uint32_t)count);
+    if (s->n_spaces > 0 && s->route_meta[first * 4 + 3] > 0.0f) {
+        /* exclusive destinations (MetaDrive's ParkingSpaceManager, marl_parking_lot.py): a space that a LIVING agent is heading for
+         * is not handed out again; it comes back when that agent is done.  The h-th of the free ones, in table order; if every
+         * one is taken the draw is over all of them. */
+        uint32_t taken = 0;
+        for (int j = 0; j < c->num_agents; ++j) {
+            if (j == n || ST_STATUS(IP(s, S_STATUS, e)[j]) != ST_ALIVE) continue;
+            int d = (int)s->route_meta[(IP(s, S_ROUTE, e)[j] & 0xffff) * 4 + 3];
+            if (d > 0) taken |= 1u << (d - 1);
+        }
+        int nfree = 0;
+        for (int k = 0; k < count; ++k) {
+            int d = (int)s->route_meta[(first + k) * 4 + 3];
+            if (!(d > 0 && ((taken >> (d - 1)) & 1u))) nfree += 1;
+        }
+        if (nfree > 0) {
+            int pick = (int)(h % (uint32_t)nfree);
+            for (int k = 0; k < count; ++k) {
+                int d = (int)s->route_meta[(first + k) * 4 + 3];
+                if (d > 0 && ((taken >> (d - 1)) & 1u)) continue;
+                if (pick == 0) { route = first + k; break; }
+                --pick;
+            }
+        }
+    }
     const float* g = SEG(s, route, 0);
     spawn_pose(s, sp, &FP(s, S_X, e)[n], &FP(s, S_Y, e)[n]);
     FP(s, S_TH, e)[n] = g[7];
@@ -319,6 +351,7 @@ static void reset_env(oracle_sim* s, int e) {
     }
     /* population capacity (curriculum): slots beyond it start empty and never respawn */
     int cap = oracle_capacity(s);
+    for (int n = 0; n < N; ++n) IP(s, S_STATUS, e)[n] = ST_PACK(ST_EMPTY, 0, 0);     /* nobody of the old episode holds a space */
     for (int n = 0; n < N; ++n) {
         if (n < cap) spawn_agent(s, e, n, perm[n]);
         else IP(s, S_STATUS, e)[n] = ST_PACK(ST_EMPTY, 0, 0);
@@ -891,15 +924,16 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
             }
             IP(s, S_ROUTE, e)[n] = route | (seg << 16);
             FP(s, S_PROG, e)[n] = prog;
-            float lanes_f = g[COPO_SEG_LANES], lanes = floorf(lanes_f), lfr = lanes_f - lanes;      /* fraction: edge-line flags */
-            int left_solid = (lfr == 0.25f) || (lfr == 0.75f), right_solid = lfr >= 0.5f;
+            float lanes_f = g[COPO_SEG_LANES], lanes = floorf(lanes_f), lfr = lanes_f - lanes;      /* fraction: edge-line flags, eighths */
+            int lcode = (int)(lfr * 8.0f);
+            int left_solid = (lcode & 2) != 0, right_solid = (lcode & 4) != 0, left_open = (lcode & 1) != 0;
             float lif = floorf(0.5f - lat * s->inv_w);
             lif = lif < 0.0f ? 0.0f : (lif > lanes - 1.0f ? lanes - 1.0f : lif);
             float left = 0.5f * w - lat, right = (lanes * w + funnel_extra(g, sl, w)) - left;
             /* the body's half extent across the road (heading error psi): the edge lines must not be touched */
             float cos2 = 1.0f - sinpsi * sinpsi;
             float edge = c->body_margin * (hw * sqrtf(cos2 > 0.0f ? cos2 : 0.0f) + hl * fabsf(sinpsi));
-            int on_road = (left >= (left_solid ? edge : 0.0f)) && (right >= (right_solid ? edge : 0.0f));
+            int on_road = (left >= (left_solid ? edge : (left_open ? -w : 0.0f))) && (right >= (right_solid ? edge : 0.0f));
             /* _is_arrive_destination: within +-5 m of the end of the final road, anywhere across it */
             int arrive = (seg == nseg - 1) && (sl > g[4] - c->arrive_margin) && (sl < g[4] + c->arrive_margin) && on_road;
             int out_of_road = !on_road;         /* vehicle.out_of_route (out_of_route_done) */

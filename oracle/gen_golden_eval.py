@@ -99,6 +99,17 @@ def populations():
         stats[algo + "_inter"] = dict(populations=len(files), episodes=int(len(d)), **{c: float(d[c].mean()) for c in cols})
         # per population (the shipped `copo_inter.npz` is population 0: get_policy_function.py:30-31 "Best")
         stats[algo + "_inter_per_population"] = [{c: float(pd.read_csv(f)[c].mean()) for c in cols} for f in files]
+    # reward-scale decomposition: per population, D_hat = episode_length_mean x velocity_step_mean / 3.6 x 0.1 s (metres an agent
+    # drives, estimated from the two recorded means, per env episode) and k_hat = (episode_reward_mean - 10 success + 10 crash + 10 out) / D_hat
+    # (reward per estimated metre net of the terminal rewards); the same two estimators are evaluated on this build's rows
+    for algo in ("ippo", "copo"):
+        files = sorted(glob.glob(os.path.join(res_dir, "%s_inter_*.csv" % algo)))
+        for f, rec in zip(files, stats[algo + "_inter_per_population"]):
+            d = pd.read_csv(f)
+            dist = d["episode_length_mean"] * d["velocity_step_mean_episode_mean"] / 3.6 * 0.1
+            net = d["episode_reward_mean"] - 10.0 * d["success_rate"] + 10.0 * d["crash_rate"] + 10.0 * d["out_rate"]
+            rec["metres_hat"] = float(dist.mean())
+            rec["reward_per_metre_hat"] = float((net / dist).mean())
     for k in list(stats):      # env episode length in steps (recoder.py:246-247: agents per 300 steps = agents / steps * 300)
         for d in (stats[k] if isinstance(stats[k], list) else [stats[k]]):
             d["env_episode_steps"] = d["num_agents_total"] / d["num_agents_total_per_300_steps"] * 300.0

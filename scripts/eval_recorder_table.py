@@ -38,3 +38,13 @@ for name, algo in (("copo_inter", "copo"), ("ippo_inter", "ippo")):
         vals = [p[c] for p in per if c in p]
         print("  %-36s %9.3f | %9.3f [%8.3f .. %8.3f]%s" % (c, m[c], ref.get(c, float("nan")), min(vals), max(vals),
                                                              (" | %9.3f" % per[0][c]) if name == "copo_inter" else ""))
+    # reward-scale decomposition: the same two estimators on this build's rows and on the reference's CSV rows
+    # (oracle/gen_golden_eval.py): metres an agent drives ~ episode_length_mean x velocity_step_mean / 3.6 x 0.1, and the reward per such
+    # metre net of the terminal rewards.  Their product is the route reward; the reference's ceiling / this build's = 1.196.
+    dist = df["episode_length_mean"] * df["velocity_step_mean_episode_mean"] / 3.6 * 0.1
+    net = df["episode_reward_mean"] - 10.0 * df["success_rate"] + 10.0 * df["crash_rate"] + 10.0 * df["out_rate"]
+    for c, here in (("metres_hat", float(dist.mean())), ("reward_per_metre_hat", float((net / dist).mean()))):
+        vals = [p[c] for p in per if c in p]
+        if vals:
+            print("  %-36s %9.3f | %9.3f [%8.3f .. %8.3f]%s" % (c, here, float(np.mean(vals)), min(vals), max(vals),
+                                                                 (" | %9.3f" % per[0][c]) if name == "copo_inter" else ""))

@@ -8,6 +8,7 @@ mkdir -p $OUT; rm -rf /tmp/prof_bench
 cd $GRAFT_REPO_ROOT
 scripts/sim_traffic.sh > /tmp/traffic.log 2>&1
 cp $OUT/sim_traffic.json profiles/sim_traffic.json 2>/dev/null     # bench.py reads it (source hash checked)
+cp $OUT/sim_valu.json profiles/sim_valu.json 2>/dev/null           # (written by scripts/prof_sim_round.sh saturated when it ran in the same call)
 python bench.py --steps 10 --warmup 5 > /tmp/bench_plain.log 2>&1
 rocprofv3 --kernel-trace --stats -d /tmp/prof_bench -- python bench.py --steps 10 --warmup 5 --no-cpu-baseline > /tmp/bench_traced.log 2>&1
 DB=$(find /tmp/prof_bench -name "*_results.db" | head -1)

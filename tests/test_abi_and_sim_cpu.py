@@ -196,6 +196,69 @@ def test_parking_lot_follows_the_block_formulas():
     assert len(park) == 8 and all(abs(t.spawn_s[s_] - 4.0) < 1e-6 for s_ in park)
 
 
+def test_parking_spaces_are_exclusive_and_the_centre_line_is_open():
+    """MAParkingLotEnv keeps a ParkingSpaceManager: a parking space is the destination of ONE living vehicle at a time and comes back
+    when that vehicle is done (route_meta[.][3] = id + 1); the centre line inside the parking block is broken, so a vehicle may run
+    one lane left of its carriageway there (road record fraction + 0.125) -- the round-3 review's two parking-lot gaps."""
+    t = maps.parkinglot()
+    dest = t.route_meta[:, 3].astype(int)
+    assert (dest > 0).sum() == 24 and sorted(set(dest[dest > 0])) == list(range(1, 9))
+    old = maps.parkinglot(unique_spaces=False, centre_line_open=False)
+    assert not old.route_meta[:, 3].any() and set(np.unique(old.route_segs[:, :, maps.SEG_LANES] % 1.0)) <= {0.0, 0.25, 0.5, 0.75}
+
+    def doubles(kwargs, unique):
+        cfg = SimConfig(map="parkinglot", map_kwargs=kwargs, num_envs=4, num_agents=10, horizon=300)
+        s = ol.OracleSim(cfg)
+        o = s.reset()
+        rng = np.random.RandomState(0)
+        n_double, n_seen = 0, 0
+        for _ in range(400):
+            psi = np.arcsin(np.clip((0.5 - o["obs"][..., 2]) * 2, -1, 1))
+            lat = -(o["obs"][..., 8] - 0.5) * 4.5
+            steer = np.clip(-1.5 * psi - 0.25 * lat + rng.normal(0, 0.02, psi.shape), -1, 1)
+            o = s.step(np.stack([steer, np.full((s.E, s.N), 0.4)], -1).astype(np.float32))
+            st, _ = s.get_state()
+            route = st[12].view(np.int32) & 0xffff
+            alive = (st[13].view(np.int32) & 0xff) == 1
+            for e in range(s.E):
+                d = dest[route[e][alive[e]]]            # (the two variants number their routes alike)
+                d = d[d > 0]
+                n_seen += len(d)
+                if len(set(d)) < len(d):
+                    n_double += 1
+                    assert not unique or len(set(d)) == 8, "a space was handed out twice while another was free"
+        s.close()
+        return n_double, n_seen
+
+    dbl, seen = doubles({}, True)
+    assert seen > 0 and dbl == 0
+    dbl_old, _ = doubles(dict(unique_spaces=False), False)
+    assert dbl_old > 0, "without the manager two vehicles do head for one space in this rollout"
+    # a vehicle one lane LEFT of its carriageway on an in-block straight: on the road with the broken centre line, off it without
+    for open_, want in ((True, 0), (False, 16)):
+        kw = dict(centre_line_open=open_)
+        tt = maps.parkinglot(**kw)
+        cfg = SimConfig(map="parkinglot", map_kwargs=kw, num_envs=1, num_agents=2, horizon=300)
+        s = ol.OracleSim(cfg)
+        s.reset()
+        st, env = s.get_state()
+        r = 1                                           # entrant to space 1: road 1 is the 3.5 m straight inside the block
+        g = tt.route_segs[r, 1].astype(np.float64)
+        assert g[maps.SEG_KAPPA] == 0 and abs(g[maps.SEG_LEN] - tt.lane_width) < 1e-6
+        assert (g[maps.SEG_LANES] % 0.25 > 0.1) == open_
+        w = tt.lane_width
+        st[0, 0, 0] = g[0] + g[2] * 1.0 - g[3] * w      # 1 m in, one lane to the left
+        st[1, 0, 0] = g[1] + g[3] * 1.0 + g[2] * w
+        st[2, 0, 0] = g[7]
+        st[3, 0, 0] = 0.0
+        st[9, 0, 0] = g[6] + 1.0
+        st[12].view(np.int32)[0, 0] = r | (1 << 16)
+        s.set_state(st, env)
+        o = s.step(np.zeros((1, 2, 2), np.float32))
+        assert int(o["flags"][0, 0]) & 16 == want, (open_, int(o["flags"][0, 0]))
+        s.close()
+
+
 def test_generated_roads_are_seeded_and_drivable():
     """PG road (the `MultiAgentMetaDrive` base env): a (sequence, seed) pair names one map, opposite carriageways stay a
     lane width apart through every block, and lane-keeping agents reach the far end in the oracle simulator."""

@@ -61,7 +61,12 @@ def _table(algo, name, gold, lcf, episodes=1):
     from copo_amd.eval.evaluate import evaluate_population_rows
     df = evaluate_population_rows(algo, "inter", _weights(gold, name), lcf, num_envs=64, num_agents=30, scene_episodes=episodes, seed=0)
     assert len(df) >= 64
-    return {k: float(v) for k, v in df.mean(numeric_only=True).items()}
+    out = {k: float(v) for k, v in df.mean(numeric_only=True).items()}
+    # the two estimators of oracle/gen_golden_eval.py (reward-scale decomposition), on this build's rows
+    dist = df["episode_length_mean"] * df["velocity_step_mean_episode_mean"] / 3.6 * 0.1
+    net = df["episode_reward_mean"] - 10.0 * df["success_rate"] + 10.0 * df["crash_rate"] + 10.0 * df["out_rate"]
+    out["metres_hat"], out["reward_per_metre_hat"] = float(dist.mean()), float((net / dist).mean())
+    return out
 
 
 def test_intersection_evaluation_tables_against_the_reference_records(golden_dir):
@@ -119,6 +124,16 @@ def test_intersection_evaluation_tables_against_the_reference_records(golden_dir
                    want["episode_reward_max"] / want["episode_reward_mean"]) < 0.03, (got, want)             # 1.383 vs 1.370, 1.787 vs 1.775
     ceiling = (56.0 + 0.5 * np.pi * 20.5 + 60.0 - 5.0) * (1.0 + 0.1 * 3.6 / 80.0 / 0.1) + 10.0      # longest route: outer left turn; driving + speed + success
     assert abs(copo["episode_reward_max"] - ceiling) < 1.5 and abs(ippo["episode_reward_max"] - ceiling) < 3.0, ceiling
+    # ---- where the 1.196 x sits (round 4): the CSV rows hold the metres an agent drives (episode length x mean velocity) and hence the
+    # reward per driven metre net of the terminal rewards; the same two estimators on this build's rows.  Population 0 drives the SAME
+    # distance here as in the release's MetaDrive (117.7 vs 119.2 m at .77 / .81 success): the road geometry is not what differs; the
+    # release pays 1.18 x (CoPO 0) / 1.13 x (IPPO 3) per driven metre.  No constant of 0.2.5's reward_function does that (driving_reward
+    # 1 / m, speed term 0.1 v / v_max = a fixed 0.045 / m, lateral factor off), and 0.2.5's own training record (below) pays this
+    # build's scale: the factor belongs to the MetaDrive release that produced the CSVs, and a fixed policy's speed cannot depend on it.
+    assert rel(copo["metres_hat"], p0["metres_hat"]) < 0.08, (copo["metres_hat"], p0["metres_hat"])
+    assert 1.08 < p0["reward_per_metre_hat"] / copo["reward_per_metre_hat"] < 1.28
+    pm = ref["ippo_inter_per_population"][matches[0]]
+    assert rel(ippo["metres_hat"], pm["metres_hat"]) < 0.10 and 1.05 < pm["reward_per_metre_hat"] / ippo["reward_per_metre_hat"] < 1.25
     prog = sorted(ref["copo_inter_training_progress"], key=lambda r: r["success"])
     xs, ys = [r["success"] for r in prog], [r["episode_reward_mean"] for r in prog]
     want = float(np.interp(copo["success_rate"], xs, ys))       # the 0.2.5 record: per-agent return as a function of the success rate
@@ -137,20 +152,25 @@ def test_reference_roundabout_populations_drive_the_hip_simulator(golden_dir):
     ippo = _roll("ippo", "round", _weights(gold, "ippo_round"), None, 40)
     copo = _roll("copo", "round", _weights(gold, "copo_round"), tuple(gold["copo_round/lcf"]), 40)
     print("ippo_round", ippo, "\ncopo_round", copo)
-    # training-time success in MetaDrive (benchmarks/MetaDrive-0.2.5/README.md:19-31): IPPO 66 %, CoPO 73 %
-    assert ippo["success"] > 0.45 and copo["success"] > 0.45, (ippo, copo)
-    assert ippo["out"] < 0.1 and copo["out"] < 0.1
+    # training-time success in MetaDrive 0.2.5 (benchmarks/MetaDrive-0.2.5/README.md:19-31): IPPO 66.43 (4.99), CoPO 72.82 (6.73); the
+    # release recorded 0.858 for the shipped CoPO population (eval/get_policy_function.py:41).  Round 4: bands of +-0.12 around the
+    # 0.2.5 table (0.691 / 0.711 here); against the release's 0.858 the CoPO population is 0.147 short -- with the crash rate (0.25)
+    # carrying all of it: out-of-road 0.034 and max-step 0.005 leave at most 0.04
+    assert abs(ippo["success"] - 0.664) < 0.12 and abs(copo["success"] - 0.728) < 0.12, (ippo, copo)
+    assert abs(copo["success"] - 0.858) < 0.17
+    assert ippo["out"] < 0.08 and copo["out"] < 0.06
 
 
 def test_reference_parking_lot_population(golden_dir):
     """ParkingLot rebuilt from MetaDrive's blocks (round 3, `maps.parkinglot`: FirstPGBlock -> ParkingLot block with eight 3.5 x 8 m
     spaces side by side, radius-4 bends to and from both lanes as overlapping roads -> T-intersection; three entrances, three
     exits).  On round 2's stand-in (7 m pitch, a straight aisle with two ends) the shipped IPPO population scored 0.110 with 55 %
-    out-of-road; on the rebuilt scene 0.184 / 33 %.  The reference's table (MetaDrive 0.2.5) has IPPO 16.98 +- 5.90."""
+    out-of-road; on the rebuilt scene 0.184 / 33 %; round 4 (exclusive parking spaces = ParkingSpaceManager, broken centre line inside the
+    block crossable) 0.188 / 31 %.  The reference's table (MetaDrive 0.2.5) has IPPO 16.98 +- 5.90: asserted at one standard deviation."""
     gold = np.load(os.path.join(golden_dir, "reference_populations.npz"))
     ippo = _roll("ippo", "parking", _weights(gold, "ippo_parking"), None, 10)
     print("ippo_parking", ippo)
-    assert abs(ippo["success"] - 0.170) < 0.08 and ippo["out"] < 0.45, ippo
+    assert abs(ippo["success"] - 0.170) < 0.059 and ippo["out"] < 0.40, ippo
 
 
 def test_reference_tollgate_and_bottleneck_populations(golden_dir):
