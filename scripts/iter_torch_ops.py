@@ -11,7 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import make_trainer  # noqa: E402
 
-t = make_trainer(256, 40)
+# COPO_ITER_NO_GRAPHS=1: every captured region runs eagerly, so the framework kernels INSIDE the graphs show up with their frames too
+t = make_trainer(256, 40, graphs=not os.environ.get("COPO_ITER_NO_GRAPHS"))
 for _ in range(6):
     t.train()
 torch.cuda.synchronize()
@@ -27,7 +28,7 @@ for ev in prof.events():
     if not ev.kernels:
         continue
     frames = [f for f in (ev.stack or []) if "/copo_amd/" in f or "bench.py" in f]
-    where = frames[0].split("/copo_amd/")[-1] if frames else "?"
+    where = " <- ".join(f.split("/copo_amd/")[-1] for f in frames[:2]) if frames else "?"
     key = (ev.name, where)
     by[key][0] += 1
     by[key][1] += sum(k.duration for k in ev.kernels)

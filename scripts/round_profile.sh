@@ -16,6 +16,9 @@ DB=$(find /tmp/prof_bench -name "*_results.db" | head -1)
   echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 5 --no-cpu-baseline     ($TAG, one MI355X)"
   echo "# bench line (traced run):"; grep '^{"metric"' /tmp/bench_traced.log | tail -1
   echo "# bench line (plain run, with cpu_baseline):"; grep '^{"metric"' /tmp/bench_plain.log | tail -1
+  echo "# note: this trace covers the WHOLE command -- warm-up, the timed iterations and the roofline legs.  The at::native elementwise kernels in the"
+  echo "#   list (MulFunctor, add, copyBuffer, sum ...) are launched by the roofline legs (the torch lane-keeping controller that records 60 steps of"
+  echo "#   actions for 16 384 scenes, random-action replays) -- a timed iteration launches 51 framework ops, 0.27 ms (COPO_ITER_NO_GRAPHS=1 python scripts/iter_torch_ops.py)"
   python scripts/top_kernels.py $DB 24
 } > $OUT/${TAG}_bench_kernel_stats.txt
 cp $OUT/sim_traffic.json $OUT/${TAG}_sim_traffic.json 2>/dev/null
