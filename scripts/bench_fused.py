@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 from test_gpu_fused_learner import _make, _dense_batch
 
 R, mb, odim = 82000, 512, 92
-pol = _make("copo", "none", odim, fused=True)
+pol = _make(os.environ.get("COPO_BENCH_ALGO", "copo"), "none", odim, fused=True)      # ippo: two nets -> 210 weight-gradient tiles, one per CU
 batch = _dense_batch(pol, R, odim)
 idx = torch.arange(R, device="cuda")
 pol.prepare_sgd(batch, R, mb)
