@@ -207,8 +207,11 @@ hipError_t launch_fused_step(FusedArgs a, hipStream_t s, const MetaTail* mt_ = n
         const int nty = (c.hidden + 32 * ot - 1) / (32 * ot), wx2 = (c.hidden + 1 + 31) / 32, wx1 = (kmax1 + 1 + 31) / 32;
         const dim3 grid((wx2 + wx1) * nty + wx2, G);      // (wgrad_tiles() below: the exchange workspace is sized by this grid)
         const size_t lds = (size_t)WG_WAVES * 32 * ot * 33 * sizeof(float);
-        if (bf) hipLaunchKernelGGL((wgrad_adam_kernel<1, true>), grid, dim3(64 * WG_WAVES), (size_t)WG_WAVES * 32 * 33 * sizeof(float), s, a, nty, (c.hidden + 1 + 31) / 32, wx1);
+        const bool fastk = c.mb == 2 * WG_RING * WG_WAVES && (bf || ot == 1);      // buffer-load operand ring (learn_update.inc)
+        if (bf && fastk) hipLaunchKernelGGL((wgrad_adam_kernel<1, true, true>), grid, dim3(64 * WG_WAVES), (size_t)WG_WAVES * 32 * 33 * sizeof(float), s, a, nty, (c.hidden + 1 + 31) / 32, wx1);
+        else if (bf) hipLaunchKernelGGL((wgrad_adam_kernel<1, true>), grid, dim3(64 * WG_WAVES), (size_t)WG_WAVES * 32 * 33 * sizeof(float), s, a, nty, (c.hidden + 1 + 31) / 32, wx1);
         else if (ot == 2) hipLaunchKernelGGL((wgrad_adam_kernel<2>), grid, dim3(64 * WG_WAVES), lds, s, a, nty, wx2, wx1);
+        else if (fastk) hipLaunchKernelGGL((wgrad_adam_kernel<1, false, true>), grid, dim3(64 * WG_WAVES), lds, s, a, nty, wx2, wx1);
         else hipLaunchKernelGGL((wgrad_adam_kernel<1>), grid, dim3(64 * WG_WAVES), lds, s, a, nty, wx2, wx1);
         return hipGetLastError();
     }
