@@ -161,7 +161,11 @@ hipError_t launch_fused_step(FusedArgs a, hipStream_t s, const MetaTail* mt_ = n
     for (int g = 0; g < (a.head_mode == COPO_HEAD_PPO ? G : 1); ++g)
         tw_ok = tw_ok && (nets[g]->w1 % 4 == 0) && (nets[g]->w2 % 4 == 0);
     const int part = mbatch ? mbatch->part : 0;
-    if (part == 2) vec = vec && ((reinterpret_cast<uintptr_t>(a.ws0) & 15) == 0);
+    if (part == 2) {
+        // the gather-all tiles address the row store with 32-bit byte offsets (buffer loads): every operand slab must stay below 4 GB
+        const uint64_t widest = (uint64_t)(c.hidden > c.pol.in_dim ? c.hidden : c.pol.in_dim);
+        vec = vec && ((reinterpret_cast<uintptr_t>(a.ws0) & 15) == 0) && ((uint64_t)a.gcap0 * (uint64_t)c.mb * widest * 4u < 0xfffffff0ull);
+    }
     const bool rowpass = (vec || tw_ok) && !mbatch && g_use_rowpass && (rp_h == 64 || rp_h == 128 || rp_h == 256 || rp_h == 512) &&
                          rp_lds <= 150 * 1024;
     // bfloat16 operands: only the row pass + fused weight-gradient kernels round where torch.autocast rounds
