@@ -78,7 +78,8 @@ static hipError_t gemm_lds_attrs() {
         for (const void* f : {reinterpret_cast<const void*>(mlp_fwd_kernel<1, 4>), reinterpret_cast<const void*>(mlp_fwd_kernel<2, 4>),
                               reinterpret_cast<const void*>(mlp_fwd_kernel<2, 8>), reinterpret_cast<const void*>(mlp_fwd_kernel<4, 8>),
                               reinterpret_cast<const void*>(mlp_fwd_kernel<1, 4, true>), reinterpret_cast<const void*>(mlp_fwd_kernel<2, 4, true>),
-                              reinterpret_cast<const void*>(mlp_fwd_kernel<2, 8, true>), reinterpret_cast<const void*>(mlp_fwd_kernel<4, 8, true>)})
+                              reinterpret_cast<const void*>(mlp_fwd_kernel<2, 8, true>), reinterpret_cast<const void*>(mlp_fwd_kernel<4, 8, true>),
+                              reinterpret_cast<const void*>(mlp_fwd_kernel<2, 8, false, 2>), reinterpret_cast<const void*>(mlp_fwd_kernel<2, 8, true, 2>)})
             if ((r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) != hipSuccess) e = r;
         if ((r = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_adam_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)) != hipSuccess) e = r;
         return e;
@@ -397,12 +398,23 @@ static int mlp_forward(const copo_ppo_cfg* cfg, const float* theta, const float*
         kmax = nets[g]->in_dim > kmax ? nets[g]->in_dim : kmax;
         if (nets[g]->w1 % 4 != 0 || nets[g]->w2 % 4 != 0) return COPO_ERR_DIM;
     }
-    const size_t lds = ((size_t)HT * (rowpass_k1p(kmax) + 4) + (size_t)2 * HT * (H + 4) + 4 * H) * sizeof(float);
+    // hidden 256 with at least two rounds of 256 workgroups of 32 rows per net: two 16-row tiles per workgroup (learn_rowpass.inc:
+    // RT).  Measured: the critic heads on 72 k rows 580 -> 478 us; a rollout step's 10 240 rows (320 workgroups of 32 rows on 256
+    // CUs) 39.5 -> 43.8 us, hence the threshold
+    const bool rt2 = H == 256 && n_rows >= 2 * 32 * 256 && rowpass_k1p(kmax) <= H;
+    const size_t lds = rt2 ? ((size_t)2 * 2 * HT * (H + 4) + 4 * H) * sizeof(float)
+                           : ((size_t)HT * (rowpass_k1p(kmax) + 4) + (size_t)2 * HT * (H + 4) + 4 * H) * sizeof(float);
     if (lds > 150 * 1024) return COPO_ERR_DIM;
     FwdArgs a{*cfg, theta, theta_t, obs_src, cc_src ? cc_src : obs_src, n_rows, first_net, n_nets, values, dist_inputs, eps,
               action, logp, clipped, rows, rows ? n_out : n_rows};
-    const dim3 grid((unsigned)((n_rows + HT - 1) / HT), n_nets);
+    const int rws = rt2 ? 2 * HT : HT;
+    const dim3 grid((unsigned)((n_rows + rws - 1) / rws), n_nets);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (rt2) {
+        if (cfg->operand_dtype == COPO_OPERAND_BF16) hipLaunchKernelGGL((mlp_fwd_kernel<2, 8, true, 2>), grid, dim3(512), lds, st, a);
+        else hipLaunchKernelGGL((mlp_fwd_kernel<2, 8, false, 2>), grid, dim3(512), lds, st, a);
+        return hipGetLastError() == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
+    }
 #define COPO_FWD(NT_, W_)                                                                                       \
         do {                                                                                                   \
             if (cfg->operand_dtype == COPO_OPERAND_BF16) hipLaunchKernelGGL((mlp_fwd_kernel<NT_, W_, true>), grid, dim3(64 * W_), lds, st, a); \
