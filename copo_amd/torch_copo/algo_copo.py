@@ -343,12 +343,17 @@ class CoPOPolicy(CCPPOPolicy):
         grads = fz.meta_batch_wgrads if self._meta_row_store else fz.meta_batch_grads
         pack = self._row_sources["pack"]
         if not D.is_dist():
-            for c0 in range(0, n_mb, nb):
-                grads(rs, c0, min(nb, n_mb - c0), mb_["gv"], mb_["stats_k"])
             # the sequential kernel streams dense {A_ego, A_nei} rows instead of chasing row indices into the pack
             rows = mb_["rows_all"][:n_mb]
-            en = torch.stack([pack[:, mb_["col_adv"]][rows], pack[:, mb_["col_nei_adv"]][rows]], dim=-1).unsqueeze(0)
-            self._meta_lcf_async(n_mb, en.contiguous(), mb_["w_all"][:n_mb].unsqueeze(0), mb_["eps_all"][:n_mb].unsqueeze(0))
+            en = torch.stack([pack[:, mb_["col_adv"]][rows], pack[:, mb_["col_nei_adv"]][rows]], dim=-1).unsqueeze(0).contiguous()
+            if self._meta_row_store and bool(self.config.get("meta_seq_per_chunk", True)):
+                # the LCF steps of a chunk start as soon as its dot products exist (side stream), not after the pass's last chunk:
+                # what is left exposed at the end of the last pass is one chunk's steps (~80 us), not a pass's (~400 us)
+                self._meta_lcf_chunks(n_mb, nb, grads, rs, en)
+                return
+            for c0 in range(0, n_mb, nb):
+                grads(rs, c0, min(nb, n_mb - c0), mb_["gv"], mb_["stats_k"])
+            self._meta_lcf_async(n_mb, en, mb_["w_all"][:n_mb].unsqueeze(0), mb_["eps_all"][:n_mb].unsqueeze(0))
             return
         # data-parallel: the minibatch gradients are sums over the ranks' rows -> all-reduce the exported gradient pairs
         # of a whole chunk BEFORE their dot products; the LCF row terms of every rank are gathered once per iteration
@@ -385,6 +390,41 @@ class CoPOPolicy(CCPPOPolicy):
         eps_all = D.all_gather_into_(torch.empty(S, n_mb, mb, dtype=torch.float64, device=self.device),
                                      mb_["eps_all"][:n_mb].contiguous())
         self._meta_lcf_async(n_mb, en_all, w_all, eps_all)
+
+    def _meta_lcf_chunks(self, n_mb, nb, grads, rs, en):
+        """Phase A chunk by chunk on the main stream, phase B of every chunk on the side stream behind that chunk's event.  The dot
+        products / statistics of a pass go to one of two buffer sets (passes alternate), so the next pass's GEMMs never write what the
+        side stream may still read; everything else the kernel reads is private to the pass."""
+        mb_, fz = self._meta_bufs, self.fused
+        if self._meta_side is None:
+            self._meta_side = torch.cuda.Stream(device=self.device)
+        if mb_.get("gv2") is None:
+            mb_["gv2"] = [mb_["gv"], torch.zeros_like(mb_["gv"])]
+            mb_["stats_k2"] = [mb_["stats_k"], torch.zeros_like(mb_["stats_k"])]
+            mb_["pass_no"] = 0
+            mb_["pass_done"] = [None, None]
+        q = mb_["pass_no"] & 1
+        mb_["pass_no"] += 1
+        if mb_["pass_done"][q] is not None:          # the pass that used this buffer set two passes ago has long finished: cheap
+            torch.cuda.current_stream().wait_event(mb_["pass_done"][q])
+        gv, stats_k = mb_["gv2"][q], mb_["stats_k2"][q]
+        priv = dict(denom=mb_["denom_all"][:n_mb].clone(), en=en, w=mb_["w_all"][:n_mb].clone(), eps=mb_["eps_all"][:n_mb].clone())
+        for c0 in range(0, n_mb, nb):
+            n = min(nb, n_mb - c0)
+            grads(rs, c0, n, gv, stats_k)
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(self._meta_side):
+                self._meta_side.wait_event(ev)
+                fz.meta_batch_lcf(dict(denom_all=priv["denom"][c0:]), n, None, gv[c0:], stats_k[c0:],
+                                  self.model.lcf_parameters.data, self._raw_ms, self._lcf_adam, self.config[LCF_LR], mb_["stats"],
+                                  0, 0, dense=(priv["en"][:, c0:c0 + n], priv["w"][c0:c0 + n].unsqueeze(0), priv["eps"][c0:c0 + n].unsqueeze(0)))
+        done = torch.cuda.Event()
+        with torch.cuda.stream(self._meta_side):
+            done.record()
+        mb_["pass_done"][q] = done
+        mb_["gv"], mb_["stats_k"] = gv, stats_k          # (what the callers / tests read after the pass)
+        self._meta_keep.append(priv)            # alive until the side stream has been joined
 
     def _meta_lcf_async(self, n_mb, en, w, eps):
         """Phase B of this pass on a side stream: the sequential LCF kernel keeps ONE compute unit busy for ~0.4 ms, and
