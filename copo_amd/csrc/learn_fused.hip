@@ -586,7 +586,7 @@ extern "C" int copo_meta_batch_wgrads_f32(const copo_ppo_cfg* cfg, const float* 
                                           double* gv_out, float* stats_out, void* stream) {
     int rc = check_cfg(cfg);
     if (rc != COPO_OK) return rc;
-    if (!obs_src || !rows || !w || !denom || !rows_ws || !rowstat || !workspace || !gv_out || !stats_out) return COPO_ERR_NULL;
+    if (!obs_src || !rows || !w || !denom || !rows_ws || !rowstat || !workspace || !gv_out) return COPO_ERR_NULL;      // (stats_out may be NULL: copo_meta_rowstat_f32)
     if (nb < 1 || nb > nb_cap || nb_cap > COPO_META_BATCH_MAX || mb_first < 0 || n_rows < 1) return COPO_ERR_DIM;
     if ((reinterpret_cast<uintptr_t>(workspace) & 7) != 0) return COPO_ERR_DIM;
     FusedArgs a;
@@ -604,8 +604,21 @@ extern "C" int copo_meta_batch_wgrads_f32(const copo_ppo_cfg* cfg, const float* 
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipError_t e = launch_fused_step(a, st, nullptr, &mbt, &fb, nullptr);
     if (e != hipSuccess) return COPO_ERR_DEVICE;
-    hipLaunchKernelGGL(meta_rowstat_kernel, dim3(nb), dim3(256), 0, st, a, mb_first, denom, stats_out);
+    if (stats_out) hipLaunchKernelGGL(meta_rowstat_kernel, dim3(nb), dim3(256), 0, st, a, mb_first, denom, stats_out);
     hipLaunchKernelGGL(meta_batch_dot_kernel, dim3(nb), dim3(256), 0, st, dot, nullptr, (int64_t)fb, gv_out, denom + mb_first);
+    return hipGetLastError() == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
+}
+
+extern "C" int copo_meta_rowstat_f32(const copo_ppo_cfg* cfg, const int64_t* rows, const float* w, const float* denom,
+                                     const float* rowstat, int64_t mb_first, int32_t nb, float* stats_out, void* stream) {
+    int rc = check_cfg(cfg);
+    if (rc != COPO_OK) return rc;
+    if (!rows || !w || !denom || !rowstat || !stats_out) return COPO_ERR_NULL;
+    if (nb < 1 || nb > 65535 || mb_first < 0) return COPO_ERR_DIM;
+    FusedArgs a;
+    fill_common(a, cfg, nullptr, nullptr, nullptr, rows, w, denom, nullptr, nullptr);
+    a.rowstat = const_cast<float*>(rowstat);
+    hipLaunchKernelGGL(meta_rowstat_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), a, mb_first, denom, stats_out);
     return hipGetLastError() == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
 }
 

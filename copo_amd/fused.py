@@ -295,14 +295,22 @@ class FusedLearner:
             C.byref(self.cfg), self.flat.flat.data_ptr(), self.target_flat.flat.data_ptr(), rs["obs"].data_ptr(),
             rs["pack"].data_ptr(), n_rows, self._rows_ws[1].data_ptr(), self._rows_ws[2].data_ptr(), _capi.current_stream()))
 
+    def meta_rowstat(self, rs, first, nb, stats_k):
+        """Loss statistics of minibatches [first, first + nb) regrouped from the row store: one launch for a whole pass, after which
+        `meta_batch_wgrads(..., stats_k=None)` leaves them alone."""
+        _capi.check(_capi.lib.copo_meta_rowstat_f32(
+            C.byref(self.cfg), rs["rows_all"].data_ptr(), rs["w_all"].data_ptr(), rs["denom_all"].data_ptr(),
+            self._rows_ws[2].data_ptr(), int(first), int(nb), stats_k[first:].data_ptr(), _capi.current_stream()))
+
     def meta_batch_wgrads(self, rs, first, nb, gv, stats_k, g_out=None):
-        """Phase A of minibatches [first, first + nb) on top of the row store (`meta_rows` must have run)."""
+        """Phase A of minibatches [first, first + nb) on top of the row store (`meta_rows` must have run).  stats_k None: the
+        statistics come from `meta_rowstat`."""
         self._ensure_batch_ws(nb)
         _capi.check(_capi.lib.copo_meta_batch_wgrads_f32(
             C.byref(self.cfg), rs["obs"].data_ptr(), rs["rows_all"].data_ptr(), rs["w_all"].data_ptr(),
             rs["denom_all"].data_ptr(), self._rows_ws[1].data_ptr(), int(self._rows_ws[0]), self._rows_ws[2].data_ptr(),
             self._batch_ws[1].data_ptr(), int(self._batch_ws[0]), int(first), int(nb),
-            None if g_out is None else g_out.data_ptr(), gv[first:].data_ptr(), stats_k[first:].data_ptr(),
+            None if g_out is None else g_out.data_ptr(), gv[first:].data_ptr(), None if stats_k is None else stats_k[first:].data_ptr(),
             _capi.current_stream()))
 
     def meta_batch_dot(self, g, n, nb, gv, denom=None):

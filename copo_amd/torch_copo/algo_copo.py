@@ -409,9 +409,10 @@ class CoPOPolicy(CCPPOPolicy):
             torch.cuda.current_stream().wait_event(mb_["pass_done"][q])
         gv, stats_k = mb_["gv2"][q], mb_["stats_k2"][q]
         priv = dict(denom=mb_["denom_all"][:n_mb].clone(), en=en, w=mb_["w_all"][:n_mb].clone(), eps=mb_["eps_all"][:n_mb].clone())
+        fz.meta_rowstat(rs, 0, n_mb, stats_k)        # the statistics of the whole pass in one launch (they do not depend on the GEMMs)
         for c0 in range(0, n_mb, nb):
             n = min(nb, n_mb - c0)
-            grads(rs, c0, n, gv, stats_k)
+            grads(rs, c0, n, gv, None)
             ev = torch.cuda.Event()
             ev.record()
             with torch.cuda.stream(self._meta_side):

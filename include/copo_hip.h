@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define COPO_ABI_VERSION 5
+#define COPO_ABI_VERSION 6
 
 #define COPO_OK 0
 #define COPO_ERR_NULL (-1)      /* required pointer is NULL */
@@ -479,6 +479,11 @@ int copo_meta_batch_wgrads_f32(const copo_ppo_cfg* cfg, const float* obs_src, co
                                const float* denom, const float* rows_ws, int64_t n_rows, const float* rowstat,
                                float* workspace, int32_t nb_cap, int64_t mb_first, int32_t nb, float* g_out,
                                double* gv_out, float* stats_out, void* stream);
+/* (ABI 6) stats_out == NULL: the chunk's loss statistics are not regrouped here -- the caller has them from ONE
+ * copo_meta_rowstat_f32 launch for all minibatches [mb_first, mb_first + nb) of the pass (they depend on the row tables and the
+ * row store only, not on the GEMMs): stats_out [nb][2][8] as copo_meta_batch_wgrads_f32 writes them.  nb <= 65535. */
+int copo_meta_rowstat_f32(const copo_ppo_cfg* cfg, const int64_t* rows, const float* w, const float* denom, const float* rowstat,
+                          int64_t mb_first, int32_t nb, float* stats_out, void* stream);
 /* Phase B: n_mb sequential LCF Adam steps (minibatch order) in one kernel.  Row inputs either gathered from
  * pack_src via rows (ego_nei NULL, n_seg 1) or dense: ego_nei [n_seg][n_mb][mb][2] = {A_ego, A_nei} with w / eps
  * [n_seg][n_mb][mb] (data-parallel: the all-gathered rows of every rank).  gv [n_mb], stats_in [n_mb][2][8] from
