@@ -371,10 +371,12 @@ class CoPOPolicy(CCPPOPolicy):
             # (exported gradients of the row store carry unit row weights: both factors 1 / D_k, applied by the kernel)
             fz.meta_batch_dot(buf, nf, n, mb_["gv"][c0:], denom=mb_["denom_all"][c0:] if self._meta_row_store else None)
 
+        if self._meta_row_store:
+            fz.meta_rowstat(rs, 0, n_mb, mb_["stats_k"])      # the pass's statistics in one launch (summed over the ranks below)
         for q, c0 in enumerate(range(0, n_mb, nb)):
             n = min(nb, n_mb - c0)
             buf = mb_["g_chunk"][q & 1]
-            grads(rs, c0, n, mb_["gv"], mb_["stats_k"], g_out=buf)
+            grads(rs, c0, n, mb_["gv"], None if self._meta_row_store else mb_["stats_k"], g_out=buf)
             work = D.all_reduce_sum_async(buf[:n])
             if pending is not None:
                 finish(*pending)
