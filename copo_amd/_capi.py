@@ -100,7 +100,7 @@ _SIGS = {
                                    [C.c_int32, C.c_int64, C.c_int32] + [C.c_void_p] * 4),
     "copo_meta_rowstat_f32": (C.c_int, [C.POINTER(PpoCfg)] + [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "copo_meta_batch_lcf_f64": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32] +
-                                [C.c_void_p] * 3 + [C.c_int32, C.c_int32] + [C.c_void_p] * 5 + [C.c_double, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+                                [C.c_void_p] * 3 + [C.c_int32, C.c_int32] + [C.c_void_p] * 5 + [C.c_double, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "copo_version": (C.c_int, []),
     "copo_last_error": (C.c_char_p, []),
     "copo_sim_create": (C.c_int, [C.POINTER(SimCfg), C.c_int, C.POINTER(C.c_void_p)]),

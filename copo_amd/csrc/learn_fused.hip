@@ -639,20 +639,22 @@ extern "C" int copo_meta_batch_lcf_f64(const float* pack_src, int32_t pack_width
                                        const int64_t* rows, const float* ego_nei, int32_t n_seg, const float* w,
                                        const double* eps, const float* denom, int32_t mb, int32_t n_mb, const double* gv,
                                        const float* stats_in, double* lcf_param, const double* raw_mean_std,
-                                       double* adam_state, double lr, double* stats, int32_t n_wg, double* exchange,
-                                       void* stream) {
+                                       double* adam_state, double lr, double* stats, int32_t k_first, int32_t k_count,
+                                       int32_t n_wg, double* exchange, void* stream) {
     if (!w || !eps || !denom || !gv || !stats_in || !lcf_param || !raw_mean_std || !adam_state) return COPO_ERR_NULL;
     if (!ego_nei && (!pack_src || !rows)) return COPO_ERR_NULL;
     if (mb < 1 || n_mb < 0 || n_mb > 65534 || n_seg < 1 || (!ego_nei && n_seg != 1)) return COPO_ERR_DIM;
     if (n_wg < 0 || n_wg > SEQ_MAX_WG) return COPO_ERR_DIM;
+    if (k_count < 0) k_count = n_mb - k_first;          // (-1: all steps from k_first on)
+    if (k_first < 0 || k_first + k_count > n_mb) return COPO_ERR_DIM;
     // measured (scripts/meta_seq_time.py, 90 steps): one workgroup 2.4 / 2.6 / 3.3 / 4.9 us per step with the rows of 1 / 2 / 4 / 8
     // ranks (eight rows per thread are still latency, not work), the hand-over ~2.4 us per step on top of a workgroup's own rows
     // (8 ranks on 8 workgroups: 4.9 us) -- so several workgroups only pay beyond eight ranks' rows: then one per four segments
     if (n_wg == 0) n_wg = (n_seg > 8 && exchange) ? ((n_seg + 3) / 4 < SEQ_MAX_WG ? (n_seg + 3) / 4 : SEQ_MAX_WG) : 1;
     if (n_wg > 1 && !exchange) return COPO_ERR_NULL;
-    if (n_mb == 0) return COPO_OK;
+    if (n_mb == 0 || k_count == 0) return COPO_OK;
     MetaSeqArgs a{pack_src, rows, ego_nei, w, eps, denom, gv, stats_in, mb, n_mb, n_seg, pack_width, col_adv, col_nei_adv,
-                  lcf_param, raw_mean_std, adam_state, lr, stats, exchange, n_wg};
+                  k_first, k_count, lcf_param, raw_mean_std, adam_state, lr, stats, exchange, n_wg};
     hipLaunchKernelGGL(meta_seq_kernel, dim3(n_wg), dim3(512), 0, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
 }

@@ -321,9 +321,10 @@ class FusedLearner:
     _seq_xchg = None
 
     def meta_batch_lcf(self, rs, n_mb, eps_all, gv, stats_k, lcf_param, raw_mean_std, adam_state, lr, stats, col_adv,
-                       col_nei_adv, dense=None, n_wg=0):
+                       col_nei_adv, dense=None, n_wg=0, k_first=0, k_count=-1):
         """Phase B.  dense = (ego_nei [S][n_mb][mb][2], w [S][n_mb][mb], eps [S][n_mb][mb]) replaces the row gather.
-        n_wg: workgroups that share every step's rows (0 = the library's choice: one up to eight ranks' rows)."""
+        n_wg: workgroups that share every step's rows (0 = the library's choice: one up to eight ranks' rows).
+        k_first / k_count: only the steps of minibatches [k_first, k_first + k_count) of the n_mb the arrays hold."""
         if self._seq_xchg is None:
             self._seq_xchg = torch.zeros(256, dtype=torch.float64, device=self.flat.flat.device)
         if dense is None:
@@ -335,7 +336,7 @@ class FusedLearner:
         _capi.check(_capi.lib.copo_meta_batch_lcf_f64(
             *args, rs["denom_all"].data_ptr(), self.cfg.mb, int(n_mb), gv.data_ptr(), stats_k.data_ptr(),
             lcf_param.data_ptr(), raw_mean_std.data_ptr(), adam_state.data_ptr(), float(lr), stats.data_ptr(),
-            int(n_wg), self._seq_xchg.data_ptr(), _capi.current_stream()))
+            int(k_first), int(k_count), int(n_wg), self._seq_xchg.data_ptr(), _capi.current_stream()))
 
     def state(self):
         return dict(adam_m=self.adam_m.clone(), adam_v=self.adam_v.clone(), step=self.step_count.clone())

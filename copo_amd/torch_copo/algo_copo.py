@@ -53,6 +53,10 @@ class CoPOConfig(CCPPOConfig):
         self.meta_batch_size = 32
         # fused learner only: compute the row-local part of the meta gradients once per iteration (row store)
         self.meta_row_store = True
+        # fused learner, row store: the LCF steps of a chunk of minibatches run behind that chunk's dot products instead of behind
+        # the pass's last chunk (local path: on; data-parallel path: off until it has been measured with real peers)
+        self.meta_seq_per_chunk = True
+        self.meta_seq_per_chunk_dist = False
         self.update_from_dict({"model": {"custom_model": "copo_model"}})
         # TF-era keys of train_copo.py:43-47 that the torch reference silently ignores
         self.initial_svo_std = None
@@ -342,11 +346,16 @@ class CoPOPolicy(CCPPOPolicy):
         # with the row store (filled once per training iteration by run_meta) a pass only redoes the weight-gradient GEMMs
         grads = fz.meta_batch_wgrads if self._meta_row_store else fz.meta_batch_grads
         pack = self._row_sources["pack"]
-        if not D.is_dist():
+        # LCF steps chunk by chunk behind each chunk's dot products: on by default in the local path (meta passes 4.1 -> 3.75 ms); in the
+        # data-parallel path it is an option -- with ONE rank forced through that path the extra launches per chunk make the host the
+        # bottleneck (5.65 -> 6.2 ms); with real peers a chunk also waits for its all-reduce, which has not been measured
+        per_chunk = self._meta_row_store and bool(self.config.get("meta_seq_per_chunk_dist" if D.is_dist() else "meta_seq_per_chunk",
+                                                                  not D.is_dist()))
+        if not D.is_dist() or per_chunk:
             # the sequential kernel streams dense {A_ego, A_nei} rows instead of chasing row indices into the pack
             rows = mb_["rows_all"][:n_mb]
             en = torch.stack([pack[:, mb_["col_adv"]][rows], pack[:, mb_["col_nei_adv"]][rows]], dim=-1).unsqueeze(0).contiguous()
-            if self._meta_row_store and bool(self.config.get("meta_seq_per_chunk", True)):
+            if per_chunk:
                 # the LCF steps of a chunk start as soon as its dot products exist (side stream), not after the pass's last chunk:
                 # what is left exposed at the end of the last pass is one chunk's steps (~80 us), not a pass's (~400 us)
                 self._meta_lcf_chunks(n_mb, nb, grads, rs, en)
@@ -396,8 +405,11 @@ class CoPOPolicy(CCPPOPolicy):
     def _meta_lcf_chunks(self, n_mb, nb, grads, rs, en):
         """Phase A chunk by chunk on the main stream, phase B of every chunk on the side stream behind that chunk's event.  The dot
         products / statistics of a pass go to one of two buffer sets (passes alternate), so the next pass's GEMMs never write what the
-        side stream may still read; everything else the kernel reads is private to the pass."""
+        side stream may still read; everything else the kernel reads is private to the pass.  Data-parallel: the row terms of all
+        ranks are gathered BEFORE the chunks (they do not depend on the GEMMs), a chunk's LCF steps follow its all-reduced dot
+        products; every rank runs them on the full rows, so the parameters stay identical."""
         mb_, fz = self._meta_bufs, self.fused
+        dist = D.is_dist()
         if self._meta_side is None:
             self._meta_side = torch.cuda.Stream(device=self.device)
         if mb_.get("gv2") is None:
@@ -410,18 +422,51 @@ class CoPOPolicy(CCPPOPolicy):
         if mb_["pass_done"][q] is not None:          # the pass that used this buffer set two passes ago has long finished: cheap
             torch.cuda.current_stream().wait_event(mb_["pass_done"][q])
         gv, stats_k = mb_["gv2"][q], mb_["stats_k2"][q]
-        priv = dict(denom=mb_["denom_all"][:n_mb].clone(), en=en, w=mb_["w_all"][:n_mb].clone(), eps=mb_["eps_all"][:n_mb].clone())
         fz.meta_rowstat(rs, 0, n_mb, stats_k)        # the statistics of the whole pass in one launch (they do not depend on the GEMMs)
-        for c0 in range(0, n_mb, nb):
-            n = min(nb, n_mb - c0)
-            grads(rs, c0, n, gv, None)
+        if dist:
+            S, mb = D.world_size(), mb_["mb"]
+            D.all_reduce_sum_(stats_k[:n_mb])
+            en_d = D.all_gather_into_(torch.empty((S,) + tuple(en.shape[1:]), dtype=en.dtype, device=self.device), en[0].contiguous())
+            w_d = D.all_gather_into_(torch.empty(S, n_mb, mb, dtype=torch.float32, device=self.device), mb_["w_all"][:n_mb].contiguous())
+            eps_d = D.all_gather_into_(torch.empty(S, n_mb, mb, dtype=torch.float64, device=self.device), mb_["eps_all"][:n_mb].contiguous())
+            nf = fz.meta_fold_len()
+            if mb_.get("g_chunk") is None or mb_["g_chunk"][0].shape[0] < nb:
+                mb_["g_chunk"] = [torch.zeros(nb, 2, nf, dtype=torch.float32, device=self.device) for _ in range(2)]
+        else:
+            en_d, w_d, eps_d = en, mb_["w_all"][:n_mb].clone().unsqueeze(0), mb_["eps_all"][:n_mb].clone().unsqueeze(0)
+        priv = dict(denom=mb_["denom_all"][:n_mb].clone(), en=en_d, w=w_d, eps=eps_d)
+
+        def lcf_steps(c0, n):
             ev = torch.cuda.Event()
             ev.record()
             with torch.cuda.stream(self._meta_side):
                 self._meta_side.wait_event(ev)
-                fz.meta_batch_lcf(dict(denom_all=priv["denom"][c0:]), n, None, gv[c0:], stats_k[c0:],
+                fz.meta_batch_lcf(dict(denom_all=priv["denom"]), n_mb, None, gv, stats_k,
                                   self.model.lcf_parameters.data, self._raw_ms, self._lcf_adam, self.config[LCF_LR], mb_["stats"],
-                                  0, 0, dense=(priv["en"][:, c0:c0 + n], priv["w"][c0:c0 + n].unsqueeze(0), priv["eps"][c0:c0 + n].unsqueeze(0)))
+                                  0, 0, dense=(en_d, w_d, eps_d), k_first=c0, k_count=n)
+
+        def finish(c0, n, buf, work):       # data-parallel: the chunk's gradient pairs are summed over the ranks, then their dot products
+            if work is not None:
+                work.wait()               # (the compute stream waits; the host does not)
+            fz.meta_batch_dot(buf, nf, n, gv[c0:], denom=mb_["denom_all"][c0:])
+            lcf_steps(c0, n)
+
+        pending = None
+        for j, c0 in enumerate(range(0, n_mb, nb)):
+            n = min(nb, n_mb - c0)
+            if dist:
+                # two export buffers: the all-reduce of chunk c runs on the collective's own stream under the GEMMs of chunk c + 1
+                buf = mb_["g_chunk"][j & 1]
+                grads(rs, c0, n, gv, None, g_out=buf)
+                work = D.all_reduce_sum_async(buf[:n])
+                if pending is not None:
+                    finish(*pending)
+                pending = (c0, n, buf, work)
+            else:
+                grads(rs, c0, n, gv, None)
+                lcf_steps(c0, n)
+        if pending is not None:
+            finish(*pending)
         done = torch.cuda.Event()
         with torch.cuda.stream(self._meta_side):
             done.record()

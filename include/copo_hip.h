@@ -492,13 +492,15 @@ int copo_meta_rowstat_f32(const copo_ppo_cfg* cfg, const int64_t* rows, const fl
  * one per four segments; <= 16): each adds up
  * its rows, publishes three partial sums in `exchange` (COPO_META_SEQ_XCHG_DOUBLES doubles of device memory, zeroed ONCE by the
  * caller and then left to the kernel) and applies the same Adam step to the sum of all partials -- with N ranks' rows a step
- * then costs what it costs with one.  A workgroup that never arrives (2 s) turns lcf_param into NaN. */
+ * then costs what it costs with one.  A workgroup that never arrives (2 s) turns lcf_param into NaN.
+ * (ABI 6) k_first / k_count: the launch takes the steps of minibatches [k_first, k_first + k_count) of the n_mb the arrays hold
+ * (k_count < 0: all from k_first on) -- a meta pass can run its LCF steps chunk by chunk, behind the dot products of each chunk. */
 #define COPO_META_SEQ_XCHG_DOUBLES 256
 int copo_meta_batch_lcf_f64(const float* pack_src, int32_t pack_width, int32_t col_adv, int32_t col_nei_adv,
                             const int64_t* rows, const float* ego_nei, int32_t n_seg, const float* w, const double* eps,
                             const float* denom, int32_t mb, int32_t n_mb, const double* gv, const float* stats_in,
                             double* lcf_param, const double* raw_mean_std, double* adam_state, double lr, double* stats,
-                            int32_t n_wg, double* exchange, void* stream);
+                            int32_t k_first, int32_t k_count, int32_t n_wg, double* exchange, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Peer all-reduce (replaces the in-process tower averaging of RLlib's multi-GPU learner,

@@ -617,15 +617,16 @@ def test_sequential_lcf_kernel_over_several_workgroups(n_seg, n_wg):
     raw = torch.tensor([0.1, 1.3], dtype=torch.float64, device=dev)
     xchg = torch.zeros(256, dtype=torch.float64, device=dev)
 
-    def run(wgs, calls=1):
+    def run(wgs, calls=1, ranges=((0, -1),)):
         p = torch.tensor([0.05, -2.3], dtype=torch.float64, device=dev)
         adam = torch.zeros(5, dtype=torch.float64, device=dev)
         st = torch.zeros(7, dtype=torch.float64, device=dev)
         for _ in range(calls):
-            _capi.check(_capi.lib.copo_meta_batch_lcf_f64(
-                None, 0, 0, 0, None, en.data_ptr(), n_seg, w.data_ptr(), eps.data_ptr(), denom.data_ptr(), mb, n_mb, gv.data_ptr(),
-                stats_in.data_ptr(), p.data_ptr(), raw.data_ptr(), adam.data_ptr(), 1e-3, st.data_ptr(), wgs, xchg.data_ptr(),
-                _capi.current_stream()))
+            for k_first, k_count in ranges:
+                _capi.check(_capi.lib.copo_meta_batch_lcf_f64(
+                    None, 0, 0, 0, None, en.data_ptr(), n_seg, w.data_ptr(), eps.data_ptr(), denom.data_ptr(), mb, n_mb, gv.data_ptr(),
+                    stats_in.data_ptr(), p.data_ptr(), raw.data_ptr(), adam.data_ptr(), 1e-3, st.data_ptr(), k_first, k_count, wgs,
+                    xchg.data_ptr(), _capi.current_stream()))
         torch.cuda.synchronize()
         return p.cpu(), adam.cpu(), st.cpu()
 
@@ -634,6 +635,12 @@ def test_sequential_lcf_kernel_over_several_workgroups(n_seg, n_wg):
     assert torch.isfinite(many[0]).all() and (one[0] - torch.tensor([0.05, -2.3], dtype=torch.float64)).abs().max() > 1e-3
     for a, b, name in zip(one, many, ("lcf_param", "adam", "stats")):
         torch.testing.assert_close(b, a, rtol=1e-10, atol=1e-12, msg=name)
+    # (ABI 6) the same steps chunk by chunk -- a launch per range of minibatches, as the trainer issues them behind each chunk's dot
+    # products: the state travels through lcf_param / adam_state / stats; a launch restarts the running products beta^t from the
+    # step count (pow) where a single launch multiplies on, hence rounding-level differences only
+    chunks = run(1, calls=2, ranges=((0, 32), (32, 32), (64, -1)))
+    for a, b, name in zip(one, chunks, ("lcf_param", "adam", "stats")):
+        torch.testing.assert_close(b, a, rtol=1e-11, atol=1e-13, msg=name)
 
 
 @pytest.mark.parametrize("name,fuse,odim", [("copo", "none", 92), ("ccppo", "mf", 91)])
