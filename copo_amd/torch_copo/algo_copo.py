@@ -337,6 +337,9 @@ class CoPOPolicy(CCPPOPolicy):
         self._meta_step_a()
         self._meta_step_b()
 
+    def _meta_per_chunk(self):
+        return bool(self.config.get("meta_seq_per_chunk_dist" if D.is_dist() else "meta_seq_per_chunk", not D.is_dist()))
+
     def _run_meta_batched(self, n_mb, nb):
         """One meta iteration the batched way: the gradient pairs of `nb` minibatches per launch chain (they do not
         depend on the LCF parameters), then all `n_mb` sequential LCF Adam steps in one kernel.  Same results as
@@ -349,12 +352,17 @@ class CoPOPolicy(CCPPOPolicy):
         # LCF steps chunk by chunk behind each chunk's dot products: on by default in the local path (meta passes 4.1 -> 3.75 ms); in the
         # data-parallel path it is an option -- with ONE rank forced through that path the extra launches per chunk make the host the
         # bottleneck (5.65 -> 6.2 ms); with real peers a chunk also waits for its all-reduce, which has not been measured
-        per_chunk = self._meta_row_store and bool(self.config.get("meta_seq_per_chunk_dist" if D.is_dist() else "meta_seq_per_chunk",
-                                                                  not D.is_dist()))
+        per_chunk = self._meta_row_store and self._meta_per_chunk()
         if not D.is_dist() or per_chunk:
             # the sequential kernel streams dense {A_ego, A_nei} rows instead of chasing row indices into the pack
             rows = mb_["rows_all"][:n_mb]
-            en = torch.stack([pack[:, mb_["col_adv"]][rows], pack[:, mb_["col_nei_adv"]][rows]], dim=-1).unsqueeze(0).contiguous()
+            if per_chunk:
+                en_src = mb_.get("en_src")          # (run_meta gathers the two columns once per iteration)
+                if en_src is None:
+                    en_src = pack[:, [mb_["col_adv"], mb_["col_nei_adv"]]].contiguous()
+                en = en_src[rows].unsqueeze(0)
+            else:
+                en = torch.stack([pack[:, mb_["col_adv"]][rows], pack[:, mb_["col_nei_adv"]][rows]], dim=-1).unsqueeze(0).contiguous()
             if per_chunk:
                 # the LCF steps of a chunk start as soon as its dot products exist (side stream), not after the pass's last chunk:
                 # what is left exposed at the end of the last pass is one chunk's steps (~80 us), not a pass's (~400 us)
@@ -415,12 +423,11 @@ class CoPOPolicy(CCPPOPolicy):
         if mb_.get("gv2") is None:
             mb_["gv2"] = [mb_["gv"], torch.zeros_like(mb_["gv"])]
             mb_["stats_k2"] = [mb_["stats_k"], torch.zeros_like(mb_["stats_k"])]
-            mb_["pass_no"] = 0
-            mb_["pass_done"] = [None, None]
-        q = mb_["pass_no"] & 1
+        # (run_meta switched the planned tables to set q and waited for the pass that used it last; a caller that drives the passes
+        # itself must not write rows_all / w_all / denom_all / eps_all before the side stream has taken the pass's last chunk)
+        q = mb_.setdefault("pass_no", 0) & 1
+        mb_.setdefault("pass_done", [None, None])
         mb_["pass_no"] += 1
-        if mb_["pass_done"][q] is not None:          # the pass that used this buffer set two passes ago has long finished: cheap
-            torch.cuda.current_stream().wait_event(mb_["pass_done"][q])
         gv, stats_k = mb_["gv2"][q], mb_["stats_k2"][q]
         fz.meta_rowstat(rs, 0, n_mb, stats_k)        # the statistics of the whole pass in one launch (they do not depend on the GEMMs)
         if dist:
@@ -433,8 +440,8 @@ class CoPOPolicy(CCPPOPolicy):
             if mb_.get("g_chunk") is None or mb_["g_chunk"][0].shape[0] < nb:
                 mb_["g_chunk"] = [torch.zeros(nb, 2, nf, dtype=torch.float32, device=self.device) for _ in range(2)]
         else:
-            en_d, w_d, eps_d = en, mb_["w_all"][:n_mb].clone().unsqueeze(0), mb_["eps_all"][:n_mb].clone().unsqueeze(0)
-        priv = dict(denom=mb_["denom_all"][:n_mb].clone(), en=en_d, w=w_d, eps=eps_d)
+            en_d, w_d, eps_d = en, mb_["w_all"][:n_mb].unsqueeze(0), mb_["eps_all"][:n_mb].unsqueeze(0)
+        priv = dict(denom=mb_["denom_all"], en=en_d, w=w_d, eps=eps_d)       # (set q of the planned tables: not written before pass_done[q])
 
         def lcf_steps(c0, n):
             ev = torch.cuda.Event()
@@ -541,7 +548,23 @@ class CoPOPolicy(CCPPOPolicy):
         if self._meta_row_store:
             self.fused.meta_rows(rs)
         perms = self.draw_perms(num_iters, B_local)
+        chunked = self._meta_row_store and self._meta_per_chunk()
+        if chunked:
+            # {A_ego, A_nei} of every row once per iteration: a pass then gathers its dense row terms with ONE index op
+            mbuf["en_src"] = rs["pack"][:, [mbuf["col_adv"], mbuf["col_nei_adv"]]].contiguous()
+            if mbuf.get("sets") is None:
+                # the planned tables of a pass are read by its LCF steps on the side stream while the next pass is being planned:
+                # two sets of tables, passes alternate (no private copies per pass)
+                keys = ("rows_all", "w_all", "denom_all", "eps_all")
+                mbuf["sets"] = [{k: mbuf[k] for k in keys}, {k: torch.zeros_like(mbuf[k]) for k in keys}]
+                mbuf["sets"][1]["denom_all"].fill_(1.0)
+                mbuf["pass_no"], mbuf["pass_done"] = 0, [None, None]
         for it in range(num_iters):
+            if chunked:
+                q = mbuf["pass_no"] & 1
+                if mbuf["pass_done"][q] is not None:      # the pass that used this set two passes ago has long finished: cheap
+                    torch.cuda.current_stream().wait_event(mbuf["pass_done"][q])
+                mbuf.update(mbuf["sets"][q])
             n_mb = self.plan_epoch(valid_idx, B_local, B_all, mb, bufs=mbuf, perm=None if perms is None else perms[it])
             mbuf["eps_all"].normal_()
             if nb_batch > 0:

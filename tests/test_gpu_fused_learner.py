@@ -581,6 +581,8 @@ def test_batched_meta_loop_vs_reference_golden(golden_dir, store):
     torch.manual_seed(int(g["in_torch_seed"]))
     mbuf["stats"].zero_()
     for _ in range(5):
+        if pol._meta_side is not None:           # (the LCF steps of the previous pass read eps_all on the side stream: this loop, not
+            torch.cuda.current_stream().wait_stream(pol._meta_side)      # run_meta with its alternating tables, drives the passes)
         mbuf["eps_all"].zero_()
         for k in range(n_mb):
             n = min(mb, B - k * mb)
