@@ -18,7 +18,7 @@ DB=$(find /tmp/prof_bench -name "*_results.db" | head -1)
   echo "# bench line (plain run, with cpu_baseline):"; grep '^{"metric"' /tmp/bench_plain.log | tail -1
   echo "# note: this trace covers the WHOLE command -- warm-up, the timed iterations and the roofline legs.  The at::native elementwise kernels in the"
   echo "#   list (MulFunctor, add, copyBuffer, sum ...) are launched by the roofline legs (the torch lane-keeping controller that records 60 steps of"
-  echo "#   actions for 16 384 scenes, random-action replays) -- a timed iteration launches 51 framework ops, 0.27 ms (COPO_ITER_NO_GRAPHS=1 python scripts/iter_torch_ops.py)"
+  echo "#   actions for 16 384 scenes, random-action replays) -- a timed iteration launches 47 framework ops, 0.24 ms (COPO_ITER_NO_GRAPHS=1 python scripts/iter_torch_ops.py)"
   python scripts/top_kernels.py $DB 24
 } > $OUT/${TAG}_bench_kernel_stats.txt
 cp $OUT/sim_traffic.json $OUT/${TAG}_sim_traffic.json 2>/dev/null
