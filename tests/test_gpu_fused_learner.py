@@ -390,6 +390,19 @@ def test_batched_meta_pass_equals_sequential_steps(nb, store):
     # the dot products of the last iteration, minibatch by minibatch, against the step-by-step gradients
     gv = b._meta_bufs["gv"][:5].cpu().numpy()
     assert np.all(np.isfinite(gv)) and np.abs(gv).max() > 0
+    if store:
+        # (ABI 6) the loss statistics of a pass regrouped from the row store in ONE launch (`copo_meta_rowstat_f32`) are what the
+        # per-chunk calls write when they are asked to (stats_out != NULL) -- bit for bit, the ragged last minibatch included
+        fz, mbuf = b.fused, b._meta_bufs
+        rs = dict(b._row_sources, **{k: mbuf[k] for k in ("rows_all", "w_all", "denom_all")})
+        once = torch.full_like(mbuf["stats_k"], float("nan"))
+        fz.meta_rowstat(rs, 0, 5, once)
+        per_chunk, gv2 = torch.full_like(mbuf["stats_k"], float("nan")), torch.zeros_like(mbuf["gv"])
+        for c0 in range(0, 5, nb):
+            fz.meta_batch_wgrads(rs, c0, min(nb, 5 - c0), gv2, per_chunk)
+        torch.cuda.synchronize()
+        assert torch.equal(once[:5], per_chunk[:5]) and bool(torch.isfinite(once[:5]).all())
+        np.testing.assert_allclose(gv2[:5].cpu().numpy(), gv, rtol=0, atol=0)      # (and the chunked dot products are the pass's)
 
 
 @pytest.mark.parametrize("B,B_all,mb", [(1337, [1337], 512), (1000, [1000, 700, 1290], 256), (0, [0, 40], 64), (5, [5], 512)])
