@@ -186,14 +186,15 @@ def _probe_child(module, port_shift, timeout, need_nccl, extra_env=None):
     return bool(ok.item())
 
 
-def probe_tile_exchange(hidden=64, obs_dim=20, nets=2, timeout=150.0):
+def probe_tile_exchange(hidden=64, obs_dim=20, nets=2, timeout=150.0, mb=128):
     """True if the data-parallel tile exchange (`copo_ppo_fused_step_dp_f32`: hipIpc-mapped uncached workspaces, peer stores,
     system-scope flags inside the weight-gradient kernel) works between the GPUs of THIS node: every rank runs
     copo_amd/dp_probe.py in a child process (its own process group on MASTER_PORT + 19) -- a learner of the caller's shape takes captured chains
     of data-parallel steps; all ranks must end with bit-identical parameters that agree with the RCCL-reduced step, and no wait
     may have timed out.  A failure or a hang (child killed after `timeout` s) leaves the RCCL loop in place."""
     return _probe_child("copo_amd.dp_probe", 19, timeout, need_nccl=False,
-                        extra_env=dict(COPO_DP_PROBE_HIDDEN=str(int(hidden)), COPO_DP_PROBE_OBS=str(int(obs_dim)), COPO_DP_PROBE_NETS=str(int(nets))))
+                        extra_env=dict(COPO_DP_PROBE_HIDDEN=str(int(hidden)), COPO_DP_PROBE_OBS=str(int(obs_dim)), COPO_DP_PROBE_NETS=str(int(nets)),
+                                       COPO_DP_PROBE_MB=str(int(mb))))
 
 
 def shutdown():

@@ -20,11 +20,12 @@ def _learner(mode, rank):
     # the learner's own shape (the parent passes it on): the weight-gradient grid -- how many workgroups wait for peers at once --
     # is what has to work, not a toy
     hidden, obs_dim = int(os.environ.get("COPO_DP_PROBE_HIDDEN", "64")), int(os.environ.get("COPO_DP_PROBE_OBS", "20"))
-    cfg.update_from_dict(dict(env=get_rllib_compatible_env(MultiAgentIntersectionEnv), seed=11, sgd_minibatch_size=128,
+    mb = _mb()
+    cfg.update_from_dict(dict(env=get_rllib_compatible_env(MultiAgentIntersectionEnv), seed=11, sgd_minibatch_size=mb,
                               model={"fcnet_hiddens": [hidden, hidden]}))
     cfg.validate()
     pol = (algo_copo.CoPOPolicy if nets >= 4 else algo_ippo.IPPOPolicy)(Box(-1, 1, (obs_dim,)), Box(-1, 1, (2,)), cfg)
-    R = 700 + 90 * rank                  # unequal shards: the smaller ranks pad with zero-weight rows
+    R = (700 + 90 * rank) * mb // 128    # unequal shards: the smaller ranks pad with zero-weight rows (~6-7 minibatches each)
     g = torch.Generator().manual_seed(100 + rank)
     rn = lambda *s: torch.randn(*s, generator=g).cuda()  # noqa: E731
     b = SampleBatch()
@@ -44,6 +45,12 @@ def _learner(mode, rank):
     return pol, b, R
 
 
+def _mb():
+    """The parent's minibatch size: 512-row minibatches take the buffer-load instantiation of the weight-gradient kernel, and it
+    is that kernel whose exchange has to work."""
+    return int(os.environ.get("COPO_DP_PROBE_MB", "128"))
+
+
 def main():
     os.environ["COPO_DIST_CHAIN"] = "0"       # (b) takes the eager RCCL loop: no probe of a probe
     os.environ.pop("COPO_PEER_ALLREDUCE", None)
@@ -57,12 +64,12 @@ def main():
     for mode in ("tile", "rccl"):
         pol, batch, R = _learner(mode, rank)
         assert pol.fused is not None
-        pol.prepare_sgd(batch, R, 128)
+        pol.prepare_sgd(batch, R, _mb())
         idx = torch.arange(R, device="cuda")
         B_all = D.all_gather_int(R, "cuda")
         torch.manual_seed(77)                 # the same shuffle keys in both modes
         t0 = __import__("time").perf_counter()
-        st = pol.run_sgd(idx, R, B_all, 128, 6)      # 6 epochs x 7 minibatches: captured chains of 16 + single steps
+        st = pol.run_sgd(idx, R, B_all, _mb(), 6)      # 6 epochs x 7 minibatches: captured chains of 16 + single steps
         if os.environ.get("COPO_DP_PROBE_VERBOSE"):
             print("rank %d mode %s: %d steps in %.2f s" % (rank, mode, st["num_sgd_steps"], __import__("time").perf_counter() - t0), flush=True)
         assert (pol._dp_mode == "tile") == (mode == "tile") and st["num_sgd_steps"] > 32

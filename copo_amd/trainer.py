@@ -479,7 +479,7 @@ class PPOPolicyBase:
         c = self.fused.cfg
         # "tile": by name, no probe, a timed-out wait raises; "try": no probe either, but a timed-out wait falls back to the RCCL loop
         # (what `auto` does after its probe has passed; the tests use it to exercise that fall-back)
-        if want in ("tile", "try") or D.probe_tile_exchange(c.hidden, c.pol.in_dim, 1 + c.n_value_heads):
+        if want in ("tile", "try") or D.probe_tile_exchange(c.hidden, c.pol.in_dim, 1 + c.n_value_heads, mb=int(c.mb)):
             tile = peer.TileExchange(self.fused.cfg, self.device)
             if tile.usable:               # (agreed by all ranks; False: a hipIpc export / open failed somewhere)
                 self._tile = tile

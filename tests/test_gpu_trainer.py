@@ -680,8 +680,9 @@ def test_bench_gpus_2_as_one_command_on_a_shared_device():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,hidden,nets", [(4, 64, 4), (3, 128, 2), (8, 64, 2)])
-def test_tile_exchange_probe_with_several_ranks_on_one_gpu(world, hidden, nets):
+@pytest.mark.parametrize("world,hidden,nets,mb", [(4, 64, 4, 128), (3, 128, 2, 128), (8, 64, 2, 128),
+                                                  (2, 128, 4, 512), (4, 64, 2, 512)])      # 512-row minibatches: the buffer-load instantiation of the weight-gradient kernel
+def test_tile_exchange_probe_with_several_ranks_on_one_gpu(world, hidden, nets, mb):
     """The data-parallel tile exchange beyond two ranks (owners dealt round-robin over 3 / 4 / 8 ranks, rank-order sums of up to
     eight partial tiles): `copo_amd/dp_probe.py` -- a learner stepping in captured chains with the exchange and, from the same
     start, with torch.distributed's all-reduce + flat Adam -- as `world` processes that share cuda:0 over gloo.  Every rank must
@@ -694,7 +695,7 @@ def test_tile_exchange_probe_with_several_ranks_on_one_gpu(world, hidden, nets):
         env = {k: v for k, v in os.environ.items() if k not in ("COPO_FORCE_DIST", "COPO_PEER_ALLREDUCE")}
         env.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT="29651",
                    COPO_DIST_BACKEND="gloo", COPO_DP_PROBE_HIDDEN=str(hidden), COPO_DP_PROBE_OBS="20", COPO_DP_PROBE_NETS=str(nets),
-                   COPO_DP_PROBE_VERBOSE="1")
+                   COPO_DP_PROBE_MB=str(mb), COPO_DP_PROBE_VERBOSE="1")
         procs.append(subprocess.Popen([sys.executable, "-m", "copo_amd.dp_probe"], env=env, cwd=root, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=400) for p in procs]
