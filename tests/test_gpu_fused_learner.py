@@ -656,6 +656,9 @@ def test_sequential_lcf_kernel_over_several_workgroups(n_seg, n_wg):
     chunks = run(1, calls=2, ranges=((0, 32), (32, 32), (64, -1)))
     for a, b, name in zip(one, chunks, ("lcf_param", "adam", "stats")):
         torch.testing.assert_close(b, a, rtol=1e-11, atol=1e-13, msg=name)
+    chunks_many = run(n_wg, calls=2, ranges=((0, 32), (32, 32), (64, -1)))      # (and with the hand-over between workgroups: a new epoch per launch)
+    for a, b, name in zip(one, chunks_many, ("lcf_param", "adam", "stats")):
+        torch.testing.assert_close(b, a, rtol=1e-10, atol=1e-12, msg=name)
 
 
 @pytest.mark.parametrize("name,fuse,odim", [("copo", "none", 92), ("ccppo", "mf", 91)])
