@@ -500,6 +500,26 @@ def test_forward_kernel_matches_torch_models(name, fuse, odim, over):
     rest[rows] = False
     assert not vr[:, rest].any()
     assert not fz.values(obs, None if cc is obs else cc, rows=rows[:0]).any()
+    if list(over.get("hiddens", (256, 256))) == [256, 256]:
+        # launches of at least 16 384 rows take two 16-row tiles per workgroup (hidden 256): the same values as the 16-row form
+        # computes for the same rows (the head's dot product is summed by 16 instead of 32 lanes: rounding only), ragged count,
+        # dense and row-list form, sampling included
+        Rb = 16384 + 1000 + 7
+        reps = -(-Rb // R)
+        obs_b, eps_b = obs.repeat(reps, 1)[:Rb].contiguous(), eps.repeat(reps, 1)[:Rb].contiguous()
+        cc_b = obs_b if cc is obs else cc.repeat(reps, 1)[:Rb].contiguous()
+        vb = fz.values(obs_b, None if cc is obs else cc_b)
+        np.testing.assert_allclose(vb[:, :R].cpu().numpy(), v.cpu().numpy(), rtol=2e-6, atol=2e-7)
+        assert torch.equal(vb[:, R:2 * R], vb[:, :R])                      # (the same rows again, in another workgroup: same bits)
+        rows_b = torch.randperm(Rb, device="cuda", generator=g)[:Rb - 300].sort().values
+        vrb = fz.values(obs_b, None if cc is obs else cc_b, rows=rows_b)
+        assert torch.equal(vrb[:, rows_b], vb[:, rows_b])
+        ab, lpb, dib, clb = (torch.empty(Rb, 2, device="cuda"), torch.empty(Rb, device="cuda"), torch.empty(Rb, 4, device="cuda"),
+                             torch.empty(Rb, 2, device="cuda"))
+        fz.act(obs_b, eps_b, ab, lpb, dib, clb)
+        np.testing.assert_allclose(dib[:R].cpu().numpy(), di.cpu().numpy(), rtol=2e-6, atol=2e-7)
+        np.testing.assert_allclose(ab[-R:].cpu().numpy(), a_ref.repeat(reps, 1)[:Rb][-R:].cpu().numpy(), rtol=2e-5, atol=2e-6)
+        assert torch.equal(clb, ab.clamp(-1.0, 1.0))
 
 
 @pytest.mark.parametrize("tag,name,fuse,over", [
