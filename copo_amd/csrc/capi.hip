@@ -59,9 +59,15 @@ static int upload(copo_sim* s, const T* host, size_t count, const T** dev) {
 // 2048 four waves per scene still win, 72 vs 96 us)
 // (`nbr_fast` = the register formulation of the neighbour lists can run, SimParams::nbr_fast: without it -- K > 8, a mean-field
 // range of 0 or beyond the radius -- one wave per scene only pays above 8192 scenes, as before that formulation existed)
-static int pick_block(int E, bool nbr_fast = true) {
-    return E <= 256 ? 1024 : (E <= 512 ? 512 : (E <= (nbr_fast ? 3072 : 8192) ? 256 : 64));
+// Above that: the PACKED shape (sim_packed.hip: several scenes per workgroup, the per-agent phases dense over the lanes) wherever
+// the configuration allows it (`packed` = scenes per workgroup, 0: not available), else one wave per scene.  Returned as -scenes.
+static int pick_block(int E, bool nbr_fast = true, int packed = 0) {
+    if (E <= 256) return 1024;
+    if (E <= 512) return 512;
+    if (E <= (nbr_fast ? 3072 : 8192)) return 256;
+    return packed > 0 ? -packed : 64;
 }
+static int packed_scenes(const SimParams& p) { return sim_packed_supported(p) ? sim_packed_default_scenes(p) : 0; }
 
 extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** out) {
     if (!cfg || !out) return fail(COPO_ERR_NULL, "copo_sim_create: cfg/out is NULL");
@@ -172,7 +178,6 @@ extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** o
         // key thresholds of a zero range cannot express it)
         p.nbr_fast = (cfg->nbr_k <= 8 && cfg->neighbours_distance > 0.0f && cfg->mf_distance > 0.0f &&
                       cfg->mf_distance < 0.99f * cfg->neighbours_distance) ? 1 : 0;
-        s->block = pick_block(cfg->num_envs, p.nbr_fast != 0);
     }
     p.dt = cfg->dt; p.hl = cfg->veh_half_len; p.hw = cfg->veh_half_wid; p.wheelbase = cfg->wheelbase;
     p.max_steer = cfg->max_steer; p.max_speed = cfg->max_speed; p.acc_max = cfg->acc_max; p.brake_gain = cfg->brake_gain;
@@ -246,6 +251,7 @@ extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** o
     if (rc == COPO_OK && p.n_lines) rc = upload(s, cfg->lines, (size_t)cfg->n_lines * COPO_LINE_STRIDE, &p.lines);
     if (rc == COPO_OK && cfg->side_lasers) rc = upload(s, cfg->side_cs, (size_t)cfg->side_lasers * 2, &p.side_cs);
     if (rc == COPO_OK && cfg->lane_line_lasers) rc = upload(s, cfg->lane_line_cs, (size_t)cfg->lane_line_lasers * 2, &p.lane_cs);
+    s->block = pick_block(cfg->num_envs, p.nbr_fast != 0, packed_scenes(p));      // (after the observation layout: the packed shape depends on it)
     sim_shape_params(p, s->block);
     if (rc == COPO_OK) {
         const SimParams* pd = nullptr;
@@ -326,9 +332,14 @@ extern "C" int copo_sim_set_debug(copo_sim* s, int64_t* stamps) {
 
 extern "C" int copo_sim_set_block(copo_sim* s, int32_t threads) {
     if (!s) return fail(COPO_ERR_NULL, "copo_sim_set_block: NULL handle");
-    if (threads == 0) threads = pick_block(s->p.E, s->p.nbr_fast != 0);
-    if (threads != 64 && threads != 128 && threads != 256 && threads != 512 && threads != 1024)
-        return fail(COPO_ERR_DIM, "block=%d must be 64/128/256/512/1024", threads);
+    if (threads == 0) threads = pick_block(s->p.E, s->p.nbr_fast != 0, packed_scenes(s->p));
+    if (threads < 0) {        // packed shape: -threads scenes per workgroup (-1: the default count)
+        if (!sim_packed_supported(s->p)) return fail(COPO_ERR_CONFIG, "the packed launch shape needs the register formulation of the neighbour lists and no traffic-light / communication block");
+        if (threads == -1) threads = -sim_packed_default_scenes(s->p);
+        if (threads < -16 || threads > -2 || sim_packed_lds_bytes(s->p, -threads) > 96 * 1024)
+            return fail(COPO_ERR_DIM, "block=%d: 2..16 scenes per workgroup within 96 KB of LDS", threads);
+    } else if (threads != 64 && threads != 128 && threads != 256 && threads != 512 && threads != 1024)
+        return fail(COPO_ERR_DIM, "block=%d must be 64/128/256/512/1024, or -scenes for the packed shape", threads);
     if (threads != s->block) {
         s->block = threads;
         sim_shape_params(s->p, threads);
@@ -343,7 +354,12 @@ extern "C" int copo_sim_set_chunk(copo_sim* s, int32_t fans) {
     if (!s) return fail(COPO_ERR_NULL, "copo_sim_set_chunk: NULL handle");
     if (fans < 0 || fans > COPO_MAX_AGENTS) return fail(COPO_ERR_DIM, "fans=%d must be 0..%d", fans, COPO_MAX_AGENTS);
     if (fans != s->p.chunk_one_wave) {
+        const int32_t before = s->p.chunk_one_wave;
         s->p.chunk_one_wave = fans;
+        if (s->block < 0 && sim_packed_lds_bytes(s->p, -s->block) > 96 * 1024) {      // packed shape: the workgroup's scenes must still fit
+            s->p.chunk_one_wave = before;
+            return fail(COPO_ERR_DIM, "fans=%d: %d scenes per workgroup would need more than 96 KB of LDS", fans, -s->block);
+        }
         sim_shape_params(s->p, s->block);
         HIP_TRY(hipSetDevice(s->device));
         HIP_TRY(hipDeviceSynchronize());         // launches in flight keep the shape they started with

@@ -22,6 +22,7 @@ struct SimParams {
     int32_t nbr_chunk;             // present agents whose pair-parallel neighbour lists are in LDS at a time (same)
     int32_t chunk_one_wave;        // `chunk` of the one-wave-per-scene shape (copo_sim_set_chunk; 0 = default)
     int32_t stage_tables;          // 1: the step kernel copies the route / spawn tables to LDS (launch shape)
+    int32_t pack_scenes;           // packed launch shape (sim_packed.hip): scenes per workgroup; 0 = one scene per workgroup
     int32_t seg_rows;              // road records per route in the DEVICE copy of route_segs: longest route + 1 (compacted at create)
     int32_t side_lasers, lane_lasers, navi_dim, toll_dim, toll_min_steps;
     int32_t lists_for_absent;      // 1: nbr_idx / nbr_dist rows of absent slots are filled with -1 / 0 (the stateless op); 0: left alone
@@ -65,6 +66,12 @@ void sim_shape_params(SimParams& p, int block);
 // p: host copy (launch shape), p_dev: the same block in device memory (what the kernels read)
 hipError_t launch_sim_reset(const SimParams& p, const SimParams* p_dev, const StepOut& out, int block, hipStream_t stream);
 hipError_t launch_sim_step(const SimParams& p, const SimParams* p_dev, const float* act, const StepOut& out, int block, hipStream_t stream);
+// packed launch shape (sim_packed.hip): S scenes per workgroup, per-agent phases dense over the lanes
+bool sim_packed_supported(const SimParams& p);
+int sim_packed_default_scenes(const SimParams& p);
+int sim_packed_chunk(const SimParams& p);
+size_t sim_packed_lds_bytes(const SimParams& p, int S);
+hipError_t launch_sim_step_packed(const SimParams& p, const SimParams* p_dev, const float* act, const StepOut& out, int S, hipStream_t stream);
 // stateless neighbour op: no communication block
 hipError_t launch_neighbours(const float* pos, const uint8_t* present, const float* rew, const SimParams& p,
                              const StepOut& out, hipStream_t stream);

@@ -233,7 +233,10 @@ int copo_sim_step(copo_sim* sim, const float* act, const copo_step_out* out, voi
 /* raw state access for tests / checkpointing: [COPO_STATE_FIELDS][E][N] fp32 words + [E][4] int32 env words */
 int copo_sim_get_state(copo_sim* sim, float* slot_state, int32_t* env_state, void* stream);
 int copo_sim_set_state(copo_sim* sim, const float* slot_state, const int32_t* env_state, void* stream);
-/* workgroup size of the step kernel: 256, 512 or 1024 (0 = pick from E); tuning knob, results do not depend on it */
+/* launch shape of the step kernel; tuning knob, results do not depend on it.  threads > 0: one scene per workgroup of 64 / 128 / 256 /
+ * 512 / 1024 threads; threads < 0: the PACKED shape for large scene counts, -threads (2..16) scenes per workgroup with the per-agent phases
+ * dense over the lanes (-1 = the default count; needs nbr_k <= 8, 0 < mf_distance < neighbours_distance, no traffic-light /
+ * communication block: COPO_ERR_CONFIG otherwise); 0 = pick from E (packed above 3072 scenes where available) */
 int copo_sim_set_block(copo_sim* sim, int32_t threads);
 /* LiDAR fans whose ray minima are held in LDS at a time when ONE wave owns a scene (workgroup size 64): 1..64, 0 = default;
  * trades resident scenes per compute unit against fuller work batches; tuning knob, results do not depend on it */

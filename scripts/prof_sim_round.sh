@@ -6,7 +6,7 @@
 # dispatches of the kernel = the replay.     usage: scripts/prof_sim_round.sh live|saturated [tag]   -> gpurun_out/prof_<tag>_<mode>/summary.txt (+ sim_valu.json for saturated)
 set -u
 MODE=$1
-TAG=${2:-r04}
+TAG=${2:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_${TAG}_$MODE
 rm -rf $OUT; mkdir -p $OUT
@@ -23,7 +23,7 @@ cd $ROOT
   echo "# (the LAST $N dispatches of the kernel are the replay of the recorded actions; line below: what the command printed in the trace pass,"
   echo "#  HIP events around the back-to-back replay)"
   grep -h '^{' $OUT/trace.log | tail -1
-  python scripts/replay_summary.py $OUT sim_step_kernel $N
+  python scripts/replay_summary.py $OUT sim_step $N
 } > $OUT/summary.txt 2>&1
 # VALU roofline of the saturated launch: wave-level VALU instructions per launch (SQ_INSTS_VALU) and the cycles the VALUs were
 # busy (SQ_ACTIVE_INST_VALU, quad-cycles) -> profiles/sim_valu.json, read by bench.py when the kernel source hash matches
@@ -37,7 +37,7 @@ def last_mean(d, counter, n):
         con = sqlite3.connect(f)
         cols = [r[1] for r in con.execute("pragma table_info(counters_collection)")]
         order = "dispatch_id" if "dispatch_id" in cols else "rowid"
-        v = [r[0] for r in con.execute("select value from counters_collection where counter_name = ? and kernel_name like '%sim_step_kernel%' order by " + order, (counter,))]
+        v = [r[0] for r in con.execute("select value from counters_collection where counter_name = ? and kernel_name like '%sim_step%' order by " + order, (counter,))]
         if v:
             return sum(v[-n:]) / len(v[-n:])
     return None

@@ -1,5 +1,6 @@
 """Randomised parity hunt: HIP simulator vs the CPU oracle, raw bits of every output, over random maps / populations /
-beam counts / launch shapes / action sources.  usage: python scripts/sim_fuzz.py [n_cases] [steps]"""
+beam counts / launch shapes / action sources.  usage: python scripts/sim_fuzz.py [n_cases] [steps] [packed]
+(`packed`: the packed launch shape of sim_packed.hip, 2 .. 16 scenes per workgroup, on configurations that allow it)"""
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,6 +14,7 @@ from copo_amd.sim import SimConfig, VecSim
 KEYS = ("obs", "rew", "nei_rew", "glob_rew", "flags", "nbr_cnt", "mf_cnt", "lcf", "info", "agent_id")
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 250
+packed = len(sys.argv) > 3 and sys.argv[3] == "packed"
 rng = np.random.RandomState(2026)
 bad = 0
 for case in range(n_cases):
@@ -20,17 +22,24 @@ for case in range(n_cases):
     kw = dict(sequence=int(rng.randint(1, 5)), seed=int(rng.randint(1000))) if name == "pgmap" else {}
     tabs = __import__("copo_amd.maps", fromlist=["x"]).MAP_BUILDERS[name](**kw)
     N = int(rng.randint(2, min(64, tabs.n_spawns) + 1))
-    E = int(rng.randint(1, 7))
+    E = int(rng.randint(1, 24 if packed else 7))
     lasers = int(rng.choice([30, 72, 72, 72, 120, 240]))
-    block = int(rng.choice([64, 64, 128, 256, 512, 1024]))
+    block = int(rng.choice([-2, -3, -5, -8, -8, -11, -16])) if packed else int(rng.choice([64, 64, 128, 256, 512, 1024]))
     cfg = SimConfig(map=name, map_kwargs=kw, num_envs=E, num_agents=N, num_lasers=lasers, horizon=int(rng.randint(40, 200)),
-                    nbr_k=int(rng.randint(1, max(2, min(N, 12)))), delay_done=int(rng.randint(0, 30)), enable_lcf=bool(rng.randint(2)),
-                    neighbours_distance=float(rng.choice([10.0, 20.0, 40.0])),
+                    nbr_k=int(rng.randint(1, max(2, min(N, 9 if packed else 12)))), delay_done=int(rng.randint(0, 30)), enable_lcf=bool(rng.randint(2)),
+                    neighbours_distance=float(rng.choice([20.0, 40.0] if packed else [10.0, 20.0, 40.0])),
                     reverse_acc=float(rng.choice([0.0, 0.0, 0.0, 2.9])))        # (round 3: optional reverse gear)
     g, o = VecSim(cfg), ol.OracleSim(cfg)
-    g.set_block(block)
+    try:
+        g.set_block(block)
+    except Exception as ex:      # (packed: more LDS than a workgroup may have with this many scenes)
+        block = -2
+        g.set_block(block)
     chunk = int(rng.choice([0, 0, 3, 8, 13, 20]))                               # (round 3: LiDAR fans per pass of the one-wave shape)
-    g.set_chunk(chunk)
+    try:
+        g.set_chunk(chunk)
+    except Exception:            # (packed: that many fans of that many rays do not fit the workgroup's LDS)
+        chunk = 0
     seeds = rng.randint(0, 2 ** 31, E).astype(np.uint64)
     go, oo = g.reset(seeds), o.reset(seeds)
     mode = rng.randint(3)

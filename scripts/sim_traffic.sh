@@ -21,7 +21,7 @@ def last_mean(d, counter, n=200):
         con = sqlite3.connect(f)
         cols = [r[1] for r in con.execute("pragma table_info(counters_collection)")]
         order = "dispatch_id" if "dispatch_id" in cols else "rowid"
-        v = [r[0] for r in con.execute("select value from counters_collection where counter_name = ? and kernel_name like '%sim_step_kernel%' order by " + order, (counter,))]
+        v = [r[0] for r in con.execute("select value from counters_collection where counter_name = ? and kernel_name like '%sim_step%' order by " + order, (counter,))]
         if v:
             return sum(v[-n:]) / len(v[-n:]), len(v)
     return None, 0

@@ -14,7 +14,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NAMES = {0: "everything (nothing skipped)", 1: "neighbour lists", 2: "LiDAR windows + box tests", 4: "LiDAR write-out",
          8: "state / navigation block", 16: "collision pairs", 32: "respawn", 64: "projection / termination", 127: "all of the above",
-         128: "neighbour lists pair-parallel (register formulation off: phase = NEGATIVE of its saving)", 3: "neighbours + LiDAR tests", 6: "LiDAR tests + write-out", 7: "neighbours + all LiDAR"}
+         128: "neighbour lists pair-parallel (register formulation off: phase = NEGATIVE of its saving)", 3: "neighbours + LiDAR tests", 6: "LiDAR tests + write-out", 7: "neighbours + all LiDAR",
+         1024: "timers + kinematic bicycle (packed shape)", 2048: "LiDAR pair queue from the reach masks (packed shape)", 3199: "all of the above (packed shape)"}
 
 
 def child(mask, E, block, path):

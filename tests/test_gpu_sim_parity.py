@@ -45,6 +45,17 @@ def _actions(rng, E, N, t):
     ("pgmap", 20, 4, 72, 200, 256),
     ("pgmap-junctions", 20, 3, 72, 260, 256),      # intersection + roundabout blocks inside the generated road
     ("parkinglot-reverse", 10, 4, 72, 150, 64),    # reverse gear (copo_sim_cfg.reverse_acc): negative throttle = engine force backwards
+    # the PACKED launch shape (sim_packed.hip; block = -scenes per workgroup): per-agent phases dense over the lanes, a last workgroup
+    # with fewer scenes than the others, slots of a scene straddling two waves, exclusive destinations, detector beams, toll columns
+    ("intersection", 40, 11, 72, 260, -8),
+    ("roundabout", 40, 5, 72, 200, -4),
+    ("parkinglot", 10, 13, 240, 150, -12),
+    ("tollgate", 40, 3, 72, 120, -2),
+    ("intersection", 4, 19, 72, 150, -16),
+    ("bottleneck", 20, 7, 72, 200, -1),
+    ("pgmap-junctions", 20, 9, 72, 260, -8),
+    ("parkinglot-reverse", 10, 6, 72, 150, -5),
+    ("intersection", 30, 9, 72, 200, -8),
 ])
 def test_rollout_bit_exact(map_name, N, E, lasers, steps, block):
     import torch
@@ -94,14 +105,14 @@ def test_register_neighbour_lists_decline_on_ties_and_band_cases():
       scene 6  three such vehicles within range of each other         -> 16 + n: a reward outside the range in which sums are exact
       scene 7  nine vehicles on a cross (ties for every one of them)  -> 2: more agents than the exact evaluation takes
     Outputs (counts, first K ids and distances, neighbourhood / global rewards, observations) are compared bit for bit, in
-    both launch shapes (one wave per scene; 16 waves per scene, where wave 1 builds the lists)."""
+    the launch shapes (one wave per scene; 16 waves per scene, where wave 1 builds the lists; packed, 8 and 3 scenes per workgroup)."""
     import torch
     import oracle_lib as ol
     from copo_amd import _capi
     from copo_amd.sim import SimConfig, VecSim
     E, N = 8, 12
     cfg = SimConfig(map="intersection", num_envs=E, num_agents=N, nbr_k=8, horizon=200)
-    for block in (64, 1024):
+    for block in (64, 1024, -8, -3):
         g, o = VecSim(cfg), ol.OracleSim(cfg)
         g.set_block(block)
         seeds = np.arange(E, dtype=np.uint64) + np.uint64(5000)
@@ -139,6 +150,10 @@ def test_register_neighbour_lists_decline_on_ties_and_band_cases():
             assert all(17 <= w <= 16 + 6 for w in which[1:4]), which
             assert 17 <= which[4] <= 16 + 6, which
             assert which[6] in (18, 19) and which[7] == 2, which
+        elif block < 0:      # packed shape: no pair-parallel formulation, every undecided agent is evaluated exactly
+            assert which[0] == 1 and which[5] == 1, which
+            assert all(17 <= w <= 16 + 6 for w in which[1:4]), which
+            assert which[4] >= 17 and which[6] in (18, 19) and which[7] >= 16 + 9, which
         else:      # (a scene whose last agent terminates in this step -- most of these -- resets, and a resetting scene of the
             #         many-wave shape builds its lists pair-parallel on the poses before the reset: column 7 stays 0)
             assert all(w == 0 or w == 2 or w == 1 or 17 <= w <= 22 for w in which) and any(w >= 17 for w in which), which
