@@ -364,39 +364,58 @@ __device__ __forceinline__ void ego_navi_obs(const SimParams& p, const LT& L, fl
 
 // One detector beam against the lane-line primitives (MetaDrive SideDetector / LaneLineDetector): see the oracle's
 // detector_ray for the arithmetic, which this repeats operation by operation.
+// one line primitive against one beam: `best` is lowered to the hit distance if the beam meets the primitive before it
+__device__ __forceinline__ void detector_line(const float* __restrict__ Ln, float x, float y, float dx, float dy, float& best) {
+    if (Ln[6] == 0.0f) {
+        const float rx = Ln[1] - x, ry = Ln[2] - y;
+        const float den = dx * Ln[4] - dy * Ln[3];
+        if (den == 0.0f) return;
+        const float sd = den > 0.0f ? 1.0f : -1.0f;
+        const float ad = den * sd;
+        const float tn = (rx * Ln[4] - ry * Ln[3]) * sd;
+        const float un = (rx * dy - ry * dx) * sd;
+        if (!(tn >= 0.0f && un >= 0.0f && un <= Ln[5] * ad && tn < best * ad)) return;
+        best = tn / ad;
+    } else {
+        const float R = 1.0f / fabsf(Ln[6]);
+        const float mx = x - Ln[7], my = y - Ln[8];
+        const float b = mx * dx + my * dy;
+        const float cq = mx * mx + my * my - R * R;
+        const float disc = b * b - cq;
+        if (!(disc >= 0.0f)) return;
+        const float sq = sqrtf(disc);
+        for (int r = 0; r < 2; ++r) {
+            const float tt = r == 0 ? -b - sq : -b + sq;
+            if (!(tt >= 0.0f && tt < best)) continue;
+            const float hx = mx + tt * dx, hy = my + tt * dy;
+            if (hx * Ln[9] + hy * Ln[10] >= R * Ln[11]) { best = tt; break; }
+        }
+    }
+}
 __device__ __forceinline__ float detector_ray(const SimParams& p, const float* __restrict__ lines, float x, float y, float dx,
                                               float dy, float range, float min_kind) {
     float best = range;
     for (int l = 0; l < p.n_lines; ++l) {
         const float* Ln = lines + (size_t)l * COPO_LINE_STRIDE;
         if (Ln[0] < min_kind) continue;
-        if (Ln[6] == 0.0f) {
-            const float rx = Ln[1] - x, ry = Ln[2] - y;
-            const float den = dx * Ln[4] - dy * Ln[3];
-            if (den == 0.0f) continue;
-            const float sd = den > 0.0f ? 1.0f : -1.0f;
-            const float ad = den * sd;
-            const float tn = (rx * Ln[4] - ry * Ln[3]) * sd;
-            const float un = (rx * dy - ry * dx) * sd;
-            if (!(tn >= 0.0f && un >= 0.0f && un <= Ln[5] * ad && tn < best * ad)) continue;
-            best = tn / ad;
-        } else {
-            const float R = 1.0f / fabsf(Ln[6]);
-            const float mx = x - Ln[7], my = y - Ln[8];
-            const float b = mx * dx + my * dy;
-            const float cq = mx * mx + my * my - R * R;
-            const float disc = b * b - cq;
-            if (!(disc >= 0.0f)) continue;
-            const float sq = sqrtf(disc);
-            for (int r = 0; r < 2; ++r) {
-                const float tt = r == 0 ? -b - sq : -b + sq;
-                if (!(tt >= 0.0f && tt < best)) continue;
-                const float hx = mx + tt * dx, hy = my + tt * dy;
-                if (hx * Ln[9] + hy * Ln[10] >= R * Ln[11]) { best = tt; break; }
-            }
-        }
+        detector_line(Ln, x, y, dx, dy, best);
     }
     return best;
+}
+// Can a beam of length `range` from (x, y) meet the primitive at all?  Conservative: distance to the segment / to the arc's full
+// circle against the range + 0.1 % + 1 cm (a hit lies on the primitive at its hit distance from the origin; rounding is ~1e-4 m).
+__device__ __forceinline__ bool detector_line_near(const float* __restrict__ Ln, float x, float y, float range) {
+    const float lim = range * 1.001f + 0.01f;
+    if (Ln[6] == 0.0f) {
+        const float rx = x - Ln[1], ry = y - Ln[2];
+        float t = rx * Ln[3] + ry * Ln[4];
+        t = t < 0.0f ? 0.0f : (t > Ln[5] ? Ln[5] : t);
+        const float ex = rx - t * Ln[3], ey = ry - t * Ln[4];
+        return ex * ex + ey * ey <= lim * lim;
+    }
+    const float R = 1.0f / fabsf(Ln[6]);
+    const float mx = x - Ln[7], my = y - Ln[8];
+    return fabsf(sqrtf(mx * mx + my * my) - R) <= lim;
 }
 
 // Ray against the box of vehicle j, in j's box frame: entering distance, or a negative value for a miss.  Box frame mirrored so that the direction is non-negative on both axes; entering / exiting
@@ -638,5 +657,255 @@ __device__ __forceinline__ void slot_project(const SimParams& p, const LT& L, fl
             s.status = st_pack(ST_EMPTY, p.respawn_cooldown, 0);
     }
 }
+
+// ---- helpers of the one-wave-per-scene phases -----------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long pk_u64(const unsigned int* w) { return *reinterpret_cast<const unsigned long long*>(w); }
+__device__ __forceinline__ void pk_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ int pk_mbcnt(unsigned long long m) {      // set bits of m below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+}
+
+// wave sum of doubles on the DPP network (row shifts, then row broadcasts); the total arrives in lane 63.  Lanes without a source
+// add +0.0.  Only used where every partial sum is exact, so the order of the tree does not matter.
+__device__ __forceinline__ double pk_wave_sum_f64(double v) {
+#define COPO_DSUM_STEP(ctrl, rmask)                                                                             \
+    {                                                                                                           \
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, rmask, 0xf, false);              \
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, rmask, 0xf, false);              \
+        v = v + __hiloint2double(hi, lo);                                                                       \
+    }
+    COPO_DSUM_STEP(0x111, 0xf)
+    COPO_DSUM_STEP(0x112, 0xf)
+    COPO_DSUM_STEP(0x114, 0xf)
+    COPO_DSUM_STEP(0x118, 0xf)
+    COPO_DSUM_STEP(0x142, 0xa)
+    COPO_DSUM_STEP(0x143, 0xc)
+#undef COPO_DSUM_STEP
+    return v;
+}
+
+__device__ __forceinline__ unsigned long long pk_uni64(unsigned long long v) {      // a wave-uniform value, in scalar registers
+    return ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+           (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+// Side / lane-line detector beams (Bottleneck, Tollgate, generated roads) of `np` present agents by `nth` threads (WG: the threads of
+// a workgroup, else one wave).  A beam only meets the primitives within its range of the vehicle: one pass marks, per agent, the
+// primitives near enough for each of the two detectors (bit masks in `scratch`, 8 words per agent, `cap` words in all); the beams then
+// walk the marked primitives in table order -- the order in which the exhaustive loop (detector_ray, the oracle's) lowers `best`, so
+// the result is that loop's, bit for bit: a primitive left out cannot lower it.
+template <bool WG, class PoseF>
+__device__ __forceinline__ void detector_beams(const SimParams& p, PoseF pose, const uint8_t* plist, int np, unsigned int* scratch, int cap,
+                                               float* __restrict__ eobs, int tid, int nth) {
+    const int nb = p.side_lasers + p.lane_lasers, NLn = p.n_lines, O = p.O;
+    if (nb <= 0) return;
+    auto sync = [&]() {
+        if (WG) __syncthreads();
+        else pk_wave_sync();
+    };
+    const int G = cap / 8 > 0 ? cap / 8 : 1;      // agents per pass
+    const float inv_nb = 1.0f / (float)nb, inv_nl = 1.0f / (float)(NLn > 0 ? NLn : 1);
+    for (int ip0 = 0; ip0 < np; ip0 += G) {
+        const int na = np - ip0 < G ? np - ip0 : G;
+        sync();
+        for (int q = tid; q < na * 8; q += nth) scratch[q] = 0u;
+        sync();
+        for (int q = tid; q < na * NLn; q += nth) {
+            const int ia = (int)(((float)q + 0.5f) * inv_nl), l = q - ia * NLn;
+            const float4 pi = pose((int)plist[ip0 + ia]);
+            const float* Ln = p.lines + (size_t)l * COPO_LINE_STRIDE;
+            const float kind = Ln[0];
+            if (p.side_lasers > 0 && kind >= 2.0f && detector_line_near(Ln, pi.x, pi.y, p.side_range)) atomicOr(&scratch[ia * 8 + (l >> 5)], 1u << (l & 31));
+            if (p.lane_lasers > 0 && kind >= 1.0f && detector_line_near(Ln, pi.x, pi.y, p.lane_range)) atomicOr(&scratch[ia * 8 + 4 + (l >> 5)], 1u << (l & 31));
+        }
+        sync();
+        for (int q = tid; q < na * nb; q += nth) {
+            const int ia = (int)(((float)q + 0.5f) * inv_nb), b = q - ia * nb;
+            const int i = plist[ip0 + ia];
+            const bool side = b < p.side_lasers;
+            const int k = side ? b : b - p.side_lasers;
+            const float* tab = side ? p.side_cs : p.lane_cs;
+            const float a0 = tab[2 * k], b0 = tab[2 * k + 1];
+            const float4 pi = pose(i);
+            const float dx = pi.z * a0 - pi.w * b0, dy = pi.w * a0 + pi.z * b0;
+            float best = side ? p.side_range : p.lane_range;
+            for (int w = 0; w < 4; ++w) {
+                unsigned int m = scratch[ia * 8 + (side ? 0 : 4) + w];
+                while (m) {
+                    const int l = 32 * w + __ffs((int)m) - 1;
+                    m &= m - 1u;
+                    detector_line(p.lines + (size_t)l * COPO_LINE_STRIDE, pi.x, pi.y, dx, dy, best);
+                }
+            }
+            eobs[i * O + (side ? k : p.col_lane + k)] = best * (side ? p.inv_side_range : p.inv_lane_range);
+        }
+    }
+}
+
+// LiDAR of one scene by its wave: the pair-driven formulation of obs_phase (sim_kernels.hip, the shapes with several waves per scene) -- conservative ray window per (fan,
+// vehicle) pair, box tests numbered by a DPP scan, hits folded with LDS atomicMin -- with
+//   * the pair queue filled from the reach masks of the neighbour walk (no all-pairs reach pass);
+//   * the pairs with a non-empty window pushed together (ds_permute) before their box tests are numbered: the owner of box test t
+//     is then simply pair number (heads before this batch) + (heads at or before t in it) - 1, a ballot of the head flags and a
+//     v_mbcnt instead of a DPP max-scan per batch of tests; the head flags carry the batch's sequence number, so the strip is
+//     never cleared;
+//   * the pair record holding the ray-minima row offset (lp * NL) next to the first ray, so a box test multiplies nothing;
+//   * the hit distance through div_nr (sim_device.h).
+// `present` / `solid`: the scene after the step (after a reset, if it reset).
+// `pose(slot)` -> float4 {x, y, cos, sin} of a vehicle; `reach(lane)` -> this LANE's slot's reach mask (two 32-bit halves in the lane's
+// registers, or read from LDS by the caller); `plist`: u8 [64] for the present slots (filled here); `best` / `cq`: the ray minima [chunk][NL]
+// and the pair queue u16 [chunk * N]; `wtag`: 64 words of this wave.
+template <class PoseF>
+__device__ __forceinline__ void lidar_by_wave(const SimParams& p, PoseF pose, uint8_t* plist, unsigned int reach_lo, unsigned int reach_hi,
+                                              unsigned int* best, uint16_t* cq, const float* __restrict__ rays, int* wtag,
+                                              int e, int lane, unsigned long long present_in, unsigned long long solid_in, bool all_reach_in,
+                                              float* __restrict__ obs) {
+    const unsigned long long present = pk_uni64(present_in), solid = pk_uni64(solid_in);
+    const bool all_reach = __builtin_amdgcn_readfirstlane(all_reach_in ? 1 : 0) != 0;
+    const int N = p.N, O = p.O, NL = p.num_lasers;
+    const float hl = p.hl, hw = p.hw;
+    const float circ = sqrtf(hl * hl + hw * hw);
+    const float range = p.lidar_range;
+    const float lim = range + circ;
+    const int np = __popcll(present);
+    const unsigned int range_bits = __float_as_uint(range);
+    float* eobs = obs + (size_t)e * N * O;
+    const int CH = p.chunk > 0 ? p.chunk : N;
+    const float rays_per_rad = (float)NL * 0.159154943f;
+    const float inv_nl = 1.0f / (float)NL;
+    const float inv_range = p.inv_range;
+    const int col_lidar = p.col_lidar;
+    const int head = (4 - (col_lidar & 3)) & 3;
+    const int nvec = (NL - head) >> 2;
+    const bool vec_out = ((O & 3) == 0) && nvec > 0 && ((reinterpret_cast<uintptr_t>(obs) & 15) == 0);
+    const float inv_nvec = 1.0f / (float)(nvec > 0 ? nvec : 1), inv_nsc = 1.0f / (float)(NL - 4 * nvec > 0 ? NL - 4 * nvec : 1);
+    if (__builtin_amdgcn_inverse_ballot_w64(present)) plist[pk_mbcnt(present)] = (uint8_t)lane;
+    wtag[lane] = 0;
+    int seq = 0;                      // sequence number of the box-test batches of this wave (head flags)
+    pk_wave_sync();
+    for (int ip0 = 0; ip0 < np; ip0 += CH) {
+        const int cha = np - ip0 < CH ? np - ip0 : CH;
+        for (int q = lane; q < cha * NL; q += 64) best[q] = range_bits;
+        // pair queue of this chunk of fans, from their reach masks
+        int nq = 0;
+        {
+            // (the mask of fan lp lives in the registers of lane plist[ip0 + lp], the fan's own slot)
+            const int islot = lane < cha ? (int)plist[ip0 + lane] : 0;
+            for (int lp = 0; lp < ((COPO_PROFILE_SKIP & 2048) ? 0 : cha); ++lp) {
+                const int i = __builtin_amdgcn_readlane(islot, lp);
+                const unsigned long long m = all_reach ? solid
+                                                       : (((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)reach_hi, i) << 32) |
+                                                          (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)reach_lo, i)) & solid;
+                if (__builtin_amdgcn_inverse_ballot_w64(m)) cq[nq + pk_mbcnt(m)] = (uint16_t)((lp << 8) | lane);
+                nq += __popcll(m);
+            }
+        }
+        pk_wave_sync();
+        for (int q0 = 0; q0 < ((COPO_PROFILE_SKIP & 2) ? 0 : nq); q0 += 64) {
+            const bool live = q0 + lane < nq;
+            const int ent = live ? (int)cq[q0 + lane] : 0;
+            const int lp = ent >> 8, j = ent & 255;
+            const int i = plist[ip0 + lp];
+            const float4 pi = pose(i), pj = pose(j);
+            const float ci = pi.z, si = pi.w, cj = pj.z, sj = pj.w;
+            const float dx = pj.x - pi.x, dy = pj.y - pi.y;
+            const float d2 = dx * dx + dy * dy;
+            int klo = 0, cnt = 0;
+            if (live && j != i && !(d2 > lim * lim)) {
+                if (d2 <= circ * circ * 1.002f) {
+                    cnt = NL;                         // origin inside the circumcircle: any ray may hit
+                } else {
+                    const float phi = p.ray_sign * atan2_window(ci * dy - si * dx, ci * dx + si * dy);   // in beam-index direction
+                    const float rd = __builtin_amdgcn_rsqf(d2);
+                    const float x = circ * rd;
+                    float w = x + 0.5708f * x * x * x;                    // >= asin(circumradius / distance)
+                    const float ux = dx * rd, uy = dy * rd;
+                    const float ca = fabsf(cj * ux + sj * uy), sa = fabsf(cj * uy - sj * ux);
+                    const float h_perp = hl * sa + hw * ca, along = d2 * rd - (hl * ca + hw * sa);
+                    if (along > 0.5f) w = fminf(w, h_perp * __builtin_amdgcn_rcpf(along) * 1.0001f);
+                    w += 0.004f;                                          // margin over the approximations above (< 1e-4 rad)
+                    const int lo = (int)ceilf((phi - w) * rays_per_rad), hi = (int)floorf((phi + w) * rays_per_rad);
+                    cnt = hi - lo + 1;
+                    cnt = cnt < 0 ? 0 : (cnt > NL ? NL : cnt);
+                    klo = lo < 0 ? lo + NL : lo;
+                }
+            }
+            // the pairs with a window, pushed together: lane r takes the r-th of them (the others push to lane 63, which only
+            // holds a pair when all 64 have a window)
+            const unsigned long long mw = __ballot(cnt > 0);
+            const int nw = __popcll(mw);
+            if (nw == 0) continue;
+            const int dst = (cnt > 0 ? pk_mbcnt(mw) : 63) << 2;
+            const float rec_ox = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(-(dx * cj + dy * sj))));
+            const float rec_oy = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(-(dy * cj - dx * sj))));
+            const float rec_cr = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(ci * cj + si * sj)));
+            const float rec_sr = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(ci * sj - si * cj)));
+            const int ck = __builtin_amdgcn_ds_permute(dst, cnt | (klo << 12) | (lp << 24));      // cnt <= 256 < 2^12, klo < 2^12, lp < 64
+            const int cnt_c = lane < nw ? (ck & 0xfff) : 0;
+            const int incl = wave_scan_incl<false>(cnt_c);
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            const int excl = incl - cnt_c;
+            // record word of the box tests: first ray - first test (16 bits, signed) | row offset of the fan's ray minima (lp * NL)
+            const int rec_ix = ((((ck >> 12) & 0xfff) - excl) & 0xffff) | (((ck >> 24) * NL) << 16);
+            int hb = -1;                              // (heads before this batch of tests) - 1
+            for (int t0 = 0; t0 < total; t0 += 64) {
+                seq += 1;
+                if (cnt_c > 0 && excl >= t0 && excl < t0 + 64) wtag[excl - t0] = seq;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const bool hd = wtag[lane] == seq;
+                const unsigned long long H = __ballot(hd);
+                const int own = hb + pk_mbcnt(H) + (hd ? 1 : 0);
+                hb += __popcll(H);
+                __builtin_amdgcn_wave_barrier();
+                const int sl = own << 2;
+                const float ox = __int_as_float(__builtin_amdgcn_ds_bpermute(sl, __float_as_int(rec_ox)));
+                const float oy = __int_as_float(__builtin_amdgcn_ds_bpermute(sl, __float_as_int(rec_oy)));
+                const float cr = __int_as_float(__builtin_amdgcn_ds_bpermute(sl, __float_as_int(rec_cr)));
+                const float sr = __int_as_float(__builtin_amdgcn_ds_bpermute(sl, __float_as_int(rec_sr)));
+                const int pw = __builtin_amdgcn_ds_bpermute(sl, rec_ix);
+                const int t = t0 + lane;
+                if (t < total) {
+                    int k = ((pw << 16) >> 16) + t;
+                    if (k >= NL) k -= NL;
+                    const float2 r = reinterpret_cast<const float2*>(rays)[k];
+                    const float tt = ray_box_nr(ox, oy, r.x * cr + r.y * sr, r.y * cr - r.x * sr, hl, hw);
+                    if (tt >= 0.0f) atomicMin(&best[(pw >> 16) + k], __float_as_uint(tt));
+                }
+            }
+        }
+        pk_wave_sync();
+        if (COPO_PROFILE_SKIP & 4) {
+        } else if (vec_out) {
+            for (int q = lane; q < cha * nvec; q += 64) {
+                const int lp = (int)(((float)q + 0.5f) * inv_nvec), k = head + 4 * (q - lp * nvec);
+                const unsigned int* b = best + lp * NL + k;
+                float4 v;
+                v.x = __uint_as_float(b[0]) * inv_range; v.y = __uint_as_float(b[1]) * inv_range;
+                v.z = __uint_as_float(b[2]) * inv_range; v.w = __uint_as_float(b[3]) * inv_range;
+                *reinterpret_cast<float4*>(eobs + (int)plist[ip0 + lp] * O + col_lidar + k) = v;
+            }
+            const int nsc = NL - 4 * nvec;
+            for (int q = lane; q < cha * nsc; q += 64) {
+                const int lp = (int)(((float)q + 0.5f) * inv_nsc), r = q - lp * nsc;
+                const int k = r < head ? r : r + 4 * nvec;
+                eobs[(int)plist[ip0 + lp] * O + col_lidar + k] = __uint_as_float(best[lp * NL + k]) * inv_range;
+            }
+        } else {
+            for (int q = lane; q < cha * NL; q += 64) {
+                const int lp = (int)(((float)q + 0.5f) * inv_nl), k = q - lp * NL;
+                eobs[(int)plist[ip0 + lp] * O + col_lidar + k] = __uint_as_float(best[q]) * inv_range;
+            }
+        }
+        if (ip0 + CH < np) pk_wave_sync();
+    }
+    // side / lane-line detector beams (Bottleneck, Tollgate): the ray minima are written out, their storage holds the line masks
+    detector_beams<false>(p, pose, plist, np, best, CH * NL, eobs, lane, 64);
+}
+
 
 }  // namespace copo

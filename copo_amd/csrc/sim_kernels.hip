@@ -341,8 +341,11 @@ __device__ __forceinline__ void neighbours_phase(const SimParams& p, EnvLds& L, 
 //  * global reward: added in slot order, which IS the reference's order.
 // K > 8, the communication block and the stateless op's filled rows take neighbours_phase as well.
 constexpr int NBR_EXACT_MAX = 6;
+// `reach_lo / reach_hi` (optional): the slots of the SOLID vehicles within LiDAR reach of this lane's slot, from the same walk (one more
+// compare on the d^2 it has anyway, the wrecks -- solid, not present -- in a short walk of their own); a superset test (1e-5 wider than
+// the LiDAR phase's own, which still decides every pair it is handed).
 __device__ __forceinline__ int neighbours_fast(const SimParams& p, EnvLds& L, int e, int lane, const StepOut& out, float4* rec,
-                                               int* n_exact) {
+                                               int* n_exact, unsigned int* reach_lo = nullptr, unsigned int* reach_hi = nullptr) {
     const int N = p.N, K = p.K;
     const unsigned long long present = L.m_present;
     const bool me = (present >> lane) & 1ull;
@@ -363,6 +366,11 @@ __device__ __forceinline__ int neighbours_fast(const SimParams& p, EnvLds& L, in
     double sum = 0.0, gs = 0.0;
     int cnt = 0;
     bool unc = false;
+    const bool want_reach = reach_lo != nullptr;
+    const unsigned long long solid = L.m_solid;
+    const float lim_r = p.lidar_range + sqrtf(p.hl * p.hl + p.hw * p.hw);
+    const float lim2 = lim_r * lim_r * 1.00001f;
+    unsigned int rlo = 0u, rhi = 0u;
     unsigned long long m = present;
     int j = m ? __ffsll((long long)m) - 1 : 0;              // wave-uniform
     float4 r = rec[j];
@@ -371,15 +379,17 @@ __device__ __forceinline__ int neighbours_fast(const SimParams& p, EnvLds& L, in
         const int jn = m ? __ffsll((long long)m) - 1 : j;
         const float4 rn = rec[jn];
         const double rj = __hiloint2double(__float_as_int(r.w), __float_as_int(r.z));
-        gs += rj;
         const float dx = xi - r.x, dy = yi - r.y;
         const float d2 = __builtin_fmaf(dy, dy, dx * dx);
         const bool other = j != lane;
         const bool in = other && d2 < r2lo, inhi = other && d2 < r2hi;
         unc |= in != inhi;
-        if (in) {
-            sum += rj;
-            cnt += 1;
+        sum = fma(in ? 1.0 : 0.0, rj, sum);      // (sum starts at +0.0 and rj is finite: the same bits as a guarded add)
+        cnt += in ? 1 : 0;
+        if (want_reach && ((solid >> j) & 1ull)) {
+            const unsigned int rb = (other && d2 <= lim2) ? 1u : 0u;
+            if (j < 32) rlo |= rb << j;
+            else rhi |= rb << (j - 32);
         }
         const uint32_t key = in ? ((__float_as_uint(d2) & ~63u) | (uint32_t)j) : NBR_SENT;
         a8 = umed3(a7, a8, key); a7 = umed3(a6, a7, key); a6 = umed3(a5, a6, key); a5 = umed3(a4, a5, key);
@@ -387,6 +397,29 @@ __device__ __forceinline__ int neighbours_fast(const SimParams& p, EnvLds& L, in
         a0 = a0 < key ? a0 : key;
         j = jn;
         r = rn;
+    }
+    if (want_reach) {
+        for (unsigned long long mw = solid & ~present; mw; mw &= mw - 1ull) {      // wrecks: solid, no agent
+            const int jw = __ffsll((long long)mw) - 1;
+            const float4 rw4 = rec[jw];
+            const float dx = xi - rw4.x, dy = yi - rw4.y;
+            const unsigned int rb = (jw != lane && __builtin_fmaf(dy, dy, dx * dx) <= lim2) ? 1u : 0u;
+            if (jw < 32) rlo |= rb << jw;
+            else rhi |= rb << (jw - 32);
+        }
+        *reach_lo = me ? rlo : 0u;
+        *reach_hi = me ? rhi : 0u;
+    }
+    // global reward (LCFEnv.step: sum(r.values()) / len(r.values()), fp64 in slot order): with every reward in the range where
+    // sums are exact in any order a DPP tree gives the slot order's bits; else the serial sum
+    if (out.glob_rew) {
+        if (odd == 0ull) {
+            gs = pk_wave_sum_f64(me ? (double)rw : 0.0);
+            gs = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(gs), 63), __builtin_amdgcn_readlane(__double2loint(gs), 63));
+            gs = 0.0 + gs;
+        } else {
+            for (unsigned long long mg = present; mg; mg &= mg - 1ull) gs += (double)readlane_f(rw, __ffsll((long long)mg) - 1);
+        }
     }
     // mean-field count from the keys (the 9 nearest), order check of adjacent keys
     const uint32_t ak[9] = {a0, a1, a2, a3, a4, a5, a6, a7, a8};
@@ -557,13 +590,15 @@ __device__ __forceinline__ unsigned long long neighbours_roles(const SimParams& 
 template <bool EXT>
 __device__ __forceinline__ void neighbours_any(const SimParams& p, EnvLds& L, int e, int tid, int nthreads, const StepOut& out,
                                                const float* __restrict__ act = nullptr, unsigned long long acted_mask = 0ull,
-                                               bool fresh = true) {
+                                               bool fresh = true, unsigned int* reach_lo = nullptr, unsigned int* reach_hi = nullptr,
+                                               bool* have_reach = nullptr) {
     // one wave owns the scene: the register formulation above, unless it declines (ties, band cases, odd rewards, K > 8, comm)
     const bool comm = EXT && p.col_comm >= 0 && out.obs != nullptr;
     if (nthreads == 64 && p.nbr_fast && !comm && !(COPO_PROFILE_SKIP & 128)) {
         extern __shared__ unsigned int dyn[];
         int n_exact = 0;
-        const int why = neighbours_fast(p, L, e, tid, out, reinterpret_cast<float4*>(dyn), &n_exact);
+        const int why = neighbours_fast(p, L, e, tid, out, reinterpret_cast<float4*>(dyn), &n_exact, reach_lo, reach_hi);
+        if (have_reach) *have_reach = reach_lo != nullptr;      // (the masks are complete whether or not the lists were declined)
         // profiling aid, which formulation ran: 1 register, 16 + n register with n agents evaluated exactly, 2 declined (pair-parallel)
         if (p.dbg && tid == 0) p.dbg[(size_t)e * COPO_DBG_STRIDE + 7] = why ? 2 : (n_exact ? 16 + n_exact : 1);
         if (why == 0) return;
@@ -796,23 +831,11 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
     }
     if (ip0 + CH < np) __syncthreads();           // the next pass reuses the minima
     }
-    // optional side / lane-line detector beams (Bottleneck, Tollgate): one thread per (present agent, beam)
-    const int nb = p.side_lasers + p.lane_lasers;
-    if ((PHASES & 4) && nb > 0) {
-        const float inv_nb = 1.0f / (float)nb;
-        for (int q = otid; q < np * nb; q += onth) {
-            const int ip = (int)(((float)q + 0.5f) * inv_nb), b = q - ip * nb;
-            const int i = L.plist[ip];
-            const bool side = b < p.side_lasers;
-            const int k = side ? b : b - p.side_lasers;
-            const float* tab = side ? p.side_cs : p.lane_cs;
-            const float a0 = tab[2 * k], b0 = tab[2 * k + 1];
-            const float ci = L.cs[i], si = L.sn[i];
-            const float dx = ci * a0 - si * b0, dy = si * a0 + ci * b0;
-            const float t = detector_ray(p, p.lines, L.x[i], L.y[i], dx, dy, side ? p.side_range : p.lane_range, side ? 2.0f : 1.0f);
-            eobs[i * O + (side ? k : p.col_lane + k)] = t * (side ? p.inv_side_range : p.inv_lane_range);
-        }
-    }
+    // optional side / lane-line detector beams (Bottleneck, Tollgate): the primitives near each agent are marked first, the beams walk only
+    // those (detector_beams, sim_device.h; its marks take the storage of the ray minima, which are written out).  Wave roles: waves
+    // 1 .. idle_n take no part in the write-out (they evaluate neighbour lists afterwards) but meet the barriers of the phase.
+    if (PHASES & 4)
+        detector_beams<true>(p, [&L](int v) { return make_float4(L.x[v], L.y[v], L.cs[v], L.sn[v]); }, L.plist, np, best, CH * NL, eobs, otid, onth);
 }
 
 __device__ __forceinline__ void stage_pose(EnvLds& L, int lane, const Slot& s) {
@@ -891,7 +914,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_reset_kernel(const Sim
 // ONE: the one-wave-per-scene launch shape as its own instantiation (workgroup = 64 threads known at compile time: the
 // wave-role branches fold away, workgroup barriers become wave-local, the register budget is that of a 64-thread kernel)
 template <bool EXT, bool ONE>
-__global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel(const SimParams* __restrict__ pp,
+__global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK, (ONE && !EXT) ? 7 : 1) sim_step_kernel(const SimParams* __restrict__ pp,
                                                                                  const float* __restrict__ act, StepOut out) {
     const SimParams& p = *pp;       // device-memory parameter block (see sim_reset_kernel)
     __shared__ EnvLds L;
@@ -970,6 +993,7 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
             }
             slot_dynamics<EXT>(p, act, (size_t)e * N + lane, s, acted, acc);
             stage_pose(L, lane, s);
+            if (ONE && st_status(s.status) == ST_EMPTY) L.x[lane] = 1.0e18f;      // (collision rows of P1: no vehicle here; P2 stages the pose again)
         } else {
             L.x[lane] = 0.0f; L.y[lane] = 0.0f; L.cs[lane] = 1.0f; L.sn[lane] = 0.0f;
         }
@@ -997,30 +1021,38 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
         const float near2 = 4.0f * (hl * hl + hw * hw) * 1.001f;   // farther apart than two circumradii: no overlap
         extern __shared__ unsigned int dyn[];
         const int qcap = 2 * lidar_lds_words(p.chunk, p.nbr_chunk, N, p.num_lasers);      // the LiDAR / neighbour work area is free here
-        if (nwaves == 1 && npair <= qcap && !(COPO_PROFILE_SKIP & 16)) {
-            // one wave owns the scene: the pairs closer than two circumradii (a few per vehicle in a queue of cars) are
-            // queued by a cheap pass and box-tested in full batches; the separating-axis test otherwise runs for a whole
-            // batch of 64 pairs as soon as one of them is close
+        if (ONE && (N * (N - 1)) / 2 <= qcap && !(COPO_PROFILE_SKIP & 16)) {
+            // one wave owns the scene: row r = 1 .. N / 2 pairs slot `lane` with slot (lane + r) mod N -- every UNORDERED pair once (the
+            // separating-axis test is symmetric bit for bit: exact negations, commutative products; the last row of an even N pairs
+            // every slot with its opposite, so its first half is all of it).  Slots without a vehicle stand at x = 1e18 (P0), so only
+            // the lane's own flag is tested.  The pairs closer than two circumradii are queued and box-tested together; the mark of a
+            // vehicle that did not act (a wreck) is never read.
             uint16_t* nq = reinterpret_cast<uint16_t*>(dyn);
             int nn = 0;
-            const unsigned long long lt = (1ull << lane) - 1ull;
-            for (int c0 = 0; c0 < npair; c0 += 64) {
-                const int c = c0 + lane;
-                const bool live = c < npair;
-                const int ia = live ? (int)(((float)c + 0.5f) * inv_nc) : 0;
-                const int i = L.alist[ia], j = L.clist[live ? c - ia * nc : 0];
-                const float ddx = L.x[j] - L.x[i], ddy = L.y[j] - L.y[i];
-                const bool near = live && (i != j) && (ddx * ddx + ddy * ddy <= near2);
+            const bool sol_me = (L.m_solid >> lane) & 1ull;
+            const float xme = L.x[lane], yme = L.y[lane];
+            const int R = N >> 1;
+            int jj = lane < N ? lane : 0;
+            for (int r = 1; r <= R; ++r) {
+                jj = jj + 1 == N ? 0 : jj + 1;
+                const float ddx = L.x[jj] - xme, ddy = L.y[jj] - yme;
+                const int lanes = (r == R && (N & 1) == 0) ? R : N;
+                const bool near = sol_me && lane < lanes && (ddx * ddx + ddy * ddy <= near2);
                 const unsigned long long m = __ballot(near);
-                if (near) nq[nn + __popcll(m & lt)] = (uint16_t)((i << 8) | j);
-                nn += __popcll(m);
+                if (m != 0ull) {
+                    if (near) nq[nn + pk_mbcnt(m)] = (uint16_t)((lane << 8) | jj);
+                    nn += __popcll(m);
+                }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            pk_wave_sync();
             for (int q0 = 0; q0 < nn; q0 += 64) {
-                const bool live = q0 + lane < nn;
-                const int pk = live ? (int)nq[q0 + lane] : 0, i = pk >> 8, j = pk & 255;
-                if (live && obb_overlap2(L.x[i], L.y[i], L.cs[i], L.sn[i], hl, hw, L.x[j], L.y[j], L.cs[j], L.sn[j], hl, hw)) L.crash[i] = 1;
+                if (q0 + lane < nn) {
+                    const int pk = (int)nq[q0 + lane], i = pk >> 8, j = pk & 255;
+                    if (obb_overlap2(L.x[i], L.y[i], L.cs[i], L.sn[i], hl, hw, L.x[j], L.y[j], L.cs[j], L.sn[j], hl, hw)) {
+                        L.crash[i] = 1;
+                        L.crash[j] = 1;
+                    }
+                }
             }
         } else
         for (int c0 = wave * 64; c0 < ((COPO_PROFILE_SKIP & 16) ? 0 : npair); c0 += nwaves * 64) {
@@ -1090,6 +1122,47 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
                     const unsigned long long solid_mask = __ballot(solid_now);
                     for (int q = 0; q < p.n_safe; ++q)
                         if ((spblk[q] & solid_mask) == 0ull) clear |= 1u << q;
+                } else if (ONE) {
+                    // one wave owns the scene: the (place, vehicle) pairs closer than the two circumradii are queued and box-tested
+                    // together (a box test per place ran for 64 lanes with one or two candidates among them)
+                    extern __shared__ unsigned int dyn[];
+                    uint16_t* bq = reinterpret_cast<uint16_t*>(dyn);
+                    const int bq_cap = 2 * lidar_lds_words(p.chunk, p.nbr_chunk, N, p.num_lasers) - 64;
+                    const float rr = sqrtf(p.region_hl * p.region_hl + p.region_hw * p.region_hw) + sqrtf(hl * hl + hw * hw);
+                    const float rr2 = rr * rr * 1.001f;
+                    uint32_t blocked = 0;
+                    int nbq = 0;
+                    auto flush = [&]() {
+                        pk_wave_sync();
+                        for (int q0 = 0; q0 < nbq; q0 += 64) {
+                            bool blk = false;
+                            int q = 0;
+                            if (q0 + lane < nbq) {
+                                const int ent = (int)bq[q0 + lane], n = ent & 255;
+                                q = ent >> 8;
+                                const float4 sp4 = reinterpret_cast<const float4*>(p.safe_pose)[q];
+                                blk = obb_overlap2(sp4.x, sp4.y, sp4.z, sp4.w, p.region_hl, p.region_hw, L.x[n], L.y[n], L.cs[n], L.sn[n], hl, hw);
+                            }
+                            for (unsigned long long mb = __ballot(blk); mb; mb &= mb - 1ull)
+                                blocked |= 1u << __builtin_amdgcn_readlane(q, __ffsll((long long)mb) - 1);
+                        }
+                        pk_wave_sync();
+                        nbq = 0;
+                    };
+                    for (int q = 0; q < p.n_safe; ++q) {
+                        const float4 sp4 = reinterpret_cast<const float4*>(p.safe_pose)[q];      // pose of respawn place q (host table)
+                        const float dx = s.x - sp4.x, dy = s.y - sp4.y;
+                        const bool pre = solid_now && (dx * dx + dy * dy <= rr2);
+                        const unsigned long long m = __ballot(pre);
+                        if (m != 0ull) {
+                            const int c = __popcll(m);
+                            if (nbq + c > bq_cap) flush();
+                            if (pre) bq[nbq + pk_mbcnt(m)] = (uint16_t)((q << 8) | lane);
+                            nbq += c;
+                        }
+                    }
+                    flush();
+                    clear = ~blocked & (p.n_safe >= 32 ? 0xffffffffu : ((1u << p.n_safe) - 1u));
                 } else
                 for (int q = 0; q < p.n_safe; ++q) {
                     const float4 sp4 = reinterpret_cast<const float4*>(p.safe_pose)[q];      // pose of respawn place q (host table)
@@ -1155,6 +1228,8 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
 
     COPO_STAMP(3);
     const bool roles = roles_ok && !ending;      // (a scene that resets this step: the neighbour lists need the poses BEFORE the reset, the LiDAR the ones after)
+    unsigned int reach_lo = 0u, reach_hi = 0u;   // one wave per scene: the solid vehicles within LiDAR reach of this lane's slot (from the neighbour walk)
+    bool have_reach = false;
     // ---- P3 (all waves): neighbour lists + reward reductions on the post-step (pre-reset) scene ---
     if (roles) {
         if (wave == 1) {
@@ -1174,7 +1249,8 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
             obs_phase<2>(p, L, e, tid, nthreads, out.obs, 3);
             COPO_ROLE_STAMP(10);
         }
-    } else if (!(COPO_PROFILE_SKIP & 1)) neighbours_any<EXT>(p, L, e, tid, nthreads, out, act, L.m_acted, ending);
+    } else if (!(COPO_PROFILE_SKIP & 1)) neighbours_any<EXT>(p, L, e, tid, nthreads, out, act, L.m_acted, ending,
+                                                             ONE ? &reach_lo : nullptr, ONE ? &reach_hi : nullptr, ONE ? &have_reach : nullptr);
     else __syncthreads();
     COPO_STAMP(4);
     // (neighbours_phase ends with a workgroup barrier: the reset below may overwrite the poses it read)
@@ -1239,6 +1315,15 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK) sim_step_kernel
             __syncthreads();        // work area that the ray minima no longer need
             neighbours_phase<EXT>(p, L, e, tid, nthreads, out, act, L.m_acted, ending);
         }
+    } else if (ONE && out.obs && have_reach && lidar_queue_words(p.chunk, N) > 0) {
+        // one wave owns the scene: the pair queue comes from the reach masks of the neighbour walk (a scene that reset has new poses:
+        // every solid vehicle is handed to the window pass, which tests the reach itself)
+        extern __shared__ unsigned int dyn[];
+        const int o_q = (p.chunk > 0 ? p.chunk : N) * p.num_lasers;
+        lidar_by_wave(p, [](int v) { return make_float4(L.x[v], L.y[v], L.cs[v], L.sn[v]); }, L.plist, reach_lo, reach_hi, dyn,
+                      reinterpret_cast<uint16_t*>(dyn + o_q), lds_rays(p),
+                      reinterpret_cast<int*>(dyn + lidar_lds_words(p.chunk, p.nbr_chunk, N, p.num_lasers) + ray_lds_words(p.num_lasers)), e, lane,
+                      L.m_present, L.m_solid, ending, out.obs);
     } else if (out.obs) obs_phase(p, L, e, tid, nthreads, out.obs);
     __syncthreads();
     COPO_STAMP(6);

@@ -75,219 +75,6 @@ struct RoadTabs {
     int32_t seg_rows;
 };
 
-__device__ __forceinline__ unsigned long long pk_u64(const unsigned int* w) { return *reinterpret_cast<const unsigned long long*>(w); }
-__device__ __forceinline__ void pk_wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-__device__ __forceinline__ int pk_mbcnt(unsigned long long m) {      // set bits of m below this lane
-    return (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
-}
-
-// wave sum of doubles on the DPP network (row shifts, then row broadcasts); the total arrives in lane 63.  Lanes without a source
-// add +0.0.  Only used where every partial sum is exact, so the order of the tree does not matter.
-__device__ __forceinline__ double pk_wave_sum_f64(double v) {
-#define COPO_DSUM_STEP(ctrl, rmask)                                                                             \
-    {                                                                                                           \
-        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, rmask, 0xf, false);              \
-        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, rmask, 0xf, false);              \
-        v = v + __hiloint2double(hi, lo);                                                                       \
-    }
-    COPO_DSUM_STEP(0x111, 0xf)
-    COPO_DSUM_STEP(0x112, 0xf)
-    COPO_DSUM_STEP(0x114, 0xf)
-    COPO_DSUM_STEP(0x118, 0xf)
-    COPO_DSUM_STEP(0x142, 0xa)
-    COPO_DSUM_STEP(0x143, 0xc)
-#undef COPO_DSUM_STEP
-    return v;
-}
-
-__device__ __forceinline__ unsigned long long pk_uni64(unsigned long long v) {      // a wave-uniform value, in scalar registers
-    return ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
-           (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)v);
-}
-
-// LiDAR of one scene by its wave: the pair-driven formulation of obs_phase (sim_kernels.hip) -- conservative ray window per (fan,
-// vehicle) pair, box tests numbered by a DPP scan, hits folded with LDS atomicMin -- with
-//   * the pair queue filled from the reach masks of the neighbour walk (no all-pairs reach pass);
-//   * the pairs with a non-empty window pushed together (ds_permute) before their box tests are numbered: the owner of box test t
-//     is then simply pair number (heads before this batch) + (heads at or before t in it) - 1, a ballot of the head flags and a
-//     v_mbcnt instead of a DPP max-scan per batch of tests; the head flags carry the batch's sequence number, so the strip is
-//     never cleared;
-//   * the pair record holding the ray-minima row offset (lp * NL) next to the first ray, so a box test multiplies nothing;
-//   * the hit distance through div_nr (sim_device.h).
-// `present` / `solid`: the scene after the step (after a reset, if it reset).
-__device__ __forceinline__ void pk_lidar(const SimParams& p, const PkLay& Y, unsigned int* sc, const float* __restrict__ rays, int* wtag,
-                                         int e, int lane, unsigned long long present_in, unsigned long long solid_in, bool all_reach_in,
-                                         float* __restrict__ obs) {
-    const unsigned long long present = pk_uni64(present_in), solid = pk_uni64(solid_in);
-    const bool all_reach = __builtin_amdgcn_readfirstlane(all_reach_in ? 1 : 0) != 0;
-    const int N = p.N, O = p.O, NL = p.num_lasers;
-    const float4* pose = reinterpret_cast<const float4*>(sc);
-    uint8_t* plist = reinterpret_cast<uint8_t*>(sc + Y.o_plist);
-    const unsigned int* reach = sc + Y.o_reach;
-    unsigned int* best = sc + Y.o_u;
-    uint16_t* cq = reinterpret_cast<uint16_t*>(sc + Y.o_queue);
-    const float hl = p.hl, hw = p.hw;
-    const float circ = sqrtf(hl * hl + hw * hw);
-    const float range = p.lidar_range;
-    const float lim = range + circ;
-    const int np = __popcll(present);
-    const unsigned int range_bits = __float_as_uint(range);
-    float* eobs = obs + (size_t)e * N * O;
-    const int CH = p.chunk > 0 ? p.chunk : N;
-    const float rays_per_rad = (float)NL * 0.159154943f;
-    const float inv_nl = 1.0f / (float)NL;
-    const float inv_range = p.inv_range;
-    const int col_lidar = p.col_lidar;
-    const int head = (4 - (col_lidar & 3)) & 3;
-    const int nvec = (NL - head) >> 2;
-    const bool vec_out = ((O & 3) == 0) && nvec > 0 && ((reinterpret_cast<uintptr_t>(obs) & 15) == 0);
-    const float inv_nvec = 1.0f / (float)(nvec > 0 ? nvec : 1), inv_nsc = 1.0f / (float)(NL - 4 * nvec > 0 ? NL - 4 * nvec : 1);
-    if (__builtin_amdgcn_inverse_ballot_w64(present)) plist[pk_mbcnt(present)] = (uint8_t)lane;
-    wtag[lane] = 0;
-    int seq = 0;                      // sequence number of the box-test batches of this wave (head flags)
-    pk_wave_sync();
-    for (int ip0 = 0; ip0 < np; ip0 += CH) {
-        const int cha = np - ip0 < CH ? np - ip0 : CH;
-        for (int q = lane; q < cha * NL; q += 64) best[q] = range_bits;
-        // pair queue of this chunk of fans, from their reach masks
-        int nq = 0;
-        {
-            unsigned int rlo = 0u, rhi = 0u;
-            if (lane < cha) {
-                const int i = plist[ip0 + lane];
-                rlo = reach[2 * i];
-                rhi = reach[2 * i + 1];
-            }
-            for (int lp = 0; lp < ((COPO_PROFILE_SKIP & 2048) ? 0 : cha); ++lp) {
-                const unsigned long long m = all_reach ? solid
-                                                       : (((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)rhi, lp) << 32) |
-                                                          (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)rlo, lp)) & solid;
-                if (__builtin_amdgcn_inverse_ballot_w64(m)) cq[nq + pk_mbcnt(m)] = (uint16_t)((lp << 8) | lane);
-                nq += __popcll(m);
-            }
-        }
-        pk_wave_sync();
-        for (int q0 = 0; q0 < ((COPO_PROFILE_SKIP & 2) ? 0 : nq); q0 += 64) {
-            const bool live = q0 + lane < nq;
-            const int ent = live ? (int)cq[q0 + lane] : 0;
-            const int lp = ent >> 8, j = ent & 255;
-            const int i = plist[ip0 + lp];
-            const float4 pi = pose[i], pj = pose[j];
-            const float ci = pi.z, si = pi.w, cj = pj.z, sj = pj.w;
-            const float dx = pj.x - pi.x, dy = pj.y - pi.y;
-            const float d2 = dx * dx + dy * dy;
-            int klo = 0, cnt = 0;
-            if (live && j != i && !(d2 > lim * lim)) {
-                if (d2 <= circ * circ * 1.002f) {
-                    cnt = NL;                         // origin inside the circumcircle: any ray may hit
-                } else {
-                    const float phi = p.ray_sign * atan2_window(ci * dy - si * dx, ci * dx + si * dy);   // in beam-index direction
-                    const float rd = __builtin_amdgcn_rsqf(d2);
-                    const float x = circ * rd;
-                    float w = x + 0.5708f * x * x * x;                    // >= asin(circumradius / distance)
-                    const float ux = dx * rd, uy = dy * rd;
-                    const float ca = fabsf(cj * ux + sj * uy), sa = fabsf(cj * uy - sj * ux);
-                    const float h_perp = hl * sa + hw * ca, along = d2 * rd - (hl * ca + hw * sa);
-                    if (along > 0.5f) w = fminf(w, h_perp * __builtin_amdgcn_rcpf(along) * 1.0001f);
-                    w += 0.004f;                                          // margin over the approximations above (< 1e-4 rad)
-                    const int lo = (int)ceilf((phi - w) * rays_per_rad), hi = (int)floorf((phi + w) * rays_per_rad);
-                    cnt = hi - lo + 1;
-                    cnt = cnt < 0 ? 0 : (cnt > NL ? NL : cnt);
-                    klo = lo < 0 ? lo + NL : lo;
-                }
-            }
-            // the pairs with a window, pushed together: lane r takes the r-th of them (the others push to lane 63, which only
-            // holds a pair when all 64 have a window)
-            const unsigned long long mw = __ballot(cnt > 0);
-            const int nw = __popcll(mw);
-            if (nw == 0) continue;
-            const int dst = (cnt > 0 ? pk_mbcnt(mw) : 63) << 2;
-            const float rec_ox = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(-(dx * cj + dy * sj))));
-            const float rec_oy = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(-(dy * cj - dx * sj))));
-            const float rec_cr = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(ci * cj + si * sj)));
-            const float rec_sr = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(ci * sj - si * cj)));
-            const int ck = __builtin_amdgcn_ds_permute(dst, cnt | (klo << 12) | (lp << 24));      // cnt <= 256 < 2^12, klo < 2^12, lp < 64
-            const int cnt_c = lane < nw ? (ck & 0xfff) : 0;
-            const int incl = wave_scan_incl<false>(cnt_c);
-            const int total = __builtin_amdgcn_readlane(incl, 63);
-            const int excl = incl - cnt_c;
-            // record word of the box tests: first ray - first test (16 bits, signed) | row offset of the fan's ray minima (lp * NL)
-            const int rec_ix = ((((ck >> 12) & 0xfff) - excl) & 0xffff) | (((ck >> 24) * NL) << 16);
-            int hb = -1;                              // (heads before this batch of tests) - 1
-            for (int t0 = 0; t0 < total; t0 += 64) {
-                seq += 1;
-                if (cnt_c > 0 && excl >= t0 && excl < t0 + 64) wtag[excl - t0] = seq;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                const bool hd = wtag[lane] == seq;
-                const unsigned long long H = __ballot(hd);
-                const int own = hb + pk_mbcnt(H) + (hd ? 1 : 0);
-                hb += __popcll(H);
-                __builtin_amdgcn_wave_barrier();
-                const int sl = own << 2;
-                const float ox = __int_as_float(__builtin_amdgcn_ds_bpermute(sl, __float_as_int(rec_ox)));
-                const float oy = __int_as_float(__builtin_amdgcn_ds_bpermute(sl, __float_as_int(rec_oy)));
-                const float cr = __int_as_float(__builtin_amdgcn_ds_bpermute(sl, __float_as_int(rec_cr)));
-                const float sr = __int_as_float(__builtin_amdgcn_ds_bpermute(sl, __float_as_int(rec_sr)));
-                const int pw = __builtin_amdgcn_ds_bpermute(sl, rec_ix);
-                const int t = t0 + lane;
-                if (t < total) {
-                    int k = ((pw << 16) >> 16) + t;
-                    if (k >= NL) k -= NL;
-                    const float2 r = reinterpret_cast<const float2*>(rays)[k];
-                    const float tt = ray_box_nr(ox, oy, r.x * cr + r.y * sr, r.y * cr - r.x * sr, hl, hw);
-                    if (tt >= 0.0f) atomicMin(&best[(pw >> 16) + k], __float_as_uint(tt));
-                }
-            }
-        }
-        pk_wave_sync();
-        if (COPO_PROFILE_SKIP & 4) {
-        } else if (vec_out) {
-            for (int q = lane; q < cha * nvec; q += 64) {
-                const int lp = (int)(((float)q + 0.5f) * inv_nvec), k = head + 4 * (q - lp * nvec);
-                const unsigned int* b = best + lp * NL + k;
-                float4 v;
-                v.x = __uint_as_float(b[0]) * inv_range; v.y = __uint_as_float(b[1]) * inv_range;
-                v.z = __uint_as_float(b[2]) * inv_range; v.w = __uint_as_float(b[3]) * inv_range;
-                *reinterpret_cast<float4*>(eobs + (int)plist[ip0 + lp] * O + col_lidar + k) = v;
-            }
-            const int nsc = NL - 4 * nvec;
-            for (int q = lane; q < cha * nsc; q += 64) {
-                const int lp = (int)(((float)q + 0.5f) * inv_nsc), r = q - lp * nsc;
-                const int k = r < head ? r : r + 4 * nvec;
-                eobs[(int)plist[ip0 + lp] * O + col_lidar + k] = __uint_as_float(best[lp * NL + k]) * inv_range;
-            }
-        } else {
-            for (int q = lane; q < cha * NL; q += 64) {
-                const int lp = (int)(((float)q + 0.5f) * inv_nl), k = q - lp * NL;
-                eobs[(int)plist[ip0 + lp] * O + col_lidar + k] = __uint_as_float(best[q]) * inv_range;
-            }
-        }
-        if (ip0 + CH < np) pk_wave_sync();
-    }
-    // side / lane-line detector beams (Bottleneck, Tollgate): one lane per (present agent, beam)
-    const int nb = p.side_lasers + p.lane_lasers;
-    if (nb > 0) {
-        const float inv_nb = 1.0f / (float)nb;
-        for (int q = lane; q < np * nb; q += 64) {
-            const int ip = (int)(((float)q + 0.5f) * inv_nb), b = q - ip * nb;
-            const int i = plist[ip];
-            const bool side = b < p.side_lasers;
-            const int k = side ? b : b - p.side_lasers;
-            const float* tab = side ? p.side_cs : p.lane_cs;
-            const float a0 = tab[2 * k], b0 = tab[2 * k + 1];
-            const float4 pi = pose[i];
-            const float dx = pi.z * a0 - pi.w * b0, dy = pi.w * a0 + pi.z * b0;
-            const float t = detector_ray(p, p.lines, pi.x, pi.y, dx, dy, side ? p.side_range : p.lane_range, side ? 2.0f : 1.0f);
-            eobs[i * O + (side ? k : p.col_lane + k)] = t * (side ? p.inv_side_range : p.inv_lane_range);
-        }
-    }
-}
-
 __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_packed_kernel(const SimParams* __restrict__ pp, const float* __restrict__ act,
                                                                              StepOut out) {
     const SimParams& p = *pp;
@@ -542,13 +329,14 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_packed_kernel(con
         float rw = 0.0f;
         if (lane < N) {
             const float lim = p.lidar_range + sqrtf(hl * hl + hw * hw);
+            const float lim2 = lim * lim * 1.00001f;      // (a superset test: the window pass decides every pair it is handed itself)
             reinterpret_cast<float4*>(sc + Y.o_u)[lane] = make_float4(ps.x, ps.y, pres ? p.nbr_r2lo : 0.0f, pres ? p.nbr_r2hi : 0.0f);
             float4* r1 = reinterpret_cast<float4*>(sc + Y.o_rec1) + lane;
             if (b1 & 1) {
                 rw = r1->w;
-                r1->z = sol ? lim * lim : -1.0f;
+                r1->z = sol ? lim2 : -1.0f;
             } else {
-                *r1 = make_float4(0.0f, 0.0f, sol ? lim * lim : -1.0f, 0.0f);
+                *r1 = make_float4(0.0f, 0.0f, sol ? lim2 : -1.0f, 0.0f);
             }
         }
         const float arw = fabsf(rw);
@@ -760,7 +548,10 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_packed_kernel(con
             unsigned long long fp = mp, fs = ms;
             if (ending) fp = fs = (cap >= 64 ? ~0ull : ((1ull << cap) - 1ull));
             pk_wave_sync();          // (the ray minima reuse the walk records the exact evaluation just read)
-            pk_lidar(p, Y, sc, rays, reinterpret_cast<int*>(dyn + o_wtag) + wave * 64, e, lane, fp, fs, ending, out.obs);
+            const float4* pose4 = reinterpret_cast<const float4*>(sc);
+            const unsigned int rl = lane < N ? sc[Y.o_reach + 2 * lane] : 0u, rh = lane < N ? sc[Y.o_reach + 2 * lane + 1] : 0u;
+            lidar_by_wave(p, [pose4](int v) { return pose4[v]; }, reinterpret_cast<uint8_t*>(sc + Y.o_plist), rl, rh, sc + Y.o_u,
+                          reinterpret_cast<uint16_t*>(sc + Y.o_queue), rays, reinterpret_cast<int*>(dyn + o_wtag) + wave * 64, e, lane, fp, fs, ending, out.obs);
         }
     }
     PK_STAMP(6);
