@@ -153,9 +153,13 @@ def measure_sim_kernel_saturated(trainer, scenes=16384, launches=60, policy="cru
     actions of a lane-keeping controller, recorded closed-loop and replayed from the saved state so that the timed loop
     holds nothing but simulator launches; `random`: N(0, 0.1) steering / U(0, 1) throttle as in round 1."""
     from copo_amd.sim import SimConfig, VecSim
-    src = trainer.env.sim
-    sim = VecSim(SimConfig(map=src.cfg.map, num_envs=scenes, num_agents=src.N, num_lasers=src.cfg.num_lasers,
-                           enable_lcf=src.cfg.enable_lcf), with_info=False)
+    if isinstance(trainer, dict):      # a named configuration (config legs): SimConfig keywords
+        sim = VecSim(SimConfig(num_envs=scenes, **trainer), with_info=False)
+    else:
+        src = trainer.env.sim
+        sim = VecSim(SimConfig(map=src.cfg.map, num_envs=scenes, num_agents=src.N, num_lasers=src.cfg.num_lasers,
+                               enable_lcf=src.cfg.enable_lcf), with_info=False)
+    measure_sim_kernel_saturated.last = dict(O=sim.O, N=sim.N, block=int(getattr(sim, "block", 0) or 0))
     out = sim.reset()
     gen = torch.Generator(device=sim.device).manual_seed(1)
     if policy == "cruise":
@@ -193,7 +197,7 @@ def kernel_source_hash():
     import hashlib
     import re
     h = hashlib.sha1()
-    for f in ("sim_kernels.hip", "sim_common.h", "sim_math.h"):
+    for f in ("sim_kernels.hip", "sim_packed.hip", "sim_device.h", "sim_common.h", "sim_math.h"):
         with open(os.path.join(ROOT, "copo_amd", "csrc", f), "r") as fh:
             text = re.sub(r"//[^\n]*", "", fh.read())
         h.update("".join(text.split()).encode())
@@ -277,6 +281,12 @@ def measure_phases(trainer, iters=4):
             "iteration_ms": round(ms.get("iteration", 0.0), 3), "agent_steps_per_iter": round(rows, 1),
             "sample_throughput": round(rows / max(ms.get("sample", 0.0), 1e-9) * 1e3, 1),
             "learn_throughput": round(rows / max(learn, 1e-9) * 1e3, 1), "unit": "agent-steps/s (phase alone, synchronised)"}
+
+
+def _capi_build_info():
+    """What the loaded libcopo_hip.so says about itself (copo_build_info: ABI, profiling mask, environment variables it reads)."""
+    from copo_amd import _capi
+    return _capi.lib.copo_build_info().decode("utf-8", "replace")
 
 
 def cpu_baseline(num_envs, num_agents, iters=1):
@@ -417,7 +427,10 @@ def cpu_baseline_all_cores(num_envs, num_agents, iters=1):
     best_t = None
     agent_steps, t0 = 0, time.perf_counter()
     t_cal = 0.0
-    for _ in range(iters):
+    split = {"sample_s": 0.0, "postprocess_s": 0.0, "sgd_s": 0.0, "meta_s": 0.0}      # where the host's iteration goes (the learner: a
+    for _ in range(iters):                                                             # chain of 750 dependent 512-row steps)
+        t_iter0 = time.perf_counter()
+        t_cal_iter = 0.0
         buf = dict(obs=torch.zeros(T, E, N, O), act=torch.zeros(T, E, N, 2), logp=torch.zeros(T, E, N), di=torch.zeros(T, E, N, 4),
                    rew3=np.zeros((3, T, E, N), np.float32), flags=np.zeros((T, E, N), np.uint8), lcf=np.zeros((T, E, N), np.float32))
         for t in range(T):
@@ -428,6 +441,7 @@ def cpu_baseline_all_cores(num_envs, num_agents, iters=1):
             buf["rew3"][2, t] = out["glob_rew"][:, None]
             buf["flags"][t], buf["lcf"][t] = out["flags"], out["lcf"]
             obs = torch.from_numpy(out["obs"])
+        t_sample_end = time.perf_counter()
         M = E * N
         vals = pol.value_heads_dense(buf["obs"].view(T * M, O)).view(3, T, M).numpy()
         adv, tgt = ol.gae3(buf["rew3"].reshape(3, T, M), vals, buf["flags"].reshape(T, M), pol.gae_gammas(), 0.95)
@@ -454,31 +468,41 @@ def cpu_baseline_all_cores(num_envs, num_agents, iters=1):
             # (the 8 threads of the plain variant unless another count is clearly -- 15 % -- faster over six real steps: on the
             #  256-thread hosts of the pool 32 threads won a three-step calibration and lost the whole learner phase by 2x)
             times = {}
-            for cand in (CPU_BASELINE_THREADS, 4, 16):
+            for cand in (CPU_BASELINE_THREADS, 4, 16, 32, 64, 128, 256):      # (round-4 review: the whole range of the host, not 4 .. 16)
                 if cand > host:
                     continue
                 torch.set_num_threads(cand)
                 pol._row_sources["k"].zero_()
-                for _ in range(2):
+                for _ in range(3):
                     pol._sgd_step_local()
                 ts = time.perf_counter()
-                for _ in range(6):
+                for _ in range(10):
                     pol._sgd_step_local()
-                times[cand] = (time.perf_counter() - ts) / 6
+                times[cand] = (time.perf_counter() - ts) / 10
+            split["learner_thread_sweep_ms_per_step"] = {str(k): round(v * 1e3, 2) for k, v in sorted(times.items())}
             best_t = min(CPU_BASELINE_THREADS, host)
             for cand, dts in times.items():
                 if dts < 0.85 * times.get(best_t, float("inf")):
                     best_t = cand
-            t_cal += time.perf_counter() - tc
+            t_cal_iter = time.perf_counter() - tc
+            t_cal += t_cal_iter
         torch.set_num_threads(best_t)
+        split["sample_s"] += t_sample_end - t_iter0
+        t1 = time.perf_counter()
+        split["postprocess_s"] += t1 - t_sample_end - t_cal_iter
         pol.run_sgd(idx, B, [B], 512, 5)
+        t2 = time.perf_counter()
         pol.run_meta(idx, B, [B], 512, 5)
         pol.update_old_policy()
+        t3 = time.perf_counter()
+        split["sgd_s"] += t2 - t1
+        split["meta_s"] += t3 - t2
         agent_steps += B
     dt = time.perf_counter() - t0 - t_cal
     wk.close()
     torch.set_num_threads(prev_threads)
-    return agent_steps / dt, dt, agent_steps, best_w, best_t
+    split = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in split.items()}
+    return agent_steps / dt, dt, agent_steps, best_w, best_t, split
 
 
 def live_reference(seconds=20.0):
@@ -627,6 +651,10 @@ def main():
     ap.add_argument("--roofline-only", action="store_true",
                     help="warm-up iterations, then ONLY the live simulator-kernel measurement (recorded replay on the trainer's scenes) "
                          "and one small JSON line: the command scripts/sim_traffic.sh runs under rocprofv3 --pmc")
+    ap.add_argument("--config-leg", default=None, choices=["c3", "c4", "c5"],
+                    help="ONLY the simulator step kernel on another BASELINE configuration (c3 Roundabout 40 slots, c4 Tollgate 40 slots / "
+                         "O = 156, c5 ParkingLot 10 slots / 240 beams / O = 260): populated scenes (lane-keeping controller, recorded replay) at "
+                         "the configuration's own scene count per GPU and at 16 384 scenes; one JSON line each (scripts/prof_sim_round.sh)")
     ap.add_argument("--saturated-only", action="store_true",
                     help="ONLY the saturated simulator-kernel measurement (16 384 populated scenes, recorded replay) and one small "
                          "JSON line: the command scripts/prof_sim_r03.sh profiles")
@@ -654,6 +682,21 @@ def main():
         sys.exit("bench.py: rank %d wants GPU %d, this node answers with %d device(s) -- not falling back to fewer GPUs"
                  % (rank, local_rank, torch.cuda.device_count() if torch.cuda.is_available() else 0))
     torch.cuda.set_device(local_rank)
+    if args.config_leg:
+        legs = {"c3": (dict(map="roundabout", num_agents=40), (128, 1024, 16384)),
+                "c4": (dict(map="tollgate", num_agents=40), (512, 16384)),
+                "c5": (dict(map="parkinglot", num_agents=10, num_lasers=240), (4096, 16384))}
+        kw, sizes = legs[args.config_leg]
+        for scenes in sizes:
+            k_s, present, slots = measure_sim_kernel_saturated(kw, scenes=scenes, launches=60, policy="cruise")
+            O = measure_sim_kernel_saturated.last["O"]
+            bpu = 202 + 4 * O
+            print(json.dumps({"kernel": "copo::sim_step_kernel / sim_step_packed_kernel", "config": args.config_leg, "sim": kw, "scenes": scenes,
+                              "launches": 60, "us_per_launch": round(k_s * 1e6, 2), "present_slots": round(present), "slots": slots,
+                              "obs_dim": O, "bytes_per_unit": bpu, "achieved_GBps": round(present * bpu / k_s * 1e-9, 1),
+                              "frac": round(present * bpu / k_s * 1e-9 / HBM_PEAK_GBPS, 4)}), flush=True)
+        D.shutdown()
+        return
     trainer = make_trainer(args.num_envs, args.num_agents, graphs=not args.no_graphs, pretrained=not args.untrained)
     if args.saturated_only:
         sat_s, sat_present, sat_slots = measure_sim_kernel_saturated(trainer, policy="cruise")
@@ -712,8 +755,7 @@ def main():
         torch.cuda.synchronize()
         coll = {"allreduce_grad_us": round(e0.elapsed_time(e1) * 1e3 / 50, 2), "bucket_bytes": 4 * n,
                 "backend": td.get_backend(), "per": "SGD minibatch (one per optimizer step)",
-                "steps_per_graph": int(getattr(trainer.policy, "_dist_chain_len", 0)),      # 16: [gradient pass, all-reduce, Adam] chains captured (start-up probe passed)
-                "peer_allreduce": getattr(trainer.policy, "_peer", None) is not None}
+                "used_by": "the RCCL loop only (dp_step = 'rccl'); the tile exchange sums inside the weight-gradient kernel"}
 
     line = None
     if rank == 0:
@@ -766,13 +808,12 @@ def main():
                        "policy_init": "random" if args.untrained else "reference population copo_inter (tests/golden, weights as data)",
                        # tuning knobs the product path reads from the environment (they skip no work): recorded, not hidden
                        "knobs": {"COPO_SGD_CHAIN": int(getattr(trainer.policy, "SGD_CHAIN", 0)),
-                                 "COPO_DIST_CHAIN": int(getattr(trainer.policy, "_dist_chain_len", 0) or 0),
                                  "COPO_FORCE_DIST": os.environ.get("COPO_FORCE_DIST", "0"),
-                                 "COPO_PEER_ALLREDUCE": os.environ.get("COPO_PEER_ALLREDUCE", "0"),
                                  "COPO_DP_EXCHANGE": os.environ.get("COPO_DP_EXCHANGE", "auto")},
                        # how the data-parallel SGD step sums its gradients: "tile" = inside the weight-gradient kernel
                        # (peer stores over xGMI), "rccl" = all-reduce + flat Adam; None = one process
-                       "dp_step": getattr(trainer.policy, "_dp_mode", None)},
+                       "dp_step": getattr(trainer.policy, "_dp_mode", None),
+                       "dp_step_reason": getattr(trainer.policy, "dp_reason", None)},
             "roofline": {"bound": "hbm", "kernel": "copo::sim_step_kernel", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                          "traffic": traffic, "traffic_units_per_launch": traffic_units,
@@ -793,7 +834,7 @@ def main():
                          "timing": "HIP events around back-to-back launches on the launch stream; rocprofv3 --kernel-trace reports "
                                    "~10 % longer per-kernel durations at 16 384 scenes because traced dispatches do not overlap "
                                    "the previous launch's drain with their own ramp-up",
-                         "library_build": "shipped libcopo_hip.so: no environment knobs, all phases compiled in"},
+                         "library_build": _capi_build_info()},
         }
         if valu is not None:
             # peak: 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction (MI355X_MICROARCH.md); issued: this launch's
@@ -824,7 +865,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             v, cdt, n, used = cpu_baseline(args.num_envs, args.num_agents)
             host = os.cpu_count() or 1
-            va, adt, an, aw, at = cpu_baseline_all_cores(args.num_envs, args.num_agents)
+            va, adt, an, aw, at, asplit = cpu_baseline_all_cores(args.num_envs, args.num_agents)
             sim1 = cpu_sim_only(args.num_agents, 1)
             simn = cpu_sim_only(args.num_agents, host)
             line["cpu_baseline"] = {"value": round(v, 1), "unit": "agent-steps/s", "cores": used, "kind": "port",
@@ -834,7 +875,8 @@ def main():
                                     "all_cores": {"value": round(va, 1), "unit": "agent-steps/s", "sim_threads": aw, "learner_threads": at,
                                                   "sample": "the same iteration (%d agent-steps, %.1f s): one C oracle instance per host thread "
                                                             "for the scenes, batched torch inference, torch learner at its fastest thread "
-                                                            "count for 512-row minibatches" % (an, adt)},
+                                                            "count for 512-row minibatches (swept over 4 .. all host threads)" % (an, adt),
+                                                  "split": asplit},
                                     "sim_only": {"threads_1": round(sim1, 1), "threads_%d" % host: round(simn, 1),
                                                  "unit": "agent-steps/s, simulator half alone (C oracle, one instance per thread)"},
                                     "live_reference": live_reference(),

@@ -2,7 +2,7 @@
 oracle's loader (tests/oracle_lib.py).  Importing this module loads no native code."""
 import ctypes as C
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_AGENTS = 64
 MAX_SEGS = 16
 SEG_STRIDE = 16

@@ -93,7 +93,7 @@ _SIGS = {
     "copo_meta_fold_len": (C.c_int64, [C.POINTER(PpoCfg)]),
     "copo_meta_batch_workspace_floats": (C.c_int64, [C.POINTER(PpoCfg), C.c_int32]),
     "copo_meta_batch_grads_f32": (C.c_int, [C.POINTER(PpoCfg)] + [C.c_void_p] * 8 + [C.c_int32, C.c_int64, C.c_int32] + [C.c_void_p] * 4),
-    "copo_meta_batch_dot_f64": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "copo_meta_batch_dot_f64": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "copo_meta_rows_workspace_floats": (C.c_int64, [C.POINTER(PpoCfg), C.c_int64]),
     "copo_meta_rows_f32": (C.c_int, [C.POINTER(PpoCfg)] + [C.c_void_p] * 4 + [C.c_int64] + [C.c_void_p] * 3),
     "copo_meta_batch_wgrads_f32": (C.c_int, [C.POINTER(PpoCfg)] + [C.c_void_p] * 5 + [C.c_int64] + [C.c_void_p] * 2 +
@@ -102,6 +102,7 @@ _SIGS = {
     "copo_meta_batch_lcf_f64": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32] +
                                 [C.c_void_p] * 3 + [C.c_int32, C.c_int32] + [C.c_void_p] * 5 + [C.c_double, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "copo_version": (C.c_int, []),
+    "copo_build_info": (C.c_char_p, []),
     "copo_last_error": (C.c_char_p, []),
     "copo_sim_create": (C.c_int, [C.POINTER(SimCfg), C.c_int, C.POINTER(C.c_void_p)]),
     "copo_sim_destroy": (C.c_int, [C.c_void_p]),

@@ -41,6 +41,16 @@ struct copo_sim {
 };
 
 extern "C" int copo_version(void) { return COPO_ABI_VERSION; }
+#define COPO_STR2(x) #x
+#define COPO_STR(x) COPO_STR2(x)
+extern "C" const char* copo_build_info(void) {
+#ifdef COPO_PROFILE_SKIP
+    return "libcopo_hip ABI " COPO_STR(COPO_ABI_VERSION) ", gfx950, PROFILING build (COPO_PROFILE_SKIP=" COPO_STR(COPO_PROFILE_SKIP)
+           "): phases may be compiled out, results may be wrong; reads COPO_ROWPASS_4X4 COPO_ROWPASS_RT8 COPO_WGRAD_OT COPO_FUSED_WGRAD COPO_FUSED_ROWPASS COPO_RP_DBG";
+#else
+    return "libcopo_hip ABI " COPO_STR(COPO_ABI_VERSION) ", gfx950, shipped build: all phases compiled in, no environment variable is read";
+#endif
+}
 extern "C" const char* copo_last_error(void) { return g_err; }
 
 template <typename T>

@@ -622,13 +622,14 @@ extern "C" int copo_meta_rowstat_f32(const copo_ppo_cfg* cfg, const int64_t* row
     return hipGetLastError() == hipSuccess ? COPO_OK : COPO_ERR_DEVICE;
 }
 
-extern "C" int copo_meta_batch_dot_f64(const float* g, int64_t n, int32_t nb, double* gv_out, const float* denom, void* stream) {
+extern "C" int copo_meta_batch_dot_f64(const float* g, int64_t n, int32_t nb, double* gv_out, const float* denom, double* partials,
+                                       void* stream) {
     if (!g || !gv_out) return COPO_ERR_NULL;
     if (n < 1 || nb < 1) return COPO_ERR_DIM;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (nb <= DOT_MAX_NB) {
-        hipLaunchKernelGGL(meta_batch_dot_part_kernel, dim3(nb, DOT_SPLIT), dim3(512), 0, st, g, n);
-        hipLaunchKernelGGL(meta_batch_dot_fin_kernel, dim3((nb + 63) / 64), dim3(64), 0, st, nb, gv_out, denom);
+    if (partials && nb <= 65535) {      // grid (nb, COPO_META_DOT_SPLIT) fills the chip; the partials meet in the caller's buffer
+        hipLaunchKernelGGL(meta_batch_dot_part_kernel, dim3(nb, DOT_SPLIT), dim3(512), 0, st, g, n, partials);
+        hipLaunchKernelGGL(meta_batch_dot_fin_kernel, dim3((nb + 63) / 64), dim3(64), 0, st, nb, gv_out, denom, partials);
     } else {
         hipLaunchKernelGGL(meta_batch_dot_kernel, dim3(nb), dim3(1024), 0, st, nullptr, g, n, gv_out, denom);
     }

@@ -113,37 +113,6 @@ def barrier():
         td.barrier()
 
 
-def probe_graphed_allreduce(timeout=90.0):
-    """True if EVERY rank could capture and replay a hipGraph that holds an RCCL all-reduce -- checked in a child process per
-    rank (copo_amd/dist_probe.py, its own process group on MASTER_PORT + 17), so that a hang costs `timeout` seconds and a
-    killed child instead of the job.  The trainer then captures [gradient pass, all-reduce, Adam] chains like the local ones
-    (one graph launch per 16 optimizer steps instead of three host calls per step)."""
-    import subprocess
-    import sys
-    if not (td.is_available() and td.is_initialized() and torch.cuda.is_available()):
-        return False
-    if td.get_backend() != "nccl" or os.environ.get("COPO_DIST_PROBE", "1") == "0":
-        return False
-    env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 17))
-    env.pop("COPO_FORCE_DIST", None)
-    env.pop("TORCHELASTIC_USE_AGENT_STORE", None)      # under torchrun: the child's rank 0 must open its OWN store on the new port
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    rc = -1
-    try:
-        p = subprocess.Popen([sys.executable, "-m", "copo_amd.dist_probe"], env=env, cwd=root,
-                             stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        try:
-            rc = p.wait(timeout=timeout)
-        except subprocess.TimeoutExpired:
-            p.kill()            # exactly the child we started
-            p.wait()
-    except OSError:
-        rc = -1
-    ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device="cuda")
-    td.all_reduce(ok, op=td.ReduceOp.MIN)
-    return bool(ok.item())
-
-
 def ranks_share_a_device(device):
     """True if two ranks of the job use the same physical GPU (tests on a one-GPU box).  Kernels that wait for their peers
     INSIDE the kernel (the tile exchange) then compete with those peers for the same compute units and may starve them."""

@@ -52,8 +52,6 @@ def _mb():
 
 
 def main():
-    os.environ["COPO_DIST_CHAIN"] = "0"       # (b) takes the eager RCCL loop: no probe of a probe
-    os.environ.pop("COPO_PEER_ALLREDUCE", None)
     import torch
     import torch.distributed as td
     from copo_amd import dist as D

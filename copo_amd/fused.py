@@ -165,6 +165,25 @@ class FusedLearner:
             _capi.current_stream()))
         return out
 
+    def gather_epoch_ok(self, rs):
+        """May the planned rows be copied into minibatch order (gather_epoch)?  The copy holds rows_all.shape[0] x mb rows of the
+        observation, pack and critic-observation sources (the whole plan, i.e. num_sgd_iter x the batch): it must fit the device
+        memory that is free now (with a quarter to spare), and the sources must be contiguous fp32.  Otherwise the step kernels
+        keep reading through the row tables (`rows_all`), which need no copy."""
+        names = ["obs", "pack"] + (["cc_obs"] if rs.get("cc_obs") is not None else [])
+        if not all(rs[k].is_contiguous() and rs[k].dtype == torch.float32 for k in names):
+            return False
+        d = rs.get("_dense")
+        cap = int(rs["rows_all"].shape[0]) * int(self.cfg.mb)
+        if d is not None and d["obs"].shape[0] == cap and d["obs"].shape[1] == rs["obs"].shape[1]:
+            return True                      # (already allocated)
+        need = 4 * cap * sum(int(rs[k].shape[1]) for k in names)
+        dev = self.flat.flat.device
+        if dev.type != "cuda":
+            return True
+        free, _total = torch.cuda.mem_get_info(dev)
+        return need * 1.25 <= free
+
     def gather_epoch(self, rs, n_mb):
         """The rows of this epoch's plan (`rs["rows_all"][:n_mb]`) copied once into minibatch order -- observation, critic
         observation and pack rows -- so that the step kernels read row kb * mb + m directly instead of chasing a row index in
@@ -315,8 +334,11 @@ class FusedLearner:
 
     def meta_batch_dot(self, g, n, nb, gv, denom=None):
         """gv[:nb] = <g[b][0], g[b][1]>; denom [nb] float32: scaled by 1 / denom^2 (unit-weight gradients of the row store)."""
+        part = getattr(self, "_dot_part", None)        # this learner's own scratch for the partial sums (8 per minibatch)
+        if part is None or part.numel() < 8 * int(nb):
+            part = self._dot_part = torch.zeros(8 * max(int(nb), 256), dtype=torch.float64, device=g.device)
         _capi.check(_capi.lib.copo_meta_batch_dot_f64(g.data_ptr(), int(n), int(nb), gv.data_ptr(),
-                                                      None if denom is None else denom.data_ptr(), _capi.current_stream()))
+                                                      None if denom is None else denom.data_ptr(), part.data_ptr(), _capi.current_stream()))
 
     _seq_xchg = None
 

@@ -1,7 +1,8 @@
 """Peer all-reduce of the data-parallel learner (C ABI `copo_peer_*` / `copo_ipc_*`): a two-shot sum over
 device memory that every rank of the node has mapped, instead of RCCL's ring, for the one message that sits on the critical
-path of every optimizer step (the 1.44 MB gradient sum of a 512-row minibatch).  Opt-in: COPO_PEER_ALLREDUCE=1 -- it has run
-with two processes sharing one GPU (tests/test_gpu_trainer.py), never on a multi-GPU node, so RCCL stays the default."""
+path of every optimizer step (the 1.44 MB gradient sum of a 512-row minibatch).  A stand-alone op since round 5 (its own tests,
+tests/test_gpu_peer_allreduce.py): the trainer's data-parallel step is the tile exchange below (the sum happens inside the
+weight-gradient kernel, no gradient buffer at all) with ONE fallback, the RCCL loop."""
 import ctypes as C
 import os
 
@@ -9,10 +10,6 @@ import torch
 import torch.distributed as td
 
 from . import _capi
-
-
-def enabled():
-    return os.environ.get("COPO_PEER_ALLREDUCE", "0") == "1"
 
 
 class _Raw:

@@ -467,56 +467,47 @@ class PPOPolicyBase:
         for _ in range(self.SGD_CHAIN_LONG):
             self._fused_local()
 
+    dp_reason = None        # why `_dp_mode` is what it is (printed in the bench line: a scaling run that fell back to RCCL says so)
+
     def _pick_dp_mode(self):
         from . import peer
         want = os.environ.get("COPO_DP_EXCHANGE", "auto")
-        if self.device.type != "cuda" or peer.enabled() or want == "rccl":
+        if self.device.type != "cuda":
+            self.dp_reason = "not a GPU job: collective loop (gloo)"
+            return "rccl"
+        if want == "rccl":
+            self.dp_reason = "COPO_DP_EXCHANGE=rccl"
             return "rccl"
         if D.world_size() == 1:
-            return "tile"                    # COPO_FORCE_DIST with one rank: nothing to exchange, the same kernels
+            self.dp_reason = "one rank (COPO_FORCE_DIST): the data-parallel step kernels, nothing to exchange"
+            return "tile"
         if want not in ("tile", "try") and D.ranks_share_a_device(self.device):
-            return "rccl"                    # (a one-GPU test box: a kernel that waits for its peers starves them of compute units)
+            # (a one-GPU test box: a kernel that waits for its peers starves them of compute units)
+            self.dp_reason = "ranks share a device: RCCL loop"
+            return "rccl"
         c = self.fused.cfg
-        # "tile": by name, no probe, a timed-out wait raises; "try": no probe either, but a timed-out wait falls back to the RCCL loop
-        # (what `auto` does after its probe has passed; the tests use it to exercise that fall-back)
-        if want in ("tile", "try") or D.probe_tile_exchange(c.hidden, c.pol.in_dim, 1 + c.n_value_heads, mb=int(c.mb)):
+        # "tile": by name, no probe, a timed-out wait raises on every rank; "try": no probe either, but a timed-out wait falls back to the
+        # RCCL loop (what `auto` does after its probe has passed; the tests use it to exercise that fall-back)
+        if want in ("tile", "try"):
+            probed = None
+        else:      # the probe learner has the job's own grid: widest input of all nets (the weight-gradient tiles follow it), all nets, minibatch
+            kmax = max([int(c.pol.in_dim)] + [int(c.val[g].in_dim) for g in range(int(c.n_value_heads))])
+            probed = D.probe_tile_exchange(c.hidden, kmax, 1 + c.n_value_heads, mb=int(c.mb))
+        if probed is None or probed:
             tile = peer.TileExchange(self.fused.cfg, self.device)
             if tile.usable:               # (agreed by all ranks; False: a hipIpc export / open failed somewhere)
                 self._tile = tile
+                self.dp_reason = ("COPO_DP_EXCHANGE=%s" % want) if probed is None else "start-up probe passed on this node"
                 return "tile"
             if want == "tile":
                 raise RuntimeError("COPO_DP_EXCHANGE=tile: the ranks could not map each other's exchange workspaces (hipIpc)")
+            self.dp_reason = "hipIpc mapping of the exchange workspaces failed: RCCL loop"
+        else:
+            self.dp_reason = "start-up probe of the tile exchange failed or timed out: RCCL loop"
         return "rccl"
 
-    # data-parallel path, opt-in (COPO_DIST_CHAIN=K): K x [gradient pass, all-reduce, Adam] captured in one graph, the
-    # collective included.  torch.distributed + RCCL capture and replay it on this stack (scripts/micro/nccl_graph_probe.py,
-    # one rank); it stays off by default until it has run on a multi-GPU node.
-    DIST_CHAIN = int(os.environ.get("COPO_DIST_CHAIN", "0"))
-
-    def _fused_dist_chain(self):
-        for _ in range(self._dist_chain_len):
-            self.fused.step(self._row_sources, apply_adam=False, stats=self.fused.stats, bump_index=False)
-            self._grad_all_reduce()
-            self.fused.adam(self._row_sources)
-
-    # COPO_PEER_ALLREDUCE=1: the gradient sums travel through the two-shot peer all-reduce (copo_amd/peer.py) instead of
-    # torch.distributed -- one kernel per step, so [gradient pass, all-reduce, Adam] chains are captured like the local ones.
-    # The gradient buffer of the fused learner then lives in the peer workspace (reduced in place).
-    _peer = None
-    _dist_chain_len = DIST_CHAIN
-
-    def _setup_peer_allreduce(self):
-        from . import peer
-        if self._peer is None and peer.enabled() and D.is_dist() and self.device.type == "cuda":
-            self._peer = peer.PeerAllReduce(self.fused.flat.numel, self.device)
-            self.fused.grad = self._peer.data
-            self._dist_chain_len = self.DIST_CHAIN or 16
-
     def _grad_all_reduce(self):
-        if self._peer is not None:
-            self._peer.all_reduce_()
-        else:
-            D.all_reduce_sum_(self.fused.grad)
+        D.all_reduce_sum_(self.fused.grad)
 
     def _fused_grads(self):
         self.fused.step(self._row_sources, apply_adam=False, stats=self.fused.stats, bump_index=False)
@@ -529,7 +520,7 @@ class PPOPolicyBase:
         self.fused.adam(self._row_sources)
         self.fused.step(self._row_sources, apply_adam=False, stats=self.fused.stats, bump_index=False)
 
-    def run_sgd_fused(self, valid_idx, B_local, B_all, mb, num_epochs):
+    def run_sgd_fused(self, valid_idx, B_local, B_all, mb, num_epochs, _perms=None):
         fz = self.fused
         assert mb == fz.cfg.mb, "fused learner was built for minibatch %d" % fz.cfg.mb
         if self._sgd is None and D.is_dist() and self._dp_mode is None:
@@ -537,15 +528,11 @@ class PPOPolicyBase:
         tile = self._dp_mode == "tile"
         if self._sgd is None:
             if D.is_dist() and not tile:
-                self._setup_peer_allreduce()
-                if self._peer is None and self._dist_chain_len == 0 and "COPO_DIST_CHAIN" not in os.environ and self.use_graphs:
-                    # RCCL inside a hipGraph: take it when a child process per rank shows that it captures and replays here
-                    if D.probe_graphed_allreduce():
-                        self._dist_chain_len = 16
+                # the RCCL loop: [gradient pass] -> all-reduce -> [Adam + next gradient pass]; the kernels run captured, the collective
+                # between them eager (ONE fallback: the captured-collective and peer-kernel variants of round 4 are gone)
                 self._sgd = (GraphedCallable(self._fused_grads, self.use_graphs),
                              GraphedCallable(self._fused_apply, self.use_graphs),
                              GraphedCallable(self._fused_apply_then_grads, self.use_graphs))
-                self._sgd_dist_chain = GraphedCallable(self._fused_dist_chain, self.use_graphs) if self._dist_chain_len > 0 else None
             else:
                 self._sgd = GraphedCallable(self._fused_local, self.use_graphs)
                 self._sgd_chain = GraphedCallable(self._fused_local_chain, self.use_graphs)
@@ -553,16 +540,20 @@ class PPOPolicyBase:
         # the tile exchange has a bounded wait instead of a hang; should one ever time out on the job's links, every rank goes back
         # to the state this call started from and repeats it through the RCCL loop (unless the exchange was asked for by name)
         snap = None
-        if tile and self._tile is not None and os.environ.get("COPO_DP_EXCHANGE", "auto") != "tile":
+        by_name = os.environ.get("COPO_DP_EXCHANGE", "auto") == "tile"
+        if tile and self._tile is not None and not by_name:
             snap = (fz.flat.flat.clone(), fz.adam_m.clone(), fz.adam_v.clone(), fz.step_count.clone(), self.num_grad_updates)
         fz.stats.zero_()
         fz.sync_mirror()          # graph replays below do not run python: refresh the transposed weights here if needed
         steps = 0
         n_epochs_asked = num_epochs
-        perms = self.draw_perms(num_epochs, B_local)
+        perms = _perms if _perms is not None else self.draw_perms(num_epochs, B_local)      # (a retry after a fall-back repeats the SAME epochs)
         rs0 = self._row_sources
         n_mb_ep = max(1, math.ceil(max(B_all) / mb))
-        if (tile or not D.is_dist()) and self.use_graphs and self.config.get("gather_epoch_rows", True) and self.config.get("plan_all_epochs", True) \
+        if getattr(self, "_gather_ok", None) is None:      # decided once: captured chains keep reading the sources they were captured on
+            self._gather_ok = bool(self.config.get("gather_epoch_rows", True) and fz.gather_epoch_ok(rs0))      # (memory for the copy, fp32 sources; else: row tables)
+        gather_ok = self._gather_ok
+        if (tile or not D.is_dist()) and self.use_graphs and gather_ok and self.config.get("plan_all_epochs", True) \
                 and num_epochs * n_mb_ep <= int(rs0["rows_all"].shape[0]):
             # every epoch's plan up front, back to back in the tables, ONE gather of all planned rows into minibatch order; the
             # device-side minibatch counter then walks all num_epochs x n_mb steps in captured chains without a host stop
@@ -586,7 +577,7 @@ class PPOPolicyBase:
             num_epochs = 0          # (the per-epoch loop below has nothing left to do)
         for ep in range(num_epochs):
             n_mb = self.plan_epoch(valid_idx, B_local, B_all, mb, perm=None if perms is None else perms[ep])
-            if (tile or not D.is_dist()) and self.config.get("gather_epoch_rows", True):
+            if (tile or not D.is_dist()) and gather_ok:
                 # (persistent buffers: the captured chains keep reading the same addresses)
                 self._rs_step = fz.gather_epoch(self._row_sources, n_mb)
             _k0 = 0
@@ -596,11 +587,6 @@ class PPOPolicyBase:
                     self._sgd_chain()
                     _k0 += self.SGD_CHAIN
                     steps += self.SGD_CHAIN
-            if D.is_dist() and not tile and self.use_graphs and getattr(self, "_sgd_dist_chain", None) is not None:
-                while _k0 + self._dist_chain_len <= n_mb:
-                    self._sgd_dist_chain()
-                    _k0 += self._dist_chain_len
-                    steps += self._dist_chain_len
             for _k in range(_k0, n_mb):
                 if D.is_dist() and not tile:
                     # two host calls per minibatch: [Adam of the previous one + this gradient pass], all-reduce; the
@@ -613,17 +599,19 @@ class PPOPolicyBase:
                     self._sgd()
                 steps += 1
         self.num_grad_updates += steps
-        if self._peer is not None:
-            self._peer.status()       # a rank that never arrived in some call: raise here instead of training on partial sums
         if self._tile is not None:
-            if snap is None:
-                self._tile.status()
-            else:
-                good = torch.tensor([1 if self._tile.ok() else 0], dtype=torch.int32, device=self.device)
-                if D.world_size() > 1:
-                    import torch.distributed as td
-                    td.all_reduce(good, op=td.ReduceOp.MIN)
-                if not bool(good.item()):
+            # every rank learns whether ANY rank's wait timed out (a rank that raised alone would leave its peers hanging in their
+            # next collective with partially summed parameters)
+            good = torch.tensor([1 if self._tile.ok() else 0], dtype=torch.int32, device=self.device)
+            if D.world_size() > 1:
+                import torch.distributed as td
+                td.all_reduce(good, op=td.ReduceOp.MIN)
+            if not bool(good.item()):
+                if snap is None:          # asked for by name: no fall-back -- close the mappings, raise on every rank
+                    self._tile.close()
+                    self._tile = None
+                    raise RuntimeError("data-parallel tile exchange (COPO_DP_EXCHANGE=tile): a wait for a peer timed out on some rank")
+                else:
                     import warnings
                     warnings.warn("data-parallel tile exchange: a wait for a peer timed out; back to the RCCL loop from the state before this call")
                     fz.flat.flat.copy_(snap[0]); fz.adam_m.copy_(snap[1]); fz.adam_v.copy_(snap[2]); fz.step_count.copy_(snap[3])
@@ -631,7 +619,8 @@ class PPOPolicyBase:
                     fz.invalidate_mirror()
                     self._tile.close()
                     self._tile, self._dp_mode, self._sgd, self._rs_step = None, "rccl", None, None
-                    return self.run_sgd_fused(valid_idx, B_local, B_all, mb, n_epochs_asked)
+                    self.dp_reason = "a wait of the tile exchange timed out during training: RCCL loop from then on"
+                    return self.run_sgd_fused(valid_idx, B_local, B_all, mb, n_epochs_asked, _perms=perms)
         tot, pol, vf, kl, ent, vfn, vfg, adv = (fz.stats / max(1, steps)).tolist()
         return dict(total_loss=tot, policy_loss=pol, vf_loss=vf, kl=kl, entropy=ent, cur_kl_coeff=self._kl_value,
                     cur_lr=float(self.config["lr"]), num_sgd_steps=steps, mean_nei_vf_loss=vfn, mean_global_vf_loss=vfg,
@@ -1099,7 +1088,7 @@ class VecTrainer:
             self.env.close()
         except Exception:
             pass
-        for name in ("_peer", "_tile"):
+        for name in ("_tile",):
             peer = getattr(self.policy, name, None)
             if peer is not None:
                 peer.close()

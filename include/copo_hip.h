@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define COPO_ABI_VERSION 6
+#define COPO_ABI_VERSION 7
 
 #define COPO_OK 0
 #define COPO_ERR_NULL (-1)      /* required pointer is NULL */
@@ -206,6 +206,9 @@ typedef struct copo_step_out {
 
 /* ---- library ---- */
 int copo_version(void);
+/* how this library was built, for bench lines and bug reports: ABI, target, profiling mask ("none" in the shipped build) and the
+ * environment variables it reads (none: every tuning knob is an argument of this ABI).  Owned by the library. */
+const char* copo_build_info(void);
 const char* copo_last_error(void);
 
 /* ---- vectorised multi-agent env: replaces MultiAgent*Env.step/reset (MetaDrive, call site
@@ -464,8 +467,11 @@ int copo_meta_batch_grads_f32(const copo_ppo_cfg* cfg, float* theta, float* thet
                               float* workspace, int32_t nb_cap, int64_t mb_first, int32_t nb, float* g_out,
                               double* gv_out, float* stats_out, void* stream);
 /* gv_out[b] = <g[b][0], g[b][1]> (fp64 accumulation, fixed order) of exported -- all-reduced -- gradient pairs; denom (may be
- * NULL): [nb] row counts D_b, the result is scaled by 1 / D_b^2 (exported gradients of the row-store path carry unit weights). */
-int copo_meta_batch_dot_f64(const float* g /* [nb][2][n] */, int64_t n, int32_t nb, double* gv_out, const float* denom,
+ * NULL): [nb] row counts D_b, the result is scaled by 1 / D_b^2 (exported gradients of the row-store path carry unit weights).
+ * partials: caller-owned scratch of nb * COPO_META_DOT_SPLIT doubles (stream-ordered like every other argument: calls on different
+ * streams need different scratch), or NULL: one workgroup per minibatch, no scratch, slower. */
+#define COPO_META_DOT_SPLIT 8
+int copo_meta_batch_dot_f64(const float* g /* [nb][2][n] */, int64_t n, int32_t nb, double* gv_out, const float* denom, double* partials,
                             void* stream);
 /* Row store.  Everything of phase A that is local to a ROW (both forward passes, the loss gradients, the activation
  * gradients -- with unit row weight) does not depend on how a meta pass groups the rows into minibatches, and the

@@ -2,6 +2,7 @@
 # Round evidence for the simulator step kernel, on the very commands whose numbers the bench line carries:
 #   live       `bench.py --roofline-only`:  the trainer's 256 scenes x 40 slots, its own policy, 200 recorded steps replayed
 #   saturated  `bench.py --saturated-only`: 16 384 populated scenes (lane-keeping controller), 60 recorded steps replayed
+#   c3|c4|c5   `bench.py --config-leg <c>`: the other BASELINE configurations' simulators (Roundabout; Tollgate O = 156; ParkingLot 10 slots x 240 beams)
 # Kernel trace + PMC passes, each in its own run (no --stats / trace domains next to --pmc); the summaries cover the LAST n
 # dispatches of the kernel = the replay.     usage: scripts/prof_sim_round.sh live|saturated [tag]   -> gpurun_out/prof_<tag>_<mode>/summary.txt (+ sim_valu.json for saturated)
 set -u
@@ -11,7 +12,11 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_${TAG}_$MODE
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-if [ "$MODE" = live ]; then ARGS="--roofline-only"; N=200; else ARGS="--saturated-only"; N=60; fi
+case $MODE in
+  live) ARGS="--roofline-only"; N=200;;
+  c3|c4|c5) ARGS="--config-leg $MODE"; N=60;;      # (the last 60 dispatches: the replay on 16 384 scenes of that configuration)
+  *) ARGS="--saturated-only"; N=60;;
+esac
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $ROOT/bench.py $ARGS > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $OUT/pmc1 -o pmc1 -- python $ROOT/bench.py $ARGS > $OUT/pmc1.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -d $OUT/pmc2 -o pmc2 -- python $ROOT/bench.py $ARGS > $OUT/pmc2.log 2>&1
@@ -22,7 +27,7 @@ cd $ROOT
   echo "# scripts/prof_sim_round.sh $MODE: copo::sim_step_kernel under rocprofv3, command: python bench.py $ARGS"
   echo "# (the LAST $N dispatches of the kernel are the replay of the recorded actions; line below: what the command printed in the trace pass,"
   echo "#  HIP events around the back-to-back replay)"
-  grep -h '^{' $OUT/trace.log | tail -1
+  grep -h '^{' $OUT/trace.log | tail -3
   python scripts/replay_summary.py $OUT sim_step $N
 } > $OUT/summary.txt 2>&1
 # VALU roofline of the saturated launch: wave-level VALU instructions per launch (SQ_INSTS_VALU) and the cycles the VALUs were

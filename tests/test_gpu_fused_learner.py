@@ -119,11 +119,12 @@ def test_fused_sgd_matches_torch(name, fuse, odim, over):
     for (n1, p1), (n2, p2) in zip(ref.model.named_parameters(), fz.model.named_parameters()):
         if p1.dtype != torch.float32:
             continue
-        diff = (p1 - p2).abs()
+        diff = (p1.detach() - p2.detach()).abs()
         # Adam's first steps move every weight by ~lr * sign(g): elements whose gradient is at the fp32 noise
         # floor may legitimately take a different sign; everything else must agree to a fraction of one step
-        assert float((diff > 3e-5).float().mean()) < 2e-3, (n1, float(diff.max()))
-        assert float(diff.max()) <= 3 * 2 * 3e-4 + 1e-6, (n1, float(diff.max()))
+        lr = float(fz.config["lr"])
+        assert float((diff > 3e-5).float().mean()) < 2e-3, (n1, float(diff.max()))      # <= 0.2 % of the elements beyond a tenth of a step
+        assert float(diff.max()) <= 2 * n_steps * lr + 1e-6, (n1, float(diff.max()))    # none beyond opposite signs in every step (6 lr)
 
 
 @pytest.mark.parametrize("name,fuse,odim", [("ccppo", "mf", 156), ("ippo", "none", 91)])

@@ -452,14 +452,13 @@ def test_lookahead_bootstrap_with_several_fragments_per_rollout():
     a.stop()
 
 
-@pytest.mark.parametrize("peer", ["0", "1", "tile", "auto"])
+@pytest.mark.parametrize("peer", ["0", "tile", "auto"])
 def test_two_ranks_fused_data_parallel_on_one_gpu(peer):
     """peer = "tile": the data-parallel step of DESIGN.md section 6 -- gradient tiles summed over the ranks inside the
     weight-gradient kernel (copo_ppo_fused_step_dp_f32), captured chains like the local step; "auto": the default -- that path
     where every rank has a GPU of its own and the start-up probe (copo_amd/dp_probe.py) passes; HERE both ranks share one GPU
     (kernels that wait for their peers would compete with them for compute units), which the default notices: RCCL loop.
-    peer = "1": the gradient sums go through the peer all-reduce (COPO_PEER_ALLREDUCE, hipIpc-mapped workspaces, captured
-    [gradient pass, all-reduce, Adam] chains) instead of torch.distributed.
+    peer = "0": the RCCL loop by name (COPO_DP_EXCHANGE=rccl), with the LCF steps chunk by chunk (meta_seq_per_chunk_dist).
     Two real ranks (gloo over CUDA tensors, both on cuda:0 -- RCCL would refuse to share a device) through the fused
     data-parallel path: gradient all-reduce + flat Adam per minibatch, batched meta pass with exported gradient pairs,
     gathered LCF rows.  Ranks own different scenes, must take the same number of steps and end with identical parameters."""
@@ -476,12 +475,12 @@ from copo_amd.torch_copo.utils.env_wrappers import MultiAgentIntersectionEnv, ge
 env = get_rllib_compatible_env(get_lcf_env(MultiAgentIntersectionEnv))
 a = CoPOTrainer(config=dict(env=env, env_config=dict(num_agents=12, horizon=60), num_envs=8 + 4 * rank, train_batch_size=(8 + 4 * rank) * 8,
                             sgd_minibatch_size=128, num_sgd_iter=2, lcf_num_iters=2, seed=3, meta_batch_size=4,
-                            meta_seq_per_chunk_dist=os.environ.get("COPO_PEER_ALLREDUCE") == "1",     # (one variant: LCF steps chunk by chunk)
+                            meta_seq_per_chunk_dist=os.environ.get("COPO_DP_EXCHANGE") == "rccl",     # (one variant: LCF steps chunk by chunk)
                             model={"fcnet_hiddens": [64, 64]}))
 assert a.policy.fused is not None and D.is_dist() and world == 2
 for _ in range(3):
     res = a.train()
-assert (a.policy._peer is not None) == (os.environ.get("COPO_PEER_ALLREDUCE") == "1")
+assert a.policy.dp_reason, a.policy.dp_reason      # the decision is recorded
 want_tile = os.environ.get("COPO_DP_EXCHANGE") == "tile"
 assert (a.policy._tile is not None) == want_tile and (a.policy._dp_mode == "tile") == want_tile, a.policy._dp_mode
 # whole-episode evaluation: the ranks' scenes finish their episode after different fragment counts, the loop holds collectives --
@@ -504,8 +503,7 @@ td.destroy_process_group()
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29561",
-                   COPO_DIST_BACKEND="gloo", COPO_FORCE_DIST="0", COPO_PEER_ALLREDUCE=peer if peer in "01" else "0",
-                   COPO_DP_EXCHANGE=peer if peer in ("tile", "auto") else "rccl")
+                   COPO_DIST_BACKEND="gloo", COPO_FORCE_DIST="0", COPO_DP_EXCHANGE=peer if peer in ("tile", "auto") else "rccl")
         procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     outs = [p.communicate(timeout=600) for p in procs]
@@ -692,7 +690,7 @@ def test_tile_exchange_probe_with_several_ranks_on_one_gpu(world, hidden, nets, 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     procs = []
     for rank in range(world):
-        env = {k: v for k, v in os.environ.items() if k not in ("COPO_FORCE_DIST", "COPO_PEER_ALLREDUCE")}
+        env = {k: v for k, v in os.environ.items() if k not in ("COPO_FORCE_DIST",)}
         env.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT="29651",
                    COPO_DIST_BACKEND="gloo", COPO_DP_PROBE_HIDDEN=str(hidden), COPO_DP_PROBE_OBS="20", COPO_DP_PROBE_NETS=str(nets),
                    COPO_DP_PROBE_MB=str(mb), COPO_DP_PROBE_VERBOSE="1")
@@ -741,7 +739,7 @@ td.destroy_process_group()
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29671",
-                   COPO_DIST_BACKEND="gloo", COPO_FORCE_DIST="0", COPO_PEER_ALLREDUCE="0", COPO_DIST_CHAIN="0")
+                   COPO_DIST_BACKEND="gloo", COPO_FORCE_DIST="0")
         procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=root))
     outs = [p.communicate(timeout=400) for p in procs]
     for p, (so, se) in zip(procs, outs):

@@ -105,6 +105,7 @@ def test_losses_vs_reference(golden_dir, tag, pcls, ccls, fuse, over):
     for k in g.files:
         if k.startswith("out_stat_") and k[9:] in model.tower_stats:
             v = model.tower_stats[k[9:]]
+            v = v.detach() if hasattr(v, "detach") else v
             np.testing.assert_allclose(float(v), float(g[k]), rtol=1e-5, atol=1e-7, err_msg=k)
     for name, p in model.named_parameters():
         ref = g["out_grad_" + name]

@@ -9,7 +9,7 @@ import oracle_lib as ol
 
 def test_oracle_builds_and_versions():
     from copo_amd._abi import ABI_VERSION
-    assert ol.lib().oracle_version() == ABI_VERSION == 6
+    assert ol.lib().oracle_version() == ABI_VERSION == 7
 
 
 def test_neighbours_and_rewards_vs_reference(golden_dir):
