@@ -468,7 +468,8 @@ def cpu_baseline_all_cores(num_envs, num_agents, iters=1):
             # (the 8 threads of the plain variant unless another count is clearly -- 15 % -- faster over six real steps: on the
             #  256-thread hosts of the pool 32 threads won a three-step calibration and lost the whole learner phase by 2x)
             times = {}
-            for cand in (CPU_BASELINE_THREADS, 4, 16, 32, 64, 128, 256):      # (round-4 review: the whole range of the host, not 4 .. 16)
+            for cand in (CPU_BASELINE_THREADS, 4, 16, 32, 64):      # (round-4 review: beyond 4 .. 16; on the 256-thread hosts of the pool 64 threads take 39 ms
+                                                                  #  per step against 5.8 at 8, 128 threads 140 ms, 256 threads 14 s -- profiles/r05_bench_line.json -- so the sweep stops at 64)
                 if cand > host:
                     continue
                 torch.set_num_threads(cand)
@@ -655,6 +656,7 @@ def main():
                     help="ONLY the simulator step kernel on another BASELINE configuration (c3 Roundabout 40 slots, c4 Tollgate 40 slots / "
                          "O = 156, c5 ParkingLot 10 slots / 240 beams / O = 260): populated scenes (lane-keeping controller, recorded replay) at "
                          "the configuration's own scene count per GPU and at 16 384 scenes; one JSON line each (scripts/prof_sim_round.sh)")
+    ap.add_argument("--leg-scenes", type=int, default=0, help="with --config-leg: only this scene count (profiling: one size per process)")
     ap.add_argument("--saturated-only", action="store_true",
                     help="ONLY the saturated simulator-kernel measurement (16 384 populated scenes, recorded replay) and one small "
                          "JSON line: the command scripts/prof_sim_r03.sh profiles")
@@ -687,7 +689,7 @@ def main():
                 "c4": (dict(map="tollgate", num_agents=40), (512, 16384)),
                 "c5": (dict(map="parkinglot", num_agents=10, num_lasers=240), (4096, 16384))}
         kw, sizes = legs[args.config_leg]
-        for scenes in sizes:
+        for scenes in (sizes if args.leg_scenes <= 0 else (args.leg_scenes,)):
             k_s, present, slots = measure_sim_kernel_saturated(kw, scenes=scenes, launches=60, policy="cruise")
             O = measure_sim_kernel_saturated.last["O"]
             bpu = 202 + 4 * O

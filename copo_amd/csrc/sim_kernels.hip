@@ -1033,15 +1033,21 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK, (ONE && !EXT) ?
             const float xme = L.x[lane], yme = L.y[lane];
             const int R = N >> 1;
             int jj = lane < N ? lane : 0;
-            for (int r = 1; r <= R; ++r) {
-                jj = jj + 1 == N ? 0 : jj + 1;
-                const float ddx = L.x[jj] - xme, ddy = L.y[jj] - yme;
-                const int lanes = (r == R && (N & 1) == 0) ? R : N;
-                const bool near = sol_me && lane < lanes && (ddx * ddx + ddy * ddy <= near2);
-                const unsigned long long m = __ballot(near);
-                if (m != 0ull) {
-                    if (near) nq[nn + pk_mbcnt(m)] = (uint16_t)((lane << 8) | jj);
-                    nn += __popcll(m);
+            for (int r = 1; r <= R; r += 2) {      // two rows per turn: both poses are requested before either is used
+                const int j0 = jj + 1 >= N ? jj + 1 - N : jj + 1, j1 = jj + 2 >= N ? jj + 2 - N : jj + 2;
+                jj = j1;
+                const float x0 = L.x[j0], y0 = L.y[j0], x1 = L.x[j1], y1 = L.y[j1];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int rr_ = r + h, jh = h ? j1 : j0;
+                    const float ddx = (h ? x1 : x0) - xme, ddy = (h ? y1 : y0) - yme;
+                    const int lanes = rr_ > R ? 0 : ((rr_ == R && (N & 1) == 0) ? R : N);
+                    const bool near = sol_me && lane < lanes && (ddx * ddx + ddy * ddy <= near2);
+                    const unsigned long long m = __ballot(near);
+                    if (m != 0ull) {
+                        if (near) nq[nn + pk_mbcnt(m)] = (uint16_t)((lane << 8) | jh);
+                        nn += __popcll(m);
+                    }
                 }
             }
             pk_wave_sync();
@@ -1149,9 +1155,10 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK, (ONE && !EXT) ?
                         pk_wave_sync();
                         nbq = 0;
                     };
+                    // (lane q loads place q once: a load per iteration would put a memory round trip in front of every place)
+                    const float2 spq = lane < p.n_safe ? *reinterpret_cast<const float2*>(p.safe_pose + 4 * lane) : make_float2(0.0f, 0.0f);
                     for (int q = 0; q < p.n_safe; ++q) {
-                        const float4 sp4 = reinterpret_cast<const float4*>(p.safe_pose)[q];      // pose of respawn place q (host table)
-                        const float dx = s.x - sp4.x, dy = s.y - sp4.y;
+                        const float dx = s.x - readlane_f(spq.x, q), dy = s.y - readlane_f(spq.y, q);
                         const bool pre = solid_now && (dx * dx + dy * dy <= rr2);
                         const unsigned long long m = __ballot(pre);
                         if (m != 0ull) {

@@ -164,16 +164,21 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_packed_kernel(con
         int nn = 0;
         const int R = (COPO_PROFILE_SKIP & 16) ? 0 : (N >> 1);
         int jj = lane < N ? lane : 0;
-        for (int r = 1; r <= R; ++r) {
-            jj = jj + 1 == N ? 0 : jj + 1;
-            const float2 pj = *reinterpret_cast<const float2*>(&pose[jj]);
-            const float ddx = pj.x - pme.x, ddy = pj.y - pme.y;
-            const int lanes = (r == R && (N & 1) == 0) ? R : N;
-            const bool near = sol_me && lane < lanes && (ddx * ddx + ddy * ddy <= near2);
-            const unsigned long long m = __ballot(near);
-            if (m != 0ull) {
-                if (near) nq[nn + pk_mbcnt(m)] = (uint16_t)((lane << 8) | jj);
-                nn += __popcll(m);
+        for (int r = 1; r <= R; r += 2) {      // two rows per turn: both poses are requested before either is used
+            const int j0 = jj + 1 >= N ? jj + 1 - N : jj + 1, j1 = jj + 2 >= N ? jj + 2 - N : jj + 2;
+            jj = j1;
+            const float2 p0 = *reinterpret_cast<const float2*>(&pose[j0]), p1 = *reinterpret_cast<const float2*>(&pose[j1]);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int rr_ = r + h, jh = h ? j1 : j0;
+                const float ddx = (h ? p1.x : p0.x) - pme.x, ddy = (h ? p1.y : p0.y) - pme.y;
+                const int lanes = rr_ > R ? 0 : ((rr_ == R && (N & 1) == 0) ? R : N);
+                const bool near = sol_me && lane < lanes && (ddx * ddx + ddy * ddy <= near2);
+                const unsigned long long m = __ballot(near);
+                if (m != 0ull) {
+                    if (near) nq[nn + pk_mbcnt(m)] = (uint16_t)((lane << 8) | jh);
+                    nn += __popcll(m);
+                }
             }
         }
         pk_wave_sync();
@@ -260,9 +265,10 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_packed_kernel(con
                 pk_wave_sync();
                 nbq = 0;
             };
+            // (lane q loads place q once: a load per iteration would put a memory round trip in front of every place)
+            const float2 spq = lane < p.n_safe ? *reinterpret_cast<const float2*>(p.safe_pose + 4 * lane) : make_float2(0.0f, 0.0f);
             for (int q = 0; q < p.n_safe; ++q) {
-                const float4 sp4 = reinterpret_cast<const float4*>(p.safe_pose)[q];
-                const float dx = ps.x - sp4.x, dy = ps.y - sp4.y;
+                const float dx = ps.x - readlane_f(spq.x, q), dy = ps.y - readlane_f(spq.y, q);
                 const bool pre = sol && (dx * dx + dy * dy <= rr2);
                 const unsigned long long m = __ballot(pre);
                 if (m != 0ull) {

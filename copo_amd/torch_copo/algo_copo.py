@@ -338,7 +338,18 @@ class CoPOPolicy(CCPPOPolicy):
         self._meta_step_b()
 
     def _meta_per_chunk(self):
-        return bool(self.config.get("meta_seq_per_chunk_dist" if D.is_dist() else "meta_seq_per_chunk", not D.is_dist()))
+        """Local: the LCF steps of a chunk follow its dot products on a side stream.  Data-parallel (row store): the same function runs
+        the pass with ONE exchange of all its gradient pairs (`meta_dist_exchange` = "pass", the default) or chunk by chunk ("chunk",
+        also selected by the older `meta_seq_per_chunk_dist`); "off" keeps the round-4 loop (exchange and dot products per chunk, the
+        LCF steps of a pass in one launch behind its last chunk)."""
+        if not D.is_dist():
+            return bool(self.config.get("meta_seq_per_chunk", True))
+        return self._meta_dist_exchange() != "off"
+
+    def _meta_dist_exchange(self):
+        if self.config.get("meta_seq_per_chunk_dist", False):
+            return "chunk"
+        return str(self.config.get("meta_dist_exchange", "pass"))
 
     def _run_meta_batched(self, n_mb, nb):
         """One meta iteration the batched way: the gradient pairs of `nb` minibatches per launch chain (they do not
@@ -437,9 +448,19 @@ class CoPOPolicy(CCPPOPolicy):
             w_d = D.all_gather_into_(torch.empty(S, n_mb, mb, dtype=torch.float32, device=self.device), mb_["w_all"][:n_mb].contiguous())
             eps_d = D.all_gather_into_(torch.empty(S, n_mb, mb, dtype=torch.float64, device=self.device), mb_["eps_all"][:n_mb].contiguous())
             nf = fz.meta_fold_len()
-            if mb_.get("g_chunk") is None or mb_["g_chunk"][0].shape[0] < nb:
+            per_pass = self._meta_dist_exchange() == "pass"
+            if per_pass:
+                # ONE exchange per pass: every chunk exports its gradient pairs into the pass's buffer ([n_mb][2][n], ~105 MB at the bench
+                # shape -- two of them, passes alternate), one all-reduce of the whole buffer, one launch of all dot products, the pass's
+                # LCF steps in one launch -- the last three on the side stream.  Five collectives per iteration instead of 25 (fewer,
+                # larger messages are what the links want), none of them in front of the main stream's GEMMs.
+                cap = int(mb_["max_mb"])
+                if mb_.get("g_pass") is None or mb_["g_pass"][0].shape[0] < cap:
+                    mb_["g_pass"] = [torch.zeros(cap, 2, nf, dtype=torch.float32, device=self.device) for _ in range(2)]
+            elif mb_.get("g_chunk") is None or mb_["g_chunk"][0].shape[0] < nb:
                 mb_["g_chunk"] = [torch.zeros(nb, 2, nf, dtype=torch.float32, device=self.device) for _ in range(2)]
         else:
+            per_pass = False
             en_d, w_d, eps_d = en, mb_["w_all"][:n_mb].unsqueeze(0), mb_["eps_all"][:n_mb].unsqueeze(0)
         priv = dict(denom=mb_["denom_all"], en=en_d, w=w_d, eps=eps_d)       # (set q of the planned tables: not written before pass_done[q])
 
@@ -458,6 +479,31 @@ class CoPOPolicy(CCPPOPolicy):
             fz.meta_batch_dot(buf, nf, n, gv[c0:], denom=mb_["denom_all"][c0:])
             lcf_steps(c0, n)
 
+        if per_pass:
+            buf = mb_["g_pass"][q]
+            for c0 in range(0, n_mb, nb):
+                n = min(nb, n_mb - c0)
+                grads(rs, c0, n, gv, None, g_out=buf[c0:c0 + n])
+            work = D.all_reduce_sum_async(buf[:n_mb])
+            # everything behind the exchange -- the wait for it, the dot products, the pass's LCF steps -- goes to the SIDE stream: the
+            # main stream moves on to the next pass's GEMMs (they do not depend on the LCF parameters) while the collective is on the
+            # wire; the buffers of this pass are taken again two passes later, behind pass_done[q]
+            ev = torch.cuda.Event()
+            ev.record()
+            done = torch.cuda.Event()
+            with torch.cuda.stream(self._meta_side):
+                self._meta_side.wait_event(ev)
+                if work is not None:
+                    work.wait()               # (the side stream waits; neither the host nor the main stream does)
+                fz.meta_batch_dot(buf, nf, n_mb, gv, denom=mb_["denom_all"])
+                fz.meta_batch_lcf(dict(denom_all=priv["denom"]), n_mb, None, gv, stats_k,
+                                  self.model.lcf_parameters.data, self._raw_ms, self._lcf_adam, self.config[LCF_LR], mb_["stats"],
+                                  0, 0, dense=(en_d, w_d, eps_d), k_first=0, k_count=n_mb)
+                done.record()
+            mb_["pass_done"][q] = done
+            mb_["gv"], mb_["stats_k"] = gv, stats_k
+            self._meta_keep.append(priv)
+            return
         pending = None
         for j, c0 in enumerate(range(0, n_mb, nb)):
             n = min(nb, n_mb - c0)

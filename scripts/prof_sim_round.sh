@@ -14,14 +14,14 @@ rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 case $MODE in
   live) ARGS="--roofline-only"; N=200;;
-  c3|c4|c5) ARGS="--config-leg $MODE"; N=60;;      # (the last 60 dispatches: the replay on 16 384 scenes of that configuration)
+  c3|c4|c5) ARGS="--config-leg $MODE --leg-scenes ${LEG_SCENES:-16384}"; N=60;;      # (one size per process; the last 60 dispatches: the replay)
   *) ARGS="--saturated-only"; N=60;;
 esac
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $ROOT/bench.py $ARGS > $OUT/trace.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $OUT/pmc1 -o pmc1 -- python $ROOT/bench.py $ARGS > $OUT/pmc1.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -d $OUT/pmc2 -o pmc2 -- python $ROOT/bench.py $ARGS > $OUT/pmc2.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc3 -o pmc3 -- python $ROOT/bench.py $ARGS > $OUT/pmc3.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc4 -o pmc4 -- python $ROOT/bench.py $ARGS > $OUT/pmc4.log 2>&1
+timeout ${PROF_TIMEOUT:-400} rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $ROOT/bench.py $ARGS > $OUT/trace.log 2>&1
+timeout ${PROF_TIMEOUT:-400} rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $OUT/pmc1 -o pmc1 -- python $ROOT/bench.py $ARGS > $OUT/pmc1.log 2>&1
+timeout ${PROF_TIMEOUT:-400} rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -d $OUT/pmc2 -o pmc2 -- python $ROOT/bench.py $ARGS > $OUT/pmc2.log 2>&1
+timeout ${PROF_TIMEOUT:-400} rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc3 -o pmc3 -- python $ROOT/bench.py $ARGS > $OUT/pmc3.log 2>&1
+timeout ${PROF_TIMEOUT:-400} rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc4 -o pmc4 -- python $ROOT/bench.py $ARGS > $OUT/pmc4.log 2>&1
 cd $ROOT
 {
   echo "# scripts/prof_sim_round.sh $MODE: copo::sim_step_kernel under rocprofv3, command: python bench.py $ARGS"

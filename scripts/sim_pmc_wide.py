@@ -54,7 +54,7 @@ if __name__ == "__main__":
     if not os.path.exists(state):
         subprocess.run(args, capture_output=True, cwd="/tmp", env=env)
     print("# %s E=%d N=%d lasers=%d block=%d: per-launch means over the step launches (12 per pass)" % (mp, E, N, lasers, block))
-    for gi, g in enumerate(GROUPS):
+    for gi, g in enumerate(GROUPS[:int(os.environ.get("PMC_GROUPS", len(GROUPS)))]):
         d = os.path.join(tmp, "g%d_b%d" % (gi, block))
         subprocess.run(["rm", "-rf", d])
         r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc"] + g.split() + ["-d", d, "--"] + args, capture_output=True, text=True, cwd="/tmp", env=env)
