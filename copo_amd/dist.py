@@ -135,7 +135,21 @@ def _probe_child(module, port_shift, timeout, need_nccl, extra_env=None):
         return False
     if (need_nccl and td.get_backend() != "nccl") or os.environ.get("COPO_DIST_PROBE", "1") == "0":
         return False
-    env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + port_shift))
+    # the children's rendezvous port: a port that is free on rank 0's host right now, handed to every rank over the parent group
+    # (a fixed MASTER_PORT + shift can collide with another job of the node); `port_shift` only if that exchange fails
+    port = [0]
+    try:
+        if td.get_rank() == 0:
+            import socket
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+                sk.bind((os.environ.get("MASTER_ADDR", "127.0.0.1"), 0))
+                port[0] = int(sk.getsockname()[1])
+        td.broadcast_object_list(port, src=0)
+    except Exception:      # noqa: BLE001
+        port = [0]
+    if not port[0]:
+        port[0] = int(os.environ.get("MASTER_PORT", "29500")) + port_shift
+    env = dict(os.environ, MASTER_PORT=str(port[0]))
     env.pop("COPO_FORCE_DIST", None)
     env.pop("TORCHELASTIC_USE_AGENT_STORE", None)      # under torchrun: the child's rank 0 must open its OWN store on the new port
     env.update(extra_env or {})

@@ -602,7 +602,12 @@ class PPOPolicyBase:
         if self._tile is not None:
             # every rank learns whether ANY rank's wait timed out (a rank that raised alone would leave its peers hanging in their
             # next collective with partially summed parameters)
-            good = torch.tensor([1 if self._tile.ok() else 0], dtype=torch.int32, device=self.device)
+            ok = self._tile.ok()
+            if int(self.config.get("dp_fault_injection_rank", -1)) == D.rank() and not getattr(self, "_dp_fault_injected", False):
+                # test hook: this rank reports a timed-out wait ONCE (the kernels' own time-out needs starving ranks or dead links;
+                # what follows it -- agreement, restore, the same epochs again through the RCCL loop -- must be covered every time)
+                ok, self._dp_fault_injected = False, True
+            good = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
             if D.world_size() > 1:
                 import torch.distributed as td
                 td.all_reduce(good, op=td.ReduceOp.MIN)

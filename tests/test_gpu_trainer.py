@@ -452,13 +452,15 @@ def test_lookahead_bootstrap_with_several_fragments_per_rollout():
     a.stop()
 
 
-@pytest.mark.parametrize("peer", ["0", "tile", "auto"])
+@pytest.mark.parametrize("peer", ["0", "tile", "auto", "try-fault"])
 def test_two_ranks_fused_data_parallel_on_one_gpu(peer):
     """peer = "tile": the data-parallel step of DESIGN.md section 6 -- gradient tiles summed over the ranks inside the
     weight-gradient kernel (copo_ppo_fused_step_dp_f32), captured chains like the local step; "auto": the default -- that path
     where every rank has a GPU of its own and the start-up probe (copo_amd/dp_probe.py) passes; HERE both ranks share one GPU
     (kernels that wait for their peers would compete with them for compute units), which the default notices: RCCL loop.
     peer = "0": the RCCL loop by name (COPO_DP_EXCHANGE=rccl), with the LCF steps chunk by chunk (meta_seq_per_chunk_dist).
+    peer = "try-fault": the tile exchange without a probe, and rank 1 reports a timed-out wait once (`dp_fault_injection_rank`): both
+    ranks must agree, restore the state the call started from, leave the exchange and repeat the SAME epochs through the RCCL loop.
     Two real ranks (gloo over CUDA tensors, both on cuda:0 -- RCCL would refuse to share a device) through the fused
     data-parallel path: gradient all-reduce + flat Adam per minibatch, batched meta pass with exported gradient pairs,
     gathered LCF rows.  Ranks own different scenes, must take the same number of steps and end with identical parameters."""
@@ -476,11 +478,14 @@ env = get_rllib_compatible_env(get_lcf_env(MultiAgentIntersectionEnv))
 a = CoPOTrainer(config=dict(env=env, env_config=dict(num_agents=12, horizon=60), num_envs=8 + 4 * rank, train_batch_size=(8 + 4 * rank) * 8,
                             sgd_minibatch_size=128, num_sgd_iter=2, lcf_num_iters=2, seed=3, meta_batch_size=4,
                             meta_seq_per_chunk_dist=os.environ.get("COPO_DP_EXCHANGE") == "rccl",     # (one variant: LCF steps chunk by chunk)
+                            dp_fault_injection_rank=1 if os.environ.get("COPO_TEST_DP_FAULT") == "1" else -1,
                             model={"fcnet_hiddens": [64, 64]}))
 assert a.policy.fused is not None and D.is_dist() and world == 2
 for _ in range(3):
     res = a.train()
 assert a.policy.dp_reason, a.policy.dp_reason      # the decision is recorded
+if os.environ.get("COPO_TEST_DP_FAULT") == "1":
+    assert a.policy._dp_mode == "rccl" and "timed out" in a.policy.dp_reason, (a.policy._dp_mode, a.policy.dp_reason)
 want_tile = os.environ.get("COPO_DP_EXCHANGE") == "tile"
 assert (a.policy._tile is not None) == want_tile and (a.policy._dp_mode == "tile") == want_tile, a.policy._dp_mode
 # whole-episode evaluation: the ranks' scenes finish their episode after different fragment counts, the loop holds collectives --
@@ -503,7 +508,8 @@ td.destroy_process_group()
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29561",
-                   COPO_DIST_BACKEND="gloo", COPO_FORCE_DIST="0", COPO_DP_EXCHANGE=peer if peer in ("tile", "auto") else "rccl")
+                   COPO_DIST_BACKEND="gloo", COPO_FORCE_DIST="0", COPO_TEST_DP_FAULT="1" if peer == "try-fault" else "0",
+                   COPO_DP_EXCHANGE=peer if peer in ("tile", "auto") else ("try" if peer == "try-fault" else "rccl"))
         procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     outs = [p.communicate(timeout=600) for p in procs]
