@@ -87,24 +87,28 @@ __device__ __forceinline__ int32_t st_pack(int st, int tm, int age) {
     return (int32_t)((uint32_t)st | ((uint32_t)tm << 8) | ((uint32_t)age << 16));
 }
 
+// (field k of slot (e, n) = state[k * E * N + e * N + n]: a UNIFORM 64-bit field base plus ONE 32-bit lane offset -- the loads and stores
+// then take the scalar-base form of the global instructions instead of a 64-bit vector address per field)
 __device__ __forceinline__ void load_slot(const SimParams& p, int e, int n, Slot& s) {
-    const size_t EN = (size_t)p.E * p.N, o = (size_t)e * p.N + n;
+    const size_t EN = (size_t)p.E * p.N;
+    const unsigned int o = (unsigned int)e * (unsigned int)p.N + (unsigned int)n;      // E * N < 2^31 (copo_sim_create)
     const float* st = p.state;
-    s.x = st[0 * EN + o]; s.y = st[1 * EN + o]; s.th = st[2 * EN + o]; s.v = st[3 * EN + o];
-    s.steer = st[4 * EN + o]; s.throttle = st[5 * EN + o]; s.psteer = st[6 * EN + o]; s.pthrottle = st[7 * EN + o];
-    s.yawrate = st[8 * EN + o]; s.prog = st[9 * EN + o]; s.lcf = st[10 * EN + o]; s.eprew = st[11 * EN + o];
+    s.x = (st + 0 * EN)[o]; s.y = (st + 1 * EN)[o]; s.th = (st + 2 * EN)[o]; s.v = (st + 3 * EN)[o];
+    s.steer = (st + 4 * EN)[o]; s.throttle = (st + 5 * EN)[o]; s.psteer = (st + 6 * EN)[o]; s.pthrottle = (st + 7 * EN)[o];
+    s.yawrate = (st + 8 * EN)[o]; s.prog = (st + 9 * EN)[o]; s.lcf = (st + 10 * EN)[o]; s.eprew = (st + 11 * EN)[o];
     const int32_t* si = reinterpret_cast<const int32_t*>(st);
-    s.route = si[12 * EN + o]; s.status = si[13 * EN + o]; s.aid = si[14 * EN + o]; s.spawncnt = si[15 * EN + o];
+    s.route = (si + 12 * EN)[o]; s.status = (si + 13 * EN)[o]; s.aid = (si + 14 * EN)[o]; s.spawncnt = (si + 15 * EN)[o];
 }
 
 __device__ __forceinline__ void store_slot(const SimParams& p, int e, int n, const Slot& s) {
-    const size_t EN = (size_t)p.E * p.N, o = (size_t)e * p.N + n;
+    const size_t EN = (size_t)p.E * p.N;
+    const unsigned int o = (unsigned int)e * (unsigned int)p.N + (unsigned int)n;
     float* st = p.state;
-    st[0 * EN + o] = s.x; st[1 * EN + o] = s.y; st[2 * EN + o] = s.th; st[3 * EN + o] = s.v;
-    st[4 * EN + o] = s.steer; st[5 * EN + o] = s.throttle; st[6 * EN + o] = s.psteer; st[7 * EN + o] = s.pthrottle;
-    st[8 * EN + o] = s.yawrate; st[9 * EN + o] = s.prog; st[10 * EN + o] = s.lcf; st[11 * EN + o] = s.eprew;
+    (st + 0 * EN)[o] = s.x; (st + 1 * EN)[o] = s.y; (st + 2 * EN)[o] = s.th; (st + 3 * EN)[o] = s.v;
+    (st + 4 * EN)[o] = s.steer; (st + 5 * EN)[o] = s.throttle; (st + 6 * EN)[o] = s.psteer; (st + 7 * EN)[o] = s.pthrottle;
+    (st + 8 * EN)[o] = s.yawrate; (st + 9 * EN)[o] = s.prog; (st + 10 * EN)[o] = s.lcf; (st + 11 * EN)[o] = s.eprew;
     int32_t* si = reinterpret_cast<int32_t*>(st);
-    si[12 * EN + o] = s.route; si[13 * EN + o] = s.status; si[14 * EN + o] = s.aid; si[15 * EN + o] = s.spawncnt;
+    (si + 12 * EN)[o] = s.route; (si + 13 * EN)[o] = s.status; (si + 14 * EN)[o] = s.aid; (si + 15 * EN)[o] = s.spawncnt;
 }
 
 // pose of spawn slot sp: lane `stab[sp][2]` of the spawn road (road 0 of its routes), `sps[sp]` metres in
@@ -450,15 +454,15 @@ __device__ __forceinline__ float div_nr(float n, float a) {
     r = __builtin_fmaf(-a, q, n);
     return __builtin_fmaf(r, y, q);
 }
-// ray_box with that division (sim_packed.hip)
-__device__ __forceinline__ float ray_box_nr(float ox, float oy, float ddx, float ddy, float hl, float hw) {
+// ray_box with that division, as one predicate: `hit` = the ray meets the box, the return value its entering distance (0 from
+// inside).  Same comparisons on the same values as ray_box, evaluated without the nested early exits.
+__device__ __forceinline__ float ray_box_nr(float ox, float oy, float ddx, float ddy, float hl, float hw, bool& hit) {
     const float ax = fabsf(ddx), ay = fabsf(ddy);
     const float oxs = ddx < 0.0f ? -ox : ox, oys = ddy < 0.0f ? -oy : oy;
     const float nxe = -(hl + oxs), nxx = hl - oxs, nye = -(hw + oys), nyx = hw - oys;
-    if (!(nxx >= 0.0f && nyx >= 0.0f)) return -1.0f;
-    if (!(nxe * ay <= nyx * ax)) return -1.0f;
-    if (!(nye * ax <= nxx * ay)) return -1.0f;
-    const bool usex = nxe * ay >= nye * ax;
+    const float exy = nxe * ay, eyx = nye * ax;
+    hit = (nxx >= 0.0f) & (nyx >= 0.0f) & (exy <= nyx * ax) & (eyx <= nxx * ay);
+    const bool usex = exy >= eyx;
     const float n = usex ? nxe : nye, a = usex ? ax : ay;
     return n > 0.0f ? div_nr(n, a) : 0.0f;
 }
@@ -469,7 +473,7 @@ template <bool MAX>
 __device__ __forceinline__ int wave_scan_incl(int v) {
 #define COPO_SCAN_STEP(ctrl, rmask)                                                       \
     {                                                                                     \
-        const int t = __builtin_amdgcn_update_dpp(0, v, ctrl, rmask, 0xf, false);         \
+        const int t = __builtin_amdgcn_update_dpp(0, v, ctrl, rmask, 0xf, (rmask) == 0xf);  \
         v = MAX ? (t > v ? t : v) : v + t;                                                \
     }
     COPO_SCAN_STEP(0x111, 0xf)   // row_shr:1
@@ -480,6 +484,21 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
     COPO_SCAN_STEP(0x143, 0xc)   // row_bcast:31 -> rows 2, 3
 #undef COPO_SCAN_STEP
     return v;                    // identity 0: counts and (lane + 1) markers are non-negative
+}
+
+// The add scan with the DPP control on the add itself (six VALU instructions; the compiler's own lowering of update_dpp + add is a
+// v_mov_b32_dpp and a v_add per step).  `s_nop 1`: a DPP read needs two wait states after the VALU write of its source.
+__device__ __forceinline__ int wave_scan_add(int v) {
+    asm volatile(
+        "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return v;
 }
 
 // Bearing of (u, v) in (-pi, pi], absolute error < 1e-5 rad.  NOT part of the deterministic spec: it only sizes the
@@ -789,7 +808,12 @@ __device__ __forceinline__ void lidar_by_wave(const SimParams& p, PoseF pose, ui
     pk_wave_sync();
     for (int ip0 = 0; ip0 < np; ip0 += CH) {
         const int cha = np - ip0 < CH ? np - ip0 : CH;
-        for (int q = lane; q < cha * NL; q += 64) best[q] = range_bits;
+        {      // ray minima of the chunk := range, 16 bytes per lane and turn (the storage is 16-byte aligned; a tail of < 4 words by the last lanes)
+            const int nw4 = (cha * NL) >> 2;
+            const uint4 r4 = make_uint4(range_bits, range_bits, range_bits, range_bits);
+            for (int q = lane; q < nw4; q += 64) reinterpret_cast<uint4*>(best)[q] = r4;
+            if (lane < ((cha * NL) & 3)) best[4 * nw4 + lane] = range_bits;
+        }
         // pair queue of this chunk of fans, from their reach masks
         int nq = 0;
         {
@@ -846,11 +870,11 @@ __device__ __forceinline__ void lidar_by_wave(const SimParams& p, PoseF pose, ui
             const float rec_sr = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(ci * sj - si * cj)));
             const int ck = __builtin_amdgcn_ds_permute(dst, cnt | (klo << 12) | (lp << 24));      // cnt <= 256 < 2^12, klo < 2^12, lp < 64
             const int cnt_c = lane < nw ? (ck & 0xfff) : 0;
-            const int incl = wave_scan_incl<false>(cnt_c);
+            const int incl = wave_scan_add(cnt_c);
             const int total = __builtin_amdgcn_readlane(incl, 63);
             const int excl = incl - cnt_c;
             // record word of the box tests: first ray - first test (16 bits, signed) | row offset of the fan's ray minima (lp * NL)
-            const int rec_ix = ((((ck >> 12) & 0xfff) - excl) & 0xffff) | (((ck >> 24) * NL) << 16);
+            const int rec_ix = ((((ck >> 12) & 0xfff) - excl) & 0xffff) | ((int)__umul24((unsigned int)(ck >> 24) & 63u, (unsigned int)NL & 0x1ffu) << 16);
             int hb = -1;                              // (heads before this batch of tests) - 1
             for (int t0 = 0; t0 < total; t0 += 64) {
                 seq += 1;
@@ -870,30 +894,35 @@ __device__ __forceinline__ void lidar_by_wave(const SimParams& p, PoseF pose, ui
                 const int pw = __builtin_amdgcn_ds_bpermute(sl, rec_ix);
                 const int t = t0 + lane;
                 if (t < total) {
-                    int k = ((pw << 16) >> 16) + t;
-                    if (k >= NL) k -= NL;
+                    const unsigned int k0 = (unsigned int)(((pw << 16) >> 16) + t);
+                    const unsigned int k = k0 < k0 - (unsigned int)NL ? k0 : k0 - (unsigned int)NL;      // k0 mod NL for k0 < 2 NL, as one v_min_u32
                     const float2 r = reinterpret_cast<const float2*>(rays)[k];
-                    const float tt = ray_box_nr(ox, oy, r.x * cr + r.y * sr, r.y * cr - r.x * sr, hl, hw);
-                    if (tt >= 0.0f) atomicMin(&best[(pw >> 16) + k], __float_as_uint(tt));
+                    bool hit;
+                    const float tt = ray_box_nr(ox, oy, r.x * cr + r.y * sr, r.y * cr - r.x * sr, hl, hw, hit);
+                    if (hit) atomicMin(&best[(unsigned int)(pw >> 16) + k], __float_as_uint(tt));
                 }
             }
         }
         pk_wave_sync();
         if (COPO_PROFILE_SKIP & 4) {
         } else if (vec_out) {
+            // (24-bit multiplies on provably small operands: the 32 / 64-bit multiply-adds the compiler picks for `int` index
+            //  arithmetic run at a quarter of the rate)
+            const unsigned int uNL = (unsigned int)NL & 0x1ffu, uO = (unsigned int)O & 0xffffu, unv = (unsigned int)nvec & 0x7fu;
             for (int q = lane; q < cha * nvec; q += 64) {
-                const int lp = (int)(((float)q + 0.5f) * inv_nvec), k = head + 4 * (q - lp * nvec);
-                const unsigned int* b = best + lp * NL + k;
+                const unsigned int lp = (unsigned int)(int)(((float)q + 0.5f) * inv_nvec) & 63u;
+                const unsigned int k = (unsigned int)head + 4u * ((unsigned int)q - __umul24(lp, unv));
+                const unsigned int* b = best + (__umul24(lp, uNL) + k);
                 float4 v;
                 v.x = __uint_as_float(b[0]) * inv_range; v.y = __uint_as_float(b[1]) * inv_range;
                 v.z = __uint_as_float(b[2]) * inv_range; v.w = __uint_as_float(b[3]) * inv_range;
-                *reinterpret_cast<float4*>(eobs + (int)plist[ip0 + lp] * O + col_lidar + k) = v;
+                *reinterpret_cast<float4*>(eobs + (__umul24((unsigned int)plist[ip0 + lp], uO) + (unsigned int)col_lidar + k)) = v;
             }
             const int nsc = NL - 4 * nvec;
             for (int q = lane; q < cha * nsc; q += 64) {
-                const int lp = (int)(((float)q + 0.5f) * inv_nsc), r = q - lp * nsc;
-                const int k = r < head ? r : r + 4 * nvec;
-                eobs[(int)plist[ip0 + lp] * O + col_lidar + k] = __uint_as_float(best[lp * NL + k]) * inv_range;
+                const unsigned int lp = (unsigned int)(int)(((float)q + 0.5f) * inv_nsc) & 63u, r = (unsigned int)q - __umul24(lp, (unsigned int)nsc & 7u);
+                const unsigned int k = r < (unsigned int)head ? r : r + 4u * unv;
+                eobs[__umul24((unsigned int)plist[ip0 + lp], uO) + (unsigned int)col_lidar + k] = __uint_as_float(best[__umul24(lp, uNL) + k]) * inv_range;
             }
         } else {
             for (int q = lane; q < cha * NL; q += 64) {
