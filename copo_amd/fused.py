@@ -221,7 +221,7 @@ class FusedLearner:
             None if cc is None else cc.data_ptr(), rs["pack"].data_ptr(), None if rs["rows_all"] is None else rs["rows_all"].data_ptr(),
             rs["w_all"].data_ptr(), rs["denom_all"].data_ptr(), kl.data_ptr(), self.step_count.data_ptr(),
             self.workspace.data_ptr(), None if stats is None else stats.data_ptr(), 1 if apply_adam else 0,
-            int(head_mode), rs["k"].data_ptr(), 1 if bump_index else 0,
+            int(head_mode), None if rs["k"] is None else rs["k"].data_ptr(), 1 if bump_index else 0,
             self.flat_t.data_ptr() if theta is None else None, _capi.current_stream()))
 
     def step_dp(self, rs, exchange, stats=None, bump_index=True):

@@ -15,6 +15,8 @@ idx = torch.arange(R, device="cuda")
 pol.prepare_sgd(batch, R, mb)
 pol.plan_epoch(idx, R, [R], mb)
 RS = pol._row_sources if os.environ.get("COPO_BENCH_TABLE") else pol.fused.gather_epoch(pol._row_sources, 160)      # the trainer's way: rows in minibatch order
+if os.environ.get("COPO_BENCH_NOK"):
+    RS = dict(RS, k=None)          # experiment: no device-side minibatch counter (every step takes minibatch 0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 for _ in range(10):
     pol.fused.step(RS, stats=pol.fused.stats)
