@@ -79,9 +79,34 @@ def all_reduce_max_(t):
     return t
 
 
+_reduce_scatter_ok = None      # None: not tried yet; False: this backend has none (gloo), all-reduce instead
+
+
+def reduce_scatter_sum_(out, flat):
+    """Rows [r c, (r + 1) c) of the sum over the ranks of `flat` [world c, ...] for rank r, c = out.shape[0]; returns the tensor that
+    holds them: `out` after a reduce-scatter (half the wire bytes of an all-reduce), or this rank's slice of `flat` after an all-reduce
+    where the backend has no reduce-scatter (gloo: the tests' ranks on one device).  Every rank takes the same branch."""
+    global _reduce_scatter_ok
+    c = out.shape[0]
+    if not _several():
+        return flat[:c]
+    if _reduce_scatter_ok is not False:
+        try:
+            td.reduce_scatter_tensor(out, flat, op=td.ReduceOp.SUM)
+            _reduce_scatter_ok = True
+            return out
+        except (RuntimeError, NotImplementedError, ValueError):
+            if _reduce_scatter_ok:
+                raise
+            _reduce_scatter_ok = False
+    td.all_reduce(flat, op=td.ReduceOp.SUM)
+    r = td.get_rank()
+    return flat[r * c:(r + 1) * c]
+
+
 def all_gather_into_(out, t):
     """out [world, *t.shape] <- every rank's t (same shape everywhere)."""
-    if not is_dist():
+    if not _several():          # (one rank, forced or not: a copy, not a trip through the collective library -- like the sums above)
         out[0].copy_(t)
         return out
     try:
@@ -103,7 +128,7 @@ def all_gather_int(v, device):
 
 def broadcast_module_(module, src=0):
     """Same initial weights on every rank (the reference broadcasts weights from the learner, algo_copo.py:572-577)."""
-    if is_dist():
+    if _several():          # (a world of one, forced or not: the identity -- and the CPU policies of bench.py's cpu_baseline leg have no backend)
         for p in list(module.parameters()) + list(module.buffers()):
             td.broadcast(p.data, src=src)
 

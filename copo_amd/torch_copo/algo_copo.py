@@ -152,6 +152,7 @@ class CoPOPolicy(CCPPOPolicy):
         self._meta = None
         self._meta_bufs = None
         self._meta_side = None
+        self._meta_aux = None           # data-parallel: the small collectives of a pass (row terms, statistics) run here
         self._meta_keep = []
 
     # ---- dense postprocess: three critic heads ----------------------------------------------------------
@@ -440,28 +441,55 @@ class CoPOPolicy(CCPPOPolicy):
         mb_.setdefault("pass_done", [None, None])
         mb_["pass_no"] += 1
         gv, stats_k = mb_["gv2"][q], mb_["stats_k2"][q]
-        fz.meta_rowstat(rs, 0, n_mb, stats_k)        # the statistics of the whole pass in one launch (they do not depend on the GEMMs)
-        if dist:
+        per_pass = dist and self._meta_dist_exchange() == "pass"
+        aux_done = None
+
+        def row_terms():
+            """The pass's statistics and, data-parallel, every rank's row terms (they do not depend on the GEMMs)."""
+            fz.meta_rowstat(rs, 0, n_mb, stats_k)
+            if not dist:
+                return en, mb_["w_all"][:n_mb].unsqueeze(0), mb_["eps_all"][:n_mb].unsqueeze(0)
             S, mb = D.world_size(), mb_["mb"]
             D.all_reduce_sum_(stats_k[:n_mb])
-            en_d = D.all_gather_into_(torch.empty((S,) + tuple(en.shape[1:]), dtype=en.dtype, device=self.device), en[0].contiguous())
-            w_d = D.all_gather_into_(torch.empty(S, n_mb, mb, dtype=torch.float32, device=self.device), mb_["w_all"][:n_mb].contiguous())
-            eps_d = D.all_gather_into_(torch.empty(S, n_mb, mb, dtype=torch.float64, device=self.device), mb_["eps_all"][:n_mb].contiguous())
+            e = D.all_gather_into_(torch.empty((S,) + tuple(en.shape[1:]), dtype=en.dtype, device=self.device), en[0].contiguous())
+            w = D.all_gather_into_(torch.empty(S, n_mb, mb, dtype=torch.float32, device=self.device), mb_["w_all"][:n_mb].contiguous())
+            x = D.all_gather_into_(torch.empty(S, n_mb, mb, dtype=torch.float64, device=self.device), mb_["eps_all"][:n_mb].contiguous())
+            return e, w, x
+
+        if per_pass:
+            # ONE exchange per pass: every chunk exports its gradient pairs into the pass's buffer ([n_mb][2][n], ~105 MB at the bench
+            # shape -- two of them, passes alternate); the ranks then share the pass's dot products: a reduce-scatter leaves every rank
+            # the summed pairs of n_mb / S minibatches (half the wire bytes of an all-reduce), it takes their dot products and an
+            # all-gather of n_mb doubles completes `gv`.  NOTHING of this is on the main stream: the four small collectives (statistics,
+            # row terms) run on `aux` as soon as the pass is planned, the exchange, the dot products and the pass's LCF steps on `side`
+            # behind the last chunk's event -- the main stream goes from this pass's GEMMs straight to the next pass's.
             nf = fz.meta_fold_len()
-            per_pass = self._meta_dist_exchange() == "pass"
-            if per_pass:
-                # ONE exchange per pass: every chunk exports its gradient pairs into the pass's buffer ([n_mb][2][n], ~105 MB at the bench
-                # shape -- two of them, passes alternate), one all-reduce of the whole buffer, one launch of all dot products, the pass's
-                # LCF steps in one launch -- the last three on the side stream.  Five collectives per iteration instead of 25 (fewer,
-                # larger messages are what the links want), none of them in front of the main stream's GEMMs.
-                cap = int(mb_["max_mb"])
-                if mb_.get("g_pass") is None or mb_["g_pass"][0].shape[0] < cap:
-                    mb_["g_pass"] = [torch.zeros(cap, 2, nf, dtype=torch.float32, device=self.device) for _ in range(2)]
-            elif mb_.get("g_chunk") is None or mb_["g_chunk"][0].shape[0] < nb:
-                mb_["g_chunk"] = [torch.zeros(nb, 2, nf, dtype=torch.float32, device=self.device) for _ in range(2)]
+            S = D.world_size()
+            parts_cap = max(1, int(self.config.get("meta_dist_parts", 2)))
+            cap = -(-(-(-int(mb_["max_mb"]) // parts_cap)) // S) * S          # minibatches per part, whole shares: rows beyond a part's own are summed and ignored
+            if mb_.get("g_pass") is None or mb_["g_pass"][0][0].shape[0] < cap or len(mb_["g_pass"][0]) < parts_cap:
+                # (two sets, passes alternate; a buffer per part: a part's exchange may still be on the wire while the next part's GEMMs export)
+                mb_["g_pass"] = [[torch.zeros(cap, 2, nf, dtype=torch.float32, device=self.device) for _ in range(parts_cap)] for _ in range(2)]
+                mb_["g_mine"] = torch.zeros(cap // S, 2, nf, dtype=torch.float32, device=self.device) if S > 1 else None
+                mb_["denom_pad"] = torch.ones(cap, dtype=torch.float32, device=self.device)
+                mb_["gv_pad"] = torch.zeros(cap, dtype=torch.float64, device=self.device)
+            if self._meta_aux is None:
+                self._meta_aux = torch.cuda.Stream(device=self.device)
+            ev0 = torch.cuda.Event()
+            ev0.record()
+            with torch.cuda.stream(self._meta_aux):
+                self._meta_aux.wait_event(ev0)
+                en_d, w_d, eps_d = row_terms()
+                for t in (en_d, w_d, eps_d):
+                    t.record_stream(self._meta_side)
+                aux_done = torch.cuda.Event()
+                aux_done.record()
         else:
-            per_pass = False
-            en_d, w_d, eps_d = en, mb_["w_all"][:n_mb].unsqueeze(0), mb_["eps_all"][:n_mb].unsqueeze(0)
+            en_d, w_d, eps_d = row_terms()
+            if dist:
+                nf = fz.meta_fold_len()
+                if mb_.get("g_chunk") is None or mb_["g_chunk"][0].shape[0] < nb:
+                    mb_["g_chunk"] = [torch.zeros(nb, 2, nf, dtype=torch.float32, device=self.device) for _ in range(2)]
         priv = dict(denom=mb_["denom_all"], en=en_d, w=w_d, eps=eps_d)       # (set q of the planned tables: not written before pass_done[q])
 
         def lcf_steps(c0, n):
@@ -480,26 +508,29 @@ class CoPOPolicy(CCPPOPolicy):
             lcf_steps(c0, n)
 
         if per_pass:
-            buf = mb_["g_pass"][q]
-            for c0 in range(0, n_mb, nb):
-                n = min(nb, n_mb - c0)
-                grads(rs, c0, n, gv, None, g_out=buf[c0:c0 + n])
-            work = D.all_reduce_sum_async(buf[:n_mb])
-            # everything behind the exchange -- the wait for it, the dot products, the pass's LCF steps -- goes to the SIDE stream: the
-            # main stream moves on to the next pass's GEMMs (they do not depend on the LCF parameters) while the collective is on the
-            # wire; the buffers of this pass are taken again two passes later, behind pass_done[q]
-            ev = torch.cuda.Event()
-            ev.record()
+            # `meta_dist_parts` exchanges per pass (default 2): the LCF steps of the first part run under the GEMMs of the second, so what
+            # the last pass leaves exposed at the end of the iteration is half a pass of LCF steps, not a whole one
+            parts = max(1, min(int(self.config.get("meta_dist_parts", 2)), n_mb))
+            bounds = [n_mb * i // parts for i in range(parts + 1)]
             done = torch.cuda.Event()
-            with torch.cuda.stream(self._meta_side):
-                self._meta_side.wait_event(ev)
-                if work is not None:
-                    work.wait()               # (the side stream waits; neither the host nor the main stream does)
-                fz.meta_batch_dot(buf, nf, n_mb, gv, denom=mb_["denom_all"])
-                fz.meta_batch_lcf(dict(denom_all=priv["denom"]), n_mb, None, gv, stats_k,
-                                  self.model.lcf_parameters.data, self._raw_ms, self._lcf_adam, self.config[LCF_LR], mb_["stats"],
-                                  0, 0, dense=(en_d, w_d, eps_d), k_first=0, k_count=n_mb)
-                done.record()
+            for pi in range(parts):
+                k0, k1 = bounds[pi], bounds[pi + 1]
+                buf = mb_["g_pass"][q][pi]
+                for c0 in range(k0, k1, nb):
+                    n = min(nb, k1 - c0)
+                    grads(rs, c0, n, gv, None, g_out=buf[c0 - k0:c0 - k0 + n])
+                ev = torch.cuda.Event()
+                ev.record()
+                with torch.cuda.stream(self._meta_side):
+                    self._meta_side.wait_event(ev)
+                    self._meta_shared_dots(buf, nf, k0, k1 - k0, gv)
+                    if pi == 0:
+                        self._meta_side.wait_event(aux_done)
+                    fz.meta_batch_lcf(dict(denom_all=priv["denom"]), n_mb, None, gv, stats_k,
+                                      self.model.lcf_parameters.data, self._raw_ms, self._lcf_adam, self.config[LCF_LR], mb_["stats"],
+                                      0, 0, dense=(en_d, w_d, eps_d), k_first=k0, k_count=k1 - k0)
+                    if pi == parts - 1:
+                        done.record()
             mb_["pass_done"][q] = done
             mb_["gv"], mb_["stats_k"] = gv, stats_k
             self._meta_keep.append(priv)
@@ -526,6 +557,24 @@ class CoPOPolicy(CCPPOPolicy):
         mb_["pass_done"][q] = done
         mb_["gv"], mb_["stats_k"] = gv, stats_k          # (what the callers / tests read after the pass)
         self._meta_keep.append(priv)            # alive until the side stream has been joined
+
+    def _meta_shared_dots(self, buf, nf, k0, n, gv):
+        """gv[k0 : k0 + n] = <sum over ranks of g_new, sum over ranks of g_old> of the n minibatches whose exported pairs `buf` holds, the
+        work shared by the ranks: rank r receives the summed pairs of minibatches [r c, (r + 1) c) of the part (reduce-scatter; a backend
+        without it all-reduces), takes their dot products with the kernel every other path uses -- so a minibatch's value does not depend
+        on who computed it -- and the values are gathered.  Runs on the current (side) stream."""
+        mb_, fz = self._meta_bufs, self.fused
+        S, r = D.world_size(), D.rank()
+        mb_["denom_pad"][:n].copy_(mb_["denom_all"][k0:k0 + n])
+        if S == 1:
+            fz.meta_batch_dot(buf, nf, n, gv[k0:], denom=mb_["denom_pad"])
+            return
+        c = -(-n // S)
+        mine = D.reduce_scatter_sum_(mb_["g_mine"][:c], buf[:S * c])
+        part = mb_["gv_pad"][r * c:(r + 1) * c]
+        fz.meta_batch_dot(mine, nf, c, part, denom=mb_["denom_pad"][r * c:])
+        every = D.all_gather_into_(torch.empty(S, c, dtype=torch.float64, device=self.device), part)
+        gv[k0:k0 + n].copy_(every.reshape(-1)[:n])
 
     def _meta_lcf_async(self, n_mb, en, w, eps):
         """Phase B of this pass on a side stream: the sequential LCF kernel keeps ONE compute unit busy for ~0.4 ms, and
@@ -631,6 +680,8 @@ class CoPOPolicy(CCPPOPolicy):
                 steps += 1
         if self._meta_side is not None:
             torch.cuda.current_stream().wait_stream(self._meta_side)
+        if self._meta_aux is not None:
+            torch.cuda.current_stream().wait_stream(self._meta_aux)
         self._meta_keep.clear()
         m = self.model
         # one device -> host read for everything this iteration reports about the meta update
