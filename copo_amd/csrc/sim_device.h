@@ -8,6 +8,9 @@
 #ifndef COPO_PROFILE_SKIP
 #define COPO_PROFILE_SKIP 0
 #endif
+// mask 256: nothing compiled out, the LiDAR phase counts its work into the debug rows [E][16] (8 queued pairs, 9 pair batches, 10 box
+// tests, 11 test batches, 12 hits, 13 pairs with a ray window); needs `p`, `e`, `lane` in scope
+#define COPO_COUNT(slot, v) do { if ((COPO_PROFILE_SKIP & 256) && p.dbg && lane == 0) p.dbg[(size_t)e * 16 + (slot)] += (long long)(v); } while (0)
 
 namespace copo {
 
@@ -829,7 +832,9 @@ __device__ __forceinline__ void lidar_by_wave(const SimParams& p, PoseF pose, ui
             }
         }
         pk_wave_sync();
+        COPO_COUNT(8, nq);
         for (int q0 = 0; q0 < ((COPO_PROFILE_SKIP & 2) ? 0 : nq); q0 += 64) {
+            COPO_COUNT(9, 1);
             const bool live = q0 + lane < nq;
             const int ent = live ? (int)cq[q0 + lane] : 0;
             const int lp = ent >> 8, j = ent & 255;
@@ -862,6 +867,7 @@ __device__ __forceinline__ void lidar_by_wave(const SimParams& p, PoseF pose, ui
             // holds a pair when all 64 have a window)
             const unsigned long long mw = __ballot(cnt > 0);
             const int nw = __popcll(mw);
+            COPO_COUNT(13, nw);
             if (nw == 0) continue;
             const int dst = (cnt > 0 ? pk_mbcnt(mw) : 63) << 2;
             const float rec_ox = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(-(dx * cj + dy * sj))));
@@ -876,6 +882,8 @@ __device__ __forceinline__ void lidar_by_wave(const SimParams& p, PoseF pose, ui
             // record word of the box tests: first ray - first test (16 bits, signed) | row offset of the fan's ray minima (lp * NL)
             const int rec_ix = ((((ck >> 12) & 0xfff) - excl) & 0xffff) | ((int)__umul24((unsigned int)(ck >> 24) & 63u, (unsigned int)NL & 0x1ffu) << 16);
             int hb = -1;                              // (heads before this batch of tests) - 1
+            COPO_COUNT(10, total);
+            COPO_COUNT(11, (total + 63) >> 6);
             for (int t0 = 0; t0 < total; t0 += 64) {
                 seq += 1;
                 if (cnt_c > 0 && excl >= t0 && excl < t0 + 64) wtag[excl - t0] = seq;
@@ -900,6 +908,7 @@ __device__ __forceinline__ void lidar_by_wave(const SimParams& p, PoseF pose, ui
                     bool hit;
                     const float tt = ray_box_nr(ox, oy, r.x * cr + r.y * sr, r.y * cr - r.x * sr, hl, hw, hit);
                     if (hit) atomicMin(&best[(unsigned int)(pw >> 16) + k], __float_as_uint(tt));
+                    if (COPO_PROFILE_SKIP & 256) { const int nh = __popcll(__ballot(hit)); COPO_COUNT(12, nh); }
                 }
             }
         }

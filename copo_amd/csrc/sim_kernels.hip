@@ -22,7 +22,7 @@
 #define COPO_DBG_STRIDE ((COPO_PROFILE_SKIP & 0x1300) ? 16 : 8)
 // (mask 512: the wave roles' own finishing times -- slot 8 wave 0, slot 9 wave 1, slot 10 the last LiDAR wave; scripts/phase_sim.py)
 #define COPO_ROLE_STAMP(slot) do { if ((COPO_PROFILE_SKIP & 512) && p.dbg && lane == 0) atomicMax(reinterpret_cast<unsigned long long*>(p.dbg) + (size_t)e * 16 + (slot), (unsigned long long)clock64()); } while (0)
-#define COPO_COUNT(slot, v) do { if ((COPO_PROFILE_SKIP & 256) && p.dbg && lane == 0) p.dbg[(size_t)e * 16 + (slot)] += (long long)(v); } while (0)
+// (COPO_COUNT: sim_device.h)
 
 namespace copo {
 

@@ -28,6 +28,6 @@ for i in range(n):
     out = sim.step(cruise_actions(out["obs"], gen))
     pres += float(((out["flags"] & 0x41) != 0).float().sum()) / E
 torch.cuda.synchronize()
-c = dbg[:, 8:13].double().mean(0).cpu() / n
-print("per scene and step: present %.1f | queued pairs %.1f  pair batches %.2f (fill %.0f %%) | box tests %.1f  test batches %.2f (fill %.0f %%)  hits %.1f (%.0f %% of tests)"
-      % (pres / n, c[0], c[1], 100 * c[0] / max(c[1] * 64, 1), c[2], c[3], 100 * c[2] / max(c[3] * 64, 1), c[4], 100 * c[4] / max(c[2], 1)))
+c = dbg[:, 8:14].double().mean(0).cpu() / n
+print("per scene and step: present %.1f | queued pairs %.1f  pair batches %.2f (fill %.0f %%) | box tests %.1f  test batches %.2f (fill %.0f %%)  hits %.1f (%.0f %% of tests) | pairs with a window %.1f"
+      % (pres / n, c[0], c[1], 100 * c[0] / max(c[1] * 64, 1), c[2], c[3], 100 * c[2] / max(c[3] * 64, 1), c[4], 100 * c[4] / max(c[2], 1), c[5]))

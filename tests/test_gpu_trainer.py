@@ -228,8 +228,18 @@ assert a.policy.fused is not None
 for _ in range(3):
     res = a.train()
 w = a.policy.model._hidden_layers[0]._model[0].weight
+rs_ok = None
+if D.is_dist():
+    # the collective the shared dot products of the meta pass use with several ranks (dist.reduce_scatter_sum_): with RCCL and a world of
+    # one it must exist in this build and hand the input through
+    import torch.distributed as td
+    flat = torch.arange(24, dtype=torch.float32, device="cuda").reshape(4, 2, 3)
+    out = torch.zeros_like(flat)
+    td.reduce_scatter_tensor(out, flat, op=td.ReduceOp.SUM)
+    torch.cuda.synchronize()
+    rs_ok = bool(torch.equal(out, flat))
 print("RESULT " + json.dumps(dict(dist=D.is_dist(), lcf=a.policy.model.lcf_parameters.tolist(), w=float(w.double().abs().sum()),
-                                  loss=res["info"]["learner"]["default"]["learner_stats"]["total_loss"])))
+                                  loss=res["info"]["learner"]["default"]["learner_stats"]["total_loss"], rs_ok=rs_ok)))
 '''
     outs = []
     for force in ("0", "1"):
@@ -240,6 +250,7 @@ print("RESULT " + json.dumps(dict(dist=D.is_dist(), lcf=a.policy.model.lcf_param
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
         outs.append(__import__("json").loads(line[7:]))
     assert outs[0]["dist"] is False and outs[1]["dist"] is True
+    assert outs[1]["rs_ok"] is True
     np.testing.assert_allclose(outs[1]["lcf"], outs[0]["lcf"], rtol=1e-5, atol=1e-8)
     np.testing.assert_allclose(outs[1]["w"], outs[0]["w"], rtol=1e-5)
     np.testing.assert_allclose(outs[1]["loss"], outs[0]["loss"], rtol=1e-3, atol=1e-5)
