@@ -210,6 +210,23 @@ extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** o
     p.inv_toll = cfg->toll_dim ? 1.0f / (float)(cfg->toll_min_steps > 0 ? cfg->toll_min_steps : 1) : 0.0f;
     p.h_sub = cfg->dt / (float)cfg->substeps;
     p.ray_sign = (cfg->num_lasers > 2 && cfg->ray_cs[3] < 0.0f) ? -1.0f : 1.0f;   // the beam table's sense of rotation
+    // detector beams: evenly spaced?  (then a line primitive only meets a WINDOW of them, detector_window in sim_device.h)
+    auto even_table = [](const float* cs, int n, float& theta0, float& rpr) {
+        theta0 = 0.0f; rpr = 0.0f;
+        if (n < 3 || !cs) return;
+        const double two_pi = 6.283185307179586;
+        const double th0 = std::atan2((double)cs[1], (double)cs[0]);
+        double step = std::atan2((double)cs[3], (double)cs[2]) - th0;
+        step = step > two_pi / 2 ? step - two_pi : (step < -two_pi / 2 ? step + two_pi : step);
+        bool even = std::fabs(std::fabs(step) * n - two_pi) < 1e-3;
+        for (int k = 0; k < n && even; ++k) {
+            const double want = th0 + k * step;
+            even = std::fabs(cs[2 * k] - std::cos(want)) < 1e-4 && std::fabs(cs[2 * k + 1] - std::sin(want)) < 1e-4;
+        }
+        if (even) { theta0 = (float)th0; rpr = (float)(1.0 / step); }
+    };
+    even_table(cfg->side_cs, cfg->side_lasers, p.side_theta0, p.side_rpr);
+    even_table(cfg->lane_line_cs, cfg->lane_line_lasers, p.lane_theta0, p.lane_rpr);
     p.n_safe = (int32_t)safe.size();
     p.n_spaces = 0;
     for (int r = 0; r < cfg->n_routes; ++r) {

@@ -11,6 +11,9 @@
 // mask 256: nothing compiled out, the LiDAR phase counts its work into the debug rows [E][16] (8 queued pairs, 9 pair batches, 10 box
 // tests, 11 test batches, 12 hits, 13 pairs with a ray window); needs `p`, `e`, `lane` in scope
 #define COPO_COUNT(slot, v) do { if ((COPO_PROFILE_SKIP & 256) && p.dbg && lane == 0) p.dbg[(size_t)e * 16 + (slot)] += (long long)(v); } while (0)
+// mask 16384: the detector beams count theirs into the same slots of row `ecount` (8 candidate batches, 9 near pairs, 10 pair batches,
+// 11 beam tests, 12 test batches, 13 hits)
+#define COPO_DCOUNT(slot, v) do { if ((COPO_PROFILE_SKIP & 16384) && p.dbg && lane == 0 && ecount >= 0) p.dbg[(size_t)ecount * 16 + (slot)] += (long long)(v); } while (0)
 
 namespace copo {
 
@@ -370,34 +373,39 @@ __device__ __forceinline__ void ego_navi_obs(const SimParams& p, const LT& L, fl
 }
 
 // One detector beam against the lane-line primitives (MetaDrive SideDetector / LaneLineDetector): see the oracle's
-// detector_ray for the arithmetic, which this repeats operation by operation.
-// one line primitive against one beam: `best` is lowered to the hit distance if the beam meets the primitive before it
-__device__ __forceinline__ void detector_line(const float* __restrict__ Ln, float x, float y, float dx, float dy, float& best) {
+// detector_ray for the arithmetic, which this repeats operation by operation.  The result of a beam is a pure MINIMUM over the
+// primitives' hit distances, so the primitives may be visited in any order and by any lane.
+// one line primitive against one beam: the hit distance (>= +0), or a negative value when the beam does not meet the primitive
+__device__ __forceinline__ float detector_line_hit(const float* __restrict__ Ln, float x, float y, float dx, float dy) {
     if (Ln[6] == 0.0f) {
         const float rx = Ln[1] - x, ry = Ln[2] - y;
         const float den = dx * Ln[4] - dy * Ln[3];
-        if (den == 0.0f) return;
+        if (den == 0.0f) return -1.0f;
         const float sd = den > 0.0f ? 1.0f : -1.0f;
         const float ad = den * sd;
         const float tn = (rx * Ln[4] - ry * Ln[3]) * sd;
         const float un = (rx * dy - ry * dx) * sd;
-        if (!(tn >= 0.0f && un >= 0.0f && un <= Ln[5] * ad && tn < best * ad)) return;
-        best = tn / ad;
-    } else {
-        const float R = 1.0f / fabsf(Ln[6]);
-        const float mx = x - Ln[7], my = y - Ln[8];
-        const float b = mx * dx + my * dy;
-        const float cq = mx * mx + my * my - R * R;
-        const float disc = b * b - cq;
-        if (!(disc >= 0.0f)) return;
-        const float sq = sqrtf(disc);
-        for (int r = 0; r < 2; ++r) {
-            const float tt = r == 0 ? -b - sq : -b + sq;
-            if (!(tt >= 0.0f && tt < best)) continue;
-            const float hx = mx + tt * dx, hy = my + tt * dy;
-            if (hx * Ln[9] + hy * Ln[10] >= R * Ln[11]) { best = tt; break; }
-        }
+        if (!(tn >= 0.0f && un >= 0.0f && un <= Ln[5] * ad)) return -1.0f;
+        return tn / ad + 0.0f;
     }
+    const float R = 1.0f / fabsf(Ln[6]);
+    const float mx = x - Ln[7], my = y - Ln[8];
+    const float b = mx * dx + my * dy;
+    const float cq = mx * mx + my * my - R * R;
+    const float disc = b * b - cq;
+    if (!(disc >= 0.0f)) return -1.0f;
+    const float sq = sqrtf(disc);
+    for (int r = 0; r < 2; ++r) {
+        const float tt = (r == 0 ? -b - sq : -b + sq) + 0.0f;
+        if (!(tt >= 0.0f)) continue;
+        const float hx = mx + tt * dx, hy = my + tt * dy;
+        if (hx * Ln[9] + hy * Ln[10] >= R * Ln[11]) return tt;
+    }
+    return -1.0f;
+}
+__device__ __forceinline__ void detector_line(const float* __restrict__ Ln, float x, float y, float dx, float dy, float& best) {
+    const float t = detector_line_hit(Ln, x, y, dx, dy);
+    if (t >= 0.0f && t < best) best = t;
 }
 __device__ __forceinline__ float detector_ray(const SimParams& p, const float* __restrict__ lines, float x, float y, float dx,
                                               float dy, float range, float min_kind) {
@@ -715,13 +723,13 @@ __device__ __forceinline__ unsigned long long pk_uni64(unsigned long long v) {  
            (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)v);
 }
 
-// Side / lane-line detector beams (Bottleneck, Tollgate, generated roads) of `np` present agents by `nth` threads (WG: the threads of
-// a workgroup, else one wave).  A beam only meets the primitives within its range of the vehicle: one pass marks, per agent, the
+// Fallback of detector_beams (below) for configurations whose LDS scratch cannot hold a row of beam minima: side / lane-line detector
+// beams of `np` present agents by `nth` threads (WG: the threads of a workgroup, else one wave).  A beam only meets the primitives within its range of the vehicle: one pass marks, per agent, the
 // primitives near enough for each of the two detectors (bit masks in `scratch`, 8 words per agent, `cap` words in all); the beams then
 // walk the marked primitives in table order -- the order in which the exhaustive loop (detector_ray, the oracle's) lowers `best`, so
 // the result is that loop's, bit for bit: a primitive left out cannot lower it.
 template <bool WG, class PoseF>
-__device__ __forceinline__ void detector_beams(const SimParams& p, PoseF pose, const uint8_t* plist, int np, unsigned int* scratch, int cap,
+__device__ __forceinline__ void detector_beams_walk(const SimParams& p, PoseF pose, const uint8_t* plist, int np, unsigned int* scratch, int cap,
                                                float* __restrict__ eobs, int tid, int nth) {
     const int nb = p.side_lasers + p.lane_lasers, NLn = p.n_lines, O = p.O;
     if (nb <= 0) return;
@@ -764,6 +772,235 @@ __device__ __forceinline__ void detector_beams(const SimParams& p, PoseF pose, c
                 }
             }
             eobs[i * O + (side ? k : p.col_lane + k)] = best * (side ? p.inv_side_range : p.inv_lane_range);
+        }
+    }
+}
+
+
+// Conservative window of detector beams that can meet line primitive Ln from (x, y) with heading (c, s): first beam `klo` in
+// [0, nbeam) and the number of beams `cnt` (0 .. nbeam, the window wraps round).  The beams are evenly spaced (`rpr` beams per
+// radian, signed; beam 0 at `theta0` in the vehicle frame -- checked on the host, else rpr = 0: every beam).  A straight piece
+// subtends the interval between the bearings of its end points (the short way round: less than pi unless the origin lies on it); an
+// arc is covered by a disc -- round the chord's mid point for a half angle up to pi / 2, else the arc's own circle.  NOT part of the
+// deterministic spec: a beam outside the window cannot meet the primitive, every hit / miss decision stays with detector_line_hit.
+__device__ __forceinline__ void detector_window(const float* __restrict__ Ln, float x, float y, float c, float s, float theta0, float rpr,
+                                                int nbeam, int& klo, int& cnt) {
+    klo = 0; cnt = nbeam;
+    if (rpr == 0.0f) return;
+    float ua, ub;                                  // beam coordinates of the interval's ends
+    const float marg = 0.004f * fabsf(rpr) + 0.02f;      // atan2_window < 1e-5 rad, the asin bound, rounding
+    if (Ln[6] == 0.0f) {
+        const float ax = Ln[1] - x, ay = Ln[2] - y;
+        const float bx = ax + Ln[5] * Ln[3], by = ay + Ln[5] * Ln[4];
+        if (!(ax * ax + ay * ay > 1e-4f) || !(bx * bx + by * by > 1e-4f)) return;      // at an end point: every beam meets it at distance 0
+        const float fa = atan2_window(c * ay - s * ax, c * ax + s * ay), fb = atan2_window(c * by - s * bx, c * bx + s * by);
+        float d = fb - fa;
+        d = d > 3.14159265f ? d - 6.28318531f : (d < -3.14159265f ? d + 6.28318531f : d);
+        if (!(fabsf(d) < 3.0f)) return;            // the origin (almost) on the piece: which way round is not decided here
+        ua = (fa - theta0) * rpr;
+        ub = ua + d * rpr;
+    } else {
+        const float R = 1.0f / fabsf(Ln[6]);
+        const float ch = Ln[11] > 0.0f ? Ln[11] : 0.0f;               // cos of the half angle, 0 beyond a quarter turn: the whole circle's disc
+        const float mx = Ln[7] + R * ch * Ln[9] - x, my = Ln[8] + R * ch * Ln[10] - y;
+        const float rho = R * sqrtf(fmaxf(1.0f - ch * ch, 0.0f)) * 1.001f + 0.01f;
+        const float d2 = mx * mx + my * my;
+        if (!(d2 > rho * rho * 1.01f)) return;     // inside (or next to) the disc
+        const float q = rho * __builtin_amdgcn_rsqf(d2);
+        const float w = (q + 0.5708f * q * q * q) * 1.001f;           // >= asin(rho / distance)
+        const float fm = atan2_window(c * my - s * mx, c * mx + s * my);
+        ua = (fm - w - theta0) * rpr;
+        ub = (fm + w - theta0) * rpr;
+    }
+    const float lo = fminf(ua, ub) - marg, hi = fmaxf(ua, ub) + marg;
+    const int ilo = (int)ceilf(lo), ihi = (int)floorf(hi);
+    const int n = ihi - ilo + 1;
+    if (n >= nbeam) return;
+    cnt = n < 0 ? 0 : n;
+    int k = ilo + 2 * nbeam;                       // |ua|, |ub| < (2 pi + pi) |rpr| + margin < 1.6 nbeam: k in (0, 4 nbeam)
+    k = k >= 2 * nbeam ? k - 2 * nbeam : k;
+    k = k >= nbeam ? k - nbeam : k;
+    klo = k < 0 ? 0 : k;
+}
+
+// Side / lane-line detector beams (Bottleneck, Tollgate, generated roads) of `np` present agents by `nth` threads (WG: the threads of
+// a workgroup -- whole waves, `tid` beyond them for waves that only meet the barriers -- else one wave).  The result of a beam is a
+// pure minimum over the primitives (detector_line_hit), so the work is laid out by (agent, primitive, detector) PAIRS as in the LiDAR:
+//   1. candidates (agent, primitive) in batches of 64: is the primitive within the detector's range of the agent (detector_line_near)?
+//      The pairs that are, are pushed together ACROSS batches (a pending batch in the lanes' registers, ds_permute), so that
+//   2. full batches of 64 pairs get their window of beams (detector_window), the windows are numbered through by a scan and every lane
+//      takes one (beam, primitive) test (owner = ballot + mbcnt of the batch's head flags, as in lidar_by_wave), folding its hit into
+//      the agent's row of beam minima in `scratch` (`cap` words: cap / beams agents per pass) with an LDS atomicMin on the float bits.
+// Tollgate: ~220 tests per agent instead of 76 beams x ~15 marked primitives.  `wtag`: 64 words of the calling wave (head flags).
+template <bool WG, class PoseF>
+__device__ __forceinline__ void detector_beams(const SimParams& p, PoseF pose, const uint8_t* plist, int np, unsigned int* scratch, int cap,
+                                               float* __restrict__ eobs, int tid, int nth, int* wtag, int ecount = -1) {
+    const int ns = p.side_lasers, nl = p.lane_lasers, nb = ns + nl, NLn = p.n_lines, O = p.O;
+    if (nb <= 0) return;
+    if (cap < nb || NLn > 255) {                   // (no room for one row of minima: the walk over marked primitives)
+        detector_beams_walk<WG>(p, pose, plist, np, scratch, cap, eobs, tid, nth);
+        return;
+    }
+    auto sync = [&]() {
+        if (WG) __syncthreads();
+        else pk_wave_sync();
+    };
+    const bool working = tid < nth;                // (WG: waves that only meet the barriers carry a huge tid)
+    const int lane = threadIdx.x & 63;
+    const int wv = working ? (tid >> 6) : 0, nwv = nth >> 6;
+    const int G = cap / nb < 64 ? cap / nb : 64;  // agents per pass
+    const float inv_nb = 1.0f / (float)nb;
+    const unsigned int side_bits = __float_as_uint(p.side_range), lane_bits = __float_as_uint(p.lane_range);
+    int seq = 0;
+    if (working) wtag[lane] = 0;
+    for (int ip0 = 0; ip0 < np; ip0 += G) {
+        const int na = np - ip0 < G ? np - ip0 : G;
+        sync();
+        for (int q = tid; q < na * nb; q += nth) {
+            const int ia = (int)(((float)q + 0.5f) * inv_nb), b = q - ia * nb;
+            scratch[q] = b < ns ? side_bits : lane_bits;
+        }
+        sync();
+        // a batch of `n` pairs, record ia | l << 8 | detector << 16 in lanes 0 .. n - 1: windows, scan, tests.  The lane of a pair (its
+        // owner) derives everything a beam test reads from the pair ONCE -- rx, ry / mx, my, cq, R cos(half angle): the same operations
+        // detector_line_hit performs per beam, so the same bits -- and the test lanes fetch it from the owner with ds_bpermute: no global
+        // load between a test's number and its atomicMin but the beam table's
+        auto tests = [&](int rec, int n) {
+            const bool live = lane < n;
+            int klo = 0, cnt = 0;
+            float fa = 0.0f, fb = 0.0f, fc = 0.0f, fd = 0.0f, fe = 0.0f, ff = 0.0f, hc = 1.0f, hs = 0.0f;
+            if (live) {
+                const int ia = rec & 63, l = (rec >> 8) & 255;
+                const bool side = ((rec >> 16) & 1) == 0;
+                const float4 pi = pose((int)plist[ip0 + ia]);
+                const float* Ln = p.lines + (size_t)l * COPO_LINE_STRIDE;
+                detector_window(Ln, pi.x, pi.y, pi.z, pi.w, side ? p.side_theta0 : p.lane_theta0,
+                                side ? p.side_rpr : p.lane_rpr, side ? ns : nl, klo, cnt);
+                cnt = cnt < 1 ? 1 : cnt;           // (an empty window still takes one test: every live lane heads a run of tests)
+                hc = pi.z; hs = pi.w;
+                if (Ln[6] == 0.0f) {
+                    fa = Ln[1] - pi.x; fb = Ln[2] - pi.y; fc = Ln[3]; fd = Ln[4]; fe = Ln[5];
+                } else {
+                    const float R = 1.0f / fabsf(Ln[6]);
+                    fa = pi.x - Ln[7]; fb = pi.y - Ln[8]; fc = Ln[9]; fd = Ln[10]; fe = R * Ln[11];
+                    ff = fa * fa + fb * fb - R * R;
+                    rec |= 1 << 17;                // an arc
+                }
+            }
+            const int incl = wave_scan_add(cnt);
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            const int excl = incl - cnt;
+            const int rec_k = klo - excl;          // first beam - first test
+            COPO_DCOUNT(10, 1); COPO_DCOUNT(11, total); COPO_DCOUNT(12, (total + 63) >> 6);
+            int hb = -1;
+            for (int t0 = 0; t0 < total; t0 += 64) {
+                seq += 1;
+                if (cnt > 0 && excl >= t0 && excl < t0 + 64) wtag[excl - t0] = seq;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const bool hd = wtag[lane] == seq;
+                const unsigned long long H = __ballot(hd);
+                const int own = hb + pk_mbcnt(H) + (hd ? 1 : 0);
+                hb += __popcll(H);
+                __builtin_amdgcn_wave_barrier();
+                const int sl = own << 2;
+                auto from = [&](float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(sl, __float_as_int(v))); };
+                const int ra = __builtin_amdgcn_ds_bpermute(sl, rec);
+                const int rk = __builtin_amdgcn_ds_bpermute(sl, rec_k);
+                const float ga = from(fa), gb = from(fb), gc = from(fc), gd = from(fd), ge = from(fe), gf = from(ff), c = from(hc), sn = from(hs);
+                const int t = t0 + lane;
+                if (t < total) {
+                    const bool side = ((ra >> 16) & 1) == 0;
+                    const int nbeam = side ? ns : nl;
+                    int k = rk + t;                     // beam of this test: in [klo, klo + cnt), the window wraps
+                    k = k >= nbeam ? k - nbeam : k;
+                    const float2 ab = reinterpret_cast<const float2*>(side ? p.side_cs : p.lane_cs)[k];
+                    const float dx = c * ab.x - sn * ab.y, dy = sn * ab.x + c * ab.y;
+                    float th = -1.0f;                   // detector_line_hit on the owner's quantities, operation by operation
+                    if (!((ra >> 17) & 1)) {
+                        const float den = dx * gd - dy * gc;
+                        if (den != 0.0f) {
+                            const float sd = den > 0.0f ? 1.0f : -1.0f;
+                            const float ad = den * sd;
+                            const float tn = (ga * gd - gb * gc) * sd;
+                            const float un = (ga * dy - gb * dx) * sd;
+                            if (tn >= 0.0f && un >= 0.0f && un <= ge * ad) th = tn / ad + 0.0f;
+                        }
+                    } else {
+                        const float b = ga * dx + gb * dy;
+                        const float disc = b * b - gf;
+                        if (disc >= 0.0f) {
+                            const float sq = sqrtf(disc);
+                            for (int r = 0; r < 2; ++r) {
+                                const float tt = (r == 0 ? -b - sq : -b + sq) + 0.0f;
+                                if (!(tt >= 0.0f)) continue;
+                                const float hx = ga + tt * dx, hy = gb + tt * dy;
+                                if (hx * gc + hy * gd >= ge) { th = tt; break; }
+                            }
+                        }
+                    }
+                    if (th >= 0.0f) atomicMin(&scratch[(ra & 63) * nb + (side ? 0 : ns) + k], __float_as_uint(th));
+                    if (COPO_PROFILE_SKIP & 16384) { const int nh = __popcll(__ballot(th >= 0.0f)); COPO_DCOUNT(13, nh); }
+                }
+            }
+        };
+        // candidates: lane = line primitive (its record in the lane's registers, read once per block of 64 lines), one agent per turn --
+        // no memory access in the turn but the agent's pose (LDS, one address for the wave)
+        int pend = 0, npend = 0;                   // the pending batch: records in lanes 0 .. npend - 1 (npend < 64, uniform)
+        for (int l0 = 0; l0 < (working ? NLn : 0); l0 += 64) {
+            const int l = l0 + lane;
+            const bool has = l < NLn;
+            const float* Ln = p.lines + (size_t)(has ? l : 0) * COPO_LINE_STRIDE;
+            const float kind = has ? Ln[0] : 0.0f, kap = Ln[6];
+            const float px = kap == 0.0f ? Ln[1] : Ln[7], py = kap == 0.0f ? Ln[2] : Ln[8];       // start point / arc centre
+            const float ux = Ln[3], uy = Ln[4], len = Ln[5];
+            const float Rr = kap == 0.0f ? 0.0f : 1.0f / fabsf(kap);
+            for (int det = 0; det < 2; ++det) {    // 0: side detector (continuous lines), 1: lane-line detector (every line)
+                if ((det == 0 ? ns : nl) <= 0) continue;
+                const float range = det == 0 ? p.side_range : p.lane_range, min_kind = det == 0 ? 2.0f : 1.0f;
+                const float lim = range * 1.001f + 0.01f;          // (detector_line_near, on the lane's registers)
+                for (int ia = wv; ia < na; ia += nwv) {
+                    const float4 pi = pose((int)plist[ip0 + ia]);
+                    bool near = false;
+                    if (kind >= min_kind) {
+                        const float rx = pi.x - px, ry = pi.y - py;
+                        if (kap == 0.0f) {
+                            float t = rx * ux + ry * uy;
+                            t = t < 0.0f ? 0.0f : (t > len ? len : t);
+                            const float ex = rx - t * ux, ey = ry - t * uy;
+                            near = ex * ex + ey * ey <= lim * lim;
+                        } else {
+                            near = fabsf(sqrtf(rx * rx + ry * ry) - Rr) <= lim;
+                        }
+                    }
+                    const unsigned long long mn = __ballot(near);
+                    const int nn = __popcll(mn);
+                    COPO_DCOUNT(8, 1); COPO_DCOUNT(9, nn);
+                    if (nn == 0) continue;
+                    const int rec = ia | (l << 8) | (det << 16);
+                    const int pos = npend + pk_mbcnt(mn);
+                    // the near pairs join the pending batch at lanes npend ..; the other lanes push to a lane whose value is not taken
+                    // (lane 0 holds a pending record when npend > 0; lane 63 is only a target when all 64 lanes push for real)
+                    const int got = __builtin_amdgcn_ds_permute(((near && pos < 64) ? pos : (npend > 0 ? 0 : 63)) << 2, rec);
+                    pend = lane < npend ? pend : got;
+                    const int tot = npend + nn;
+                    if (tot >= 64) {
+                        tests(pend, 64);
+                        pend = __builtin_amdgcn_ds_permute(((near && pos >= 64) ? pos - 64 : 63) << 2, rec);      // the batch's overflow: < 64 pairs
+                        npend = tot - 64;
+                    } else {
+                        npend = tot;
+                    }
+                }
+            }
+        }
+        if (npend > 0) tests(pend, npend);
+        sync();
+        for (int q = tid; q < na * nb; q += nth) {
+            const int ia = (int)(((float)q + 0.5f) * inv_nb), b = q - ia * nb;
+            const int i = plist[ip0 + ia];
+            const bool side = b < ns;
+            eobs[i * O + (side ? b : p.col_lane + b - ns)] = __uint_as_float(scratch[q]) * (side ? p.inv_side_range : p.inv_lane_range);
         }
     }
 }
@@ -942,7 +1179,7 @@ __device__ __forceinline__ void lidar_by_wave(const SimParams& p, PoseF pose, ui
         if (ip0 + CH < np) pk_wave_sync();
     }
     // side / lane-line detector beams (Bottleneck, Tollgate): the ray minima are written out, their storage holds the line masks
-    detector_beams<false>(p, pose, plist, np, best, CH * NL, eobs, lane, 64);
+    detector_beams<false>(p, pose, plist, np, best, CH * NL, eobs, lane, 64, wtag, e);
 }
 
 

@@ -19,7 +19,7 @@
 // 256: nothing compiled out, the LiDAR phase COUNTS its work into the debug rows instead ([E][16] then: 8 queued pairs,
 // 9 pair batches, 10 box tests, 11 test batches, 12 hits).  The shipped library is built without it.
 // (the macro's default lives in sim_device.h)
-#define COPO_DBG_STRIDE ((COPO_PROFILE_SKIP & 0x1300) ? 16 : 8)
+#define COPO_DBG_STRIDE ((COPO_PROFILE_SKIP & 0x5300) ? 16 : 8)
 // (mask 512: the wave roles' own finishing times -- slot 8 wave 0, slot 9 wave 1, slot 10 the last LiDAR wave; scripts/phase_sim.py)
 #define COPO_ROLE_STAMP(slot) do { if ((COPO_PROFILE_SKIP & 512) && p.dbg && lane == 0) atomicMax(reinterpret_cast<unsigned long long*>(p.dbg) + (size_t)e * 16 + (slot), (unsigned long long)clock64()); } while (0)
 // (COPO_COUNT: sim_device.h)
@@ -835,7 +835,7 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
     // those (detector_beams, sim_device.h; its marks take the storage of the ray minima, which are written out).  Wave roles: waves
     // 1 .. idle_n take no part in the write-out (they evaluate neighbour lists afterwards) but meet the barriers of the phase.
     if (PHASES & 4)
-        detector_beams<true>(p, [&L](int v) { return make_float4(L.x[v], L.y[v], L.cs[v], L.sn[v]); }, L.plist, np, best, CH * NL, eobs, otid, onth);
+        detector_beams<true>(p, [&L](int v) { return make_float4(L.x[v], L.y[v], L.cs[v], L.sn[v]); }, L.plist, np, best, CH * NL, eobs, otid, onth, wtag);
 }
 
 __device__ __forceinline__ void stage_pose(EnvLds& L, int lane, const Slot& s) {

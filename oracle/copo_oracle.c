@@ -464,8 +464,10 @@ static void comm_cols(int CS, int comm_nb, int add_pos, int fresh, const int* id
 
 /* One detector beam (MetaDrive SideDetector / LaneLineDetector: a ray test against the lane-line bodies): smallest
  * t in [0, range] at which the ray (x, y) + t (dx, dy) meets a line primitive of kind >= min_kind, or `range`.
- * Straight pieces are decided by cross-multiplied comparisons (one division, for a hit that improves the minimum);
- * arcs by the two roots of the circle equation, each accepted if its point lies within the arc's angular extent. */
+ * The result is a pure MINIMUM over the primitives' hit distances (any evaluation order gives the same bits): a straight
+ * piece is decided by cross-multiplied comparisons and contributes tn / ad, an arc the smaller of the roots of the circle
+ * equation whose point lies within the arc's angular extent; `+ 0.0f` turns a -0 hit distance into +0 (so that the
+ * unsigned order of the float bits is the order of the values). */
 static float detector_ray(const oracle_sim* s, float x, float y, float dx, float dy, float range, float min_kind) {
     float best = range;
     for (int l = 0; l < s->cfg.n_lines; ++l) {
@@ -479,8 +481,9 @@ static float detector_ray(const oracle_sim* s, float x, float y, float dx, float
             float ad = den * sd;
             float tn = (rx * L[4] - ry * L[3]) * sd;
             float un = (rx * dy - ry * dx) * sd;
-            if (!(tn >= 0.0f && un >= 0.0f && un <= L[5] * ad && tn < best * ad)) continue;
-            best = tn / ad;
+            if (!(tn >= 0.0f && un >= 0.0f && un <= L[5] * ad)) continue;
+            float th = tn / ad + 0.0f;
+            if (th < best) best = th;
         } else {
             float R = 1.0f / fabsf(L[6]);
             float mx = x - L[7], my = y - L[8];
@@ -490,10 +493,10 @@ static float detector_ray(const oracle_sim* s, float x, float y, float dx, float
             if (!(disc >= 0.0f)) continue;
             float sq = sqrtf(disc);
             for (int r = 0; r < 2; ++r) {
-                float tt = r == 0 ? -b - sq : -b + sq;
-                if (!(tt >= 0.0f && tt < best)) continue;
+                float tt = (r == 0 ? -b - sq : -b + sq) + 0.0f;
+                if (!(tt >= 0.0f)) continue;
                 float hx = mx + tt * dx, hy = my + tt * dy;
-                if (hx * L[9] + hy * L[10] >= R * L[11]) { best = tt; break; }
+                if (hx * L[9] + hy * L[10] >= R * L[11]) { if (tt < best) best = tt; break; }
             }
         }
     }
