@@ -853,6 +853,15 @@ __device__ __forceinline__ void detector_beams(const SimParams& p, PoseF pose, c
     const unsigned int side_bits = __float_as_uint(p.side_range), lane_bits = __float_as_uint(p.lane_range);
     int seq = 0;
     if (working) wtag[lane] = 0;
+    // the beam tables in the lanes' registers (beam b of [side | lane-line] in lane b & 63, two registers deep): a test fetches its
+    // beam's direction with ds_bpermute instead of a global load at the end of its dependent chain
+    const bool tab_regs = nb <= 128;
+    float2 tb0 = make_float2(0.f, 0.f), tb1 = make_float2(0.f, 0.f);
+    if (tab_regs) {
+        auto entry = [&](int b) { return b < ns ? reinterpret_cast<const float2*>(p.side_cs)[b] : reinterpret_cast<const float2*>(p.lane_cs)[b - ns]; };
+        if (lane < nb) tb0 = entry(lane);
+        if (64 + lane < nb) tb1 = entry(64 + lane);
+    }
     for (int ip0 = 0; ip0 < np; ip0 += G) {
         const int na = np - ip0 < G ? np - ip0 : G;
         sync();
@@ -866,6 +875,14 @@ __device__ __forceinline__ void detector_beams(const SimParams& p, PoseF pose, c
         // detector_line_hit performs per beam, so the same bits -- and the test lanes fetch it from the owner with ds_bpermute: no global
         // load between a test's number and its atomicMin but the beam table's
         auto tests = [&](int rec, int n) {
+            {   // the arcs behind the straight pieces: a batch of 64 tests then takes one of the two branches of the hit test, not both
+                const bool lv = lane < n, arc = lv && ((rec >> 17) & 1);
+                const unsigned long long ma = __ballot(arc), ms = __ballot(lv && !arc);
+                if (ma != 0ull && ms != 0ull) {
+                    const int to = arc ? __popcll(ms) + pk_mbcnt(ma) : (lv ? pk_mbcnt(ms) : lane);
+                    rec = __builtin_amdgcn_ds_permute(to << 2, rec);
+                }
+            }
             const bool live = lane < n;
             int klo = 0, cnt = 0;
             float fa = 0.0f, fb = 0.0f, fc = 0.0f, fd = 0.0f, fe = 0.0f, ff = 0.0f, hc = 1.0f, hs = 0.0f;
@@ -883,8 +900,7 @@ __device__ __forceinline__ void detector_beams(const SimParams& p, PoseF pose, c
                 } else {
                     const float R = 1.0f / fabsf(Ln[6]);
                     fa = pi.x - Ln[7]; fb = pi.y - Ln[8]; fc = Ln[9]; fd = Ln[10]; fe = R * Ln[11];
-                    ff = fa * fa + fb * fb - R * R;
-                    rec |= 1 << 17;                // an arc
+                    ff = fa * fa + fb * fb - R * R;        // (the record says "arc": bit 17)
                 }
             }
             const int incl = wave_scan_add(cnt);
@@ -909,12 +925,22 @@ __device__ __forceinline__ void detector_beams(const SimParams& p, PoseF pose, c
                 const int rk = __builtin_amdgcn_ds_bpermute(sl, rec_k);
                 const float ga = from(fa), gb = from(fb), gc = from(fc), gd = from(fd), ge = from(fe), gf = from(ff), c = from(hc), sn = from(hs);
                 const int t = t0 + lane;
+                // (every lane takes part in the fetches: ds_bpermute returns 0 from a lane that is switched off)
+                const bool side = ((ra >> 16) & 1) == 0;
+                const int nbeam = side ? ns : nl;
+                int k = rk + t;                         // beam of this test: in [klo, klo + cnt), the window wraps
+                k = k >= nbeam ? k - nbeam : k;
+                k = t < total ? k : 0;
+                float2 ab;
+                if (tab_regs) {
+                    const int kk = (side ? 0 : ns) + k, ks = (kk & 63) << 2;
+                    const float x0 = __int_as_float(__builtin_amdgcn_ds_bpermute(ks, __float_as_int(tb0.x))), y0 = __int_as_float(__builtin_amdgcn_ds_bpermute(ks, __float_as_int(tb0.y)));
+                    const float x1 = __int_as_float(__builtin_amdgcn_ds_bpermute(ks, __float_as_int(tb1.x))), y1 = __int_as_float(__builtin_amdgcn_ds_bpermute(ks, __float_as_int(tb1.y)));
+                    ab = kk < 64 ? make_float2(x0, y0) : make_float2(x1, y1);
+                } else {
+                    ab = reinterpret_cast<const float2*>(side ? p.side_cs : p.lane_cs)[k];
+                }
                 if (t < total) {
-                    const bool side = ((ra >> 16) & 1) == 0;
-                    const int nbeam = side ? ns : nl;
-                    int k = rk + t;                     // beam of this test: in [klo, klo + cnt), the window wraps
-                    k = k >= nbeam ? k - nbeam : k;
-                    const float2 ab = reinterpret_cast<const float2*>(side ? p.side_cs : p.lane_cs)[k];
                     const float dx = c * ab.x - sn * ab.y, dy = sn * ab.x + c * ab.y;
                     float th = -1.0f;                   // detector_line_hit on the owner's quantities, operation by operation
                     if (!((ra >> 17) & 1)) {
@@ -955,10 +981,14 @@ __device__ __forceinline__ void detector_beams(const SimParams& p, PoseF pose, c
             const float px = kap == 0.0f ? Ln[1] : Ln[7], py = kap == 0.0f ? Ln[2] : Ln[8];       // start point / arc centre
             const float ux = Ln[3], uy = Ln[4], len = Ln[5];
             const float Rr = kap == 0.0f ? 0.0f : 1.0f / fabsf(kap);
+            const int arc_bit = (has && kap != 0.0f) ? (1 << 17) : 0;
             for (int det = 0; det < 2; ++det) {    // 0: side detector (continuous lines), 1: lane-line detector (every line)
                 if ((det == 0 ? ns : nl) <= 0) continue;
                 const float range = det == 0 ? p.side_range : p.lane_range, min_kind = det == 0 ? 2.0f : 1.0f;
                 const float lim = range * 1.001f + 0.01f;          // (detector_line_near, on the lane's registers)
+                // an arc is near when the distance to its centre is within lim of its radius: squared bounds, no square root in the turn
+                const float rlo = Rr - lim > 0.0f ? (Rr - lim) * 0.9999f : 0.0f, rhi = (Rr + lim) * 1.0001f;
+                const float rlo2 = rlo * rlo, rhi2 = rhi * rhi;
                 for (int ia = wv; ia < na; ia += nwv) {
                     const float4 pi = pose((int)plist[ip0 + ia]);
                     bool near = false;
@@ -970,14 +1000,15 @@ __device__ __forceinline__ void detector_beams(const SimParams& p, PoseF pose, c
                             const float ex = rx - t * ux, ey = ry - t * uy;
                             near = ex * ex + ey * ey <= lim * lim;
                         } else {
-                            near = fabsf(sqrtf(rx * rx + ry * ry) - Rr) <= lim;
+                            const float d2 = rx * rx + ry * ry;
+                            near = d2 >= rlo2 && d2 <= rhi2;
                         }
                     }
                     const unsigned long long mn = __ballot(near);
                     const int nn = __popcll(mn);
                     COPO_DCOUNT(8, 1); COPO_DCOUNT(9, nn);
                     if (nn == 0) continue;
-                    const int rec = ia | (l << 8) | (det << 16);
+                    const int rec = ia | (l << 8) | (det << 16) | arc_bit;
                     const int pos = npend + pk_mbcnt(mn);
                     // the near pairs join the pending batch at lanes npend ..; the other lanes push to a lane whose value is not taken
                     // (lane 0 holds a pending record when npend > 0; lane 63 is only a target when all 64 lanes push for real)
