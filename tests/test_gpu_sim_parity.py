@@ -56,6 +56,12 @@ def _actions(rng, E, N, t):
     ("pgmap-junctions", 20, 9, 72, 260, -8),
     ("parkinglot-reverse", 10, 6, 72, 150, -5),
     ("intersection", 30, 9, 72, 200, -8),
+    # detector beams: 8 LiDAR beams x 10 fans leave no room for a row of 76 beam minima in the LDS scratch -> the fallback that walks the
+    # marked primitives beam by beam (detector_beams_walk), one wave per scene and several waves per scene; then the pair formulation
+    # with several passes of few agents (30 beams x 3 fans = 90 words: one agent's row per pass)
+    ("tollgate", 40, 3, 8, 100, 64),
+    ("tollgate", 24, 2, 8, 100, 256),
+    ("tollgate-chunk3", 40, 3, 30, 100, 64),
 ])
 def test_rollout_bit_exact(map_name, N, E, lasers, steps, block):
     import torch
@@ -66,6 +72,8 @@ def test_rollout_bit_exact(map_name, N, E, lasers, steps, block):
                     delay_done=5, map_kwargs=kw, reverse_acc=2.9 if map_name.endswith("-reverse") else None)
     g, o = VecSim(cfg), ol.OracleSim(cfg)
     g.set_block(block)
+    if map_name.endswith("-chunk3"):
+        g.set_chunk(3)
     seeds = np.arange(E, dtype=np.uint64) * np.uint64(7919) + np.uint64(5000)
     _compare("reset", g.reset(seeds), o.reset(seeds))
     rng = np.random.RandomState(3)
