@@ -148,3 +148,38 @@ def test_two_rank_learner_equals_union_replay():
     for k, v in pol.model.state_dict().items():
         torch.testing.assert_close(v, r[0]["params"][k], rtol=2e-5, atol=2e-7, msg=k)
     assert abs(pol.model.lcf_parameters[0].item()) > 0           # the meta step moved the LCF
+
+
+def _rs_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    from copo_amd import dist as D
+    D.init_from_env("cpu")
+    c, n = 3, 5                                 # rows per rank, row length; 2 * 3 rows hold 5 real minibatches + 1 pad row
+    g = torch.Generator().manual_seed(7 + rank)
+    flat = torch.randn(world * c, 2, n, generator=g)
+    mine_buf = torch.zeros(c, 2, n)
+    keep = flat.clone()
+    mine = D.reduce_scatter_sum_(mine_buf, flat)
+    # the shared dot products of the data-parallel meta pass (algo_copo.py:_meta_shared_dots), in miniature: every rank takes the dot
+    # products of ITS rows of the sum, the values are gathered
+    part = (mine[:, 0].double() * mine[:, 1].double()).sum(-1)
+    every = D.all_gather_into_(torch.empty(world, c, dtype=torch.float64), part)
+    torch.save(dict(sent=keep, mine=mine.clone(), gv=every.reshape(-1).clone()), os.path.join(out_dir, "rs%d.pt" % rank))
+    D.barrier()
+
+
+@pytest.mark.timeout(300)
+def test_reduce_scatter_rows_and_shared_dot_products_two_ranks():
+    """dist.reduce_scatter_sum_ on a backend without reduce-scatter (gloo: the all-reduce branch): rank r ends up with rows
+    [r c, (r + 1) c) of the sum, and the gathered per-row dot products equal those of the summed pairs on every rank."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_rs_worker, args=(2, _free_port(), d), nprocs=2, join=True)
+        r = [torch.load(os.path.join(d, "rs%d.pt" % k), weights_only=False) for k in range(2)]
+    total = r[0]["sent"] + r[1]["sent"]
+    for k in range(2):
+        assert torch.equal(r[k]["mine"], total[k * 3:(k + 1) * 3]), k
+    want = (total[:, 0].double() * total[:, 1].double()).sum(-1)
+    assert torch.equal(r[0]["gv"], r[1]["gv"]) and torch.allclose(r[0]["gv"], want, rtol=0, atol=0)
