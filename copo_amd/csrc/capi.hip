@@ -77,10 +77,14 @@ static int pick_block(int E, bool nbr_fast = true, int packed = 0) {
     if (E <= (nbr_fast ? 3072 : 8192)) return 256;
     return packed > 0 ? -packed : 64;
 }
-// (measured, 16 384 populated scenes, scripts/bench_sim.py: with 40 slots the packed shape issues 9 % fewer vector instructions than one
-// wave per scene but has fewer runnable waves -- 3 workgroups of 8 waves per compute unit, 3 of every 8 parked through the packed phases --
-// and ends level, 213 vs 206 us; level at 24 and 30 slots; 2-4 % ahead at 8 .. 20 slots, 20 % at 10 slots x 240 beams: automatic up to 20)
-static int packed_scenes(const SimParams& p) { return (p.N <= 20 && sim_packed_supported(p)) ? sim_packed_default_scenes(p) : 0; }
+// (measured, 16 384 populated scenes, scripts/bench_sim.py, 4 scenes per workgroup against one wave per scene: 8 slots 62.7 / 66.0 us, 12 78.8 /
+// 87.9, 16 90.9 / 99.6, 20 109.1 / 115.8, 10 slots x 240 beams 109 / 124 (fans of 5); with 40 slots the packed shape issues 9 % fewer vector
+// instructions but ends behind, 209 vs 193 us: parked waves, barriers.  With detector beams (Bottleneck, 20 slots: 332 / 290 us) one wave
+// per scene is ahead; 24 slots 127.9 / 134.2, 30 slots 154.7 / 161.3, 40 slots 207.9 / 204.4: automatic up to 32 slots on maps without
+// detector beams)
+static int packed_scenes(const SimParams& p) {
+    return (p.N <= 32 && p.side_lasers == 0 && p.lane_lasers == 0 && sim_packed_supported(p)) ? sim_packed_default_scenes(p) : 0;
+}
 
 extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** out) {
     if (!cfg || !out) return fail(COPO_ERR_NULL, "copo_sim_create: cfg/out is NULL");

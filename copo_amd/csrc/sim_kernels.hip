@@ -1406,7 +1406,9 @@ void sim_shape_params(SimParams& p, int block) {
     }
     // one wave per scene: 10 fans at a time (scripts/bench_sim.py --chunks, 16 384 populated scenes: 6 263 / 8 257 / 10 251 / 12 262 /
     // 14 259 / 16 275 us -- fuller pair and box-test batches against resident scenes per compute unit, 26 at 6.2 KB of LDS)
-    const int lch = p.chunk_one_wave > 0 ? p.chunk_one_wave : 10;
+    // (with more beams per fan, fewer fans: 240 beams x 10 slots 166 us at fans of 10, 124 at 5, 126 at 4, 130 at 6)
+    const int lch_auto = 1280 / (p.num_lasers > 0 ? p.num_lasers : 1);
+    const int lch = p.chunk_one_wave > 0 ? p.chunk_one_wave : (lch_auto < 2 ? 2 : (lch_auto > 10 ? 10 : lch_auto));
     p.chunk = block > 64 ? p.N : (p.N < lch ? p.N : lch);
     // (pair-parallel neighbour lists, one wave per scene: 4 agents at a time when they only serve the scenes the register
     //  formulation declines, 8 when they are the only formulation this configuration has)

@@ -573,28 +573,21 @@ static hipError_t pk_lds_attr() {
 
 int sim_packed_chunk(const SimParams& p) {
     if (p.chunk_one_wave > 0) return p.chunk_one_wave < p.N ? p.chunk_one_wave : p.N;
-    int ch = 768 / p.num_lasers;
+    int ch = 1280 / p.num_lasers;      // (240 beams: fans of 5 -- 3: 145 us, 5: 109 us per launch of 16 384 scenes x 10 slots, 7: 138)
     ch = ch < 2 ? 2 : (ch > 10 ? 10 : ch);
     return ch < p.N ? ch : p.N;
 }
 
 size_t sim_packed_lds_bytes(const SimParams& p, int S) { return (size_t)pk_wg_words(S, p.N, p.num_lasers, sim_packed_chunk(p)) * sizeof(unsigned int); }
 
-// scenes per workgroup: the count (4 .. 16) that fills the packed waves best within 64 KB of LDS, 8 on ties
+// scenes per workgroup: FOUR (one wave per SIMD), fewer when four do not fit 64 KB of LDS.  Measured at 16 384 scenes, 8 .. 20 slots x 72
+// beams and 10 slots x 240 beams (scripts/bench_sim.py --blocks -2 .. -8): 4 scenes are the fastest everywhere, 2 / 3 within 2-6 %, 8
+// within 3-8 %, and 5 or 6 -- the counts that fill the packed waves' lanes best -- 20-30 % behind: a workgroup's waves are dealt over the
+// four SIMDs, so five or six leave one SIMD with twice the others' work; lane use of the packed phases matters less than that.
 int sim_packed_default_scenes(const SimParams& p) {
-    int best = 0;
-    float best_u = 0.0f;
-    for (int S = 4; S <= 16; ++S) {
-        if (sim_packed_lds_bytes(p, S) > 64 * 1024) break;
-        const int thr = S * p.N, waves = (thr + 63) / 64;
-        float u = (float)thr / (float)(waves * 64);
-        if (S == 8) u += 0.03f;
-        if (u > best_u + 1e-6f) {
-            best_u = u;
-            best = S;
-        }
-    }
-    return best;
+    for (int S = 4; S >= 2; --S)
+        if (sim_packed_lds_bytes(p, S) <= 64 * 1024) return S;
+    return 0;
 }
 
 bool sim_packed_supported(const SimParams& p) {
