@@ -25,7 +25,13 @@ pol._row_sources["k"].zero_()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 t0 = time.perf_counter()
 e0.record()
+KC = os.environ.get("COPO_BENCH_KCONST")      # experiment: the minibatch index of step i read from a table that is never written (bump off)
+kc = torch.arange(128, dtype=torch.int64, device="cuda") if KC else None
+rs_i = [dict(RS, k=kc[i:i + 1]) for i in range(128)] if KC else None
 for i in range(n):
+    if KC:
+        pol.fused.step(rs_i[i % 128], stats=pol.fused.stats, bump_index=False)
+        continue
     if i % 128 == 0:
         pol._row_sources["k"].zero_()          # stay inside the epoch plan (161 minibatches)
     pol.fused.step(RS, stats=pol.fused.stats)
