@@ -877,7 +877,8 @@ def main():
                                     "all_cores": {"value": round(va, 1), "unit": "agent-steps/s", "sim_threads": aw, "learner_threads": at,
                                                   "sample": "the same iteration (%d agent-steps, %.1f s): one C oracle instance per host thread "
                                                             "for the scenes, batched torch inference, torch learner at its fastest thread "
-                                                            "count for 512-row minibatches (swept over 4 .. all host threads)" % (an, adt),
+                                                            "count for 512-row minibatches (candidates 4, 8, 16, 32, 64 threads, 8 kept unless another is 15 %% faster; "
+                                                            "per-candidate times in split.learner_thread_sweep_ms_per_step)" % (an, adt),
                                                   "split": asplit},
                                     "sim_only": {"threads_1": round(sim1, 1), "threads_%d" % host: round(simn, 1),
                                                  "unit": "agent-steps/s, simulator half alone (C oracle, one instance per thread)"},

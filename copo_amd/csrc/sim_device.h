@@ -18,6 +18,10 @@
 namespace copo {
 
 __device__ __host__ inline int ray_lds_words(int n_lasers) { return (2 * n_lasers + 3) & ~3; }      // LDS copy of the ray table
+// lidar_by_wave keeps the ray minima of a fan SHIFTED by up to 3 words, so that the 16-byte groups of rays that the write-out stores
+// to an aligned observation address are 16-byte aligned in LDS too (one ds_read_b128 per lane instead of four ds_read_b32 at a
+// stride of four words: a 4-way bank conflict); the work area is these words longer and the pair queue starts behind them
+constexpr int LIDAR_MIN_PAD = 4;
 constexpr uint32_t NBR_SENT = 0xffffffffu;      // empty key of the register formulation of the neighbour lists
 
 // ------------------------------------------------------------------------------------------------
@@ -30,22 +34,22 @@ __device__ __forceinline__ void project_seg(const float* __restrict__ g, float x
     const float gx = g[0], gy = g[1], gc = g[2], gs = g[3], kap = g[5];
     const float dx = x - gx, dy = y - gy;
     if (kap == 0.0f) {
-        sl = dx * gc + dy * gs;
-        lat = dy * gc - dx * gs;
-        sinpsi = sh * gc - ch * gs;
+        sl = fm(dx, gc, dy * gs);
+        lat = fm(dy, gc, -(dx * gs));
+        sinpsi = fm(sh, gc, -(ch * gs));
     } else {
         const float sg = kap > 0.0f ? 1.0f : -1.0f;
         const float R = g[12];
-        const float cx = gx - sg * R * gs, cy = gy + sg * R * gc;
+        const float cx = fm(-(sg * R), gs, gx), cy = fm(sg * R, gc, gy);
         const float ex = x - cx, ey = y - cy;
-        const float rho = sqrtf(ex * ex + ey * ey);
+        const float rho = sqrtf(fm(ex, ex, ey * ey));
         const float umx = g[14], umy = g[15];
-        const float dotp = umx * ex + umy * ey;
-        const float crs = umx * ey - umy * ex;
+        const float dotp = fm(umx, ex, umy * ey);
+        const float crs = fm(umx, ey, -(umy * ex));
         const float ang = atan2_det(sg * crs, dotp);
-        sl = ang * R + 0.5f * g[4];
+        sl = fm(ang, R, 0.5f * g[4]);
         lat = sg * (R - rho);
-        sinpsi = rho > 0.0f ? (-sg * (ch * ex + sh * ey)) / rho : 0.0f;
+        sinpsi = rho > 0.0f ? (-sg * fm(ch, ex, sh * ey)) / rho : 0.0f;
     }
 }
 
@@ -71,11 +75,13 @@ __device__ __forceinline__ float funnel_extra(const float* __restrict__ g, float
 __device__ __forceinline__ bool obb_overlap2(float xi, float yi, float ci, float si, float ai, float bi, float xj, float yj,
                                              float cj, float sj, float aj, float bj) {
     const float dx = xj - xi, dy = yj - yi;
-    const float cc = fabsf(ci * cj + si * sj), ss = fabsf(ci * sj - si * cj);
-    if (fabsf(dx * ci + dy * si) > ai + aj * cc + bj * ss) return false;
-    if (fabsf(dy * ci - dx * si) > bi + aj * ss + bj * cc) return false;
-    if (fabsf(dx * cj + dy * sj) > aj + ai * cc + bi * ss) return false;
-    if (fabsf(dy * cj - dx * sj) > bj + ai * ss + bi * cc) return false;
+    // (ss stays two products and a subtraction: a fused ci sj - round(si cj) is not the exact negation of the pair's other order,
+    //  and the one-wave / packed shapes test every UNORDERED pair once; everything else is symmetric under the swap as before)
+    const float cc = fabsf(fm(ci, cj, si * sj)), ss = fabsf(ci * sj - si * cj);
+    if (fabsf(fm(dx, ci, dy * si)) > fm(bj, ss, fm(aj, cc, ai))) return false;
+    if (fabsf(fm(dy, ci, -(dx * si))) > fm(bj, cc, fm(aj, ss, bi))) return false;
+    if (fabsf(fm(dx, cj, dy * sj)) > fm(bi, ss, fm(ai, cc, aj))) return false;
+    if (fabsf(fm(dy, cj, -(dx * sj))) > fm(bi, cc, fm(ai, ss, bj))) return false;
     return true;
 }
 
@@ -310,7 +316,7 @@ __device__ __forceinline__ void ego_navi_obs(const SimParams& p, const LT& L, fl
     project_seg(g, s.x, s.y, cs, sn, sl, lat, sinpsi);
     const float w = p.lane_width;
     const float lanes = floorf(g[COPO_SEG_LANES]);
-    float lif = floorf(0.5f - lat * p.inv_w);
+    float lif = floorf(fm(-lat, p.inv_w, 0.5f));
     lif = lif < 0.0f ? 0.0f : (lif > lanes - 1.0f ? lanes - 1.0f : lif);
     const float left = 0.5f * w - lat;
     const float right = lanes * w - left;
@@ -320,15 +326,15 @@ __device__ __forceinline__ void ego_navi_obs(const SimParams& p, const LT& L, fl
         row[1] = clipf(right / tw, 0.0f, 1.0f);
     }
     float* q = row + p.col_state;
-    q[0] = clipf(0.5f - 0.5f * sinpsi, 0.0f, 1.0f);
-    q[1] = clipf((fabsf(s.v) * 3.6f + 1.0f) * p.inv_vnorm, 0.0f, 1.0f);      // vehicle.speed is a magnitude
-    q[2] = clipf(0.5f + s.steer * (1.0f / 120.0f), 0.0f, 1.0f);
-    q[3] = clipf(0.5f + 0.5f * s.psteer, 0.0f, 1.0f);
-    q[4] = clipf(0.5f + 0.5f * s.pthrottle, 0.0f, 1.0f);
+    q[0] = clipf(fm(-0.5f, sinpsi, 0.5f), 0.0f, 1.0f);
+    q[1] = clipf(fm(fabsf(s.v), 3.6f, 1.0f) * p.inv_vnorm, 0.0f, 1.0f);      // vehicle.speed is a magnitude
+    q[2] = clipf(fm(s.steer, 1.0f / 120.0f, 0.5f), 0.0f, 1.0f);
+    q[3] = clipf(fm(0.5f, s.psteer, 0.5f), 0.0f, 1.0f);
+    q[4] = clipf(fm(0.5f, s.pthrottle, 0.5f), 0.0f, 1.0f);
     q[5] = clipf(fabsf(s.yawrate), 0.0f, 1.0f);
     if (p.lane_lasers == 0) {
-        const float latr = -(lat + lif * w);
-        row[p.col_lane] = clipf(0.5f + latr * (1.0f / 4.5f), 0.0f, 1.0f);
+        const float latr = -fm(lif, w, lat);
+        row[p.col_lane] = clipf(fm(latr, 1.0f / 4.5f, 0.5f), 0.0f, 1.0f);
     }
     if (p.navi_dim) {
 #pragma unroll
@@ -347,17 +353,17 @@ __device__ __forceinline__ void ego_navi_obs(const SimParams& p, const LT& L, fl
                 cky = gn[1] - gn[2] * off;
             }
             float vx = ckx - s.x, vy = cky - s.y;
-            const float nrm = sqrtf(vx * vx + vy * vy);
+            const float nrm = sqrtf(fm(vx, vx, vy * vy));
             if (nrm > 50.0f) {
                 const float sc = 50.0f / nrm;
                 vx = vx * sc;
                 vy = vy * sc;
             }
-            const float fwd = vx * cs + vy * sn, rhs = vx * sn - vy * cs;
+            const float fwd = fm(vx, cs, vy * sn), rhs = fm(vx, sn, -(vy * cs));
             float* n5 = row + p.col_navi + 5 * j;
             const float kap = gk[5];
-            n5[0] = clipf(0.5f + fwd * 0.01f, 0.0f, 1.0f);
-            n5[1] = clipf(0.5f + rhs * 0.01f, 0.0f, 1.0f);
+            n5[0] = clipf(fm(fwd, 0.01f, 0.5f), 0.0f, 1.0f);
+            n5[1] = clipf(fm(rhs, 0.01f, 0.5f), 0.0f, 1.0f);
             n5[2] = gk[COPO_SEG_FEAT];
             n5[3] = kap == 0.0f ? 0.5f : (kap < 0.0f ? 1.0f : 0.0f);
             n5[4] = gk[COPO_SEG_FEAT + 2];
@@ -574,11 +580,11 @@ __device__ __forceinline__ void slot_dynamics(const SimParams& p, const float* _
             // (reverse gear, MetaDrive enable_reverse: a negative throttle is engine force backwards, no brake, v may go negative;
             //  the engine is cut at max_speed in either direction)
             const float a = a1 >= 0.0f ? (v < p.max_speed ? a1 * p.acc_max : 0.0f) : (p.reverse_acc > 0.0f ? (v > -p.max_speed ? a1 * p.reverse_acc : 0.0f) : -brake);
-            v = v + a * h;
+            v = fm(a, h, v);
             if (v < 0.0f && !(p.reverse_acc > 0.0f)) v = 0.0f;
-            const float dxh = cs * cb - sn * sb, dyh = sn * cb + cs * sb;
-            x = x + v * dxh * h;
-            y = y + v * dyh * h;
+            const float dxh = fm(cs, cb, -(sn * sb)), dyh = fm(sn, cb, cs * sb);
+            x = fm(v * dxh, h, x);
+            y = fm(v * dyh, h, y);
             // turn the heading vector by the sub-step's small angle: 3-term sine / cosine, no range reduction
             float dth = v * yawk * h;
             if (p.lat_acc_max > 0.0f && v * fabsf(dth) > p.lat_acc_max * h) {      // tyres slide: v x yaw rate is friction-limited
@@ -586,9 +592,9 @@ __device__ __forceinline__ void slot_dynamics(const SimParams& p, const float* _
                 dth = dth < 0.0f ? -lim : lim;
             }
             const float q = dth * dth;
-            const float sd2 = dth - dth * q * (0.166666667f - q * 0.00833333333f);
-            const float cd2 = 1.0f - q * (0.5f - q * 0.0416666667f);
-            const float cn = cs * cd2 - sn * sd2, sm = sn * cd2 + cs * sd2;
+            const float sd2 = fm(-(dth * q), fm(-q, 0.00833333333f, 0.166666667f), dth);
+            const float cd2 = fm(-q, fm(-q, 0.0416666667f, 0.5f), 1.0f);
+            const float cn = fm(cs, cd2, -(sn * sd2)), sm = fm(sn, cd2, cs * sd2);
             cs = cn;
             sn = sm;
             th = wrap_pi(th + dth);
@@ -647,16 +653,16 @@ __device__ __forceinline__ void slot_project(const SimParams& p, const LT& L, fl
     const float lanes_f = g[COPO_SEG_LANES], lanes = floorf(lanes_f), lfr = lanes_f - lanes;      // fraction: edge-line flags
     const int lcode = (int)(lfr * 8.0f);      // edge-line flags in eighths: 1 = left edge open (broken centre line), 2 / 4 = left / right edge solid
     const bool left_solid = (lcode & 2) != 0, right_solid = (lcode & 4) != 0, left_open = (lcode & 1) != 0;
-    float lif = floorf(0.5f - lat * p.inv_w);
+    float lif = floorf(fm(-lat, p.inv_w, 0.5f));
     lif = lif < 0.0f ? 0.0f : (lif > lanes - 1.0f ? lanes - 1.0f : lif);
     const float left = 0.5f * w - lat, right = (lanes * w + funnel_extra(g, sl, w)) - left;
-    const float cos2 = 1.0f - sinpsi * sinpsi;
-    const float edge = p.body_margin * (hw * sqrtf(cos2 > 0.0f ? cos2 : 0.0f) + hl * fabsf(sinpsi));      // body extent across the road
+    const float cos2 = fm(-sinpsi, sinpsi, 1.0f);
+    const float edge = p.body_margin * fm(hl, fabsf(sinpsi), hw * sqrtf(cos2 > 0.0f ? cos2 : 0.0f));      // body extent across the road
     const bool on_road = (left >= (left_solid ? edge : (left_open ? -w : 0.0f))) && (right >= (right_solid ? edge : 0.0f));
     const bool arrive = (seg == nseg - 1) && (sl > g[4] - p.arrive_margin) && (sl < g[4] + p.arrive_margin) && on_road;
     const bool oor = !on_road;
     const bool crash = crash_in || too_fast;
-    float r = p.driving_reward * ((prog - prev) * (1.0f + g[5] * (lif * w))) + p.speed_reward * (fabsf(s.v) / p.max_speed);
+    float r = fm(p.driving_reward, (prog - prev) * fm(g[5], lif * w, 1.0f), p.speed_reward * (fabsf(s.v) / p.max_speed));
     fl = COPO_F_ACTED;
     if (arrive) { r = p.success_reward; fl |= COPO_F_ARRIVE; }
     else if (oor) { r = -p.out_penalty; }
@@ -1073,6 +1079,8 @@ __device__ __forceinline__ void lidar_by_wave(const SimParams& p, PoseF pose, ui
     const int nvec = (NL - head) >> 2;
     const bool vec_out = ((O & 3) == 0) && nvec > 0 && ((reinterpret_cast<uintptr_t>(obs) & 15) == 0);
     const float inv_nvec = 1.0f / (float)(nvec > 0 ? nvec : 1), inv_nsc = 1.0f / (float)(NL - 4 * nvec > 0 ? NL - 4 * nvec : 1);
+    const int sh = (NL & 3) == 0 ? ((4 - head) & 3) : 0;      // the shift of the minima rows (LIDAR_MIN_PAD)
+    unsigned int* bs = best + sh;
     if (__builtin_amdgcn_inverse_ballot_w64(present)) plist[pk_mbcnt(present)] = (uint8_t)lane;
     wtag[lane] = 0;
     int seq = 0;                      // sequence number of the box-test batches of this wave (head flags)
@@ -1080,10 +1088,11 @@ __device__ __forceinline__ void lidar_by_wave(const SimParams& p, PoseF pose, ui
     for (int ip0 = 0; ip0 < np; ip0 += CH) {
         const int cha = np - ip0 < CH ? np - ip0 : CH;
         {      // ray minima of the chunk := range, 16 bytes per lane and turn (the storage is 16-byte aligned; a tail of < 4 words by the last lanes)
-            const int nw4 = (cha * NL) >> 2;
+            const int nwords = cha * NL + sh;         // (the shifted rows end inside the pad)
+            const int nw4 = nwords >> 2;
             const uint4 r4 = make_uint4(range_bits, range_bits, range_bits, range_bits);
             for (int q = lane; q < nw4; q += 64) reinterpret_cast<uint4*>(best)[q] = r4;
-            if (lane < ((cha * NL) & 3)) best[4 * nw4 + lane] = range_bits;
+            if (lane < (nwords & 3)) best[4 * nw4 + lane] = range_bits;
         }
         // pair queue of this chunk of fans, from their reach masks
         int nq = 0;
@@ -1110,7 +1119,7 @@ __device__ __forceinline__ void lidar_by_wave(const SimParams& p, PoseF pose, ui
             const float4 pi = pose(i), pj = pose(j);
             const float ci = pi.z, si = pi.w, cj = pj.z, sj = pj.w;
             const float dx = pj.x - pi.x, dy = pj.y - pi.y;
-            const float d2 = dx * dx + dy * dy;
+            const float d2 = fm(dx, dx, dy * dy);
             int klo = 0, cnt = 0;
             if (live && j != i && !(d2 > lim * lim)) {
                 if (d2 <= circ * circ * 1.002f) {
@@ -1138,10 +1147,10 @@ __device__ __forceinline__ void lidar_by_wave(const SimParams& p, PoseF pose, ui
             COPO_COUNT(13, nw);
             if (nw == 0) continue;
             const int dst = (cnt > 0 ? pk_mbcnt(mw) : 63) << 2;
-            const float rec_ox = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(-(dx * cj + dy * sj))));
-            const float rec_oy = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(-(dy * cj - dx * sj))));
-            const float rec_cr = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(ci * cj + si * sj)));
-            const float rec_sr = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(ci * sj - si * cj)));
+            const float rec_ox = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(-fm(dx, cj, dy * sj))));
+            const float rec_oy = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(-fm(dy, cj, -(dx * sj)))));
+            const float rec_cr = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(fm(ci, cj, si * sj))));
+            const float rec_sr = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(fm(ci, sj, -(si * cj)))));
             const int ck = __builtin_amdgcn_ds_permute(dst, cnt | (klo << 12) | (lp << 24));      // cnt <= 256 < 2^12, klo < 2^12, lp < 64
             const int cnt_c = lane < nw ? (ck & 0xfff) : 0;
             const int incl = wave_scan_add(cnt_c);
@@ -1174,8 +1183,8 @@ __device__ __forceinline__ void lidar_by_wave(const SimParams& p, PoseF pose, ui
                     const unsigned int k = k0 < k0 - (unsigned int)NL ? k0 : k0 - (unsigned int)NL;      // k0 mod NL for k0 < 2 NL, as one v_min_u32
                     const float2 r = reinterpret_cast<const float2*>(rays)[k];
                     bool hit;
-                    const float tt = ray_box_nr(ox, oy, r.x * cr + r.y * sr, r.y * cr - r.x * sr, hl, hw, hit);
-                    if (hit) atomicMin(&best[(unsigned int)(pw >> 16) + k], __float_as_uint(tt));
+                    const float tt = ray_box_nr(ox, oy, fm(r.x, cr, r.y * sr), fm(r.y, cr, -(r.x * sr)), hl, hw, hit);
+                    if (hit) atomicMin(&bs[(unsigned int)(pw >> 16) + k], __float_as_uint(tt));
                     if (COPO_PROFILE_SKIP & 256) { const int nh = __popcll(__ballot(hit)); COPO_COUNT(12, nh); }
                 }
             }
@@ -1189,22 +1198,25 @@ __device__ __forceinline__ void lidar_by_wave(const SimParams& p, PoseF pose, ui
             for (int q = lane; q < cha * nvec; q += 64) {
                 const unsigned int lp = (unsigned int)(int)(((float)q + 0.5f) * inv_nvec) & 63u;
                 const unsigned int k = (unsigned int)head + 4u * ((unsigned int)q - __umul24(lp, unv));
-                const unsigned int* b = best + (__umul24(lp, uNL) + k);
+                const unsigned int* b = bs + (__umul24(lp, uNL) + k);
+                uint4 b4;
+                if ((NL & 3) == 0) b4 = *reinterpret_cast<const uint4*>(b);      // sh + lp NL + head + 4 m: a multiple of four words
+                else b4 = make_uint4(b[0], b[1], b[2], b[3]);
                 float4 v;
-                v.x = __uint_as_float(b[0]) * inv_range; v.y = __uint_as_float(b[1]) * inv_range;
-                v.z = __uint_as_float(b[2]) * inv_range; v.w = __uint_as_float(b[3]) * inv_range;
+                v.x = __uint_as_float(b4.x) * inv_range; v.y = __uint_as_float(b4.y) * inv_range;
+                v.z = __uint_as_float(b4.z) * inv_range; v.w = __uint_as_float(b4.w) * inv_range;
                 *reinterpret_cast<float4*>(eobs + (__umul24((unsigned int)plist[ip0 + lp], uO) + (unsigned int)col_lidar + k)) = v;
             }
             const int nsc = NL - 4 * nvec;
             for (int q = lane; q < cha * nsc; q += 64) {
                 const unsigned int lp = (unsigned int)(int)(((float)q + 0.5f) * inv_nsc) & 63u, r = (unsigned int)q - __umul24(lp, (unsigned int)nsc & 7u);
                 const unsigned int k = r < (unsigned int)head ? r : r + 4u * unv;
-                eobs[__umul24((unsigned int)plist[ip0 + lp], uO) + (unsigned int)col_lidar + k] = __uint_as_float(best[__umul24(lp, uNL) + k]) * inv_range;
+                eobs[__umul24((unsigned int)plist[ip0 + lp], uO) + (unsigned int)col_lidar + k] = __uint_as_float(bs[__umul24(lp, uNL) + k]) * inv_range;
             }
         } else {
             for (int q = lane; q < cha * NL; q += 64) {
                 const int lp = (int)(((float)q + 0.5f) * inv_nl), k = q - lp * NL;
-                eobs[(int)plist[ip0 + lp] * O + col_lidar + k] = __uint_as_float(best[q]) * inv_range;
+                eobs[(int)plist[ip0 + lp] * O + col_lidar + k] = __uint_as_float(bs[q]) * inv_range;
             }
         }
         if (ip0 + CH < np) pk_wave_sync();

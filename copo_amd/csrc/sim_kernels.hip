@@ -61,7 +61,7 @@ __device__ __host__ inline int lidar_queue_words(int ch, int n_agents) { return 
 // (`nch`: the chunk of the pair-parallel neighbour lists -- smaller than the LiDAR chunk when one wave owns the scene: that path
 // only runs for the scenes the register formulation declines)
 __device__ __host__ inline int lidar_lds_words(int ch, int nch, int n_agents, int n_lasers) {
-    const int a = ch * n_lasers + lidar_queue_words(ch, n_agents), b = nbr_lds_words(nch, n_agents) + COPO_MAX_SPAWNS / 2;
+    const int a = ch * n_lasers + LIDAR_MIN_PAD + lidar_queue_words(ch, n_agents), b = nbr_lds_words(nch, n_agents) + COPO_MAX_SPAWNS / 2;
     const int c = a > b ? a : b;
     return ((c > 256 ? c : 256) + 3) & ~3;     // (>= the 64 float4 records of neighbours_fast)
 }
@@ -665,7 +665,7 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
     auto pair_batch = [&](const bool live, const int lp, const int i, const int j) {
         const float ci = L.cs[i], si = L.sn[i], cj = L.cs[j], sj = L.sn[j];      // (all eight pose reads in one LDS round trip)
         const float dx = L.x[j] - L.x[i], dy = L.y[j] - L.y[i];
-        const float d2 = dx * dx + dy * dy;
+        const float d2 = fm(dx, dx, dy * dy);
         int klo = 0, cnt = 0;
         if (live && j != i && !(d2 > lim * lim)) {
             if (d2 <= circ * circ * 1.002f) {
@@ -696,8 +696,8 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
         // the pair's record for its box tests (registers of this lane, fetched by the test lanes with ds_bpermute -- no LDS
         // storage: a strip of records per wave cost more in resident scenes than it saved in instructions): ray origin in
         // j's box frame, rotation from i's frame into it, first ray / first test (klo - excl: 24 bits signed, local fan: 6)
-        const float rec_ox = -(dx * cj + dy * sj), rec_oy = -(dy * cj - dx * sj);
-        const float rec_cr = ci * cj + si * sj, rec_sr = ci * sj - si * cj;
+        const float rec_ox = -fm(dx, cj, dy * sj), rec_oy = -fm(dy, cj, -(dx * sj));
+        const float rec_cr = fm(ci, cj, si * sj), rec_sr = fm(ci, sj, -(si * cj));
         const int rec_ix = ((klo - excl) & 0xffffff) | (lp << 24);      // ray of test t = (klo - excl + t) mod NL
         int carry = 0;                                    // (lane + 1) of the pair that owns the last test of the previous batch
         for (int t0 = 0; t0 < total; t0 += 64) {
@@ -722,7 +722,7 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
                 int k = ((pw << 8) >> 8) + t;              // (klo - excl) is a signed 24-bit field
                 if (k >= NL) k -= NL;
                 const float2 r = reinterpret_cast<const float2*>(rays)[k];
-                const float tt = ray_box(ox, oy, r.x * cr + r.y * sr, r.y * cr - r.x * sr, hl, hw);
+                const float tt = ray_box(ox, oy, fm(r.x, cr, r.y * sr), fm(r.y, cr, -(r.x * sr)), hl, hw);
                 if (tt >= 0.0f) atomicMin(&best[slp * NL + k], __float_as_uint(tt));
                 if (COPO_PROFILE_SKIP & 256) { const int nh = __popcll(__ballot(tt >= 0.0f)); COPO_COUNT(12, nh); }
             }
@@ -742,7 +742,7 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
             const int lp = live ? (int)(((float)c + 0.5f) * inv_ns) : 0;
             const int i = L.plist[ip0 + lp], j = L.slist[live ? c - lp * ns : 0];
             const float dx = L.x[j] - L.x[i], dy = L.y[j] - L.y[i];
-            const bool reach = live && j != i && !(dx * dx + dy * dy > lim * lim);
+            const bool reach = live && j != i && !(fm(dx, dx, dy * dy) > lim * lim);
             const unsigned long long m = __ballot(reach);
             if (reach) cq[nq + __popcll(m & lt)] = (uint16_t)c;
             nq += __popcll(m);
@@ -778,7 +778,7 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const float dx = L.x[jj[h]] - L.x[ii[h]], dy = L.y[jj[h]] - L.y[ii[h]];
-                rr[h] = rr[h] && jj[h] != ii[h] && !(dx * dx + dy * dy > lim * lim);
+                rr[h] = rr[h] && jj[h] != ii[h] && !(fm(dx, dx, dy * dy) > lim * lim);
             }
             const unsigned long long m0 = __ballot(rr[0]), m1 = __ballot(rr[1]);
             const int n0 = __popcll(m0), n1 = __popcll(m1);
@@ -1042,7 +1042,7 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK, (ONE && !EXT) ?
                     const int rr_ = r + h, jh = h ? j1 : j0;
                     const float ddx = (h ? x1 : x0) - xme, ddy = (h ? y1 : y0) - yme;
                     const int lanes = rr_ > R ? 0 : ((rr_ == R && (N & 1) == 0) ? R : N);
-                    const bool near = sol_me && lane < lanes && (ddx * ddx + ddy * ddy <= near2);
+                    const bool near = sol_me && lane < lanes && (fm(ddx, ddx, ddy * ddy) <= near2);
                     const unsigned long long m = __ballot(near);
                     if (m != 0ull) {
                         if (near) nq[nn + pk_mbcnt(m)] = (uint16_t)((lane << 8) | jh);
@@ -1068,7 +1068,7 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK, (ONE && !EXT) ?
             const int i = L.alist[ia], j = L.clist[live ? c - ia * nc : 0];
             const float xi = L.x[i], yi = L.y[i], xj = L.x[j], yj = L.y[j];
             const float ddx = xj - xi, ddy = yj - yi;
-            const bool near = live && (i != j) && (ddx * ddx + ddy * ddy <= near2);
+            const bool near = live && (i != j) && (fm(ddx, ddx, ddy * ddy) <= near2);
             if (near && obb_overlap2(xi, yi, L.cs[i], L.sn[i], hl, hw, xj, yj, L.cs[j], L.sn[j], hl, hw)) L.crash[i] = 1;
         }
     }
@@ -1159,7 +1159,7 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK, (ONE && !EXT) ?
                     const float2 spq = lane < p.n_safe ? *reinterpret_cast<const float2*>(p.safe_pose + 4 * lane) : make_float2(0.0f, 0.0f);
                     for (int q = 0; q < p.n_safe; ++q) {
                         const float dx = s.x - readlane_f(spq.x, q), dy = s.y - readlane_f(spq.y, q);
-                        const bool pre = solid_now && (dx * dx + dy * dy <= rr2);
+                        const bool pre = solid_now && (fm(dx, dx, dy * dy) <= rr2);
                         const unsigned long long m = __ballot(pre);
                         if (m != 0ull) {
                             const int c = __popcll(m);
@@ -1326,7 +1326,7 @@ __global__ void __launch_bounds__(ONE ? 64 : COPO_SIM_MAX_BLOCK, (ONE && !EXT) ?
         // one wave owns the scene: the pair queue comes from the reach masks of the neighbour walk (a scene that reset has new poses:
         // every solid vehicle is handed to the window pass, which tests the reach itself)
         extern __shared__ unsigned int dyn[];
-        const int o_q = (p.chunk > 0 ? p.chunk : N) * p.num_lasers;
+        const int o_q = (p.chunk > 0 ? p.chunk : N) * p.num_lasers + LIDAR_MIN_PAD;
         lidar_by_wave(p, [](int v) { return make_float4(L.x[v], L.y[v], L.cs[v], L.sn[v]); }, L.plist, reach_lo, reach_hi, dyn,
                       reinterpret_cast<uint16_t*>(dyn + o_q), lds_rays(p),
                       reinterpret_cast<int*>(dyn + lidar_lds_words(p.chunk, p.nbr_chunk, N, p.num_lasers) + ray_lds_words(p.num_lasers)), e, lane,

@@ -14,17 +14,20 @@ constexpr float kPi = 3.14159265f;
 constexpr float kTwoPi = 6.28318531f;
 constexpr float kHalfPi = 1.57079633f;
 
+// Round 6: the hot expressions of the spec are stated with explicit fused multiply-adds (v_fma_f32, one rounding) -- the same
+// ones, in the same places, as `fm` (= fmaf) in oracle/copo_oracle.c; -ffp-contract=off keeps the compiler from fusing anything else.
+__device__ __forceinline__ float fm(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
 // sin/cos with 3-term Cody-Waite reduction by pi/2 and the cephes single-precision kernels.
 __device__ __forceinline__ void sincos_det(float x, float& s, float& c) {
-    const float kf = floorf(x * 0.636619772f + 0.5f);
+    const float kf = floorf(fm(x, 0.636619772f, 0.5f));
     const int k = (int)kf;
-    float r = x - kf * 1.5703125f;
-    r = r - kf * 4.83751297e-4f;
-    r = r - kf * 7.54978996e-8f;
+    float r = fm(-kf, 1.5703125f, x);
+    r = fm(-kf, 4.83751297e-4f, r);
+    r = fm(-kf, 7.54978996e-8f, r);
     const float z = r * r;
-    const float sp = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
-    const float cp =
-        ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
+    const float sp = fm(fm(fm(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+    const float cp = fm(z, fm(z, fm(fm(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), -0.5f), 1.0f);
     const int q = k & 3;
     const float a = (q & 1) ? cp : sp;
     const float b = (q & 1) ? sp : cp;
@@ -41,8 +44,7 @@ __device__ __forceinline__ float atan2_det(float y, float x) {
     const float t = (hi ? mn - mx : mn) / (hi ? mn + mx : mx);
     const float off = hi ? 0.785398163f : 0.0f;
     const float z = t * t;
-    const float p =
-        (((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * t + t;
+    const float p = fm(fm(fm(fm(8.05374449538e-2f, z, -1.38776856032e-1f), z, 1.99777106478e-1f), z, -3.33329491539e-1f) * z, t, t);
     float r = off + p;
     if (ay > ax) r = kHalfPi - r;
     if (x < 0.0f) r = kPi - r;

@@ -59,8 +59,8 @@ __host__ __device__ inline PkLay pk_lay(int N, int NL, int CH) {
     y.o_dec = y.o_u + 8 * y.NP;
     y.o_aid = y.o_u + 9 * y.NP;
     y.o_perm = y.o_u + 10 * y.NP;
-    y.o_queue = y.o_u + CH * NL;
-    const int a = 10 * y.NP + COPO_MAX_SPAWNS / 2, b = CH * NL + (CH * N + 1) / 2, c = (N * N / 2 + 1) / 2 + 1;
+    y.o_queue = y.o_u + CH * NL + LIDAR_MIN_PAD;
+    const int a = 10 * y.NP + COPO_MAX_SPAWNS / 2, b = CH * NL + LIDAR_MIN_PAD + (CH * N + 1) / 2, c = (N * N / 2 + 1) / 2 + 1;
     const int u = a > b ? (a > c ? a : c) : (b > c ? b : c);
     y.scene_words = (y.o_u + u + 3) & ~3;
     return y;
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_packed_kernel(con
                 const int rr_ = r + h, jh = h ? j1 : j0;
                 const float ddx = (h ? p1.x : p0.x) - pme.x, ddy = (h ? p1.y : p0.y) - pme.y;
                 const int lanes = rr_ > R ? 0 : ((rr_ == R && (N & 1) == 0) ? R : N);
-                const bool near = sol_me && lane < lanes && (ddx * ddx + ddy * ddy <= near2);
+                const bool near = sol_me && lane < lanes && (fm(ddx, ddx, ddy * ddy) <= near2);
                 const unsigned long long m = __ballot(near);
                 if (m != 0ull) {
                     if (near) nq[nn + pk_mbcnt(m)] = (uint16_t)((lane << 8) | jh);
@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(COPO_SIM_MAX_BLOCK) sim_step_packed_kernel(con
             const float2 spq = lane < p.n_safe ? *reinterpret_cast<const float2*>(p.safe_pose + 4 * lane) : make_float2(0.0f, 0.0f);
             for (int q = 0; q < p.n_safe; ++q) {
                 const float dx = ps.x - readlane_f(spq.x, q), dy = ps.y - readlane_f(spq.y, q);
-                const bool pre = sol && (dx * dx + dy * dy <= rr2);
+                const bool pre = sol && (fm(dx, dx, dy * dy) <= rr2);
                 const unsigned long long m = __ballot(pre);
                 if (m != 0ull) {
                     const int c = __popcll(m);

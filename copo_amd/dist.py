@@ -79,26 +79,26 @@ def all_reduce_max_(t):
     return t
 
 
-_reduce_scatter_ok = None      # None: not tried yet; False: this backend has none (gloo), all-reduce instead
+def has_reduce_scatter():
+    """Decided ONCE from the backend's name, identically on every rank (a per-rank try / except at call time could send one rank
+    into the all-reduce while its peers sit in the reduce-scatter): RCCL has reduce_scatter_tensor, gloo does not.
+    COPO_REDUCE_SCATTER=0 forces the all-reduce branch (the multi-GPU A/B of the two)."""
+    if os.environ.get("COPO_REDUCE_SCATTER", "1") == "0":
+        return False
+    return is_dist() and td.get_backend() == "nccl"
 
 
 def reduce_scatter_sum_(out, flat):
     """Rows [r c, (r + 1) c) of the sum over the ranks of `flat` [world c, ...] for rank r, c = out.shape[0]; returns the tensor that
     holds them: `out` after a reduce-scatter (half the wire bytes of an all-reduce), or this rank's slice of `flat` after an all-reduce
-    where the backend has no reduce-scatter (gloo: the tests' ranks on one device).  Every rank takes the same branch."""
-    global _reduce_scatter_ok
+    where the backend has no reduce-scatter (gloo: the tests' ranks on one device).  Every rank takes the same branch
+    (`has_reduce_scatter`); an error of the collective is raised, never turned into the other branch."""
     c = out.shape[0]
     if not _several():
         return flat[:c]
-    if _reduce_scatter_ok is not False:
-        try:
-            td.reduce_scatter_tensor(out, flat, op=td.ReduceOp.SUM)
-            _reduce_scatter_ok = True
-            return out
-        except (RuntimeError, NotImplementedError, ValueError):
-            if _reduce_scatter_ok:
-                raise
-            _reduce_scatter_ok = False
+    if has_reduce_scatter():
+        td.reduce_scatter_tensor(out, flat, op=td.ReduceOp.SUM)
+        return out
     td.all_reduce(flat, op=td.ReduceOp.SUM)
     r = td.get_rank()
     return flat[r * c:(r + 1) * c]
@@ -162,16 +162,19 @@ def _probe_child(module, port_shift, timeout, need_nccl, extra_env=None):
         return False
     # the children's rendezvous port: a port that is free on rank 0's host right now, handed to every rank over the parent group
     # (a fixed MASTER_PORT + shift can collide with another job of the node); `port_shift` only if that exchange fails
+    # Only the bind may fail quietly (an IPv6-only or unresolvable MASTER_ADDR): rank 0 then broadcasts 0 and EVERY rank takes the
+    # shifted port.  The broadcast itself is executed by every rank unconditionally -- a rank that skipped it would pair its next
+    # collective with the peers' pending broadcast.
     port = [0]
-    try:
-        if td.get_rank() == 0:
+    if td.get_rank() == 0:
+        try:
             import socket
             with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
                 sk.bind((os.environ.get("MASTER_ADDR", "127.0.0.1"), 0))
                 port[0] = int(sk.getsockname()[1])
-        td.broadcast_object_list(port, src=0)
-    except Exception:      # noqa: BLE001
-        port = [0]
+        except Exception:      # noqa: BLE001
+            port[0] = 0
+    td.broadcast_object_list(port, src=0)
     if not port[0]:
         port[0] = int(os.environ.get("MASTER_PORT", "29500")) + port_shift
     env = dict(os.environ, MASTER_PORT=str(port[0]))

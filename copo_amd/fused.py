@@ -11,6 +11,8 @@ import torch
 
 from . import _capi
 
+_META_DOT_SPLIT = 8      # COPO_META_DOT_SPLIT of include/copo_hip.h (DOT_SPLIT in csrc/learn_meta.inc): partial sums per minibatch
+
 
 def _mlp_layers(seq_or_list):
     """[SlimFC, ...] -> list of nn.Linear."""
@@ -334,9 +336,14 @@ class FusedLearner:
 
     def meta_batch_dot(self, g, n, nb, gv, denom=None):
         """gv[:nb] = <g[b][0], g[b][1]>; denom [nb] float32: scaled by 1 / denom^2 (unit-weight gradients of the row store)."""
-        part = getattr(self, "_dot_part", None)        # this learner's own scratch for the partial sums (8 per minibatch)
-        if part is None or part.numel() < 8 * int(nb):
-            part = self._dot_part = torch.zeros(8 * max(int(nb), 256), dtype=torch.float64, device=g.device)
+        # caller-owned scratch for the partial sums (COPO_META_DOT_SPLIT = 8 per minibatch, learn_meta.inc), ONE PER STREAM: two
+        # calls on different streams never share it, and a buffer that grows is allocated under the stream that uses it (the old one
+        # stays referenced by the allocator until that stream's queued kernels are past it)
+        key = int(torch.cuda.current_stream(g.device).cuda_stream)
+        parts = self.__dict__.setdefault("_dot_parts", {})
+        part = parts.get(key)
+        if part is None or part.numel() < _META_DOT_SPLIT * int(nb):
+            part = parts[key] = torch.zeros(_META_DOT_SPLIT * max(int(nb), 256), dtype=torch.float64, device=g.device)
         _capi.check(_capi.lib.copo_meta_batch_dot_f64(g.data_ptr(), int(n), int(nb), gv.data_ptr(),
                                                       None if denom is None else denom.data_ptr(), part.data_ptr(), _capi.current_stream()))
 

@@ -477,6 +477,9 @@ class CoPOPolicy(CCPPOPolicy):
                 self._meta_aux = torch.cuda.Stream(device=self.device)
             ev0 = torch.cuda.Event()
             ev0.record()
+            # (`en` is a main-stream temporary of the caller that the aux stream reads: the caching allocator must not hand its block
+            #  out again before aux is past it -- c10d no longer record_stream()s the inputs of synchronous collectives)
+            en.record_stream(self._meta_aux)
             with torch.cuda.stream(self._meta_aux):
                 self._meta_aux.wait_event(ev0)
                 en_d, w_d, eps_d = row_terms()

@@ -37,20 +37,24 @@
 /* ------------------------------------------------------------------------------------------------
  * deterministic math (spec: DESIGN.md section 3.2)
  * ---------------------------------------------------------------------------------------------- */
+/* Round 6: the hot expressions of the spec are stated with explicit FUSED multiply-adds (one rounding), the same ones in
+ * the HIP kernels (`fm` in csrc/sim_math.h = v_fma_f32): a rotation, dot or cross product is a multiply + an fma instead of
+ * two multiplies + an add.  fmaf() is exact-then-rounded on every IEEE machine (glibc's software path included), so HIP ==
+ * oracle stays bit for bit; -ffp-contract=off still keeps the compiler from fusing anything that is not written as fm(). */
+static inline float fm(float a, float b, float c) { return fmaf(a, b, c); }
 #define PI_F 3.14159265f
 #define TWO_PI_F 6.28318531f
 #define HALF_PI_F 1.57079633f
 
 static void o_sincosf(float x, float* s, float* c) {
-    float kf = floorf(x * 0.636619772f + 0.5f);
+    float kf = floorf(fm(x, 0.636619772f, 0.5f));
     int k = (int)kf;
-    float r = x - kf * 1.5703125f;
-    r = r - kf * 4.83751297e-4f;
-    r = r - kf * 7.54978996e-8f;
+    float r = fm(-kf, 1.5703125f, x);
+    r = fm(-kf, 4.83751297e-4f, r);
+    r = fm(-kf, 7.54978996e-8f, r);
     float z = r * r;
-    float sp = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
-    float cp = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z -
-               0.5f * z + 1.0f;
+    float sp = fm(fm(fm(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+    float cp = fm(z, fm(z, fm(fm(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), -0.5f), 1.0f);
     switch (k & 3) {
         case 0: *s = sp; *c = cp; break;
         case 1: *s = cp; *c = -sp; break;
@@ -68,7 +72,7 @@ static float o_atan2f(float y, float x) {
     float t = (hi ? mn - mx : mn) / (hi ? mn + mx : mx);
     float off = hi ? 0.785398163f : 0.0f;
     float z = t * t;
-    float p = (((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * t + t;
+    float p = fm(fm(fm(fm(8.05374449538e-2f, z, -1.38776856032e-1f), z, 1.99777106478e-1f), z, -3.33329491539e-1f) * z, t, t);
     float r = off + p;
     if (ay > ax) r = HALF_PI_F - r;
     if (x < 0.0f) r = PI_F - r;
@@ -365,23 +369,23 @@ static void project_seg(const float* g, float x, float y, float ch, float sh, fl
     float dx = x - g[0], dy = y - g[1];
     float kap = g[5];
     if (kap == 0.0f) {
-        *sl = dx * g[2] + dy * g[3];
-        *lat = dy * g[2] - dx * g[3];
-        *sinpsi = sh * g[2] - ch * g[3];
+        *sl = fm(dx, g[2], dy * g[3]);
+        *lat = fm(dy, g[2], -(dx * g[3]));
+        *sinpsi = fm(sh, g[2], -(ch * g[3]));
     } else {
         float sg = kap > 0.0f ? 1.0f : -1.0f;
         float R = g[12];
         /* centre = p0 + sg*R*n0, n0 = (-sin0, cos0) */
-        float cx = g[0] - sg * R * g[3], cy = g[1] + sg * R * g[2];
+        float cx = fm(-(sg * R), g[3], g[0]), cy = fm(sg * R, g[2], g[1]);
         float ex = x - cx, ey = y - cy;
-        float rho = sqrtf(ex * ex + ey * ey);
-        float dotp = g[14] * ex + g[15] * ey;
-        float crs = g[14] * ey - g[15] * ex;
+        float rho = sqrtf(fm(ex, ex, ey * ey));
+        float dotp = fm(g[14], ex, g[15] * ey);
+        float crs = fm(g[14], ey, -(g[15] * ex));
         float ang = o_atan2f(sg * crs, dotp);
-        *sl = ang * R + 0.5f * g[4];
+        *sl = fm(ang, R, 0.5f * g[4]);
         *lat = sg * (R - rho);
         /* left normal of the lane at the vehicle = -sg * e / rho */
-        *sinpsi = rho > 0.0f ? (-sg * (ch * ex + sh * ey)) / rho : 0.0f;
+        *sinpsi = rho > 0.0f ? (-sg * fm(ch, ex, sh * ey)) / rho : 0.0f;
     }
 }
 
@@ -417,13 +421,15 @@ typedef struct step_tmp {
 static int obb_overlap2(float xi, float yi, float ci, float si, float ai, float bi,
                         float xj, float yj, float cj, float sj, float aj, float bj) {
     float dx = xj - xi, dy = yj - yi;
-    float cc = fabsf(ci * cj + si * sj), ss = fabsf(ci * sj - si * cj);
+    /* (ss stays two products and a subtraction: a fused ci * sj - round(si * cj) is not the exact negation of the pair's
+     *  other order cj * si - round(sj * ci), and the kernel tests every UNORDERED pair once) */
+    float cc = fabsf(fm(ci, cj, si * sj)), ss = fabsf(ci * sj - si * cj);
     /* axes of i */
-    if (fabsf(dx * ci + dy * si) > ai + aj * cc + bj * ss) return 0;
-    if (fabsf(dy * ci - dx * si) > bi + aj * ss + bj * cc) return 0;
+    if (fabsf(fm(dx, ci, dy * si)) > fm(bj, ss, fm(aj, cc, ai))) return 0;
+    if (fabsf(fm(dy, ci, -(dx * si))) > fm(bj, cc, fm(aj, ss, bi))) return 0;
     /* axes of j */
-    if (fabsf(dx * cj + dy * sj) > aj + ai * cc + bi * ss) return 0;
-    if (fabsf(dy * cj - dx * sj) > bj + ai * ss + bi * cc) return 0;
+    if (fabsf(fm(dx, cj, dy * sj)) > fm(bi, ss, fm(ai, cc, aj))) return 0;
+    if (fabsf(fm(dy, cj, -(dx * sj))) > fm(bi, cc, fm(ai, ss, bj))) return 0;
     return 1;
 }
 
@@ -530,7 +536,7 @@ static void write_obs(oracle_sim* s, int e, const copo_step_out* out, const uint
         float sl, lat, sinpsi;
         project_seg(g, x, y, cs[i], sn[i], &sl, &lat, &sinpsi);
         float lanes = floorf(g[COPO_SEG_LANES]);
-        float lif = floorf(0.5f - lat * s->inv_w);
+        float lif = floorf(fm(-lat, s->inv_w, 0.5f));
         lif = lif < 0.0f ? 0.0f : (lif > lanes - 1.0f ? lanes - 1.0f : lif);
         float left = 0.5f * w - lat;            /* distance to the left edge of the road (of the current route) */
         float right = lanes * w - left;
@@ -546,11 +552,11 @@ static void write_obs(oracle_sim* s, int e, const copo_step_out* out, const uint
             o[col++] = o_clip(left / tw, 0.0f, 1.0f);
             o[col++] = o_clip(right / tw, 0.0f, 1.0f);
         }
-        o[col++] = o_clip(0.5f - 0.5f * sinpsi, 0.0f, 1.0f);        /* heading_diff: cos to the lane's RIGHT normal */
-        o[col++] = o_clip((fabsf(FP(s, S_V, e)[i]) * 3.6f + 1.0f) * s->inv_vnorm, 0.0f, 1.0f);    /* vehicle.speed: a magnitude */
-        o[col++] = o_clip(0.5f + FP(s, S_STEER, e)[i] * (1.0f / 120.0f), 0.0f, 1.0f);  /* (steering / MAX_STEERING(60) + 1) / 2 */
-        o[col++] = o_clip(0.5f + 0.5f * FP(s, S_PSTEER, e)[i], 0.0f, 1.0f);    /* last_current_action[0]: the step before */
-        o[col++] = o_clip(0.5f + 0.5f * FP(s, S_PTHROTTLE, e)[i], 0.0f, 1.0f);
+        o[col++] = o_clip(fm(-0.5f, sinpsi, 0.5f), 0.0f, 1.0f);        /* heading_diff: cos to the lane's RIGHT normal */
+        o[col++] = o_clip(fm(fabsf(FP(s, S_V, e)[i]), 3.6f, 1.0f) * s->inv_vnorm, 0.0f, 1.0f);    /* vehicle.speed: a magnitude */
+        o[col++] = o_clip(fm(FP(s, S_STEER, e)[i], 1.0f / 120.0f, 0.5f), 0.0f, 1.0f);  /* (steering / MAX_STEERING(60) + 1) / 2 */
+        o[col++] = o_clip(fm(0.5f, FP(s, S_PSTEER, e)[i], 0.5f), 0.0f, 1.0f);    /* last_current_action[0]: the step before */
+        o[col++] = o_clip(fm(0.5f, FP(s, S_PTHROTTLE, e)[i], 0.5f), 0.0f, 1.0f);
         o[col++] = o_clip(fabsf(FP(s, S_YAWRATE, e)[i]), 0.0f, 1.0f);          /* |heading change| / 0.1 */
         if (c->lane_line_lasers > 0) {
             for (int k = 0; k < c->lane_line_lasers; ++k) {
@@ -559,8 +565,8 @@ static void write_obs(oracle_sim* s, int e, const copo_step_out* out, const uint
                 o[col++] = detector_ray(s, x, y, dx, dy, c->lane_line_range, 1.0f) * s->inv_lane_range;
             }
         } else {
-            float latr = -(lat + lif * w);      /* offset in the vehicle's lane, right +; MAX_LANE_WIDTH 4.5 */
-            o[col++] = o_clip(0.5f + latr * (1.0f / 4.5f), 0.0f, 1.0f);
+            float latr = -fm(lif, w, lat);      /* offset in the vehicle's lane, right +; MAX_LANE_WIDTH 4.5 */
+            o[col++] = o_clip(fm(latr, 1.0f / 4.5f, 0.5f), 0.0f, 1.0f);
         }
         /* navigation block: check points at the end of the current road and of the next one (the current one again on
          * the final road), Navigation._get_info_for_checkpoint */
@@ -579,16 +585,16 @@ static void write_obs(oracle_sim* s, int e, const copo_step_out* out, const uint
                     cky = gn[1] - gn[2] * off;
                 }
                 float vx = ckx - x, vy = cky - y;
-                float nrm = sqrtf(vx * vx + vy * vy);
+                float nrm = sqrtf(fm(vx, vx, vy * vy));
                 if (nrm > 50.0f) {
                     float sc = 50.0f / nrm;
                     vx = vx * sc;
                     vy = vy * sc;
                 }
-                float fwd = vx * cs[i] + vy * sn[i], rhs = vx * sn[i] - vy * cs[i];
+                float fwd = fm(vx, cs[i], vy * sn[i]), rhs = fm(vx, sn[i], -(vy * cs[i]));
                 float* q = o + col;
-                q[0] = o_clip(0.5f + fwd * 0.01f, 0.0f, 1.0f);
-                q[1] = o_clip(0.5f + rhs * 0.01f, 0.0f, 1.0f);
+                q[0] = o_clip(fm(fwd, 0.01f, 0.5f), 0.0f, 1.0f);
+                q[1] = o_clip(fm(rhs, 0.01f, 0.5f), 0.0f, 1.0f);
                 q[2] = gk[COPO_SEG_FEAT];
                 q[3] = gk[5] == 0.0f ? 0.5f : (gk[5] < 0.0f ? 1.0f : 0.0f);
                 q[4] = gk[COPO_SEG_FEAT + 2];
@@ -606,12 +612,12 @@ static void write_obs(oracle_sim* s, int e, const copo_step_out* out, const uint
             if (j == i || !solid[j]) continue;
             float rx = FP(s, S_X, e)[j] - x, ry = FP(s, S_Y, e)[j] - y;
             float lim = range + circ;
-            if (rx * rx + ry * ry > lim * lim) continue;
+            if (fm(rx, rx, ry * ry) > lim * lim) continue;
             near[j] = 1;
-            pox[j] = -(rx * cs[j] + ry * sn[j]);
-            poy[j] = -(ry * cs[j] - rx * sn[j]);
-            pcr[j] = cs[i] * cs[j] + sn[i] * sn[j];
-            psr[j] = cs[i] * sn[j] - sn[i] * cs[j];
+            pox[j] = -fm(rx, cs[j], ry * sn[j]);
+            poy[j] = -fm(ry, cs[j], -(rx * sn[j]));
+            pcr[j] = fm(cs[i], cs[j], sn[i] * sn[j]);
+            psr[j] = fm(cs[i], sn[j], -(sn[i] * cs[j]));
         }
         for (int k = 0; k < L; ++k) {
             float rc = s->ray_cs[2 * k], rs = s->ray_cs[2 * k + 1];
@@ -621,7 +627,7 @@ static void write_obs(oracle_sim* s, int e, const copo_step_out* out, const uint
                 /* ray vs box j in j's frame, mirrored so that the direction is non-negative on both axes; entering and
                  * exiting times are fractions n/a compared by cross-multiplication (no division until a hit is known) */
                 float ox = pox[j], oy = poy[j];
-                float ddx = rc * pcr[j] + rs * psr[j], ddy = rs * pcr[j] - rc * psr[j];
+                float ddx = fm(rc, pcr[j], rs * psr[j]), ddy = fm(rs, pcr[j], -(rc * psr[j]));
                 float ax = fabsf(ddx), ay = fabsf(ddy);
                 float oxs = ddx < 0.0f ? -ox : ox, oys = ddy < 0.0f ? -oy : oy;
                 float nxe = -(hl + oxs), nxx = hl - oxs, nye = -(hw + oys), nyx = hw - oys;
@@ -842,20 +848,20 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
             for (int k = 0; k < c->substeps; ++k) {
                 /* reverse gear (MetaDrive enable_reverse): a negative throttle is engine force backwards, no brake, v may go negative */
                 float a = a1 >= 0.0f ? (v < c->max_speed ? a1 * c->acc_max : 0.0f) : (c->reverse_acc > 0.0f ? (v > -c->max_speed ? a1 * c->reverse_acc : 0.0f) : -brake);
-                v = v + a * h;
+                v = fm(a, h, v);
                 if (v < 0.0f && !(c->reverse_acc > 0.0f)) v = 0.0f;
-                float dxh = cs * cb - sn * sb, dyh = sn * cb + cs * sb;
-                x = x + v * dxh * h;
-                y = y + v * dyh * h;
+                float dxh = fm(cs, cb, -(sn * sb)), dyh = fm(sn, cb, cs * sb);
+                x = fm(v * dxh, h, x);
+                y = fm(v * dyh, h, y);
                 float dth = v * yawk * h;
                 if (c->lat_acc_max > 0.0f && v * fabsf(dth) > c->lat_acc_max * h) {      /* tyres slide: v x yaw rate is friction-limited */
                     float lim = (c->lat_acc_max * h) / v;
                     dth = dth < 0.0f ? -lim : lim;
                 }
                 float q = dth * dth;
-                float sd2 = dth - dth * q * (0.166666667f - q * 0.00833333333f);
-                float cd2 = 1.0f - q * (0.5f - q * 0.0416666667f);
-                float cn = cs * cd2 - sn * sd2, sm = sn * cd2 + cs * sd2;
+                float sd2 = fm(-(dth * q), fm(-q, 0.00833333333f, 0.166666667f), dth);
+                float cd2 = fm(-q, fm(-q, 0.0416666667f, 0.5f), 1.0f);
+                float cn = fm(cs, cd2, -(sn * sd2)), sm = fm(sn, cd2, cs * sd2);
                 cs = cn;
                 sn = sm;
                 th = o_wrap_pi(th + dth);
@@ -930,12 +936,12 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
             float lanes_f = g[COPO_SEG_LANES], lanes = floorf(lanes_f), lfr = lanes_f - lanes;      /* fraction: edge-line flags, eighths */
             int lcode = (int)(lfr * 8.0f);
             int left_solid = (lcode & 2) != 0, right_solid = (lcode & 4) != 0, left_open = (lcode & 1) != 0;
-            float lif = floorf(0.5f - lat * s->inv_w);
+            float lif = floorf(fm(-lat, s->inv_w, 0.5f));
             lif = lif < 0.0f ? 0.0f : (lif > lanes - 1.0f ? lanes - 1.0f : lif);
             float left = 0.5f * w - lat, right = (lanes * w + funnel_extra(g, sl, w)) - left;
             /* the body's half extent across the road (heading error psi): the edge lines must not be touched */
-            float cos2 = 1.0f - sinpsi * sinpsi;
-            float edge = c->body_margin * (hw * sqrtf(cos2 > 0.0f ? cos2 : 0.0f) + hl * fabsf(sinpsi));
+            float cos2 = fm(-sinpsi, sinpsi, 1.0f);
+            float edge = c->body_margin * fm(hl, fabsf(sinpsi), hw * sqrtf(cos2 > 0.0f ? cos2 : 0.0f));
             int on_road = (left >= (left_solid ? edge : (left_open ? -w : 0.0f))) && (right >= (right_solid ? edge : 0.0f));
             /* _is_arrive_destination: within +-5 m of the end of the final road, anywhere across it */
             int arrive = (seg == nseg - 1) && (sl > g[4] - c->arrive_margin) && (sl < g[4] + c->arrive_margin) && on_road;
@@ -943,7 +949,7 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
             int crash = crash_any[n] || too_fast;
             /* reward_function: longitudinal movement on the vehicle's lane (lane i of an arc is 1 + kappa * i * w longer
              * than lane 0) + speed term; use_lateral is off in 0.2.5 */
-            float r = c->driving_reward * ((prog - prev) * (1.0f + g[5] * (lif * w))) + c->speed_reward * (fabsf(V[n]) / c->max_speed);
+            float r = fm(c->driving_reward, (prog - prev) * fm(g[5], lif * w, 1.0f), c->speed_reward * (fabsf(V[n]) / c->max_speed));
             uint8_t fl = COPO_F_ACTED;
             if (arrive) { r = c->success_reward; fl |= COPO_F_ARRIVE; }
             else if (out_of_road) { r = -c->out_penalty; }

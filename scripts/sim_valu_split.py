@@ -3,7 +3,9 @@
 launch, so the difference of the SQ_INSTS_VALU counter against the full build is the phase's own instruction count.
 
 usage (on the GPU box):  python scripts/sim_valu_split.py [E] [block]
-   -> one rocprofv3 --pmc pass per variant, table on stdout.  Child mode: sim_valu_split.py --child <mask> E block state.pt"""
+   -> one rocprofv3 --pmc pass per variant, table on stdout.  SPLIT_LDS=1: a second pass per variant with the LDS counters
+   (SQ_LDS_BANK_CONFLICT, SQ_LDS_ADDR_CONFLICT, SQ_LDS_IDX_ACTIVE, SQ_ACTIVE_INST_LDS: cycles summed over the chip), so that the
+   difference against the full build says which phase the bank conflicts belong to.  Child mode: sim_valu_split.py --child <mask> E block state.pt"""
 import json
 import os
 import sqlite3
@@ -83,6 +85,7 @@ if __name__ == "__main__":
     if not os.path.exists(state):      # scene state after 60 steps of the full build (not profiled)
         subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "0", str(E), str(block), state], capture_output=True, cwd="/tmp", env=env)
     base = None
+    base_lds = None
     for mask, name in NAMES.items():
         if not os.path.exists(os.path.join(ROOT, "copo_amd", "lib", "libcopo_hip_prof_%d.so" % mask)):
             continue
@@ -103,4 +106,18 @@ if __name__ == "__main__":
             msg += "   -> phase: VALU %6.0f (%4.1f %%)  SALU %6.0f  LDS %5.0f" % (
                 base["SQ_INSTS_VALU"] - per["SQ_INSTS_VALU"], 100 * (base["SQ_INSTS_VALU"] - per["SQ_INSTS_VALU"]) / base["SQ_INSTS_VALU"],
                 base["SQ_INSTS_SALU"] - per["SQ_INSTS_SALU"], base["SQ_INSTS_LDS"] - per["SQ_INSTS_LDS"])
+        if os.environ.get("SPLIT_LDS"):
+            d2 = os.path.join(tmp, "l%d" % mask)
+            subprocess.run(["rm", "-rf", d2])
+            subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_ADDR_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_LDS", "SQ_INSTS_LDS", "-d", d2, "--",
+                            sys.executable, os.path.abspath(__file__), "--child", str(mask), str(E), str(block), state],
+                           capture_output=True, text=True, cwd="/tmp", env=env)
+            c2 = counters(d2)
+            lds = {k: c2.get(k, float("nan")) / E for k in ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_ADDR_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_LDS")}
+            if mask == 0:
+                base_lds = lds
+            msg += "\n          LDS cycles per scene: bank conflict %6.0f  addr conflict %6.0f  idx active %6.0f  inst active %6.0f" % (
+                lds["SQ_LDS_BANK_CONFLICT"], lds["SQ_LDS_ADDR_CONFLICT"], lds["SQ_LDS_IDX_ACTIVE"], lds["SQ_ACTIVE_INST_LDS"])
+            if mask:
+                msg += "   -> phase: bank conflict %6.0f  idx active %6.0f" % (base_lds["SQ_LDS_BANK_CONFLICT"] - lds["SQ_LDS_BANK_CONFLICT"], base_lds["SQ_LDS_IDX_ACTIVE"] - lds["SQ_LDS_IDX_ACTIVE"])
         print(msg, flush=True)

@@ -192,9 +192,13 @@ def test_fused_bf16_operand_mode_matches_autocast(name, fuse, odim):
         fz.fused.step(fz._row_sources, stats=fz.fused.stats)
     for (n1, p1), (n2, p2) in zip(ref.model.named_parameters(), fz.model.named_parameters()):
         if p1.dtype == torch.float32:
-            diff = (p1 - p2).abs()       # Adam's first steps are ~lr * sign(g): only gradients at the rounding floor may flip
+            # bfloat16 OPERANDS: a gradient element carries ~2^-9 of relative rounding from the two evaluations' different operand
+            # roundings, so more signs flip in Adam's first steps than in fp32 (5 % of the elements allowed beyond a tenth of a
+            # step); none may differ by more than opposite signs in both steps
+            lr = float(fz.config["lr"])
+            diff = (p1.detach() - p2.detach()).abs()
             assert float((diff > 3e-5).float().mean()) < 0.05, (n1, float((diff > 3e-5).float().mean()))
-            assert float(diff.max()) <= 2 * 2 * 3e-4 + 1e-6, (n1, float(diff.max()))
+            assert float(diff.max()) <= 2 * 2 * lr + 1e-6, (n1, float(diff.max()))
 
 
 def bf16_round(x):
