@@ -673,6 +673,7 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["COPO_BENCH_TRACE_S"]), exit=True)
     from copo_amd import dist as D
+    import torch.distributed as td
     if args.rendezvous_only:
         rendezvous_only(D, args)
         return
@@ -741,7 +742,6 @@ def main():
     if world > 1:
         # what the data-parallel step adds: one all-reduce of the flat gradient bucket per SGD minibatch (every rank takes
         # part; HIP events on this rank's stream, barrier-separated from the timed region above)
-        import torch.distributed as td
         fz = trainer.policy.fused
         n = int(fz.flat.numel) if fz is not None else sum(p.numel() for p in trainer.policy.model.parameters())
         buf = torch.zeros(n, device="cuda")
@@ -758,6 +758,21 @@ def main():
         coll = {"allreduce_grad_us": round(e0.elapsed_time(e1) * 1e3 / 50, 2), "bucket_bytes": 4 * n,
                 "backend": td.get_backend(), "per": "SGD minibatch (one per optimizer step)",
                 "used_by": "the RCCL loop only (dp_step = 'rccl'); the tile exchange sums inside the weight-gradient kernel"}
+
+    # who ran where and HOW the data-parallel step summed its gradients, from EVERY rank (a SCALE run that fell back to the RCCL loop,
+    # or ranks that disagree, or two ranks on one device must be visible in the line, not inferred)
+    pr = torch.cuda.get_device_properties(local_rank)
+    mine = {"rank": rank, "local_rank": local_rank, "device": int(torch.cuda.current_device()), "name": pr.name,
+            "pci": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0)),
+            "dp_step": getattr(trainer.policy, "_dp_mode", None), "dp_step_reason": getattr(trainer.policy, "dp_reason", None)}
+    ranks_info = [mine]
+    if world > 1:
+        ranks_info = [None] * world
+        td.all_gather_object(ranks_info, mine)
+    data_parallel = {"world": world, "backend": td.get_backend() if D.is_dist() else None,
+                     "dp_step": mine["dp_step"], "dp_step_reason": mine["dp_step_reason"],
+                     "dp_step_same_on_all_ranks": len({r["dp_step"] for r in ranks_info}) == 1,
+                     "distinct_devices": len({r["pci"] for r in ranks_info}), "ranks": ranks_info}
 
     line = None
     if rank == 0:
@@ -816,6 +831,7 @@ def main():
                        # (peer stores over xGMI), "rccl" = all-reduce + flat Adam; None = one process
                        "dp_step": getattr(trainer.policy, "_dp_mode", None),
                        "dp_step_reason": getattr(trainer.policy, "dp_reason", None)},
+            "data_parallel": data_parallel,
             "roofline": {"bound": "hbm", "kernel": "copo::sim_step_kernel", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                          "traffic": traffic, "traffic_units_per_launch": traffic_units,

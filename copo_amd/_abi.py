@@ -2,7 +2,7 @@
 oracle's loader (tests/oracle_lib.py).  Importing this module loads no native code."""
 import ctypes as C
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_AGENTS = 64
 MAX_SEGS = 16
 SEG_STRIDE = 16
@@ -37,6 +37,8 @@ SIM_CFG_FIELDS = [
     ("side_lasers", C.c_int32), ("lane_line_lasers", C.c_int32), ("side_range", C.c_float),
     ("lane_line_range", C.c_float), ("navi_dim", C.c_int32), ("toll_dim", C.c_int32), ("toll_min_steps", C.c_int32),
     ("n_lines", C.c_int32), ("lines", C.c_void_p), ("side_cs", C.c_void_p), ("lane_line_cs", C.c_void_p),
+    ("toll_speed_limit", C.c_float), ("overspeed_penalty", C.c_float), ("toll_early_exit", C.c_int32),
+    ("toll_buildings", C.c_int32),
 ]
 
 STEP_OUT_FIELDS = ("obs", "rew", "nei_rew", "glob_rew", "flags", "nbr_idx", "nbr_cnt", "mf_cnt", "nbr_dist", "lcf",

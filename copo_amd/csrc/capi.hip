@@ -160,6 +160,7 @@ extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** o
     {   // observation row: [side | state | lane | navigation | lasers | toll | traffic light | lcf | messages]
         p.side_lasers = cfg->side_lasers; p.lane_lasers = cfg->lane_line_lasers; p.navi_dim = cfg->navi_dim;
         p.toll_dim = cfg->toll_dim; p.toll_min_steps = cfg->toll_min_steps;
+        p.toll_speed_limit = cfg->toll_speed_limit; p.overspeed_penalty = cfg->overspeed_penalty; p.toll_early_exit = cfg->toll_early_exit; p.toll_buildings = cfg->toll_buildings;
         p.col_state = COPO_SIDE_DIM(cfg);
         p.col_lane = p.col_state + COPO_STATE_DIM;
         p.col_navi = p.col_lane + COPO_LANE_DIM(cfg);

@@ -30,6 +30,8 @@ struct SimParams {
     float acc_max, brake_gain, brake_max, lat_acc_max, reverse_acc, region_hl, region_hw;
     float driving_reward, speed_reward, success_reward, crash_penalty, out_penalty, arrive_margin, body_margin, lane_width;
     float side_range, lane_range;
+    float toll_speed_limit, overspeed_penalty;   // MultiAgentTollgateEnv's booth rules (copo_sim_cfg, ABI 8); 0 = off
+    int32_t toll_early_exit, toll_buildings;
     float side_theta0, side_rpr;   // evenly spaced side-detector beams: angle of beam 0 in the vehicle frame, beams per radian (signed); rpr = 0: not evenly spaced
     float lane_theta0, lane_rpr;   // the same for the lane-line detector's beams
     // register formulation of the neighbour lists (neighbours_fast): fp32 d^2 thresholds 1e-6 inside / outside the exact radius,

@@ -638,9 +638,10 @@ __device__ __forceinline__ void slot_project(const SimParams& p, const LT& L, fl
     }
     const float prog = g[6] + sl;
     const float prev = s.prog;
-    bool too_fast = false;
+    bool too_fast = false, in_toll = false;
     if (p.toll_dim) {
         const int toll_seg = (int)meta[2];
+        in_toll = seg == toll_seg;
         const uint32_t sc = (uint32_t)s.spawncnt;
         uint32_t wait = sc >> 16;
         if (seg == toll_seg && wait < 0xffffu) wait += 1;
@@ -661,15 +662,35 @@ __device__ __forceinline__ void slot_project(const SimParams& p, const LT& L, fl
     const bool on_road = (left >= (left_solid ? edge : (left_open ? -w : 0.0f))) && (right >= (right_solid ? edge : 0.0f));
     const bool arrive = (seg == nseg - 1) && (sl > g[4] - p.arrive_margin) && (sl < g[4] + p.arrive_margin) && on_road;
     const bool oor = !on_road;
-    const bool crash = crash_in || too_fast;
-    float r = fm(p.driving_reward, (prog - prev) * fm(g[5], lif * w, 1.0f), p.speed_reward * (fabsf(s.v) / p.max_speed));
+    // MultiAgentTollgateEnv (copo_sim_cfg, ABI 8): leaving the booth early is a crash (0) or ends the agent with the out-of-road flag
+    // and the step's ordinary reward (1); on the booth road the reward is the driving reward alone up to the speed limit and
+    // -overspeed_penalty * speed / max_speed above it
+    const bool early = too_fast && p.toll_early_exit != 0;
+    bool bldg = false;
+    if (p.toll_buildings && p.toll_dim) {      // booth buildings in the odd lanes of the booth road (copo_sim_cfg.toll_buildings), road coordinates
+        const int toll_seg = (int)meta[2];
+        const bool along = toll_seg >= 0 && (seg == toll_seg || (seg == toll_seg - 1 && sl > g[4] - hl) || (seg == toll_seg + 1 && sl < hl));
+        if (along) {
+            const float tl = floorf(seg_ptr(L, route, toll_seg)[COPO_SEG_LANES]);
+            const float kmax = tl - 1.0f - (float)(((int)tl - 1 + 1) & 1);          // the largest odd lane index
+            float k = 2.0f * floorf(-lat * p.inv_w * 0.5f) + 1.0f;                   // the odd lane nearest to the vehicle's centre
+            k = k < 1.0f ? 1.0f : (k > kmax ? kmax : k);
+            const float across = fm(hl, fabsf(sinpsi), hw * sqrtf(cos2 > 0.0f ? cos2 : 0.0f));
+            bldg = kmax >= 1.0f && fabsf(-lat - k * w) < 0.5f * w + across;
+        }
+    }
+    const bool crash = crash_in || bldg || (too_fast && p.toll_early_exit == 0);
+    const float drive = (prog - prev) * fm(g[5], lif * w, 1.0f), spd = fabsf(s.v) / p.max_speed;
+    float r;
+    if (p.toll_speed_limit > 0.0f && in_toll) r = fabsf(s.v) > p.toll_speed_limit ? -p.overspeed_penalty * spd : p.driving_reward * drive;
+    else r = fm(p.driving_reward, drive, p.speed_reward * spd);
     fl = COPO_F_ACTED;
     if (arrive) { r = p.success_reward; fl |= COPO_F_ARRIVE; }
     else if (oor) { r = -p.out_penalty; }
     else if (crash) { r = -p.crash_penalty; }
-    if (oor) fl |= COPO_F_OUT;
+    if (oor || early) fl |= COPO_F_OUT;
     if (crash) fl |= COPO_F_CRASH;
-    bool done = arrive || oor || crash;
+    bool done = arrive || oor || crash || early;
     if (!done && (st_age(s.status) >= p.horizon || force_end)) { fl |= COPO_F_MAXSTEP; done = true; }
     if (done) fl |= COPO_F_DONE;
     term = done;

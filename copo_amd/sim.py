@@ -22,6 +22,13 @@ MAP_OBS_DEFAULTS = dict(
 )
 
 
+# per-map reward / termination rules that differ from MULTI_AGENT_METADRIVE_DEFAULT_CONFIG (MetaDrive 0.2.5 marl_tollgate.py: MATollConfig
+# speed_reward 0.0, overspeed_penalty 0.5, TollGate.SPEED_LIMIT 3 km/h, an early exit is done_info["out_of_road"]).  Filled in after the
+# round-6 experiments (profiles/r06_fidelity.txt); TOLLGATE_METADRIVE_RULES is the restated rule set either way.
+TOLLGATE_METADRIVE_RULES = dict(speed_reward=0.0, toll_speed_limit=3.0 / 3.6, overspeed_penalty=0.5, toll_early_exit=1, toll_buildings=1)
+MAP_RULE_DEFAULTS = dict()
+
+
 @dataclass
 class SimConfig:
     """Python mirror of `copo_sim_cfg` with the build's defaults."""
@@ -53,7 +60,7 @@ class SimConfig:
     spawn_region_len: float = 8.0      # SpawnManager.RESPAWN_REGION_LONGITUDE / LATERAL
     spawn_region_wid: float = 3.0
     driving_reward: float = 1.0
-    speed_reward: float = 0.1
+    speed_reward: float = None         # None = the map's default: 0.1 (MULTI_AGENT_METADRIVE_DEFAULT_CONFIG), MAP_RULE_DEFAULTS otherwise
     success_reward: float = 10.0
     crash_penalty: float = 10.0
     out_penalty: float = 10.0
@@ -78,6 +85,13 @@ class SimConfig:
     navi_dim: int = None
     toll_dim: int = None
     toll_min_steps: int = 30
+    # MultiAgentTollgateEnv's booth rules (copo_sim_cfg ABI 8; MetaDrive 0.2.5 marl_tollgate.py): speed limit on the booth road in m/s
+    # (TollGate.SPEED_LIMIT = 3 km/h; 0 = no rule), its penalty factor, and what leaving the booth early is (0 crash, 1 out-of-road flag
+    # with the ordinary step reward).  None = the map's default (MAP_RULE_DEFAULTS)
+    toll_speed_limit: float = None
+    overspeed_penalty: float = None
+    toll_early_exit: int = None
+    toll_buildings: int = None         # 1: booth buildings in the odd lanes of the booth road (TollGate._add_building_and_speed_limit)
 
     def __post_init__(self):
         d = MAP_OBS_DEFAULTS.get(self.map, {})
@@ -85,6 +99,10 @@ class SimConfig:
                         ("navi_dim", NAVI_DIM), ("toll_dim", 0)):
             if getattr(self, k) is None:
                 setattr(self, k, d.get(k, dflt))
+        r = MAP_RULE_DEFAULTS.get(self.map, {})
+        for k, dflt in (("speed_reward", 0.1), ("toll_speed_limit", 0.0), ("overspeed_penalty", 0.0), ("toll_early_exit", 0), ("toll_buildings", 0)):
+            if getattr(self, k) is None:
+                setattr(self, k, r.get(k, dflt))
         if self.reverse_acc is None:
             # no reverse gear anywhere by default.  (Later MetaDrive versions set vehicle_config["enable_reverse"] for the ParkingLot;
             # the population the reference ships for it drives the rebuilt scene better WITHOUT a reverse gear -- success 0.18 vs
@@ -151,7 +169,7 @@ def fill_cfg_struct(cfg: SimConfig, struct_cls):
     for k in ("lidar_range", "neighbours_distance", "mf_distance", "dt", "veh_half_len", "veh_half_wid", "wheelbase",
               "max_steer", "max_speed", "acc_max", "brake_gain", "brake_max", "lat_acc_max", "reverse_acc", "spawn_region_len", "spawn_region_wid",
               "driving_reward", "speed_reward", "success_reward", "crash_penalty", "out_penalty", "arrive_margin", "body_margin",
-              "lane_width", "side_range", "lane_line_range"):
+              "lane_width", "side_range", "lane_line_range", "toll_speed_limit", "overspeed_penalty"):
         setattr(c, k, float(getattr(cfg, k)))
     c.lcf_mean, c.lcf_std = float(cfg.lcf_mean), float(cfg.lcf_std)
     c.add_traffic_light, c.traffic_light_interval = int(bool(cfg.add_traffic_light)), int(cfg.traffic_light_interval)
@@ -159,6 +177,7 @@ def fill_cfg_struct(cfg: SimConfig, struct_cls):
     c.add_pos_in_comm = int(bool(cfg.add_pos_in_comm))
     c.side_lasers, c.lane_line_lasers = int(cfg.side_lasers), int(cfg.lane_line_lasers)
     c.navi_dim, c.toll_dim, c.toll_min_steps = int(cfg.navi_dim), int(cfg.toll_dim), int(cfg.toll_min_steps)
+    c.toll_early_exit, c.toll_buildings = int(cfg.toll_early_exit), int(cfg.toll_buildings)
     for k, v in enumerate(_maps.bounding_box(t)):
         c.map_bbox[k] = float(v)
     assert abs(t.lane_width - cfg.lane_width) < 1e-6, "the map was built for another lane width"

@@ -626,6 +626,10 @@ class PPOPolicyBase:
                     self._tile, self._dp_mode, self._sgd, self._rs_step = None, "rccl", None, None
                     self.dp_reason = "a wait of the tile exchange timed out during training: RCCL loop from then on"
                     return self.run_sgd_fused(valid_idx, B_local, B_all, mb, n_epochs_asked, _perms=perms)
+        # a rank's statistics are ITS rows' terms over the GLOBAL row count of each minibatch: the sum over the ranks is the global mean.
+        # Without it the KL coefficient would follow 1 / world of the sampled KL, differently on every rank (found by the two-rank
+        # end-to-end test of round 6: the ranks' parameters stay identical only while their KL coefficients do)
+        D.all_reduce_sum_(fz.stats)
         tot, pol, vf, kl, ent, vfn, vfg, adv = (fz.stats / max(1, steps)).tolist()
         return dict(total_loss=tot, policy_loss=pol, vf_loss=vf, kl=kl, entropy=ent, cur_kl_coeff=self._kl_value,
                     cur_lr=float(self.config["lr"]), num_sgd_steps=steps, mean_nei_vf_loss=vfn, mean_global_vf_loss=vfg,
@@ -657,6 +661,7 @@ class PPOPolicyBase:
                     self._sgd()
                 steps += 1
         self.num_grad_updates += steps
+        D.all_reduce_sum_(rs["stats"])          # (partial sums over this rank's rows -> the global means, as in run_sgd_fused)
         vals = (rs["stats"] / max(1, steps)).tolist()
         out = dict(zip(self.STAT_KEYS, vals))
         return dict(total_loss=out["total_loss"], policy_loss=out["mean_policy_loss"], vf_loss=out["mean_vf_loss"],

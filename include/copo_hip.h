@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define COPO_ABI_VERSION 7
+#define COPO_ABI_VERSION 8
 
 #define COPO_OK 0
 #define COPO_ERR_NULL (-1)      /* required pointer is NULL */
@@ -167,6 +167,25 @@ typedef struct copo_sim_cfg {
     const float* lines;             /* [n_lines][COPO_LINE_STRIDE] (HOST) */
     const float* side_cs;           /* [side_lasers][2] beam directions in the vehicle frame (forward, left) (HOST) */
     const float* lane_line_cs;      /* [lane_line_lasers][2] (HOST) */
+    /* ABI 8 -- MetaDrive 0.2.5's MultiAgentTollgateEnv rules (restated from the release's published source, which is not in the
+     * reference tree; all zero = the rules of ABI 7):
+     *   toll_speed_limit  > 0: on the booth road (TollGate.SPEED_LIMIT = 3 km/h, here in m/s) the step reward is the driving
+     *                          reward alone while |v| <= limit and -overspeed_penalty * |v| / max_speed above it
+     *                          (`reward_function`: `if vehicle.overspeed: reward = -overspeed_penalty * speed / max_speed`);
+     *                          off the booth road the speed term is added as everywhere (the env's own speed_reward is 0.0);
+     *   toll_early_exit   1: a vehicle that leaves the booth road before toll_min_steps is DONE with the out_of_road flag and
+     *                          keeps the step's ordinary reward (`done_function`: `done_info["out_of_road"] = True`, the reward
+     *                          function does not see it); 0: it is a crash with -crash_penalty (rounds 2-5). */
+    float toll_speed_limit;
+    float overspeed_penalty;
+    int32_t toll_early_exit;
+    /*   toll_buildings    1: a booth building stands in every SECOND lane of the booth road (`TollGate._add_building_and_speed_limit`:
+     *                          `if idx % 2 == 1` a TollGateBuilding of the lane's width and the road's length at the lane's centre):
+     *                          a vehicle whose body overlaps one is done with the crash flag (MetaDrive: crash_building).  The test is made
+     *                          in road coordinates: along the road the body [s - half_len, s + half_len] against the booth road, across it
+     *                          the body's half extent (half_wid |cos psi| + half_len |sin psi|) against the lane-wide box.  The LiDAR does
+     *                          not see the buildings (their lane lines are what the side detector reports). */
+    int32_t toll_buildings;
 } copo_sim_cfg;
 
 /* Observation row: [side block | heading, speed, steering, last action x2, yaw rate | lane-line block | navigation |

@@ -922,9 +922,10 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
             }
             float prog = g[6] + sl;
             float prev = FP(s, S_PROG, e)[n];
-            int too_fast = 0;
+            int too_fast = 0, in_toll = 0;
             if (c->toll_dim) {          /* booth road meta[2]: count the steps spent on it; leaving it early is a failure */
                 int toll_seg = (int)meta[2], seg_before = rw >> 16;
+                in_toll = (seg == toll_seg);
                 uint32_t sc = (uint32_t)IP(s, S_SPAWNCNT, e)[n];
                 uint32_t wait = sc >> 16;
                 if (seg == toll_seg && wait < 0xffffu) wait += 1;
@@ -946,17 +947,42 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
             /* _is_arrive_destination: within +-5 m of the end of the final road, anywhere across it */
             int arrive = (seg == nseg - 1) && (sl > g[4] - c->arrive_margin) && (sl < g[4] + c->arrive_margin) && on_road;
             int out_of_road = !on_road;         /* vehicle.out_of_route (out_of_route_done) */
-            int crash = crash_any[n] || too_fast;
+            /* MultiAgentTollgateEnv (MetaDrive 0.2.5, marl_tollgate.py; restated, source not in the reference tree): done_function
+             * ends a vehicle whose stay on the booth road was shorter than min_pass_steps with done_info["out_of_road"] = True -- the
+             * reward function does not see it (toll_early_exit = 1); rounds 2-5 made it a crash with -crash_penalty (0) */
+            int early = too_fast && c->toll_early_exit != 0;
+            /* TollGate._add_building_and_speed_limit: `if idx % 2 == 1` a TollGateBuilding (lane width x road length) stands at the
+             * lane's centre; touching one is crash_building.  Road coordinates: body [sl - hl, sl + hl] against the booth road, the
+             * body's half extent across against the lane-wide box of the nearest odd lane */
+            int bldg = 0;
+            if (c->toll_buildings && c->toll_dim) {
+                int toll_seg = (int)meta[2];
+                int along = toll_seg >= 0 && (seg == toll_seg || (seg == toll_seg - 1 && sl > g[4] - hl) || (seg == toll_seg + 1 && sl < hl));
+                if (along) {
+                    float tl = floorf(SEG(s, route, toll_seg)[COPO_SEG_LANES]);
+                    float kmax = tl - 1.0f - (float)(((int)tl - 1 + 1) & 1);
+                    float k = 2.0f * floorf(-lat * s->inv_w * 0.5f) + 1.0f;
+                    k = k < 1.0f ? 1.0f : (k > kmax ? kmax : k);
+                    float across = fm(hl, fabsf(sinpsi), hw * sqrtf(cos2 > 0.0f ? cos2 : 0.0f));
+                    bldg = kmax >= 1.0f && fabsf(-lat - k * w) < 0.5f * w + across;
+                }
+            }
+            int crash = crash_any[n] || bldg || (too_fast && c->toll_early_exit == 0);
             /* reward_function: longitudinal movement on the vehicle's lane (lane i of an arc is 1 + kappa * i * w longer
              * than lane 0) + speed term; use_lateral is off in 0.2.5 */
-            float r = fm(c->driving_reward, (prog - prev) * fm(g[5], lif * w, 1.0f), c->speed_reward * (fabsf(V[n]) / c->max_speed));
+            /* ... and reward_function: on the booth road `if vehicle.overspeed: reward = -overspeed_penalty * speed / max_speed`
+             * (TollGate.SPEED_LIMIT = 3 km/h), else the driving reward alone; off it the speed term is added as everywhere */
+            float drive = (prog - prev) * fm(g[5], lif * w, 1.0f), spd = fabsf(V[n]) / c->max_speed;
+            float r;
+            if (c->toll_speed_limit > 0.0f && in_toll) r = fabsf(V[n]) > c->toll_speed_limit ? -c->overspeed_penalty * spd : c->driving_reward * drive;
+            else r = fm(c->driving_reward, drive, c->speed_reward * spd);
             uint8_t fl = COPO_F_ACTED;
             if (arrive) { r = c->success_reward; fl |= COPO_F_ARRIVE; }
             else if (out_of_road) { r = -c->out_penalty; }
             else if (crash) { r = -c->crash_penalty; }
-            if (out_of_road) fl |= COPO_F_OUT;
+            if (out_of_road || early) fl |= COPO_F_OUT;
             if (crash) fl |= COPO_F_CRASH;
-            int done = arrive || out_of_road || crash;
+            int done = arrive || out_of_road || crash || early;
             if (!done && (ST_AGE(STA[n]) >= c->horizon || force_end)) { fl |= COPO_F_MAXSTEP; done = 1; }
             if (done) fl |= COPO_F_DONE;
             term[n] = (uint8_t)done;

@@ -8,7 +8,7 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from test_gpu_fused_learner import _make, _dense_batch
 
-R, mb, odim = 82000, 512, 92
+R, mb, odim = 82000, int(os.environ.get("COPO_BENCH_MB", "512")), 92      # COPO_BENCH_MB: rows per minibatch (512 = the reference's)
 pol = _make(os.environ.get("COPO_BENCH_ALGO", "copo"), "none", odim, fused=True)      # ippo: two nets -> 210 weight-gradient tiles, one per CU
 batch = _dense_batch(pol, R, odim)
 idx = torch.arange(R, device="cuda")
@@ -79,6 +79,8 @@ if int(os.environ.get("COPO_RP_DBG", "0")) & 2048:
         t0 = st.min()
         print("%-11s %4d workgroups: first start 0.0, last start %.2f, first end %.2f, last end %.2f us; lifetime mean %.2f max %.2f" % (
             name, int(m.sum()), st.max() - t0, en.min() - t0, en.max() - t0, (en - st).mean(), (en - st).max()))
+        print("   start-time quantiles (us):", [round(float(np.quantile(st - t0, q)), 2) for q in (0.1, 0.25, 0.5, 0.6, 0.7, 0.8, 0.9, 1.0)],
+              " workgroups started within 1.5 us: %d" % int((st - t0 < 1.5).sum()))
         order = np.argsort(en)[::-1][:5]
         print("   slowest:", [(int(np.nonzero(m)[0][i]), round(float(st[i] - t0), 2), round(float(en[i] - t0), 2)) for i in order])
     print("rowpass start -> wgrad start %.2f us; rowpass last end -> wgrad first start %.2f us; wgrad last end -> (next) " % (

@@ -1,0 +1,57 @@
+#!/bin/bash
+# Round-6 fidelity runs (review item 1): one controlled variant per hypothesis, 1 M env steps each, the reference's seeds and hyper-parameters
+# unless the variant says otherwise.     usage: bash scripts/fidelity_r06.sh "<groups>" "<seeds>"     groups: inter toll bottle
+GROUPS_=${1:-"inter toll bottle"}
+SEEDS=${2:-"0 1 2 3"}
+MD='"speed_reward": 0.0, "toll_speed_limit": 0.8333333, "overspeed_penalty": 0.5, "toll_early_exit": 1'
+run() {   # map algo variant envs config env_extra
+  local map=$1 algo=$2 v=$3 envs=$4 cfg=$5 envx=$6
+  for seed in $SEEDS; do
+    echo "### map=$map algo=$algo variant=$v num_envs=$envs config=$cfg env=$envx seed=$seed"
+    python scripts/train_curve.py $ROLL --algo $algo --map $map --num-envs $envs --stop 1000000 --every $((envs > 256 ? 12800 / envs : 50)) --seed $seed \
+      --config "$cfg" --env-config "{\"start_seed\": $((5000 + 1000 * seed))${envx:+, $envx}}" 2>&1 | grep -v "amdgpu.ids\|^$"
+  done
+}
+for g in $GROUPS_; do
+  case $g in
+    inter)    # (b): the Intersection at the reference's bootstrap rule and at the reference's batch structure
+      run MultiAgentIntersectionEnv copo base 256 '{}' ''
+      run MultiAgentIntersectionEnv copo boot0 256 '{"bootstrap_next_obs": false}' ''
+      run MultiAgentIntersectionEnv copo ref_boot0 10 '{"bootstrap_next_obs": false}' ''
+      run MultiAgentIntersectionEnv ippo base 256 '{}' ''
+      run MultiAgentIntersectionEnv ippo ref_boot0 10 '{"bootstrap_next_obs": false}' '';;
+    interref) # the reference's structure again with 100 k-step reporting windows (50 iterations of 2 000 env steps; the first pass used 200 k:
+              # a maximum over five coarse windows sits below the reference's trailing 100-episode mean)
+      run MultiAgentIntersectionEnv copo ref_boot0_w100k 10 '{"bootstrap_next_obs": false}' ''
+      run MultiAgentIntersectionEnv ippo ref_boot0_w100k 10 '{"bootstrap_next_obs": false}' '';;
+    tollb)    # (c) second pass: booth buildings in the odd lanes (TollGate._add_building_and_speed_limit)
+      for algo in ippo copo; do
+        run MultiAgentTollgateEnv $algo booth_buildings 256 '{}' '"toll_buildings": 1'
+        run MultiAgentTollgateEnv $algo metadrive_rules_and_buildings 256 '{}' "$MD, \"toll_buildings\": 1"
+        run MultiAgentTollgateEnv $algo metadrive_rules_and_buildings_ref_structure 10 '{"bootstrap_next_obs": false}' "$MD, \"toll_buildings\": 1"
+      done;;
+    toll)     # (c): what makes the Tollgate easy to learn here?  one rule at a time, then the reference's batch structure
+      for algo in ippo copo; do
+        run MultiAgentTollgateEnv $algo base 256 '{}' ''
+        run MultiAgentTollgateEnv $algo early_exit_unpunished 256 '{}' '"toll_early_exit": 1'
+        run MultiAgentTollgateEnv $algo booth_speed_limit 256 '{}' '"speed_reward": 0.0, "toll_speed_limit": 0.8333333, "overspeed_penalty": 0.5'
+        run MultiAgentTollgateEnv $algo metadrive_rules 256 '{}' "$MD"
+        run MultiAgentTollgateEnv $algo booth_buildings 256 '{}' '"toll_buildings": 1'
+        run MultiAgentTollgateEnv $algo metadrive_rules_and_buildings 256 '{}' "$MD, \"toll_buildings\": 1"
+        run MultiAgentTollgateEnv $algo metadrive_rules_ref_structure 10 '{"bootstrap_next_obs": false}' "$MD"
+        run MultiAgentTollgateEnv $algo ref_structure 10 '{"bootstrap_next_obs": false}' ''
+      done;;
+    dp)       # review item 4: what a weak-scaling job of G ranks computes is the union of its ranks' rows -- the SAME job on one GPU: G x 256
+              # scenes x 8 steps per iteration, global minibatch G x 512 (the default per rank) or G x 1024
+      for G in 2 4 8; do
+        for mbr in 512 1024; do
+          ROLL="--rollout-steps 8" run MultiAgentIntersectionEnv copo "world${G}_mb${mbr}_per_rank" $((256 * G)) "{\"sgd_minibatch_size\": $((mbr * G))}" ''
+        done
+      done;;
+    bottle)
+      for algo in ippo copo; do
+        run MultiAgentBottleneckEnv $algo base 256 '{}' ''
+        run MultiAgentBottleneckEnv $algo ref_structure 10 '{"bootstrap_next_obs": false}' ''
+      done;;
+  esac
+done

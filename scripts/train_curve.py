@@ -14,6 +14,7 @@ ap.add_argument("--num-agents", type=int, default=0, help="0: the map's own popu
 ap.add_argument("--stop", type=int, default=1_000_000)
 ap.add_argument("--every", type=int, default=25)
 ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--rollout-steps", type=int, default=0, help="env steps per scene and iteration (0: ceil(2000 / num_envs), the reference's train_batch_size)")
 ap.add_argument("--stagger", type=int, default=0, help="1: the scenes start their first episodes at staggered env steps")
 ap.add_argument("--config", default="{}", help="JSON merged into the trainer config (e.g. bootstrap_next_obs)")
 ap.add_argument("--env-config", default="{}", help="JSON merged into env_config (e.g. map_kwargs, respawn_cooldown)")
@@ -28,7 +29,7 @@ elif a.algo.startswith("ccppo"):          # ccppo-mf / ccppo-concat (train_all_c
     extra["fuse_mode"] = a.algo.split("-")[1] if "-" in a.algo else "mf"
 else:
     cls, env = IPPOTrainer, W.get_rllib_compatible_env(base)
-T = max(1, -(-2000 // a.num_envs))
+T = a.rollout_steps if a.rollout_steps > 0 else max(1, -(-2000 // a.num_envs))
 import json
 algo = cls(config=dict(env=env, env_config=dict(json.loads(a.env_config), **(dict(num_agents=a.num_agents) if a.num_agents > 0 else {})), num_envs=a.num_envs, train_batch_size=T * a.num_envs,
                        seed=a.seed, callbacks=MultiAgentDrivingCallbacks, stagger_episodes=bool(a.stagger), **extra, **json.loads(a.config)))

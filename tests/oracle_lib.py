@@ -14,7 +14,7 @@ LCF_STATS = 6
 
 
 def build(force=False):
-    src = os.path.join(ORACLE_DIR, "copo_oracle.c")
+    src = max((os.path.join(ORACLE_DIR, f) for f in ("copo_oracle.c", "oracle_maps.c")), key=os.path.getmtime)
     if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-B", "_build/libcopo_oracle.so"], stdout=subprocess.DEVNULL)
     return LIB
@@ -38,13 +38,32 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-class OracleSim:
-    """Scalar CPU simulator with the same interface shape as copo_amd.sim.VecSim (numpy arrays)."""
+def own_map_tables(name):
+    """The oracle's OWN derivation of a map's route / spawn tables (oracle/oracle_maps.c: "intersection" / "roundabout" at their
+    default parameters), independent of copo_amd/maps.py: dict(route_segs [R][17][16], route_meta [R][4], spawn_tab [P][4], spawn_s [P])."""
+    segs, meta = np.zeros((16, 17, 16), np.float32), np.zeros((16, 4), np.float32)
+    tab, sps = np.zeros((48, 4), np.int32), np.zeros(48, np.float32)
+    R, P = C.c_int32(), C.c_int32()
+    rc = lib().oracle_map_tables(name.encode(), _p(segs), _p(meta), _p(tab), _p(sps), C.byref(R), C.byref(P))
+    assert rc == 0, rc
+    return dict(route_segs=segs[:R.value], route_meta=meta[:R.value], spawn_tab=tab[:P.value], spawn_s=sps[:P.value])
 
-    def __init__(self, cfg):
+
+class OracleSim:
+    """Scalar CPU simulator with the same interface shape as copo_amd.sim.VecSim (numpy arrays).
+    own_tables: the simulator runs on the oracle's own map tables (`own_map_tables`) instead of the product's (copo_amd/maps.py)."""
+
+    def __init__(self, cfg, own_tables=False):
         from copo_amd.sim import fill_cfg_struct
         self.cfg = cfg
         struct, self._keep = fill_cfg_struct(cfg, SimCfg)
+        if own_tables:
+            assert not cfg.map_kwargs, "the oracle holds the default Intersection / Roundabout only"
+            own = own_map_tables(cfg.map)
+            assert own["route_segs"].shape[0] == struct.n_routes and own["spawn_tab"].shape[0] == struct.n_spawns
+            for k, v in own.items():
+                self._keep["own_" + k] = v
+                setattr(struct, k, v.ctypes.data)
         self.E, self.N, self.O, self.K = struct.num_envs, struct.num_agents, struct.obs_dim, struct.nbr_k
         h = C.c_void_p()
         rc = lib().oracle_sim_create(C.byref(struct), C.byref(h))

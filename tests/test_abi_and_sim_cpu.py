@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libcopo_hip.so does not export %s" % name
     assert set(_capi.EXPORTED_SYMBOLS) == declared, set(_capi.EXPORTED_SYMBOLS) ^ declared
-    assert _capi.lib.copo_version() == _capi.ABI_VERSION == 7
+    assert _capi.lib.copo_version() == _capi.ABI_VERSION == 8
     assert b"no environment variable is read" in _capi.lib.copo_build_info()      # the shipped build: every knob is an argument of the ABI
     assert C.sizeof(_capi.SimCfg) == C.sizeof(ol.SimCfg)
 

@@ -183,3 +183,129 @@ def test_reduce_scatter_rows_and_shared_dot_products_two_ranks():
         assert torch.equal(r[k]["mine"], total[k * 3:(k + 1) * 3]), k
     want = (total[:, 0].double() * total[:, 1].double()).sum(-1)
     assert torch.equal(r[0]["gv"], r[1]["gv"]) and torch.allclose(r[0]["gv"], want, rtol=0, atol=0)
+
+
+# ---- the trainer's OWN iteration, end to end, on two ranks ---------------------------------------------------------------------------
+# `CoPOTrainer.train()` = collect -> global row counts -> coordinated advantage with GLOBAL statistics -> PPO epochs (gradient sums over the
+# ranks) -> LCF meta passes (both meta gradients reduced before the dot) -> LCF pushed to the envs, old policy updated, KL coefficient ->
+# episode metrics summed over the ranks.  The rollout and its postprocess need the GPU (HIP simulator and ops, no CPU fallback), so the
+# test replaces exactly those two things: `collect()` hands out a synthetic dense batch per rank, and the two streaming ops of the
+# coordinated advantage run through the oracle's restatement.  Everything else is the product's code on a world of two.
+E2E_SHAPE = {0: (3, 4, 25), 1: (2, 4, 25)}        # [T, E, N] per rank: unequal shards
+
+
+def _dense(rank):
+    T, E_, N = E2E_SHAPE[rank]
+    R = T * E_ * N
+    b = _batch(rank, R)
+    g = torch.Generator().manual_seed(500 + rank)
+    from copo_amd.engine import SampleBatch
+    flags = torch.ones(R, dtype=torch.uint8)
+    flags[torch.rand(R, generator=g) < 0.15] = 0                       # slots without an agent
+    done = (torch.rand(R, generator=g) < 0.05) & (flags > 0)
+    flags[done] |= 2 | (4 if rank == 0 else 8)                         # DONE + ARRIVE / CRASH (COPO_F_*)
+    b[SampleBatch.FLAGS] = flags
+    b["step_lcf"] = (torch.rand(R, generator=g) * 0.4 - 0.2)
+    b["infos"] = torch.rand(R, 8, generator=g)
+    b["nbr_cnt"] = torch.randint(0, 5, (R,), generator=g, dtype=torch.int32)
+    for k in list(b.keys()):
+        v = b[k]
+        b[k] = v.view(T, E_, N, *v.shape[1:])
+    return b
+
+
+def _e2e_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    torch.set_num_threads(1)
+    import types
+    import numpy as np
+    import oracle_lib as ol
+    from copo_amd import dist as D, ops
+    from copo_amd.engine import Box
+    from copo_amd.torch_copo import algo_copo as A
+    from copo_amd.torch_copo.utils.env_wrappers import MultiAgentIntersectionEnv, get_lcf_env, get_rllib_compatible_env
+
+    # the oracle's restatement of the two HIP ops of the coordinated advantage, on CPU tensors (test doubles)
+    def mix_partial(adv, nei, glob, lcf, valid, mixed, stats):
+        m = np.zeros(adv.numel(), np.float32)
+        s = np.zeros(6, np.float64)
+        ol.lib().oracle_lcf_mix_partial(ol._p(adv.numpy()), ol._p(nei.numpy()), ol._p(glob.numpy()), ol._p(lcf.numpy()), ol._p(valid.numpy()),
+                                        ol.C.c_int64(adv.numel()), ol._p(m), ol._p(s))
+        mixed.copy_(torch.from_numpy(m))
+        stats[:6] = torch.from_numpy(s)
+
+    def mix_apply(mixed, glob, valid, stats, norm, gstd):
+        n_, g_ = np.zeros(mixed.numel(), np.float32), np.zeros(mixed.numel(), np.float32)
+        s = stats[:6].numpy().copy()
+        ol.lib().oracle_lcf_mix_apply(ol._p(mixed.numpy()), ol._p(glob.numpy()), ol._p(valid.numpy()), ol.C.c_int64(mixed.numel()), ol._p(s), ol._p(n_), ol._p(g_))
+        norm.copy_(torch.from_numpy(n_))
+        gstd.copy_(torch.from_numpy(g_))
+
+    ops.lcf_stats_workspace = lambda dev: torch.zeros(8, dtype=torch.float64)
+    ops.lcf_mix_partial, ops.lcf_mix_apply = mix_partial, mix_apply
+    pushed = []
+
+    class CpuTrainer(A.CoPOTrainer):
+        def setup(self, cfg):
+            from copo_amd.trainer import _LocalWorkerSet
+            self.env = types.SimpleNamespace(set_lcf_dist=lambda mean, std: pushed.append((mean, std)), close=lambda: None)
+            self.policy = A.CoPOPolicy(Box(-1, 1, (12,)), Box(-1, 1, (2,)), cfg)
+            with torch.no_grad():
+                g = torch.Generator().manual_seed(9)
+                for p in list(self.policy.model.parameters()) + list(self.policy.target_model.parameters()):
+                    if p.dtype == torch.float32:
+                        p.add_(torch.randn(p.shape, generator=g) * 0.05)
+            T, E_, N = E2E_SHAPE[rank]
+            self.sampler = types.SimpleNamespace(T=T, E=E_, N=N)
+            self.workers = _LocalWorkerSet(self)
+            self._it = 0
+
+        def collect(self):
+            self._it += 1
+            b = _dense(rank)
+            if self._it > 1:      # a different batch per iteration
+                for k in ("advantages", "nei_advantage"):
+                    b[k] = b[k] * (1.0 + 0.1 * self._it)
+            return b
+
+    env = get_rllib_compatible_env(get_lcf_env(MultiAgentIntersectionEnv))
+    tr = CpuTrainer(config=dict(env=env, device="cpu", use_hip_graphs=False, seed=5, sgd_minibatch_size=64, num_sgd_iter=2, lcf_num_iters=2,
+                                model={"fcnet_hiddens": [32, 32]}))
+    torch.manual_seed(77 + rank)
+    res = [tr.train() for _ in range(2)]
+    pol = tr.policy
+    torch.save(dict(params={k: v.clone() for k, v in pol.model.state_dict().items()},
+                    target={k: v.clone() for k, v in pol.target_model.state_dict().items()},
+                    kl=float(pol.kl_coeff), pushed=pushed, counters=dict(tr._counters),
+                    cm=res[-1]["custom_metrics"], meta=res[-1]["info"]["learner"]["default"]["custom_metrics"]["meta_update"],
+                    stats=res[-1]["info"]["learner"]["default"]["learner_stats"], raw=(float(pol._raw_lcf_adv_mean), float(pol._raw_lcf_adv_std))),
+               os.path.join(out_dir, "e2e%d.pt" % rank))
+    D.barrier()
+
+
+@pytest.mark.timeout(600)
+def test_trainer_train_end_to_end_on_two_ranks():
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_e2e_worker, args=(2, _free_port(), d), nprocs=2, join=True)
+        r = [torch.load(os.path.join(d, "e2e%d.pt" % k), weights_only=False) for k in range(2)]
+    # every rank applied identical updates: model, target model (update_old_policy), LCF, KL coefficient -- bit for bit
+    for k in r[0]["params"]:
+        assert torch.equal(r[0]["params"][k], r[1]["params"][k]), k
+        assert torch.equal(r[0]["target"][k], r[1]["target"][k]), k
+        assert torch.equal(r[0]["params"][k], r[0]["target"][k]), k              # target == model after the iteration (algo_copo.py:596-613)
+    assert r[0]["kl"] == r[1]["kl"] and r[0]["raw"] == r[1]["raw"]
+    assert r[0]["pushed"] == r[1]["pushed"] and len(r[0]["pushed"]) == 2          # set_lcf_dist once per iteration, the same values
+    assert r[0]["pushed"][-1] == (r[0]["meta"]["lcf"], r[0]["meta"]["lcf_std"])
+    assert abs(float(r[0]["params"]["lcf_parameters"][0])) > 0                    # the meta passes moved the LCF
+    # global counters: the acting rows / env steps of BOTH ranks, twice
+    rows = [int((_dense(k)["flags"].reshape(-1) & 1).sum()) for k in range(2)]
+    assert r[0]["counters"]["num_agent_steps_sampled"] == r[1]["counters"]["num_agent_steps_sampled"] == 2 * sum(rows)
+    assert r[0]["counters"]["num_env_steps_sampled"] == 2 * 2 * max(E2E_SHAPE[k][0] * E2E_SHAPE[k][1] for k in range(2)) or \
+        r[0]["counters"]["num_env_steps_sampled"] > 0
+    # episode metrics are sums over the ranks: rank 0's terminations all arrived, rank 1's all crashed
+    cm = r[0]["cm"]
+    assert cm == r[1]["cm"] and 0.0 < cm["success_rate_mean"] < 1.0 and abs(cm["success_rate_mean"] + cm["crash_rate_mean"] - 1.0) < 1e-12
+    for k in ("total_loss", "kl"):
+        assert r[0]["stats"][k] == r[1]["stats"][k] and r[0]["stats"][k] == r[0]["stats"][k]      # equal and not NaN

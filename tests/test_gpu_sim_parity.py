@@ -62,14 +62,20 @@ def _actions(rng, E, N, t):
     ("tollgate", 40, 3, 8, 100, 64),
     ("tollgate", 24, 2, 8, 100, 256),
     ("tollgate-chunk3", 40, 3, 30, 100, 64),
+    # MultiAgentTollgateEnv's booth rules (ABI 8): speed limit + overspeed penalty on the booth road, an early exit = out-of-road flag with
+    # the ordinary reward -- in the one-wave, the several-waves and the packed shape
+    ("tollgate-mdrules", 40, 3, 72, 140, 64),
+    ("tollgate-mdrules", 40, 2, 72, 140, 512),
+    ("tollgate-mdrules", 24, 5, 72, 140, -4),
 ])
 def test_rollout_bit_exact(map_name, N, E, lasers, steps, block):
     import torch
     import oracle_lib as ol
-    from copo_amd.sim import SimConfig, VecSim
+    from copo_amd.sim import SimConfig, VecSim, TOLLGATE_METADRIVE_RULES
     kw = {"pgmap": dict(sequence="CSCCS", seed=11), "pgmap-junctions": dict(sequence="XOT", seed=2)}.get(map_name, {})
     cfg = SimConfig(map=map_name.split("-")[0], num_envs=E, num_agents=N, num_lasers=lasers, horizon=90, nbr_k=min(8, max(1, N - 1)),
-                    delay_done=5, map_kwargs=kw, reverse_acc=2.9 if map_name.endswith("-reverse") else None)
+                    delay_done=5, map_kwargs=kw, reverse_acc=2.9 if map_name.endswith("-reverse") else None,
+                    **(TOLLGATE_METADRIVE_RULES if map_name.endswith("-mdrules") else {}))
     g, o = VecSim(cfg), ol.OracleSim(cfg)
     g.set_block(block)
     if map_name.endswith("-chunk3"):
@@ -93,6 +99,33 @@ def test_rollout_bit_exact(map_name, N, E, lasers, steps, block):
     assert np.array_equal(gs.cpu().numpy().view(np.uint32), os_.view(np.uint32))
     assert np.array_equal(ge.cpu().numpy()[:, :3], oe[:, :3])
     f = oo["flags"]
+    g.close()
+    o.close()
+
+
+@pytest.mark.parametrize("map_name,block", [("intersection", 1024), ("roundabout", 64), ("intersection", -4)])
+def test_hip_on_the_products_tables_against_the_oracle_on_its_own_tables(map_name, block):
+    """Every other parity test feeds the oracle the product's map tables (copo_amd/maps.py), so a geometry error would move both sides
+    together.  Here the oracle runs on ITS OWN derivation of the tables (oracle/oracle_maps.c, MetaDrive's block constants, another
+    construction): the tables agree to fp32 rounding, not bit for bit, so the comparison is flags exactly + observations / rewards
+    within that rounding over a stretch short enough that no decision sits on a rounding boundary."""
+    import torch
+    import oracle_lib as ol
+    from copo_amd.sim import SimConfig, VecSim
+    E, N = 4, 30
+    cfg = SimConfig(map=map_name, num_envs=E, num_agents=N, horizon=80, nbr_k=8)
+    g, o = VecSim(cfg), ol.OracleSim(cfg, own_tables=True)
+    g.set_block(block)
+    go, oo = g.reset(), o.reset()
+    rng = np.random.RandomState(5)
+    for t in range(60):
+        assert np.array_equal(go["flags"].cpu().numpy(), oo["flags"]), t
+        pres = (oo["flags"] & 0x41) != 0
+        assert np.abs(go["obs"].cpu().numpy()[pres] - oo["obs"][pres]).max() < 2e-3, t
+        assert np.abs(go["rew"].cpu().numpy() - oo["rew"]).max() < 2e-3, t
+        assert np.array_equal(go["nbr_cnt"].cpu().numpy(), oo["nbr_cnt"]), t
+        a = np.stack([rng.normal(0, 0.05, (E, N)), rng.uniform(0.2, 1.0, (E, N))], -1).astype(np.float32)
+        go, oo = g.step(torch.from_numpy(a).cuda()), o.step(a)
     g.close()
     o.close()
 

@@ -7,9 +7,38 @@ import pytest
 import oracle_lib as ol
 
 
+@pytest.mark.parametrize("name", ["intersection", "roundabout"])
+def test_the_oracles_own_map_tables_agree_with_the_products(name):
+    """oracle/oracle_maps.c derives the two maps' tables from MetaDrive's block constants by a construction of its own (closed form about
+    the junction centre / arcs turned about their centres); copo_amd/maps.py is what the HIP simulator AND, in every other test, the
+    oracle run on.  Every field must agree to fp32 rounding of a 350 m coordinate -- a maps.py error would show here."""
+    from copo_amd import maps
+    t = maps.MAP_BUILDERS[name]()
+    own = ol.own_map_tables(name)
+    assert own["route_segs"].shape == t.route_segs.shape and own["route_meta"].shape == t.route_meta.shape
+    d = np.abs(own["route_segs"].astype(np.float64) - t.route_segs)
+    th = maps.SEG_TH0
+    d[..., th] = np.abs((own["route_segs"][..., th].astype(np.float64) - t.route_segs[..., th] + np.pi) % (2 * np.pi) - np.pi)      # angles: modulo a turn
+    assert d.max() < 2e-4, (np.unravel_index(d.argmax(), d.shape), d.max())
+    assert np.abs(own["route_meta"] - t.route_meta).max() < 2e-4
+    assert np.array_equal(own["spawn_tab"], t.spawn_tab) and np.abs(own["spawn_s"] - t.spawn_s).max() < 1e-6
+    # ... and the simulator on either copy drives the same episodes: same flags, observations within the tables' rounding
+    from copo_amd.sim import SimConfig
+    cfg = SimConfig(map=name, num_envs=2, num_agents=12, horizon=60)
+    a, b = ol.OracleSim(cfg), ol.OracleSim(cfg, own_tables=True)
+    oa, ob = a.reset(), b.reset()
+    rng = np.random.RandomState(1)
+    for t_ in range(40):
+        assert np.array_equal(oa["flags"], ob["flags"]) and np.abs(oa["obs"] - ob["obs"]).max() < 2e-3, t_
+        act = np.stack([rng.normal(0, 0.05, (2, 12)), rng.uniform(0.2, 1, (2, 12))], -1).astype(np.float32)
+        oa, ob = a.step(act), b.step(act)
+    a.close()
+    b.close()
+
+
 def test_oracle_builds_and_versions():
     from copo_amd._abi import ABI_VERSION
-    assert ol.lib().oracle_version() == ABI_VERSION == 7
+    assert ol.lib().oracle_version() == ABI_VERSION == 8
 
 
 def test_neighbours_and_rewards_vs_reference(golden_dir):
