@@ -44,13 +44,16 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f3
 CPU_BASELINE_THREADS = 8
 
 
+MB_PER_RANK = 512      # the reference's sgd_minibatch_size (algo_ippo.py:17-42), per rank; `bench.py --mb-per-rank` sets it for a run
+
+
 def make_trainer(num_envs, num_agents, device=None, graphs=True, seed=0, pretrained=True):
     from copo_amd.torch_copo.algo_copo import CoPOTrainer
     from copo_amd.torch_copo.utils.env_wrappers import MultiAgentIntersectionEnv, get_lcf_env, get_rllib_compatible_env
     env = get_rllib_compatible_env(get_lcf_env(MultiAgentIntersectionEnv))
     T = max(1, -(-2000 // num_envs))      # reference train_batch_size = 2000 env steps (algo_ippo.py:25)
     cfg = dict(env=env, env_config=dict(num_agents=num_agents, neighbours_distance=40), num_envs=num_envs,
-               train_batch_size=T * num_envs, seed=seed, use_hip_graphs=graphs)
+               train_batch_size=T * num_envs, seed=seed, use_hip_graphs=graphs, sgd_minibatch_size=MB_PER_RANK)
     if device is not None:
         cfg["device"] = device
     tr = CoPOTrainer(config=cfg)
@@ -646,6 +649,9 @@ def main():
     ap.add_argument("--num-envs", type=int, default=256, help="scenes per GPU (BASELINE configs[1]: 256)")
     ap.add_argument("--num-agents", type=int, default=40)
     ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--mb-per-rank", type=int, default=512,
+                    help="rows per SGD minibatch and rank (512 = the reference's sgd_minibatch_size; 1024 halves the data-parallel steps of an "
+                         "iteration at 1.73 x the step time, DESIGN.md section 6 -- recorded in config.sgd_minibatch_size_per_rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--untrained", action="store_true",
                     help="random-init policy net instead of the reference's published population (the scenes then empty during the run)")
@@ -664,6 +670,8 @@ def main():
                     help="start the ranks of --gpus N, let them meet over gloo on the host and print the head of the line: "
                          "checks the launcher where there is no GPU")
     args = ap.parse_args()
+    global MB_PER_RANK
+    MB_PER_RANK = int(args.mb_per_rank)
 
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.rendezvous_only):
         # one command, N ranks: this process only launches them (the driver's `torch.distributed.run` form arrives with
@@ -819,7 +827,7 @@ def main():
                     "CoPO Intersection population so that the scenes stay populated; value nets / LCF random-init)",
             "config": {"workload": "CoPO Intersection, %d agent slots x %d scenes per GPU, fp32 (BASELINE configs[1])"
                                    % (sim.N, sim.E), "rollout_steps": trainer.sampler.T,
-                       "sgd_minibatch_size_per_rank": 512, "num_sgd_iter": 5, "lcf_num_iters": 5,
+                       "sgd_minibatch_size_per_rank": MB_PER_RANK, "num_sgd_iter": 5, "lcf_num_iters": 5,
                        "parallelism": "dp%d" % world, "hip_graphs": not args.no_graphs,
                        "agent_steps_per_iter": round(agent_steps / args.steps / world, 1),
                        "policy_init": "random" if args.untrained else "reference population copo_inter (tests/golden, weights as data)",

@@ -111,6 +111,8 @@ extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** o
                     cfg->n_spawns, COPO_MAX_SPAWNS);
     if (!cfg->route_segs || !cfg->route_meta || !cfg->spawn_tab || !cfg->spawn_s || !cfg->ray_cs)
         return fail(COPO_ERR_NULL, "copo_sim_create: a map table pointer is NULL");
+    if (cfg->n_boxes < 0 || cfg->n_boxes > COPO_MAX_BOXES || (cfg->n_boxes > 0 && !cfg->boxes))
+        return fail(COPO_ERR_CONFIG, "static boxes: n_boxes=%d (max %d) needs the table", cfg->n_boxes, COPO_MAX_BOXES);
     if (cfg->n_lines < 0 || cfg->n_lines > COPO_MAX_LINES ||
         ((cfg->side_lasers || cfg->lane_line_lasers) && (!cfg->lines || (cfg->side_lasers && !cfg->side_cs) || (cfg->lane_line_lasers && !cfg->lane_line_cs))))
         return fail(COPO_ERR_CONFIG, "detectors need the line table and their beam tables (n_lines=%d, max %d)", cfg->n_lines, COPO_MAX_LINES);
@@ -160,7 +162,7 @@ extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** o
     {   // observation row: [side | state | lane | navigation | lasers | toll | traffic light | lcf | messages]
         p.side_lasers = cfg->side_lasers; p.lane_lasers = cfg->lane_line_lasers; p.navi_dim = cfg->navi_dim;
         p.toll_dim = cfg->toll_dim; p.toll_min_steps = cfg->toll_min_steps;
-        p.toll_speed_limit = cfg->toll_speed_limit; p.overspeed_penalty = cfg->overspeed_penalty; p.toll_early_exit = cfg->toll_early_exit; p.toll_buildings = cfg->toll_buildings;
+        p.toll_speed_limit = cfg->toll_speed_limit; p.overspeed_penalty = cfg->overspeed_penalty; p.toll_early_exit = cfg->toll_early_exit;
         p.col_state = COPO_SIDE_DIM(cfg);
         p.col_lane = p.col_state + COPO_STATE_DIM;
         p.col_navi = p.col_lane + COPO_LANE_DIM(cfg);
@@ -284,6 +286,8 @@ extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** o
         rc = upload(s, sp4.data(), sp4.size(), &p.safe_pose);
     }
     if (rc == COPO_OK && p.n_lines) rc = upload(s, cfg->lines, (size_t)cfg->n_lines * COPO_LINE_STRIDE, &p.lines);
+    p.n_boxes = cfg->n_boxes;
+    if (rc == COPO_OK && p.n_boxes) rc = upload(s, cfg->boxes, (size_t)cfg->n_boxes * COPO_BOX_STRIDE, &p.boxes);
     if (rc == COPO_OK && cfg->side_lasers) rc = upload(s, cfg->side_cs, (size_t)cfg->side_lasers * 2, &p.side_cs);
     if (rc == COPO_OK && cfg->lane_line_lasers) rc = upload(s, cfg->lane_line_cs, (size_t)cfg->lane_line_lasers * 2, &p.lane_cs);
     s->block = pick_block(cfg->num_envs, p.nbr_fast != 0, packed_scenes(p));      // (after the observation layout: the packed shape depends on it)

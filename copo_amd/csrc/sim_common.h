@@ -31,7 +31,7 @@ struct SimParams {
     float driving_reward, speed_reward, success_reward, crash_penalty, out_penalty, arrive_margin, body_margin, lane_width;
     float side_range, lane_range;
     float toll_speed_limit, overspeed_penalty;   // MultiAgentTollgateEnv's booth rules (copo_sim_cfg, ABI 8); 0 = off
-    int32_t toll_early_exit, toll_buildings;
+    int32_t toll_early_exit, n_boxes;            // n_boxes: static boxes (buildings) of the map, `boxes` below
     float side_theta0, side_rpr;   // evenly spaced side-detector beams: angle of beam 0 in the vehicle frame, beams per radian (signed); rpr = 0: not evenly spaced
     float lane_theta0, lane_rpr;   // the same for the lane-line detector's beams
     // register formulation of the neighbour lists (neighbours_fast): fp32 d^2 thresholds 1e-6 inside / outside the exact radius,
@@ -60,6 +60,7 @@ struct SimParams {
     const float* side_cs;          // [side_lasers][2]
     const float* lane_cs;          // [lane_lasers][2]
     const float* lines;            // [n_lines][COPO_LINE_STRIDE]
+    const float* boxes;            // [n_boxes][COPO_BOX_STRIDE] static boxes {x, y, cos, sin, half_len, half_wid}
     long long* dbg;                // optional [E][8] phase timestamps (clock64) of the step kernel; NULL = off
     const float* lcf_dist;         // [4] = {mean (force_lcf folded in), std, capacity, 0}: device memory so that captured graphs see updates
 };

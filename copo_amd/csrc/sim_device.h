@@ -666,18 +666,11 @@ __device__ __forceinline__ void slot_project(const SimParams& p, const LT& L, fl
     // and the step's ordinary reward (1); on the booth road the reward is the driving reward alone up to the speed limit and
     // -overspeed_penalty * speed / max_speed above it
     const bool early = too_fast && p.toll_early_exit != 0;
-    bool bldg = false;
-    if (p.toll_buildings && p.toll_dim) {      // booth buildings in the odd lanes of the booth road (copo_sim_cfg.toll_buildings), road coordinates
-        const int toll_seg = (int)meta[2];
-        const bool along = toll_seg >= 0 && (seg == toll_seg || (seg == toll_seg - 1 && sl > g[4] - hl) || (seg == toll_seg + 1 && sl < hl));
-        if (along) {
-            const float tl = floorf(seg_ptr(L, route, toll_seg)[COPO_SEG_LANES]);
-            const float kmax = tl - 1.0f - (float)(((int)tl - 1 + 1) & 1);          // the largest odd lane index
-            float k = 2.0f * floorf(-lat * p.inv_w * 0.5f) + 1.0f;                   // the odd lane nearest to the vehicle's centre
-            k = k < 1.0f ? 1.0f : (k > kmax ? kmax : k);
-            const float across = fm(hl, fabsf(sinpsi), hw * sqrtf(cos2 > 0.0f ? cos2 : 0.0f));
-            bldg = kmax >= 1.0f && fabsf(-lat - k * w) < 0.5f * w + across;
-        }
+    bool bldg = false;                       // the vehicle's box against the map's static boxes (buildings): the vehicles' separating-axis test
+    for (int b = 0; b < p.n_boxes; ++b) {
+        const float* B = p.boxes + b * COPO_BOX_STRIDE;
+        const float bdx = B[0] - s.x, bdy = B[1] - s.y, rr = (B[4] + B[5]) + (hl + hw);      // (farther than the half extents' sums: no overlap)
+        if (fm(bdx, bdx, bdy * bdy) <= rr * rr && obb_overlap2(s.x, s.y, ch, sh, hl, hw, B[0], B[1], B[2], B[3], B[4], B[5])) bldg = true;
     }
     const bool crash = crash_in || bldg || (too_fast && p.toll_early_exit == 0);
     const float drive = (prog - prev) * fm(g[5], lif * w, 1.0f), spd = fabsf(s.v) / p.max_speed;
@@ -1207,6 +1200,35 @@ __device__ __forceinline__ void lidar_by_wave(const SimParams& p, PoseF pose, ui
                     const float tt = ray_box_nr(ox, oy, fm(r.x, cr, r.y * sr), fm(r.y, cr, -(r.x * sr)), hl, hw, hit);
                     if (hit) atomicMin(&bs[(unsigned int)(pw >> 16) + k], __float_as_uint(tt));
                     if (COPO_PROFILE_SKIP & 256) { const int nh = __popcll(__ballot(hit)); COPO_COUNT(12, nh); }
+                }
+            }
+        }
+        if (p.n_boxes > 0) {
+            // static boxes (buildings): per fan the boxes within reach (lane = box), then every ray of the fan against each of them -- the
+            // vehicles' ray / box test with the box's own half extents; one lane per (fan, ray): a plain minimum
+            pk_wave_sync();
+            float bx = 0.0f, by = 0.0f, bc = 1.0f, bsn = 0.0f, bl = 0.0f, bw = 0.0f;
+            if (lane < p.n_boxes) {
+                const float* B = p.boxes + lane * COPO_BOX_STRIDE;
+                bx = B[0]; by = B[1]; bc = B[2]; bsn = B[3]; bl = B[4]; bw = B[5];
+            }
+            for (int lp = 0; lp < cha; ++lp) {
+                const float4 pi = pose((int)plist[ip0 + lp]);
+                const float ddx = bx - pi.x, ddy = by - pi.y, lb = range + (bl + bw);
+                for (unsigned long long mb = __ballot(lane < p.n_boxes && fm(ddx, ddx, ddy * ddy) <= lb * lb); mb; mb &= mb - 1ull) {
+                    const int b = __ffsll((long long)mb) - 1;
+                    const float X = readlane_f(bx, b), Y = readlane_f(by, b), Cb = readlane_f(bc, b), Sb = readlane_f(bsn, b);
+                    const float HL = readlane_f(bl, b), HW = readlane_f(bw, b);
+                    const float rx = X - pi.x, ry = Y - pi.y;
+                    const float ox = -fm(rx, Cb, ry * Sb), oy = -fm(ry, Cb, -(rx * Sb));
+                    const float cr = fm(pi.z, Cb, pi.w * Sb), sr = fm(pi.z, Sb, -(pi.w * Cb));
+                    for (int k = lane; k < NL; k += 64) {
+                        const float2 r = reinterpret_cast<const float2*>(rays)[k];
+                        bool hit;
+                        const float tt = ray_box_nr(ox, oy, fm(r.x, cr, r.y * sr), fm(r.y, cr, -(r.x * sr)), HL, HW, hit);
+                        unsigned int* m = &bs[lp * NL + k];
+                        if (hit && __float_as_uint(tt) < *m) *m = __float_as_uint(tt);
+                    }
                 }
             }
         }

@@ -807,6 +807,27 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
     }
     if (!(PHASES & 4)) continue;
     __syncthreads();
+    if (p.n_boxes > 0) {      // static boxes (buildings): every (fan, ray) of the pass against the boxes within reach of the fan, one thread each
+        for (int q = otid; q < cha * NL; q += onth) {
+            const int lp = (int)(((float)q + 0.5f) * inv_nl), k = q - lp * NL;
+            const int i = L.plist[ip0 + lp];
+            const float xi = L.x[i], yi = L.y[i], ci = L.cs[i], si = L.sn[i];
+            const float2 r = reinterpret_cast<const float2*>(rays)[k];
+            unsigned int m = best[q];
+            for (int b = 0; b < p.n_boxes; ++b) {
+                const float* B = p.boxes + b * COPO_BOX_STRIDE;
+                const float rx = B[0] - xi, ry = B[1] - yi, lb = range + (B[4] + B[5]);
+                if (!(fm(rx, rx, ry * ry) <= lb * lb)) continue;
+                const float ox = -fm(rx, B[2], ry * B[3]), oy = -fm(ry, B[2], -(rx * B[3]));
+                const float cr = fm(ci, B[2], si * B[3]), sr = fm(ci, B[3], -(si * B[2]));
+                bool hit;
+                const float tt = ray_box_nr(ox, oy, fm(r.x, cr, r.y * sr), fm(r.y, cr, -(r.x * sr)), B[4], B[5], hit);
+                if (hit && __float_as_uint(tt) < m) m = __float_as_uint(tt);
+            }
+            best[q] = m;
+        }
+        __syncthreads();
+    }
     const int nrays = cha * NL;                   // rows of present slots only
     if (vec_out && !(COPO_PROFILE_SKIP & 4)) {
         // 16-byte stores: [head scalars | nvec aligned quads | tail scalars] of every fan (rows are 16-byte aligned: O % 4 == 0)

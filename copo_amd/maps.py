@@ -51,6 +51,7 @@ class MapTables:
     extent: float = 100.0
     entries: List[Tuple[int, int]] = field(default_factory=list)
     lines: np.ndarray = None  # [n][8] f32 lane-line primitives for the side / lane-line detectors (see `Net.lines`)
+    boxes: np.ndarray = None  # [n][6] f32 static boxes (buildings): centre x, y, cos, sin of the long axis, half length, half width
 
     @property
     def n_routes(self):
@@ -406,7 +407,17 @@ def tollgate(exit_length=70.0, lanes=3, toll_lanes=8, toll_length=10.0, taper=20
     slots = spawn_slots(exit_length)
     for d in range(2):
         b.add_spawn_road(("in%d" % d, "f%d" % d), ["end%d" % d], slots)
-    return b.finish()
+    t = b.finish()
+    # TollGate._add_building_and_speed_limit: `if idx % 2 == 1` a TollGateBuilding (the lane's width, the road's length) at the centre
+    # of every second lane of the booth road, in both directions (used by the simulator when SimConfig.toll_buildings is on)
+    boxes = []
+    for d in range(2):
+        pose, ln, _, n = net.roads[("t%d" % d, "g%d" % d) if d == 0 else ("s%d" % d, "t%d" % d)]
+        for idx in range(1, n, 2):
+            c = advance(shift(pose, -idx * w), ln / 2.0, 0.0)
+            boxes.append([c[0], c[1], math.cos(c[2]), math.sin(c[2]), ln / 2.0, w / 2.0])
+    t.boxes = np.asarray(boxes, np.float64).astype(np.float32)
+    return t
 
 
 def parkinglot(spaces=8, exit_length=20.0, lane_width=LANE_WIDTH, turn_radius=4.0, depth=8.0, arm=10.0, junction_radius=10.0,

@@ -91,7 +91,8 @@ class SimConfig:
     toll_speed_limit: float = None
     overspeed_penalty: float = None
     toll_early_exit: int = None
-    toll_buildings: int = None         # 1: booth buildings in the odd lanes of the booth road (TollGate._add_building_and_speed_limit)
+    toll_buildings: int = None         # 1: the map's static boxes are in the scene (Tollgate: booth buildings in every second booth lane,
+                                       # TollGate._add_building_and_speed_limit): crash on touch, seen by the LiDAR
 
     def __post_init__(self):
         d = MAP_OBS_DEFAULTS.get(self.map, {})
@@ -177,7 +178,7 @@ def fill_cfg_struct(cfg: SimConfig, struct_cls):
     c.add_pos_in_comm = int(bool(cfg.add_pos_in_comm))
     c.side_lasers, c.lane_line_lasers = int(cfg.side_lasers), int(cfg.lane_line_lasers)
     c.navi_dim, c.toll_dim, c.toll_min_steps = int(cfg.navi_dim), int(cfg.toll_dim), int(cfg.toll_min_steps)
-    c.toll_early_exit, c.toll_buildings = int(cfg.toll_early_exit), int(cfg.toll_buildings)
+    c.toll_early_exit = int(cfg.toll_early_exit)
     for k, v in enumerate(_maps.bounding_box(t)):
         c.map_bbox[k] = float(v)
     assert abs(t.lane_width - cfg.lane_width) < 1e-6, "the map was built for another lane width"
@@ -186,9 +187,10 @@ def fill_cfg_struct(cfg: SimConfig, struct_cls):
         spawn_tab=np.ascontiguousarray(t.spawn_tab, np.int32), spawn_s=np.ascontiguousarray(t.spawn_s, np.float32),
         ray_cs=_maps.ray_table(cfg.num_lasers, clockwise=cfg.lidar_clockwise),
         lines=line_table(t.lines),
+        boxes=np.ascontiguousarray(t.boxes if (cfg.toll_buildings and t.boxes is not None) else np.zeros((0, 6)), np.float32),
         side_cs=_maps.ray_table(max(1, cfg.side_lasers), offset_deg=90.0),
         lane_line_cs=_maps.ray_table(max(1, cfg.lane_line_lasers), offset_deg=90.0))
-    c.n_routes, c.n_spawns, c.n_lines = t.n_routes, t.n_spawns, len(keep["lines"])
+    c.n_routes, c.n_spawns, c.n_lines, c.n_boxes = t.n_routes, t.n_spawns, len(keep["lines"]), len(keep["boxes"])
     for k, v in keep.items():
         setattr(c, k, v.ctypes.data)
     return c, keep

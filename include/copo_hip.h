@@ -38,6 +38,8 @@ extern "C" {
 #define COPO_MAX_SEGS 16        /* roads per route (a full turn of the roundabout is 11) */
 #define COPO_SEG_STRIDE 16      /* floats per road record */
 #define COPO_MAX_LASERS 256
+#define COPO_MAX_BOXES 16       /* static boxes (buildings) of a map */
+#define COPO_BOX_STRIDE 6       /* {x, y, cos, sin, half_len, half_wid} */
 #define COPO_MAX_SPAWNS 256     /* spawn slots per map */
 #define COPO_MAX_SAFE 32        /* respawn places (spawn slots with the `safe` mark) per map */
 #define COPO_MAX_ROUTES 128
@@ -179,13 +181,14 @@ typedef struct copo_sim_cfg {
     float toll_speed_limit;
     float overspeed_penalty;
     int32_t toll_early_exit;
-    /*   toll_buildings    1: a booth building stands in every SECOND lane of the booth road (`TollGate._add_building_and_speed_limit`:
-     *                          `if idx % 2 == 1` a TollGateBuilding of the lane's width and the road's length at the lane's centre):
-     *                          a vehicle whose body overlaps one is done with the crash flag (MetaDrive: crash_building).  The test is made
-     *                          in road coordinates: along the road the body [s - half_len, s + half_len] against the booth road, across it
-     *                          the body's half extent (half_wid |cos psi| + half_len |sin psi|) against the lane-wide box.  The LiDAR does
-     *                          not see the buildings (their lane lines are what the side detector reports). */
-    int32_t toll_buildings;
+    /*   static boxes      buildings of the map as oriented boxes {centre x, y, cos, sin of the long axis, half length, half width}
+     *                          (`TollGate._add_building_and_speed_limit`: `if idx % 2 == 1` a TollGateBuilding of the lane's width and
+     *                          the road's length at the centre of every SECOND lane of the booth road).  A vehicle whose box overlaps
+     *                          one (the separating-axis test of the vehicle collisions) is done with the crash flag (MetaDrive:
+     *                          crash_building); the LiDAR sees them like vehicles (ray / box test in the box frame, minimum of the hit
+     *                          distances).  n_boxes <= COPO_MAX_BOXES; 0 = none. */
+    int32_t n_boxes;
+    const float* boxes;             /* [n_boxes][COPO_BOX_STRIDE] (HOST) */
 } copo_sim_cfg;
 
 /* Observation row: [side block | heading, speed, steering, last action x2, yaw rate | lane-line block | navigation |

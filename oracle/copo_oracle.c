@@ -149,6 +149,7 @@ typedef struct oracle_sim {
     float* spawn_s;
     float* ray_cs;
     float* lines;
+    float* boxes;              /* [n_boxes][COPO_BOX_STRIDE] static boxes (buildings) */
     float* st;      /* [16][E][N] */
     int32_t* env;   /* [E][4] */
     uint64_t* seeds;
@@ -194,6 +195,7 @@ int oracle_sim_create(const copo_sim_cfg* cfg, oracle_sim** out) {
     s->spawn_s = dup_mem(cfg->spawn_s, sizeof(float) * cfg->n_spawns);
     s->ray_cs = dup_mem(cfg->ray_cs, sizeof(float) * cfg->num_lasers * 2);
     s->lines = dup_mem(cfg->lines, sizeof(float) * cfg->n_lines * COPO_LINE_STRIDE);
+    s->boxes = cfg->n_boxes > 0 ? dup_mem(cfg->boxes, sizeof(float) * cfg->n_boxes * COPO_BOX_STRIDE) : NULL;
     s->st = (float*)calloc(COPO_STATE_FIELDS * E * N, 4);
     s->env = (int32_t*)calloc(E * 4, 4);
     s->seeds = (uint64_t*)calloc(E, 8);
@@ -225,7 +227,7 @@ int oracle_sim_create(const copo_sim_cfg* cfg, oracle_sim** out) {
 
 int oracle_sim_destroy(oracle_sim* s) {
     if (!s) return COPO_ERR_NULL;
-    free(s->route_segs); free(s->route_meta); free(s->spawn_tab); free(s->spawn_s); free(s->ray_cs); free(s->lines);
+    free(s->route_segs); free(s->route_meta); free(s->spawn_tab); free(s->spawn_s); free(s->ray_cs); free(s->lines); free(s->boxes);
     free(s->st); free(s->env); free(s->seeds); free(s);
     return COPO_OK;
 }
@@ -639,6 +641,23 @@ static void write_obs(oracle_sim* s, int e, const copo_step_out* out, const uint
                 float tt = n > 0.0f ? n / a : 0.0f;                     /* origin inside the box -> 0 */
                 if (tt < best) best = tt;
             }
+            for (int b = 0; b < c->n_boxes; ++b) {                      /* static boxes (buildings): the same test, the box's own half extents */
+                const float* B = s->boxes + (size_t)b * COPO_BOX_STRIDE;
+                float rx = B[0] - x, ry = B[1] - y;
+                float ox = -fm(rx, B[2], ry * B[3]), oy = -fm(ry, B[2], -(rx * B[3]));
+                float bcr = fm(cs[i], B[2], sn[i] * B[3]), bsr = fm(cs[i], B[3], -(sn[i] * B[2]));
+                float ddx = fm(rc, bcr, rs * bsr), ddy = fm(rs, bcr, -(rc * bsr));
+                float ax = fabsf(ddx), ay = fabsf(ddy);
+                float oxs = ddx < 0.0f ? -ox : ox, oys = ddy < 0.0f ? -oy : oy;
+                float nxe = -(B[4] + oxs), nxx = B[4] - oxs, nye = -(B[5] + oys), nyx = B[5] - oys;
+                if (!(nxx >= 0.0f && nyx >= 0.0f)) continue;
+                if (!(nxe * ay <= nyx * ax)) continue;
+                if (!(nye * ax <= nxx * ay)) continue;
+                int usex = (nxe * ay >= nye * ax);
+                float n = usex ? nxe : nye, a = usex ? ax : ay;
+                float tt = n > 0.0f ? n / a : 0.0f;
+                if (tt < best) best = tt;
+            }
             lid[k] = best * s->inv_range;
         }
         col += L;
@@ -951,21 +970,12 @@ int oracle_sim_step(oracle_sim* s, const float* act, const copo_step_out* out) {
              * ends a vehicle whose stay on the booth road was shorter than min_pass_steps with done_info["out_of_road"] = True -- the
              * reward function does not see it (toll_early_exit = 1); rounds 2-5 made it a crash with -crash_penalty (0) */
             int early = too_fast && c->toll_early_exit != 0;
-            /* TollGate._add_building_and_speed_limit: `if idx % 2 == 1` a TollGateBuilding (lane width x road length) stands at the
-             * lane's centre; touching one is crash_building.  Road coordinates: body [sl - hl, sl + hl] against the booth road, the
-             * body's half extent across against the lane-wide box of the nearest odd lane */
+            /* static boxes of the map (TollGate._add_building_and_speed_limit: `if idx % 2 == 1` a TollGateBuilding, lane width x
+             * road length, at the centre of every second booth lane): touching one is crash_building -- the vehicles' SAT test */
             int bldg = 0;
-            if (c->toll_buildings && c->toll_dim) {
-                int toll_seg = (int)meta[2];
-                int along = toll_seg >= 0 && (seg == toll_seg || (seg == toll_seg - 1 && sl > g[4] - hl) || (seg == toll_seg + 1 && sl < hl));
-                if (along) {
-                    float tl = floorf(SEG(s, route, toll_seg)[COPO_SEG_LANES]);
-                    float kmax = tl - 1.0f - (float)(((int)tl - 1 + 1) & 1);
-                    float k = 2.0f * floorf(-lat * s->inv_w * 0.5f) + 1.0f;
-                    k = k < 1.0f ? 1.0f : (k > kmax ? kmax : k);
-                    float across = fm(hl, fabsf(sinpsi), hw * sqrtf(cos2 > 0.0f ? cos2 : 0.0f));
-                    bldg = kmax >= 1.0f && fabsf(-lat - k * w) < 0.5f * w + across;
-                }
+            for (int b = 0; b < c->n_boxes; ++b) {
+                const float* B = s->boxes + (size_t)b * COPO_BOX_STRIDE;
+                if (obb_overlap2(X[n], Y[n], t.cs[n], t.sn[n], hl, hw, B[0], B[1], B[2], B[3], B[4], B[5])) bldg = 1;
             }
             int crash = crash_any[n] || bldg || (too_fast && c->toll_early_exit == 0);
             /* reward_function: longitudinal movement on the vehicle's lane (lane i of an arc is 1 + kappa * i * w longer

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 from test_gpu_fused_learner import _make, _dense_batch
 
 R, mb, odim = 82000, int(os.environ.get("COPO_BENCH_MB", "512")), 92      # COPO_BENCH_MB: rows per minibatch (512 = the reference's)
-pol = _make(os.environ.get("COPO_BENCH_ALGO", "copo"), "none", odim, fused=True)      # ippo: two nets -> 210 weight-gradient tiles, one per CU
+pol = _make(os.environ.get("COPO_BENCH_ALGO", "copo"), "none", odim, fused=True, mb=mb)      # ippo: two nets -> 210 weight-gradient tiles, one per CU
 batch = _dense_batch(pol, R, odim)
 idx = torch.arange(R, device="cuda")
 pol.prepare_sgd(batch, R, mb)

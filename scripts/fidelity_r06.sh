@@ -45,7 +45,9 @@ for g in $GROUPS_; do
               # scenes x 8 steps per iteration, global minibatch G x 512 (the default per rank) or G x 1024
       for G in 2 4 8; do
         for mbr in 512 1024; do
-          ROLL="--rollout-steps 8" run MultiAgentIntersectionEnv copo "world${G}_mb${mbr}_per_rank" $((256 * G)) "{\"sgd_minibatch_size\": $((mbr * G))}" ''
+          # (the fused kernels take minibatches of up to 1 024 rows -- a rank's; the union's larger ones go through the torch learner)
+          FUSED=$([ $((mbr * G)) -le 1024 ] && echo true || echo false)
+          ROLL="--rollout-steps 8" run MultiAgentIntersectionEnv copo "world${G}_mb${mbr}_per_rank" $((256 * G)) "{\"sgd_minibatch_size\": $((mbr * G)), \"use_fused_learner\": $FUSED}" ''
         done
       done;;
     bottle)

@@ -18,10 +18,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _roll(algo, env, weights, lcf, n):
+def _roll(algo, env, weights, lcf, n, env_config=None):
     """One whole scene episode (the reference's evaluation unit) of 64 scenes."""
     from copo_amd.eval.evaluate import evaluate_population
-    r = evaluate_population(algo, env, weights, lcf, num_envs=64, num_agents=n, scene_episodes=1, seed=0)
+    r = evaluate_population(algo, env, weights, lcf, num_envs=64, num_agents=n, scene_episodes=1, seed=0, env_config=env_config or {})
     return dict(success=float(r["success_rate_mean"]), crash=float(r["crash_rate_mean"]), out=float(r["out_of_road_rate_mean"]),
                 max_step=float(r["max_step_rate_mean"]), length=float(r["episode_length_mean"]),
                 velocity=float(r["velocity_mean"]), raw=r)
@@ -193,6 +193,55 @@ def test_reference_tollgate_and_bottleneck_populations(golden_dir):
     assert abs(copo_b["success"] - 0.867) < 0.12 and copo_b["out"] < 0.05 and copo_b["crash"] < 0.3, copo_b      # 0.787 / 0.009 / 0.203
     assert 0.4 < ippo_b["success"] < 0.8 and ippo_b["out"] < 0.15, ippo_b                                          # 0.597 / 0.088
     assert copo_b["success"] > ippo_b["success"] + 0.1
-    assert 0.25 < copo_t["success"] < 0.7, copo_t                                                                  # 0.479
+    assert 0.25 < copo_t["success"] < 0.7, copo_t                                                                  # 0.468
     assert ippo_t["success"] < 0.15, ippo_t          # IPPO does not learn the booth rule in the reference either
     assert copo_t["success"] > ippo_t["success"] + 0.1
+    # Round 6: MetaDrive's booth BUILDINGS (TollGate._add_building_and_speed_limit: a TollGateBuilding in every second booth lane; restated,
+    # `sim.TOLLGATE_METADRIVE_RULES`, off by default) as static boxes that end an agent on touch and that the LiDAR sees.  The shipped CoPO
+    # population then scores 0.19 -- within 0.15 of the only Tollgate record the reference holds (training table: 27.19 +- 25.63) where the
+    # scene without buildings gives 0.47 -- and the IPPO population, which rushes the booths of the empty plaza at 22 km/h (0.014), slows to
+    # 10 km/h for booths it can see and gets through more often (0.17; table 4.41 +- 2.56).  Both populations were trained WITH the
+    # buildings in view; what they do NOT settle is the default: learning from scratch reaches 80-87 % with or without them
+    # (profiles/r06_fidelity.txt), far above the table either way.
+    from copo_amd.sim import TOLLGATE_METADRIVE_RULES
+    copo_tb = _roll("copo", "tollgate", _weights(gold, "copo_tollgate"), meta_svo_lookup_table["copo_tollgate"], 40, env_config=dict(TOLLGATE_METADRIVE_RULES))
+    ippo_tb = _roll("ippo", "tollgate", _weights(gold, "ippo_tollgate"), None, 40, env_config=dict(TOLLGATE_METADRIVE_RULES))
+    print("with booth buildings + MetaDrive's booth rules: copo_tollgate", copo_tb, "\nippo_tollgate", ippo_tb)
+    assert abs(copo_tb["success"] - 0.272) < 0.15, copo_tb                                                          # 0.193
+    assert ippo_tb["velocity"] < 0.7 * ippo_t["velocity"] and ippo_tb["success"] < 0.3, (ippo_tb, ippo_t)           # 10.4 vs 22.2 km/h; 0.167
+
+
+# ---- the bands the round-5 review asked for, where this build is OUTSIDE them ---------------------------------------------------------
+# Strict expected failures: each states the review's band, this build's value and the TESTED reason it is not met
+# (profiles/r06_fidelity.txt has the sweeps).  A strict xfail turns into an error the day the gap closes, so the text cannot go stale.
+def _copo_inter(golden_dir):
+    gold = np.load(os.path.join(golden_dir, "eval_policy_function.npz"))
+    from copo_amd.eval.get_policy_function import meta_svo_lookup_table
+    return _roll("copo", "inter", _weights(gold, "copo_inter"), meta_svo_lookup_table["copo_inter"], 30)
+
+
+@pytest.mark.xfail(strict=True, reason="CoPO population 0 drives 11.5-12.5 km/h here, 16.7 in the release's MetaDrive.  Not a constant of the bicycle: "
+                   "brake_gain 6.75 .. 54 and acc_max 2.4 .. 3.5 move it over 10.4 .. 13.3 km/h only (scripts/fidelity_dynamics_sweep.py) while the IPPO "
+                   "population matches at 30.4 vs 31.8 -- the speed is the policy's own answer to what it observes at low speed among neighbours")
+def test_open_gap_copo_population_speed_within_3_kmh_of_the_release(golden_dir):
+    assert abs(_copo_inter(golden_dir)["velocity"] - 16.7) < 3.0
+
+
+@pytest.mark.xfail(strict=True, reason="336-346 steps per agent here, 260 in the release's CSVs (the same 118 m driven): follows the speed above; the reference's own "
+                   "0.2.5 TRAINING record has ~330 steps per agent at the same success rate (asserted in test_intersection_evaluation_tables...)")
+def test_open_gap_copo_population_lifetime_within_15_percent_of_the_release(golden_dir):
+    assert abs(_copo_inter(golden_dir)["length"] - 260.0) / 260.0 < 0.15
+
+
+@pytest.mark.xfail(strict=True, reason="out-of-road 0.098 vs 0.039 at body_margin 0.75; 0.023 at 0.5 (success 0.857 vs 0.812): the two shipped Intersection populations "
+                   "bracket the margin -- IPPO's 0.048 vs 0.051 wants 0.75 -- and a second digit is not identifiable from them")
+def test_open_gap_copo_population_out_of_road_within_004_of_the_release(golden_dir):
+    assert abs(_copo_inter(golden_dir)["out"] - 0.039) < 0.04
+
+
+@pytest.mark.xfail(strict=True, reason="shipped CoPO Roundabout population 0.71 here, 0.858 recorded by the release (get_policy_function.py:41); the 0.2.5 training table "
+                   "has 0.728 +- 0.067.  All of the gap is crash rate (0.25); out-of-road 0.034 and max-step 0.005 leave at most 0.04")
+def test_open_gap_copo_roundabout_population_within_010_of_the_release(golden_dir):
+    gold = np.load(os.path.join(golden_dir, "reference_populations.npz"))
+    copo = _roll("copo", "round", _weights(gold, "copo_round"), tuple(gold["copo_round/lcf"]), 40)
+    assert abs(copo["success"] - 0.858) < 0.10
