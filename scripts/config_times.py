@@ -1,5 +1,6 @@
 import sys, time, torch
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from copo_amd.torch_copo import algo_ccppo, algo_copo, algo_ippo
 from copo_amd.torch_copo.utils import env_wrappers as W
 cfgs = [
@@ -17,3 +18,6 @@ for name, cls, env, cfg in cfgs:
     n = a._counters["num_agent_steps_sampled"] - n0
     print("%-40s %.1f ms/iter  %.2f M agent-steps/s  (T=%d, rows/iter %d)" % (name, dt / 6 * 1e3, n / dt / 1e6, a.sampler.T, n // 6), flush=True)
     a.stop()
+    if name == "C4 fp32":      # round 6: the same configuration with MetaDrive's booth rules and buildings (static boxes: an extra LiDAR pass)
+        from copo_amd.sim import TOLLGATE_METADRIVE_RULES
+        cfgs.append(("C4 fp32 + booth rules and buildings", cls, env, dict(cfg, env_config=dict(cfg["env_config"], **TOLLGATE_METADRIVE_RULES))))
