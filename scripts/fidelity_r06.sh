@@ -24,6 +24,12 @@ for g in $GROUPS_; do
               # a maximum over five coarse windows sits below the reference's trailing 100-episode mean)
       run MultiAgentIntersectionEnv copo ref_boot0_w100k 10 '{"bootstrap_next_obs": false}' ''
       run MultiAgentIntersectionEnv ippo ref_boot0_w100k 10 '{"bootstrap_next_obs": false}' '';;
+    tolll)    # (c) third pass: MATollConfig's LiDAR is 72 beams / 20 m; this build's Tollgate has had the 40 m of the other scenes since round 2
+      for algo in ippo copo; do
+        run MultiAgentTollgateEnv $algo lidar_20m 256 '{}' '"lidar_range": 20.0'
+        run MultiAgentTollgateEnv $algo lidar_20m_metadrive_rules_and_buildings 256 '{}' "$MD, \"toll_buildings\": 1, \"lidar_range\": 20.0"
+        run MultiAgentTollgateEnv $algo lidar_20m_metadrive_rules_and_buildings_ref_structure 10 '{"bootstrap_next_obs": false}' "$MD, \"toll_buildings\": 1, \"lidar_range\": 20.0"
+      done;;
     tollb)    # (c) second pass: booth buildings in the odd lanes (TollGate._add_building_and_speed_limit)
       for algo in ippo copo; do
         run MultiAgentTollgateEnv $algo booth_buildings 256 '{}' '"toll_buildings": 1'

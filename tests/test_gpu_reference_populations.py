@@ -187,28 +187,28 @@ def test_reference_tollgate_and_bottleneck_populations(golden_dir):
     from copo_amd.eval.get_policy_function import meta_svo_lookup_table
     copo_b = _roll("copo", "bottle", _weights(gold, "copo_bottle"), meta_svo_lookup_table["copo_bottle"], 20)
     ippo_b = _roll("ippo", "bottle", _weights(gold, "ippo_bottle"), None, 20)
+    from copo_amd.sim import TOLLGATE_ROUND5_SCENE
+    r5 = dict(TOLLGATE_ROUND5_SCENE)
+    copo_t5 = _roll("copo", "tollgate", _weights(gold, "copo_tollgate"), meta_svo_lookup_table["copo_tollgate"], 40, env_config=r5)
+    ippo_t5 = _roll("ippo", "tollgate", _weights(gold, "ippo_tollgate"), None, 40, env_config=r5)
     copo_t = _roll("copo", "tollgate", _weights(gold, "copo_tollgate"), meta_svo_lookup_table["copo_tollgate"], 40)
     ippo_t = _roll("ippo", "tollgate", _weights(gold, "ippo_tollgate"), None, 40)
-    print("copo_bottle", copo_b, "\nippo_bottle", ippo_b, "\ncopo_tollgate", copo_t, "\nippo_tollgate", ippo_t)
+    print("copo_bottle", copo_b, "\nippo_bottle", ippo_b, "\nrounds 2-5 Tollgate scene: copo", copo_t5, "\nippo", ippo_t5, "\nround-6 Tollgate scene: copo", copo_t, "\nippo", ippo_t)
     assert abs(copo_b["success"] - 0.867) < 0.12 and copo_b["out"] < 0.05 and copo_b["crash"] < 0.3, copo_b      # 0.787 / 0.009 / 0.203
     assert 0.4 < ippo_b["success"] < 0.8 and ippo_b["out"] < 0.15, ippo_b                                          # 0.597 / 0.088
     assert copo_b["success"] > ippo_b["success"] + 0.1
-    assert 0.25 < copo_t["success"] < 0.7, copo_t                                                                  # 0.468
-    assert ippo_t["success"] < 0.15, ippo_t          # IPPO does not learn the booth rule in the reference either
-    assert copo_t["success"] > ippo_t["success"] + 0.1
-    # Round 6: MetaDrive's booth BUILDINGS (TollGate._add_building_and_speed_limit: a TollGateBuilding in every second booth lane; restated,
-    # `sim.TOLLGATE_METADRIVE_RULES`, off by default) as static boxes that end an agent on touch and that the LiDAR sees.  The shipped CoPO
-    # population then scores 0.19 -- within 0.15 of the only Tollgate record the reference holds (training table: 27.19 +- 25.63) where the
-    # scene without buildings gives 0.47 -- and the IPPO population, which rushes the booths of the empty plaza at 22 km/h (0.014), slows to
-    # 10 km/h for booths it can see and gets through more often (0.17; table 4.41 +- 2.56).  Both populations were trained WITH the
-    # buildings in view; what they do NOT settle is the default: learning from scratch reaches 80-87 % with or without them
-    # (profiles/r06_fidelity.txt), far above the table either way.
-    from copo_amd.sim import TOLLGATE_METADRIVE_RULES
-    copo_tb = _roll("copo", "tollgate", _weights(gold, "copo_tollgate"), meta_svo_lookup_table["copo_tollgate"], 40, env_config=dict(TOLLGATE_METADRIVE_RULES))
-    ippo_tb = _roll("ippo", "tollgate", _weights(gold, "ippo_tollgate"), None, 40, env_config=dict(TOLLGATE_METADRIVE_RULES))
-    print("with booth buildings + MetaDrive's booth rules: copo_tollgate", copo_tb, "\nippo_tollgate", ippo_tb)
-    assert abs(copo_tb["success"] - 0.272) < 0.15, copo_tb                                                          # 0.193
-    assert ippo_tb["velocity"] < 0.7 * ippo_t["velocity"] and ippo_tb["success"] < 0.3, (ippo_tb, ippo_t)           # 10.4 vs 22.2 km/h; 0.167
+    # rounds 2-5's Tollgate (LiDAR 40 m, no buildings, an early exit = crash): kept as a regression pin
+    assert 0.3 < copo_t5["success"] < 0.65 and ippo_t5["success"] < 0.1, (copo_t5, ippo_t5)                         # 0.468 / 0.014
+    # Round 6's Tollgate = MATollConfig as restated (SPEC.md): LiDAR 72 beams / 20 m -- in the spec since round 3, missing in the code until now --,
+    # booth BUILDINGS in every second booth lane as static boxes (crash on touch, seen by the LiDAR), the booth's speed limit and the unpunished
+    # early exit.  The populations say which scene they were trained in: with the buildings in view and obstacles at their trained scale the IPPO
+    # population slows for the booths (24 instead of 27 km/h) and gets through 25 % of the time instead of 0.7 %, the CoPO population 57 % (50 % without
+    # buildings); with buildings but the LiDAR at 40 m the CoPO population reads a booth 10 m ahead as 5 m and half its agents stand until max_step
+    # (0.54; profiles/r06_fidelity.txt).  No record of the reference scores these two files on 0.2.5 (its Tollgate row -- IPPO 4.41 +- 2.56, CoPO
+    # 27.19 +- 25.63 -- is from-scratch training), so the bands are regression pins around this build's values.
+    assert abs(copo_t["success"] - 0.57) < 0.12 and abs(ippo_t["success"] - 0.25) < 0.12, (copo_t, ippo_t)
+    assert copo_t["max_step"] < 0.05 and ippo_t["max_step"] < 0.05, (copo_t, ippo_t)                                # nobody stalls in front of a booth
+    assert copo_t["success"] > ippo_t["success"] + 0.15 and ippo_t["success"] > ippo_t5["success"] + 0.1
 
 
 # ---- the bands the round-5 review asked for, where this build is OUTSIDE them ---------------------------------------------------------
