@@ -214,7 +214,7 @@ def _dense(rank):
     return b
 
 
-def _e2e_worker(rank, world, port, out_dir):
+def _e2e_worker(rank, world, port, out_dir, algo="copo"):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -247,14 +247,17 @@ def _e2e_worker(rank, world, port, out_dir):
     ops.lcf_mix_partial, ops.lcf_mix_apply = mix_partial, mix_apply
     pushed = []
 
-    class CpuTrainer(A.CoPOTrainer):
+    from copo_amd.torch_copo import algo_ippo as I
+    base, pcls = (A.CoPOTrainer, A.CoPOPolicy) if algo == "copo" else (I.IPPOTrainer, I.IPPOPolicy)
+
+    class CpuTrainer(base):
         def setup(self, cfg):
             from copo_amd.trainer import _LocalWorkerSet
             self.env = types.SimpleNamespace(set_lcf_dist=lambda mean, std: pushed.append((mean, std)), close=lambda: None)
-            self.policy = A.CoPOPolicy(Box(-1, 1, (12,)), Box(-1, 1, (2,)), cfg)
+            self.policy = pcls(Box(-1, 1, (12,)), Box(-1, 1, (2,)), cfg)
             with torch.no_grad():
                 g = torch.Generator().manual_seed(9)
-                for p in list(self.policy.model.parameters()) + list(self.policy.target_model.parameters()):
+                for p in list(self.policy.model.parameters()) + (list(self.policy.target_model.parameters()) if algo == "copo" else []):
                     if p.dtype == torch.float32:
                         p.add_(torch.randn(p.shape, generator=g) * 0.05)
             T, E_, N = E2E_SHAPE[rank]
@@ -270,35 +273,43 @@ def _e2e_worker(rank, world, port, out_dir):
                     b[k] = b[k] * (1.0 + 0.1 * self._it)
             return b
 
-    env = get_rllib_compatible_env(get_lcf_env(MultiAgentIntersectionEnv))
-    tr = CpuTrainer(config=dict(env=env, device="cpu", use_hip_graphs=False, seed=5, sgd_minibatch_size=64, num_sgd_iter=2, lcf_num_iters=2,
-                                model={"fcnet_hiddens": [32, 32]}))
+    env = get_rllib_compatible_env(get_lcf_env(MultiAgentIntersectionEnv) if algo == "copo" else MultiAgentIntersectionEnv)
+    extra = dict(lcf_num_iters=2) if algo == "copo" else {}
+    tr = CpuTrainer(config=dict(env=env, device="cpu", use_hip_graphs=False, seed=5, sgd_minibatch_size=64, num_sgd_iter=2,
+                                model={"fcnet_hiddens": [32, 32]}, **extra))
     torch.manual_seed(77 + rank)
     res = [tr.train() for _ in range(2)]
     pol = tr.policy
+    copo = algo == "copo"
     torch.save(dict(params={k: v.clone() for k, v in pol.model.state_dict().items()},
-                    target={k: v.clone() for k, v in pol.target_model.state_dict().items()},
+                    target={k: v.clone() for k, v in pol.target_model.state_dict().items()} if copo else {},
                     kl=float(pol.kl_coeff), pushed=pushed, counters=dict(tr._counters),
-                    cm=res[-1]["custom_metrics"], meta=res[-1]["info"]["learner"]["default"]["custom_metrics"]["meta_update"],
-                    stats=res[-1]["info"]["learner"]["default"]["learner_stats"], raw=(float(pol._raw_lcf_adv_mean), float(pol._raw_lcf_adv_std))),
+                    cm=res[-1]["custom_metrics"], meta=res[-1]["info"]["learner"]["default"]["custom_metrics"]["meta_update"] if copo else {},
+                    stats=res[-1]["info"]["learner"]["default"]["learner_stats"],
+                    raw=(float(pol._raw_lcf_adv_mean), float(pol._raw_lcf_adv_std)) if copo else (0.0, 0.0)),
                os.path.join(out_dir, "e2e%d.pt" % rank))
     D.barrier()
 
 
 @pytest.mark.timeout(600)
-def test_trainer_train_end_to_end_on_two_ranks():
+@pytest.mark.parametrize("algo", ["copo", "ippo"])
+def test_trainer_train_end_to_end_on_two_ranks(algo):
+    """`CoPOTrainer.training_step` (algo_copo.py) and, for IPPO, `VecTrainer.training_step` (the PPO family's: standardised advantages with
+    global statistics, PPO epochs, KL rule) through `train()` on two gloo ranks."""
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_e2e_worker, args=(2, _free_port(), d), nprocs=2, join=True)
+        mp.spawn(_e2e_worker, args=(2, _free_port(), d, algo), nprocs=2, join=True)
         r = [torch.load(os.path.join(d, "e2e%d.pt" % k), weights_only=False) for k in range(2)]
     # every rank applied identical updates: model, target model (update_old_policy), LCF, KL coefficient -- bit for bit
     for k in r[0]["params"]:
         assert torch.equal(r[0]["params"][k], r[1]["params"][k]), k
-        assert torch.equal(r[0]["target"][k], r[1]["target"][k]), k
-        assert torch.equal(r[0]["params"][k], r[0]["target"][k]), k              # target == model after the iteration (algo_copo.py:596-613)
     assert r[0]["kl"] == r[1]["kl"] and r[0]["raw"] == r[1]["raw"]
-    assert r[0]["pushed"] == r[1]["pushed"] and len(r[0]["pushed"]) == 2          # set_lcf_dist once per iteration, the same values
-    assert r[0]["pushed"][-1] == (r[0]["meta"]["lcf"], r[0]["meta"]["lcf_std"])
-    assert abs(float(r[0]["params"]["lcf_parameters"][0])) > 0                    # the meta passes moved the LCF
+    if algo == "copo":
+        for k in r[0]["params"]:
+            assert torch.equal(r[0]["target"][k], r[1]["target"][k]), k
+            assert torch.equal(r[0]["params"][k], r[0]["target"][k]), k              # target == model after the iteration (algo_copo.py:596-613)
+        assert r[0]["pushed"] == r[1]["pushed"] and len(r[0]["pushed"]) == 2          # set_lcf_dist once per iteration, the same values
+        assert r[0]["pushed"][-1] == (r[0]["meta"]["lcf"], r[0]["meta"]["lcf_std"])
+        assert abs(float(r[0]["params"]["lcf_parameters"][0])) > 0                    # the meta passes moved the LCF
     # global counters: the acting rows / env steps of BOTH ranks, twice
     rows = [int((_dense(k)["flags"].reshape(-1) & 1).sum()) for k in range(2)]
     assert r[0]["counters"]["num_agent_steps_sampled"] == r[1]["counters"]["num_agent_steps_sampled"] == 2 * sum(rows)
