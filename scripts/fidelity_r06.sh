@@ -24,6 +24,13 @@ for g in $GROUPS_; do
               # a maximum over five coarse windows sits below the reference's trailing 100-episode mean)
       run MultiAgentIntersectionEnv copo ref_boot0_w100k 10 '{"bootstrap_next_obs": false}' ''
       run MultiAgentIntersectionEnv ippo ref_boot0_w100k 10 '{"bootstrap_next_obs": false}' '';;
+    margin)   # H6: MetaDrive ends an agent whose BODY touches the sidewalk / the continuous yellow line (body_margin 1.0); this build's 0.75 was chosen on the
+              # Intersection populations -- in a 3.5 m neck or booth lane it leaves +-1.06 m instead of +-0.82 m
+      for algo in ippo copo; do
+        run MultiAgentBottleneckEnv $algo body_margin_1.0 256 '{}' '"body_margin": 1.0'
+        run MultiAgentTollgateEnv $algo body_margin_1.0 256 '{}' '"body_margin": 1.0'
+        run MultiAgentIntersectionEnv $algo body_margin_1.0 256 '{}' '"body_margin": 1.0'
+      done;;
     tolll)    # (c) third pass: MATollConfig's LiDAR is 72 beams / 20 m; this build's Tollgate has had the 40 m of the other scenes since round 2
       for algo in ippo copo; do
         run MultiAgentTollgateEnv $algo lidar_20m 256 '{}' '"lidar_range": 20.0'
