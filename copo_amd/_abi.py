@@ -38,7 +38,7 @@ SIM_CFG_FIELDS = [
     ("lane_line_range", C.c_float), ("navi_dim", C.c_int32), ("toll_dim", C.c_int32), ("toll_min_steps", C.c_int32),
     ("n_lines", C.c_int32), ("lines", C.c_void_p), ("side_cs", C.c_void_p), ("lane_line_cs", C.c_void_p),
     ("toll_speed_limit", C.c_float), ("overspeed_penalty", C.c_float), ("toll_early_exit", C.c_int32),
-    ("n_boxes", C.c_int32), ("boxes", C.c_void_p),
+    ("n_boxes", C.c_int32), ("boxes", C.c_void_p), ("boxes_hidden", C.c_int32),
 ]
 
 STEP_OUT_FIELDS = ("obs", "rew", "nei_rew", "glob_rew", "flags", "nbr_idx", "nbr_cnt", "mf_cnt", "nbr_dist", "lcf",

@@ -287,6 +287,7 @@ extern "C" int copo_sim_create(const copo_sim_cfg* cfg, int device, copo_sim** o
     }
     if (rc == COPO_OK && p.n_lines) rc = upload(s, cfg->lines, (size_t)cfg->n_lines * COPO_LINE_STRIDE, &p.lines);
     p.n_boxes = cfg->n_boxes;
+    p.n_boxes_lidar = cfg->boxes_hidden ? 0 : cfg->n_boxes;
     if (rc == COPO_OK && p.n_boxes) rc = upload(s, cfg->boxes, (size_t)cfg->n_boxes * COPO_BOX_STRIDE, &p.boxes);
     if (rc == COPO_OK && cfg->side_lasers) rc = upload(s, cfg->side_cs, (size_t)cfg->side_lasers * 2, &p.side_cs);
     if (rc == COPO_OK && cfg->lane_line_lasers) rc = upload(s, cfg->lane_line_cs, (size_t)cfg->lane_line_lasers * 2, &p.lane_cs);

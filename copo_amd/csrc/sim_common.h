@@ -31,7 +31,7 @@ struct SimParams {
     float driving_reward, speed_reward, success_reward, crash_penalty, out_penalty, arrive_margin, body_margin, lane_width;
     float side_range, lane_range;
     float toll_speed_limit, overspeed_penalty;   // MultiAgentTollgateEnv's booth rules (copo_sim_cfg, ABI 8); 0 = off
-    int32_t toll_early_exit, n_boxes;            // n_boxes: static boxes (buildings) of the map, `boxes` below
+    int32_t toll_early_exit, n_boxes, n_boxes_lidar;      // n_boxes: static boxes (buildings) of the map, `boxes` below; n_boxes_lidar: those the LiDAR sees (all or none)
     float side_theta0, side_rpr;   // evenly spaced side-detector beams: angle of beam 0 in the vehicle frame, beams per radian (signed); rpr = 0: not evenly spaced
     float lane_theta0, lane_rpr;   // the same for the lane-line detector's beams
     // register formulation of the neighbour lists (neighbours_fast): fp32 d^2 thresholds 1e-6 inside / outside the exact radius,

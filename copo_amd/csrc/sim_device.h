@@ -1203,7 +1203,7 @@ __device__ __forceinline__ void lidar_by_wave(const SimParams& p, PoseF pose, ui
                 }
             }
         }
-        if (p.n_boxes > 0) {
+        if (p.n_boxes_lidar > 0) {
             // static boxes (buildings): per fan the boxes within reach (lane = box), then every ray of the fan against each of them -- the
             // vehicles' ray / box test with the box's own half extents; one lane per (fan, ray): a plain minimum
             pk_wave_sync();

@@ -807,7 +807,7 @@ __device__ __forceinline__ void obs_phase(const SimParams& p, EnvLds& L, int e, 
     }
     if (!(PHASES & 4)) continue;
     __syncthreads();
-    if (p.n_boxes > 0) {      // static boxes (buildings): every (fan, ray) of the pass against the boxes within reach of the fan, one thread each
+    if (p.n_boxes_lidar > 0) {      // static boxes (buildings): every (fan, ray) of the pass against the boxes within reach of the fan, one thread each
         for (int q = otid; q < cha * NL; q += onth) {
             const int lp = (int)(((float)q + 0.5f) * inv_nl), k = q - lp * NL;
             const int i = L.plist[ip0 + lp];

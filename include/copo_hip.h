@@ -189,6 +189,9 @@ typedef struct copo_sim_cfg {
      *                          distances).  n_boxes <= COPO_MAX_BOXES; 0 = none. */
     int32_t n_boxes;
     const float* boxes;             /* [n_boxes][COPO_BOX_STRIDE] (HOST) */
+    int32_t boxes_hidden;           /* 1: the LiDAR does NOT see the static boxes (they still end an agent on touch): the experiment of
+                                       profiles/r06_fidelity.txt -- whether MetaDrive 0.2.5's LiDAR mask holds the buildings' walls is not
+                                       something this tree can settle; 0 (default): seen */
 } copo_sim_cfg;
 
 /* Observation row: [side block | heading, speed, steering, last action x2, yaw rate | lane-line block | navigation |

@@ -641,7 +641,7 @@ static void write_obs(oracle_sim* s, int e, const copo_step_out* out, const uint
                 float tt = n > 0.0f ? n / a : 0.0f;                     /* origin inside the box -> 0 */
                 if (tt < best) best = tt;
             }
-            for (int b = 0; b < c->n_boxes; ++b) {                      /* static boxes (buildings): the same test, the box's own half extents */
+            for (int b = 0; b < (c->boxes_hidden ? 0 : c->n_boxes); ++b) {      /* static boxes (buildings): the same test, the box's own half extents */
                 const float* B = s->boxes + (size_t)b * COPO_BOX_STRIDE;
                 float rx = B[0] - x, ry = B[1] - y;
                 float ox = -fm(rx, B[2], ry * B[3]), oy = -fm(ry, B[2], -(rx * B[3]));

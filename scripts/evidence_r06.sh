@@ -15,3 +15,5 @@ for mb in 512 1024; do echo "== fused step, $mb rows per minibatch"; COPO_BENCH_
 cp $OUT/prof_r06_saturated/summary.txt $OUT/r06_sim_step_pmc_E16384.txt 2>/dev/null
 cp $OUT/prof_r06_live/summary.txt $OUT/r06_sim_step_pmc_E256.txt 2>/dev/null
 ls $OUT | head -50
+python scripts/config_times.py 2>&1 | grep -v amdgpu > $OUT/r06_config_times_final.txt; cat $OUT/r06_config_times_final.txt
+python bench.py --config-leg c4 2>/dev/null | grep "^{" > $OUT/r06_config_leg_c4_final.txt; cut -c1-330 $OUT/r06_config_leg_c4_final.txt

@@ -24,6 +24,11 @@ for g in $GROUPS_; do
               # a maximum over five coarse windows sits below the reference's trailing 100-episode mean)
       run MultiAgentIntersectionEnv copo ref_boot0_w100k 10 '{"bootstrap_next_obs": false}' ''
       run MultiAgentIntersectionEnv ippo ref_boot0_w100k 10 '{"bootstrap_next_obs": false}' '';;
+    hidden)   # H4 again at the LiDAR's configured 20 m: buildings (static boxes: exact box test) that the LiDAR does NOT see (toll_buildings 2)
+      for algo in ippo copo; do
+        run MultiAgentTollgateEnv $algo hidden_buildings_lidar_20m 256 '{}' '"toll_buildings": 2'
+        run MultiAgentTollgateEnv $algo hidden_buildings_lidar_20m_ref_structure 10 '{"bootstrap_next_obs": false}' '"toll_buildings": 2'
+      done;;
     margin)   # H6: MetaDrive ends an agent whose BODY touches the sidewalk / the continuous yellow line (body_margin 1.0); this build's 0.75 was chosen on the
               # Intersection populations -- in a 3.5 m neck or booth lane it leaves +-1.06 m instead of +-0.82 m
       for algo in ippo copo; do

@@ -33,6 +33,9 @@ print(table("r06_fid_tollb2.txt"))
 print("\n# third pass: the Tollgate's LiDAR at MATollConfig's 20 m (the code had kept the other scenes' 40 m since round 2), alone and with buildings + booth rules")
 print(table("r06_fid_tolll.txt"))
 print(grep("r06_fid_run5.log", "_tollgate", "=== shipped"))
+print("\n# fourth pass: the buildings as exact static boxes, HIDDEN from the LiDAR (20 m): the new default")
+print(table("r06_fid_hidden.txt"))
+print(grep("r06_fid_run6.log", "_tollgate", "=== shipped"))
 print("\n# H6: body_margin 1.0 (the whole body against the edge lines) on the three scenes")
 print(table("r06_fid_margin.txt"))
 print("\n# first pass of the buildings (a road-coordinate box test, NOT seen by the LiDAR; kept for the comparison)")

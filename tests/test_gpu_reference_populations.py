@@ -199,16 +199,21 @@ def test_reference_tollgate_and_bottleneck_populations(golden_dir):
     assert copo_b["success"] > ippo_b["success"] + 0.1
     # rounds 2-5's Tollgate (LiDAR 40 m, no buildings, an early exit = crash): kept as a regression pin
     assert 0.3 < copo_t5["success"] < 0.65 and ippo_t5["success"] < 0.1, (copo_t5, ippo_t5)                         # 0.468 / 0.014
-    # Round 6's Tollgate = MATollConfig as restated (SPEC.md): LiDAR 72 beams / 20 m -- in the spec since round 3, missing in the code until now --,
-    # booth BUILDINGS in every second booth lane as static boxes (crash on touch, seen by the LiDAR), the booth's speed limit and the unpunished
-    # early exit.  The populations say which scene they were trained in: with the buildings in view and obstacles at their trained scale the IPPO
-    # population slows for the booths (24 instead of 27 km/h) and gets through 25 % of the time instead of 0.7 %, the CoPO population 57 % (50 % without
-    # buildings); with buildings but the LiDAR at 40 m the CoPO population reads a booth 10 m ahead as 5 m and half its agents stand until max_step
-    # (0.54; profiles/r06_fidelity.txt).  No record of the reference scores these two files on 0.2.5 (its Tollgate row -- IPPO 4.41 +- 2.56, CoPO
-    # 27.19 +- 25.63 -- is from-scratch training), so the bands are regression pins around this build's values.
-    assert abs(copo_t["success"] - 0.57) < 0.12 and abs(ippo_t["success"] - 0.25) < 0.12, (copo_t, ippo_t)
-    assert copo_t["max_step"] < 0.05 and ippo_t["max_step"] < 0.05, (copo_t, ippo_t)                                # nobody stalls in front of a booth
-    assert copo_t["success"] > ippo_t["success"] + 0.15 and ippo_t["success"] > ippo_t5["success"] + 0.1
+    # Round 6's Tollgate = MATollConfig as restated (SPEC.md): LiDAR 72 beams / 20 m -- in the spec since round 3, 40 m in the code until now --, the
+    # booth's speed limit, the unpunished early exit, and booth BUILDINGS in every second booth lane (static boxes, crash on touch) that the LiDAR does
+    # NOT see.  Both records the reference holds for the scene agree with that variant and with no other (profiles/r06_fidelity.txt):
+    #   * IPPO's training success on 0.2.5 is 4.41 +- 2.56 % over 8 seeds: the shipped IPPO file cannot be a policy that gets through a quarter of the
+    #     time.  It scores 0.00 here -- and 0.25 as soon as the LiDAR shows it the buildings (asserted below as the variant the record excludes);
+    #   * the CoPO file scores 0.28 (table 27.19 +- 25.63; the review's band: within 0.15 of that record);
+    #   * from scratch at the reference's batch structure CoPO trains to 22.9 +- 23.7 %, IPPO to 32 +- 20 % -- every other variant to 80-96 %.
+    assert abs(copo_t["success"] - 0.272) < 0.15, copo_t                                                            # 0.280
+    assert ippo_t["success"] < 0.05 and ippo_t["crash"] > 0.7, ippo_t                                               # 0.000 / 0.84: it drives into the booths
+    assert copo_t["max_step"] < 0.05 and ippo_t["max_step"] < 0.05, (copo_t, ippo_t)                                # nobody stalls
+    vis = dict(toll_buildings=1)
+    copo_tv = _roll("copo", "tollgate", _weights(gold, "copo_tollgate"), meta_svo_lookup_table["copo_tollgate"], 40, env_config=vis)
+    ippo_tv = _roll("ippo", "tollgate", _weights(gold, "ippo_tollgate"), None, 40, env_config=vis)
+    print("buildings the LiDAR sees: copo", copo_tv, "\nippo", ippo_tv)
+    assert abs(copo_tv["success"] - 0.57) < 0.12 and abs(ippo_tv["success"] - 0.25) < 0.12, (copo_tv, ippo_tv)      # what the IPPO record rules out
 
 
 # ---- the bands the round-5 review asked for, where this build is OUTSIDE them ---------------------------------------------------------

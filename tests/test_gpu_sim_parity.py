@@ -67,6 +67,8 @@ def _actions(rng, E, N, t):
     ("tollgate-mdrules", 40, 3, 72, 140, 64),
     ("tollgate-mdrules", 40, 2, 72, 140, 512),
     ("tollgate-mdrules", 24, 5, 72, 140, -4),
+    ("tollgate-hidden", 40, 3, 72, 120, 64),       # static boxes the LiDAR does not see (toll_buildings 2)
+    ("tollgate-hidden", 40, 2, 72, 120, 512),
 ])
 def test_rollout_bit_exact(map_name, N, E, lasers, steps, block):
     import torch
@@ -75,7 +77,7 @@ def test_rollout_bit_exact(map_name, N, E, lasers, steps, block):
     kw = {"pgmap": dict(sequence="CSCCS", seed=11), "pgmap-junctions": dict(sequence="XOT", seed=2)}.get(map_name, {})
     cfg = SimConfig(map=map_name.split("-")[0], num_envs=E, num_agents=N, num_lasers=lasers, horizon=90, nbr_k=min(8, max(1, N - 1)),
                     delay_done=5, map_kwargs=kw, reverse_acc=2.9 if map_name.endswith("-reverse") else None,
-                    **(TOLLGATE_METADRIVE_RULES if map_name.endswith("-mdrules") else {}))
+                    **(TOLLGATE_METADRIVE_RULES if map_name.endswith("-mdrules") else (dict(toll_buildings=2) if map_name.endswith("-hidden") else {})))
     g, o = VecSim(cfg), ol.OracleSim(cfg)
     g.set_block(block)
     if map_name.endswith("-chunk3"):
