@@ -24,6 +24,13 @@ for g in $GROUPS_; do
               # a maximum over five coarse windows sits below the reference's trailing 100-episode mean)
       run MultiAgentIntersectionEnv copo ref_boot0_w100k 10 '{"bootstrap_next_obs": false}' ''
       run MultiAgentIntersectionEnv ippo ref_boot0_w100k 10 '{"bootstrap_next_obs": false}' '';;
+    rest)     # the table's other scenes on the round-6 code, default structure and the reference's
+      for map in MultiAgentRoundaboutEnv MultiAgentParkingLotEnv MultiAgentMetaDrive; do
+        for algo in ippo copo; do
+          run $map $algo base 256 '{}' ''
+          run $map $algo ref_structure 10 '{"bootstrap_next_obs": false}' ''
+        done
+      done;;
     hidden)   # H4 again at the LiDAR's configured 20 m: buildings (static boxes: exact box test) that the LiDAR does NOT see (toll_buildings 2)
       for algo in ippo copo; do
         run MultiAgentTollgateEnv $algo hidden_buildings_lidar_20m 256 '{}' '"toll_buildings": 2'

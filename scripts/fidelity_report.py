@@ -44,6 +44,8 @@ print("\n# the reference's shipped Tollgate populations (64 whole scene episodes
 print(grep("r06_fid_run4.log", "_tollgate", "=== shipped"))
 print("# ... and with the first-pass buildings the LiDAR does not see")
 print(grep("r06_fid_run2.log", "_tollgate"))
+print("\n## the table's other scenes (Roundabout, Parking Lot, PG map = MultiAgentMetaDrive) on the round-6 code")
+print(table("r06_fid_rest.txt"))
 print("\n## (a) which dynamics constant moves the shipped CoPO Intersection population's speed?  (scripts/fidelity_dynamics_sweep.py)")
 print(grep("r06_fid_dynamics.txt", "km/h"))
 print("\n## review item 4: the weak-scaling job of G ranks as ONE job on one GPU (G x 256 scenes x 8 steps per iteration, global minibatch G x 512 / G x 1 024)")

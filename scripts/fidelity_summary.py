@@ -9,7 +9,7 @@ runs = {}
 for path in sys.argv[1:]:
     key = None
     for line in open(path):
-        m = re.match(r"### map=MultiAgent(\S+)Env algo=(\S+) variant=(\S+) num_envs=(\d+) config=(.*) env=(.*) seed=(\d+)", line)
+        m = re.match(r"### map=MultiAgent(\S+?)(?:Env)? algo=(\S+) variant=(\S+) num_envs=(\d+) config=(.*) env=(.*) seed=(\d+)", line)
         if m:
             key = (m.group(1), m.group(2), m.group(3), int(m.group(4)))
             runs.setdefault(key, []).append([])
