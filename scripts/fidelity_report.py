@@ -26,6 +26,29 @@ def grep(path, *keys):
 print(open(os.path.join(ROOT, "scripts", "fidelity_report_head.txt")).read().rstrip())
 print("\n## (b) Intersection, 30 agents, 1 M env steps, 8 seeds: the default against the reference's bootstrap rule and the reference's batch structure")
 print(table("r06_fid_inter.txt", "r06_fid_interref.txt"))
+# learning curves of the default: success per ~100 k-step window, mean over the seeds
+import re as _re
+import numpy as _np
+def curve(path, mapname, algo, variant):
+    p = os.path.join(G, path)
+    if not os.path.exists(p):
+        return "(missing)"
+    runs, cur = [], None
+    for line in open(p):
+        m = _re.match(r"### map=MultiAgent(\S+?)(?:Env)? algo=(\S+) variant=(\S+) ", line)
+        if m:
+            cur = [] if (m.group(1), m.group(2), m.group(3)) == (mapname, algo, variant) else None
+            if cur is not None:
+                runs.append(cur)
+            continue
+        f = line.split()
+        if cur is not None and len(f) >= 14 and f[0].isdigit():
+            cur.append((int(f[1]), float(f[4])))
+    n = min(len(r) for r in runs)
+    return "  ".join("%dk: %.3f" % (runs[0][k][0] // 1000, _np.mean([r[k][1] for r in runs])) for k in range(n)) + "   (%d seeds)" % len(runs)
+print("\n# success rate against env steps, default structure (mean over the seeds of the rates of all agents that finished in the window)")
+print("CoPO Intersection: " + curve("r06_fid_inter.txt", "Intersection", "copo", "base"))
+print("IPPO Intersection: " + curve("r06_fid_inter.txt", "Intersection", "ippo", "base"))
 print("\n## (c) Tollgate (40 agents) and Bottleneck (20 agents), 4 seeds per variant: what makes them easy to learn here?")
 print(table("r06_fid_toll_bottle.txt"))
 print("\n# second pass: booth buildings as static boxes (crash on touch, seen by the LiDAR)")
