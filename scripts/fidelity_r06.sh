@@ -4,6 +4,10 @@
 GROUPS_=${1:-"inter toll bottle"}
 SEEDS=${2:-"0 1 2 3"}
 MD='"speed_reward": 0.0, "toll_speed_limit": 0.8333333, "overspeed_penalty": 0.5, "toll_early_exit": 1'
+# the passes were run in this order, each on the Tollgate defaults of ITS time; the keys below pin those defaults, so that a re-run on the final code
+# (Tollgate default = LiDAR 20 m + booth rules + hidden buildings) reproduces the same scenes: R5 = rounds 2-5's scene, V20 = the rules with VISIBLE buildings at 20 m
+R5='"speed_reward": 0.1, "toll_speed_limit": 0.0, "overspeed_penalty": 0.0, "toll_early_exit": 0, "toll_buildings": 0, "lidar_range": 40.0'
+V20='"speed_reward": 0.0, "toll_speed_limit": 0.8333333, "overspeed_penalty": 0.5, "toll_early_exit": 1, "toll_buildings": 1, "lidar_range": 20.0'
 run() {   # map algo variant envs config env_extra
   local map=$1 algo=$2 v=$3 envs=$4 cfg=$5 envx=$6
   for seed in $SEEDS; do
@@ -33,38 +37,38 @@ for g in $GROUPS_; do
       done;;
     hidden)   # H4 again at the LiDAR's configured 20 m: buildings (static boxes: exact box test) that the LiDAR does NOT see (toll_buildings 2)
       for algo in ippo copo; do
-        run MultiAgentTollgateEnv $algo hidden_buildings_lidar_20m 256 '{}' '"toll_buildings": 2'
-        run MultiAgentTollgateEnv $algo hidden_buildings_lidar_20m_ref_structure 10 '{"bootstrap_next_obs": false}' '"toll_buildings": 2'
+        run MultiAgentTollgateEnv $algo hidden_buildings_lidar_20m 256 '{}' "$V20, \"toll_buildings\": 2"
+        run MultiAgentTollgateEnv $algo hidden_buildings_lidar_20m_ref_structure 10 '{"bootstrap_next_obs": false}' "$V20, \"toll_buildings\": 2"
       done;;
     margin)   # H6: MetaDrive ends an agent whose BODY touches the sidewalk / the continuous yellow line (body_margin 1.0); this build's 0.75 was chosen on the
               # Intersection populations -- in a 3.5 m neck or booth lane it leaves +-1.06 m instead of +-0.82 m
       for algo in ippo copo; do
         run MultiAgentBottleneckEnv $algo body_margin_1.0 256 '{}' '"body_margin": 1.0'
-        run MultiAgentTollgateEnv $algo body_margin_1.0 256 '{}' '"body_margin": 1.0'
+        run MultiAgentTollgateEnv $algo body_margin_1.0 256 '{}' "$V20, \"body_margin\": 1.0"
         run MultiAgentIntersectionEnv $algo body_margin_1.0 256 '{}' '"body_margin": 1.0'
       done;;
     tolll)    # (c) third pass: MATollConfig's LiDAR is 72 beams / 20 m; this build's Tollgate has had the 40 m of the other scenes since round 2
       for algo in ippo copo; do
-        run MultiAgentTollgateEnv $algo lidar_20m 256 '{}' '"lidar_range": 20.0'
-        run MultiAgentTollgateEnv $algo lidar_20m_metadrive_rules_and_buildings 256 '{}' "$MD, \"toll_buildings\": 1, \"lidar_range\": 20.0"
-        run MultiAgentTollgateEnv $algo lidar_20m_metadrive_rules_and_buildings_ref_structure 10 '{"bootstrap_next_obs": false}' "$MD, \"toll_buildings\": 1, \"lidar_range\": 20.0"
+        run MultiAgentTollgateEnv $algo lidar_20m 256 '{}' "$R5, \"lidar_range\": 20.0"
+        run MultiAgentTollgateEnv $algo lidar_20m_metadrive_rules_and_buildings 256 '{}' "$V20"
+        run MultiAgentTollgateEnv $algo lidar_20m_metadrive_rules_and_buildings_ref_structure 10 '{"bootstrap_next_obs": false}' "$V20"
       done;;
     tollb)    # (c) second pass: booth buildings in the odd lanes (TollGate._add_building_and_speed_limit)
       for algo in ippo copo; do
-        run MultiAgentTollgateEnv $algo booth_buildings 256 '{}' '"toll_buildings": 1'
-        run MultiAgentTollgateEnv $algo metadrive_rules_and_buildings 256 '{}' "$MD, \"toll_buildings\": 1"
-        run MultiAgentTollgateEnv $algo metadrive_rules_and_buildings_ref_structure 10 '{"bootstrap_next_obs": false}' "$MD, \"toll_buildings\": 1"
+        run MultiAgentTollgateEnv $algo booth_buildings 256 '{}' "$R5, \"toll_buildings\": 1"
+        run MultiAgentTollgateEnv $algo metadrive_rules_and_buildings 256 '{}' "$R5, $MD, \"toll_buildings\": 1"
+        run MultiAgentTollgateEnv $algo metadrive_rules_and_buildings_ref_structure 10 '{"bootstrap_next_obs": false}' "$R5, $MD, \"toll_buildings\": 1"
       done;;
     toll)     # (c): what makes the Tollgate easy to learn here?  one rule at a time, then the reference's batch structure
       for algo in ippo copo; do
-        run MultiAgentTollgateEnv $algo base 256 '{}' ''
-        run MultiAgentTollgateEnv $algo early_exit_unpunished 256 '{}' '"toll_early_exit": 1'
-        run MultiAgentTollgateEnv $algo booth_speed_limit 256 '{}' '"speed_reward": 0.0, "toll_speed_limit": 0.8333333, "overspeed_penalty": 0.5'
-        run MultiAgentTollgateEnv $algo metadrive_rules 256 '{}' "$MD"
-        run MultiAgentTollgateEnv $algo booth_buildings 256 '{}' '"toll_buildings": 1'
-        run MultiAgentTollgateEnv $algo metadrive_rules_and_buildings 256 '{}' "$MD, \"toll_buildings\": 1"
-        run MultiAgentTollgateEnv $algo metadrive_rules_ref_structure 10 '{"bootstrap_next_obs": false}' "$MD"
-        run MultiAgentTollgateEnv $algo ref_structure 10 '{"bootstrap_next_obs": false}' ''
+        run MultiAgentTollgateEnv $algo base 256 '{}' "$R5"
+        run MultiAgentTollgateEnv $algo early_exit_unpunished 256 '{}' "$R5, \"toll_early_exit\": 1"
+        run MultiAgentTollgateEnv $algo booth_speed_limit 256 '{}' "$R5, \"speed_reward\": 0.0, \"toll_speed_limit\": 0.8333333, \"overspeed_penalty\": 0.5"
+        run MultiAgentTollgateEnv $algo metadrive_rules 256 '{}' "$R5, $MD"
+        run MultiAgentTollgateEnv $algo booth_buildings 256 '{}' "$R5, \"toll_buildings\": 1"
+        run MultiAgentTollgateEnv $algo metadrive_rules_and_buildings 256 '{}' "$R5, $MD, \"toll_buildings\": 1"
+        run MultiAgentTollgateEnv $algo metadrive_rules_ref_structure 10 '{"bootstrap_next_obs": false}' "$R5, $MD"
+        run MultiAgentTollgateEnv $algo ref_structure 10 '{"bootstrap_next_obs": false}' "$R5"
       done;;
     dp)       # review item 4: what a weak-scaling job of G ranks computes is the union of its ranks' rows -- the SAME job on one GPU: G x 256
               # scenes x 8 steps per iteration, global minibatch G x 512 (the default per rank) or G x 1024
