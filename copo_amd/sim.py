@@ -31,7 +31,7 @@ TOLLGATE_METADRIVE_RULES = dict(speed_reward=0.0, toll_speed_limit=3.0 / 3.6, ov
 # Round 6: ON for the Tollgate, with buildings that end an agent on touch and that the LiDAR does NOT see (toll_buildings = 2).  That is the one variant
 # both of the reference's Tollgate records agree with (profiles/r06_fidelity.txt): the shipped IPPO population scores 0.00 in it -- IPPO's training
 # success on 0.2.5 is 4.41 +- 2.56 %, so a file of such a run CANNOT score the 0.25 it reaches when it sees the buildings -- the CoPO population 0.28
-# (table 27.19), and from scratch at the reference's batch structure CoPO trains to 22.9 +- 23.7 % (27.19 +- 25.63) where every visible-building or
+# (table 27.19), and from scratch at the reference's batch structure CoPO trains to 24.1 +- 24.5 % (27.19 +- 25.63) where every visible-building or
 # no-building variant trains to 80-96 %.  toll_buildings = 1: the LiDAR sees them; TOLLGATE_ROUND5_SCENE: rounds 2-5's scene.
 MAP_RULE_DEFAULTS = dict(tollgate=TOLLGATE_METADRIVE_RULES)
 TOLLGATE_ROUND5_SCENE = dict(speed_reward=0.1, toll_speed_limit=0.0, overspeed_penalty=0.0, toll_early_exit=0, toll_buildings=0, lidar_range=40.0)

@@ -57,7 +57,7 @@ print("\n# third pass: the Tollgate's LiDAR at MATollConfig's 20 m (the code had
 print(table("r06_fid_tolll.txt"))
 print(grep("r06_fid_run5.log", "_tollgate", "=== shipped"))
 print("\n# fourth pass: the buildings as exact static boxes, HIDDEN from the LiDAR (20 m): the new default")
-print(table("r06_fid_hidden.txt"))
+print(table("r06_fid_hidden.txt", "r06_fid_hidden_b.txt"))
 print(grep("r06_fid_run6.log", "_tollgate", "=== shipped"))
 print("\n# H6: body_margin 1.0 (the whole body against the edge lines) on the three scenes")
 print(table("r06_fid_margin.txt"))

@@ -205,7 +205,7 @@ def test_reference_tollgate_and_bottleneck_populations(golden_dir):
     #   * IPPO's training success on 0.2.5 is 4.41 +- 2.56 % over 8 seeds: the shipped IPPO file cannot be a policy that gets through a quarter of the
     #     time.  It scores 0.00 here -- and 0.25 as soon as the LiDAR shows it the buildings (asserted below as the variant the record excludes);
     #   * the CoPO file scores 0.28 (table 27.19 +- 25.63; the review's band: within 0.15 of that record);
-    #   * from scratch at the reference's batch structure CoPO trains to 22.9 +- 23.7 %, IPPO to 32 +- 20 % -- every other variant to 80-96 %.
+    #   * from scratch at the reference's batch structure CoPO trains to 24.1 +- 24.5 %, IPPO to 32 +- 20 % -- every other variant to 80-96 %.
     assert abs(copo_t["success"] - 0.272) < 0.15, copo_t                                                            # 0.280
     assert ippo_t["success"] < 0.05 and ippo_t["crash"] > 0.7, ippo_t                                               # 0.000 / 0.84: it drives into the booths
     assert copo_t["max_step"] < 0.05 and ippo_t["max_step"] < 0.05, (copo_t, ippo_t)                                # nobody stalls
