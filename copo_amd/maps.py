@@ -130,7 +130,7 @@ class Net:
                 self.lines.append([p[0], p[1], p[2], ln, k, kind, 0.0, 0.0])
         return advance(pose, length, kappa)
 
-    def add_funnel(self, a, b, pose, length, lanes, extra_lanes, narrowing):
+    def add_funnel(self, a, b, pose, length, lanes, extra_lanes, narrowing, centre=LINE_CONTINUOUS):
         """MetaDrive's Merge ("y", `narrowing`) / Split ("Y") block: the route follows a straight `lanes`-lane road of
         `length` (Bottleneck.BOTTLENECK_LEN = 20 m); `extra_lanes` more lanes to its right run into it / out of it on WAVE lanes
         -- two arcs of opposite sense, `create_wave_lanes`: lane `index` is shifted by `index * lane_width` over the length, half
@@ -139,8 +139,8 @@ class Net:
         points, lane index) and carries the outermost wave lane as extra width on its right (R, D, direction); the only lines
         are the centre line (continuous) and the outer edge of the outermost wave lane (continuous): two arcs."""
         w = self.w
-        end = self.add(a, b, pose, length, 0.0, lanes, LINE_CONTINUOUS, 0, 0)
-        self.solid[(a, b)] = (True, True)
+        end = self.add(a, b, pose, length, 0.0, lanes, centre, 0, 0)
+        self.solid[(a, b)] = (centre == LINE_CONTINUOUS, True)
         d = extra_lanes * w / 2.0                              # lateral_dist of the outermost wave lane, per arc
         ang = math.pi - 2.0 * math.atan(length / (2.0 * d))
         if not 0.0 < ang < math.pi / 2:      # (each arc turns by less than a quarter: the edge arcs R +- w / 2 stay real for the width function)
@@ -355,13 +355,17 @@ def roundabout(exit_length=60.0, exit_radius=10.0, inner_radius=30.0, angle_deg=
     return b.finish()
 
 
-def bottleneck(exit_length=60.0, bottle_lanes=4, neck_lanes=1, neck_length=20.0, taper=20.0, lane_width=LANE_WIDTH):
+def bottleneck(exit_length=60.0, bottle_lanes=4, neck_lanes=1, neck_length=20.0, taper=20.0, lane_width=LANE_WIDTH, centre_open=False):
     """MABottleneckMap (20 agents, eval/evaluate_population.py:118-124; `bottle_lane_num=4, neck_lane_num=1, neck_length=20`):
     FirstPGBlock -> Merge -> Split.  The first block's spawn road is `exit_length - 10` long (NODE_2 -> NODE_3), the Split's socket
     road `exit_length`; the Merge / Split blocks are funnels (`Net.add_funnel`): the route follows the `neck_lanes` leftmost lanes
     straight through, the other lanes bend into / out of them on wave lanes over `taper` = BOTTLENECK_LEN = 20 m."""
     w = lane_width
     net = Net(w)
+    # centre_open (experiment, profiles/r06_fidelity.txt): the centre line of the Merge / neck / Split roads BROKEN and crossable by one lane
+    # width (MetaDrive's BOTTLENECK_PARAMETER has a `solid_center_line` entry whose default the map does not override -- as remembered, unverified)
+    net.open_left_if_broken = bool(centre_open)
+    cl = LINE_BROKEN if centre_open else LINE_CONTINUOUS
     first = exit_length - ENTRANCE_LENGTH
     total = first + exit_length + 2 * taper + neck_length
     extra = bottle_lanes - neck_lanes
@@ -369,9 +373,9 @@ def bottleneck(exit_length=60.0, bottle_lanes=4, neck_lanes=1, neck_length=20.0,
         o = (0.0, 0.0, 0.0) if d == 0 else reverse(shift((total, 0.0, 0.0), w))
         l_in, l_out = (first, exit_length) if d == 0 else (exit_length, first)
         e = net.add("in%d" % d, "w%d" % d, o, l_in, 0.0, bottle_lanes)
-        e = net.add_funnel("w%d" % d, "n%d" % d, e, taper, neck_lanes, extra, True)
-        e = net.add("n%d" % d, "m%d" % d, e, neck_length, 0.0, neck_lanes)
-        e = net.add_funnel("m%d" % d, "x%d" % d, e, taper, neck_lanes, extra, False)
+        e = net.add_funnel("w%d" % d, "n%d" % d, e, taper, neck_lanes, extra, True, centre=cl)
+        e = net.add("n%d" % d, "m%d" % d, e, neck_length, 0.0, neck_lanes, left_line=cl)
+        e = net.add_funnel("m%d" % d, "x%d" % d, e, taper, neck_lanes, extra, False, centre=cl)
         net.add("x%d" % d, "end%d" % d, e, l_out, 0.0, bottle_lanes)
     b = _Builder("bottleneck", net, 20, total / 2)
     slots = spawn_slots(exit_length)

@@ -28,6 +28,11 @@ for g in $GROUPS_; do
               # a maximum over five coarse windows sits below the reference's trailing 100-episode mean)
       run MultiAgentIntersectionEnv copo ref_boot0_w100k 10 '{"bootstrap_next_obs": false}' ''
       run MultiAgentIntersectionEnv ippo ref_boot0_w100k 10 '{"bootstrap_next_obs": false}' '';;
+    bottleopen)   # Bottleneck: the centre line of the Merge / neck / Split roads broken and crossable (maps.bottleneck(centre_open=True))
+      for algo in ippo copo; do
+        run MultiAgentBottleneckEnv $algo centre_line_open 256 '{}' '"map_kwargs": {"centre_open": true}'
+        run MultiAgentBottleneckEnv $algo centre_line_open_ref_structure 10 '{"bootstrap_next_obs": false}' '"map_kwargs": {"centre_open": true}'
+      done;;
     rest)     # the table's other scenes on the round-6 code, default structure and the reference's
       for map in MultiAgentRoundaboutEnv MultiAgentParkingLotEnv MultiAgentMetaDrive; do
         for algo in ippo copo; do

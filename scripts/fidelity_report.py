@@ -59,6 +59,9 @@ print(grep("r06_fid_run5.log", "_tollgate", "=== shipped"))
 print("\n# fourth pass: the buildings as exact static boxes, HIDDEN from the LiDAR (20 m): the new default")
 print(table("r06_fid_hidden.txt", "r06_fid_hidden_b.txt"))
 print(grep("r06_fid_run6.log", "_tollgate", "=== shipped"))
+print("\n# H7: Bottleneck with the centre line of the Merge / neck / Split roads broken and crossable (maps.bottleneck(centre_open=True))")
+print(table("r06_fid_bottleopen.txt"))
+print(grep("r06_fid_run7.log", "_bottle", "=== shipped"))
 print("\n# H6: body_margin 1.0 (the whole body against the edge lines) on the three scenes")
 print(table("r06_fid_margin.txt"))
 print("\n# first pass of the buildings (a road-coordinate box test, NOT seen by the LiDAR; kept for the comparison)")
