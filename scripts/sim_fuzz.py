@@ -15,7 +15,7 @@ KEYS = ("obs", "rew", "nei_rew", "glob_rew", "flags", "nbr_cnt", "mf_cnt", "lcf"
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 250
 packed = len(sys.argv) > 3 and sys.argv[3] == "packed"
-rng = np.random.RandomState(2026)
+rng = np.random.RandomState(int(os.environ.get("COPO_FUZZ_SEED", "2026")))
 bad = 0
 for case in range(n_cases):
     name = ["intersection", "roundabout", "parkinglot", "tollgate", "bottleneck", "pgmap"][rng.randint(6)]
@@ -25,10 +25,19 @@ for case in range(n_cases):
     E = int(rng.randint(1, 24 if packed else 7))
     lasers = int(rng.choice([30, 72, 72, 72, 120, 240]))
     block = int(rng.choice([-2, -3, -5, -8, -8, -11, -16])) if packed else int(rng.choice([64, 64, 128, 256, 512, 1024]))
+    # round 6: the Tollgate's booth rules and static boxes (absent / seen by the LiDAR / hidden from it), LiDAR range, body margin -- a third of
+    # the cases keep the per-map defaults
+    r6 = {}
+    if rng.randint(3):
+        r6 = dict(lidar_range=float(rng.choice([20.0, 40.0, 50.0])), body_margin=float(rng.choice([0.0, 0.5, 0.75, 1.0])))
+        if name == "tollgate":
+            r6.update(toll_buildings=int(rng.randint(3)), toll_early_exit=int(rng.randint(2)), speed_reward=float(rng.choice([0.0, 0.1])),
+                      toll_speed_limit=float(rng.choice([0.0, 3.0 / 3.6, 2.0])), overspeed_penalty=float(rng.choice([0.0, 0.5])))
     cfg = SimConfig(map=name, map_kwargs=kw, num_envs=E, num_agents=N, num_lasers=lasers, horizon=int(rng.randint(40, 200)),
                     nbr_k=int(rng.randint(1, max(2, min(N, 9 if packed else 12)))), delay_done=int(rng.randint(0, 30)), enable_lcf=bool(rng.randint(2)),
                     neighbours_distance=float(rng.choice([20.0, 40.0] if packed else [10.0, 20.0, 40.0])),
-                    reverse_acc=float(rng.choice([0.0, 0.0, 0.0, 2.9])))        # (round 3: optional reverse gear)
+                    reverse_acc=float(rng.choice([0.0, 0.0, 0.0, 2.9])),        # (round 3: optional reverse gear)
+                    **r6)
     g, o = VecSim(cfg), ol.OracleSim(cfg)
     try:
         g.set_block(block)
@@ -72,8 +81,8 @@ for case in range(n_cases):
                 break
         if fail:
             break
-    print("case %3d %-12s N=%2d E=%d lasers=%3d block=%4d chunk=%2d rev=%.1f O=%3d mode=%d: %s" % (case, name, N, E, lasers, block, chunk, cfg.reverse_acc, cfg.obs_dim, mode,
-          "ok" if not fail else "MISMATCH step %d %s (%d words)" % fail), flush=True)
+    print("case %3d %-12s N=%2d E=%d lasers=%3d block=%4d chunk=%2d rev=%.1f O=%3d mode=%d r6=%s: %s" % (case, name, N, E, lasers, block, chunk, cfg.reverse_acc, cfg.obs_dim, mode,
+          ",".join("%s=%g" % (k[:9], v) for k, v in sorted(r6.items())) or "-", "ok" if not fail else "MISMATCH step %d %s (%d words)" % fail), flush=True)
     bad += 1 if fail else 0
     g.close()
     o.close()
