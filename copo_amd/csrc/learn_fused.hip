@@ -223,8 +223,9 @@ hipError_t launch_fused_step(FusedArgs a, hipStream_t s, const MetaTail* mt_ = n
     {
         // layers 2 / 3: no tile for the bias column alone when the hidden width fills whole tiles (BwOpT::bias_by_rowsum)
         const int nx2 = (c.hidden % TN == 0) ? c.hidden / TN : (c.hidden + 1 + TN - 1) / TN, nx1 = (kmax1 + 1 + TN - 1) / TN;
-        const dim3 grid((nx2 + nx1) * ht + nx2, G * a.ksplit);
+        dim3 grid((nx2 + nx1) * ht + nx2, G * a.ksplit);
         if (part == 2) {
+            if (vec) grid.x = (nx2 + nx1) * ht + 1;          // gather-all mode, vector rows: the head layer is one workgroup on the lanes (head_wgrad_lanes)
             if (vec) hipLaunchKernelGGL((gemm_bw_kernel<true, true>), grid, dim3(256), gemm_lds_bytes(a.c.mb), s, a, c.mb, nx2, nx1, ht);
             else hipLaunchKernelGGL((gemm_bw_kernel<false, true>), grid, dim3(256), gemm_lds_bytes(a.c.mb), s, a, c.mb, nx2, nx1, ht);
         } else if (vec) hipLaunchKernelGGL((gemm_bw_kernel<true>), grid, dim3(256), gemm_lds_bytes(a.c.mb), s, a, c.mb, nx2, nx1, ht);

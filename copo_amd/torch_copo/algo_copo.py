@@ -649,7 +649,9 @@ class CoPOPolicy(CCPPOPolicy):
         chunked = self._meta_row_store and self._meta_per_chunk()
         if chunked:
             # {A_ego, A_nei} of every row once per iteration: a pass then gathers its dense row terms with ONE index op
-            mbuf["en_src"] = rs["pack"][:, [mbuf["col_adv"], mbuf["col_nei_adv"]]].contiguous()
+            if mbuf.get("en_cols") is None:      # (a Python index list would cost a host -> device copy, i.e. a host stop, per iteration)
+                mbuf["en_cols"] = torch.tensor([mbuf["col_adv"], mbuf["col_nei_adv"]], dtype=torch.int64, device=dev)
+            mbuf["en_src"] = rs["pack"].index_select(1, mbuf["en_cols"])
             if mbuf.get("sets") is None:
                 # the planned tables of a pass are read by its LCF steps on the side stream while the next pass is being planned:
                 # two sets of tables, passes alternate (no private copies per pass)
@@ -826,14 +828,16 @@ class CoPOTrainer(CCPPOTrainer):
         t0 = time.perf_counter()
         mb = int(cfg["sgd_minibatch_size"])
         pol.prepare_sgd(batch, batch[SampleBatch.FLAGS].numel(), mb)
-        stats = pol.run_sgd(idx, B, B_all, mb, int(cfg["num_sgd_iter"]))
+        # (the epochs' statistics are read back AFTER the meta passes have been queued: the host does not stop in between)
+        pending_stats = pol.run_sgd(idx, B, B_all, mb, int(cfg["num_sgd_iter"]), defer=True)
         self._timers["learn_time_ms"] = (time.perf_counter() - t0) * 1e3
-        train_results = {"default": {LEARNER_STATS_KEY: stats, "custom_metrics": {}}}
         # ---- global coordination: LCF meta update ----
         t0 = time.perf_counter()
         lcf_mb = int(cfg["lcf_sgd_minibatch_size"] or cfg["sgd_minibatch_size"])
         meta = pol.run_meta(idx, B, B_all, lcf_mb, int(cfg["lcf_num_iters"]))
         self._timers["meta_time_ms"] = (time.perf_counter() - t0) * 1e3
+        stats = pending_stats()
+        train_results = {"default": {LEARNER_STATS_KEY: stats, "custom_metrics": {}}}
         lcf_parameters = pol.model.lcf_parameters.detach().clone()
         lcf_mean, lcf_std = meta["lcf"], meta["lcf_std"]
 

@@ -520,7 +520,10 @@ class PPOPolicyBase:
         self.fused.adam(self._row_sources)
         self.fused.step(self._row_sources, apply_adam=False, stats=self.fused.stats, bump_index=False)
 
-    def run_sgd_fused(self, valid_idx, B_local, B_all, mb, num_epochs, _perms=None):
+    def run_sgd_fused(self, valid_idx, B_local, B_all, mb, num_epochs, _perms=None, defer=False):
+        """defer=True: returns a callable that reads the statistics back (the ONE device -> host read of the PPO epochs) instead of the
+        dict itself -- a caller with more device work to queue (CoPO's meta passes) resolves it afterwards, so the host keeps running
+        ahead of the device instead of stopping at the end of the epochs (round 6: ~0.2 ms of launch gaps at the start of the meta phase)."""
         fz = self.fused
         assert mb == fz.cfg.mb, "fused learner was built for minibatch %d" % fz.cfg.mb
         if self._sgd is None and D.is_dist() and self._dp_mode is None:
@@ -625,20 +628,25 @@ class PPOPolicyBase:
                     self._tile.close()
                     self._tile, self._dp_mode, self._sgd, self._rs_step = None, "rccl", None, None
                     self.dp_reason = "a wait of the tile exchange timed out during training: RCCL loop from then on"
-                    return self.run_sgd_fused(valid_idx, B_local, B_all, mb, n_epochs_asked, _perms=perms)
+                    return self.run_sgd_fused(valid_idx, B_local, B_all, mb, n_epochs_asked, _perms=perms, defer=defer)
         # a rank's statistics are ITS rows' terms over the GLOBAL row count of each minibatch: the sum over the ranks is the global mean.
         # Without it the KL coefficient would follow 1 / world of the sampled KL, differently on every rank (found by the two-rank
         # end-to-end test of round 6: the ranks' parameters stay identical only while their KL coefficients do)
         D.all_reduce_sum_(fz.stats)
-        tot, pol, vf, kl, ent, vfn, vfg, adv = (fz.stats / max(1, steps)).tolist()
-        return dict(total_loss=tot, policy_loss=pol, vf_loss=vf, kl=kl, entropy=ent, cur_kl_coeff=self._kl_value,
-                    cur_lr=float(self.config["lr"]), num_sgd_steps=steps, mean_nei_vf_loss=vfn, mean_global_vf_loss=vfg,
-                    normalized_advantages=adv)
+        means = fz.stats / max(1, steps)          # (its own tensor: the next call zeroes fz.stats)
 
-    def run_sgd(self, valid_idx, B_local, B_all, mb, num_epochs):
-        """`num_sgd_iter` epochs of minibatch SGD; returns the mean learner stats over every step taken."""
+        def resolve():
+            tot, pol, vf, kl, ent, vfn, vfg, adv = means.tolist()
+            return dict(total_loss=tot, policy_loss=pol, vf_loss=vf, kl=kl, entropy=ent, cur_kl_coeff=self._kl_value,
+                        cur_lr=float(self.config["lr"]), num_sgd_steps=steps, mean_nei_vf_loss=vfn, mean_global_vf_loss=vfg,
+                        normalized_advantages=adv)
+        return resolve if defer else resolve()
+
+    def run_sgd(self, valid_idx, B_local, B_all, mb, num_epochs, defer=False):
+        """`num_sgd_iter` epochs of minibatch SGD; returns the mean learner stats over every step taken (defer=True: a callable
+        that returns them, see run_sgd_fused)."""
         if self.fused is not None:
-            return self.run_sgd_fused(valid_idx, B_local, B_all, mb, num_epochs)
+            return self.run_sgd_fused(valid_idx, B_local, B_all, mb, num_epochs, defer=defer)
         self._ensure_flat_grads()
         rs = self._row_sources
         if self._sgd is None:
@@ -664,11 +672,12 @@ class PPOPolicyBase:
         D.all_reduce_sum_(rs["stats"])          # (partial sums over this rank's rows -> the global means, as in run_sgd_fused)
         vals = (rs["stats"] / max(1, steps)).tolist()
         out = dict(zip(self.STAT_KEYS, vals))
-        return dict(total_loss=out["total_loss"], policy_loss=out["mean_policy_loss"], vf_loss=out["mean_vf_loss"],
-                    kl=out["mean_kl_loss"], entropy=out["mean_entropy"], cur_kl_coeff=self._kl_value,
-                    cur_lr=float(self.config["lr"]), num_sgd_steps=steps,
-                    **{k: v for k, v in out.items() if k not in ("total_loss", "mean_policy_loss", "mean_vf_loss",
-                                                                 "mean_kl_loss", "mean_entropy")})
+        res = dict(total_loss=out["total_loss"], policy_loss=out["mean_policy_loss"], vf_loss=out["mean_vf_loss"],
+                   kl=out["mean_kl_loss"], entropy=out["mean_entropy"], cur_kl_coeff=self._kl_value,
+                   cur_lr=float(self.config["lr"]), num_sgd_steps=steps,
+                   **{k: v for k, v in out.items() if k not in ("total_loss", "mean_policy_loss", "mean_vf_loss",
+                                                                "mean_kl_loss", "mean_entropy")})
+        return (lambda: res) if defer else res
 
     # ---- postprocess (dense) -----------------------------------------------------------------------------
     def critic_obs_dense(self, batch):
@@ -871,6 +880,8 @@ class VecTrainer:
         t0 = time.perf_counter()
         batch = self.sampler.sample()
         self._metrics_batch = batch            # the rows of THIS rollout (episode metrics, counters)
+        # its metric sums are queued NOW and read back at the end of train(): no kernel launch behind the iteration's last host stop
+        self._metric_sums = (batch, self.episode_sums(batch))
         if self.policy.wants_lookahead():
             batch = self._lookahead_batch(batch)
         self.policy.postprocess_trajectory(batch)
@@ -949,6 +960,10 @@ class VecTrainer:
         """Device-side reduction of the terminal flags / info of this iteration's rows: the quantities
         `MultiAgentDrivingCallbacks` derives from info dicts (utils/callbacks.py:48-110), aggregated over the
         agents that terminated in this iteration."""
+        return self._metrics_from_sums(self.episode_sums(batch))
+
+    def episode_sums(self, batch):
+        """The device half of `episode_metrics`: 15 float64 sums over all ranks (no host read)."""
         fl8 = batch[SampleBatch.FLAGS].reshape(-1)
         info = batch["infos"].reshape(-1, 8)
         nbr = batch["nbr_cnt"].reshape(-1)
@@ -964,7 +979,7 @@ class VecTrainer:
             done = ((flags & F_DONE) > 0) & acted
             sums = self._episode_sums_torch(flags, info, acted, done, nbr)
         D.all_reduce_sum_(sums)
-        return self._metrics_from_sums(sums)
+        return sums
 
     def _episode_sums_torch(self, flags, info, acted, done, nbr):
         f64 = torch.float64
@@ -1054,7 +1069,9 @@ class VecTrainer:
         train_results = self.training_step()
         dt = time.perf_counter() - t0
         self.iteration += 1
-        cm = self.episode_metrics(getattr(self, "_metrics_batch", None) or self._last_batch)
+        mbatch = getattr(self, "_metrics_batch", None) or self._last_batch
+        early, self._metric_sums = getattr(self, "_metric_sums", None), None
+        cm = self._metrics_from_sums(early[1]) if early is not None and early[0] is mbatch else self.episode_metrics(mbatch)
         agent_steps = self._counters[NUM_AGENT_STEPS_SAMPLED]
         result = dict(
             training_iteration=self.iteration, timesteps_total=self._counters[NUM_ENV_STEPS_SAMPLED],
