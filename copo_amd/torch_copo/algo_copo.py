@@ -422,6 +422,13 @@ class CoPOPolicy(CCPPOPolicy):
                                      mb_["eps_all"][:n_mb].contiguous())
         self._meta_lcf_async(n_mb, en_all, w_all, eps_all)
 
+    def _side_stream(self):
+        """The stream of the sequential LCF kernels: one that is on another hardware queue than the main stream (trainer.concurrent_stream)."""
+        from copo_amd.trainer import concurrent_stream
+        if torch.cuda.is_current_stream_capturing():
+            return torch.cuda.Stream(device=self.device)
+        return concurrent_stream(self.device)
+
     def _meta_lcf_chunks(self, n_mb, nb, grads, rs, en):
         """Phase A chunk by chunk on the main stream, phase B of every chunk on the side stream behind that chunk's event.  The dot
         products / statistics of a pass go to one of two buffer sets (passes alternate), so the next pass's GEMMs never write what the
@@ -431,7 +438,7 @@ class CoPOPolicy(CCPPOPolicy):
         mb_, fz = self._meta_bufs, self.fused
         dist = D.is_dist()
         if self._meta_side is None:
-            self._meta_side = torch.cuda.Stream(device=self.device)
+            self._meta_side = self._side_stream()
         if mb_.get("gv2") is None:
             mb_["gv2"] = [mb_["gv"], torch.zeros_like(mb_["gv"])]
             mb_["stats_k2"] = [mb_["stats_k"], torch.zeros_like(mb_["stats_k"])]
@@ -474,7 +481,7 @@ class CoPOPolicy(CCPPOPolicy):
                 mb_["denom_pad"] = torch.ones(cap, dtype=torch.float32, device=self.device)
                 mb_["gv_pad"] = torch.zeros(cap, dtype=torch.float64, device=self.device)
             if self._meta_aux is None:
-                self._meta_aux = torch.cuda.Stream(device=self.device)
+                self._meta_aux = self._side_stream()
             ev0 = torch.cuda.Event()
             ev0.record()
             # (`en` is a main-stream temporary of the caller that the aux stream reads: the caching allocator must not hand its block
@@ -585,7 +592,7 @@ class CoPOPolicy(CCPPOPolicy):
         Everything the kernel reads is private to the pass (fresh tensors / copies); run_meta joins the stream."""
         mb_, fz = self._meta_bufs, self.fused
         if self._meta_side is None:
-            self._meta_side = torch.cuda.Stream(device=self.device)
+            self._meta_side = self._side_stream()
         priv = dict(gv=mb_["gv"][:n_mb].clone(), stats_k=mb_["stats_k"][:n_mb].clone(), denom=mb_["denom_all"][:n_mb].clone(),
                     en=en, w=w.clone(), eps=eps.clone())
         ev = torch.cuda.Event()

@@ -67,6 +67,41 @@ class GraphedCallable:
         self.calls, self.graph = 0, None
 
 
+_side_candidates = []      # keeps the probed pool streams alive (a stream object's identity is its slot in torch's pool)
+
+
+def concurrent_stream(device, tries=8):
+    """A stream whose kernels really run UNDER the current stream's.  HIP maps streams onto a handful of hardware queues round-robin
+    and torch hands out pool streams round-robin, so a plain second stream may sit on the current stream's queue -- whatever is
+    queued there runs BETWEEN the main stream's kernels instead of under them (round 6: with other captured-chain lengths the
+    sequential LCF kernels landed on the main queue and the meta passes took 5.5 instead of 3.5 ms).  Probe: a ~1 ms spin on the
+    current stream, a tiny kernel on the candidate behind an event recorded BEFORE the spin; the candidate is concurrent if that kernel
+    finished well before the spin did.  (High-priority streams do have queues of their own, but measured 3x slower iterations.)"""
+    main = torch.cuda.current_stream(device)
+    best = None
+    probe = torch.zeros(64, device=device)
+    for _ in range(tries):
+        cand = torch.cuda.Stream(device=device)
+        _side_candidates.append(cand)
+        if best is None:
+            best = cand
+        with torch.cuda.stream(cand):
+            probe.add_(1.0)            # (first use of a stream creates its queue: ~0.3 ms, not part of the measurement)
+        torch.cuda.synchronize(device)
+        e0, e_main, e_side = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record(main)
+        torch.cuda._sleep(2_000_000)
+        e_main.record(main)
+        with torch.cuda.stream(cand):
+            cand.wait_event(e0)
+            probe.add_(1.0)            # (a real dispatch: an event on an idle stream completes without touching the queue)
+            e_side.record(cand)
+        torch.cuda.synchronize(device)
+        if e0.elapsed_time(e_side) < 0.5 * e0.elapsed_time(e_main):
+            return cand
+    return best          # (no candidate overlapped, e.g. GPU_MAX_HW_QUEUES=1: correct either way, only slower)
+
+
 # ----------------------------------------------------------------------------------------------------
 # sampler
 # ----------------------------------------------------------------------------------------------------
