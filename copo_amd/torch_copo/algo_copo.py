@@ -604,8 +604,11 @@ class CoPOPolicy(CCPPOPolicy):
                               0, 0, dense=(priv["en"], priv["w"], priv["eps"]))
         self._meta_keep.append(priv)            # alive until the side stream has been joined
 
-    def run_meta(self, valid_idx, B_local, B_all, mb, num_iters):
-        """`lcf_num_iters` passes of shuffled minibatches through `meta_update` (algo_copo.py:581-589)."""
+    def run_meta(self, valid_idx, B_local, B_all, mb, num_iters, defer=False, extra=()):
+        """`lcf_num_iters` passes of shuffled minibatches through `meta_update` (algo_copo.py:581-589).
+        defer=True: everything is queued and a callable is returned that does the ONE device -> host read and builds the result;
+        `extra`: 1-D device tensors whose values ride along in that read (the callable leaves them in `self._extra_host`), so that an
+        iteration ends with one host stop instead of three (PPO statistics, meta results, episode metrics)."""
         rs = self._row_sources
         dev = self.device
         max_mb = max(rs["max_mb"], 1) if mb == rs["mb"] else max(1, math.ceil(rs["max_mb"] * rs["mb"] / mb))
@@ -696,14 +699,31 @@ class CoPOPolicy(CCPPOPolicy):
             torch.cuda.current_stream().wait_stream(self._meta_aux)
         self._meta_keep.clear()
         m = self.model
-        # one device -> host read for everything this iteration reports about the meta update
-        host = torch.cat([mbuf["stats"] / max(1, steps), m.lcf_mean.reshape(1).double(), m.lcf_std.reshape(1).double(),
-                          m.lcf_parameters.detach().double().reshape(-1), self._raw_ms.double().reshape(-1)]).tolist()
+        # one device -> host read for everything this iteration reports about the meta update (+ the caller's `extra`); the LCF mean /
+        # std are the model's formulas (CoPOModel.lcf_mean / lcf_std) applied to the parameters on the host, in float64 like there
+        extra = [t.detach().reshape(-1).double() for t in extra]
+        packed = torch.cat([mbuf["stats"] / max(1, steps), m.lcf_parameters.detach().double().reshape(-1),
+                            self._raw_ms.double().reshape(-1)] + extra)
         nk = len(self.META_KEYS)
-        out = dict(zip(self.META_KEYS, host[:nk]))
-        lm, ls, p0, p1, self._raw_host = host[nk], host[nk + 1], host[nk + 2], host[nk + 3], (host[nk + 4], host[nk + 5])
-        out.update(lcf=lm, lcf_deg=lm * 90, lcf_param=p0, lcf_std=ls, lcf_std_deg=ls * 90, lcf_std_param=p1)
-        return out
+        distributional = bool(m.model_config["custom_model_config"][USE_DISTRIBUTIONAL_LCF])
+
+        def resolve():
+            host = packed.tolist()
+            out = dict(zip(self.META_KEYS, host[:nk]))
+            p0, p1, self._raw_host = host[nk], host[nk + 1], (host[nk + 2], host[nk + 3])
+            lm = min(max(math.tanh(p0), -1 + 1e-6), 1 - 1e-6)
+            out.update(lcf=lm, lcf_deg=lm * 90, lcf_param=p0)
+            if distributional:
+                ls = math.exp(min(max(p1, -20.0), 2.0))
+                out.update(lcf_std=ls, lcf_std_deg=ls * 90, lcf_std_param=p1)
+            else:
+                out.update(lcf_std=None)
+            o, self._extra_host = nk + 4, []
+            for t in extra:
+                self._extra_host.append(host[o:o + t.numel()])
+                o += t.numel()
+            return out
+        return resolve if defer else resolve()
 
     def update_old_policy(self):
         fz = self.fused
@@ -722,7 +742,7 @@ class CoPOPolicy(CCPPOPolicy):
         assert self.model.lcf_parameters.size() == lcf_parameters.size()
         with torch.no_grad():
             self.model.lcf_parameters.data.copy_(lcf_parameters)
-        if os.environ.get("COPO_CHECK_ASSIGN_LCF", "0") == "1":     # the reference's sanity check costs two device reads
+        if lcf_mean is not None and os.environ.get("COPO_CHECK_ASSIGN_LCF", "0") == "1":     # the reference's sanity check costs two device reads
             new_mean = self.model.lcf_mean.item()
             assert abs(new_mean - lcf_mean) < 1e-5, (new_mean, lcf_mean)
             if lcf_std is not None:
@@ -835,27 +855,45 @@ class CoPOTrainer(CCPPOTrainer):
         t0 = time.perf_counter()
         mb = int(cfg["sgd_minibatch_size"])
         pol.prepare_sgd(batch, batch[SampleBatch.FLAGS].numel(), mb)
-        # (the epochs' statistics are read back AFTER the meta passes have been queued: the host does not stop in between)
-        pending_stats = pol.run_sgd(idx, B, B_all, mb, int(cfg["num_sgd_iter"]), defer=True)
+        # The epochs' statistics are read back HERE, i.e. the host stops behind the PPO epochs before it queues the meta passes.
+        # Reading them later (run_sgd(defer=True): the host then queues the whole meta phase while the captured SGD chains still
+        # run) closes the ~0.2 ms of launch gaps at the start of the meta phase but costs 1.1 ms per iteration elsewhere (free-running
+        # iterations 26.2 -> 27.3 ms on one box, same synchronised phase times: profiles/r06_meta_pass.txt) -- measured, not kept.
+        stats = pol.run_sgd(idx, B, B_all, mb, int(cfg["num_sgd_iter"]))
+        pending_stats = None
         self._timers["learn_time_ms"] = (time.perf_counter() - t0) * 1e3
         # ---- global coordination: LCF meta update ----
         t0 = time.perf_counter()
         lcf_mb = int(cfg["lcf_sgd_minibatch_size"] or cfg["sgd_minibatch_size"])
-        meta = pol.run_meta(idx, B, B_all, lcf_mb, int(cfg["lcf_num_iters"]))
-        self._timers["meta_time_ms"] = (time.perf_counter() - t0) * 1e3
-        stats = pending_stats()
-        train_results = {"default": {LEARNER_STATS_KEY: stats, "custom_metrics": {}}}
+        # ONE host stop at the end of the iteration: the episode-metric sums ride along in the meta pass's read
+        extra = []
+        if getattr(pending_stats, "means", None) is not None:
+            extra.append(pending_stats.means)
+        early = getattr(self, "_metric_sums", None)
+        if early is not None and early[1] is not None:
+            self._wait_metric_sums()
+            extra.append(early[1])
+        pending_meta = pol.run_meta(idx, B, B_all, lcf_mb, int(cfg["lcf_num_iters"]), defer=True, extra=extra)
+        # the device half of the reference's weight / LCF broadcast (algo_copo.py:555-558, 596-613) is queued BEFORE that read
         lcf_parameters = pol.model.lcf_parameters.detach().clone()
-        lcf_mean, lcf_std = meta["lcf"], meta["lcf_std"]
 
-        def _update_lcf_2(w_id, w):
+        def _update_lcf_dev(w_id, w):
             def _update_lcf_1(pi, pi_id):
-                pi.assign_lcf(lcf_parameters, lcf_mean, lcf_std)
+                pi.assign_lcf(lcf_parameters, None)
                 pi.update_old_policy()
             w.foreach_policy(_update_lcf_1)
-            w.foreach_env(lambda e: e.set_lcf_dist(mean=lcf_mean, std=lcf_std))
 
-        self.workers.foreach_worker_with_id(_update_lcf_2)
+        self.workers.foreach_worker_with_id(_update_lcf_dev)
+        meta = pending_meta()
+        self._timers["meta_time_ms"] = (time.perf_counter() - t0) * 1e3
+        host = list(getattr(pol, "_extra_host", []))
+        if pending_stats is not None:
+            stats = pending_stats(host.pop(0)) if getattr(pending_stats, "means", None) is not None else pending_stats()
+        if early is not None and early[1] is not None:
+            self._metric_sums = (early[0], host.pop(0))
+        train_results = {"default": {LEARNER_STATS_KEY: stats, "custom_metrics": {}}}
+        lcf_mean, lcf_std = meta["lcf"], meta["lcf_std"]
+        self.workers.foreach_worker_with_id(lambda w_id, w: w.foreach_env(lambda e: e.set_lcf_dist(mean=lcf_mean, std=lcf_std)))
         raw = getattr(pol, "_raw_host", None) or (float(pol._raw_lcf_adv_mean.item()), float(pol._raw_lcf_adv_std.item()))
         fetches = dict(raw_lcf_adv_mean_value=float(raw[0]), raw_lcf_adv_std_value=float(raw[1]))
         fetches.update(meta)

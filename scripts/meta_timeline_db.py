@@ -51,3 +51,18 @@ if len(starts) >= 3:
     print("  gaps below 8 us (kernel-to-kernel hand-overs): %.3f ms in %d; larger ones:" % (small / 1e3, sum(1 for g in gaps if g[0] < 8.0)))
     for g in sorted(gaps, reverse=True)[:40]:
         print("  %7.1f us idle at %9.1f us   after %-44s before %s" % (g[0], g[1], g[2].split("(")[0][-44:], g[3].split("(")[0][-44:]))
+    if len(sys.argv) > 2 and sys.argv[2] == "head":
+        print("\nthe iteration up to its first SGD step:")
+        pe = rows[a][1]
+        for r in seg:
+            if "rowpass" in r[0]:
+                break
+            print("  %9.1f us  +%7.1f us  (idle before %6.1f)  %s" % ((r[1] - rows[a][1]) / 1e3, (r[2] - r[1]) / 1e3, max(0.0, (r[1] - pe) / 1e3), r[0].split("(")[0][-60:]))
+            pe = max(pe, r[2])
+    if len(sys.argv) > 2 and sys.argv[2] in ("head", "tail"):
+        print("\nthe iteration behind its last sequential LCF kernel:")
+        last = max(k for k, r in enumerate(seg) if "meta_seq" in r[0])
+        pe = seg[last][2]
+        for r in seg[last:] + rows[b:b + 2]:
+            print("  %9.1f us  +%7.1f us  (idle before %6.1f)  %s" % ((r[1] - rows[a][1]) / 1e3, (r[2] - r[1]) / 1e3, max(0.0, (r[1] - pe) / 1e3), r[0].split("(")[0][-60:]))
+            pe = max(pe, r[2])
