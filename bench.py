@@ -272,6 +272,8 @@ def measure_phases(trainer, iters=4):
     saved = [wrap(trainer, "collect", "sample"), wrap(trainer.policy, "run_sgd", "sgd"), wrap(trainer, "train", "iteration")]
     if hasattr(trainer.policy, "run_meta"):
         saved.append(wrap(trainer.policy, "run_meta", "meta"))
+        if hasattr(trainer.policy, "meta_rows_early"):      # (the meta phase's row store, queued ahead of the statistics read)
+            saved.append(wrap(trainer.policy, "meta_rows_early", "meta"))
     a0 = trainer._counters["num_agent_steps_sampled"]
     for _ in range(iters):
         trainer.train()

@@ -604,6 +604,25 @@ class CoPOPolicy(CCPPOPolicy):
                               0, 0, dense=(priv["en"], priv["w"], priv["eps"]))
         self._meta_keep.append(priv)            # alive until the side stream has been joined
 
+    def _wants_row_store(self, mb, num_iters):
+        rs = self._row_sources
+        nb_batch = int(self.config.get("meta_batch_size", 32)) if self.fused is not None else 0
+        # the row store costs 8 H bytes per row and net; beyond ~1M rows recomputing per pass is the better trade
+        return nb_batch > 0 and bool(self.config.get("meta_row_store", True)) and num_iters > 1 \
+            and mb == rs["mb"] and int(rs["max_rows"]) <= int(self.config.get("meta_row_store_max_rows", 1 << 20))
+
+    def meta_rows_early(self, mb, num_iters):
+        """Queue the row store of the coming `run_meta` call NOW (it needs the parameters the PPO epochs leave and nothing from the
+        host): the caller puts this between the PPO epochs and the read of their statistics, so the device goes from the last SGD
+        step straight into 0.7 ms of row-pass kernels while the host wakes up and queues the passes.  Four launches on the MAIN
+        stream only -- queuing the whole meta phase that early (second queue, ~150 launches) slows the SGD chains (training_step)."""
+        if self.fused is None or self._meta_bufs is None or self._meta_bufs["mb"] != mb or not self._wants_row_store(mb, num_iters) \
+                or int(self.config.get("meta_batch_size", 32)) <= 0:
+            return False
+        self.fused.meta_rows(self._row_sources)
+        self._rows_early = True
+        return True
+
     def run_meta(self, valid_idx, B_local, B_all, mb, num_iters, defer=False, extra=()):
         """`lcf_num_iters` passes of shuffled minibatches through `meta_update` (algo_copo.py:581-589).
         defer=True: everything is queued and a callable is returned that does the ONE device -> host read and builds the result;
@@ -650,10 +669,9 @@ class CoPOPolicy(CCPPOPolicy):
         mbuf["stats"].zero_()
         steps = 0
         nb_batch = int(self.config.get("meta_batch_size", 32)) if self.fused is not None else 0
-        # the row store costs 8 H bytes per row and net; beyond ~1M rows recomputing per pass is the better trade
-        self._meta_row_store = nb_batch > 0 and bool(self.config.get("meta_row_store", True)) and num_iters > 1 \
-            and mb == rs["mb"] and int(rs["max_rows"]) <= int(self.config.get("meta_row_store_max_rows", 1 << 20))
-        if self._meta_row_store:
+        self._meta_row_store = self._wants_row_store(mb, num_iters)
+        early, self._rows_early = getattr(self, "_rows_early", False), False
+        if self._meta_row_store and not early:
             self.fused.meta_rows(rs)
         perms = self.draw_perms(num_iters, B_local)
         chunked = self._meta_row_store and self._meta_per_chunk()
@@ -859,7 +877,14 @@ class CoPOTrainer(CCPPOTrainer):
         # Reading them later (run_sgd(defer=True): the host then queues the whole meta phase while the captured SGD chains still
         # run) closes the ~0.2 ms of launch gaps at the start of the meta phase but costs 1.1 ms per iteration elsewhere (free-running
         # iterations 26.2 -> 27.3 ms on one box, same synchronised phase times: profiles/r06_meta_pass.txt) -- measured, not kept.
-        stats = pol.run_sgd(idx, B, B_all, mb, int(cfg["num_sgd_iter"]))
+        # What IS queued before that read: the meta phase's row store (main stream only, four launches), behind an asynchronous
+        # copy of the statistics -- the host wakes up on the copy's event while the device is already in the row pass.
+        lcf_mb = int(cfg["lcf_sgd_minibatch_size"] or cfg["sgd_minibatch_size"])
+        pending = pol.run_sgd(idx, B, B_all, mb, int(cfg["num_sgd_iter"]), defer=True)
+        if hasattr(pending, "start_copy") and not D.is_dist():
+            pending.start_copy()
+            pol.meta_rows_early(lcf_mb, int(cfg["lcf_num_iters"]))
+        stats = pending()
         pending_stats = None
         self._timers["learn_time_ms"] = (time.perf_counter() - t0) * 1e3
         # ---- global coordination: LCF meta update ----

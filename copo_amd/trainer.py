@@ -670,12 +670,25 @@ class PPOPolicyBase:
         D.all_reduce_sum_(fz.stats)
         means = fz.stats / max(1, steps)          # (its own tensor: the next call zeroes fz.stats)
 
+        copy = {}
+
+        def start_copy():                  # asynchronous device -> host copy; resolve() then waits for ITS event, not for the stream
+            if means.is_cuda:
+                if getattr(self, "_stats_pin", None) is None:
+                    self._stats_pin = torch.empty(means.numel(), dtype=means.dtype, pin_memory=True)
+                self._stats_pin.copy_(means, non_blocking=True)
+                copy["ev"] = torch.cuda.Event()
+                copy["ev"].record()
+
         def resolve(values=None):          # values: the means, already on the host (they rode along in another read)
+            if values is None and "ev" in copy:
+                copy["ev"].synchronize()
+                values = self._stats_pin.tolist()
             tot, pol, vf, kl, ent, vfn, vfg, adv = means.tolist() if values is None else values
             return dict(total_loss=tot, policy_loss=pol, vf_loss=vf, kl=kl, entropy=ent, cur_kl_coeff=self._kl_value,
                         cur_lr=float(self.config["lr"]), num_sgd_steps=steps, mean_nei_vf_loss=vfn, mean_global_vf_loss=vfg,
                         normalized_advantages=adv)
-        resolve.means = means
+        resolve.means, resolve.start_copy = means, start_copy
         return resolve if defer else resolve()
 
     def run_sgd(self, valid_idx, B_local, B_all, mb, num_epochs, defer=False):
