@@ -410,6 +410,46 @@ def test_batched_meta_pass_equals_sequential_steps(nb, store):
         np.testing.assert_allclose(gv2[:5].cpu().numpy(), gv, rtol=0, atol=0)      # (and the chunked dot products are the pass's)
 
 
+def test_run_meta_deferred_read_with_riders_and_early_row_store():
+    """Round 6: `run_meta(defer=True, extra=...)` queues everything and returns a callable that does the ONE host read (the riders'
+    values land in `_extra_host`); `meta_rows_early` queues the row store ahead of the call.  Both must give what the plain call gives:
+    same seeds -> the same LCF parameters, Adam state and reported values, bit for bit (the same kernels in the same order), and the
+    reported LCF mean / std are the model's formulas applied to the parameters."""
+    import math
+    R, mb, odim = 2300, 512, 92
+    pols = [_make("copo", "none", odim, fused=True) for _ in range(2)]
+    _copy_weights(pols[1], pols[0])
+    batch = _dense_batch(pols[0], R, odim, seed=12)
+    idx = torch.arange(R, device="cuda")
+    outs = []
+    for i, pol in enumerate(pols):
+        pol.prepare_sgd(batch, R, mb)
+        pol._raw_lcf_adv_mean.fill_(0.1)
+        pol._raw_lcf_adv_std.fill_(1.4)
+        pol.use_graphs = False
+        for rep in range(2):                   # (the second call finds the meta buffers allocated: only then can the row store run early)
+            torch.manual_seed(33 + rep)
+            if i == 0:
+                outs.append(pol.run_meta(idx, R, [R], mb, 3))
+            else:
+                assert pol.meta_rows_early(mb, 3) == (rep == 1)
+                riders = [torch.arange(3, device="cuda", dtype=torch.float32) + rep, torch.tensor([7.5], device="cuda", dtype=torch.float64)]
+                pending = pol.run_meta(idx, R, [R], mb, 3, defer=True, extra=riders)
+                assert callable(pending)
+                outs.append(pending())
+                assert pol._extra_host == [[0.0 + rep, 1.0 + rep, 2.0 + rep], [7.5]]
+    a, b = pols
+    assert torch.equal(a.model.lcf_parameters, b.model.lcf_parameters) and torch.equal(a._lcf_adam, b._lcf_adam)
+    for rep in range(2):
+        x, y = outs[rep], outs[2 + rep]
+        assert x.keys() == y.keys()
+        for k in x:
+            assert x[k] == y[k], (rep, k, x[k], y[k])
+    p0, p1 = (float(v) for v in a.model.lcf_parameters.detach().cpu())
+    assert outs[-1]["lcf"] == min(max(math.tanh(p0), -1 + 1e-6), 1 - 1e-6) and outs[-1]["lcf_std"] == math.exp(min(max(p1, -20.0), 2.0))
+    np.testing.assert_allclose([outs[-1]["lcf"], outs[-1]["lcf_std"]], [a.model.lcf_mean.item(), a.model.lcf_std.item()], rtol=1e-12)
+
+
 @pytest.mark.parametrize("B,B_all,mb", [(1337, [1337], 512), (1000, [1000, 700, 1290], 256), (0, [0, 40], 64), (5, [5], 512)])
 def test_plan_epoch_kernel_tables(B, B_all, mb):
     """copo_plan_epoch == the tensor formulation of the epoch plan (shuffled valid rows cut into near-equal static
