@@ -927,6 +927,7 @@ class VecTrainer:
     # ---- the iteration ------------------------------------------------------------------------------------
     def collect(self):
         t0 = time.perf_counter()
+        self._wait_metric_sums()               # (a caller that never read the previous rollout's sums: they read the buffers this rollout rewrites)
         batch = self.sampler.sample()
         self._metrics_batch = batch            # the rows of THIS rollout (episode metrics, counters)
         # its metric sums are queued NOW and read back at the end of train(): no kernel launch behind the iteration's last host stop.
