@@ -408,6 +408,26 @@ def test_batched_meta_pass_equals_sequential_steps(nb, store):
         torch.cuda.synchronize()
         assert torch.equal(once[:5], per_chunk[:5]) and bool(torch.isfinite(once[:5]).all())
         np.testing.assert_allclose(gv2[:5].cpu().numpy(), gv, rtol=0, atol=0)      # (and the chunked dot products are the pass's)
+        if nb == 8:
+            # (round 6) the head layer's gradient of the gather-all launch runs on the lanes (`head_wgrad_lanes`, vector rows) instead of
+            # four 64 x 64 MFMA tiles.  The tile path is still what a row store that is NOT 16-byte aligned takes: the same store copied
+            # to an address 4 bytes off must give the same exported gradient pairs -- every layer exactly (same tiles, same order) except
+            # the head layer's 4 x 257 entries, which the two paths add up in different orders (512 fp32 products per entry).
+            nf = fz.meta_fold_len()
+            n_rows, ws, rowstat = fz._rows_ws
+            g_vec, g_tile = (torch.zeros(5, 2, nf, device="cuda") for _ in range(2))
+            fz.meta_batch_wgrads(rs, 0, 5, torch.zeros_like(mbuf["gv"]), None, g_out=g_vec)
+            off = torch.empty(ws.numel() + 1, device="cuda")
+            off[1:].copy_(ws)
+            assert off[1:].data_ptr() % 16 == 4
+            fz._rows_ws = (n_rows, off[1:], rowstat)
+            fz.meta_batch_wgrads(rs, 0, 5, torch.zeros_like(mbuf["gv"]), None, g_out=g_tile)
+            fz._rows_ws = (n_rows, ws, rowstat)
+            torch.cuda.synchronize()
+            a_, b_ = g_vec.cpu().numpy(), g_tile.cpu().numpy()
+            differ = np.flatnonzero(np.any(a_ != b_, axis=(0, 1)))
+            assert 0 < differ.size <= 4 * 257, differ.size                     # only head-layer entries may differ (and some do: other order)
+            np.testing.assert_allclose(a_, b_, rtol=0, atol=1e-5 * float(np.abs(b_).max()))
 
 
 def test_run_meta_deferred_read_with_riders_and_early_row_store():
