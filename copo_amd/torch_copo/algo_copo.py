@@ -885,15 +885,12 @@ class CoPOTrainer(CCPPOTrainer):
             pending.start_copy()
             pol.meta_rows_early(lcf_mb, int(cfg["lcf_num_iters"]))
         stats = pending()
-        pending_stats = None
         self._timers["learn_time_ms"] = (time.perf_counter() - t0) * 1e3
         # ---- global coordination: LCF meta update ----
         t0 = time.perf_counter()
         lcf_mb = int(cfg["lcf_sgd_minibatch_size"] or cfg["sgd_minibatch_size"])
         # ONE host stop at the end of the iteration: the episode-metric sums ride along in the meta pass's read
         extra = []
-        if getattr(pending_stats, "means", None) is not None:
-            extra.append(pending_stats.means)
         early = getattr(self, "_metric_sums", None)
         if early is not None and early[1] is not None:
             self._wait_metric_sums()
@@ -912,12 +909,12 @@ class CoPOTrainer(CCPPOTrainer):
         meta = pending_meta()
         self._timers["meta_time_ms"] = (time.perf_counter() - t0) * 1e3
         host = list(getattr(pol, "_extra_host", []))
-        if pending_stats is not None:
-            stats = pending_stats(host.pop(0)) if getattr(pending_stats, "means", None) is not None else pending_stats()
         if early is not None and early[1] is not None:
             self._metric_sums = (early[0], host.pop(0))
         train_results = {"default": {LEARNER_STATS_KEY: stats, "custom_metrics": {}}}
         lcf_mean, lcf_std = meta["lcf"], meta["lcf_std"]
+        if os.environ.get("COPO_CHECK_ASSIGN_LCF", "0") == "1":     # the reference's sanity check (algo_copo.py:446-471), two device reads
+            self.workers.foreach_worker_with_id(lambda w_id, w: w.foreach_policy(lambda pi, pi_id: pi.assign_lcf(lcf_parameters, lcf_mean, lcf_std)))
         self.workers.foreach_worker_with_id(lambda w_id, w: w.foreach_env(lambda e: e.set_lcf_dist(mean=lcf_mean, std=lcf_std)))
         raw = getattr(pol, "_raw_host", None) or (float(pol._raw_lcf_adv_mean.item()), float(pol._raw_lcf_adv_std.item()))
         fetches = dict(raw_lcf_adv_mean_value=float(raw[0]), raw_lcf_adv_std_value=float(raw[1]))
